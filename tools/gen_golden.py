@@ -1,0 +1,380 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference in the build container.
+
+Runs only where /root/reference exists (never on the GPU box, never from tests).
+It imports the reference's own modules -- src/loss.py and src/transformer_utils.py
+directly, src/models_multimodal.py after registering inert stand-ins for the
+third-party packages this image lacks (pytorch_lightning, ruamel.yaml, wandb,
+torchmetrics, seaborn, and whatever else src/utils.py pulls in); the stand-ins
+touch none of the arithmetic -- and stores inputs, parameters, outputs and
+gradients as small .npz fixtures.  Fixture layout:  "P/<state_dict key>" parameters
+and buffers, "in/<name>" inputs, "out/<name>" expected outputs, "grad/<key>"
+expected gradients (of sum(out * cot) or of the loss), "cfg" a JSON string.
+
+    python tools/gen_golden.py            # rewrites every fixture
+"""
+import importlib
+import json
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+class _Anything:
+    """Inert stand-in: any attribute / call / subscript yields another stand-in."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Anything()
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Anything()
+
+    def __getitem__(self, k):
+        return _Anything()
+
+    def __iter__(self):
+        return iter(())
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+
+    def _missing(attr):
+        if attr.startswith("__"):
+            raise AttributeError(attr)
+        return _Anything
+
+    m.__getattr__ = _missing  # type: ignore[attr-defined]
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    class LightningModule(torch.nn.Module):
+        def log(self, *a, **k):
+            pass
+
+    pl = _stub("pytorch_lightning", LightningModule=LightningModule, Callback=object, Trainer=_Anything)
+    _stub("pytorch_lightning.callbacks")
+    _stub("pytorch_lightning.loggers")
+    pl.callbacks = sys.modules["pytorch_lightning.callbacks"]
+    for name in ["ruamel", "ruamel.yaml", "wandb", "torchmetrics", "torchmetrics.classification", "seaborn",
+                 "matplotlib", "matplotlib.pyplot", "matplotlib.colors", "matplotlib.ticker",
+                 "matplotlib.patches", "matplotlib.lines", "h5py", "astropy", "astropy.io", "extinction",
+                 "torchvision", "torchvision.transforms", "umap", "IPython"]:
+        try:
+            importlib.import_module(name)
+        except Exception:
+            _stub(name)
+    sys.path.insert(0, REF)
+    ref_loss = importlib.import_module("src.loss")
+    ref_tr = importlib.import_module("src.transformer_utils")
+    ref_mm = importlib.import_module("src.models_multimodal")
+    return ref_loss, ref_tr, ref_mm
+
+
+def save(name, cfg=None, **groups):
+    arrays = {"cfg": np.array(json.dumps(cfg or {}))}
+    for g, d in groups.items():
+        for k, v in d.items():
+            if isinstance(v, torch.Tensor):
+                v = v.detach().cpu().numpy()
+            arrays[f"{g}/{k}"] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KB")
+
+
+def unit(n, d, g):
+    x = torch.randn(n, d, generator=g)
+    return x / x.norm(dim=-1, keepdim=True)
+
+
+def sd_of(module):
+    return {k: v.clone() for k, v in module.state_dict().items()}
+
+
+def grads_of(module):
+    return {k: p.grad.clone() for k, p in module.named_parameters() if p.grad is not None}
+
+
+def randomise(module, g, scale=0.3):
+    """Replace the default init by seeded values stored explicitly in the fixture (BN/LN gains
+    near 1, running_var positive) so nothing depends on init order."""
+    with torch.no_grad():
+        for k, p in module.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * scale)
+            if k.endswith("norm1.weight") or k.endswith("norm2.weight") or (
+                    p.dim() == 1 and k.endswith(".weight") and "net." in k):
+                p.add_(1.0)
+        for k, b in module.named_buffers():
+            if k.endswith("running_mean"):
+                b.copy_(torch.randn(b.shape, generator=g) * 0.1)
+            elif k.endswith("running_var"):
+                b.copy_(torch.rand(b.shape, generator=g) + 0.5)
+
+
+def ragged_mask(b, t, g, nband=1):
+    per = t // nband
+    m = torch.zeros(b, t, dtype=torch.bool)
+    for i in range(b):
+        for k in range(nband):
+            n = int(torch.randint(1, per + 1, (1,), generator=g))
+            m[i, k * per:k * per + n] = True
+    return m
+
+
+# ----------------------------------------------------------------------------------------
+def gen_loss(ref_loss):
+    g = torch.Generator().manual_seed(11)
+    eye = torch.eye(4)
+    kat = {}
+    kat["clip_I4_s0_b0"] = ref_loss.clip_loss(eye, eye, torch.tensor(0.0), torch.tensor(0.0))
+    kat["clip_I4_ln10_bm10"] = ref_loss.clip_loss(eye, eye, torch.tensor(math.log(10.0)), torch.tensor(-10.0))
+    kat["sigmoid_I4_ln10_bm10"] = ref_loss.sigmoid_loss(eye, eye, torch.tensor(math.log(10.0)),
+                                                        torch.tensor(-10.0))
+    save("loss_kat", out=kat)
+
+    for n, d in [(8, 16), (32, 128), (256, 128)]:
+        e1 = unit(n, d, g).requires_grad_()
+        e2 = unit(n, d, g).requires_grad_()
+        ls = torch.tensor(math.log(10.0), requires_grad=True)
+        lb = torch.tensor(-10.0, requires_grad=True)
+        loss = ref_loss.clip_loss(e1, e2, ls, lb)
+        loss.backward()
+        ins = {"e1": e1, "e2": e2, "logit_scale": ls, "logit_bias": lb}
+        if n == 256:  # keep the fixture small: store fp16-exact inputs? no -- store as is (256 KB)
+            pass
+        save(f"loss_clip_n{n}", **{"in": ins, "out": {"loss": loss},
+                                   "grad": {"e1": e1.grad, "e2": e2.grad, "logit_scale": ls.grad,
+                                            "logit_bias": lb.grad}})
+        e1s, e2s = e1.detach().clone().requires_grad_(), e2.detach().clone().requires_grad_()
+        ls2 = torch.tensor(math.log(3.0), requires_grad=True)
+        lb2 = torch.tensor(0.7, requires_grad=True)
+        sl = ref_loss.sigmoid_loss(e1s, e2s, ls2, lb2)
+        sl.backward()
+        if n <= 32:
+            save(f"loss_sigmoid_n{n}", **{"in": {"e1": e1s, "e2": e2s, "logit_scale": ls2, "logit_bias": lb2},
+                                          "out": {"loss": sl},
+                                          "grad": {"e1": e1s.grad, "e2": e2s.grad, "logit_scale": ls2.grad,
+                                                   "logit_bias": lb2.grad}})
+
+    # unequal lengths (n = min)
+    e1, e2 = unit(6, 16, g), unit(9, 16, g)
+    save("loss_clip_unequal", **{"in": {"e1": e1, "e2": e2, "logit_scale": torch.tensor(1.3),
+                                        "logit_bias": torch.tensor(-0.5)},
+                                 "out": {"loss": ref_loss.clip_loss(e1, e2, torch.tensor(1.3), torch.tensor(-0.5))}})
+
+    # three-way multimodal, shared 0-dim scale/bias and per-pair vectors
+    embs = [unit(8, 16, g).requires_grad_() for _ in range(3)]
+    ls = torch.tensor(math.log(7.0), requires_grad=True)
+    lb = torch.tensor(-10.0, requires_grad=True)
+    loss = ref_loss.clip_loss_multimodal(embs, ls, lb)
+    loss.backward()
+    lsv = torch.tensor([0.5, 1.0, 1.5])
+    lbv = torch.tensor([-1.0, 0.0, 2.0])
+    save("loss_clip_multimodal3", **{
+        "in": {"e0": embs[0], "e1": embs[1], "e2": embs[2], "logit_scale": ls, "logit_bias": lb,
+               "scales_vec": lsv, "biases_vec": lbv},
+        "out": {"loss": loss,
+                "loss_vec": ref_loss.clip_loss_multimodal([e.detach() for e in embs], lsv, lbv),
+                "sigmoid": ref_loss.sigmoid_loss_multimodal([e.detach() for e in embs], ls.detach(), lb.detach())},
+        "grad": {"e0": embs[0].grad, "e1": embs[1].grad, "e2": embs[2].grad, "logit_scale": ls.grad,
+                 "logit_bias": lb.grad}})
+
+
+def gen_transformer(ref_tr):
+    g = torch.Generator().manual_seed(23)
+    b, t, e, h = 3, 12, 16, 4
+    x = torch.randn(b, t, e, generator=g)
+    cot = torch.randn(b, t, e, generator=g)
+    masks = {"full": torch.ones(b, t, dtype=torch.bool), "ragged": ragged_mask(b, t, g)}
+    masks["ragged"][2] = False  # a fully padded sample: softmax over -1e7 everywhere = uniform
+    for mname, mask in masks.items():
+        att = ref_tr.SelfAttention(e, heads=h)
+        randomise(att, g)
+        xi = x.clone().requires_grad_()
+        y = att(xi, mask)
+        (y * cot).sum().backward()
+        save(f"attn_{mname}", cfg={"emb": e, "heads": h}, P=sd_of(att), **{
+            "in": {"x": x, "mask": mask, "cot": cot}, "out": {"y": y},
+            "grad": {"x": xi.grad, **grads_of(att)}})
+
+        blk = ref_tr.TransformerBlock(e, h, ff_hidden_mult=4, dropout=0.0)
+        randomise(blk, g)
+        xi = x.clone().requires_grad_()
+        y = blk(xi, mask)
+        (y * cot).sum().backward()
+        save(f"block_{mname}", cfg={"emb": e, "heads": h}, P=sd_of(blk), **{
+            "in": {"x": x, "mask": mask, "cot": cot}, "out": {"y": y},
+            "grad": {"x": xi.grad, **grads_of(blk)}})
+
+    tt = torch.rand(b, t, generator=g) * 100.0
+    pe = ref_tr.TimePositionalEncoding(e, 20583.37)(tt)
+    save("timeenc", cfg={"emb": e, "norm": 20583.37}, **{"in": {"t": tt}, "out": {"pe": pe}})
+
+    n_out = 8
+    for agg in ["mean", "max", "attn", "pretraining"]:
+        for nband in [1, 2]:
+            for mname in ["full", "ragged"]:
+                mask = torch.ones(b, t, dtype=torch.bool) if mname == "full" else ragged_mask(b, t, g, nband)
+                kw = dict(emb=e, heads=h, depth=2, dropout=0.0)
+                m = ref_tr.TransformerWithTimeEmbeddings(n_out=n_out, nband=nband, agg=agg,
+                                                         time_norm=20583.37, **kw)
+                randomise(m, g)
+                xv = torch.randn(b, t, 1, generator=g)
+                tv = torch.sort(torch.rand(b, t, generator=g) * 100.0, dim=1)[0]
+                y = m(xv, tv, mask)
+                c = torch.randn(y.shape, generator=g)
+                (y * c).sum().backward()
+                save(f"tenc_{agg}_nb{nband}_{mname}",
+                     cfg={"emb": e, "heads": h, "depth": 2, "time_norm": 20583.37, "nband": nband,
+                          "agg": agg, "n_out": n_out},
+                     P=sd_of(m), **{"in": {"x": xv, "t": tv, "mask": mask, "cot": c}, "out": {"y": y},
+                                    "grad": grads_of(m)})
+
+
+def gen_convmixer_mlp(ref_mm):
+    g = torch.Generator().manual_seed(37)
+    for name, (hw, p) in {"p4": (16, 4), "p10floor": (23, 10)}.items():
+        kw = dict(dim=8, depth=2, channels=3, kernel_size=5, patch_size=p, n_out=8, dropout_prob=0.0)
+        for mode in ["train", "eval"]:
+            m = ref_mm.ConvMixer(**kw)
+            randomise(m, g)
+            m.train(mode == "train")
+            before = sd_of(m)
+            x = torch.rand(5, 3, hw, hw, generator=g)
+            xi = x.clone().requires_grad_()
+            y = m(xi)
+            c = torch.randn(y.shape, generator=g)
+            (y * c).sum().backward()
+            after = {k: v for k, v in sd_of(m).items() if "running" in k or "num_batches" in k}
+            save(f"convmixer_{name}_{mode}", cfg={**kw, "mode": mode}, P=before,
+                 **{"in": {"x": x, "cot": c}, "out": {"y": y}, "grad": {"x": xi.grad, **grads_of(m)},
+                    "stats": after})
+    m = ref_mm.MLP(input_dim=12, hidden_dim=16, output_dim=8, num_layers=2, dropout=0.0)
+    randomise(m, g)
+    x = torch.randn(6, 12, generator=g)
+    xi = x.clone().requires_grad_()
+    y = m(xi)
+    c = torch.randn(y.shape, generator=g)
+    (y * c).sum().backward()
+    save("mlp", cfg={"num_layers": 2}, P=sd_of(m),
+         **{"in": {"x": x, "cot": c}, "out": {"y": y}, "grad": {"x": xi.grad, **grads_of(m)}})
+
+
+def _batch(g, b, combos, hw=16, t_lc=12, t_sp=10, nband=2, n_classes=5):
+    x_img = torch.rand(b, 3, hw, hw, generator=g) if "host_galaxy" in combos else None
+    x_lc = torch.randn(b, t_lc, generator=g)
+    per = t_lc // nband
+    t_lcv = torch.cat([torch.sort(torch.rand(b, per, generator=g) * 100.0, dim=1)[0] for _ in range(nband)], 1)
+    m_lc = ragged_mask(b, t_lc, g, nband)
+    x_sp = torch.randn(b, t_sp, generator=g)
+    t_spv = torch.sort(torch.rand(b, t_sp, generator=g) * 6000.0 + 3000.0, dim=1)[0]
+    m_sp = ragged_mask(b, t_sp, g)
+    red = torch.rand(b, generator=g)
+    cls = torch.randint(0, n_classes, (b,), generator=g)
+    return (x_img, x_lc, t_lcv, m_lc, x_sp, t_spv, m_sp, red, cls)
+
+
+def gen_clip(ref_mm):
+    g = torch.Generator().manual_seed(53)
+    tk = dict(n_out=8, emb=16, heads=4, depth=2, dropout=0.0, time_norm=20583.37, agg="mean")
+    sk = dict(n_out=8, emb=8, heads=2, depth=3, dropout=0.0, time_norm=17945.14, agg="mean")
+    ck = dict(dim=8, depth=2, channels=3, kernel_size=5, patch_size=4, n_out=8, dropout_prob=0.0)
+    mk = dict(input_dim=8, hidden_dim=16, num_layers=2, dropout=0.0)
+    cases = {
+        "clip_img_lc": ["host_galaxy", "lightcurve"],
+        "clip_lc_sp": ["lightcurve", "spectral"],
+        "clip_3tower": ["spectral", "host_galaxy", "lightcurve"],   # order given != order used
+        "clip_4tower": ["host_galaxy", "lightcurve", "spectral", "meta"],
+    }
+    for name, combos in cases.items():
+        for loss in (["softmax", "sigmoid"] if name == "clip_lc_sp" else ["softmax"]):
+            model = ref_mm.LightCurveImageCLIP(
+                enc_dim=16, logit_scale=10.0, nband=2, transformer_kwargs=tk, transformer_spectral_kwargs=sk,
+                conv_kwargs=ck, meta_kwargs=mk, combinations=combos, optimizer_kwargs={"weight_decay": 1e-3},
+                lr=1e-2, loss=loss)
+            randomise(model, g)
+            with torch.no_grad():
+                model.logit_scale.fill_(math.log(10.0))
+                model.logit_bias.fill_(-10.0)
+            model.train()
+            before = sd_of(model)
+            b = 6
+            batch = _batch(g, b, combos)
+            embs = model(*batch)
+            model.zero_grad()
+            loss_v = model.training_step(batch, 0)
+            loss_v.backward()
+            cfg = {"combinations": combos, "nband": 2, "transformer_kwargs": tk,
+                   "transformer_spectral_kwargs": sk, "conv_kwargs": ck, "meta_kwargs": mk, "enc_dim": 16,
+                   "loss": loss, "lr": 1e-2, "weight_decay": 1e-3}
+            ins = {k: v for k, v in zip(["x_img", "x_lc", "t_lc", "mask_lc", "x_sp", "t_sp", "mask_sp",
+                                         "redshift", "classification"], batch) if v is not None}
+            outs = {f"emb{i}": e for i, e in enumerate(embs)}
+            outs["loss"] = loss_v
+            suffix = "" if loss == "softmax" else "_sigmoid"
+            save(name + suffix, cfg=cfg, P=before, **{"in": ins, "out": outs, "grad": grads_of(model)})
+
+    # harness row H: 3 optimiser steps with RAdam as configure_optimizers builds it, two batches cycled
+    combos = ["host_galaxy", "lightcurve"]
+    model = ref_mm.LightCurveImageCLIP(
+        enc_dim=16, logit_scale=10.0, nband=2, transformer_kwargs=tk, transformer_spectral_kwargs=sk,
+        conv_kwargs=ck, meta_kwargs=mk, combinations=combos, optimizer_kwargs={"weight_decay": 1e-3},
+        lr=1e-2, loss="softmax")
+    randomise(model, g)
+    with torch.no_grad():
+        model.logit_scale.fill_(math.log(10.0))
+        model.logit_bias.fill_(-10.0)
+    model.train()
+    before = sd_of(model)
+    opt = model.configure_optimizers()["optimizer"]
+    batches = [_batch(g, 6, combos) for _ in range(2)]
+    losses = []
+    n_steps = 8  # crosses RAdam's rho_t > 5 switch (step 6 with beta2 = 0.999)
+    for step in range(n_steps):
+        opt.zero_grad()
+        lv = model.training_step(batches[step % 2], step)
+        lv.backward()
+        opt.step()
+        losses.append(lv.detach())
+    ins = {}
+    for bi, batch in enumerate(batches):
+        for k, v in zip(["x_img", "x_lc", "t_lc", "mask_lc", "x_sp", "t_sp", "mask_sp", "redshift",
+                         "classification"], batch):
+            if v is not None:
+                ins[f"b{bi}.{k}"] = v
+    cfg = {"combinations": combos, "nband": 2, "transformer_kwargs": tk, "transformer_spectral_kwargs": sk,
+           "conv_kwargs": ck, "meta_kwargs": mk, "enc_dim": 16, "loss": "softmax", "lr": 1e-2,
+           "weight_decay": 1e-3, "n_steps": n_steps}
+    save("harness_radam", cfg=cfg, P=before, **{"in": ins, "out": {"losses": torch.stack(losses)},
+                                               "after": sd_of(model)})
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    ref_loss, ref_tr, ref_mm = import_reference()
+    gen_loss(ref_loss)
+    gen_transformer(ref_tr)
+    gen_convmixer_mlp(ref_mm)
+    gen_clip(ref_mm)
+
+
+if __name__ == "__main__":
+    main()
