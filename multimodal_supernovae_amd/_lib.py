@@ -1,0 +1,80 @@
+"""ctypes binding of libmsn_hip.so (the C-ABI declared in include/msn_hip.h).
+
+There is NO CPU fallback: `lib()` raises if the shared library has not been built, and
+`require_gpu()` raises if no MI355X is visible.  Everything in ops.py goes through here.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmsn_hip.so")
+
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_f32 = ctypes.c_float
+c_f64 = ctypes.c_double
+c_ptr = ctypes.c_void_p
+c_size = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/msn_hip.h one to one
+SIGNATURES = {
+    "msn_version": (c_int, []),
+    "msn_last_error": (ctypes.c_char_p, []),
+    "msn_device_count": (c_int, []),
+    "msn_sgemm_workspace_bytes": (c_size, [c_int, c_int, c_i64, c_i64, c_i64]),
+    "msn_sgemm": (c_int, [c_int, c_int, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr,
+                          c_int, c_ptr, c_i64, c_ptr, c_size, c_ptr]),
+    "msn_colsum_workspace_bytes": (c_size, [c_i64, c_i64]),
+    "msn_colsum": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_size, c_ptr]),
+    "msn_infonce_workspace_bytes": (c_size, [c_int] * 5),
+    "msn_infonce_fwd": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_i64, c_int,
+                                c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "msn_infonce_bwd": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_i64, c_int,
+                                c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr,
+                                c_ptr, c_size, c_ptr]),
+}
+
+_lib = None
+
+
+class MsnHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises (loudly) when it is missing -- the product has no other path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MsnHipError(
+                f"{LIB_PATH} not found: build it with `python -m multimodal_supernovae_amd.build` "
+                "(there is no CPU fallback for the contrastive hot path)")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here = header / library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise MsnHipError("multimodal_supernovae_amd needs an MI355X (gfx950): torch.cuda.is_available() is "
+                          "False and the hot path has no CPU implementation")
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().msn_last_error().decode("utf-8", "replace")
+        raise MsnHipError(f"{what or 'libmsn_hip'} failed (code {rc}): {msg}")
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)

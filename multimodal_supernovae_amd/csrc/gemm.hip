@@ -1,0 +1,375 @@
+// fp32 GEMM on the gfx950 f32-input matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chain).
+//
+// Tiling (per 256-thread workgroup = 4 waves): BM x BN output tile, BK = 32 deep K-steps, operand
+// tiles double-buffered in LDS, next tile prefetched global->registers while the current one is
+// multiplied.  One MFMA consumes a 32x2 A slab and a 2x32 B slab: lane l supplies A[l&31][l>>5]
+// and B[l>>5][l&31].  K order inside a K-step is free (it is a sum), so the lane half h = l>>5
+// owns k = 4h..4h+3 of every 8-deep "octet" and reads them with ONE 16-byte LDS read when the
+// operand is stored K-contiguous ([row][k], rows padded by 4 floats -> conflict-free b128 reads);
+// a K-major operand ([k][col]) is read with four 4-byte reads whose 32 lanes sweep one row.
+//
+// Workgroup -> tile map is XCD-aware: the 8 XCDs have private L2s and consecutive workgroup ids
+// are dealt round-robin over them, so ids are remapped to give each XCD a contiguous run of
+// tiles that walk N fastest (neighbours share the A row-panel in that XCD's L2).
+#include <algorithm>
+
+#include "msn_common.h"
+
+namespace msn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int KPAD = 4;  // floats; keeps 16-B alignment and makes b128 fragment reads conflict-free
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    float* aux;
+    int64_t M, N, K;
+    int64_t lda, ldb, ldc, ldaux;
+    int epilogue;
+    int tiles_m, tiles_n;
+    int k_per_split;  // multiple of BK
+    int splits;
+    float* partial;   // [splits][M][N] when splits > 1
+};
+
+// Load 4 consecutive elements (r, c..c+3) of a stored row-major matrix, zero beyond [nr, nc).
+__device__ __forceinline__ float4 load4_guard(const float* __restrict__ base, int64_t r, int64_t c,
+                                              int64_t ld, int64_t nr, int64_t nc, bool vec_ok) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < nr) {
+        const float* p = base + r * ld + c;
+        if (vec_ok && c + 3 < nc) {
+            v = *reinterpret_cast<const float4*>(p);
+        } else {
+            if (c < nc) v.x = p[0];
+            if (c + 1 < nc) v.y = p[1];
+            if (c + 2 < nc) v.z = p[2];
+            if (c + 3 < nc) v.w = p[3];
+        }
+    }
+    return v;
+}
+
+template <int ROWS, bool KMAJOR>
+struct OperandTile {
+    // K-contiguous: [ROWS][BK + KPAD];  K-major: [BK][ROWS + KPAD]
+    static constexpr int kStride = KMAJOR ? (ROWS + KPAD) : (BK + KPAD);
+    static constexpr int kFloats = KMAJOR ? BK * (ROWS + KPAD) : ROWS * (BK + KPAD);
+    static constexpr int kLoads = ROWS / 32;  // float4 per thread per K-step (256 threads)
+
+    // row0: first row (M or N index) of this tile; k0: first k.  `nrows` = M or N, `nk` = K limit.
+    __device__ static __forceinline__ void fetch(float4 (&reg)[kLoads], const float* __restrict__ g,
+                                                 int64_t ld, int64_t row0, int64_t nrows, int64_t k0,
+                                                 int64_t nk, bool vec_ok) {
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) {
+            const int idx = t + 256 * i;
+            if (KMAJOR) {  // stored [K][rows]: 4 consecutive rows of one k
+                const int k = idx / (ROWS / 4), q = idx % (ROWS / 4);
+                reg[i] = load4_guard(g, k0 + k, row0 + 4 * q, ld, nk, nrows, vec_ok);
+            } else {  // stored [rows][K]: 4 consecutive k of one row
+                const int r = idx / (BK / 4), q = idx % (BK / 4);
+                reg[i] = load4_guard(g, row0 + r, k0 + 4 * q, ld, nrows, nk, vec_ok);
+            }
+        }
+    }
+    __device__ static __forceinline__ void stash(const float4 (&reg)[kLoads], float* lds) {
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) {
+            const int idx = t + 256 * i;
+            if (KMAJOR) {
+                const int k = idx / (ROWS / 4), q = idx % (ROWS / 4);
+                *reinterpret_cast<float4*>(lds + k * kStride + 4 * q) = reg[i];
+            } else {
+                const int r = idx / (BK / 4), q = idx % (BK / 4);
+                *reinterpret_cast<float4*>(lds + r * kStride + 4 * q) = reg[i];
+            }
+        }
+    }
+    // Fragment for one 32-row MFMA slab and one k-octet `ko`: f.{x,y,z,w} = element k = 8ko+4h+{0..3}.
+    __device__ static __forceinline__ float4 frag(const float* lds, int row_in_tile, int ko, int h) {
+        if (KMAJOR) {
+            const float* p = lds + (8 * ko + 4 * h) * kStride + row_in_tile;
+            return make_float4(p[0], p[kStride], p[2 * kStride], p[3 * kStride]);
+        } else {
+            return *reinterpret_cast<const float4*>(lds + row_in_tile * kStride + 8 * ko + 4 * h);
+        }
+    }
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    // bijective for any nwg: XCD x (= bid % 8) owns a contiguous chunk of logical ids
+    const int q = nwg / 8, r = nwg % 8, x = bid % 8;
+    const int base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + bid / 8;
+}
+
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM>
+__global__ __launch_bounds__(256) void sgemm_kernel(const GemmArgs p) {
+    using TA = OperandTile<BM, AKM>;
+    using TB = OperandTile<BN, BKM>;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * (TA::kFloats + TB::kFloats)];
+    auto a_buf = [&](int i) { return smem + i * TA::kFloats; };
+    auto b_buf = [&](int i) { return smem + 2 * TA::kFloats + i * TB::kFloats; };
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int logical = xcd_remap(blockIdx.x, nwg);
+    const int tile_m = logical / p.tiles_n, tile_n = logical % p.tiles_n;
+    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+    const int split = blockIdx.y;
+    const int64_t k_begin = (int64_t)split * p.k_per_split;
+    const int64_t k_end = min(p.K, k_begin + (int64_t)p.k_per_split);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, l32 = lane & 31;
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+
+    const bool a_vec = (p.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
+    const bool b_vec = (p.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[TA::kLoads], rb[TB::kLoads];
+    const int nkt = (int)((k_end - k_begin + BK - 1) / BK);
+    if (nkt > 0) {
+        TA::fetch(ra, p.A, p.lda, m0, p.M, k_begin, k_end, a_vec);
+        TB::fetch(rb, p.B, p.ldb, n0, p.N, k_begin, k_end, b_vec);
+        TA::stash(ra, a_buf(0));
+        TB::stash(rb, b_buf(0));
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nkt;
+        if (more) {  // prefetch the next K-step into registers while this one is multiplied
+            const int64_t k0 = k_begin + (int64_t)(kt + 1) * BK;
+            TA::fetch(ra, p.A, p.lda, m0, p.M, k0, k_end, a_vec);
+            TB::fetch(rb, p.B, p.ldb, n0, p.N, k0, k_end, b_vec);
+        }
+        const float* as = a_buf(cur);
+        const float* bs = b_buf(cur);
+#pragma unroll
+        for (int ko = 0; ko < BK / 8; ++ko) {
+            float4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = TA::frag(as, wm0 + 32 * i + l32, ko, h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = TB::frag(bs, wn0 + 32 * j + l32, ko, h);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more) {
+            TA::stash(ra, a_buf(cur ^ 1));
+            TB::stash(rb, b_buf(cur ^ 1));
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h ----
+    const bool to_partial = p.splits > 1;
+    float* out = to_partial ? p.partial + (int64_t)split * p.M * p.N : p.C;
+    const int64_t ldo = to_partial ? p.N : p.ldc;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int64_t col = n0 + wn0 + 32 * j + l32;
+            if (col >= p.N) continue;
+            const float bv = (!to_partial && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (!to_partial) {
+                    switch (p.epilogue) {
+                        case MSN_EPI_RELU: v = fmaxf(v, 0.f); break;
+                        case MSN_EPI_GELU:
+                            if (p.aux) p.aux[row * p.ldaux + col] = v;
+                            v = gelu_f(v);
+                            break;
+                        case MSN_EPI_RELU_BWD: v = p.aux[row * p.ldaux + col] > 0.f ? v : 0.f; break;
+                        case MSN_EPI_GELU_BWD: v *= gelu_grad_f(p.aux[row * p.ldaux + col]); break;
+                        case MSN_EPI_ADD: v += p.aux[row * p.ldaux + col]; break;
+                        default: break;
+                    }
+                }
+                out[row * ldo + col] = v;
+            }
+        }
+}
+
+// C[m][n] = sum_s partial[s][m][n]   (split-K finish; fixed order -> deterministic)
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C, int64_t M,
+                                     int64_t N, int64_t ldc, int splits) {
+    const int64_t total = M * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += partial[(int64_t)k * total + i];
+        C[(i / N) * ldc + (i % N)] = s;
+    }
+}
+
+// Column sums, two deterministic stages: each block sums a slab of rows, then one pass over slabs.
+constexpr int kColsumRows = 256;
+__global__ void colsum_partial_kernel(const float* __restrict__ X, int64_t ldx, int64_t M, int64_t N,
+                                      float* __restrict__ part) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int64_t r0 = (int64_t)blockIdx.y * kColsumRows, r1 = min(M, r0 + kColsumRows);
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += X[r * ldx + n];
+    part[(int64_t)blockIdx.y * N + n] = s;
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int64_t slabs, int64_t N,
+                                    float* __restrict__ out) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int64_t k = 0; k < slabs; ++k) s += part[k * N + n];
+    out[n] = s;
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(const GemmArgs& a, int opA, int opB, hipStream_t st) {
+    const dim3 grid(a.tiles_m * a.tiles_n, a.splits), block(256);
+#define MSN_GEMM_GO(AKM, BKM) \
+    { hipLaunchKernelGGL((sgemm_kernel<BM, BN, WM, WN, AKM, BKM>), grid, block, 0, st, a); }
+    if (opA == MSN_OP_N && opB == MSN_OP_T) MSN_GEMM_GO(false, false)
+    else if (opA == MSN_OP_N && opB == MSN_OP_N) MSN_GEMM_GO(false, true)
+    else if (opA == MSN_OP_T && opB == MSN_OP_N) MSN_GEMM_GO(true, true)
+    else MSN_GEMM_GO(true, false)
+#undef MSN_GEMM_GO
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+// Tile shape by N; split-K count so that a reduction-heavy product (wgrad: small M x N, huge K)
+// still fills the 256 CUs.
+static void plan(int64_t M, int64_t N, int64_t K, int opA, int* bm, int* bn, int* splits, int* kps) {
+    *bm = 128;
+    *bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
+    const int64_t tiles = cdiv(M, *bm) * cdiv(N, *bn);
+    int s = 1;
+    if (opA == MSN_OP_T && tiles < 512) {
+        const int64_t ksteps = cdiv(K, BK);
+        s = (int)std::min<int64_t>(std::min<int64_t>(cdiv(1024, tiles), ksteps / 4 > 0 ? ksteps / 4 : 1), 64);
+        if (s < 1) s = 1;
+    }
+    int64_t per = cdiv(cdiv(K, s), BK) * BK;
+    if (per < BK) per = BK;
+    s = (int)cdiv(K, per);
+    if (s < 1) s = 1;
+    *splits = s;
+    *kps = (int)per;
+}
+
+}  // namespace msn
+
+using namespace msn;
+
+extern "C" size_t msn_sgemm_workspace_bytes(int opA, int opB, int64_t M, int64_t N, int64_t K) {
+    (void)opB;
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    int bm, bn, splits, kps;
+    plan(M, N, K, opA, &bm, &bn, &splits, &kps);
+    return splits > 1 ? sizeof(float) * (size_t)splits * (size_t)M * (size_t)N : 0;
+}
+
+extern "C" int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                         const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int epilogue,
+                         float* aux, int64_t ldaux, void* ws, size_t ws_bytes, msn_stream_t stream) {
+    MSN_REQUIRE(M >= 0 && N >= 0 && K >= 0, "msn_sgemm: negative size M=%lld N=%lld K=%lld", (long long)M,
+                (long long)N, (long long)K);
+    if (M == 0 || N == 0) return MSN_OK;
+    MSN_REQUIRE(K > 0, "msn_sgemm: K must be positive");
+    MSN_REQUIRE(A && B && C, "msn_sgemm: null operand");
+    MSN_REQUIRE((opA == MSN_OP_N || opA == MSN_OP_T) && (opB == MSN_OP_N || opB == MSN_OP_T),
+                "msn_sgemm: bad op flags %d %d", opA, opB);
+    MSN_REQUIRE(lda >= (opA == MSN_OP_N ? K : M), "msn_sgemm: lda %lld too small", (long long)lda);
+    MSN_REQUIRE(ldb >= (opB == MSN_OP_N ? N : K), "msn_sgemm: ldb %lld too small", (long long)ldb);
+    MSN_REQUIRE(ldc >= N, "msn_sgemm: ldc %lld < N", (long long)ldc);
+    MSN_REQUIRE(epilogue >= MSN_EPI_NONE && epilogue <= MSN_EPI_ADD, "msn_sgemm: bad epilogue %d", epilogue);
+    const bool needs_aux = epilogue == MSN_EPI_RELU_BWD || epilogue == MSN_EPI_GELU_BWD || epilogue == MSN_EPI_ADD;
+    MSN_REQUIRE(!needs_aux || (aux && ldaux >= N), "msn_sgemm: epilogue %d needs aux with ldaux >= N", epilogue);
+    MSN_REQUIRE(!(epilogue == MSN_EPI_GELU && aux) || ldaux >= N, "msn_sgemm: ldaux < N");
+
+    GemmArgs a;
+    a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
+    a.epilogue = epilogue;
+    int bm, bn, splits, kps;
+    plan(M, N, K, opA, &bm, &bn, &splits, &kps);
+    a.tiles_m = (int)cdiv(M, bm);
+    a.tiles_n = (int)cdiv(N, bn);
+    a.splits = splits;
+    a.k_per_split = kps;
+    a.partial = nullptr;
+    if (splits > 1) {
+        MSN_REQUIRE(epilogue == MSN_EPI_NONE && bias == nullptr,
+                    "msn_sgemm: split-K (opA=T) supports only the plain epilogue without bias");
+        const size_t need = sizeof(float) * (size_t)splits * (size_t)M * (size_t)N;
+        MSN_REQUIRE(ws && ws_bytes >= need, "msn_sgemm: workspace %zu < %zu bytes", ws_bytes, need);
+        a.partial = static_cast<float*>(ws);
+    }
+    MSN_REQUIRE((int64_t)a.tiles_m * a.tiles_n < (1ll << 31), "msn_sgemm: too many tiles");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc;
+    if (bn == 128) rc = launch_cfg<128, 128, 64, 64>(a, opA, opB, st);
+    else if (bn == 64) rc = launch_cfg<128, 64, 64, 32>(a, opA, opB, st);
+    else rc = launch_cfg<128, 32, 32, 32>(a, opA, opB, st);
+    if (rc != MSN_OK) return rc;
+    if (splits > 1) {
+        const int64_t total = M * N;
+        const int blocks = (int)std::min<int64_t>(cdiv(total, 256), 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.partial, C, M, N, ldc, splits);
+        MSN_LAUNCH_CHECK();
+    }
+    return MSN_OK;
+}
+
+extern "C" size_t msn_colsum_workspace_bytes(int64_t M, int64_t N) {
+    if (M <= 0 || N <= 0) return 0;
+    return sizeof(float) * (size_t)cdiv(M, kColsumRows) * (size_t)N;
+}
+
+extern "C" int msn_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, float* out, void* ws,
+                          size_t ws_bytes, msn_stream_t stream) {
+    MSN_REQUIRE(M > 0 && N > 0 && X && out && ldx >= N, "msn_colsum: bad arguments");
+    const int64_t slabs = cdiv(M, kColsumRows);
+    MSN_REQUIRE(ws && ws_bytes >= sizeof(float) * (size_t)slabs * (size_t)N, "msn_colsum: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(ws);
+    const int bx = (int)cdiv(N, 64);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(bx, (unsigned)slabs), dim3(64), 0, st, X, ldx, M, N, part);
+    MSN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(bx), dim3(64), 0, st, part, slabs, N, out);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}

@@ -1,0 +1,441 @@
+// Fused symmetric InfoNCE (CLIP loss) forward / backward -- never materialises the N x N logits.
+//
+// Reference: src/loss.py:14-38 (clip_loss).  With S = s * E2 . E1^T + b  (s = exp(logit_scale)):
+//   loss = 1/(2n) * sum_{i<n} [ LSE_j S_ij + LSE_j S_ji - 2 S_ii ]
+//   G_ij = dloss/dS_ij = ( [i<n] softmax_row(S)_ij + [j<n] softmax_col(S)_ij - 2 delta_ij ) / (2n)
+//   dE2_i = s * sum_j G_ij E1_j ;  dE1_j = s * sum_i G_ij E2_i ;  dlogit_scale = sum_ij G_ij (S_ij - b)
+//
+// Sharding (one process per GPU, rows of the global batch split by rank): a rank owns `b` rows of
+// each modality and holds the all-gathered (N x D) matrices.  Both directions have the same shape:
+// "queries" = the local rows of one modality, "keys" = all rows of the other; direction 0 takes
+// queries from E2 (rows of S), direction 1 from E1 (columns of S).  The forward needs only the
+// per-query log-sum-exp; the backward recomputes S tiles from E and the (all-gathered) LSE vectors,
+// so dE of the local rows is complete on the owning rank and no reduce-scatter is needed.
+//
+// Kernel shape: workgroup = 4 waves, wave w owns the 32-query tile 128*blockIdx.x + 32*w for the
+// whole launch and keeps its Q fragments in registers; the workgroup sweeps its share of the keys
+// (blockIdx.y = key split) in 32-key tiles staged in LDS.  S^T tile = K_tile . Q_tile^T on the
+// f32 matrix cores (v_mfma_f32_32x32x2_f32), oriented so that the lane's column is the QUERY:
+// the softmax statistics of a query are then lane-local (16 registers = 16 keys per half-wave),
+// combined once at the end with one cross-half shuffle.  In the backward the G^T tile sitting in
+// the accumulator registers is directly the A operand of the second product dQ += G . K
+// (key index on the MFMA k axis), whose B operand is read from the same LDS key tile.
+// Partial results of the key splits go to caller scratch and are merged in a fixed order
+// (deterministic; no float atomics).
+#include <algorithm>
+#include <math.h>
+
+#include "msn_common.h"
+
+namespace msn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int QT = 32;        // queries per wave
+constexpr int QB = 128;       // queries per workgroup
+constexpr int KT = 32;        // keys per tile
+constexpr int MODE_SOFTMAX = 0, MODE_SIGMOID = 1;
+
+struct Side {
+    const float* Q;      // local rows (queries), [nq][ldq]
+    const float* K;      // all rows of the other modality (keys), [nk][ldk]
+    const float* lse_q;  // bwd: LSE of the queries' own direction, indexed by GLOBAL row id
+    const float* lse_k;  // bwd: LSE of the keys' direction, indexed by global row id
+    float* dQ;           // bwd: [nq][ldd]
+    int64_t ldq, ldk, ldd;
+    int nq, nk;
+};
+
+struct NceArgs {
+    Side side[2];
+    const float* log_scale;  // device scalar (log of the logit scale)
+    const float* bias;       // device scalar
+    int q_offset;            // global row id of local row 0
+    int n_diag;              // n = min(N1, N2)
+    int ksplit, keys_per_split;
+    float* part_m;           // fwd scratch [2][ksplit][maxq]
+    float* part_l;
+    float* slab;             // bwd scratch [2][ksplit][maxq][D]
+    double* scal;            // bwd scratch [2 * gridDim.x * ksplit][2] : partial dscale, dbias; fwd sigmoid partial loss
+    int maxq;
+    int mode;
+};
+
+__device__ __forceinline__ int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// Stage one 32-key tile (rows k0..k0+31 of K, zero beyond nk) into LDS, row stride D + 4.
+template <int D>
+__device__ __forceinline__ void stage_keys(float* Ks, const float* __restrict__ K, int64_t ldk, int k0, int nk,
+                                           bool vec_ok) {
+    constexpr int KS = D + 4;
+    constexpr int PER_ROW = D / 4;
+    for (int idx = threadIdx.x; idx < KT * PER_ROW; idx += 256) {
+        const int r = idx / PER_ROW, q = idx % PER_ROW;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k0 + r < nk) {
+            const float* p = K + (int64_t)(k0 + r) * ldk + 4 * q;
+            if (vec_ok) v = *reinterpret_cast<const float4*>(p);
+            else v = make_float4(p[0], p[1], p[2], p[3]);
+        }
+        *reinterpret_cast<float4*>(Ks + r * KS + 4 * q) = v;
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void load_q_frags(float4 (&qf)[D / 8], const float* __restrict__ Q, int64_t ldq,
+                                             int qrow, int h, bool vec_ok) {
+    const float* p = Q + (int64_t)qrow * ldq + 4 * h;
+#pragma unroll
+    for (int ko = 0; ko < D / 8; ++ko) {
+        if (vec_ok) qf[ko] = *reinterpret_cast<const float4*>(p + 8 * ko);
+        else qf[ko] = make_float4(p[8 * ko], p[8 * ko + 1], p[8 * ko + 2], p[8 * ko + 3]);
+    }
+}
+
+// acc[key][query] = sum_d K[key][d] * Q[query][d] for the staged tile; lane col = query (lane & 31).
+template <int D>
+__device__ __forceinline__ f32x16 score_tile(const float* Ks, const float4 (&qf)[D / 8], int l32, int h) {
+    constexpr int KS = D + 4;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ko = 0; ko < D / 8; ++ko) {
+        const float4 kf = *reinterpret_cast<const float4*>(Ks + l32 * KS + 8 * ko + 4 * h);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[ko].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[ko].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[ko].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[ko].w, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------ forward
+template <int D>
+__global__ __launch_bounds__(256) void nce_fwd_kernel(const NceArgs p) {
+    __shared__ __attribute__((aligned(16))) float Ks[KT * (D + 4)];
+    const Side& sd = p.side[blockIdx.z];
+    const int qb0 = blockIdx.x * QB;
+    if (qb0 >= sd.nq) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l32 = lane & 31, h = lane >> 5;
+    const int q_local = qb0 + QT * wave + l32;
+    const bool q_ok = q_local < sd.nq;
+    const float scale = __expf(*p.log_scale), bias = *p.bias;
+    const bool qvec = (sd.ldq % 4 == 0) && ((reinterpret_cast<uintptr_t>(sd.Q) & 15) == 0);
+    const bool kvec = (sd.ldk % 4 == 0) && ((reinterpret_cast<uintptr_t>(sd.K) & 15) == 0);
+
+    float4 qf[D / 8];
+    load_q_frags<D>(qf, sd.Q, sd.ldq, q_ok ? q_local : sd.nq - 1, h, qvec);
+
+    const int k_begin = blockIdx.y * p.keys_per_split;
+    const int k_end = min(sd.nk, k_begin + p.keys_per_split);
+    float m = -INFINITY, l = 0.f;
+    for (int k0 = k_begin; k0 < k_end; k0 += KT) {
+        __syncthreads();
+        stage_keys<D>(Ks, sd.K, sd.ldk, k0, k_end, kvec);
+        __syncthreads();
+        const f32x16 acc = score_tile<D>(Ks, qf, l32, h);
+        float s[16];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = (k0 + row_of(r, h) < k_end) ? acc[r] * scale + bias : -INFINITY;
+            tmax = fmaxf(tmax, s[r]);
+        }
+        const float mn = fmaxf(m, tmax);
+        if (mn > -INFINITY) {
+            float add = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) add += __expf(s[r] - mn);
+            l = l * __expf(m - mn) + add;
+            m = mn;
+        }
+    }
+    // combine the two half-waves (keys were split between them), then publish this split's (m, l)
+    const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64);
+    const float mm = fmaxf(m, m2);
+    float ll = 0.f;
+    if (mm > -INFINITY) ll = l * __expf(m - mm) + l2 * __expf(m2 - mm);
+    if (h == 0 && q_ok) {
+        const int64_t o = ((int64_t)blockIdx.z * p.ksplit + blockIdx.y) * p.maxq + q_local;
+        p.part_m[o] = mm;
+        p.part_l[o] = ll;
+    }
+}
+
+// Merge key splits -> LSE per local row and direction; diagonal; this rank's share of the loss.
+__global__ void nce_fwd_finish_kernel(const NceArgs p, float* __restrict__ lse_row, float* __restrict__ lse_col,
+                                      float* __restrict__ loss, int D) {
+    __shared__ float red[16];
+    const float scale = __expf(*p.log_scale), bias = *p.bias;
+    float* lse_out[2] = {lse_row, lse_col};
+    for (int dir = 0; dir < 2; ++dir) {
+        const int nq = p.side[dir].nq;
+        for (int i = threadIdx.x; i < nq; i += blockDim.x) {
+            float M = -INFINITY;
+            for (int s = 0; s < p.ksplit; ++s) M = fmaxf(M, p.part_m[((int64_t)dir * p.ksplit + s) * p.maxq + i]);
+            float L = 0.f;
+            for (int s = 0; s < p.ksplit; ++s) {
+                const int64_t o = ((int64_t)dir * p.ksplit + s) * p.maxq + i;
+                const float ms = p.part_m[o];
+                if (ms > -INFINITY) L += p.part_l[o] * __expf(ms - M);
+            }
+            lse_out[dir][i] = M + __logf(L);
+        }
+    }
+    __syncthreads();
+    // rows of S come from side[0].Q (E2), columns from side[1].Q (E1); local row i <-> global q_offset + i
+    const int nb = min(p.side[0].nq, p.side[1].nq);
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+        if (p.q_offset + i >= p.n_diag) continue;
+        const float* a = p.side[0].Q + (int64_t)i * p.side[0].ldq;
+        const float* b = p.side[1].Q + (int64_t)i * p.side[1].ldq;
+        float dot = 0.f;
+        for (int d = 0; d < D; ++d) dot = fmaf(a[d], b[d], dot);
+        acc += lse_row[i] + lse_col[i] - 2.f * (dot * scale + bias);
+    }
+    const float tot = block_sum(acc, red);
+    if (threadIdx.x == 0) *loss = tot / (2.f * (float)p.n_diag);
+}
+
+// ----------------------------------------------------------------------------------------- backward
+template <int D>
+__global__ __launch_bounds__(256) void nce_bwd_kernel(const NceArgs p) {
+    constexpr int KS = D + 4;
+    constexpr int DT = (D + 31) / 32;
+    __shared__ __attribute__((aligned(16))) float Ks[KT * KS];
+    __shared__ float lseK[KT];
+    __shared__ float red[8];
+    const int dir = blockIdx.z;
+    const Side& sd = p.side[dir];
+    const int qb0 = blockIdx.x * QB;
+    if (qb0 >= sd.nq) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l32 = lane & 31, h = lane >> 5;
+    const int q_local = qb0 + QT * wave + l32;
+    const bool q_ok = q_local < sd.nq;
+    const int q_glob = p.q_offset + q_local;
+    const float scale = __expf(*p.log_scale), bias = *p.bias;
+    const bool qvec = (sd.ldq % 4 == 0) && ((reinterpret_cast<uintptr_t>(sd.Q) & 15) == 0);
+    const bool kvec = (sd.ldk % 4 == 0) && ((reinterpret_cast<uintptr_t>(sd.K) & 15) == 0);
+
+    float4 qf[D / 8];
+    load_q_frags<D>(qf, sd.Q, sd.ldq, q_ok ? q_local : sd.nq - 1, h, qvec);
+    const bool q_in = q_ok && q_glob < p.n_diag;
+    const float lq = q_in ? sd.lse_q[q_glob] : 0.f;
+
+    f32x16 dq[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[t][r] = 0.f;
+    float ds = 0.f, db = 0.f;  // partial sum G (S - b), sum G
+
+    const int k_begin = blockIdx.y * p.keys_per_split;
+    const int k_end = min(sd.nk, k_begin + p.keys_per_split);
+    for (int k0 = k_begin; k0 < k_end; k0 += KT) {
+        __syncthreads();
+        stage_keys<D>(Ks, sd.K, sd.ldk, k0, k_end, kvec);
+        if (threadIdx.x < KT) {
+            const int kj = k0 + threadIdx.x;
+            lseK[threadIdx.x] = (kj < k_end && kj < p.n_diag) ? sd.lse_k[kj] : INFINITY;
+        }
+        __syncthreads();
+        f32x16 g = score_tile<D>(Ks, qf, l32, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kr = row_of(r, h);
+            const int kj = k0 + kr;
+            const float S = g[r] * scale + bias;
+            float G = 0.f;
+            if (q_ok && kj < k_end) {
+                if (q_in) G += __expf(S - lq);
+                G += __expf(S - lseK[kr]);  // lseK = +inf for keys outside the diagonal range -> 0
+                if (q_in && kj == q_glob) G -= 2.f;
+            }
+            g[r] = G;
+            ds = fmaf(G, S - bias, ds);
+            db += G;
+        }
+        // dQ[query][d] += sum_key G[query][key] * K[key][d]: A = G (lane = query, k = half-wave),
+        // B = K[key_r(h)][32 t + lane&31] from LDS (32 lanes sweep one row: conflict-free)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float* krow = Ks + row_of(r, h) * KS;
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                const int d = 32 * t + l32;
+                const float bv = (D % 32 == 0 || d < D) ? krow[d] : 0.f;
+                dq[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[r], bv, dq[t], 0, 0, 0);
+            }
+        }
+    }
+    // partial dQ of this key split -> slab[dir][split][q][D]  (C layout: col = d, rows = queries)
+    float* slab = p.slab + (((int64_t)dir * p.ksplit + blockIdx.y) * p.maxq) * D;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+        const int d = 32 * t + l32;
+        if (D % 32 != 0 && d >= D) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = qb0 + QT * wave + row_of(r, h);
+            if (q < sd.nq) slab[(int64_t)q * D + d] = dq[t][r];
+        }
+    }
+    // scalar partials (direction 0 covers every (i, j) exactly once)
+    if (dir == 0) {
+        const float s1 = block_sum(ds, red);
+        const float s2 = block_sum(db, red);
+        if (threadIdx.x == 0) {
+            double* o = p.scal + 2 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x);
+            o[0] = (double)s1;
+            o[1] = (double)s2;
+        }
+    }
+}
+
+// dQ = grad_out * s / (2n) * sum_split slab ; dscale/dbias = grad_out / (2n) * sum partials
+__global__ void nce_bwd_finish_kernel(const NceArgs p, const float* __restrict__ grad_out, int D, int n_scal,
+                                      float* __restrict__ dscal_out) {
+    const float g = *grad_out / (2.f * (float)p.n_diag);
+    const float f = g * __expf(*p.log_scale);
+    for (int dir = 0; dir < 2; ++dir) {
+        const Side& sd = p.side[dir];
+        const int64_t total = (int64_t)sd.nq * D;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+             i += (int64_t)gridDim.x * blockDim.x) {
+            float s = 0.f;
+            for (int k = 0; k < p.ksplit; ++k) s += p.slab[(((int64_t)dir * p.ksplit + k) * p.maxq) * D + i];
+            sd.dQ[(i / D) * sd.ldd + (i % D)] = f * s;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 2 && dscal_out) {
+        double s = 0.0;
+        for (int k = 0; k < n_scal; ++k) s += p.scal[2 * k + threadIdx.x];
+        dscal_out[threadIdx.x] = g * (float)s;
+    }
+}
+
+static int pick_ksplit(int maxq, int maxk) {
+    const int qblocks = (int)cdiv(maxq, QB);
+    int ks = std::max(1, 512 / (2 * qblocks));
+    ks = std::min(ks, (int)cdiv(maxk, KT));
+    ks = std::min(ks, 64);
+    return std::max(ks, 1);
+}
+
+struct Plan {
+    int ksplit, keys_per_split, maxq, qblocks;
+    size_t off_m, off_l, off_slab, off_scal, total;
+};
+
+static Plan make_plan(int b1, int b2, int n1, int n2, int D) {
+    Plan pl;
+    pl.maxq = std::max(b1, b2);
+    const int maxk = std::max(n1, n2);
+    pl.qblocks = (int)cdiv(pl.maxq, QB);
+    pl.ksplit = pick_ksplit(pl.maxq, maxk);
+    pl.keys_per_split = (int)(cdiv(cdiv(maxk, pl.ksplit), KT) * KT);
+    pl.ksplit = (int)cdiv(maxk, pl.keys_per_split);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
+    pl.off_m = take(sizeof(float) * 2 * pl.ksplit * (size_t)pl.maxq);
+    pl.off_l = take(sizeof(float) * 2 * pl.ksplit * (size_t)pl.maxq);
+    pl.off_slab = take(sizeof(float) * 2 * pl.ksplit * (size_t)pl.maxq * D);
+    pl.off_scal = take(sizeof(double) * 2 * (size_t)pl.ksplit * pl.qblocks);
+    pl.total = o;
+    return pl;
+}
+
+static int check_common(const char* who, int b1, int b2, int n1, int n2, int D, int q_offset) {
+    MSN_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64 || D == 128,
+                "%s: embedding width D=%d unsupported (8, 16, 32, 64 or 128)", who, D);
+    MSN_REQUIRE(b1 > 0 && b2 > 0 && n1 >= b1 && n2 >= b2 && q_offset >= 0, "%s: bad row counts b1=%d b2=%d N1=%d N2=%d",
+                who, b1, b2, n1, n2);
+    return MSN_OK;
+}
+
+#define MSN_NCE_DISPATCH(KERNEL, ...)                                                        \
+    switch (D) {                                                                             \
+        case 8: hipLaunchKernelGGL((KERNEL<8>), __VA_ARGS__); break;                         \
+        case 16: hipLaunchKernelGGL((KERNEL<16>), __VA_ARGS__); break;                       \
+        case 32: hipLaunchKernelGGL((KERNEL<32>), __VA_ARGS__); break;                       \
+        case 64: hipLaunchKernelGGL((KERNEL<64>), __VA_ARGS__); break;                       \
+        default: hipLaunchKernelGGL((KERNEL<128>), __VA_ARGS__); break;                      \
+    }
+
+}  // namespace msn
+
+using namespace msn;
+
+extern "C" size_t msn_infonce_workspace_bytes(int b1, int b2, int n1, int n2, int D) {
+    if (b1 <= 0 || b2 <= 0 || n1 <= 0 || n2 <= 0 || D <= 0) return 0;
+    return make_plan(b1, b2, n1, n2, D).total;
+}
+
+extern "C" int msn_infonce_fwd(const float* E1_loc, int64_t ld1, int b1, const float* E2_loc, int64_t ld2, int b2,
+                               const float* E1_all, int64_t ld1a, int n1, const float* E2_all, int64_t ld2a, int n2,
+                               int D, int q_offset, const float* log_scale, const float* bias, float* lse_row,
+                               float* lse_col, float* loss, void* ws, size_t ws_bytes, msn_stream_t stream) {
+    if (int rc = check_common("msn_infonce_fwd", b1, b2, n1, n2, D, q_offset)) return rc;
+    MSN_REQUIRE(E1_loc && E2_loc && E1_all && E2_all && log_scale && bias && lse_row && lse_col && loss,
+                "msn_infonce_fwd: null pointer");
+    MSN_REQUIRE(ld1 >= D && ld2 >= D && ld1a >= D && ld2a >= D, "msn_infonce_fwd: leading dimension < D");
+    const Plan pl = make_plan(b1, b2, n1, n2, D);
+    MSN_REQUIRE(ws && ws_bytes >= pl.total, "msn_infonce_fwd: workspace %zu < %zu bytes", ws_bytes, pl.total);
+    NceArgs a = {};
+    a.side[0] = Side{E2_loc, E1_all, nullptr, nullptr, nullptr, ld2, ld1a, 0, b2, n1};
+    a.side[1] = Side{E1_loc, E2_all, nullptr, nullptr, nullptr, ld1, ld2a, 0, b1, n2};
+    a.log_scale = log_scale; a.bias = bias; a.q_offset = q_offset; a.n_diag = std::min(n1, n2);
+    a.ksplit = pl.ksplit; a.keys_per_split = pl.keys_per_split; a.maxq = pl.maxq; a.mode = MODE_SOFTMAX;
+    char* w = static_cast<char*>(ws);
+    a.part_m = reinterpret_cast<float*>(w + pl.off_m);
+    a.part_l = reinterpret_cast<float*>(w + pl.off_l);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(pl.qblocks, pl.ksplit, 2), block(256);
+    MSN_NCE_DISPATCH(nce_fwd_kernel, grid, block, 0, st, a)
+    MSN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nce_fwd_finish_kernel, dim3(1), dim3(1024), 0, st, a, lse_row, lse_col, loss, D);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" int msn_infonce_bwd(const float* E1_loc, int64_t ld1, int b1, const float* E2_loc, int64_t ld2, int b2,
+                               const float* E1_all, int64_t ld1a, int n1, const float* E2_all, int64_t ld2a, int n2,
+                               int D, int q_offset, const float* log_scale, const float* bias,
+                               const float* lse_row_all, const float* lse_col_all, const float* grad_out,
+                               float* dE1_loc, int64_t ldd1, float* dE2_loc, int64_t ldd2, float* dscale_dbias,
+                               void* ws, size_t ws_bytes, msn_stream_t stream) {
+    if (int rc = check_common("msn_infonce_bwd", b1, b2, n1, n2, D, q_offset)) return rc;
+    MSN_REQUIRE(E1_loc && E2_loc && E1_all && E2_all && log_scale && bias && lse_row_all && lse_col_all &&
+                    grad_out && dE1_loc && dE2_loc,
+                "msn_infonce_bwd: null pointer");
+    MSN_REQUIRE(ld1 >= D && ld2 >= D && ld1a >= D && ld2a >= D && ldd1 >= D && ldd2 >= D,
+                "msn_infonce_bwd: leading dimension < D");
+    const Plan pl = make_plan(b1, b2, n1, n2, D);
+    MSN_REQUIRE(ws && ws_bytes >= pl.total, "msn_infonce_bwd: workspace %zu < %zu bytes", ws_bytes, pl.total);
+    NceArgs a = {};
+    // direction 0: queries = rows of S (E2), own LSE = row LSE, keys = E1 with the column LSE
+    a.side[0] = Side{E2_loc, E1_all, lse_row_all, lse_col_all, dE2_loc, ld2, ld1a, ldd2, b2, n1};
+    a.side[1] = Side{E1_loc, E2_all, lse_col_all, lse_row_all, dE1_loc, ld1, ld2a, ldd1, b1, n2};
+    a.log_scale = log_scale; a.bias = bias; a.q_offset = q_offset; a.n_diag = std::min(n1, n2);
+    a.ksplit = pl.ksplit; a.keys_per_split = pl.keys_per_split; a.maxq = pl.maxq; a.mode = MODE_SOFTMAX;
+    char* w = static_cast<char*>(ws);
+    a.slab = reinterpret_cast<float*>(w + pl.off_slab);
+    a.scal = reinterpret_cast<double*>(w + pl.off_scal);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // direction-0 blocks beyond its query count exit before writing their scalar partials: zero them
+    if (hipMemsetAsync(a.scal, 0, sizeof(double) * 2 * (size_t)pl.ksplit * pl.qblocks, st) != hipSuccess) {
+        set_error("msn_infonce_bwd: hipMemsetAsync failed");
+        return MSN_ERR_HIP;
+    }
+    const dim3 grid(pl.qblocks, pl.ksplit, 2), block(256);
+    MSN_NCE_DISPATCH(nce_bwd_kernel, grid, block, 0, st, a)
+    MSN_LAUNCH_CHECK();
+    const int64_t total = (int64_t)pl.maxq * D;
+    const int blocks = (int)std::min<int64_t>(cdiv(total, 256), 1024);
+    hipLaunchKernelGGL(nce_bwd_finish_kernel, dim3(blocks), dim3(256), 0, st, a, grad_out, D,
+                       pl.ksplit * pl.qblocks, dscale_dbias);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}

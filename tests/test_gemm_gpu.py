@@ -1,0 +1,114 @@
+"""GPU parity: msn_sgemm / msn_colsum through the C-ABI vs fp64 torch on the same inputs.
+Tolerance: fp32 accumulation over K -> |err| <= 2e-6 * sum|a||b| (checked as rtol 1e-4 on a
+scale-normalised result); the north-star bound is 1e-3 relative."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(a, b, op_a, op_b):
+    A = a.double() if op_a == 0 else a.double().T
+    B = b.double() if op_b == 0 else b.double().T
+    return A @ B
+
+
+SHAPES = [(128, 128, 32), (256, 384, 192), (130, 70, 33), (1, 1, 1), (65, 32, 8), (300, 64, 64),
+          (37, 1536, 384), (512, 32, 100), (33, 130, 257)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("op_a,op_b", [(0, 1), (0, 0), (1, 0), (1, 1)])
+def test_sgemm_layouts(M, N, K, op_a, op_b):
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn((M, K) if op_a == 0 else (K, M), generator=g).cuda()
+    b = torch.randn((K, N) if op_b == 0 else (N, K), generator=g).cuda()
+    c = ops.sgemm(a, b, op_a, op_b)
+    ref = _ref(a, b, op_a, op_b)
+    torch.testing.assert_close(c.double(), ref, rtol=1e-4, atol=1e-4 * K ** 0.5)
+
+
+def test_sgemm_asymmetric_identity():
+    """A = I with an asymmetric B catches a transposed C write (cdna guide section 3)."""
+    from multimodal_supernovae_amd import ops
+    n = 96
+    eye = torch.eye(n).cuda()
+    b = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) / 7.0).cuda()
+    torch.testing.assert_close(ops.sgemm(eye, b, 0, 0), b)
+    torch.testing.assert_close(ops.sgemm(eye, b, 0, 1), b.T.contiguous())
+    torch.testing.assert_close(ops.sgemm(b, eye, 1, 0), b.T.contiguous())
+
+
+def test_sgemm_strided_operands_and_output():
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(3)
+    big_a = torch.randn(70, 3 * 48, generator=g).cuda()
+    a = big_a[:, 48:96]                       # row stride 144, K = 48
+    w = torch.randn(40, 48, generator=g).cuda()
+    out_big = torch.zeros(70, 100).cuda()
+    out = out_big[:, 20:60]
+    ops.sgemm(a, w, 0, 1, out=out)
+    torch.testing.assert_close(out.double(), a.double() @ w.double().T, rtol=1e-4, atol=1e-4)
+    assert float(out_big[:, :20].abs().sum()) == 0.0 and float(out_big[:, 60:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 96, 64), (64, 33, 40)])
+def test_sgemm_epilogues(M, N, K):
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(M, K, generator=g).cuda()
+    w = torch.randn(N, K, generator=g).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    pre = x.double() @ w.double().T + bias.double()
+    tol = dict(rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(ops.sgemm(x, w, bias=bias).double(), pre, **tol)
+    torch.testing.assert_close(ops.sgemm(x, w, bias=bias, epilogue=ops.EPI_RELU).double(), pre.relu(), **tol)
+    aux = torch.empty(M, N).cuda()
+    y = ops.sgemm(x, w, bias=bias, epilogue=ops.EPI_GELU, aux=aux)
+    torch.testing.assert_close(aux.double(), pre, **tol)
+    torch.testing.assert_close(y.double(), torch.nn.functional.gelu(pre), **tol)
+    res = torch.randn(M, N, generator=g).cuda()
+    torch.testing.assert_close(ops.sgemm(x, w, bias=bias, epilogue=ops.EPI_ADD, aux=res).double(),
+                               pre + res.double(), **tol)
+    # backward-side epilogues: dpre = (dy @ W2) * act'(saved)
+    dy = torch.randn(M, K, generator=g).cuda()          # (M, K) @ (K -> N): use w2 of shape (K, N)
+    w2 = torch.randn(K, N, generator=g).cuda()
+    dh = dy.double() @ w2.double()
+    h = pre.relu().float()
+    torch.testing.assert_close(ops.sgemm(dy, w2, 0, 0, epilogue=ops.EPI_RELU_BWD, aux=h).double(),
+                               dh * (h.double() > 0), **tol)
+    p = pre.clone().requires_grad_()
+    torch.nn.functional.gelu(p).backward(dh)
+    torch.testing.assert_close(ops.sgemm(dy, w2, 0, 0, epilogue=ops.EPI_GELU_BWD, aux=pre.float()).double(),
+                               p.grad, **tol)
+
+
+def test_sgemm_splitk_wgrad_large_reduction():
+    """dW = dY^T X with a long reduction (opA = T) takes the split-K path."""
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(5)
+    rows, n_out, k_in = 20000, 96, 64
+    dy = torch.randn(rows, n_out, generator=g).cuda()
+    x = torch.randn(rows, k_in, generator=g).cuda()
+    dw = ops.sgemm(dy, x, 1, 0)
+    torch.testing.assert_close(dw.double(), dy.double().T @ x.double(), rtol=1e-4, atol=2e-2)
+    again = ops.sgemm(dy, x, 1, 0)
+    assert torch.equal(dw, again), "split-K reduction must be deterministic"
+
+
+def test_sgemm_rejects_bad_arguments():
+    from multimodal_supernovae_amd import ops, _lib
+    a = torch.randn(8, 4).cuda()
+    b = torch.randn(8, 5).cuda()
+    with pytest.raises(_lib.MsnHipError):
+        ops.sgemm(a, b, 0, 1)
+    with pytest.raises(_lib.MsnHipError):
+        ops.sgemm(a.cpu(), b.cpu(), 0, 1)
+
+
+@pytest.mark.parametrize("M,N", [(1, 1), (1000, 64), (257, 130), (70000, 32)])
+def test_colsum(M, N):
+    from multimodal_supernovae_amd import ops
+    x = torch.randn(M, N, generator=torch.Generator().manual_seed(M + N)).cuda()
+    torch.testing.assert_close(ops.colsum(x).double(), x.double().sum(0), rtol=1e-4, atol=1e-3)
