@@ -105,6 +105,73 @@ int msn_infonce_bwd(const float* E1_loc, int64_t ld1, int b1, const float* E2_lo
                     float* dE1_loc, int64_t ldd1, float* dE2_loc, int64_t ldd2, float* dscale_dbias,
                     void* ws, size_t ws_bytes, msn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over the last dimension (rows x cols, cols % 4 == 0, cols <= 1024), eps inside the
+ * square root -- nn.LayerNorm as used at src/transformer_utils.py:97-98,111,114 (post-norm; the
+ * residual sum is produced by the preceding GEMM's MSN_EPI_ADD epilogue).
+ * fwd writes y and the per-row mean / rstd; bwd consumes them and returns dx, dgamma, dbeta.
+ */
+int msn_layernorm_fwd(const float* x, int64_t ldx, int64_t rows, int cols, const float* gamma,
+                      const float* beta, float eps, float* y, int64_t ldy, float* mean, float* rstd,
+                      msn_stream_t stream);
+size_t msn_layernorm_bwd_workspace_bytes(int64_t rows, int cols);
+int msn_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t rows, int cols,
+                      const float* mean, const float* rstd, const float* gamma, float* dx, int64_t lddx,
+                      float* dgamma, float* dbeta, void* ws, size_t ws_bytes, msn_stream_t stream);
+
+/* y = x / ||x||_2 per row, NO epsilon (src/models_multimodal.py:279,286,293,304); inv_norm[r] = 1/||x_r||.
+ * bwd: dx = inv_norm * (dy - y <y, dy>). */
+int msn_l2norm_fwd(const float* x, int64_t ldx, int64_t rows, int cols, float* y, int64_t ldy,
+                   float* inv_norm, msn_stream_t stream);
+int msn_l2norm_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, int64_t rows, int cols,
+                   const float* inv_norm, float* dx, int64_t lddx, msn_stream_t stream);
+
+/* Token embedding of an irregular time series -- src/transformer_utils.py:166-176 and :214-231:
+ *   out[b,t,c] = x[b,t] * w[c] + bw[c] + (c even ? sin : cos)(t[b,t] * omega[c/2]) + band[t / (T/nband)][c]
+ * omega[k] = exp(-2k ln(norm) / e) is passed in (e/2 floats); band (nband x e) only when nband > 1.
+ * bwd returns dw, dbw (e each) and dband (nband x e; NULL when nband == 1); x, t get no gradient. */
+int msn_time_embed_fwd(const float* x, const float* t, int64_t B, int T, int e, const float* w,
+                       const float* bw, const float* omega, const float* band, int nband, float* out,
+                       msn_stream_t stream);
+size_t msn_time_embed_bwd_workspace_bytes(int64_t B, int e, int nband);
+int msn_time_embed_bwd(const float* dy, const float* x, int64_t B, int T, int e, int nband, float* dw,
+                       float* dbw, float* dband, void* ws, size_t ws_bytes, msn_stream_t stream);
+
+/* Masked pooling over tokens -- src/transformer_utils.py:234-239.  mask: (B, T) bytes (torch.bool).
+ * mode MSN_POOL_MEAN: sum_t x*mask / sum_t mask (writes count[b]; an all-false row gives NaN as
+ * the reference does); MSN_POOL_MAX: max_t (x*mask) over ALL t (writes argmax (B, e) int32). */
+#define MSN_POOL_MEAN 0
+#define MSN_POOL_MAX 1
+int msn_masked_pool_fwd(const float* x, const uint8_t* mask, int64_t B, int T, int e, int mode, float* out,
+                        int* argmax, float* count, msn_stream_t stream);
+int msn_masked_pool_bwd(const float* dout, const uint8_t* mask, int64_t B, int T, int e, int mode,
+                        const int* argmax, const float* count, float* dx, msn_stream_t stream);
+/* y[r,:] = x[r,:] * mask[r]  (the `x * mask[:, :, None]` of :235; its own backward) */
+int msn_mask_tokens(const float* x, const uint8_t* mask, int64_t rows, int e, float* y, msn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused multi-head attention, exact fp32, no T x T tensor in memory -- SelfAttention.forward,
+ * src/transformer_utils.py:36-89 (scale = 1/sqrt(emb); key-padding scores REPLACED by -1e7), also
+ * the 1-query nn.MultiheadAttention pooling (:240-246) and the build-defined ViT blocks.
+ * q: (B, Tq, H*hd) rows `ldq` apart, batches `q_bstride` apart (0 = one query shared by the batch);
+ * k, v: (B, Tk, H*hd); head h lives in columns h*hd .. h*hd+hd-1 (so a packed q|k|v buffer works by
+ * pointer offset + ld = 3*H*hd).  key_mask: (B, Tk) bytes or NULL.  hd <= 128.
+ * lse: (B, H, Tq, 2) = (row max, log of the exp-sum), kept apart because a fully padded sample has
+ * max = -1e7 where fp32 cannot hold the sum.  bwd recomputes the probabilities from lse; `delta` is
+ * (B, H, Tq) scratch.
+ */
+int msn_attention_fwd(const float* q, int64_t ldq, int64_t q_bstride, const float* k, int64_t ldk,
+                      int64_t k_bstride, const float* v, int64_t ldv, int64_t v_bstride,
+                      const uint8_t* key_mask, int B, int H, int Tq, int Tk, int head_dim, float scale,
+                      float* out, int64_t ldo, int64_t o_bstride, float* lse, msn_stream_t stream);
+int msn_attention_bwd(const float* q, int64_t ldq, int64_t q_bstride, const float* k, int64_t ldk,
+                      int64_t k_bstride, const float* v, int64_t ldv, int64_t v_bstride,
+                      const uint8_t* key_mask, int B, int H, int Tq, int Tk, int head_dim, float scale,
+                      const float* out, int64_t ldo, int64_t o_bstride, const float* lse,
+                      const float* dout, int64_t ldd, int64_t d_bstride, float* delta, float* dq,
+                      int64_t lddq, int64_t dq_bstride, float* dk, int64_t lddk, int64_t dk_bstride,
+                      float* dv, int64_t lddv, int64_t dv_bstride, msn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,26 @@ SIGNATURES = {
                           c_int, c_ptr, c_i64, c_ptr, c_size, c_ptr]),
     "msn_colsum_workspace_bytes": (c_size, [c_i64, c_i64]),
     "msn_colsum": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_size, c_ptr]),
+    "msn_layernorm_fwd": (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_f32, c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
+    "msn_layernorm_bwd_workspace_bytes": (c_size, [c_i64, c_int]),
+    "msn_layernorm_bwd": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
+                                  c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "msn_l2norm_fwd": (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_i64, c_ptr, c_ptr]),
+    "msn_l2norm_bwd": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr]),
+    "msn_time_embed_fwd": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr,
+                                   c_ptr]),
+    "msn_time_embed_bwd_workspace_bytes": (c_size, [c_i64, c_int, c_int]),
+    "msn_time_embed_bwd": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_size,
+                                   c_ptr]),
+    "msn_masked_pool_fwd": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "msn_masked_pool_bwd": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "msn_mask_tokens": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
+    "msn_attention_fwd": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr,
+                                  c_int, c_int, c_int, c_int, c_int, c_f32, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    "msn_attention_bwd": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr,
+                                  c_int, c_int, c_int, c_int, c_int, c_f32, c_ptr, c_i64, c_i64, c_ptr,
+                                  c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64,
+                                  c_ptr, c_i64, c_i64, c_ptr]),
     "msn_infonce_workspace_bytes": (c_size, [c_int] * 5),
     "msn_infonce_fwd": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_i64, c_int,
                                 c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),

@@ -1,0 +1,508 @@
+// Row-wise HBM-bound kernels: LayerNorm fwd/bwd, L2-normalise fwd/bwd, time/band embedding
+// fwd/bwd, masked pooling fwd/bwd.  All are streaming kernels: 16-byte loads, a row is owned by a
+// group of LPR lanes of one wave (LPR = 4 / 16 / 64 by row length) so the row statistics are
+// wave-shuffle reductions; column reductions (d gamma, d beta, d embedding weights) are
+// block partials in caller scratch + a fixed-order final pass (deterministic, no atomics).
+#include <algorithm>
+#include <math.h>
+
+#include "msn_common.h"
+
+namespace msn {
+
+constexpr int NCH = 4;  // 16-byte chunks per lane -> rows of up to LPR * 16 floats
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+struct RowGeom {
+    int64_t rows;
+    int cols;      // multiple of 4
+    int64_t ld;    // multiple of 4
+};
+
+template <int LPR>
+__device__ __forceinline__ void load_row(float4 (&v)[NCH], const float* __restrict__ p, int cols, int lr) {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c = 4 * (lr + k * LPR);
+        v[k] = c < cols ? *reinterpret_cast<const float4*>(p + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <int LPR>
+__device__ __forceinline__ void store_row(const float4 (&v)[NCH], float* __restrict__ p, int cols, int lr) {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c = 4 * (lr + k * LPR);
+        if (c < cols) *reinterpret_cast<float4*>(p + c) = v[k];
+    }
+}
+__device__ __forceinline__ float sum4(float4 a) { return (a.x + a.y) + (a.z + a.w); }
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+// ------------------------------------------------------------------------------------- LayerNorm
+template <int LPR>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t ldx, RowGeom g,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float eps, float* __restrict__ y, int64_t ldy,
+                                                     float* __restrict__ mean, float* __restrict__ rstd) {
+    constexpr int RG = 256 / LPR;
+    const int lr = threadIdx.x % LPR, rg = threadIdx.x / LPR;
+    float4 gm[NCH], bt[NCH];
+    load_row<LPR>(gm, gamma, g.cols, lr);
+    load_row<LPR>(bt, beta, g.cols, lr);
+    const float inv_n = 1.f / (float)g.cols;
+    for (int64_t r = (int64_t)blockIdx.x * RG + rg; r < g.rows; r += (int64_t)gridDim.x * RG) {
+        float4 v[NCH];
+        load_row<LPR>(v, x + r * ldx, g.cols, lr);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) s += sum4(v[k]);
+        const float mu = group_sum<LPR>(s) * inv_n;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            if (4 * (lr + k * LPR) < g.cols) {
+                const float a = v[k].x - mu, b = v[k].y - mu, c = v[k].z - mu, d = v[k].w - mu;
+                q += a * a + b * b + c * c + d * d;
+            }
+        }
+        const float rs = rsqrtf(group_sum<LPR>(q) * inv_n + eps);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            v[k].x = (v[k].x - mu) * rs * gm[k].x + bt[k].x;
+            v[k].y = (v[k].y - mu) * rs * gm[k].y + bt[k].y;
+            v[k].z = (v[k].z - mu) * rs * gm[k].z + bt[k].z;
+            v[k].w = (v[k].w - mu) * rs * gm[k].w + bt[k].w;
+        }
+        store_row<LPR>(v, y + r * ldy, g.cols, lr);
+        if (lr == 0) {
+            mean[r] = mu;
+            rstd[r] = rs;
+        }
+    }
+}
+
+// dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  block partials of dgamma / dbeta
+template <int LPR>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
+                                                     const float* __restrict__ x, int64_t ldx, RowGeom g,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, float* __restrict__ dx,
+                                                     int64_t lddx, float* __restrict__ part) {
+    constexpr int RG = 256 / LPR;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [RG][2][cols]
+    const int lr = threadIdx.x % LPR, rg = threadIdx.x / LPR;
+    float4 gm[NCH], dg[NCH], db[NCH];
+    load_row<LPR>(gm, gamma, g.cols, lr);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) dg[k] = db[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float inv_n = 1.f / (float)g.cols;
+    for (int64_t r = (int64_t)blockIdx.x * RG + rg; r < g.rows; r += (int64_t)gridDim.x * RG) {
+        float4 v[NCH], d[NCH];
+        load_row<LPR>(v, x + r * ldx, g.cols, lr);
+        load_row<LPR>(d, dy + r * lddy, g.cols, lr);
+        const float mu = mean[r], rs = rstd[r];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const bool on = 4 * (lr + k * LPR) < g.cols;
+            v[k].x = on ? (v[k].x - mu) * rs : 0.f;  // xhat
+            v[k].y = on ? (v[k].y - mu) * rs : 0.f;
+            v[k].z = on ? (v[k].z - mu) * rs : 0.f;
+            v[k].w = on ? (v[k].w - mu) * rs : 0.f;
+            dg[k].x += d[k].x * v[k].x; dg[k].y += d[k].y * v[k].y; dg[k].z += d[k].z * v[k].z; dg[k].w += d[k].w * v[k].w;
+            db[k].x += d[k].x; db[k].y += d[k].y; db[k].z += d[k].z; db[k].w += d[k].w;
+            d[k].x *= gm[k].x; d[k].y *= gm[k].y; d[k].z *= gm[k].z; d[k].w *= gm[k].w;  // g * dy
+            s1 += sum4(d[k]);
+            s2 += dot4(d[k], v[k]);
+        }
+        const float m1 = group_sum<LPR>(s1) * inv_n, m2 = group_sum<LPR>(s2) * inv_n;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            d[k].x = rs * (d[k].x - m1 - v[k].x * m2);
+            d[k].y = rs * (d[k].y - m1 - v[k].y * m2);
+            d[k].z = rs * (d[k].z - m1 - v[k].z * m2);
+            d[k].w = rs * (d[k].w - m1 - v[k].w * m2);
+        }
+        store_row<LPR>(d, dx + r * lddx, g.cols, lr);
+    }
+    // reduce the RG row-groups of this block, then publish [2][cols] for the final pass
+    float* mine = lds + (int64_t)rg * 2 * g.cols;
+    store_row<LPR>(dg, mine, g.cols, lr);
+    store_row<LPR>(db, mine + g.cols, g.cols, lr);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * g.cols; i += 256) {
+        float s = 0.f;
+        for (int k = 0; k < RG; ++k) s += lds[(int64_t)k * 2 * g.cols + i];
+        part[(int64_t)blockIdx.x * 2 * g.cols + i] = s;
+    }
+}
+
+// out[i] = sum_b part[b][i], i < n
+__global__ void sum_slabs_kernel(const float* __restrict__ part, int nslabs, int n, float* __restrict__ out0,
+                                 float* __restrict__ out1, int split) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < nslabs; ++b) s += part[(int64_t)b * n + i];
+    if (i < split) out0[i] = s;
+    else out1[i - split] = s;
+}
+
+// ------------------------------------------------------------------------------------ L2 normalise
+template <int LPR>
+__global__ __launch_bounds__(256) void l2n_fwd_kernel(const float* __restrict__ x, int64_t ldx, RowGeom g,
+                                                      float* __restrict__ y, int64_t ldy, float* __restrict__ inv) {
+    constexpr int RG = 256 / LPR;
+    const int lr = threadIdx.x % LPR, rg = threadIdx.x / LPR;
+    for (int64_t r = (int64_t)blockIdx.x * RG + rg; r < g.rows; r += (int64_t)gridDim.x * RG) {
+        float4 v[NCH];
+        load_row<LPR>(v, x + r * ldx, g.cols, lr);
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) q += dot4(v[k], v[k]);
+        const float nrm = sqrtf(group_sum<LPR>(q));
+        const float iv = 1.f / nrm;  // no epsilon: ref models_multimodal.py:279
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) { v[k].x /= nrm; v[k].y /= nrm; v[k].z /= nrm; v[k].w /= nrm; }
+        store_row<LPR>(v, y + r * ldy, g.cols, lr);
+        if (lr == 0) inv[r] = iv;
+    }
+}
+// dx = inv * (dy - y * <y, dy>)
+template <int LPR>
+__global__ __launch_bounds__(256) void l2n_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
+                                                      const float* __restrict__ y, int64_t ldy, RowGeom g,
+                                                      const float* __restrict__ inv, float* __restrict__ dx,
+                                                      int64_t lddx) {
+    constexpr int RG = 256 / LPR;
+    const int lr = threadIdx.x % LPR, rg = threadIdx.x / LPR;
+    for (int64_t r = (int64_t)blockIdx.x * RG + rg; r < g.rows; r += (int64_t)gridDim.x * RG) {
+        float4 v[NCH], d[NCH];
+        load_row<LPR>(v, y + r * ldy, g.cols, lr);
+        load_row<LPR>(d, dy + r * lddy, g.cols, lr);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) s += dot4(v[k], d[k]);
+        s = group_sum<LPR>(s);
+        const float iv = inv[r];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            d[k].x = iv * (d[k].x - v[k].x * s);
+            d[k].y = iv * (d[k].y - v[k].y * s);
+            d[k].z = iv * (d[k].z - v[k].z * s);
+            d[k].w = iv * (d[k].w - v[k].w * s);
+        }
+        store_row<LPR>(d, dx + r * lddx, g.cols, lr);
+    }
+}
+
+// -------------------------------------------------------------------------- time / band embedding
+// out[b,t,c] = x[b,t] * w[c] + bw[c] + (c even ? sin : cos)(t[b,t] * omega[c/2]) + band[band(t)][c]
+// ref transformer_utils.py:166-176 (interleaved sin/cos) and :214-231.
+__global__ void time_embed_fwd_kernel(const float* __restrict__ x, const float* __restrict__ t, int64_t rows, int T,
+                                      int e, const float* __restrict__ w, const float* __restrict__ bw,
+                                      const float* __restrict__ omega, const float* __restrict__ band, int nband,
+                                      float* __restrict__ out) {
+    const int64_t total = rows * e;
+    const int per_band = nband > 1 ? T / nband : T;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / e;
+        const int c = (int)(i % e);
+        const float ang = t[r] * omega[c >> 1];
+        float v = x[r] * w[c] + bw[c];
+        v += (c & 1) ? cosf(ang) : sinf(ang);
+        if (nband > 1) v += band[(int64_t)(((int)(r % T)) / per_band) * e + c];
+        out[i] = v;
+    }
+}
+
+// One block per sample b: seg[b][k][c] = sum_{t in band k} dy[b,t,c];  sdx[b][c] = sum_t dy[b,t,c] * x[b,t]
+__global__ __launch_bounds__(256) void time_embed_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             int T, int e, int nband, float* __restrict__ seg,
+                                                             float* __restrict__ sdx) {
+    extern __shared__ float lds[];  // [groups][e]
+    const int b = blockIdx.x;
+    const int cpt = e < 256 ? e : 256;           // threads along columns
+    const int groups = 256 / cpt;                // row groups
+    const int c0 = threadIdx.x % cpt, gidx = threadIdx.x / cpt;
+    const int per_band = T / nband;
+    const float* dyb = dy + (int64_t)b * T * e;
+    const float* xb = x + (int64_t)b * T;
+    for (int cb = 0; cb < e; cb += cpt) {
+        const int c = cb + c0;
+        float sx = 0.f;
+        for (int k = 0; k < nband; ++k) {
+            float s = 0.f;
+            if (c < e && gidx < groups)
+                for (int tt = k * per_band + gidx; tt < (k + 1) * per_band; tt += groups) {
+                    const float d = dyb[(int64_t)tt * e + c];
+                    s += d;
+                    sx = fmaf(d, xb[tt], sx);
+                }
+            __syncthreads();
+            if (gidx < groups) lds[gidx * cpt + c0] = s;
+            __syncthreads();
+            if (gidx == 0 && c < e) {
+                float tot = 0.f;
+                for (int q = 0; q < groups; ++q) tot += lds[q * cpt + c0];
+                seg[((int64_t)b * nband + k) * e + c] = tot;
+            }
+        }
+        __syncthreads();
+        if (gidx < groups) lds[gidx * cpt + c0] = sx;
+        __syncthreads();
+        if (gidx == 0 && c < e) {
+            float tot = 0.f;
+            for (int q = 0; q < groups; ++q) tot += lds[q * cpt + c0];
+            sdx[(int64_t)b * e + c] = tot;
+        }
+    }
+}
+// dw[c] = sum_b sdx[b][c]; dband[k][c] = sum_b seg[b][k][c]; dbw[c] = sum_k dband[k][c]
+__global__ void time_embed_bwd_finish_kernel(const float* __restrict__ seg, const float* __restrict__ sdx, int B,
+                                             int e, int nband, float* __restrict__ dw, float* __restrict__ dbw,
+                                             float* __restrict__ dband) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= e) return;
+    float sw = 0.f;
+    for (int b = 0; b < B; ++b) sw += sdx[(int64_t)b * e + c];
+    dw[c] = sw;
+    float sb = 0.f;
+    for (int k = 0; k < nband; ++k) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += seg[((int64_t)b * nband + k) * e + c];
+        if (dband) dband[(int64_t)k * e + c] = s;
+        sb += s;
+    }
+    dbw[c] = sb;
+}
+
+// ---------------------------------------------------------------------------------- masked pooling
+// ref transformer_utils.py:234-239: x = x * mask; mean: sum_t / sum_t mask (0/0 -> NaN for an empty
+// row, as the reference); max: max over ALL t of the zeroed tokens (padded zeros take part).
+constexpr int POOL_MEAN = 0, POOL_MAX = 1;
+__global__ void pool_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask, int T, int e, int mode,
+                                float* __restrict__ out, int* __restrict__ arg, float* __restrict__ count) {
+    const int b = blockIdx.x;
+    const float* xb = x + (int64_t)b * T * e;
+    const uint8_t* mb = mask + (int64_t)b * T;
+    for (int c = threadIdx.x; c < e; c += blockDim.x) {
+        if (mode == POOL_MEAN) {
+            float s = 0.f, cnt = 0.f;
+            for (int t = 0; t < T; ++t) {
+                const float m = mb[t] ? 1.f : 0.f;
+                s += xb[(int64_t)t * e + c] * m;
+                cnt += m;
+            }
+            out[(int64_t)b * e + c] = s / cnt;
+            if (c == 0) count[b] = cnt;
+        } else {
+            float best = -INFINITY;
+            int bi = 0;
+            for (int t = 0; t < T; ++t) {
+                const float v = xb[(int64_t)t * e + c] * (mb[t] ? 1.f : 0.f);
+                if (v > best) { best = v; bi = t; }
+            }
+            out[(int64_t)b * e + c] = best;
+            arg[(int64_t)b * e + c] = bi;
+        }
+    }
+}
+__global__ void pool_bwd_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ mask, int64_t B, int T,
+                                int e, int mode, const int* __restrict__ arg, const float* __restrict__ count,
+                                float* __restrict__ dx) {
+    const int64_t total = B * T * e;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % e);
+        const int64_t bt = i / e;
+        const int t = (int)(bt % T);
+        const int64_t b = bt / T;
+        const float m = mask[bt] ? 1.f : 0.f;
+        float v;
+        if (mode == POOL_MEAN) {
+            v = dout[b * e + c] * m / count[b];
+        } else {
+            v = (arg[b * e + c] == t) ? dout[b * e + c] * m : 0.f;
+        }
+        dx[i] = v;
+    }
+}
+// y[b,t,:] = x[b,t,:] * mask[b,t]   (agg = "pretraining" tokens, and the zeroing before attn pooling)
+__global__ void mask_tokens_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask, int64_t rows, int e,
+                                   float* __restrict__ y) {
+    const int64_t total = rows * e;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = mask[i / e] ? x[i] : 0.f * x[i];
+}
+
+static int pick_lpr(int cols) {
+    const int chunks = cols / 4;
+    if (chunks <= 4 * NCH) return 4;
+    if (chunks <= 16 * NCH) return 16;
+    return 64;
+}
+static int check_rows(const char* who, int64_t rows, int cols, std::initializer_list<int64_t> lds,
+                      std::initializer_list<const void*> ptrs) {
+    MSN_REQUIRE(rows > 0 && cols > 0, "%s: empty input", who);
+    MSN_REQUIRE(cols % 4 == 0 && cols <= 64 * NCH * 4, "%s: row length %d must be a multiple of 4 and <= %d", who, cols,
+                64 * NCH * 4);
+    for (int64_t ld : lds) MSN_REQUIRE(ld >= cols && ld % 4 == 0, "%s: leading dimension %lld", who, (long long)ld);
+    for (const void* p : ptrs)
+        MSN_REQUIRE(p && (reinterpret_cast<uintptr_t>(p) & 15) == 0, "%s: null or unaligned pointer", who);
+    return MSN_OK;
+}
+
+#define MSN_LPR_DISPATCH(KERNEL, lpr, grid, lds, st, ...)                                         \
+    if (lpr == 4) hipLaunchKernelGGL((KERNEL<4>), grid, dim3(256), lds, st, __VA_ARGS__);         \
+    else if (lpr == 16) hipLaunchKernelGGL((KERNEL<16>), grid, dim3(256), lds, st, __VA_ARGS__);  \
+    else hipLaunchKernelGGL((KERNEL<64>), grid, dim3(256), lds, st, __VA_ARGS__);
+
+static int ln_grid(int64_t rows, int lpr) {
+    return (int)std::min<int64_t>(cdiv(rows, 256 / lpr), 2048);
+}
+static int ln_bwd_grid(int64_t rows, int lpr) {
+    return (int)std::min<int64_t>(cdiv(rows, 4 * (256 / lpr)), 512);
+}
+
+}  // namespace msn
+
+using namespace msn;
+
+extern "C" int msn_layernorm_fwd(const float* x, int64_t ldx, int64_t rows, int cols, const float* gamma,
+                                 const float* beta, float eps, float* y, int64_t ldy, float* mean, float* rstd,
+                                 msn_stream_t stream) {
+    if (int rc = check_rows("msn_layernorm_fwd", rows, cols, {ldx, ldy}, {x, y, gamma, beta})) return rc;
+    MSN_REQUIRE(mean && rstd, "msn_layernorm_fwd: null statistics pointer");
+    const int lpr = pick_lpr(cols);
+    const RowGeom g{rows, cols, ldx};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MSN_LPR_DISPATCH(ln_fwd_kernel, lpr, dim3(ln_grid(rows, lpr)), 0, st, x, ldx, g, gamma, beta, eps, y, ldy, mean, rstd)
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" size_t msn_layernorm_bwd_workspace_bytes(int64_t rows, int cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    return sizeof(float) * 2 * (size_t)cols * (size_t)ln_bwd_grid(rows, pick_lpr(cols));
+}
+
+extern "C" int msn_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t rows, int cols,
+                                 const float* mean, const float* rstd, const float* gamma, float* dx, int64_t lddx,
+                                 float* dgamma, float* dbeta, void* ws, size_t ws_bytes, msn_stream_t stream) {
+    if (int rc = check_rows("msn_layernorm_bwd", rows, cols, {lddy, ldx, lddx}, {dy, x, dx, gamma})) return rc;
+    MSN_REQUIRE(mean && rstd && dgamma && dbeta, "msn_layernorm_bwd: null pointer");
+    const int lpr = pick_lpr(cols);
+    const int grid = ln_bwd_grid(rows, lpr);
+    MSN_REQUIRE(ws && ws_bytes >= sizeof(float) * 2 * (size_t)cols * grid, "msn_layernorm_bwd: workspace too small");
+    const RowGeom g{rows, cols, ldx};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(ws);
+    const size_t lds = sizeof(float) * 2 * (size_t)cols * (256 / lpr);
+    MSN_LPR_DISPATCH(ln_bwd_kernel, lpr, dim3(grid), lds, st, dy, lddy, x, ldx, g, mean, rstd, gamma, dx, lddx, part)
+    MSN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)cdiv(2 * cols, 128)), dim3(128), 0, st, part, grid, 2 * cols,
+                       dgamma, dbeta, cols);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" int msn_l2norm_fwd(const float* x, int64_t ldx, int64_t rows, int cols, float* y, int64_t ldy,
+                              float* inv_norm, msn_stream_t stream) {
+    if (int rc = check_rows("msn_l2norm_fwd", rows, cols, {ldx, ldy}, {x, y})) return rc;
+    MSN_REQUIRE(inv_norm, "msn_l2norm_fwd: null inv_norm");
+    const int lpr = pick_lpr(cols);
+    const RowGeom g{rows, cols, ldx};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MSN_LPR_DISPATCH(l2n_fwd_kernel, lpr, dim3(ln_grid(rows, lpr)), 0, st, x, ldx, g, y, ldy, inv_norm)
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" int msn_l2norm_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, int64_t rows, int cols,
+                              const float* inv_norm, float* dx, int64_t lddx, msn_stream_t stream) {
+    if (int rc = check_rows("msn_l2norm_bwd", rows, cols, {lddy, ldy, lddx}, {dy, y, dx})) return rc;
+    MSN_REQUIRE(inv_norm, "msn_l2norm_bwd: null inv_norm");
+    const int lpr = pick_lpr(cols);
+    const RowGeom g{rows, cols, ldy};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MSN_LPR_DISPATCH(l2n_bwd_kernel, lpr, dim3(ln_grid(rows, lpr)), 0, st, dy, lddy, y, ldy, g, inv_norm, dx, lddx)
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" int msn_time_embed_fwd(const float* x, const float* t, int64_t B, int T, int e, const float* w,
+                                  const float* bw, const float* omega, const float* band, int nband, float* out,
+                                  msn_stream_t stream) {
+    MSN_REQUIRE(B > 0 && T > 0 && e > 0 && e % 2 == 0, "msn_time_embed_fwd: bad sizes B=%lld T=%d e=%d", (long long)B, T, e);
+    MSN_REQUIRE(x && t && w && bw && omega && out, "msn_time_embed_fwd: null pointer");
+    MSN_REQUIRE(nband >= 1 && (nband == 1 || (band && T % nband == 0)),
+                "msn_time_embed_fwd: T=%d must be divisible by nband=%d", T, nband);
+    const int64_t total = B * T * e;
+    const int grid = (int)std::min<int64_t>(cdiv(total, 256), 4096);
+    hipLaunchKernelGGL(time_embed_fwd_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), x, t, B * T, T,
+                       e, w, bw, omega, band, nband, out);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" size_t msn_time_embed_bwd_workspace_bytes(int64_t B, int e, int nband) {
+    if (B <= 0 || e <= 0 || nband <= 0) return 0;
+    return sizeof(float) * (size_t)B * (size_t)e * (size_t)(nband + 1);
+}
+
+extern "C" int msn_time_embed_bwd(const float* dy, const float* x, int64_t B, int T, int e, int nband, float* dw,
+                                  float* dbw, float* dband, void* ws, size_t ws_bytes, msn_stream_t stream) {
+    MSN_REQUIRE(B > 0 && T > 0 && e > 0 && nband >= 1 && T % nband == 0, "msn_time_embed_bwd: bad sizes");
+    MSN_REQUIRE(dy && x && dw && dbw && (nband == 1 || dband), "msn_time_embed_bwd: null pointer");
+    MSN_REQUIRE(ws && ws_bytes >= msn_time_embed_bwd_workspace_bytes(B, e, nband), "msn_time_embed_bwd: workspace too small");
+    MSN_REQUIRE(B < (1ll << 31), "msn_time_embed_bwd: batch too large");
+    float* seg = static_cast<float*>(ws);
+    float* sdx = seg + (size_t)B * nband * e;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int cpt = std::min(e, 256);
+    const size_t lds = sizeof(float) * (256 / cpt) * cpt;
+    hipLaunchKernelGGL(time_embed_bwd_kernel, dim3((unsigned)B), dim3(256), lds, st, dy, x, T, e, nband, seg, sdx);
+    MSN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(time_embed_bwd_finish_kernel, dim3((unsigned)cdiv(e, 64)), dim3(64), 0, st, seg, sdx, (int)B, e,
+                       nband, dw, dbw, nband > 1 ? dband : nullptr);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" int msn_masked_pool_fwd(const float* x, const uint8_t* mask, int64_t B, int T, int e, int mode, float* out,
+                                   int* argmax, float* count, msn_stream_t stream) {
+    MSN_REQUIRE(B > 0 && T > 0 && e > 0 && B < (1ll << 31), "msn_masked_pool_fwd: bad sizes");
+    MSN_REQUIRE(x && mask && out && ((mode == POOL_MEAN && count) || (mode == POOL_MAX && argmax)),
+                "msn_masked_pool_fwd: bad arguments");
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3((unsigned)B), dim3(std::min(256, (e + 63) / 64 * 64)), 0,
+                       static_cast<hipStream_t>(stream), x, mask, T, e, mode, out, argmax, count);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" int msn_masked_pool_bwd(const float* dout, const uint8_t* mask, int64_t B, int T, int e, int mode,
+                                   const int* argmax, const float* count, float* dx, msn_stream_t stream) {
+    MSN_REQUIRE(B > 0 && T > 0 && e > 0, "msn_masked_pool_bwd: bad sizes");
+    MSN_REQUIRE(dout && mask && dx && ((mode == POOL_MEAN && count) || (mode == POOL_MAX && argmax)),
+                "msn_masked_pool_bwd: bad arguments");
+    const int64_t total = B * T * e;
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 4096)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), dout, mask, B, T, e, mode, argmax, count, dx);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" int msn_mask_tokens(const float* x, const uint8_t* mask, int64_t rows, int e, float* y, msn_stream_t stream) {
+    MSN_REQUIRE(rows > 0 && e > 0 && x && mask && y, "msn_mask_tokens: bad arguments");
+    const int64_t total = rows * e;
+    hipLaunchKernelGGL(mask_tokens_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 4096)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, mask, rows, e, y);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}

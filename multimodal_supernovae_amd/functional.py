@@ -1,0 +1,363 @@
+"""Differentiable building blocks: torch.autograd.Function nodes whose forward AND backward are
+sequences of libmsn_hip kernels (ops.py).  One node per transformer block / linear chain / pooling
+step, so residual adds, bias adds, activations and their derivatives ride in GEMM epilogues and no
+stock ATen arithmetic runs on the hot path.  Reference lines are cited per node."""
+import math
+
+import torch
+
+from . import ops
+from .ops import (EPI_ADD, EPI_GELU, EPI_GELU_BWD, EPI_NONE, EPI_RELU, EPI_RELU_BWD, OP_N, OP_T, colsum, sgemm)
+
+ACT_NONE, ACT_RELU, ACT_GELU = "none", "relu", "gelu"
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------- linear chains
+class _LinearChain(torch.autograd.Function):
+    """y = L_n(act_{n-1}(... act_1(L_1(x)))) -- nn.Linear stacks with ReLU / GELU between them
+    (MLP, ref models_multimodal.py:853-856; ConvMixer head :85-88; any single Linear).  The
+    activation derivative of layer i is applied in the epilogue of layer i+1's dgrad GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, acts, *wb):
+        n = len(acts)
+        shape = x.shape
+        h = _c(x).view(-1, shape[-1])
+        inputs, pres = [], []
+        for i in range(n):
+            w, b = wb[2 * i], wb[2 * i + 1]
+            inputs.append(h)
+            if acts[i] == ACT_GELU:
+                pre = torch.empty((h.shape[0], w.shape[0]), dtype=torch.float32, device=h.device)
+                h = sgemm(h, w, OP_N, OP_T, bias=b, epilogue=EPI_GELU, aux=pre)
+                pres.append(pre)
+            elif acts[i] == ACT_RELU:
+                h = sgemm(h, w, OP_N, OP_T, bias=b, epilogue=EPI_RELU)
+                pres.append(None)
+            else:
+                h = sgemm(h, w, OP_N, OP_T, bias=b)
+                pres.append(None)
+        if acts[-1] != ACT_NONE:
+            raise ValueError("the last layer of a linear chain carries no activation")
+        ctx.acts, ctx.shape = acts, shape
+        ctx.n_saved_in = n
+        ctx.save_for_backward(*inputs, *[p if p is not None else torch.empty(0) for p in pres], *wb)
+        return h.view(*shape[:-1], h.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        n = ctx.n_saved_in
+        saved = ctx.saved_tensors
+        inputs, pres, wb = saved[:n], saved[n:2 * n], saved[2 * n:]
+        d = _c(dy).view(-1, dy.shape[-1])
+        grads = [None] * (2 * n)
+        for i in range(n - 1, -1, -1):
+            w, b = wb[2 * i], wb[2 * i + 1]
+            grads[2 * i] = sgemm(d, inputs[i], OP_T, OP_N)            # dW = d^T . input
+            if b is not None:
+                grads[2 * i + 1] = colsum(d)
+            if i > 0:
+                act = ctx.acts[i - 1]
+                if act == ACT_RELU:      # inputs[i] = relu output of layer i-1
+                    d = sgemm(d, w, OP_N, OP_N, epilogue=EPI_RELU_BWD, aux=inputs[i])
+                elif act == ACT_GELU:
+                    d = sgemm(d, w, OP_N, OP_N, epilogue=EPI_GELU_BWD, aux=pres[i - 1])
+                else:
+                    d = sgemm(d, w, OP_N, OP_N)
+            elif ctx.needs_input_grad[0]:
+                d = sgemm(d, w, OP_N, OP_N)
+            else:
+                d = None
+        dx = d.view(ctx.shape) if d is not None else None
+        return (dx, None, *grads)
+
+
+def linear_chain(x, layers, acts):
+    """layers: [(weight, bias_or_None), ...]; acts: one of none/relu/gelu per layer (last = none)."""
+    flat = []
+    for w, b in layers:
+        flat += [w, b]
+    return _LinearChain.apply(x, tuple(acts), *flat)
+
+
+def linear(x, weight, bias=None):
+    return _LinearChain.apply(x, (ACT_NONE,), weight, bias)
+
+
+# --------------------------------------------------------------------- projection + L2 normalise
+class _ProjectNormalise(torch.autograd.Function):
+    """x -> Linear(n_out, enc_dim) -> x / ||x||  (ref models_multimodal.py:275-304, no epsilon)."""
+
+    @staticmethod
+    def forward(ctx, h, w, b):
+        h = _c(h)
+        z = sgemm(h, w, OP_N, OP_T, bias=b)
+        y, inv = ops.l2norm_fwd(z)
+        ctx.save_for_backward(h, w, y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, w, y, inv = ctx.saved_tensors
+        dz = ops.l2norm_bwd(_c(dy), y, inv)
+        return sgemm(dz, w, OP_N, OP_N), sgemm(dz, h, OP_T, OP_N), colsum(dz)
+
+
+def project_normalise(h, weight, bias):
+    return _ProjectNormalise.apply(h, weight, bias)
+
+
+class _L2Normalise(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y, inv = ops.l2norm_fwd(_c(x))
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        return ops.l2norm_bwd(_c(dy), y, inv)
+
+
+def l2_normalise(x):
+    return _L2Normalise.apply(x)
+
+
+# ------------------------------------------------------------------------------ self-attention
+def _attn_forward_raw(x2, B, T, wq, wk, wv, wu, bu, mask_u8, heads, scale, residual):
+    """x2: (B*T, e).  Returns z = unify(attn) (+ residual) and what backward needs."""
+    M, e = x2.shape
+    qkv = torch.empty((M, 3 * e), dtype=torch.float32, device=x2.device)
+    sgemm(x2, wq, OP_N, OP_T, out=qkv[:, :e])
+    sgemm(x2, wk, OP_N, OP_T, out=qkv[:, e:2 * e])
+    sgemm(x2, wv, OP_N, OP_T, out=qkv[:, 2 * e:])
+    q3 = qkv.view(B, T, 3 * e)
+    a, lse = ops.attention_fwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], mask_u8, heads, scale)
+    a2 = a.view(M, e)
+    if residual is not None:
+        z = sgemm(a2, wu, OP_N, OP_T, bias=bu, epilogue=EPI_ADD, aux=residual)
+    else:
+        z = sgemm(a2, wu, OP_N, OP_T, bias=bu)
+    return z, (qkv, a2, lse)
+
+
+def _attn_backward_raw(dz, x2, B, T, saved, wq, wk, wv, wu, mask_u8, heads, scale, add_to):
+    """dz: grad of unify output.  Returns dx (+ add_to fused) and the parameter grads."""
+    qkv, a2, lse = saved
+    M, e = x2.shape
+    dwu = sgemm(dz, a2, OP_T, OP_N)
+    dbu = colsum(dz)
+    da = sgemm(dz, wu, OP_N, OP_N)
+    dqkv = torch.empty_like(qkv)
+    q3, d3 = qkv.view(B, T, 3 * e), dqkv.view(B, T, 3 * e)
+    ops.attention_bwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], mask_u8, heads, scale, a2.view(B, T, e), lse,
+                      da.view(B, T, e), d3[..., :e], d3[..., e:2 * e], d3[..., 2 * e:])
+    dq, dk, dv = dqkv[:, :e], dqkv[:, e:2 * e], dqkv[:, 2 * e:]
+    dwq, dwk, dwv = sgemm(dq, x2, OP_T, OP_N), sgemm(dk, x2, OP_T, OP_N), sgemm(dv, x2, OP_T, OP_N)
+    if add_to is not None:
+        dx = sgemm(dq, wq, OP_N, OP_N, epilogue=EPI_ADD, aux=add_to)
+    else:
+        dx = sgemm(dq, wq, OP_N, OP_N)
+    sgemm(dk, wk, OP_N, OP_N, epilogue=EPI_ADD, aux=dx, out=dx)
+    sgemm(dv, wv, OP_N, OP_N, epilogue=EPI_ADD, aux=dx, out=dx)
+    return dx, dwq, dwk, dwv, dwu, dbu
+
+
+class _SelfAttention(torch.autograd.Function):
+    """ref transformer_utils.py:36-89 as one node (q/k/v GEMMs, fused attention, unifyheads)."""
+
+    @staticmethod
+    def forward(ctx, x, mask_u8, heads, wk, wq, wv, wu, bu):
+        B, T, e = x.shape
+        x2 = _c(x).view(B * T, e)
+        scale = 1.0 / math.sqrt(e)
+        z, saved = _attn_forward_raw(x2, B, T, wq, wk, wv, wu, bu, mask_u8, heads, scale, None)
+        ctx.dims = (B, T, e, heads, scale)
+        ctx.mask = mask_u8
+        ctx.save_for_backward(x2, wq, wk, wv, wu, *saved)
+        return z.view(B, T, e)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, e, heads, scale = ctx.dims
+        x2, wq, wk, wv, wu, qkv, a2, lse = ctx.saved_tensors
+        dz = _c(dy).view(B * T, e)
+        dx, dwq, dwk, dwv, dwu, dbu = _attn_backward_raw(dz, x2, B, T, (qkv, a2, lse), wq, wk, wv, wu, ctx.mask,
+                                                         heads, scale, None)
+        return dx.view(B, T, e), None, None, dwk, dwq, dwv, dwu, dbu
+
+
+def self_attention(x, mask, heads, tokeys, toqueries, tovalues, unify_w, unify_b):
+    return _SelfAttention.apply(x, ops._mask_u8(mask), heads, tokeys, toqueries, tovalues, unify_w, unify_b)
+
+
+# ---------------------------------------------------------------- post-norm transformer block
+class _PostNormBlock(torch.autograd.Function):
+    """ref transformer_utils.py:109-116: x = LN1(attn(x) + x); x = LN2(FF(x) + x), FF = Linear ->
+    ReLU -> Linear.  Residual adds ride in the unifyheads / ff.2 GEMM epilogues; in backward the
+    residual-branch gradients ride in the dgrad epilogues."""
+
+    @staticmethod
+    def forward(ctx, x, mask_u8, heads, wk, wq, wv, wu, bu, g1, b1, w1, c1, w2, c2, g2, b2):
+        B, T, e = x.shape
+        x2 = _c(x).view(B * T, e)
+        scale = 1.0 / math.sqrt(e)
+        z1, (qkv, a2, lse) = _attn_forward_raw(x2, B, T, wq, wk, wv, wu, bu, mask_u8, heads, scale, x2)
+        y1, m1, r1 = ops.layernorm_fwd(z1, g1, b1)
+        hdn = sgemm(y1, w1, OP_N, OP_T, bias=c1, epilogue=EPI_RELU)
+        z2 = sgemm(hdn, w2, OP_N, OP_T, bias=c2, epilogue=EPI_ADD, aux=y1)
+        y2, m2, r2 = ops.layernorm_fwd(z2, g2, b2)
+        ctx.dims = (B, T, e, heads, scale)
+        ctx.mask = mask_u8
+        ctx.save_for_backward(x2, wq, wk, wv, wu, g1, w1, w2, g2, qkv, a2, lse, z1, m1, r1, y1, hdn, z2, m2, r2)
+        return y2.view(B, T, e)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, e, heads, scale = ctx.dims
+        (x2, wq, wk, wv, wu, g1, w1, w2, g2, qkv, a2, lse, z1, m1, r1, y1, hdn, z2, m2, r2) = ctx.saved_tensors
+        dy2 = _c(dy).view(B * T, e)
+        dz2, dg2, db2 = ops.layernorm_bwd(dy2, z2, m2, r2, g2)
+        dw2 = sgemm(dz2, hdn, OP_T, OP_N)
+        dc2 = colsum(dz2)
+        dpre = sgemm(dz2, w2, OP_N, OP_N, epilogue=EPI_RELU_BWD, aux=hdn)
+        dw1 = sgemm(dpre, y1, OP_T, OP_N)
+        dc1 = colsum(dpre)
+        dy1 = sgemm(dpre, w1, OP_N, OP_N, epilogue=EPI_ADD, aux=dz2)       # + residual branch of LN2's input
+        dz1, dg1, db1 = ops.layernorm_bwd(dy1, z1, m1, r1, g1)
+        dx, dwq, dwk, dwv, dwu, dbu = _attn_backward_raw(dz1, x2, B, T, (qkv, a2, lse), wq, wk, wv, wu, ctx.mask,
+                                                         heads, scale, dz1)  # + residual branch of LN1's input
+        return (dx.view(B, T, e), None, None, dwk, dwq, dwv, dwu, dbu, dg1, db1, dw1, dc1, dw2, dc2, dg2, db2)
+
+
+def post_norm_block(x, mask_u8, heads, p):
+    """p: dict with tokeys, toqueries, tovalues, unify_w, unify_b, norm1_w, norm1_b, ff0_w, ff0_b,
+    ff2_w, ff2_b, norm2_w, norm2_b."""
+    return _PostNormBlock.apply(x, mask_u8, heads, p["tokeys"], p["toqueries"], p["tovalues"], p["unify_w"],
+                                p["unify_b"], p["norm1_w"], p["norm1_b"], p["ff0_w"], p["ff0_b"], p["ff2_w"],
+                                p["ff2_b"], p["norm2_w"], p["norm2_b"])
+
+
+# ------------------------------------------------------------------- time / band embedding
+class _TimeEmbed(torch.autograd.Function):
+    """ref transformer_utils.py:214-231: Linear(1, emb)(x) + sin/cos(t * omega) (+ band embedding)."""
+
+    @staticmethod
+    def forward(ctx, x, t, w, bw, band, omega):
+        x, t = _c(x), _c(t)
+        out = ops.time_embed_fwd(x, t, _c(w).view(-1), bw, omega, band)
+        ctx.nband = band.shape[0] if band is not None else 1
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dw, dbw, dband = ops.time_embed_bwd(_c(dy), x, ctx.nband)
+        return None, None, dw.view(-1, 1), dbw, dband, None
+
+
+def time_embed(x, t, mag_w, mag_b, band_w, omega):
+    return _TimeEmbed.apply(x, t, mag_w, mag_b, band_w, omega)
+
+
+# ----------------------------------------------------------------------------------- pooling
+class _MaskedPool(torch.autograd.Function):
+    """ref transformer_utils.py:234-239 (zero padded tokens, then mean over valid / max over all)."""
+
+    @staticmethod
+    def forward(ctx, x, mask_u8, mode):
+        out, arg, cnt = ops.masked_pool_fwd(_c(x), mask_u8, mode)
+        ctx.mode, ctx.T, ctx.mask = mode, x.shape[1], mask_u8
+        ctx.save_for_backward(arg if arg is not None else torch.empty(0), cnt if cnt is not None else torch.empty(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        arg, cnt = ctx.saved_tensors
+        dx = ops.masked_pool_bwd(_c(dout), ctx.mask, ctx.T, ctx.mode, arg if ctx.mode == ops.POOL_MAX else None,
+                                 cnt if ctx.mode == ops.POOL_MEAN else None)
+        return dx, None, None
+
+
+def masked_pool(x, mask_u8, mode):
+    return _MaskedPool.apply(x, mask_u8, ops.POOL_MEAN if mode == "mean" else ops.POOL_MAX)
+
+
+class _MaskTokens(torch.autograd.Function):
+    """x * mask[:, :, None] (ref transformer_utils.py:235)."""
+
+    @staticmethod
+    def forward(ctx, x, mask_u8):
+        ctx.mask = mask_u8
+        return ops.mask_tokens(_c(x), mask_u8)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.mask_tokens(_c(dy), ctx.mask), None
+
+
+def mask_tokens(x, mask_u8):
+    return _MaskTokens.apply(x, mask_u8)
+
+
+class _AttnPool(torch.autograd.Function):
+    """ref transformer_utils.py:240-246: nn.MultiheadAttention(emb, 2 heads, batch_first) with ONE
+    learnable query shared by the batch, keys = values = the (zeroed) tokens, no key mask."""
+
+    HEADS = 2
+
+    @staticmethod
+    def forward(ctx, x, query, w_in, b_in, w_out, b_out):
+        B, T, e = x.shape
+        x2 = _c(x).view(B * T, e)
+        q0 = _c(query).view(1, e)
+        qp = sgemm(q0, w_in[:e], OP_N, OP_T, bias=b_in[:e])                  # (1, e)
+        kv = torch.empty((B * T, 2 * e), dtype=torch.float32, device=x.device)
+        sgemm(x2, w_in[e:2 * e], OP_N, OP_T, bias=b_in[e:2 * e], out=kv[:, :e])
+        sgemm(x2, w_in[2 * e:], OP_N, OP_T, bias=b_in[2 * e:], out=kv[:, e:])
+        kv3 = kv.view(B, T, 2 * e)
+        scale = 1.0 / math.sqrt(e // _AttnPool.HEADS)
+        a, lse = ops.attention_fwd(qp.view(1, 1, e), kv3[..., :e], kv3[..., e:], None, _AttnPool.HEADS, scale,
+                                   q_shared=True)
+        a2 = a.view(B, e)
+        out = sgemm(a2, w_out, OP_N, OP_T, bias=b_out)
+        ctx.dims = (B, T, e, scale)
+        ctx.save_for_backward(x2, q0, w_in, w_out, qp, kv, a2, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, T, e, scale = ctx.dims
+        x2, q0, w_in, w_out, qp, kv, a2, lse = ctx.saved_tensors
+        dout = _c(dout)
+        dw_out = sgemm(dout, a2, OP_T, OP_N)
+        db_out = colsum(dout)
+        da = sgemm(dout, w_out, OP_N, OP_N)
+        kv3 = kv.view(B, T, 2 * e)
+        dq = torch.empty((B, 1, e), dtype=torch.float32, device=dout.device)
+        dkv = torch.empty_like(kv)
+        d3 = dkv.view(B, T, 2 * e)
+        ops.attention_bwd(qp.view(1, 1, e), kv3[..., :e], kv3[..., e:], None, _AttnPool.HEADS, scale,
+                          a2.view(B, 1, e), lse, da.view(B, 1, e), dq, d3[..., :e], d3[..., e:], q_shared=True)
+        dqp = colsum(dq.view(B, e)).view(1, e)
+        dw_in = torch.empty_like(w_in)
+        db_in = torch.empty(3 * e, dtype=torch.float32, device=dout.device)
+        sgemm(dqp, q0, OP_T, OP_N, out=dw_in[:e])
+        sgemm(dkv[:, :e], x2, OP_T, OP_N, out=dw_in[e:2 * e])
+        sgemm(dkv[:, e:], x2, OP_T, OP_N, out=dw_in[2 * e:])
+        db_in[:e].copy_(dqp.view(-1))
+        db_in[e:] = colsum(dkv)
+        dquery = sgemm(dqp, w_in[:e], OP_N, OP_N).view(-1)
+        dx = sgemm(dkv[:, :e], w_in[e:2 * e], OP_N, OP_N)
+        sgemm(dkv[:, e:], w_in[2 * e:], OP_N, OP_N, epilogue=EPI_ADD, aux=dx, out=dx)
+        return dx.view(B, T, e), dquery, dw_in, db_in, dw_out, db_out
+
+
+def attn_pool(x, query, in_proj_weight, in_proj_bias, out_w, out_b):
+    return _AttnPool.apply(x, query, in_proj_weight, in_proj_bias, out_w, out_b)

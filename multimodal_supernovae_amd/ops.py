@@ -55,3 +55,167 @@ def colsum(x):
     ws = _workspace(nb, x.device)
     check(L.msn_colsum(ptr(x), x.stride(0), M, N, ptr(out), ptr(ws), nb, stream_ptr()), "msn_colsum")
     return out
+
+
+# ------------------------------------------------------------------------------------------ row ops
+def _rows2d(t):
+    """View (..., C) as (rows, C) without copying (last dim contiguous, uniform row stride)."""
+    if t.dim() == 2:
+        assert t.stride(1) == 1
+        return t
+    assert t.is_contiguous()
+    return t.view(-1, t.shape[-1])
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5):
+    x2 = _rows2d(_f32c(x, "x"))
+    rows, cols = x2.shape
+    y = torch.empty((rows, cols), dtype=torch.float32, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib().msn_layernorm_fwd(ptr(x2), x2.stride(0), rows, cols, ptr(gamma), ptr(beta), eps, ptr(y), cols,
+                                  ptr(mean), ptr(rstd), stream_ptr()), "msn_layernorm_fwd")
+    return y.view(x.shape), mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma):
+    dy2, x2 = _rows2d(_f32c(dy, "dy")), _rows2d(x)
+    rows, cols = x2.shape
+    dx = torch.empty((rows, cols), dtype=torch.float32, device=x.device)
+    dg = torch.empty(cols, dtype=torch.float32, device=x.device)
+    db = torch.empty(cols, dtype=torch.float32, device=x.device)
+    L = lib()
+    nb = L.msn_layernorm_bwd_workspace_bytes(rows, cols)
+    ws = _workspace(nb, x.device)
+    check(L.msn_layernorm_bwd(ptr(dy2), dy2.stride(0), ptr(x2), x2.stride(0), rows, cols, ptr(mean), ptr(rstd),
+                              ptr(gamma), ptr(dx), cols, ptr(dg), ptr(db), ptr(ws), nb, stream_ptr()),
+          "msn_layernorm_bwd")
+    return dx.view(x.shape), dg, db
+
+
+def l2norm_fwd(x):
+    x2 = _rows2d(_f32c(x, "x"))
+    rows, cols = x2.shape
+    y = torch.empty((rows, cols), dtype=torch.float32, device=x.device)
+    inv = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib().msn_l2norm_fwd(ptr(x2), x2.stride(0), rows, cols, ptr(y), cols, ptr(inv), stream_ptr()),
+          "msn_l2norm_fwd")
+    return y, inv
+
+
+def l2norm_bwd(dy, y, inv):
+    dy2, y2 = _rows2d(_f32c(dy, "dy")), _rows2d(y)
+    rows, cols = y2.shape
+    dx = torch.empty((rows, cols), dtype=torch.float32, device=y.device)
+    check(lib().msn_l2norm_bwd(ptr(dy2), dy2.stride(0), ptr(y2), y2.stride(0), rows, cols, ptr(inv), ptr(dx), cols,
+                               stream_ptr()), "msn_l2norm_bwd")
+    return dx
+
+
+def time_embed_fwd(x, t, w, bw, omega, band=None):
+    """x, t: (B, T) contiguous -> (B, T, e)."""
+    B, T = x.shape
+    e = w.numel()
+    nband = band.shape[0] if band is not None else 1
+    out = torch.empty((B, T, e), dtype=torch.float32, device=x.device)
+    check(lib().msn_time_embed_fwd(ptr(_f32c(x, "x")), ptr(_f32c(t, "t")), B, T, e, ptr(w), ptr(bw), ptr(omega),
+                                   ptr(band), nband, ptr(out), stream_ptr()), "msn_time_embed_fwd")
+    return out
+
+
+def time_embed_bwd(dy, x, nband):
+    B, T, e = dy.shape
+    dev = dy.device
+    dw = torch.empty(e, dtype=torch.float32, device=dev)
+    dbw = torch.empty(e, dtype=torch.float32, device=dev)
+    dband = torch.empty((nband, e), dtype=torch.float32, device=dev) if nband > 1 else None
+    L = lib()
+    nb = L.msn_time_embed_bwd_workspace_bytes(B, e, nband)
+    ws = _workspace(nb, dev)
+    check(L.msn_time_embed_bwd(ptr(_f32c(dy, "dy")), ptr(x), B, T, e, nband, ptr(dw), ptr(dbw), ptr(dband), ptr(ws),
+                               nb, stream_ptr()), "msn_time_embed_bwd")
+    return dw, dbw, dband
+
+
+POOL_MEAN, POOL_MAX = 0, 1
+
+
+def _mask_u8(mask):
+    if mask is None:
+        return None
+    if mask.dtype == torch.bool:
+        return mask.contiguous().view(torch.uint8)
+    return (mask != 0).contiguous().view(torch.uint8)
+
+
+def masked_pool_fwd(x, mask_u8, mode):
+    B, T, e = x.shape
+    out = torch.empty((B, e), dtype=torch.float32, device=x.device)
+    arg = torch.empty((B, e), dtype=torch.int32, device=x.device) if mode == POOL_MAX else None
+    cnt = torch.empty(B, dtype=torch.float32, device=x.device) if mode == POOL_MEAN else None
+    check(lib().msn_masked_pool_fwd(ptr(_f32c(x, "x")), ptr(mask_u8), B, T, e, mode, ptr(out), ptr(arg), ptr(cnt),
+                                    stream_ptr()), "msn_masked_pool_fwd")
+    return out, arg, cnt
+
+
+def masked_pool_bwd(dout, mask_u8, T, mode, arg, cnt):
+    B, e = dout.shape
+    dx = torch.empty((B, T, e), dtype=torch.float32, device=dout.device)
+    check(lib().msn_masked_pool_bwd(ptr(_f32c(dout, "dout")), ptr(mask_u8), B, T, e, mode, ptr(arg), ptr(cnt), ptr(dx),
+                                    stream_ptr()), "msn_masked_pool_bwd")
+    return dx
+
+
+def mask_tokens(x, mask_u8):
+    y = torch.empty_like(x)
+    e = x.shape[-1]
+    check(lib().msn_mask_tokens(ptr(_f32c(x, "x")), ptr(mask_u8), x.numel() // e, e, ptr(y), stream_ptr()),
+          "msn_mask_tokens")
+    return y
+
+
+# ----------------------------------------------------------------------------------------- attention
+def _bt(t):
+    """(ld, batch stride) of a (B, T, C) view whose last dim is contiguous."""
+    assert t.dim() == 3 and t.stride(2) == 1
+    return t.stride(1), t.stride(0)
+
+
+def attention_fwd(q, k, v, mask_u8, heads, scale, q_shared=False):
+    """q: (B, Tq, E) (or (1, Tq, E) with q_shared), k, v: (B, Tk, E) views (column slices allowed)."""
+    B, Tk, E = k.shape
+    Tq = q.shape[1]
+    hd = E // heads
+    out = torch.empty((B, Tq, E), dtype=torch.float32, device=k.device)
+    lse = torch.empty((B, heads, Tq, 2), dtype=torch.float32, device=k.device)
+    ldq, qbs = _bt(q)
+    if q_shared:
+        qbs = 0
+    ldk, kbs = _bt(k)
+    ldv, vbs = _bt(v)
+    check(lib().msn_attention_fwd(ptr(_f32c(q, "q")), ldq, qbs, ptr(k), ldk, kbs, ptr(v), ldv, vbs, ptr(mask_u8),
+                                  B, heads, Tq, Tk, hd, scale, ptr(out), E, Tq * E, ptr(lse), stream_ptr()),
+          "msn_attention_fwd")
+    return out, lse
+
+
+def attention_bwd(q, k, v, mask_u8, heads, scale, out, lse, dout, dq, dk, dv, q_shared=False):
+    """Writes into the provided dq (B, Tq, E), dk, dv (B, Tk, E) views."""
+    B, Tk, E = k.shape
+    Tq = out.shape[1]
+    hd = E // heads
+    delta = torch.empty((B, heads, Tq), dtype=torch.float32, device=k.device)
+    ldq, qbs = _bt(q)
+    if q_shared:
+        qbs = 0
+    ldk, kbs = _bt(k)
+    ldv, vbs = _bt(v)
+    ldd, dbs = _bt(dout)
+    lq, bq = _bt(dq)
+    lk, bk = _bt(dk)
+    lv, bv = _bt(dv)
+    check(lib().msn_attention_bwd(ptr(q), ldq, qbs, ptr(k), ldk, kbs, ptr(v), ldv, vbs, ptr(mask_u8), B, heads, Tq,
+                                  Tk, hd, scale, ptr(out), E, Tq * E, ptr(lse), ptr(_f32c(dout, "dout")), ldd, dbs,
+                                  ptr(delta), ptr(dq), lq, bq, ptr(dk), lk, bk, ptr(dv), lv, bv, stream_ptr()),
+          "msn_attention_bwd")
+    return dq, dk, dv

@@ -1,0 +1,142 @@
+"""Light-curve / spectrum encoders with the reference's class names, constructor arguments and
+state_dict keys (src/transformer_utils.py), computing through libmsn_hip only.
+
+torch.nn.Linear / LayerNorm / Embedding / MultiheadAttention objects appear here purely as
+PARAMETER HOLDERS (same names, shapes and default initialisation as the reference, so its
+checkpoints load with strict=True); their own forward methods are never called.
+"""
+import math
+import warnings
+
+import torch
+import torch.nn as nn
+
+from . import functional as F_
+from . import ops
+
+
+def _warn_dropout(p):
+    if p and p > 0:
+        warnings.warn(f"dropout p={p} requested: this build evaluates the contrastive path with dropout "
+                      "disabled (the shipped configs use p ~ 2e-4)", stacklevel=3)
+
+
+def _mask_bytes(mask):
+    return None if mask is None else ops._mask_u8(mask)
+
+
+class SelfAttention(nn.Module):
+    """Multi-head self-attention, ref src/transformer_utils.py:8-89 (scores / sqrt(emb), -1e7 key fill)."""
+
+    def __init__(self, emb, heads=2):
+        super().__init__()
+        assert emb % heads == 0, f"Embedding dimension ({emb}) should be divisible by nr. of heads ({heads})"
+        self.emb, self.heads = emb, heads
+        self.tokeys = nn.Linear(emb, emb, bias=False)
+        self.toqueries = nn.Linear(emb, emb, bias=False)
+        self.tovalues = nn.Linear(emb, emb, bias=False)
+        self.unifyheads = nn.Linear(emb, emb)
+
+    def forward(self, x, mask=None):
+        assert x.shape[-1] == self.emb, f"Input embedding dim ({x.shape[-1]}) should match layer embedding dim ({self.emb})"
+        return F_.self_attention(x, mask, self.heads, self.tokeys.weight, self.toqueries.weight, self.tovalues.weight,
+                                 self.unifyheads.weight, self.unifyheads.bias)
+
+
+class TransformerBlock(nn.Module):
+    """Post-norm block with a ReLU feed-forward, ref src/transformer_utils.py:92-116."""
+
+    def __init__(self, emb, heads, ff_hidden_mult=6, dropout=0.0):
+        super().__init__()
+        self.attention = SelfAttention(emb, heads=heads)
+        self.norm1 = nn.LayerNorm(emb)
+        self.norm2 = nn.LayerNorm(emb)
+        self.ff = nn.Sequential(nn.Linear(emb, ff_hidden_mult * emb), nn.ReLU(), nn.Linear(ff_hidden_mult * emb, emb))
+        self.do = nn.Dropout(dropout)
+        _warn_dropout(dropout)
+
+    def _params(self):
+        a = self.attention
+        return {"tokeys": a.tokeys.weight, "toqueries": a.toqueries.weight, "tovalues": a.tovalues.weight,
+                "unify_w": a.unifyheads.weight, "unify_b": a.unifyheads.bias,
+                "norm1_w": self.norm1.weight, "norm1_b": self.norm1.bias,
+                "ff0_w": self.ff[0].weight, "ff0_b": self.ff[0].bias, "ff2_w": self.ff[2].weight,
+                "ff2_b": self.ff[2].bias, "norm2_w": self.norm2.weight, "norm2_b": self.norm2.bias}
+
+    def forward(self, x, mask=None):
+        return F_.post_norm_block(x, _mask_bytes(mask) if mask is None or mask.dtype != torch.uint8 else mask,
+                                  self.attention.heads, self._params())
+
+
+class Transformer(nn.Module):
+    """`depth` blocks, no final norm -- ref src/transformer_utils.py:119-153 (ff_hidden_mult = 4)."""
+
+    def __init__(self, emb, heads, depth, ff_hidden_mult=4, dropout=0.0):
+        super().__init__()
+        self.tblocks = nn.ModuleList(
+            [TransformerBlock(emb=emb, heads=heads, ff_hidden_mult=ff_hidden_mult, dropout=dropout) for _ in range(depth)])
+        self.do = nn.Dropout(dropout)
+
+    def forward(self, x, mask=None):
+        m = _mask_bytes(mask)
+        for blk in self.tblocks:
+            x = blk(x, m)
+        return x
+
+
+class TimePositionalEncoding(nn.Module):
+    """Interleaved sin / cos of t * norm^(-2k/d) -- ref src/transformer_utils.py:156-176."""
+
+    def __init__(self, d_emb, norm=10000.0):
+        super().__init__()
+        self.d_emb, self.norm = d_emb, norm
+        # the frequency table is computed exactly as the reference does (fp32 on the host, :169-171)
+        omega = torch.exp(torch.arange(0, d_emb, 2).float() * (-math.log(norm) / d_emb))
+        self.register_buffer("_omega", omega, persistent=False)
+
+    def forward(self, t):
+        zeros_e = torch.zeros(self.d_emb, dtype=torch.float32, device=t.device)
+        return ops.time_embed_fwd(torch.zeros_like(t, dtype=torch.float32), t.float().contiguous(), zeros_e, zeros_e,
+                                  self._omega.to(t.device))
+
+
+class TransformerWithTimeEmbeddings(nn.Module):
+    """ref src/transformer_utils.py:179-253: value + time (+ band) embedding -> Transformer ->
+    zero the padded tokens -> mean | max | attn pooling -> projection.  `agg="pretraining"`
+    returns the zeroed tokens (B, T, emb)."""
+
+    def __init__(self, n_out, nband=1, agg="mean", time_norm=10000.0, **kwargs):
+        super().__init__()
+        emb = kwargs["emb"]
+        self.agg, self.nband = agg, nband
+        self.embedding_mag = nn.Linear(in_features=1, out_features=emb)
+        self.embedding_t = TimePositionalEncoding(emb, time_norm)
+        self.transformer = Transformer(**kwargs)
+        if nband > 1:
+            self.band_emb = nn.Embedding(nband, emb)
+        self.projection = nn.Linear(emb, n_out)
+        if self.agg == "attn":
+            self.query = nn.Parameter(torch.rand(emb))
+            self.agg_attn = nn.MultiheadAttention(embed_dim=emb, num_heads=2, dropout=0.0, batch_first=True)
+
+    def forward(self, x, t, mask=None):
+        if mask is None:
+            raise TypeError("TransformerWithTimeEmbeddings needs the (B, T) padding mask (the reference "
+                            "multiplies by it unconditionally, src/transformer_utils.py:235)")
+        B, T = t.shape
+        if self.nband > 1 and T % self.nband != 0:
+            raise RuntimeError(f"sequence length {T} is not divisible by nband={self.nband}")
+        m = _mask_bytes(mask)
+        h = F_.time_embed(x.reshape(B, T).float(), t.float(), self.embedding_mag.weight, self.embedding_mag.bias,
+                          self.band_emb.weight if self.nband > 1 else None, self.embedding_t._omega)
+        h = self.transformer(h, m)
+        if self.agg in ("mean", "max"):
+            h = F_.masked_pool(h, m, self.agg)       # zeroing + reduction in one kernel
+        else:
+            h = F_.mask_tokens(h, m)
+            if self.agg == "attn":
+                a = self.agg_attn
+                h = F_.attn_pool(h, self.query, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias)
+            elif self.agg == "pretraining":
+                return h
+        return F_.linear(h, self.projection.weight, self.projection.bias)

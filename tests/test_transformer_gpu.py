@@ -1,0 +1,130 @@
+"""GPU parity of the transformer-tower modules (same class names / state_dict keys as the
+reference) against golden vectors produced by the reference itself (tools/gen_golden.py).
+Tolerance: 1e-3 relative (north star) on outputs and gradients, scaled by the tensor's magnitude."""
+import pytest
+import torch
+
+from conftest import Fixture, golden_names
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-3
+
+
+def close(a, b, what):
+    b = b.to(a.dtype)
+    scale = float(b.abs().max()) + 1e-6
+    torch.testing.assert_close(a, b, rtol=RTOL, atol=RTOL * scale * 0.1, msg=lambda m: f"{what}: {m}")
+
+
+def check_param_grads(module, f, skip=()):
+    for k, p in module.named_parameters():
+        if k in skip:
+            continue
+        assert k in f.grad, f"reference has no gradient for {k}"
+        assert p.grad is not None, f"no gradient for {k}"
+        close(p.grad.cpu(), f.grad[k], "grad " + k)
+
+
+@pytest.mark.parametrize("name", golden_names("attn_"))
+def test_self_attention(name):
+    from multimodal_supernovae_amd.transformer_utils import SelfAttention
+    f = Fixture(name)
+    m = SelfAttention(f.cfg["emb"], f.cfg["heads"])
+    m.load_state_dict(f.P, strict=True)
+    m.cuda()
+    x = f.groups["in"]["x"].cuda().requires_grad_()
+    y = m(x, f.groups["in"]["mask"].cuda())
+    close(y.detach().cpu(), f.out["y"], "y")
+    y.backward(f.groups["in"]["cot"].cuda())
+    close(x.grad.cpu(), f.grad["x"], "dx")
+    check_param_grads(m, f)
+
+
+@pytest.mark.parametrize("name", golden_names("block_"))
+def test_transformer_block(name):
+    from multimodal_supernovae_amd.transformer_utils import TransformerBlock
+    f = Fixture(name)
+    m = TransformerBlock(f.cfg["emb"], f.cfg["heads"], ff_hidden_mult=4, dropout=0.0)
+    m.load_state_dict(f.P, strict=True)
+    m.cuda()
+    x = f.groups["in"]["x"].cuda().requires_grad_()
+    y = m(x, f.groups["in"]["mask"].cuda())
+    close(y.detach().cpu(), f.out["y"], "y")
+    y.backward(f.groups["in"]["cot"].cuda())
+    close(x.grad.cpu(), f.grad["x"], "dx")
+    check_param_grads(m, f)
+
+
+def test_time_positional_encoding():
+    from multimodal_supernovae_amd.transformer_utils import TimePositionalEncoding
+    f = Fixture("timeenc")
+    pe = TimePositionalEncoding(f.cfg["emb"], f.cfg["norm"]).cuda()(f.groups["in"]["t"].cuda())
+    torch.testing.assert_close(pe.cpu(), f.out["pe"], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", golden_names("tenc_"))
+def test_transformer_with_time_embeddings(name):
+    from multimodal_supernovae_amd.transformer_utils import TransformerWithTimeEmbeddings
+    f = Fixture(name)
+    c = f.cfg
+    m = TransformerWithTimeEmbeddings(n_out=c["n_out"], nband=c["nband"], agg=c["agg"], time_norm=c["time_norm"],
+                                      emb=c["emb"], heads=c["heads"], depth=c["depth"], dropout=0.0)
+    m.load_state_dict(f.P, strict=True)
+    m.cuda()
+    i = f.groups["in"]
+    y = m(i["x"].cuda(), i["t"].cuda(), i["mask"].cuda())
+    close(y.detach().cpu(), f.out["y"], "y")
+    y.backward(i["cot"].cuda())
+    unused = ("projection.weight", "projection.bias") if c["agg"] == "pretraining" else ()
+    check_param_grads(m, f, skip=unused)
+
+
+def test_mask_is_mandatory_and_band_divisibility():
+    from multimodal_supernovae_amd.transformer_utils import TransformerWithTimeEmbeddings
+    m = TransformerWithTimeEmbeddings(n_out=8, nband=2, emb=16, heads=4, depth=1).cuda()
+    x, t = torch.randn(2, 11, 1).cuda(), torch.rand(2, 11).cuda()
+    with pytest.raises(TypeError):
+        m(x[:, :10], t[:, :10], None)
+    with pytest.raises(RuntimeError):
+        m(x, t, torch.ones(2, 11, dtype=torch.bool).cuda())
+
+
+def test_state_dict_keys_match_reference_fixture():
+    from multimodal_supernovae_amd.transformer_utils import TransformerWithTimeEmbeddings
+    f = Fixture("tenc_attn_nb2_full")
+    c = f.cfg
+    m = TransformerWithTimeEmbeddings(n_out=c["n_out"], nband=2, agg="attn", time_norm=c["time_norm"], emb=c["emb"],
+                                      heads=c["heads"], depth=c["depth"])
+    assert set(m.state_dict().keys()) == set(f.P.keys())
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(f.P[k].shape), k
+
+
+def test_maven_sized_towers_against_oracle():
+    """Reference-native sizes (pretrain_config/maven_pretrain_config.yaml:28-48): LC T=200 e=64 h=8 L=5 nband=2,
+    spectrum T=220 e=32 h=2 L=13; batch 16; forward + parameter gradients vs the CPU oracle."""
+    from multimodal_supernovae_amd.transformer_utils import TransformerWithTimeEmbeddings
+    from oracle import encoders as oenc
+    g = torch.Generator().manual_seed(9)
+    for (T, e, h, L, nband, norm) in [(200, 64, 8, 5, 2, 20583.369161312577), (220, 32, 2, 13, 1, 17945.142213594805)]:
+        torch.manual_seed(1)
+        m = TransformerWithTimeEmbeddings(n_out=32, nband=nband, agg="mean", time_norm=norm, emb=e, heads=h, depth=L)
+        P = {k: v.clone().requires_grad_() for k, v in m.state_dict().items()}
+        B = 16
+        x = torch.randn(B, T, 1, generator=g)
+        t = torch.sort(torch.rand(B, T // nband, generator=g) * 100, dim=1)[0].repeat(1, nband)
+        mask = torch.zeros(B, T, dtype=torch.bool)
+        for b in range(B):
+            for k in range(nband):
+                n = int(torch.randint(10, T // nband + 1, (1,), generator=g))
+                mask[b, k * (T // nband):k * (T // nband) + n] = True
+        cot = torch.randn(B, 32, generator=g)
+        ref = oenc.transformer_with_time_embeddings(P, "", x, t, mask, emb=e, heads=h, depth=L, time_norm=norm,
+                                                    nband=nband, agg="mean")
+        (ref * cot).sum().backward()
+        m.cuda()
+        y = m(x.cuda(), t.cuda(), mask.cuda())
+        close(y.detach().cpu(), ref.detach(), "y")
+        y.backward(cot.cuda())
+        for k, p in m.named_parameters():
+            close(p.grad.cpu(), P[k].grad, "grad " + k)
