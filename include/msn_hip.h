@@ -172,6 +172,48 @@ int msn_attention_bwd(const float* q, int64_t ldq, int64_t q_bstride, const floa
                       int64_t lddq, int64_t dq_bstride, float* dk, int64_t lddk, int64_t dk_bstride,
                       float* dv, int64_t lddv, int64_t dv_bstride, msn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * ConvMixer image tower pieces -- src/models_multimodal.py:38-95, channels-last token matrices
+ * X[(b, i, j)][c].  The patch conv (stride = kernel = p, no bias, :54-56) and the 1x1 convs (:75)
+ * are msn_sgemm on these matrices with the GELU epilogue.
+ */
+/* img (B, C, H, W) -> patches [(b, i, j)][(c, u, v)], grid = floor(H/p) x floor(W/p) (extra pixels unused) */
+int msn_patchify(const float* img, int B, int C, int H, int W, int p, float* patches, msn_stream_t stream);
+/* its adjoint: d img from d patches (zeros outside the grid) */
+int msn_unpatchify(const float* dpatches, int B, int C, int H, int W, int p, float* dimg, msn_stream_t stream);
+
+/* nn.BatchNorm2d over the rows of x (rows x C), :58,70,77.  training != 0: two-pass batch statistics,
+ * `mean` / `rstd` (C each) written, running_mean / running_var updated in place when non-NULL
+ * (momentum; unbiased variance) ; training == 0: running statistics are used.  y = bn(x) (+ residual).
+ * bwd: dx = dL/dx, additionally multiplied by gelu'(pre) when pre != NULL (conv -> GELU -> BN order). */
+size_t msn_bn_workspace_bytes(int64_t rows, int C);
+int msn_batchnorm_fwd(const float* x, int64_t rows, int C, const float* gamma, const float* beta, float eps,
+                      int training, float momentum, float* running_mean, float* running_var,
+                      const float* residual, float* y, float* mean, float* rstd, void* ws, size_t ws_bytes,
+                      msn_stream_t stream);
+int msn_batchnorm_bwd(const float* dy, const float* x, const float* pre, int64_t rows, int C,
+                      const float* mean, const float* rstd, const float* gamma, int training, float* dx,
+                      float* dgamma, float* dbeta, void* ws, size_t ws_bytes, msn_stream_t stream);
+
+/* depthwise k x k conv, padding='same', + bias, + GELU (:65-69): x (B, gh, gw, C) channels-last,
+ * w (C, 1, k, k).  fwd writes pre (conv + bias) and act = gelu(pre).
+ * bwd: dx = conv^T(dpre) (+ add), dw (C,1,k,k), dbias (C; may be NULL). */
+int msn_dwconv_gelu_fwd(const float* x, const float* w, const float* bias, int B, int gh, int gw, int C,
+                        int k, float* pre, float* act, msn_stream_t stream);
+size_t msn_dwconv_bwd_workspace_bytes(int B, int C, int k);
+int msn_dwconv_bwd(const float* dpre, const float* x, const float* w, int B, int gh, int gw, int C, int k,
+                   const float* add, float* dx, float* dw, float* dbias, void* ws, size_t ws_bytes,
+                   msn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused multi-tensor RAdam step with torch.optim.RAdam semantics (betas, eps, coupled L2 weight
+ * decay, rectification once rho_t > 5) -- the optimiser of src/models_multimodal.py:306-310.
+ * table: DEVICE array of n_tensors records of five 64-bit words {p*, g*, m*, v*, numel};
+ * step is the 1-based update count.  One launch for the whole model; 28 B of HBM traffic / parameter.
+ */
+int msn_radam_step(const void* table, int n_tensors, int64_t max_numel, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int64_t step, msn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,18 @@ SIGNATURES = {
                                   c_int, c_int, c_int, c_int, c_int, c_f32, c_ptr, c_i64, c_i64, c_ptr,
                                   c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64,
                                   c_ptr, c_i64, c_i64, c_ptr]),
+    "msn_patchify": (c_int, [c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
+    "msn_unpatchify": (c_int, [c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
+    "msn_bn_workspace_bytes": (c_size, [c_i64, c_int]),
+    "msn_batchnorm_fwd": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_f32, c_int, c_f32, c_ptr, c_ptr, c_ptr, c_ptr,
+                                  c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "msn_batchnorm_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr,
+                                  c_ptr, c_size, c_ptr]),
+    "msn_dwconv_gelu_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
+    "msn_dwconv_bwd_workspace_bytes": (c_size, [c_int, c_int, c_int]),
+    "msn_dwconv_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr,
+                               c_ptr, c_size, c_ptr]),
+    "msn_radam_step": (c_int, [c_ptr, c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_ptr]),
     "msn_infonce_workspace_bytes": (c_size, [c_int] * 5),
     "msn_infonce_fwd": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_i64, c_int,
                                 c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),

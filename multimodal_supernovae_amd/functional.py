@@ -361,3 +361,76 @@ class _AttnPool(torch.autograd.Function):
 
 def attn_pool(x, query, in_proj_weight, in_proj_bias, out_w, out_b):
     return _AttnPool.apply(x, query, in_proj_weight, in_proj_bias, out_w, out_b)
+
+
+# ------------------------------------------------------------------------------ ConvMixer trunk
+class _ConvMixerTrunk(torch.autograd.Function):
+    """ref models_multimodal.py:52-79 (the `net` Sequential): patch conv -> GELU -> BN, then per
+    layer x + BN(GELU(depthwise(x))) followed by BN(GELU(1x1 conv)).  Channels-last token matrices;
+    convs with dense weights are GEMMs (GELU in the epilogue), the residual add rides in the BN
+    apply kernel, GELU' rides in the BN backward kernel.  Returns tokens (B, gh*gw, dim).
+
+    flat parameter order: w0, g0, b0, rm0, rv0, then per layer
+      dw_w, dw_b, gA, bA, rmA, rvA, pw_w, pw_b, gB, bB, rmB, rvB."""
+
+    PER_LAYER = 12
+
+    @staticmethod
+    def forward(ctx, img, training, depth, patch, *P):
+        B, C, H, W = img.shape
+        gh, gw = H // patch, W // patch
+        img = _c(img.float())
+        w0, g0, b0, rm0, rv0 = P[:5]
+        dim = w0.shape[0]
+        patches = ops.patchify(img, patch)
+        M = patches.shape[0]
+        pre0 = torch.empty((M, dim), dtype=torch.float32, device=img.device)
+        act0 = sgemm(patches, w0.view(dim, -1), OP_N, OP_T, epilogue=EPI_GELU, aux=pre0)
+        y, mean0, rstd0 = ops.batchnorm_fwd(act0, g0, b0, rm0, rv0, training)
+        saved = [patches, pre0, act0, mean0, rstd0]
+        for i in range(depth):
+            dw_w, dw_b, gA, bA, rmA, rvA, pw_w, pw_b, gB, bB, rmB, rvB = P[5 + 12 * i: 17 + 12 * i]
+            preA, actA = ops.dwconv_gelu_fwd(y, dw_w, dw_b, B, gh, gw)
+            yA, meanA, rstdA = ops.batchnorm_fwd(actA, gA, bA, rmA, rvA, training, residual=y)
+            preB = torch.empty((M, dim), dtype=torch.float32, device=img.device)
+            actB = sgemm(yA, pw_w.view(dim, dim), OP_N, OP_T, bias=pw_b, epilogue=EPI_GELU, aux=preB)
+            yB, meanB, rstdB = ops.batchnorm_fwd(actB, gB, bB, rmB, rvB, training)
+            saved += [y, preA, actA, meanA, rstdA, yA, preB, actB, meanB, rstdB]
+            y = yB
+        ctx.geom = (B, C, H, W, gh, gw, dim, depth, patch, bool(training))
+        ctx.n_act = len(saved)
+        ctx.save_for_backward(*saved, *P)
+        return y.view(B, gh * gw, dim)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W, gh, gw, dim, depth, patch, training = ctx.geom
+        saved = ctx.saved_tensors
+        acts, P = saved[:ctx.n_act], saved[ctx.n_act:]
+        grads = [None] * len(P)
+        d = _c(dy).view(B * gh * gw, dim)
+        for i in range(depth - 1, -1, -1):
+            o = 5 + 12 * i
+            dw_w, dw_b, gA, bA, rmA, rvA, pw_w, pw_b, gB, bB, rmB, rvB = P[o:o + 12]
+            y_in, preA, actA, meanA, rstdA, yA, preB, actB, meanB, rstdB = acts[5 + 10 * i: 15 + 10 * i]
+            dpreB, dgB, dbB = ops.batchnorm_bwd(d, actB, preB, meanB, rstdB, gB, training)
+            grads[o + 6] = sgemm(dpreB, yA, OP_T, OP_N).view_as(pw_w)
+            grads[o + 7] = colsum(dpreB)
+            grads[o + 8], grads[o + 9] = dgB, dbB
+            dyA = sgemm(dpreB, pw_w.view(dim, dim), OP_N, OP_N)
+            dpreA, dgA, dbA = ops.batchnorm_bwd(dyA, actA, preA, meanA, rstdA, gA, training)
+            d, ddw, ddb = ops.dwconv_bwd(dpreA, y_in, dw_w, B, gh, gw, add=dyA)   # + the residual branch
+            grads[o], grads[o + 1], grads[o + 2], grads[o + 3] = ddw, ddb, dgA, dbA
+        patches, pre0, act0, mean0, rstd0 = acts[:5]
+        w0, g0 = P[0], P[1]
+        dpre0, dg0, db0 = ops.batchnorm_bwd(d, act0, pre0, mean0, rstd0, g0, training)
+        grads[0] = sgemm(dpre0, patches, OP_T, OP_N).view_as(w0)
+        grads[1], grads[2] = dg0, db0
+        dimg = None
+        if ctx.needs_input_grad[0]:
+            dimg = ops.unpatchify(sgemm(dpre0, w0.view(dim, -1), OP_N, OP_N), (B, C, H, W), patch)
+        return (dimg, None, None, None, *grads)
+
+
+def convmixer_trunk(img, training, depth, patch, flat_params):
+    return _ConvMixerTrunk.apply(img, training, depth, patch, *flat_params)

@@ -219,3 +219,74 @@ def attention_bwd(q, k, v, mask_u8, heads, scale, out, lse, dout, dq, dk, dv, q_
                                   ptr(delta), ptr(dq), lq, bq, ptr(dk), lk, bk, ptr(dv), lv, bv, stream_ptr()),
           "msn_attention_bwd")
     return dq, dk, dv
+
+
+# ----------------------------------------------------------------------------------------- ConvMixer
+def patchify(img, p):
+    B, C, H, W = img.shape
+    gh, gw = H // p, W // p
+    out = torch.empty((B * gh * gw, C * p * p), dtype=torch.float32, device=img.device)
+    check(lib().msn_patchify(ptr(_f32c(img, "img")), B, C, H, W, p, ptr(out), stream_ptr()), "msn_patchify")
+    return out
+
+
+def unpatchify(dpatches, shape, p):
+    B, C, H, W = shape
+    dimg = torch.empty(shape, dtype=torch.float32, device=dpatches.device)
+    check(lib().msn_unpatchify(ptr(_f32c(dpatches, "dpatches")), B, C, H, W, p, ptr(dimg), stream_ptr()),
+          "msn_unpatchify")
+    return dimg
+
+
+def batchnorm_fwd(x, gamma, beta, running_mean, running_var, training, residual=None, momentum=0.1, eps=1e-5):
+    rows, C = x.shape
+    dev = x.device
+    y = torch.empty_like(x)
+    mean = torch.empty(C, dtype=torch.float32, device=dev)
+    rstd = torch.empty(C, dtype=torch.float32, device=dev)
+    L = lib()
+    nb = L.msn_bn_workspace_bytes(rows, C)
+    ws = _workspace(nb, dev)
+    check(L.msn_batchnorm_fwd(ptr(_f32c(x, "x")), rows, C, ptr(gamma), ptr(beta), eps, 1 if training else 0, momentum,
+                              ptr(running_mean), ptr(running_var), ptr(residual), ptr(y), ptr(mean), ptr(rstd),
+                              ptr(ws), nb, stream_ptr()), "msn_batchnorm_fwd")
+    return y, mean, rstd
+
+
+def batchnorm_bwd(dy, x, pre, mean, rstd, gamma, training):
+    rows, C = x.shape
+    dev = x.device
+    dx = torch.empty_like(x)
+    dg = torch.empty(C, dtype=torch.float32, device=dev)
+    db = torch.empty(C, dtype=torch.float32, device=dev)
+    L = lib()
+    nb = L.msn_bn_workspace_bytes(rows, C)
+    ws = _workspace(nb, dev)
+    check(L.msn_batchnorm_bwd(ptr(_f32c(dy, "dy")), ptr(x), ptr(pre), rows, C, ptr(mean), ptr(rstd), ptr(gamma),
+                              1 if training else 0, ptr(dx), ptr(dg), ptr(db), ptr(ws), nb, stream_ptr()),
+          "msn_batchnorm_bwd")
+    return dx, dg, db
+
+
+def dwconv_gelu_fwd(x, w, bias, B, gh, gw):
+    C = x.shape[-1]
+    k = w.shape[-1]
+    pre, act = torch.empty_like(x), torch.empty_like(x)
+    check(lib().msn_dwconv_gelu_fwd(ptr(_f32c(x, "x")), ptr(w), ptr(bias), B, gh, gw, C, k, ptr(pre), ptr(act),
+                                    stream_ptr()), "msn_dwconv_gelu_fwd")
+    return pre, act
+
+
+def dwconv_bwd(dpre, x, w, B, gh, gw, add=None, want_bias=True):
+    C = x.shape[-1]
+    k = w.shape[-1]
+    dev = x.device
+    dx = torch.empty_like(x)
+    dw = torch.empty_like(w)
+    dbias = torch.empty(C, dtype=torch.float32, device=dev) if want_bias else None
+    L = lib()
+    nb = L.msn_dwconv_bwd_workspace_bytes(B, C, k)
+    ws = _workspace(nb, dev)
+    check(L.msn_dwconv_bwd(ptr(_f32c(dpre, "dpre")), ptr(x), ptr(w), B, gh, gw, C, k, ptr(add), ptr(dx), ptr(dw),
+                           ptr(dbias), ptr(ws), nb, stream_ptr()), "msn_dwconv_bwd")
+    return dx, dw, dbias

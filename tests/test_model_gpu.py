@@ -1,0 +1,143 @@
+"""GPU parity of the image tower, the MLP, the full CLIP module and the training harness against
+golden vectors from the reference (tools/gen_golden.py).  1e-3 relative, magnitude-scaled."""
+import pytest
+import torch
+
+from conftest import Fixture, golden_names
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-3
+BATCH_KEYS = ["x_img", "x_lc", "t_lc", "mask_lc", "x_sp", "t_sp", "mask_sp", "redshift", "classification"]
+
+
+def close(a, b, what, rtol=RTOL):
+    b = b.to(a.dtype)
+    scale = float(b.abs().max()) + 1e-6
+    torch.testing.assert_close(a, b, rtol=rtol, atol=rtol * scale * 0.1, msg=lambda m: f"{what}: {m}")
+
+
+def _batch(ins, prefix="", device="cuda"):
+    return tuple(ins[prefix + k].to(device) if prefix + k in ins else None for k in BATCH_KEYS)
+
+
+@pytest.mark.parametrize("name", golden_names("convmixer_"))
+def test_convmixer(name):
+    from multimodal_supernovae_amd.models_multimodal import ConvMixer
+    f = Fixture(name)
+    c = f.cfg
+    m = ConvMixer(dim=c["dim"], depth=c["depth"], channels=c["channels"], kernel_size=c["kernel_size"],
+                  patch_size=c["patch_size"], n_out=c["n_out"], dropout_prob=0.0)
+    m.load_state_dict(f.P, strict=True)
+    m.cuda().train(c["mode"] == "train")
+    x = f.groups["in"]["x"].cuda().requires_grad_()
+    y = m(x)
+    close(y.detach().cpu(), f.out["y"], "y")
+    y.backward(f.groups["in"]["cot"].cuda())
+    close(x.grad.cpu(), f.grad["x"], "dx")
+    for k, p in m.named_parameters():
+        close(p.grad.cpu(), f.grad[k], "grad " + k)
+    sd = m.state_dict()
+    for k, v in f.stats.items():   # running statistics after the step (unchanged in eval mode)
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(v), k
+        else:
+            close(sd[k].cpu(), v, k, rtol=1e-4)
+
+
+def test_mlp():
+    from multimodal_supernovae_amd.models_multimodal import MLP
+    f = Fixture("mlp")
+    m = MLP(input_dim=12, hidden_dim=16, output_dim=8, num_layers=2, dropout=0.0)
+    m.load_state_dict(f.P, strict=True)
+    m.cuda()
+    x = f.groups["in"]["x"].cuda().requires_grad_()
+    y = m(x)
+    close(y.detach().cpu(), f.out["y"], "y")
+    y.backward(f.groups["in"]["cot"].cuda())
+    close(x.grad.cpu(), f.grad["x"], "dx")
+    for k, p in m.named_parameters():
+        close(p.grad.cpu(), f.grad[k], "grad " + k)
+
+
+def _build(cfg):
+    from multimodal_supernovae_amd.models_multimodal import LightCurveImageCLIP
+    return LightCurveImageCLIP(enc_dim=cfg["enc_dim"], logit_scale=10.0, nband=cfg["nband"],
+                               transformer_kwargs=cfg["transformer_kwargs"],
+                               transformer_spectral_kwargs=cfg["transformer_spectral_kwargs"],
+                               conv_kwargs=cfg["conv_kwargs"], meta_kwargs=cfg["meta_kwargs"],
+                               combinations=cfg["combinations"], optimizer_kwargs={"weight_decay": cfg["weight_decay"]},
+                               lr=cfg["lr"], loss=cfg["loss"])
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names("clip_") if "sigmoid" not in n])
+def test_clip_module_training_step(name):
+    f = Fixture(name)
+    model = _build(f.cfg)
+    assert set(model.state_dict().keys()) == set(f.P.keys())
+    model.load_state_dict(f.P, strict=True)
+    model.cuda().train()
+    batch = _batch(f.groups["in"])
+    embs = model(*batch)
+    assert len(embs) == len(f.cfg["combinations"])
+    for k, e in enumerate(embs):                       # fixed order img, lc, sp, meta
+        close(e.detach().cpu(), f.out[f"emb{k}"], f"emb{k}")
+    model.zero_grad()
+    model = _build(f.cfg)                              # fresh BN running stats for the step itself
+    model.load_state_dict(f.P, strict=True)
+    model.cuda().train()
+    loss = model.training_step(batch, 0)
+    assert abs(float(loss.detach()) - float(f.out["loss"])) <= RTOL * abs(float(f.out["loss"]))
+    loss.backward()
+    for k, p in model.named_parameters():
+        assert k in f.grad, k
+        if k == "logit_bias":      # analytically zero (the bias cancels in both log-softmaxes): rounding noise only
+            assert abs(float(p.grad)) < 1e-5 and abs(float(f.grad[k])) < 1e-5
+            continue
+        close(p.grad.cpu(), f.grad[k], "grad " + k, rtol=2e-3)
+
+
+def test_harness_eight_radam_steps_match_reference():
+    """the reference's loop (zero_grad -> training_step -> backward -> RAdam.step) over two
+    cycled batches for 8 steps (crossing RAdam's rectification switch): loss trajectory + final weights."""
+    from multimodal_supernovae_amd.trainer import Trainer
+    f = Fixture("harness_radam")
+    model = _build(f.cfg)
+    model.load_state_dict(f.P, strict=True)
+    batches = [_batch(f.groups["in"], f"b{i}.", device="cpu") for i in range(2)]
+    tr = Trainer(max_epochs=f.cfg["n_steps"] // 2).fit(model, batches)
+    got = torch.stack(tr.step_losses).cpu()
+    torch.testing.assert_close(got, f.out["losses"], rtol=2e-3, atol=1e-4)
+    sd = model.state_dict()
+    for k, v in f.after.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(v)
+        else:
+            close(sd[k].cpu(), v, "after " + k, rtol=5e-3)
+
+
+def test_radam_kernel_matches_torch_optimizer():
+    from multimodal_supernovae_amd.optim import RAdam
+    g = torch.Generator().manual_seed(3)
+    shapes = [(7, 3), (5,), (), (129, 33), (1000,)]
+    w0 = [torch.randn(s, generator=g) for s in shapes]
+    a = [w.clone().cuda().requires_grad_() for w in w0]
+    b = [w.clone().requires_grad_() for w in w0]
+    oa, ob = RAdam(a, lr=1e-2, weight_decay=1e-3), torch.optim.RAdam(b, lr=1e-2, weight_decay=1e-3)
+    for step in range(10):
+        for ps, opt in ((a, oa), (b, ob)):
+            opt.zero_grad()
+            for p in ps:
+                p.grad = (torch.sin(p.detach() * (step + 1)) + 0.1).to(p.device)
+            opt.step()
+        for pa, pb in zip(a, b):
+            torch.testing.assert_close(pa.detach().cpu(), pb.detach(), rtol=1e-5, atol=1e-6)
+    assert set(oa.state[a[0]].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+def test_cpu_module_fails_loudly():
+    """No CPU fallback: calling the product path without the GPU raises instead of computing."""
+    from multimodal_supernovae_amd import _lib
+    from multimodal_supernovae_amd.models_multimodal import MLP
+    m = MLP(input_dim=4, hidden_dim=4, output_dim=2, num_layers=1, dropout=0.0)
+    with pytest.raises(_lib.MsnHipError):
+        m(torch.randn(3, 4))
