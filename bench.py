@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Headline benchmark: contrastive pairs/s of one full training step (forward, fused InfoNCE with
+global negatives, backward, gradient all-reduce, fused RAdam) on synthetic data resident in HBM.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2] towers; SURVEY.md section 8(d) "headline cfg3"): build-defined ViT-S/8
+image encoder on 64x64x3 cutouts + the reference light-curve TransformerWithTimeEmbeddings (T = 200 =
+2 bands x 100, emb 64, 8 heads, depth 5, mean pooling), n_out 32, enc_dim 128, fp32 (the reference
+precision).  Per-GPU batch 1024: at N = 1 that is the metric's "global batch 1024"; weak scaling keeps
+1024 rows per GPU and all-gathers the embeddings so every rank contrasts against all N * 1024 rows.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LC = dict(n_out=32, emb=64, heads=8, depth=5, dropout=0.0, time_norm=20583.369161312577, agg="mean")
+CONV_PLACEHOLDER = dict(dim=8, depth=1, channels=3, kernel_size=5, patch_size=8, n_out=32, dropout_prob=0.0)
+IMG, T_LC, NBAND, ENC_DIM, N_OUT = 64, 200, 2, 128, 32
+LR, WD, LOGIT_SCALE = 3.716367614864064e-05, 0.000555522900788888, 19.545966923442453  # maven_pretrain_config.yaml
+
+
+def synthetic_batch(b, seed, device):
+    """images U[0,1); light curves N(0,1) with per-band sorted U[0,100) day stamps."""
+    g = torch.Generator().manual_seed(seed)
+    x_img = torch.rand(b, 3, IMG, IMG, generator=g)
+    x_lc = torch.randn(b, T_LC, generator=g)
+    per = T_LC // NBAND
+    t_lc = torch.cat([torch.sort(torch.rand(b, per, generator=g) * 100.0, dim=1)[0] for _ in range(NBAND)], dim=1)
+    mask = torch.ones(b, T_LC, dtype=torch.bool)
+    return tuple(t.to(device) if t is not None else None
+                 for t in (x_img, x_lc, t_lc, mask, None, None, None, None, None))
+
+
+def build_model(device, seed=0):
+    from multimodal_supernovae_amd.encoders import vit_s8
+    from multimodal_supernovae_amd.models_multimodal import LightCurveImageCLIP
+    torch.manual_seed(seed)
+    model = LightCurveImageCLIP(enc_dim=ENC_DIM, logit_scale=LOGIT_SCALE, nband=NBAND, transformer_kwargs=LC,
+                                conv_kwargs=CONV_PLACEHOLDER, combinations=["host_galaxy", "lightcurve"],
+                                optimizer_kwargs={"weight_decay": WD}, lr=LR, loss="softmax")
+    model.image_encoder = vit_s8(img_size=IMG, n_out=N_OUT)     # the encoder slot (ref models_multimodal.py:190)
+    return model.to(device).train()
+
+
+def flops_per_pair():
+    """Algorithmic work model of BASELINE.md section 4 (2 flop / MAC, GEMM-shaped work only, train = 3 x fwd)."""
+    def f_tr(t, e, l):
+        return l * (24 * t * e * e + 4 * t * t * e)
+    hw = (IMG // 8) ** 2
+    vit = f_tr(1 + hw, 384, 12) + 2 * hw * (3 * 8 * 8) * 384
+    lc = f_tr(T_LC, 64, 5)
+    return 3.0 * (vit + lc)
+
+
+def usable_cores(cap=32):
+    """Threads the CPU leg uses: the scheduler affinity and the cgroup CPU quota bound what this process
+    really owns (os.cpu_count() reports the whole host); capped so a shared host is not oversubscribed."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
+def cpu_baseline(sample_b, steps):
+    """The oracle (CPU restatement, parity-pinned against the reference) timed on this host's cores on a
+    bounded sample of the same workload: full train step incl. RAdam, `sample_b` pairs per step."""
+    from oracle import clip as oclip
+    from oracle.build_defined import vision_transformer
+    from oracle import encoders as oenc
+    from oracle import loss as oloss
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    model = build_model("cpu")
+    P = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    batch = synthetic_batch(sample_b, 4321, "cpu")
+    opt = oclip.RAdam([v for v in P.values() if v.requires_grad], lr=LR, weight_decay=WD)
+
+    def step():
+        opt.zero_grad()
+        h = vision_transformer(P, "image_encoder.", batch[0], patch=8, heads=6, depth=12)
+        e_img = oclip.l2_normalise(oenc.linear(P, "image_projection", h))
+        h = oenc.transformer_with_time_embeddings(P, "lightcurve_encoder.", batch[1][..., None], batch[2], batch[3],
+                                                  emb=LC["emb"], heads=LC["heads"], depth=LC["depth"],
+                                                  time_norm=LC["time_norm"], nband=NBAND, agg="mean")
+        e_lc = oclip.l2_normalise(oenc.linear(P, "lightcurve_projection", h))
+        loss = oloss.clip_loss_multimodal([e_img, e_lc], P["logit_scale"], P["logit_bias"])
+        loss.backward()
+        opt.step()
+        return float(loss.detach())
+
+    t0 = time.perf_counter()
+    step()                                  # first step also warms the allocator / thread pool
+    first = time.perf_counter() - t0
+    if first > 12.0:                        # keep the whole leg bounded (~10-30 s of CPU work)
+        steps, dt = 1, first
+    else:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        dt = (time.perf_counter() - t0) / steps
+    return {"value": sample_b / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} full train steps (fwd + InfoNCE + bwd + RAdam) of the same two-tower workload at batch "
+                      f"{sample_b} on {cores} host threads (torch {torch.__version__} CPU fp32), {dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--per-gpu-batch", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=32)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    from multimodal_supernovae_amd import _lib, distributed as D, ops
+    _lib.require_gpu()
+    rank, local, world = D.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    device = torch.device("cuda", local)
+    b = args.per_gpu_batch
+    model = build_model(device)
+    D.broadcast_module(model)
+    opt = model.configure_optimizers()["optimizer"]
+    batch = synthetic_batch(b, 1234 + rank, device)
+    params = [p for p in model.parameters()]
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = model.training_step(batch, 0)
+        loss.backward()
+        D.allreduce_gradients(params)
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t)
+    loss_value = float(loss.detach())
+
+    # ---- roofline of the dominant kernel (sgemm_kernel: every dense product of both towers) -----------
+    # One extra, identical step with HIP events recorded on the launch stream around every msn_sgemm call.
+    ops.GEMM_PROFILE = []
+    step()
+    torch.cuda.synchronize()
+    prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+    gemm_ms = sum(a.elapsed_time(c) for a, c, _ in prof)
+    gemm_flops = sum(f for _, _, f in prof)
+    achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    peak = 157.3  # TFLOP/s, dense fp32 matrix (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        pairs = b * world * args.steps / dt
+        out = {
+            "metric": "contrastive pairs/sec (image+light-curve) at global batch 1024, 1/2/4/8 GPUs",
+            "value": pairs, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ViT-S/8 image tower (64x64x3, build-defined) + reference light-curve "
+                                   "transformer (T=200, emb 64, 8 heads, depth 5, 2 bands) -> enc_dim 128, "
+                                   "symmetric InfoNCE with all-gathered global negatives, RAdam; full train step",
+                       "per_gpu_batch": b, "global_batch": b * world, "parallelism": f"dp{world}",
+                       "loss": loss_value, "algorithmic_gflop_per_pair": flops_per_pair() / 1e9,
+                       "model_tflops": pairs * flops_per_pair() / 1e12},
+            "roofline": {"bound": "mfma", "kernel": "msn::sgemm_kernel (fp32 v_mfma_f32_32x32x2_f32)",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": None, "launches_per_step": len(prof), "ms_per_step_in_kernel": gemm_ms,
+                         "algorithmic_gflop_per_step": gemm_flops / 1e9},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_batch, args.cpu_steps)
+        elif world == 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -109,15 +109,17 @@ int msn_infonce_bwd(const float* E1_loc, int64_t ld1, int b1, const float* E2_lo
  * LayerNorm over the last dimension (rows x cols, cols % 4 == 0, cols <= 1024), eps inside the
  * square root -- nn.LayerNorm as used at src/transformer_utils.py:97-98,111,114 (post-norm; the
  * residual sum is produced by the preceding GEMM's MSN_EPI_ADD epilogue).
- * fwd writes y and the per-row mean / rstd; bwd consumes them and returns dx, dgamma, dbeta.
+ * fwd writes y and the per-row mean / rstd; bwd consumes them and returns dx (+ `add`, the
+ * gradient of a residual branch around the norm, when non-NULL), dgamma, dbeta.
  */
 int msn_layernorm_fwd(const float* x, int64_t ldx, int64_t rows, int cols, const float* gamma,
                       const float* beta, float eps, float* y, int64_t ldy, float* mean, float* rstd,
                       msn_stream_t stream);
 size_t msn_layernorm_bwd_workspace_bytes(int64_t rows, int cols);
 int msn_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t rows, int cols,
-                      const float* mean, const float* rstd, const float* gamma, float* dx, int64_t lddx,
-                      float* dgamma, float* dbeta, void* ws, size_t ws_bytes, msn_stream_t stream);
+                      const float* mean, const float* rstd, const float* gamma, const float* add,
+                      int64_t ldadd, float* dx, int64_t lddx, float* dgamma, float* dbeta, void* ws,
+                      size_t ws_bytes, msn_stream_t stream);
 
 /* y = x / ||x||_2 per row, NO epsilon (src/models_multimodal.py:279,286,293,304); inv_norm[r] = 1/||x_r||.
  * bwd: dx = inv_norm * (dy - y <y, dy>). */
@@ -213,6 +215,13 @@ int msn_dwconv_bwd(const float* dpre, const float* x, const float* w, int B, int
  */
 int msn_radam_step(const void* table, int n_tensors, int64_t max_numel, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int64_t step, msn_stream_t stream);
+
+/* Build-defined ViT image encoder (not in the reference; fills its `image_encoder` slot):
+ * tok[b][0] = cls + pos[0], tok[b][1+i] = patch[b][i] + pos[1+i]  with T = 1 + n_patches, and the
+ * compaction dpatch[b][i] = dtok[b][1+i] used by the backward. */
+int msn_vit_tokens_fwd(const float* patch, const float* cls, const float* pos, int64_t B, int T, int e,
+                       float* tok, msn_stream_t stream);
+int msn_vit_tokens_bwd(const float* dtok, int64_t B, int T, int e, float* dpatch, msn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -31,7 +31,9 @@ SIGNATURES = {
     "msn_layernorm_fwd": (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_f32, c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
     "msn_layernorm_bwd_workspace_bytes": (c_size, [c_i64, c_int]),
     "msn_layernorm_bwd": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
-                                  c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+                                  c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "msn_vit_tokens_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr]),
+    "msn_vit_tokens_bwd": (c_int, [c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr]),
     "msn_l2norm_fwd": (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_i64, c_ptr, c_ptr]),
     "msn_l2norm_bwd": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr]),
     "msn_time_embed_fwd": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr,

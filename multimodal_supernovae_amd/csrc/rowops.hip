@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ x, int64_t ldx, RowGeom g,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, float* __restrict__ dx,
-                                                     int64_t lddx, float* __restrict__ part) {
+                                                     int64_t lddx, float* __restrict__ part,
+                                                     const float* __restrict__ add, int64_t ldadd) {
     constexpr int RG = 256 / LPR;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [RG][2][cols]
     const int lr = threadIdx.x % LPR, rg = threadIdx.x / LPR;
@@ -128,6 +129,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             d[k].y = rs * (d[k].y - m1 - v[k].y * m2);
             d[k].z = rs * (d[k].z - m1 - v[k].z * m2);
             d[k].w = rs * (d[k].w - m1 - v[k].w * m2);
+        }
+        if (add) {  // gradient arriving through the residual branch around this LayerNorm
+            float4 a[NCH];
+            load_row<LPR>(a, add + r * ldadd, g.cols, lr);
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) { d[k].x += a[k].x; d[k].y += a[k].y; d[k].z += a[k].z; d[k].w += a[k].w; }
         }
         store_row<LPR>(d, dx + r * lddx, g.cols, lr);
     }
@@ -341,6 +348,30 @@ __global__ void mask_tokens_kernel(const float* __restrict__ x, const uint8_t* _
         y[i] = mask[i / e] ? x[i] : 0.f * x[i];
 }
 
+// ---------------------------------------------------------------- ViT token assembly (build-defined)
+// tok[b][0] = cls + pos[0];  tok[b][1+i] = patch[b][i] + pos[1+i]      (T = 1 + n_patches)
+__global__ void vit_tokens_fwd_kernel(const float* __restrict__ patch, const float* __restrict__ cls,
+                                      const float* __restrict__ pos, int64_t B, int T, int e, float* __restrict__ tok) {
+    const int64_t total = B * T * e;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % e);
+        const int t = (int)((i / e) % T);
+        const int64_t b = i / ((int64_t)e * T);
+        const float base = t == 0 ? cls[c] : patch[(b * (T - 1) + (t - 1)) * e + c];
+        tok[i] = base + pos[(int64_t)t * e + c];
+    }
+}
+// dpatch[b][i] = dtok[b][1+i]  (compaction for the patch-embedding wgrad GEMM)
+__global__ void vit_tokens_bwd_kernel(const float* __restrict__ dtok, int64_t B, int T, int e, float* __restrict__ dpatch) {
+    const int64_t total = B * (T - 1) * e;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % e);
+        const int t = (int)((i / e) % (T - 1));
+        const int64_t b = i / ((int64_t)e * (T - 1));
+        dpatch[i] = dtok[(b * T + t + 1) * e + c];
+    }
+}
+
 static int pick_lpr(int cols) {
     const int chunks = cols / 4;
     if (chunks <= 4 * NCH) return 4;
@@ -393,10 +424,13 @@ extern "C" size_t msn_layernorm_bwd_workspace_bytes(int64_t rows, int cols) {
 }
 
 extern "C" int msn_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t rows, int cols,
-                                 const float* mean, const float* rstd, const float* gamma, float* dx, int64_t lddx,
-                                 float* dgamma, float* dbeta, void* ws, size_t ws_bytes, msn_stream_t stream) {
+                                 const float* mean, const float* rstd, const float* gamma, const float* add,
+                                 int64_t ldadd, float* dx, int64_t lddx, float* dgamma, float* dbeta, void* ws,
+                                 size_t ws_bytes, msn_stream_t stream) {
     if (int rc = check_rows("msn_layernorm_bwd", rows, cols, {lddy, ldx, lddx}, {dy, x, dx, gamma})) return rc;
     MSN_REQUIRE(mean && rstd && dgamma && dbeta, "msn_layernorm_bwd: null pointer");
+    MSN_REQUIRE(!add || (ldadd >= cols && ldadd % 4 == 0 && (reinterpret_cast<uintptr_t>(add) & 15) == 0),
+                "msn_layernorm_bwd: bad residual-gradient operand");
     const int lpr = pick_lpr(cols);
     const int grid = ln_bwd_grid(rows, lpr);
     MSN_REQUIRE(ws && ws_bytes >= sizeof(float) * 2 * (size_t)cols * grid, "msn_layernorm_bwd: workspace too small");
@@ -404,7 +438,7 @@ extern "C" int msn_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* part = static_cast<float*>(ws);
     const size_t lds = sizeof(float) * 2 * (size_t)cols * (256 / lpr);
-    MSN_LPR_DISPATCH(ln_bwd_kernel, lpr, dim3(grid), lds, st, dy, lddy, x, ldx, g, mean, rstd, gamma, dx, lddx, part)
+    MSN_LPR_DISPATCH(ln_bwd_kernel, lpr, dim3(grid), lds, st, dy, lddy, x, ldx, g, mean, rstd, gamma, dx, lddx, part, add, ldadd)
     MSN_LAUNCH_CHECK();
     hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)cdiv(2 * cols, 128)), dim3(128), 0, st, part, grid, 2 * cols,
                        dgamma, dbeta, cols);
@@ -503,6 +537,22 @@ extern "C" int msn_mask_tokens(const float* x, const uint8_t* mask, int64_t rows
     const int64_t total = rows * e;
     hipLaunchKernelGGL(mask_tokens_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 4096)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, mask, rows, e, y);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" int msn_vit_tokens_fwd(const float* patch, const float* cls, const float* pos, int64_t B, int T, int e,
+                                  float* tok, msn_stream_t stream) {
+    MSN_REQUIRE(patch && cls && pos && tok && B > 0 && T > 1 && e > 0, "msn_vit_tokens_fwd: bad arguments");
+    hipLaunchKernelGGL(vit_tokens_fwd_kernel, dim3((unsigned)std::min<int64_t>(cdiv(B * T * e, 256), 4096)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), patch, cls, pos, B, T, e, tok);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+extern "C" int msn_vit_tokens_bwd(const float* dtok, int64_t B, int T, int e, float* dpatch, msn_stream_t stream) {
+    MSN_REQUIRE(dtok && dpatch && B > 0 && T > 1 && e > 0, "msn_vit_tokens_bwd: bad arguments");
+    hipLaunchKernelGGL(vit_tokens_bwd_kernel, dim3((unsigned)std::min<int64_t>(cdiv(B * (T - 1) * e, 256), 4096)),
+                       dim3(256), 0, static_cast<hipStream_t>(stream), dtok, B, T, e, dpatch);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }

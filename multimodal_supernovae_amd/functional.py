@@ -434,3 +434,130 @@ class _ConvMixerTrunk(torch.autograd.Function):
 
 def convmixer_trunk(img, training, depth, patch, flat_params):
     return _ConvMixerTrunk.apply(img, training, depth, patch, *flat_params)
+
+
+# ------------------------------------------------------------- pre-norm (ViT) transformer block
+class _PreNormBlock(torch.autograd.Function):
+    """Build-defined ViT block (not in the reference): x += Attn(LN1(x)); x += MLP_GELU(LN2(x)),
+    packed qkv projection with bias, scale 1/sqrt(head_dim), no mask.  Same fusion plan as the
+    post-norm block: residual adds in GEMM epilogues / the LayerNorm backward kernel."""
+
+    @staticmethod
+    def forward(ctx, x, heads, eps, g1, b1, wqkv, bqkv, wo, bo, g2, b2, w1, c1, w2, c2):
+        B, T, e = x.shape
+        x2 = _c(x).view(B * T, e)
+        scale = 1.0 / math.sqrt(e // heads)
+        h1, m1, r1 = ops.layernorm_fwd(x2, g1, b1, eps)
+        qkv = sgemm(h1, wqkv, OP_N, OP_T, bias=bqkv)
+        q3 = qkv.view(B, T, 3 * e)
+        a, lse = ops.attention_fwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], None, heads, scale)
+        a2 = a.view(B * T, e)
+        x1 = sgemm(a2, wo, OP_N, OP_T, bias=bo, epilogue=EPI_ADD, aux=x2)
+        h2, m2, r2 = ops.layernorm_fwd(x1, g2, b2, eps)
+        pre = torch.empty((B * T, w1.shape[0]), dtype=torch.float32, device=x.device)
+        f = sgemm(h2, w1, OP_N, OP_T, bias=c1, epilogue=EPI_GELU, aux=pre)
+        out = sgemm(f, w2, OP_N, OP_T, bias=c2, epilogue=EPI_ADD, aux=x1)
+        ctx.dims = (B, T, e, heads, scale)
+        ctx.save_for_backward(x2, g1, wqkv, wo, g2, w1, w2, m1, r1, h1, qkv, a2, lse, x1, m2, r2, h2, pre, f)
+        return out.view(B, T, e)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, e, heads, scale = ctx.dims
+        (x2, g1, wqkv, wo, g2, w1, w2, m1, r1, h1, qkv, a2, lse, x1, m2, r2, h2, pre, f) = ctx.saved_tensors
+        d2 = _c(dy).view(B * T, e)
+        dw2 = sgemm(d2, f, OP_T, OP_N)
+        dc2 = colsum(d2)
+        dpre = sgemm(d2, w2, OP_N, OP_N, epilogue=EPI_GELU_BWD, aux=pre)
+        dw1 = sgemm(dpre, h2, OP_T, OP_N)
+        dc1 = colsum(dpre)
+        dh2 = sgemm(dpre, w1, OP_N, OP_N)
+        dx1, dg2, db2 = ops.layernorm_bwd(dh2, x1, m2, r2, g2, add=d2)        # + skip connection
+        dwo = sgemm(dx1, a2, OP_T, OP_N)
+        dbo = colsum(dx1)
+        da = sgemm(dx1, wo, OP_N, OP_N)
+        dqkv = torch.empty_like(qkv)
+        q3, d3 = qkv.view(B, T, 3 * e), dqkv.view(B, T, 3 * e)
+        ops.attention_bwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], None, heads, scale, a2.view(B, T, e), lse,
+                          da.view(B, T, e), d3[..., :e], d3[..., e:2 * e], d3[..., 2 * e:])
+        dwqkv = sgemm(dqkv, h1, OP_T, OP_N)
+        dbqkv = colsum(dqkv)
+        dh1 = sgemm(dqkv, wqkv, OP_N, OP_N)
+        dx, dg1, db1 = ops.layernorm_bwd(dh1, x2, m1, r1, g1, add=dx1)          # + skip connection
+        return (dx.view(B, T, e), None, None, dg1, db1, dwqkv, dbqkv, dwo, dbo, dg2, db2, dw1, dc1, dw2, dc2)
+
+
+def pre_norm_block(x, heads, p, eps=1e-6):
+    return _PreNormBlock.apply(x, heads, eps, *p)
+
+
+class _VitTokens(torch.autograd.Function):
+    """[cls ; patch embeddings] + positional embedding."""
+
+    @staticmethod
+    def forward(ctx, patch_emb, cls, pos, B, T):
+        return ops.vit_tokens_fwd(_c(patch_emb), _c(cls).view(-1), _c(pos).view(T, -1), B, T)
+
+    @staticmethod
+    def backward(ctx, dtok):
+        dtok = _c(dtok)
+        B, T, e = dtok.shape
+        dpos = colsum(dtok.view(B, T * e)).view(1, T, e)
+        dcls = dpos[:, :1, :].clone()
+        return ops.vit_tokens_bwd(dtok), dcls, dpos, None, None
+
+
+def vit_tokens(patch_emb, cls, pos, B, T):
+    return _VitTokens.apply(patch_emb, cls, pos, B, T)
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, b, eps):
+        y, m, r = ops.layernorm_fwd(_c(x), g, b, eps)
+        ctx.save_for_backward(_c(x), m, r, g)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, m, r, g = ctx.saved_tensors
+        dx, dg, db = ops.layernorm_bwd(_c(dy), x, m, r, g)
+        return dx, dg, db, None
+
+
+def layer_norm(x, g, b, eps=1e-5):
+    return _LayerNorm.apply(x, g, b, eps)
+
+
+class _Patchify(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, p):
+        ctx.shape, ctx.p = tuple(img.shape), p
+        return ops.patchify(_c(img.float()), p)
+
+    @staticmethod
+    def backward(ctx, dpatches):
+        return ops.unpatchify(_c(dpatches), ctx.shape, ctx.p), None
+
+
+def patchify(img, p):
+    return _Patchify.apply(img, p)
+
+
+class _TakeToken(torch.autograd.Function):
+    """x[:, idx, :] of a (B, T, e) token tensor (the class token read-out) with a dense backward."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.shape, ctx.idx = tuple(x.shape), idx
+        return x[:, idx, :].contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = torch.zeros(ctx.shape, dtype=dy.dtype, device=dy.device)
+        dx[:, ctx.idx, :] = dy
+        return dx, None
+
+
+def take_token(x, idx):
+    return _TakeToken.apply(x, idx)

@@ -5,6 +5,10 @@ import torch
 from . import _lib
 from ._lib import check, lib, ptr, stream_ptr
 
+# bench.py sets this to a list to time every GEMM launch of one step with HIP events recorded on the
+# launch stream: entries are (start_event, end_event, algorithmic_flops).  None = no instrumentation.
+GEMM_PROFILE = None
+
 OP_N, OP_T = 0, 1
 EPI_NONE, EPI_RELU, EPI_GELU, EPI_RELU_BWD, EPI_GELU_BWD, EPI_ADD = range(6)
 
@@ -38,9 +42,16 @@ def sgemm(a, b, op_a=OP_N, op_b=OP_T, bias=None, epilogue=EPI_NONE, aux=None, ou
     if aux is not None:
         _f32c(aux, "aux")
         assert aux.stride(1) == 1
+    prof = GEMM_PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     check(L.msn_sgemm(op_a, op_b, M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(c),
                       c.stride(0) if c.numel() else max(N, 1), ptr(bias), epilogue, ptr(aux),
                       aux.stride(0) if aux is not None else 0, ptr(ws), ws_bytes, stream_ptr()), "msn_sgemm")
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, 2.0 * M * N * K))
     return c
 
 
@@ -78,8 +89,9 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5):
     return y.view(x.shape), mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma):
+def layernorm_bwd(dy, x, mean, rstd, gamma, add=None):
     dy2, x2 = _rows2d(_f32c(dy, "dy")), _rows2d(x)
+    add2 = _rows2d(add) if add is not None else None
     rows, cols = x2.shape
     dx = torch.empty((rows, cols), dtype=torch.float32, device=x.device)
     dg = torch.empty(cols, dtype=torch.float32, device=x.device)
@@ -88,8 +100,8 @@ def layernorm_bwd(dy, x, mean, rstd, gamma):
     nb = L.msn_layernorm_bwd_workspace_bytes(rows, cols)
     ws = _workspace(nb, x.device)
     check(L.msn_layernorm_bwd(ptr(dy2), dy2.stride(0), ptr(x2), x2.stride(0), rows, cols, ptr(mean), ptr(rstd),
-                              ptr(gamma), ptr(dx), cols, ptr(dg), ptr(db), ptr(ws), nb, stream_ptr()),
-          "msn_layernorm_bwd")
+                              ptr(gamma), ptr(add2), add2.stride(0) if add2 is not None else 0, ptr(dx), cols, ptr(dg),
+                              ptr(db), ptr(ws), nb, stream_ptr()), "msn_layernorm_bwd")
     return dx.view(x.shape), dg, db
 
 
@@ -290,3 +302,19 @@ def dwconv_bwd(dpre, x, w, B, gh, gw, add=None, want_bias=True):
     check(L.msn_dwconv_bwd(ptr(_f32c(dpre, "dpre")), ptr(x), ptr(w), B, gh, gw, C, k, ptr(add), ptr(dx), ptr(dw),
                            ptr(dbias), ptr(ws), nb, stream_ptr()), "msn_dwconv_bwd")
     return dx, dw, dbias
+
+
+# ------------------------------------------------------------------------------ ViT token assembly
+def vit_tokens_fwd(patch_emb, cls, pos, B, T):
+    e = patch_emb.shape[-1]
+    tok = torch.empty((B, T, e), dtype=torch.float32, device=patch_emb.device)
+    check(lib().msn_vit_tokens_fwd(ptr(_f32c(patch_emb, "patch_emb")), ptr(cls), ptr(pos), B, T, e, ptr(tok),
+                                   stream_ptr()), "msn_vit_tokens_fwd")
+    return tok
+
+
+def vit_tokens_bwd(dtok):
+    B, T, e = dtok.shape
+    dpatch = torch.empty((B * (T - 1), e), dtype=torch.float32, device=dtok.device)
+    check(lib().msn_vit_tokens_bwd(ptr(_f32c(dtok, "dtok")), B, T, e, ptr(dpatch), stream_ptr()), "msn_vit_tokens_bwd")
+    return dpatch

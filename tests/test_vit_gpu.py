@@ -1,0 +1,54 @@
+"""GPU parity of the build-defined ViT image encoder against its CPU specification
+(oracle/build_defined.py).  Not in the reference: "parity unpinned by the reference"."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, what, rtol=1e-3):
+    scale = float(b.abs().max()) + 1e-6
+    torch.testing.assert_close(a, b.to(a.dtype), rtol=rtol, atol=rtol * scale * 0.1, msg=lambda m: f"{what}: {m}")
+
+
+@pytest.mark.parametrize("img,patch,emb,depth,heads,B", [(16, 4, 32, 2, 4, 3), (64, 8, 384, 2, 6, 4), (32, 16, 64, 1, 2, 2)])
+def test_vit_forward_backward(img, patch, emb, depth, heads, B):
+    from multimodal_supernovae_amd.encoders import VisionTransformer
+    from oracle.build_defined import vision_transformer
+    torch.manual_seed(img + emb)
+    m = VisionTransformer(img_size=img, patch_size=patch, channels=3, emb=emb, depth=depth, heads=heads, n_out=8)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+    P = {k: v.clone().requires_grad_() for k, v in m.state_dict().items()}
+    x = torch.rand(B, 3, img, img)
+    cot = torch.randn(B, 8)
+    xr = x.clone().requires_grad_()
+    ref = vision_transformer(P, "", xr, patch=patch, heads=heads, depth=depth)
+    (ref * cot).sum().backward()
+    m.cuda()
+    xg = x.cuda().requires_grad_()
+    y = m(xg)
+    close(y.detach().cpu(), ref.detach(), "y")
+    y.backward(cot.cuda())
+    close(xg.grad.cpu(), xr.grad, "dx")
+    for k, p in m.named_parameters():
+        close(p.grad.cpu(), P[k].grad, "grad " + k, rtol=2e-3)
+
+
+def test_vit_fills_the_image_encoder_slot():
+    from multimodal_supernovae_amd.encoders import VisionTransformer
+    from multimodal_supernovae_amd.models_multimodal import LightCurveImageCLIP
+    tk = dict(n_out=8, emb=16, heads=4, depth=1, dropout=0.0, time_norm=1e4, agg="mean")
+    ck = dict(dim=8, depth=1, channels=3, kernel_size=5, patch_size=4, n_out=8, dropout_prob=0.0)
+    model = LightCurveImageCLIP(enc_dim=16, nband=2, transformer_kwargs=tk, conv_kwargs=ck,
+                                combinations=["host_galaxy", "lightcurve"], loss="softmax")
+    model.image_encoder = VisionTransformer(img_size=16, patch_size=4, emb=32, depth=1, heads=4, n_out=8)
+    model.cuda().train()
+    B = 8
+    batch = (torch.rand(B, 3, 16, 16).cuda(), torch.randn(B, 12).cuda(), torch.rand(B, 12).cuda(),
+             torch.ones(B, 12, dtype=torch.bool).cuda(), None, None, None, None, None)
+    loss = model.training_step(batch, 0)
+    loss.backward()
+    assert torch.isfinite(loss.detach()) and all(p.grad is not None for p in model.parameters())
