@@ -37,20 +37,31 @@ struct GemmArgs {
     float* partial;   // [splits][M][N] when splits > 1
 };
 
-// Load 4 consecutive elements (r, c..c+3) of a stored row-major matrix, zero beyond [nr, nc).
-__device__ __forceinline__ float4 load4_guard(const float* __restrict__ base, int64_t r, int64_t c,
-                                              int64_t ld, int64_t nr, int64_t nc, bool vec_ok) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < nr) {
-        const float* p = base + r * ld + c;
-        if (vec_ok && c + 3 < nc) {
-            v = *reinterpret_cast<const float4*>(p);
-        } else {
-            if (c < nc) v.x = p[0];
-            if (c + 1 < nc) v.y = p[1];
-            if (c + 2 < nc) v.z = p[2];
-            if (c + 3 < nc) v.w = p[3];
-        }
+// Load 4 consecutive elements (r, c..c+3) of a stored row-major matrix from an address CLAMPED into
+// the matrix; `ok` bit j says whether element j is really inside [nr, nc).  Branch-free and with the
+// zero-masking deferred to the LDS write (OperandTile::stash), so that a K-step's loads issue back to
+// back, stay in flight across the MFMA block of the previous K-step, and are waited for only when
+// they are written to LDS.  (A guarded `if (in range) load`, or even a wave-uniform runtime
+// `if (aligned)`, makes hipcc wait vmcnt(0) after every load; masking right after the load makes it
+// wait before the MFMAs.)  VEC is chosen on the host: base 16-B aligned, ld % 4 == 0 and the
+// contiguous extent % 4 == 0, so a vector never straddles nc; otherwise the scalar instantiation runs.
+template <bool VEC>
+__device__ __forceinline__ float4 load4_clamped(const float* __restrict__ base, int64_t r, int64_t c, int64_t ld,
+                                                int64_t nr, int64_t nc, unsigned& ok) {
+    const bool in_r = r < nr;
+    const float* row = base + (in_r ? r : nr - 1) * ld;
+    float4 v;
+    if (VEC) {
+        const bool in = in_r && c < nc;
+        v = *reinterpret_cast<const float4*>(row + (c < nc ? c : 0));
+        ok = in ? 0xFu : 0u;
+    } else {
+        const int64_t last = nc - 1;
+        v.x = row[c < nc ? c : last];
+        v.y = row[c + 1 < nc ? c + 1 : last];
+        v.z = row[c + 2 < nc ? c + 2 : last];
+        v.w = row[c + 3 < nc ? c + 3 : last];
+        ok = in_r ? ((c < nc ? 1u : 0u) | (c + 1 < nc ? 2u : 0u) | (c + 2 < nc ? 4u : 0u) | (c + 3 < nc ? 8u : 0u)) : 0u;
     }
     return v;
 }
@@ -63,33 +74,43 @@ struct OperandTile {
     static constexpr int kLoads = ROWS / 32;  // float4 per thread per K-step (256 threads)
 
     // row0: first row (M or N index) of this tile; k0: first k.  `nrows` = M or N, `nk` = K limit.
-    __device__ static __forceinline__ void fetch(float4 (&reg)[kLoads], const float* __restrict__ g,
-                                                 int64_t ld, int64_t row0, int64_t nrows, int64_t k0,
-                                                 int64_t nk, bool vec_ok) {
+    // ok: 4 validity bits per load, consumed by stash().
+    template <bool VEC>
+    __device__ static __forceinline__ void fetch(float4 (&reg)[kLoads], unsigned& ok, const float* __restrict__ g,
+                                                 int64_t ld, int64_t row0, int64_t nrows, int64_t k0, int64_t nk) {
         const int t = threadIdx.x;
+        ok = 0u;
 #pragma unroll
         for (int i = 0; i < kLoads; ++i) {
             const int idx = t + 256 * i;
+            unsigned m;
             if (KMAJOR) {  // stored [K][rows]: 4 consecutive rows of one k
                 const int k = idx / (ROWS / 4), q = idx % (ROWS / 4);
-                reg[i] = load4_guard(g, k0 + k, row0 + 4 * q, ld, nk, nrows, vec_ok);
+                reg[i] = load4_clamped<VEC>(g, k0 + k, row0 + 4 * q, ld, nk, nrows, m);
             } else {  // stored [rows][K]: 4 consecutive k of one row
                 const int r = idx / (BK / 4), q = idx % (BK / 4);
-                reg[i] = load4_guard(g, row0 + r, k0 + 4 * q, ld, nrows, nk, vec_ok);
+                reg[i] = load4_clamped<VEC>(g, row0 + r, k0 + 4 * q, ld, nrows, nk, m);
             }
+            ok |= m << (4 * i);
         }
     }
-    __device__ static __forceinline__ void stash(const float4 (&reg)[kLoads], float* lds) {
+    __device__ static __forceinline__ void stash(const float4 (&reg)[kLoads], unsigned ok, float* lds) {
         const int t = threadIdx.x;
 #pragma unroll
         for (int i = 0; i < kLoads; ++i) {
             const int idx = t + 256 * i;
+            const unsigned m = ok >> (4 * i);
+            float4 v = reg[i];
+            v.x = (m & 1u) ? v.x : 0.f;
+            v.y = (m & 2u) ? v.y : 0.f;
+            v.z = (m & 4u) ? v.z : 0.f;
+            v.w = (m & 8u) ? v.w : 0.f;
             if (KMAJOR) {
                 const int k = idx / (ROWS / 4), q = idx % (ROWS / 4);
-                *reinterpret_cast<float4*>(lds + k * kStride + 4 * q) = reg[i];
+                *reinterpret_cast<float4*>(lds + k * kStride + 4 * q) = v;
             } else {
                 const int r = idx / (BK / 4), q = idx % (BK / 4);
-                *reinterpret_cast<float4*>(lds + r * kStride + 4 * q) = reg[i];
+                *reinterpret_cast<float4*>(lds + r * kStride + 4 * q) = v;
             }
         }
     }
@@ -111,7 +132,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + bid / 8;
 }
 
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM>
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, bool VEC>
 __global__ __launch_bounds__(256) void sgemm_kernel(const GemmArgs p) {
     using TA = OperandTile<BM, AKM>;
     using TB = OperandTile<BN, BKM>;
@@ -135,8 +156,6 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmArgs p) {
     const int h = lane >> 5, l32 = lane & 31;
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
 
-    const bool a_vec = (p.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
-    const bool b_vec = (p.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -147,12 +166,13 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[TA::kLoads], rb[TB::kLoads];
+    unsigned oka = 0u, okb = 0u;
     const int nkt = (int)((k_end - k_begin + BK - 1) / BK);
     if (nkt > 0) {
-        TA::fetch(ra, p.A, p.lda, m0, p.M, k_begin, k_end, a_vec);
-        TB::fetch(rb, p.B, p.ldb, n0, p.N, k_begin, k_end, b_vec);
-        TA::stash(ra, a_buf(0));
-        TB::stash(rb, b_buf(0));
+        TA::template fetch<VEC>(ra, oka, p.A, p.lda, m0, p.M, k_begin, k_end);
+        TB::template fetch<VEC>(rb, okb, p.B, p.ldb, n0, p.N, k_begin, k_end);
+        TA::stash(ra, oka, a_buf(0));
+        TB::stash(rb, okb, b_buf(0));
     }
     __syncthreads();
 
@@ -161,8 +181,8 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmArgs p) {
         const bool more = kt + 1 < nkt;
         if (more) {  // prefetch the next K-step into registers while this one is multiplied
             const int64_t k0 = k_begin + (int64_t)(kt + 1) * BK;
-            TA::fetch(ra, p.A, p.lda, m0, p.M, k0, k_end, a_vec);
-            TB::fetch(rb, p.B, p.ldb, n0, p.N, k0, k_end, b_vec);
+            TA::template fetch<VEC>(ra, oka, p.A, p.lda, m0, p.M, k0, k_end);
+            TB::template fetch<VEC>(rb, okb, p.B, p.ldb, n0, p.N, k0, k_end);
         }
         const float* as = a_buf(cur);
         const float* bs = b_buf(cur);
@@ -184,8 +204,8 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmArgs p) {
                 }
         }
         if (more) {
-            TA::stash(ra, a_buf(cur ^ 1));
-            TB::stash(rb, b_buf(cur ^ 1));
+            TA::stash(ra, oka, a_buf(cur ^ 1));
+            TB::stash(rb, okb, b_buf(cur ^ 1));
         }
         __syncthreads();
     }
@@ -259,8 +279,16 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int64_t slab
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const GemmArgs& a, int opA, int opB, hipStream_t st) {
     const dim3 grid(a.tiles_m * a.tiles_n, a.splits), block(256);
-#define MSN_GEMM_GO(AKM, BKM) \
-    { hipLaunchKernelGGL((sgemm_kernel<BM, BN, WM, WN, AKM, BKM>), grid, block, 0, st, a); }
+    // 16-byte operand loads need: base aligned, ld % 4 == 0, contiguous extent % 4 == 0 (K for a
+    // K-contiguous operand, M / N for a K-major one)
+    const int64_t a_ext = opA == MSN_OP_T ? a.M : a.K, b_ext = opB == MSN_OP_N ? a.N : a.K;
+    const bool vec = (a.lda % 4 == 0) && (a_ext % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0) &&
+                     (a.ldb % 4 == 0) && (b_ext % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0);
+#define MSN_GEMM_GO(AKM, BKM)                                                                               \
+    {                                                                                                       \
+        if (vec) hipLaunchKernelGGL((sgemm_kernel<BM, BN, WM, WN, AKM, BKM, true>), grid, block, 0, st, a); \
+        else hipLaunchKernelGGL((sgemm_kernel<BM, BN, WM, WN, AKM, BKM, false>), grid, block, 0, st, a);    \
+    }
     if (opA == MSN_OP_N && opB == MSN_OP_T) MSN_GEMM_GO(false, false)
     else if (opA == MSN_OP_N && opB == MSN_OP_N) MSN_GEMM_GO(false, true)
     else if (opA == MSN_OP_T && opB == MSN_OP_N) MSN_GEMM_GO(true, true)
