@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--per-gpu-batch", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-table", action="store_true", help="per-shape GEMM timing of one step on stderr")
     ap.add_argument("--cpu-sample-batch", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=2)
     args = ap.parse_args()
@@ -175,11 +176,21 @@ def main():
     step()
     torch.cuda.synchronize()
     prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
-    gemm_ms = sum(a.elapsed_time(c) for a, c, _ in prof)
-    gemm_flops = sum(f for _, _, f in prof)
+    gemm_ms = sum(e[0].elapsed_time(e[1]) for e in prof)
+    gemm_flops = sum(e[2] for e in prof)
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     peak = 157.3  # TFLOP/s, dense fp32 matrix (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md
 
+    if rank == 0 and args.gemm_table:
+        table = {}
+        for e in prof:
+            t = table.setdefault(e[3], [0, 0.0, 0.0])
+            t[0] += 1
+            t[1] += e[0].elapsed_time(e[1])
+            t[2] += e[2]
+        for key, (n, ms_, fl) in sorted(table.items(), key=lambda kv: -kv[1][1]):
+            print(f"# gemm opA={key[0]} opB={key[1]} M={key[2]:6d} N={key[3]:5d} K={key[4]:6d} epi={key[5]} calls={n:3d} "
+                  f"{ms_:8.3f} ms {fl / ms_ / 1e9:7.1f} TFLOP/s", file=sys.stderr)
     if rank == 0:
         ms = dt / args.steps * 1e3
         pairs = b * world * args.steps / dt

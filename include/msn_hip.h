@@ -51,9 +51,9 @@ int msn_device_count(void);
  * epilogue:
  *   MSN_EPI_NONE      C = acc + bias
  *   MSN_EPI_RELU      C = max(acc + bias, 0)
- *   MSN_EPI_GELU      C = gelu(acc + bias) (erf form); if aux != NULL also aux = acc + bias
+ *   MSN_EPI_GELU      C = gelu(acc + bias) (erf form); if aux != NULL also aux = gelu'(acc + bias)
  *   MSN_EPI_RELU_BWD  C = acc * (aux > 0)            (aux = forward ReLU output)
- *   MSN_EPI_GELU_BWD  C = acc * gelu'(aux)           (aux = forward pre-activation)
+ *   MSN_EPI_GELU_BWD  C = acc * aux                  (aux = the gelu' saved by the forward epilogue)
  *   MSN_EPI_ADD       C = acc + bias + aux           (residual add)
  * bias may be NULL.  `ws` is only needed for opA = T (split-K wgrad; see workspace_bytes).
  */
@@ -187,21 +187,22 @@ int msn_unpatchify(const float* dpatches, int B, int C, int H, int W, int p, flo
 /* nn.BatchNorm2d over the rows of x (rows x C), :58,70,77.  training != 0: two-pass batch statistics,
  * `mean` / `rstd` (C each) written, running_mean / running_var updated in place when non-NULL
  * (momentum; unbiased variance) ; training == 0: running statistics are used.  y = bn(x) (+ residual).
- * bwd: dx = dL/dx, additionally multiplied by gelu'(pre) when pre != NULL (conv -> GELU -> BN order). */
+ * bwd: dx = dL/dx, additionally multiplied by dact[.] when dact != NULL (conv -> GELU -> BN order:
+ * dact is the gelu' that msn_sgemm's GELU epilogue / msn_dwconv_gelu_fwd saved). */
 size_t msn_bn_workspace_bytes(int64_t rows, int C);
 int msn_batchnorm_fwd(const float* x, int64_t rows, int C, const float* gamma, const float* beta, float eps,
                       int training, float momentum, float* running_mean, float* running_var,
                       const float* residual, float* y, float* mean, float* rstd, void* ws, size_t ws_bytes,
                       msn_stream_t stream);
-int msn_batchnorm_bwd(const float* dy, const float* x, const float* pre, int64_t rows, int C,
+int msn_batchnorm_bwd(const float* dy, const float* x, const float* dact, int64_t rows, int C,
                       const float* mean, const float* rstd, const float* gamma, int training, float* dx,
                       float* dgamma, float* dbeta, void* ws, size_t ws_bytes, msn_stream_t stream);
 
 /* depthwise k x k conv, padding='same', + bias, + GELU (:65-69): x (B, gh, gw, C) channels-last,
- * w (C, 1, k, k).  fwd writes pre (conv + bias) and act = gelu(pre).
+ * w (C, 1, k, k).  fwd writes act = gelu(pre) and dact = gelu'(pre) with pre = conv + bias.
  * bwd: dx = conv^T(dpre) (+ add), dw (C,1,k,k), dbias (C; may be NULL). */
 int msn_dwconv_gelu_fwd(const float* x, const float* w, const float* bias, int B, int gh, int gw, int C,
-                        int k, float* pre, float* act, msn_stream_t stream);
+                        int k, float* dact, float* act, msn_stream_t stream);
 size_t msn_dwconv_bwd_workspace_bytes(int B, int C, int k);
 int msn_dwconv_bwd(const float* dpre, const float* x, const float* w, int B, int gh, int gw, int C, int k,
                    const float* add, float* dx, float* dw, float* dbias, void* ws, size_t ws_bytes,

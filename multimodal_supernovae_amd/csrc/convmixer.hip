@@ -152,7 +152,7 @@ __global__ void bn_bwd_finish_kernel(const float* __restrict__ part, int nblocks
     dbeta[c] = sa;
     dgamma[c] = sb;
 }
-// dx = gamma * rstd * (dy - [train](dbeta + xhat * dgamma) / rows), then * gelu'(pre) when pre != null
+// dx = gamma * rstd * (dy - [train](dbeta + xhat * dgamma) / rows), then * pre[] (= saved gelu') when non-null
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                     const float* __restrict__ pre, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -168,7 +168,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
             d -= (dbeta[c] + xhat * dgamma[c]) * inv_n;
         }
         d *= gamma[c] * rstd[c];
-        if (pre) d *= gelu_grad_f(pre[i]);
+        if (pre) d *= pre[i];   // pre[] holds gelu'(pre-activation)
         dx[i] = d;
     }
 }
@@ -193,8 +193,9 @@ __global__ void dwconv_fwd_kernel(const float* __restrict__ x, const float* __re
                 s = fmaf(w[((int64_t)c * g.k + u) * g.k + v], x[((b * g.gh + yy) * g.gw + xx) * g.C + c], s);
             }
         }
-        pre[i] = s;
-        act[i] = gelu_f(s);
+        const float cdf = 0.5f * (1.f + erff(s * 0.70710678118654752f));
+        pre[i] = cdf + s * 0.39894228040143268f * __expf(-0.5f * s * s);   // gelu'(pre), consumed by the BN backward
+        act[i] = s * cdf;
     }
 }
 // dx[b,y,x,c] = sum_{u,v} w[c,u,v] * dpre[b, y-u+pad, x-v+pad, c] (+ add)

@@ -211,35 +211,43 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmArgs p) {
     }
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h ----
+    // The aux operand of a 32x32 tile is read as one batch of 16 loads before any arithmetic, so the
+    // loads overlap instead of paying one memory round trip per element.
     const bool to_partial = p.splits > 1;
     float* out = to_partial ? p.partial + (int64_t)split * p.M * p.N : p.C;
     const int64_t ldo = to_partial ? p.N : p.ldc;
+    const int epi = to_partial ? MSN_EPI_NONE : p.epilogue;
+    const bool reads_aux = epi == MSN_EPI_RELU_BWD || epi == MSN_EPI_GELU_BWD || epi == MSN_EPI_ADD;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int64_t col = n0 + wn0 + 32 * j + l32;
-            if (col >= p.N) continue;
-            const float bv = (!to_partial && p.bias) ? p.bias[col] : 0.f;
+            const bool col_ok = col < p.N;
+            const float bv = (!to_partial && p.bias && col_ok) ? p.bias[col] : 0.f;
+            const int64_t row0 = m0 + wm0 + 32 * i + 4 * h;
+            float av[16];
+            if (reads_aux) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
+                    av[r] = (col_ok && row < p.M) ? p.aux[row * p.ldaux + col] : 0.f;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row >= p.M) continue;
+                const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
                 float v = acc[i][j][r] + bv;
-                if (!to_partial) {
-                    switch (p.epilogue) {
-                        case MSN_EPI_RELU: v = fmaxf(v, 0.f); break;
-                        case MSN_EPI_GELU:
-                            if (p.aux) p.aux[row * p.ldaux + col] = v;
-                            v = gelu_f(v);
-                            break;
-                        case MSN_EPI_RELU_BWD: v = p.aux[row * p.ldaux + col] > 0.f ? v : 0.f; break;
-                        case MSN_EPI_GELU_BWD: v *= gelu_grad_f(p.aux[row * p.ldaux + col]); break;
-                        case MSN_EPI_ADD: v += p.aux[row * p.ldaux + col]; break;
-                        default: break;
-                    }
-                }
-                out[row * ldo + col] = v;
+                if (epi == MSN_EPI_RELU) v = fmaxf(v, 0.f);
+                else if (epi == MSN_EPI_GELU) {
+                    const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
+                    if (p.aux && col_ok && row < p.M)
+                        p.aux[row * p.ldaux + col] = cdf + v * 0.39894228040143268f * __expf(-0.5f * v * v);
+                    v *= cdf;
+                } else if (epi == MSN_EPI_RELU_BWD) v = av[r] > 0.f ? v : 0.f;
+                else if (epi == MSN_EPI_GELU_BWD) v *= av[r];
+                else if (epi == MSN_EPI_ADD) v += av[r];
+                if (col_ok && row < p.M) out[row * ldo + col] = v;
             }
         }
 }
@@ -256,25 +264,44 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* _
     }
 }
 
-// Column sums, two deterministic stages: each block sums a slab of rows, then one pass over slabs.
-constexpr int kColsumRows = 256;
-__global__ void colsum_partial_kernel(const float* __restrict__ X, int64_t ldx, int64_t M, int64_t N,
-                                      float* __restrict__ part) {
-    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const int64_t r0 = (int64_t)blockIdx.y * kColsumRows, r1 = min(M, r0 + kColsumRows);
-    float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) s += X[r * ldx + n];
-    part[(int64_t)blockIdx.y * N + n] = s;
+// Column sums, two deterministic stages.  Stage 1: a 256-thread block = 4 row groups x 64 columns
+// streams its share of the rows (coalesced 256-B row segments, 4 rows in flight per thread) and
+// reduces the row groups through LDS -> part[block][N].  Stage 2: the same shape sums the slabs.
+constexpr int CS_COLS = 64, CS_RG = 4, CS_MAX_BLOCKS = 512;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int64_t ldx, int64_t M,
+                                                             int64_t N, float* __restrict__ part) {
+    __shared__ float red[CS_RG][CS_COLS];
+    const int cl = threadIdx.x % CS_COLS, rg = threadIdx.x / CS_COLS;
+    const int64_t n = (int64_t)blockIdx.y * CS_COLS + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (n < N) {
+        const int64_t stride = (int64_t)gridDim.x * CS_RG;
+        int64_t r = (int64_t)blockIdx.x * CS_RG + rg;
+        for (; r + 3 * stride < M; r += 4 * stride) {
+            s0 += X[r * ldx + n];
+            s1 += X[(r + stride) * ldx + n];
+            s2 += X[(r + 2 * stride) * ldx + n];
+            s3 += X[(r + 3 * stride) * ldx + n];
+        }
+        for (; r < M; r += stride) s0 += X[r * ldx + n];
+    }
+    red[rg][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rg == 0 && n < N) part[(int64_t)blockIdx.x * N + n] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, int64_t slabs, int64_t N,
-                                    float* __restrict__ out) {
-    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int64_t slabs, int64_t N,
+                                                           float* __restrict__ out) {
+    __shared__ float red[CS_RG][CS_COLS];
+    const int cl = threadIdx.x % CS_COLS, rg = threadIdx.x / CS_COLS;
+    const int64_t n = (int64_t)blockIdx.x * CS_COLS + cl;
     float s = 0.f;
-    for (int64_t k = 0; k < slabs; ++k) s += part[k * N + n];
-    out[n] = s;
+    if (n < N)
+        for (int64_t k = rg; k < slabs; k += CS_RG) s += part[k * N + n];
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && n < N) out[n] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
+static int colsum_blocks(int64_t M) { return (int)std::min<int64_t>(cdiv(M, 16 * CS_RG), CS_MAX_BLOCKS); }
 
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const GemmArgs& a, int opA, int opB, hipStream_t st) {
@@ -307,7 +334,7 @@ static void plan(int64_t M, int64_t N, int64_t K, int opA, int* bm, int* bn, int
     int s = 1;
     if (opA == MSN_OP_T && tiles < 512) {
         const int64_t ksteps = cdiv(K, BK);
-        s = (int)std::min<int64_t>(std::min<int64_t>(cdiv(1024, tiles), ksteps / 4 > 0 ? ksteps / 4 : 1), 64);
+        s = (int)std::min<int64_t>(std::min<int64_t>(cdiv(1024, tiles), ksteps / 4 > 0 ? ksteps / 4 : 1), 512);
         if (s < 1) s = 1;
     }
     int64_t per = cdiv(cdiv(K, s), BK) * BK;
@@ -384,20 +411,21 @@ extern "C" int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, cons
 
 extern "C" size_t msn_colsum_workspace_bytes(int64_t M, int64_t N) {
     if (M <= 0 || N <= 0) return 0;
-    return sizeof(float) * (size_t)cdiv(M, kColsumRows) * (size_t)N;
+    return sizeof(float) * (size_t)colsum_blocks(M) * (size_t)N;
 }
 
 extern "C" int msn_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, float* out, void* ws,
                           size_t ws_bytes, msn_stream_t stream) {
     MSN_REQUIRE(M > 0 && N > 0 && X && out && ldx >= N, "msn_colsum: bad arguments");
-    const int64_t slabs = cdiv(M, kColsumRows);
+    const int slabs = colsum_blocks(M);
     MSN_REQUIRE(ws && ws_bytes >= sizeof(float) * (size_t)slabs * (size_t)N, "msn_colsum: workspace too small");
+    MSN_REQUIRE(cdiv(N, CS_COLS) <= 65535, "msn_colsum: too many columns");
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* part = static_cast<float*>(ws);
-    const int bx = (int)cdiv(N, 64);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(bx, (unsigned)slabs), dim3(64), 0, st, X, ldx, M, N, part);
+    const unsigned by = (unsigned)cdiv(N, CS_COLS);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(slabs, by), dim3(256), 0, st, X, ldx, M, N, part);
     MSN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(bx), dim3(64), 0, st, part, slabs, N, out);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(by), dim3(256), 0, st, part, (int64_t)slabs, N, out);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }

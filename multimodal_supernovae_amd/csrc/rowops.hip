@@ -150,15 +150,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
-// out[i] = sum_b part[b][i], i < n
-__global__ void sum_slabs_kernel(const float* __restrict__ part, int nslabs, int n, float* __restrict__ out0,
-                                 float* __restrict__ out1, int split) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// out[i] = sum_b part[b][i], i < n : 4 slab groups x 64 columns per block, LDS-combined
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ part, int nslabs, int n,
+                                                        float* __restrict__ out0, float* __restrict__ out1, int split) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x % 64, g = threadIdx.x / 64;
+    const int i = blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int b = 0; b < nslabs; ++b) s += part[(int64_t)b * n + i];
-    if (i < split) out0[i] = s;
-    else out1[i - split] = s;
+    if (i < n)
+        for (int b = g; b < nslabs; b += 4) s += part[(int64_t)b * n + i];
+    red[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        const float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        if (i < split) out0[i] = t;
+        else out1[i - split] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------ L2 normalise
@@ -398,7 +405,7 @@ static int ln_grid(int64_t rows, int lpr) {
     return (int)std::min<int64_t>(cdiv(rows, 256 / lpr), 2048);
 }
 static int ln_bwd_grid(int64_t rows, int lpr) {
-    return (int)std::min<int64_t>(cdiv(rows, 4 * (256 / lpr)), 512);
+    return (int)std::min<int64_t>(cdiv(rows, 4 * (256 / lpr)), 256);
 }
 
 }  // namespace msn
@@ -440,7 +447,7 @@ extern "C" int msn_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
     const size_t lds = sizeof(float) * 2 * (size_t)cols * (256 / lpr);
     MSN_LPR_DISPATCH(ln_bwd_kernel, lpr, dim3(grid), lds, st, dy, lddy, x, ldx, g, mean, rstd, gamma, dx, lddx, part, add, ldadd)
     MSN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)cdiv(2 * cols, 128)), dim3(128), 0, st, part, grid, 2 * cols,
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)cdiv(2 * cols, 64)), dim3(256), 0, st, part, grid, 2 * cols,
                        dgamma, dbeta, cols);
     MSN_LAUNCH_CHECK();
     return MSN_OK;

@@ -6,7 +6,7 @@ from . import _lib
 from ._lib import check, lib, ptr, stream_ptr
 
 # bench.py sets this to a list to time every GEMM launch of one step with HIP events recorded on the
-# launch stream: entries are (start_event, end_event, algorithmic_flops).  None = no instrumentation.
+# launch stream: entries are (start_event, end_event, algorithmic_flops, (opA, opB, M, N, K, epilogue)).  None = no instrumentation.
 GEMM_PROFILE = None
 
 OP_N, OP_T = 0, 1
@@ -51,7 +51,7 @@ def sgemm(a, b, op_a=OP_N, op_b=OP_T, bias=None, epilogue=EPI_NONE, aux=None, ou
                       aux.stride(0) if aux is not None else 0, ptr(ws), ws_bytes, stream_ptr()), "msn_sgemm")
     if prof is not None:
         ev1.record()
-        prof.append((ev0, ev1, 2.0 * M * N * K))
+        prof.append((ev0, ev1, 2.0 * M * N * K, (op_a, op_b, M, N, K, epilogue)))
     return c
 
 

@@ -66,7 +66,9 @@ def test_sgemm_epilogues(M, N, K):
     torch.testing.assert_close(ops.sgemm(x, w, bias=bias, epilogue=ops.EPI_RELU).double(), pre.relu(), **tol)
     aux = torch.empty(M, N).cuda()
     y = ops.sgemm(x, w, bias=bias, epilogue=ops.EPI_GELU, aux=aux)
-    torch.testing.assert_close(aux.double(), pre, **tol)
+    pg = pre.clone().requires_grad_()
+    torch.nn.functional.gelu(pg).sum().backward()
+    torch.testing.assert_close(aux.double(), pg.grad, **tol)          # aux = gelu'(pre)
     torch.testing.assert_close(y.double(), torch.nn.functional.gelu(pre), **tol)
     res = torch.randn(M, N, generator=g).cuda()
     torch.testing.assert_close(ops.sgemm(x, w, bias=bias, epilogue=ops.EPI_ADD, aux=res).double(),
@@ -80,7 +82,7 @@ def test_sgemm_epilogues(M, N, K):
                                dh * (h.double() > 0), **tol)
     p = pre.clone().requires_grad_()
     torch.nn.functional.gelu(p).backward(dh)
-    torch.testing.assert_close(ops.sgemm(dy, w2, 0, 0, epilogue=ops.EPI_GELU_BWD, aux=pre.float()).double(),
+    torch.testing.assert_close(ops.sgemm(dy, w2, 0, 0, epilogue=ops.EPI_GELU_BWD, aux=aux).double(),
                                p.grad, **tol)
 
 
