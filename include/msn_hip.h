@@ -173,6 +173,11 @@ int msn_attention_bwd(const float* q, int64_t ldq, int64_t q_bstride, const floa
                       const float* dout, int64_t ldd, int64_t d_bstride, float* delta, float* dq,
                       int64_t lddq, int64_t dq_bstride, float* dk, int64_t lddk, int64_t dk_bstride,
                       float* dv, int64_t lddv, int64_t dv_bstride, msn_stream_t stream);
+/* Two implementations sit behind msn_attention_*: vector-ALU kernels (any head width <= 128, any
+ * length; the reference-native 8/16-wide heads) and matrix-core kernels (v_mfma_f32_16x16x4_f32; head
+ * width 16/32/48/64, <= 256 tokens: the ViT tower).  mode 0 = pick automatically (default),
+ * 1 = always vector-ALU, 2 = matrix cores whenever applicable.  Process-wide; meant for tests. */
+int msn_set_attention_path(int mode);
 
 /* ------------------------------------------------------------------------------------------
  * ConvMixer image tower pieces -- src/models_multimodal.py:38-95, channels-last token matrices

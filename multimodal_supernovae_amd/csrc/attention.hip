@@ -275,6 +275,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     }
 }
 
+// matrix-core path (attention_mfma.hip)
+struct MAttn {
+    const float* q; const float* k; const float* v; const float* o; const float* dout;
+    float* out; float* dq; float* dk; float* dv;
+    const uint8_t* mask;
+    float* lse;
+    float* delta;
+    int64_t ldq, ldk, ldv, ldo, ldd, lddq, lddk, lddv;
+    int64_t q_bs, k_bs, v_bs, o_bs, d_bs, dq_bs, dk_bs, dv_bs;
+    int B, H, Tq, Tk, hd;
+    float scale;
+};
+bool mattn_applicable(const MAttn& a);
+int mattn_forward(const MAttn& a, hipStream_t st);
+int mattn_backward(const MAttn& a, hipStream_t st);
+static int g_attn_path = 0;  // 0 = automatic, 1 = always the vector-ALU kernels, 2 = matrix cores whenever applicable
+
 static int pad_head(int s) {
     for (int c : {4, 8, 16, 32, 64, 128})
         if (s <= c) return c;
@@ -314,12 +331,26 @@ extern "C" int msn_attention_fwd(const float* q, int64_t ldq, int64_t q_bstride,
     a.q_bstride = q_bstride; a.k_bstride = k_bstride; a.v_bstride = v_bstride; a.o_bstride = o_bstride;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.s = head_dim; a.scale = scale;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (g_attn_path != 1) {
+        MAttn m = {};
+        m.q = q; m.k = k; m.v = v; m.out = out; m.mask = key_mask; m.lse = lse;
+        m.ldq = ldq; m.ldk = ldk; m.ldv = ldv; m.ldo = ldo;
+        m.q_bs = q_bstride; m.k_bs = k_bstride; m.v_bs = v_bstride; m.o_bs = o_bstride;
+        m.B = B; m.H = H; m.Tq = Tq; m.Tk = Tk; m.hd = head_dim; m.scale = scale;
+        if (mattn_applicable(m)) return mattn_forward(m, st);
+    }
     const int S = pad_head(head_dim);
     const unsigned bs = block_for(Tq);
     const dim3 grid((unsigned)cdiv(Tq, bs), H, B), block(bs);
-    hipStream_t st = static_cast<hipStream_t>(stream);
     MSN_ATTN_DISPATCH(attn_fwd_kernel, S, grid, block, st, a)
     MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" int msn_set_attention_path(int mode) {
+    MSN_REQUIRE(mode >= 0 && mode <= 2, "msn_set_attention_path: mode must be 0, 1 or 2");
+    g_attn_path = mode;
     return MSN_OK;
 }
 
@@ -340,8 +371,18 @@ extern "C" int msn_attention_bwd(const float* q, int64_t ldq, int64_t q_bstride,
     a.dout = dout; a.ldd = ldd; a.d_bstride = d_bstride; a.delta = delta;
     a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
     a.dq_bstride = dq_bstride; a.dk_bstride = dk_bstride; a.dv_bstride = dv_bstride;
-    const int S = pad_head(head_dim);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (g_attn_path != 1) {
+        MAttn m = {};
+        m.q = q; m.k = k; m.v = v; m.o = out; m.dout = dout; m.dq = dq; m.dk = dk; m.dv = dv;
+        m.mask = key_mask; m.lse = const_cast<float*>(lse); m.delta = delta;
+        m.ldq = ldq; m.ldk = ldk; m.ldv = ldv; m.ldo = ldo; m.ldd = ldd; m.lddq = lddq; m.lddk = lddk; m.lddv = lddv;
+        m.q_bs = q_bstride; m.k_bs = k_bstride; m.v_bs = v_bstride; m.o_bs = o_bstride; m.d_bs = d_bstride;
+        m.dq_bs = dq_bstride; m.dk_bs = dk_bstride; m.dv_bs = dv_bstride;
+        m.B = B; m.H = H; m.Tq = Tq; m.Tk = Tk; m.hd = head_dim; m.scale = scale;
+        if (mattn_applicable(m)) return mattn_backward(m, st);
+    }
+    const int S = pad_head(head_dim);
     {
         const unsigned bs = block_for(Tq);
         const dim3 grid((unsigned)cdiv(Tq, bs), H, B), block(bs);

@@ -118,12 +118,27 @@ def _attn_ref(q, k, v, mask, heads, scale):
     return torch.einsum("bhij,bjhs->bihs", p, vh).reshape(B, Tq, E)
 
 
+@pytest.fixture
+def attention_path():
+    """Select the vector-ALU (1) or matrix-core (2) attention kernels for one test, then restore auto."""
+    from multimodal_supernovae_amd import _lib
+
+    def choose(mode):
+        _lib.check(_lib.lib().msn_set_attention_path(mode))
+    yield choose
+    _lib.lib().msn_set_attention_path(0)
+
+
 @pytest.mark.parametrize("B,T,E,heads", [(3, 12, 16, 4), (2, 200, 64, 8), (2, 220, 32, 2), (1, 1024, 32, 2),
-                                        (2, 65, 384, 6), (2, 33, 24, 2), (1, 300, 96, 3)])
+                                        (2, 65, 384, 6), (2, 33, 24, 2), (1, 300, 96, 3), (1, 197, 768, 12),
+                                        (3, 80, 96, 2), (2, 256, 128, 4), (2, 16, 32, 2)])
 @pytest.mark.parametrize("masked", [False, True])
-def test_attention_fwd_bwd_packed_qkv(B, T, E, heads, masked):
-    """q|k|v live in one (B, T, 3E) buffer (the layout the transformer block uses)."""
+@pytest.mark.parametrize("path", [1, 2])
+def test_attention_fwd_bwd_packed_qkv(B, T, E, heads, masked, path, attention_path):
+    """q|k|v live in one (B, T, 3E) buffer (the layout the transformer block uses).  path 1 = vector-ALU
+    kernels, path 2 = matrix-core kernels wherever they apply (head width % 16 == 0, T <= 256)."""
     from multimodal_supernovae_amd import ops
+    attention_path(path)
     g = _g(B * T + E + heads)
     qkv = torch.randn(B, T, 3 * E, generator=g)
     dout = torch.randn(B, T, E, generator=g)
