@@ -267,7 +267,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* _
 // Column sums, two deterministic stages.  Stage 1: a 256-thread block = 4 row groups x 64 columns
 // streams its share of the rows (coalesced 256-B row segments, 4 rows in flight per thread) and
 // reduces the row groups through LDS -> part[block][N].  Stage 2: the same shape sums the slabs.
-constexpr int CS_COLS = 64, CS_RG = 4, CS_MAX_BLOCKS = 512;
+constexpr int CS_COLS = 64, CS_RG = 4, CS_MAX_BLOCKS = 128;
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int64_t ldx, int64_t M,
                                                              int64_t N, float* __restrict__ part) {
     __shared__ float red[CS_RG][CS_COLS];

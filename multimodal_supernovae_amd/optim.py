@@ -17,6 +17,21 @@ class RAdam(torch.optim.Optimizer):
             raise ValueError("invalid RAdam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
+    def _staging(self, n):
+        """Two pinned buffers used alternately; a buffer is rewritten only after the copy that last read it
+        has completed (its event), so the host may run a whole step ahead of the GPU."""
+        slots = getattr(self, "_pinned", None)
+        if slots is None:
+            slots = self._pinned = [[None, None], [None, None]]
+            self._slot = 0
+        self._slot ^= 1
+        slot = slots[self._slot]
+        if slot[1] is not None:
+            slot[1].synchronize()
+        if slot[0] is None or slot[0].numel() < n:
+            slot[0] = torch.empty(max(n, 1024), dtype=torch.int64).pin_memory()
+        return slot
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -49,7 +64,13 @@ class RAdam(torch.optim.Optimizer):
                     keep.append(g)
                     words += [p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()]
                     max_n = max(max_n, p.numel())
-                table = torch.tensor(words, dtype=torch.int64).to(dev, non_blocking=False)
+                # descriptor table: persistent pinned staging buffer + async copy, so the step never
+                # blocks the host on the stream (a pageable H2D copy would drain the whole queue)
+                slot = self._staging(len(words))
+                slot[0][:len(words)] = torch.tensor(words, dtype=torch.int64)
+                table = slot[0][:len(words)].to(dev, non_blocking=True)
+                slot[1] = torch.cuda.Event()
+                slot[1].record()
                 b1, b2 = group["betas"]
                 check(lib().msn_radam_step(ptr(table), len(items), max_n, group["lr"], b1, b2, group["eps"],
                                            group["weight_decay"], step, stream_ptr()), "msn_radam_step")

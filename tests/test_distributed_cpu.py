@@ -1,0 +1,99 @@
+"""world_size = 2 on CPU (gloo): the all-gather / row-offset / sum-over-ranks algebra of the
+global-negatives loss and of the gradient all-reduce, with the ORACLE injected as the compute
+backend (the product kernels need a GPU).  Checks against the single-process oracle at batch R*b:
+loss equal on every rank, dE of the local rows equal to the matching rows of the full gradient,
+scale gradient and a toy encoder's parameter gradient equal after the SUM all-reduce."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n_mod, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from multimodal_supernovae_amd import distributed as D
+    from multimodal_supernovae_amd.loss import clip_loss_multimodal
+    from oracle.sharded import OraclePairKernels
+    from oracle import loss as oloss
+    torch.set_num_threads(1)
+    r, _, w = D.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and D.world_size() == world
+    b, d_in, d = 6, 5, 8
+    g = torch.Generator().manual_seed(7)
+    x_all = [torch.randn(world * b, d_in, generator=g) for _ in range(n_mod)]
+    w_all = [torch.randn(d, d_in, generator=g) for _ in range(n_mod)]
+    ls0, lb0 = torch.tensor(1.7), torch.tensor(-0.4)
+
+    def encode(xs, ws):
+        es = [x @ wt.T for x, wt in zip(xs, ws)]
+        return [e / e.norm(dim=-1, keepdim=True) for e in es]
+
+    # single-process oracle at the global batch
+    wr = [t.clone().requires_grad_() for t in w_all]
+    lsr, lbr = ls0.clone().requires_grad_(), lb0.clone().requires_grad_()
+    er = encode(x_all, wr)
+    for e in er:
+        e.retain_grad()
+    ref = oloss.clip_loss_multimodal(er, lsr, lbr)
+    ref.backward()
+
+    # this rank: local rows only, weights replicated (broadcast from rank 0 after a deliberate perturbation)
+    lin = torch.nn.ModuleList([torch.nn.Linear(d_in, d, bias=False) for _ in range(n_mod)])
+    with torch.no_grad():
+        for m, wt in zip(lin, w_all):
+            m.weight.copy_(wt + (0.5 if rank else 0.0))
+    D.broadcast_module(lin)
+    ls, lb = ls0.clone().requires_grad_(), lb0.clone().requires_grad_()
+    sl = slice(rank * b, (rank + 1) * b)
+    el = encode([x[sl] for x in x_all], [m.weight for m in lin])
+    for e in el:
+        e.retain_grad()
+    loss = clip_loss_multimodal(el, ls, lb, kernels=OraclePairKernels, global_negatives=True)
+    loss.backward()
+    params = [m.weight for m in lin] + [ls, lb]
+    D.allreduce_gradients(params)
+
+    ok = torch.allclose(loss.detach(), ref.detach(), rtol=1e-5, atol=1e-6)
+    for e_loc, e_ref in zip(el, er):
+        ok = ok and torch.allclose(e_loc.grad, e_ref.grad[sl], rtol=1e-4, atol=1e-6)
+    for m, wref in zip(lin, wr):
+        ok = ok and torch.allclose(m.weight.grad, wref.grad, rtol=1e-4, atol=1e-6)
+    ok = ok and torch.allclose(ls.grad, lsr.grad, rtol=1e-4, atol=1e-6)
+    ok = ok and abs(float(lb.grad)) < 1e-5
+    # local-negatives mode must NOT communicate: equals the oracle on the local rows alone
+    loc = clip_loss_multimodal([e.detach() for e in el], ls0, lb0, kernels=OraclePairKernels, global_negatives=False)
+    ok = ok and torch.allclose(loc, oloss.clip_loss_multimodal([e.detach() for e in el], ls0, lb0), rtol=1e-5, atol=1e-6)
+    out[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_mod", [2, 3])
+def test_global_negatives_two_ranks_gloo(n_mod):
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_mod, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    assert dict(out) == {0: True, 1: True}

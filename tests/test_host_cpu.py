@@ -1,0 +1,103 @@
+"""CPU-side checks of the boundary and the host mirror (no compute: the product has no CPU path)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT, Fixture, golden_names
+
+HEADER = os.path.join(ROOT, "include", "msn_hip.h")
+
+
+def _declared():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(msn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol_and_bindings_cover_the_header():
+    import __graft_entry__ as entry
+    entry.build()                                     # hipcc cross-compiles gfx950 without a GPU
+    from multimodal_supernovae_amd import _lib
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(handle, n), f"{n} declared in include/msn_hip.h but not exported"
+    assert set(_lib.SIGNATURES) == set(names), set(_lib.SIGNATURES) ^ set(names)
+    lib = _lib.lib()
+    assert lib.msn_version() >= 100
+    assert lib.msn_device_count() in (-1, 0) or torch.cuda.is_available()
+
+
+def test_shape_errors_are_reported_without_a_gpu():
+    """Argument validation happens before any launch, so it can be exercised on a CPU-only box."""
+    from multimodal_supernovae_amd import _lib
+    lib = _lib.lib()
+    rc = lib.msn_sgemm(0, 1, 4, 4, 0, None, 4, None, 4, None, 4, None, 0, None, 0, None, 0, None)
+    assert rc == 1 and b"K must be positive" in lib.msn_last_error()
+    rc = lib.msn_infonce_fwd(None, 12, 4, None, 12, 4, None, 12, 4, None, 12, 4, 12, 0, None, None, None, None, None,
+                             None, 0, None)
+    assert rc == 1 and b"unsupported" in lib.msn_last_error()
+    assert lib.msn_set_attention_path(7) == 1
+    assert lib.msn_sgemm_workspace_bytes(1, 0, 384, 1536, 66560) > 0      # wgrad takes the split-K path
+    assert lib.msn_sgemm_workspace_bytes(0, 1, 66560, 1536, 384) == 0
+
+
+def test_no_cpu_fallback():
+    from multimodal_supernovae_amd import _lib, ops
+    from multimodal_supernovae_amd.loss import clip_loss
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.MsnHipError):
+        ops.sgemm(torch.randn(4, 4), torch.randn(4, 4))
+    with pytest.raises(_lib.MsnHipError):
+        clip_loss(torch.randn(8, 16), torch.randn(8, 16), torch.tensor(0.0), torch.tensor(0.0))
+
+
+def _build(cfg):
+    from multimodal_supernovae_amd.models_multimodal import LightCurveImageCLIP
+    return LightCurveImageCLIP(enc_dim=cfg["enc_dim"], logit_scale=10.0, nband=cfg["nband"],
+                               transformer_kwargs=cfg["transformer_kwargs"],
+                               transformer_spectral_kwargs=cfg["transformer_spectral_kwargs"],
+                               conv_kwargs=cfg["conv_kwargs"], meta_kwargs=cfg["meta_kwargs"],
+                               combinations=cfg["combinations"], loss=cfg["loss"])
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names("clip_") if "sigmoid" not in n])
+def test_state_dict_is_the_reference_state_dict(name):
+    """Keys, shapes and dtypes equal the reference module's, so its checkpoints load strict=True."""
+    f = Fixture(name)
+    model = _build(f.cfg)
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(f.P.keys()) or set(sd.keys()) == set(f.P.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(f.P[k].shape) and v.dtype == f.P[k].dtype, k
+    model.load_state_dict(f.P, strict=True)
+    assert abs(float(model.logit_bias) + 10.0) < 1e-6
+
+
+def test_constructor_contract():
+    from multimodal_supernovae_amd.models_multimodal import LightCurveImageCLIP, MLP
+    from multimodal_supernovae_amd.transformer_utils import SelfAttention
+    with pytest.raises(NotImplementedError):
+        LightCurveImageCLIP(regression=True)
+    with pytest.raises(AssertionError):
+        SelfAttention(10, heads=3)                       # ref transformer_utils.py:21-23
+    m = MLP(input_dim=4, hidden_dim=8, output_dim=2, num_layers=2, dropout=0.0)
+    assert [k for k in m.state_dict()] == ["layers.0.weight", "layers.0.bias", "layers.3.weight", "layers.3.bias",
+                                           "layers.6.weight", "layers.6.bias"]
+    model = LightCurveImageCLIP(combinations=["spectral", "lightcurve"], loss="softmax")
+    assert model.combinations == {"spectral", "lightcurve"} and not hasattr(model, "image_encoder")
+    opt = model.configure_optimizers()["optimizer"]
+    assert opt.param_groups[0]["lr"] == 1e-4 and opt.defaults["betas"] == (0.9, 0.999)
+
+
+def test_trainer_moves_the_nine_tuple_and_drops_empty_placeholders():
+    from multimodal_supernovae_amd.trainer import _to_device
+    batch = (None, torch.zeros(2, 3), torch.zeros(2, 3), torch.ones(2, 3, dtype=torch.bool), torch.empty(0),
+             torch.empty(0), torch.empty(0), torch.zeros(2), None)
+    out = _to_device(batch, "cpu")
+    assert len(out) == 9 and out[0] is None and out[4] is None and out[8] is None and out[3].dtype == torch.bool
