@@ -105,6 +105,21 @@ int msn_infonce_bwd(const float* E1_loc, int64_t ld1, int b1, const float* E2_lo
                     float* dE1_loc, int64_t ldd1, float* dE2_loc, int64_t ldd2, float* dscale_dbias,
                     void* ws, size_t ws_bytes, msn_stream_t stream);
 
+/* SigLIP-style loss with the reference's sign convention -- sigmoid_loss, src/loss.py:68-83:
+ *   Z = -(E2 . E1^T) exp(log_scale) + bias (fp32);  loss = mean_ij softplus(z_ij Z_ij) evaluated in fp64,
+ *   z = +1 on the diagonal, -1 elsewhere (mean over all n x n entries).  Same row-sharded calling
+ *   convention and workspace as msn_infonce_*; both modalities have b local / n global rows.
+ *   fwd writes this rank's share of the loss; bwd writes dE1_loc, dE2_loc and (dlog_scale, dbias) shares. */
+int msn_sigmoid_loss_fwd(const float* E1_loc, int64_t ld1, const float* E2_loc, int64_t ld2, int b,
+                         const float* E1_all, int64_t ld1a, const float* E2_all, int64_t ld2a, int n, int D,
+                         int q_offset, const float* log_scale, const float* bias, float* loss, void* ws,
+                         size_t ws_bytes, msn_stream_t stream);
+int msn_sigmoid_loss_bwd(const float* E1_loc, int64_t ld1, const float* E2_loc, int64_t ld2, int b,
+                         const float* E1_all, int64_t ld1a, const float* E2_all, int64_t ld2a, int n, int D,
+                         int q_offset, const float* log_scale, const float* bias, const float* grad_out,
+                         float* dE1_loc, int64_t ldd1, float* dE2_loc, int64_t ldd2, float* dscale_dbias,
+                         void* ws, size_t ws_bytes, msn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dimension (rows x cols, cols % 4 == 0, cols <= 1024), eps inside the
  * square root -- nn.LayerNorm as used at src/transformer_utils.py:97-98,111,114 (post-norm; the

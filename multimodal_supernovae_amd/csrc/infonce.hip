@@ -129,6 +129,34 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(const NceArgs p) {
 
     const int k_begin = blockIdx.y * p.keys_per_split;
     const int k_end = min(sd.nk, k_begin + p.keys_per_split);
+    if (p.mode == MODE_SIGMOID) {
+        // ref src/loss.py:68-83: Z = -(E2 . E1^T) s + b (fp32), then -log sigmoid(-z Z) = softplus(z Z) in fp64,
+        // z = +1 on the diagonal and -1 elsewhere.  Only direction 0 accumulates (each (i, j) once).
+        __shared__ double dred[4];
+        double part = 0.0;
+        const int q_glob = p.q_offset + q_local;
+        for (int k0 = k_begin; k0 < k_end; k0 += KT) {
+            __syncthreads();
+            stage_keys<D>(Ks, sd.K, sd.ldk, k0, k_end, kvec);
+            __syncthreads();
+            const f32x16 acc = score_tile<D>(Ks, qf, l32, h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kj = k0 + row_of(r, h);
+                if (q_ok && kj < k_end) {
+                    const float Z = -acc[r] * scale + bias;
+                    const double u = (kj == q_glob) ? (double)Z : -(double)Z;     // z * Z
+                    part += u > 0.0 ? u + log1p(exp(-u)) : log1p(exp(u));         // softplus(u)
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        if (lane == 0) dred[wave] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) p.scal[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (dred[0] + dred[1]) + (dred[2] + dred[3]);
+        return;
+    }
     float m = -INFINITY, l = 0.f;
     for (int k0 = k_begin; k0 < k_end; k0 += KT) {
         __syncthreads();
@@ -167,6 +195,14 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(const NceArgs p) {
 __global__ void nce_fwd_finish_kernel(const NceArgs p, float* __restrict__ lse_row, float* __restrict__ lse_col,
                                       float* __restrict__ loss, int D) {
     __shared__ float red[16];
+    if (p.mode == MODE_SIGMOID) {   // loss = sum of the block partials / bs^2 (mean over all bs x bs entries)
+        if (threadIdx.x == 0) {
+            double tot = 0.0;
+            for (int k = 0; k < D; ++k) tot += p.scal[k];       // D carries the number of partials here
+            *loss = (float)(tot / ((double)p.n_diag * (double)p.n_diag));
+        }
+        return;
+    }
     const float scale = __expf(*p.log_scale), bias = *p.bias;
     float* lse_out[2] = {lse_row, lse_col};
     for (int dir = 0; dir < 2; ++dir) {
@@ -221,8 +257,9 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(const NceArgs p) {
 
     float4 qf[D / 8];
     load_q_frags<D>(qf, sd.Q, sd.ldq, q_ok ? q_local : sd.nq - 1, h, qvec);
+    const bool sig = p.mode == MODE_SIGMOID;
     const bool q_in = q_ok && q_glob < p.n_diag;
-    const float lq = q_in ? sd.lse_q[q_glob] : 0.f;
+    const float lq = (q_in && !sig) ? sd.lse_q[q_glob] : 0.f;
 
     f32x16 dq[DT];
 #pragma unroll
@@ -238,7 +275,7 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(const NceArgs p) {
         stage_keys<D>(Ks, sd.K, sd.ldk, k0, k_end, kvec);
         if (threadIdx.x < KT) {
             const int kj = k0 + threadIdx.x;
-            lseK[threadIdx.x] = (kj < k_end && kj < p.n_diag) ? sd.lse_k[kj] : INFINITY;
+            lseK[threadIdx.x] = (!sig && kj < k_end && kj < p.n_diag) ? sd.lse_k[kj] : INFINITY;
         }
         __syncthreads();
         f32x16 g = score_tile<D>(Ks, qf, l32, h);
@@ -246,12 +283,21 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(const NceArgs p) {
         for (int r = 0; r < 16; ++r) {
             const int kr = row_of(r, h);
             const int kj = k0 + kr;
-            const float S = g[r] * scale + bias;
-            float G = 0.f;
-            if (q_ok && kj < k_end) {
-                if (q_in) G += __expf(S - lq);
-                G += __expf(S - lseK[kr]);  // lseK = +inf for keys outside the diagonal range -> 0
-                if (q_in && kj == q_glob) G -= 2.f;
+            float S, G = 0.f;
+            if (sig) {  // dL/dZ = z sigmoid(z Z) (/ bs^2 in the finish), Z = -x s + b
+                S = -g[r] * scale + bias;
+                if (q_ok && kj < k_end) {
+                    const float zz = (kj == q_glob) ? S : -S;
+                    const float sg = 1.f / (1.f + __expf(-zz));
+                    G = (kj == q_glob) ? sg : -sg;
+                }
+            } else {
+                S = g[r] * scale + bias;
+                if (q_ok && kj < k_end) {
+                    if (q_in) G += __expf(S - lq);
+                    G += __expf(S - lseK[kr]);  // lseK = +inf for keys outside the diagonal range -> 0
+                    if (q_in && kj == q_glob) G -= 2.f;
+                }
             }
             g[r] = G;
             ds = fmaf(G, S - bias, ds);
@@ -297,8 +343,10 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(const NceArgs p) {
 // dQ = grad_out * s / (2n) * sum_split slab ; dscale/dbias = grad_out / (2n) * sum partials
 __global__ void nce_bwd_finish_kernel(const NceArgs p, const float* __restrict__ grad_out, int D, int n_scal,
                                       float* __restrict__ dscal_out) {
-    const float g = *grad_out / (2.f * (float)p.n_diag);
-    const float f = g * __expf(*p.log_scale);
+    // softmax: G carries 1/(2n) and dS/dx = +s ; sigmoid: G carries 1/bs^2 and dZ/dx = -s
+    const float g = p.mode == MODE_SIGMOID ? *grad_out / ((float)p.n_diag * (float)p.n_diag)
+                                           : *grad_out / (2.f * (float)p.n_diag);
+    const float f = (p.mode == MODE_SIGMOID ? -g : g) * __expf(*p.log_scale);
     for (int dir = 0; dir < 2; ++dir) {
         const Side& sd = p.side[dir];
         const int64_t total = (int64_t)sd.nq * D;
@@ -373,13 +421,34 @@ extern "C" size_t msn_infonce_workspace_bytes(int b1, int b2, int n1, int n2, in
     return make_plan(b1, b2, n1, n2, D).total;
 }
 
+static int infonce_fwd_impl(int mode, const float* E1_loc, int64_t ld1, int b1, const float* E2_loc, int64_t ld2, int b2,
+                            const float* E1_all, int64_t ld1a, int n1, const float* E2_all, int64_t ld2a, int n2, int D,
+                            int q_offset, const float* log_scale, const float* bias, float* lse_row, float* lse_col,
+                            float* loss, void* ws, size_t ws_bytes, msn_stream_t stream);
+
 extern "C" int msn_infonce_fwd(const float* E1_loc, int64_t ld1, int b1, const float* E2_loc, int64_t ld2, int b2,
                                const float* E1_all, int64_t ld1a, int n1, const float* E2_all, int64_t ld2a, int n2,
                                int D, int q_offset, const float* log_scale, const float* bias, float* lse_row,
                                float* lse_col, float* loss, void* ws, size_t ws_bytes, msn_stream_t stream) {
+    MSN_REQUIRE(lse_row && lse_col, "msn_infonce_fwd: null pointer");
+    return infonce_fwd_impl(MODE_SOFTMAX, E1_loc, ld1, b1, E2_loc, ld2, b2, E1_all, ld1a, n1, E2_all, ld2a, n2, D, q_offset,
+                            log_scale, bias, lse_row, lse_col, loss, ws, ws_bytes, stream);
+}
+
+extern "C" int msn_sigmoid_loss_fwd(const float* E1_loc, int64_t ld1, const float* E2_loc, int64_t ld2, int b,
+                                    const float* E1_all, int64_t ld1a, const float* E2_all, int64_t ld2a, int n, int D,
+                                    int q_offset, const float* log_scale, const float* bias, float* loss, void* ws,
+                                    size_t ws_bytes, msn_stream_t stream) {
+    return infonce_fwd_impl(MODE_SIGMOID, E1_loc, ld1, b, E2_loc, ld2, b, E1_all, ld1a, n, E2_all, ld2a, n, D, q_offset,
+                            log_scale, bias, nullptr, nullptr, loss, ws, ws_bytes, stream);
+}
+
+static int infonce_fwd_impl(int mode, const float* E1_loc, int64_t ld1, int b1, const float* E2_loc, int64_t ld2, int b2,
+                               const float* E1_all, int64_t ld1a, int n1, const float* E2_all, int64_t ld2a, int n2,
+                               int D, int q_offset, const float* log_scale, const float* bias, float* lse_row,
+                               float* lse_col, float* loss, void* ws, size_t ws_bytes, msn_stream_t stream) {
     if (int rc = check_common("msn_infonce_fwd", b1, b2, n1, n2, D, q_offset)) return rc;
-    MSN_REQUIRE(E1_loc && E2_loc && E1_all && E2_all && log_scale && bias && lse_row && lse_col && loss,
-                "msn_infonce_fwd: null pointer");
+    MSN_REQUIRE(E1_loc && E2_loc && E1_all && E2_all && log_scale && bias && loss, "msn_infonce_fwd: null pointer");
     MSN_REQUIRE(ld1 >= D && ld2 >= D && ld1a >= D && ld2a >= D, "msn_infonce_fwd: leading dimension < D");
     const Plan pl = make_plan(b1, b2, n1, n2, D);
     MSN_REQUIRE(ws && ws_bytes >= pl.total, "msn_infonce_fwd: workspace %zu < %zu bytes", ws_bytes, pl.total);
@@ -387,17 +456,37 @@ extern "C" int msn_infonce_fwd(const float* E1_loc, int64_t ld1, int b1, const f
     a.side[0] = Side{E2_loc, E1_all, nullptr, nullptr, nullptr, ld2, ld1a, 0, b2, n1};
     a.side[1] = Side{E1_loc, E2_all, nullptr, nullptr, nullptr, ld1, ld2a, 0, b1, n2};
     a.log_scale = log_scale; a.bias = bias; a.q_offset = q_offset; a.n_diag = std::min(n1, n2);
-    a.ksplit = pl.ksplit; a.keys_per_split = pl.keys_per_split; a.maxq = pl.maxq; a.mode = MODE_SOFTMAX;
+    a.ksplit = pl.ksplit; a.keys_per_split = pl.keys_per_split; a.maxq = pl.maxq; a.mode = mode;
     char* w = static_cast<char*>(ws);
     a.part_m = reinterpret_cast<float*>(w + pl.off_m);
     a.part_l = reinterpret_cast<float*>(w + pl.off_l);
+    a.scal = reinterpret_cast<double*>(w + pl.off_scal);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid(pl.qblocks, pl.ksplit, 2), block(256);
+    // the sigmoid loss sums each (i, j) once: direction 0 only
+    const dim3 grid(pl.qblocks, pl.ksplit, mode == MODE_SIGMOID ? 1 : 2), block(256);
     MSN_NCE_DISPATCH(nce_fwd_kernel, grid, block, 0, st, a)
     MSN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nce_fwd_finish_kernel, dim3(1), dim3(1024), 0, st, a, lse_row, lse_col, loss, D);
+    hipLaunchKernelGGL(nce_fwd_finish_kernel, dim3(1), dim3(1024), 0, st, a, lse_row, lse_col, loss,
+                       mode == MODE_SIGMOID ? pl.qblocks * pl.ksplit : D);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
+}
+
+static int infonce_bwd_impl(int mode, const float* E1_loc, int64_t ld1, int b1, const float* E2_loc, int64_t ld2, int b2,
+                            const float* E1_all, int64_t ld1a, int n1, const float* E2_all, int64_t ld2a, int n2, int D,
+                            int q_offset, const float* log_scale, const float* bias, const float* lse_row_all,
+                            const float* lse_col_all, const float* grad_out, float* dE1_loc, int64_t ldd1,
+                            float* dE2_loc, int64_t ldd2, float* dscale_dbias, void* ws, size_t ws_bytes,
+                            msn_stream_t stream);
+
+extern "C" int msn_sigmoid_loss_bwd(const float* E1_loc, int64_t ld1, const float* E2_loc, int64_t ld2, int b,
+                                    const float* E1_all, int64_t ld1a, const float* E2_all, int64_t ld2a, int n, int D,
+                                    int q_offset, const float* log_scale, const float* bias, const float* grad_out,
+                                    float* dE1_loc, int64_t ldd1, float* dE2_loc, int64_t ldd2, float* dscale_dbias,
+                                    void* ws, size_t ws_bytes, msn_stream_t stream) {
+    return infonce_bwd_impl(MODE_SIGMOID, E1_loc, ld1, b, E2_loc, ld2, b, E1_all, ld1a, n, E2_all, ld2a, n, D, q_offset,
+                            log_scale, bias, nullptr, nullptr, grad_out, dE1_loc, ldd1, dE2_loc, ldd2, dscale_dbias, ws,
+                            ws_bytes, stream);
 }
 
 extern "C" int msn_infonce_bwd(const float* E1_loc, int64_t ld1, int b1, const float* E2_loc, int64_t ld2, int b2,
@@ -406,9 +495,20 @@ extern "C" int msn_infonce_bwd(const float* E1_loc, int64_t ld1, int b1, const f
                                const float* lse_row_all, const float* lse_col_all, const float* grad_out,
                                float* dE1_loc, int64_t ldd1, float* dE2_loc, int64_t ldd2, float* dscale_dbias,
                                void* ws, size_t ws_bytes, msn_stream_t stream) {
+    MSN_REQUIRE(lse_row_all && lse_col_all, "msn_infonce_bwd: null pointer");
+    return infonce_bwd_impl(MODE_SOFTMAX, E1_loc, ld1, b1, E2_loc, ld2, b2, E1_all, ld1a, n1, E2_all, ld2a, n2, D, q_offset,
+                            log_scale, bias, lse_row_all, lse_col_all, grad_out, dE1_loc, ldd1, dE2_loc, ldd2,
+                            dscale_dbias, ws, ws_bytes, stream);
+}
+
+static int infonce_bwd_impl(int mode, const float* E1_loc, int64_t ld1, int b1, const float* E2_loc, int64_t ld2, int b2,
+                               const float* E1_all, int64_t ld1a, int n1, const float* E2_all, int64_t ld2a, int n2,
+                               int D, int q_offset, const float* log_scale, const float* bias,
+                               const float* lse_row_all, const float* lse_col_all, const float* grad_out,
+                               float* dE1_loc, int64_t ldd1, float* dE2_loc, int64_t ldd2, float* dscale_dbias,
+                               void* ws, size_t ws_bytes, msn_stream_t stream) {
     if (int rc = check_common("msn_infonce_bwd", b1, b2, n1, n2, D, q_offset)) return rc;
-    MSN_REQUIRE(E1_loc && E2_loc && E1_all && E2_all && log_scale && bias && lse_row_all && lse_col_all &&
-                    grad_out && dE1_loc && dE2_loc,
+    MSN_REQUIRE(E1_loc && E2_loc && E1_all && E2_all && log_scale && bias && grad_out && dE1_loc && dE2_loc,
                 "msn_infonce_bwd: null pointer");
     MSN_REQUIRE(ld1 >= D && ld2 >= D && ld1a >= D && ld2a >= D && ldd1 >= D && ldd2 >= D,
                 "msn_infonce_bwd: leading dimension < D");
@@ -419,7 +519,7 @@ extern "C" int msn_infonce_bwd(const float* E1_loc, int64_t ld1, int b1, const f
     a.side[0] = Side{E2_loc, E1_all, lse_row_all, lse_col_all, dE2_loc, ld2, ld1a, ldd2, b2, n1};
     a.side[1] = Side{E1_loc, E2_all, lse_col_all, lse_row_all, dE1_loc, ld1, ld2a, ldd1, b1, n2};
     a.log_scale = log_scale; a.bias = bias; a.q_offset = q_offset; a.n_diag = std::min(n1, n2);
-    a.ksplit = pl.ksplit; a.keys_per_split = pl.keys_per_split; a.maxq = pl.maxq; a.mode = MODE_SOFTMAX;
+    a.ksplit = pl.ksplit; a.keys_per_split = pl.keys_per_split; a.maxq = pl.maxq; a.mode = mode;
     char* w = static_cast<char*>(ws);
     a.slab = reinterpret_cast<float*>(w + pl.off_slab);
     a.scal = reinterpret_cast<double*>(w + pl.off_scal);

@@ -141,3 +141,78 @@ def clip_loss_multimodal(embeddings, logit_scales=1.0, logit_biases=0.0, *, glob
     if n_pairs == 0:
         raise ValueError("clip_loss_multimodal needs at least two modalities")
     return total
+
+
+# ------------------------------------------------------------------------------------- sigmoid loss
+class _SigmoidPair(torch.autograd.Function):
+    """sigmoid_loss of one modality pair (ref src/loss.py:68-83) on msn_sigmoid_loss_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, e1, e2, log_scale, bias, group, sharded):
+        _lib.require_gpu()
+        e1, e2 = e1.contiguous(), e2.contiguous()
+        if e1.shape != e2.shape:
+            raise ValueError("sigmoid_loss needs the same number of rows in both modalities (labels are bs x bs)")
+        log_scale = log_scale.detach().to(torch.float32).reshape(()).contiguous()
+        bias = bias.detach().to(torch.float32).reshape(()).contiguous()
+        if sharded:
+            e1_all, e2_all = _gather_rows(e1, group), _gather_rows(e2, group)
+            q_offset = dist.get_rank(group) * e1.shape[0]
+        else:
+            e1_all, e2_all, q_offset = e1, e2, 0
+        b, D = e1.shape
+        n = e1_all.shape[0]
+        L = lib()
+        nb = L.msn_infonce_workspace_bytes(b, b, n, n, D)
+        ws = torch.empty(max(nb, 16) // 4 + 1, dtype=torch.float32, device=e1.device)
+        loss = torch.empty((), dtype=torch.float32, device=e1.device)
+        check(L.msn_sigmoid_loss_fwd(ptr(e1), e1.stride(0), ptr(e2), e2.stride(0), b, ptr(e1_all), e1_all.stride(0),
+                                     ptr(e2_all), e2_all.stride(0), n, D, q_offset, ptr(log_scale), ptr(bias),
+                                     ptr(loss), ptr(ws), nb, stream_ptr()), "msn_sigmoid_loss_fwd")
+        if sharded:
+            dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=group)
+        ctx.q_offset = q_offset
+        ctx.save_for_backward(e1, e2, e1_all, e2_all, log_scale, bias)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        e1, e2, e1_all, e2_all, log_scale, bias = ctx.saved_tensors
+        g = grad_out.to(torch.float32).reshape(()).contiguous()
+        b, D = e1.shape
+        n = e1_all.shape[0]
+        L = lib()
+        nb = L.msn_infonce_workspace_bytes(b, b, n, n, D)
+        ws = torch.empty(max(nb, 16) // 4 + 1, dtype=torch.float32, device=e1.device)
+        d1, d2 = torch.empty_like(e1), torch.empty_like(e2)
+        dsb = torch.empty(2, dtype=torch.float32, device=e1.device)
+        check(L.msn_sigmoid_loss_bwd(ptr(e1), e1.stride(0), ptr(e2), e2.stride(0), b, ptr(e1_all), e1_all.stride(0),
+                                     ptr(e2_all), e2_all.stride(0), n, D, ctx.q_offset, ptr(log_scale), ptr(bias),
+                                     ptr(g), ptr(d1), D, ptr(d2), D, ptr(dsb), ptr(ws), nb, stream_ptr()),
+              "msn_sigmoid_loss_bwd")
+        return d1, d2, dsb[0], dsb[1], None, None
+
+
+def sigmoid_loss(embs1, embs2, logit_scale=1.0, logit_bias=2.73, *, global_negatives=True, group=None):
+    """Sigmoid-based CLIP loss with the reference's sign convention (ref src/loss.py:68-83); returns a
+    float32 0-dim tensor (the reference returns float64: the fp64 evaluation happens inside the kernel)."""
+    dev = embs1.device
+    logit_scale = torch.as_tensor(logit_scale, dtype=torch.float32, device=dev)
+    logit_bias = torch.as_tensor(logit_bias, dtype=torch.float32, device=dev)
+    return _SigmoidPair.apply(embs1, embs2, logit_scale, logit_bias, group, _is_sharded(global_negatives, group))
+
+
+def sigmoid_loss_multimodal(embeds, logit_scales=1.0, logit_biases=2.73, *, global_negatives=True, group=None):
+    """Pairwise sum of sigmoid_loss (ref src/loss.py:86-107)."""
+    m = len(embeds)
+    if m < 2:
+        raise ValueError("sigmoid_loss_multimodal needs at least two modalities")
+    dev = embeds[0].device
+    scales = torch.as_tensor(logit_scales, dtype=torch.float32, device=dev)
+    biases = torch.as_tensor(logit_biases, dtype=torch.float32, device=dev)
+    total = 0
+    for k, (i, j) in enumerate(_pairs(range(m), 2)):
+        s = scales if scales.dim() == 0 else scales[k]
+        b = biases if biases.dim() == 0 else biases[k]
+        total = total + sigmoid_loss(embeds[i], embeds[j], s, b, global_negatives=global_negatives, group=group)
+    return total

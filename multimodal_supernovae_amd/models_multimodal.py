@@ -192,7 +192,8 @@ class LightCurveImageCLIP(nn.Module):
                                         global_negatives=self.global_negatives)
         if self.loss == "sigmoid":
             from .loss import sigmoid_loss_multimodal
-            return sigmoid_loss_multimodal(embs, self.logit_scale, self.logit_bias)
+            return sigmoid_loss_multimodal(embs, self.logit_scale, self.logit_bias,
+                                           global_negatives=self.global_negatives)
         raise ValueError(f"unknown loss {self.loss!r}")
 
     def training_step(self, batch, batch_idx):

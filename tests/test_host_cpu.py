@@ -38,8 +38,9 @@ def test_shape_errors_are_reported_without_a_gpu():
     lib = _lib.lib()
     rc = lib.msn_sgemm(0, 1, 4, 4, 0, None, 4, None, 4, None, 4, None, 0, None, 0, None, 0, None)
     assert rc == 1 and b"K must be positive" in lib.msn_last_error()
-    rc = lib.msn_infonce_fwd(None, 12, 4, None, 12, 4, None, 12, 4, None, 12, 4, 12, 0, None, None, None, None, None,
-                             None, 0, None)
+    fake = ctypes.c_void_p(4096)          # never dereferenced: validation rejects the call before any launch
+    rc = lib.msn_infonce_fwd(fake, 12, 4, fake, 12, 4, fake, 12, 4, fake, 12, 4, 12, 0, fake, fake, fake, fake, fake,
+                             fake, 0, None)
     assert rc == 1 and b"unsupported" in lib.msn_last_error()
     assert lib.msn_set_attention_path(7) == 1
     assert lib.msn_sgemm_workspace_bytes(1, 0, 384, 1536, 66560) > 0      # wgrad takes the split-K path

@@ -174,3 +174,52 @@ def test_rejects_unsupported_width_and_cpu_tensors():
     from multimodal_supernovae_amd.loss import clip_loss
     with pytest.raises(_lib.MsnHipError):
         clip_loss(_unit(8, 12, 1).cuda(), _unit(8, 12, 2).cuda(), torch.tensor(0.0), torch.tensor(0.0))
+
+
+# ------------------------------------------------------------------------------------ sigmoid loss
+@pytest.mark.parametrize("name", golden_names("loss_sigmoid_n"))
+def test_sigmoid_loss_against_reference_golden(name):
+    from multimodal_supernovae_amd.loss import sigmoid_loss
+    f = Fixture(name)
+    i = f.groups["in"]
+    a, b = i["e1"].cuda().requires_grad_(), i["e2"].cuda().requires_grad_()
+    s, c = i["logit_scale"].cuda().requires_grad_(), i["logit_bias"].cuda().requires_grad_()
+    loss = sigmoid_loss(a, b, s, c)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(f.out["loss"])) <= RTOL * abs(float(f.out["loss"]))
+    for got, k in ((a.grad, "e1"), (b.grad, "e2")):
+        ref = f.grad[k].float()
+        torch.testing.assert_close(got.cpu(), ref, rtol=RTOL, atol=RTOL * float(ref.abs().max()))
+    assert abs(float(s.grad) - float(f.grad["logit_scale"])) <= RTOL * abs(float(f.grad["logit_scale"])) + 1e-6
+    assert abs(float(c.grad) - float(f.grad["logit_bias"])) <= RTOL * abs(float(f.grad["logit_bias"])) + 1e-6
+
+
+def test_sigmoid_known_answer_and_multimodal():
+    from multimodal_supernovae_amd.loss import sigmoid_loss, sigmoid_loss_multimodal
+    kat = Fixture("loss_kat")
+    e = torch.cat([torch.eye(4), torch.zeros(4, 4)], dim=1).cuda()
+    v = sigmoid_loss(e, e, torch.tensor(math.log(10.0)), torch.tensor(-10.0))
+    assert abs(float(v) - float(kat.out["sigmoid_I4_ln10_bm10"])) < 1e-4          # 7.5000340
+    f = Fixture("loss_clip_multimodal3")
+    i = f.groups["in"]
+    embs = [i[k].cuda() for k in ("e0", "e1", "e2")]
+    got = sigmoid_loss_multimodal(embs, i["logit_scale"].cuda(), i["logit_bias"].cuda())
+    assert abs(float(got) - float(f.out["sigmoid"])) <= RTOL * abs(float(f.out["sigmoid"]))
+
+
+@pytest.mark.parametrize("n,d", [(33, 32), (256, 128), (1024, 128)])
+def test_sigmoid_loss_against_oracle(n, d):
+    from multimodal_supernovae_amd.loss import sigmoid_loss
+    from oracle.loss import sigmoid_loss as ref_fn
+    e1, e2 = _unit(n, d, 300 + n), _unit(n, d, 400 + n)
+    ls, lb = torch.tensor(math.log(5.0)), torch.tensor(-3.0)
+    a, b = e1.cuda().requires_grad_(), e2.cuda().requires_grad_()
+    s, c = ls.cuda().requires_grad_(), lb.cuda().requires_grad_()
+    sigmoid_loss(a, b, s, c).backward()
+    ra, rb = e1.clone().requires_grad_(), e2.clone().requires_grad_()
+    rs, rc = ls.clone().requires_grad_(), lb.clone().requires_grad_()
+    ref_fn(ra, rb, rs, rc).backward()
+    for got, ref in ((a.grad, ra.grad), (b.grad, rb.grad)):
+        torch.testing.assert_close(got.cpu(), ref, rtol=RTOL, atol=RTOL * float(ref.abs().max()))
+    assert abs(float(s.grad) - float(rs.grad)) <= RTOL * abs(float(rs.grad)) + 1e-6
+    assert abs(float(c.grad) - float(rc.grad)) <= RTOL * abs(float(rc.grad)) + 1e-6
