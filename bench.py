@@ -178,6 +178,7 @@ def main():
     prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
     gemm_ms = sum(e[0].elapsed_time(e[1]) for e in prof)
     gemm_flops = sum(e[2] for e in prof)
+    gemm_bytes = sum(4.0 * (e[3][2] * e[3][4] + e[3][4] * e[3][3] + e[3][2] * e[3][3]) for e in prof)
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     peak = 157.3  # TFLOP/s, dense fp32 matrix (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md
 
@@ -191,6 +192,16 @@ def main():
         for key, (n, ms_, fl) in sorted(table.items(), key=lambda kv: -kv[1][1]):
             print(f"# gemm opA={key[0]} opB={key[1]} M={key[2]:6d} N={key[3]:5d} K={key[4]:6d} epi={key[5]} calls={n:3d} "
                   f"{ms_:8.3f} ms {fl / ms_ / 1e9:7.1f} TFLOP/s", file=sys.stderr)
+    # HBM-side traffic of the same kernel comes from separate rocprofv3 --pmc passes of this command
+    # (FETCH_SIZE, WRITE_SIZE; tools/summarize_pmc.py) -- counters cannot be read from inside the process.
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_sgemm.json")))
+        if b == 1024 and world == 1:
+            traffic = pmc["traffic_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         pairs = b * world * args.steps / dt
@@ -207,8 +218,10 @@ def main():
                        "model_tflops": pairs * flops_per_pair() / 1e12},
             "roofline": {"bound": "mfma", "kernel": "msn::sgemm_kernel (fp32 v_mfma_f32_32x32x2_f32)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None, "launches_per_step": len(prof), "ms_per_step_in_kernel": gemm_ms,
-                         "algorithmic_gflop_per_step": gemm_flops / 1e9},
+                         "traffic": traffic, "traffic_unit": "bytes per launch (mean), 2 x FETCH_SIZE + WRITE_SIZE",
+                         "launches_per_step": len(prof), "ms_per_step_in_kernel": gemm_ms,
+                         "algorithmic_gflop_per_step": gemm_flops / 1e9,
+                         "algorithmic_bytes_per_launch": gemm_bytes / max(len(prof), 1)},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_batch, args.cpu_steps)

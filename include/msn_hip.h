@@ -206,14 +206,17 @@ int msn_unpatchify(const float* dpatches, int B, int C, int H, int W, int p, flo
 
 /* nn.BatchNorm2d over the rows of x (rows x C), :58,70,77.  training != 0: two-pass batch statistics,
  * `mean` / `rstd` (C each) written, running_mean / running_var updated in place when non-NULL
- * (momentum; unbiased variance) ; training == 0: running statistics are used.  y = bn(x) (+ residual).
+ * (momentum; unbiased variance) ; training == 0: running statistics are used.  y = bn(x) (+ residual),
+ * then ReLU when relu != 0 (build-defined ResNet blocks).
  * bwd: dx = dL/dx, additionally multiplied by dact[.] when dact != NULL (conv -> GELU -> BN order:
  * dact is the gelu' that msn_sgemm's GELU epilogue / msn_dwconv_gelu_fwd saved). */
 size_t msn_bn_workspace_bytes(int64_t rows, int C);
 int msn_batchnorm_fwd(const float* x, int64_t rows, int C, const float* gamma, const float* beta, float eps,
                       int training, float momentum, float* running_mean, float* running_var,
-                      const float* residual, float* y, float* mean, float* rstd, void* ws, size_t ws_bytes,
-                      msn_stream_t stream);
+                      const float* residual, int relu, float* y, float* mean, float* rstd, void* ws,
+                      size_t ws_bytes, msn_stream_t stream);
+/* dmasked = dy * (y > 0): gradient through a trailing ReLU (relu != 0 above), given its output y */
+int msn_relu_mask(const float* dy, const float* y, int64_t total, float* dmasked, msn_stream_t stream);
 int msn_batchnorm_bwd(const float* dy, const float* x, const float* dact, int64_t rows, int C,
                       const float* mean, const float* rstd, const float* gamma, int training, float* dx,
                       float* dgamma, float* dbeta, void* ws, size_t ws_bytes, msn_stream_t stream);
@@ -236,6 +239,19 @@ int msn_dwconv_bwd(const float* dpre, const float* x, const float* w, int B, int
  */
 int msn_radam_step(const void* table, int n_tensors, int64_t max_numel, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int64_t step, msn_stream_t stream);
+
+/* Channels-last convolution plumbing for the build-defined ResNet-18 / 1-D CNN encoders (not in the
+ * reference): cols[(b,oh,ow)][(c,u,v)] = x[b, oh*sh+u-ph, ow*sw+v-pw, c] (0 outside), column order equal to
+ * the flattening of a (C_out, C_in, kh, kw) weight, so conv = msn_sgemm(cols, W) ; col2im is its adjoint
+ * (deterministic gather); a 1-D conv is the H = 1 case.  Max pooling keeps the arg-max pixel (int32). */
+int msn_im2col(const float* x, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
+               float* cols, msn_stream_t stream);
+int msn_col2im(const float* dcols, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
+               float* dx, msn_stream_t stream);
+int msn_maxpool2d_fwd(const float* x, int B, int H, int W, int C, int k, int s, int p, float* y, int* argmax,
+                      msn_stream_t stream);
+int msn_maxpool2d_bwd(const float* dy, const int* argmax, int B, int H, int W, int C, int k, int s, int p,
+                      float* dx, msn_stream_t stream);
 
 /* Build-defined ViT image encoder (not in the reference; fills its `image_encoder` slot):
  * tok[b][0] = cls + pos[0], tok[b][1+i] = patch[b][i] + pos[1+i]  with T = 1 + n_patches, and the

@@ -1,0 +1,160 @@
+// Channels-last convolution plumbing for the build-defined ResNet-18 / 1-D CNN encoders (not in the
+// reference): im2col gather, its adjoint (a deterministic gather over the windows covering a pixel --
+// no atomics), and 2-D max pooling.  The convolutions themselves are msn_sgemm on the column matrix:
+//   y[(b,oh,ow)][co] = sum_{(c,u,v)} cols[(b,oh,ow)][(c,u,v)] * W[co][(c,u,v)]
+// with the column order (c, u, v) equal to the flattening of a (C_out, C_in, kh, kw) weight, so
+// torchvision-style parameters are used as they are.  A 1-D convolution is the H = 1 case.
+#include <algorithm>
+
+#include "msn_common.h"
+
+namespace msn {
+
+struct ConvGeom {
+    int B, H, W, C;          // input, channels-last (B, H, W, C)
+    int kh, kw, sh, sw, ph, pw;
+    int OH, OW;
+};
+
+__global__ void im2col_kernel(const float* __restrict__ x, ConvGeom g, float* __restrict__ cols) {
+    const int64_t K = (int64_t)g.C * g.kh * g.kw;
+    const int64_t total = (int64_t)g.B * g.OH * g.OW * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / K;
+        const int kk = (int)(i % K);
+        const int v = kk % g.kw, u = (kk / g.kw) % g.kh, c = kk / (g.kw * g.kh);
+        const int ow = (int)(row % g.OW), oh = (int)((row / g.OW) % g.OH);
+        const int64_t b = row / ((int64_t)g.OW * g.OH);
+        const int y = oh * g.sh + u - g.ph, xx = ow * g.sw + v - g.pw;
+        float val = 0.f;
+        if (y >= 0 && y < g.H && xx >= 0 && xx < g.W) val = x[((b * g.H + y) * g.W + xx) * g.C + c];
+        cols[i] = val;
+    }
+}
+// dx[b,y,x,c] = sum over windows (oh, ow) and taps (u, v) with oh*sh + u - ph = y, ow*sw + v - pw = x
+__global__ void col2im_kernel(const float* __restrict__ dcols, ConvGeom g, float* __restrict__ dx) {
+    const int64_t K = (int64_t)g.C * g.kh * g.kw;
+    const int64_t total = (int64_t)g.B * g.H * g.W * g.C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % g.C);
+        const int xx = (int)((i / g.C) % g.W), y = (int)((i / ((int64_t)g.C * g.W)) % g.H);
+        const int64_t b = i / ((int64_t)g.C * g.W * g.H);
+        float s = 0.f;
+        for (int u = 0; u < g.kh; ++u) {
+            const int ty = y + g.ph - u;
+            if (ty < 0 || ty % g.sh != 0) continue;
+            const int oh = ty / g.sh;
+            if (oh >= g.OH) continue;
+            for (int v = 0; v < g.kw; ++v) {
+                const int tx = xx + g.pw - v;
+                if (tx < 0 || tx % g.sw != 0) continue;
+                const int ow = tx / g.sw;
+                if (ow >= g.OW) continue;
+                s += dcols[((b * g.OH + oh) * g.OW + ow) * K + ((int64_t)c * g.kh + u) * g.kw + v];
+            }
+        }
+        dx[i] = s;
+    }
+}
+
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, ConvGeom g, float* __restrict__ y, int* __restrict__ arg) {
+    const int64_t total = (int64_t)g.B * g.OH * g.OW * g.C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % g.C);
+        const int ow = (int)((i / g.C) % g.OW), oh = (int)((i / ((int64_t)g.C * g.OW)) % g.OH);
+        const int64_t b = i / ((int64_t)g.C * g.OW * g.OH);
+        float best = -INFINITY;
+        int bi = 0;
+        for (int u = 0; u < g.kh; ++u) {
+            const int yy = oh * g.sh + u - g.ph;
+            if (yy < 0 || yy >= g.H) continue;
+            for (int v = 0; v < g.kw; ++v) {
+                const int xx = ow * g.sw + v - g.pw;
+                if (xx < 0 || xx >= g.W) continue;
+                const float val = x[((b * g.H + yy) * g.W + xx) * g.C + c];
+                if (val > best) { best = val; bi = yy * g.W + xx; }
+            }
+        }
+        y[i] = best;
+        arg[i] = bi;
+    }
+}
+// dx[b,y,x,c] = sum of dy over the windows whose arg-max is this pixel (gather: deterministic)
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ arg, ConvGeom g,
+                                   float* __restrict__ dx) {
+    const int64_t total = (int64_t)g.B * g.H * g.W * g.C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % g.C);
+        const int xx = (int)((i / g.C) % g.W), y = (int)((i / ((int64_t)g.C * g.W)) % g.H);
+        const int64_t b = i / ((int64_t)g.C * g.W * g.H);
+        const int me = y * g.W + xx;
+        float s = 0.f;
+        for (int u = 0; u < g.kh; ++u) {
+            const int ty = y + g.ph - u;
+            if (ty < 0 || ty % g.sh != 0 || ty / g.sh >= g.OH) continue;
+            for (int v = 0; v < g.kw; ++v) {
+                const int tx = xx + g.pw - v;
+                if (tx < 0 || tx % g.sw != 0 || tx / g.sw >= g.OW) continue;
+                const int64_t o = ((b * g.OH + ty / g.sh) * g.OW + tx / g.sw) * g.C + c;
+                if (arg[o] == me) s += dy[o];
+            }
+        }
+        dx[i] = s;
+    }
+}
+
+static int make_geom(const char* who, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
+                     ConvGeom* g) {
+    MSN_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0,
+                "%s: bad geometry", who);
+    const int OH = (H + 2 * ph - kh) / sh + 1, OW = (W + 2 * pw - kw) / sw + 1;
+    MSN_REQUIRE(OH > 0 && OW > 0, "%s: kernel larger than the padded input", who);
+    *g = ConvGeom{B, H, W, C, kh, kw, sh, sw, ph, pw, OH, OW};
+    return MSN_OK;
+}
+static unsigned grid_for(int64_t total) { return (unsigned)std::min<int64_t>(cdiv(total, 256), 8192); }
+
+}  // namespace msn
+
+using namespace msn;
+
+extern "C" int msn_im2col(const float* x, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
+                          float* cols, msn_stream_t stream) {
+    ConvGeom g;
+    if (int rc = make_geom("msn_im2col", B, H, W, C, kh, kw, sh, sw, ph, pw, &g)) return rc;
+    MSN_REQUIRE(x && cols, "msn_im2col: null pointer");
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for((int64_t)B * g.OH * g.OW * C * kh * kw)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, g, cols);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+extern "C" int msn_col2im(const float* dcols, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
+                          float* dx, msn_stream_t stream) {
+    ConvGeom g;
+    if (int rc = make_geom("msn_col2im", B, H, W, C, kh, kw, sh, sw, ph, pw, &g)) return rc;
+    MSN_REQUIRE(dx && dcols, "msn_col2im: null pointer");
+    hipLaunchKernelGGL(col2im_kernel, dim3(grid_for((int64_t)B * H * W * C)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       dcols, g, dx);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+extern "C" int msn_maxpool2d_fwd(const float* x, int B, int H, int W, int C, int k, int s, int p, float* y, int* argmax,
+                                 msn_stream_t stream) {
+    ConvGeom g;
+    if (int rc = make_geom("msn_maxpool2d_fwd", B, H, W, C, k, k, s, s, p, p, &g)) return rc;
+    MSN_REQUIRE(x && y && argmax, "msn_maxpool2d_fwd: null pointer");
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((int64_t)B * g.OH * g.OW * C)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, g, y, argmax);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+extern "C" int msn_maxpool2d_bwd(const float* dy, const int* argmax, int B, int H, int W, int C, int k, int s, int p,
+                                 float* dx, msn_stream_t stream) {
+    ConvGeom g;
+    if (int rc = make_geom("msn_maxpool2d_bwd", B, H, W, C, k, k, s, s, p, p, &g)) return rc;
+    MSN_REQUIRE(dy && dx && argmax, "msn_maxpool2d_bwd: null pointer");
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((int64_t)B * H * W * C)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), dy, argmax, g, dx);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}

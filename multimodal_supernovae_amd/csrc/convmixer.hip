@@ -117,17 +117,25 @@ __global__ void bn_eval_rstd_kernel(const float* __restrict__ running_var, int C
     if (c < C) rstd[c] = 1.f / sqrtf(running_var[c] + eps);
 }
 
-// y = (x - mean) * rstd * gamma + beta (+ res)
+// y = (x - mean) * rstd * gamma + beta (+ res), optionally followed by ReLU
 __global__ void bn_apply_kernel(const float* __restrict__ x, int64_t rows, int C, const float* __restrict__ mean,
                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, const float* __restrict__ res, float* __restrict__ y) {
+                                const float* __restrict__ beta, const float* __restrict__ res, int relu,
+                                float* __restrict__ y) {
     const int64_t total = rows * C;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         float v = (x[i] - mean[c]) * rstd[c] * gamma[c] + beta[c];
         if (res) v += res[i];
+        if (relu) v = fmaxf(v, 0.f);
         y[i] = v;
     }
+}
+// dm = dy * (y > 0): the gradient after a trailing ReLU (also what flows into the residual branch)
+__global__ void relu_mask_kernel(const float* __restrict__ dy, const float* __restrict__ y, int64_t total,
+                                 float* __restrict__ dm) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        dm[i] = y[i] > 0.f ? dy[i] : 0.f;
 }
 // partial (sum dy, sum dy * xhat)
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -292,8 +300,8 @@ extern "C" size_t msn_bn_workspace_bytes(int64_t rows, int C) {
 // training == 0: mean := running_mean (must be passed as `mean`), rstd from running_var.
 extern "C" int msn_batchnorm_fwd(const float* x, int64_t rows, int C, const float* gamma, const float* beta, float eps,
                                  int training, float momentum, float* running_mean, float* running_var,
-                                 const float* residual, float* y, float* mean, float* rstd, void* ws, size_t ws_bytes,
-                                 msn_stream_t stream) {
+                                 const float* residual, int relu, float* y, float* mean, float* rstd, void* ws,
+                                 size_t ws_bytes, msn_stream_t stream) {
     MSN_REQUIRE(x && gamma && beta && y && mean && rstd && rows > 0 && C > 0, "msn_batchnorm_fwd: bad arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const unsigned cb = (unsigned)cdiv(C, 64);
@@ -316,7 +324,7 @@ extern "C" int msn_batchnorm_fwd(const float* x, int64_t rows, int C, const floa
         hipLaunchKernelGGL(bn_eval_rstd_kernel, dim3(cb), dim3(64), 0, st, running_var, C, eps, rstd);
     }
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(rows * C)), dim3(256), 0, st, x, rows, C, mean, rstd, gamma, beta,
-                       residual, y);
+                       residual, relu, y);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }
@@ -378,6 +386,14 @@ extern "C" int msn_dwconv_bwd(const float* dpre, const float* x, const float* w,
     const int nout = C * (k * k + 1);
     hipLaunchKernelGGL(dwconv_bwd_dw_finish_kernel, dim3((unsigned)cdiv(nout, 128)), dim3(128), 0, st, part, nb, C, k * k,
                        dw, dbias);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" int msn_relu_mask(const float* dy, const float* y, int64_t total, float* dmasked, msn_stream_t stream) {
+    MSN_REQUIRE(dy && y && dmasked && total > 0, "msn_relu_mask: bad arguments");
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(ew_grid(total)), dim3(256), 0, static_cast<hipStream_t>(stream), dy, y, total,
+                       dmasked);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }

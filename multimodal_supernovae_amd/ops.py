@@ -250,7 +250,8 @@ def unpatchify(dpatches, shape, p):
     return dimg
 
 
-def batchnorm_fwd(x, gamma, beta, running_mean, running_var, training, residual=None, momentum=0.1, eps=1e-5):
+def batchnorm_fwd(x, gamma, beta, running_mean, running_var, training, residual=None, momentum=0.1, eps=1e-5,
+                  relu=False):
     rows, C = x.shape
     dev = x.device
     y = torch.empty_like(x)
@@ -260,8 +261,8 @@ def batchnorm_fwd(x, gamma, beta, running_mean, running_var, training, residual=
     nb = L.msn_bn_workspace_bytes(rows, C)
     ws = _workspace(nb, dev)
     check(L.msn_batchnorm_fwd(ptr(_f32c(x, "x")), rows, C, ptr(gamma), ptr(beta), eps, 1 if training else 0, momentum,
-                              ptr(running_mean), ptr(running_var), ptr(residual), ptr(y), ptr(mean), ptr(rstd),
-                              ptr(ws), nb, stream_ptr()), "msn_batchnorm_fwd")
+                              ptr(running_mean), ptr(running_var), ptr(residual), 1 if relu else 0, ptr(y), ptr(mean),
+                              ptr(rstd), ptr(ws), nb, stream_ptr()), "msn_batchnorm_fwd")
     return y, mean, rstd
 
 
@@ -318,3 +319,49 @@ def vit_tokens_bwd(dtok):
     dpatch = torch.empty((B * (T - 1), e), dtype=torch.float32, device=dtok.device)
     check(lib().msn_vit_tokens_bwd(ptr(_f32c(dtok, "dtok")), B, T, e, ptr(dpatch), stream_ptr()), "msn_vit_tokens_bwd")
     return dpatch
+
+
+# ------------------------------------------------------------------ conv plumbing (build-defined encoders)
+def conv_out(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+def im2col(x, kh, kw, sh, sw, ph, pw):
+    """x: (B, H, W, C) channels-last -> (B*OH*OW, C*kh*kw)."""
+    B, H, W, C = x.shape
+    oh, ow = conv_out(H, kh, sh, ph), conv_out(W, kw, sw, pw)
+    cols = torch.empty((B * oh * ow, C * kh * kw), dtype=torch.float32, device=x.device)
+    check(lib().msn_im2col(ptr(_f32c(x, "x")), B, H, W, C, kh, kw, sh, sw, ph, pw, ptr(cols), stream_ptr()), "msn_im2col")
+    return cols
+
+
+def col2im(dcols, shape, kh, kw, sh, sw, ph, pw):
+    B, H, W, C = shape
+    dx = torch.empty(shape, dtype=torch.float32, device=dcols.device)
+    check(lib().msn_col2im(ptr(_f32c(dcols, "dcols")), B, H, W, C, kh, kw, sh, sw, ph, pw, ptr(dx), stream_ptr()),
+          "msn_col2im")
+    return dx
+
+
+def maxpool2d_fwd(x, k, s, p):
+    B, H, W, C = x.shape
+    oh, ow = conv_out(H, k, s, p), conv_out(W, k, s, p)
+    y = torch.empty((B, oh, ow, C), dtype=torch.float32, device=x.device)
+    arg = torch.empty((B, oh, ow, C), dtype=torch.int32, device=x.device)
+    check(lib().msn_maxpool2d_fwd(ptr(_f32c(x, "x")), B, H, W, C, k, s, p, ptr(y), ptr(arg), stream_ptr()),
+          "msn_maxpool2d_fwd")
+    return y, arg
+
+
+def maxpool2d_bwd(dy, arg, shape, k, s, p):
+    B, H, W, C = shape
+    dx = torch.empty(shape, dtype=torch.float32, device=dy.device)
+    check(lib().msn_maxpool2d_bwd(ptr(_f32c(dy, "dy")), ptr(arg), B, H, W, C, k, s, p, ptr(dx), stream_ptr()),
+          "msn_maxpool2d_bwd")
+    return dx
+
+
+def relu_mask(dy, y):
+    dm = torch.empty_like(dy)
+    check(lib().msn_relu_mask(ptr(_f32c(dy, "dy")), ptr(y), dy.numel(), ptr(dm), stream_ptr()), "msn_relu_mask")
+    return dm

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES ...) of bench.py into a
+per-kernel table + profiles/pmc_sgemm.json (HBM-side traffic per GEMM launch, gfx950 corrections applied:
+FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads -> doubled; WRITE_SIZE exact; both in KB).
+
+    python tools/summarize_pmc.py gpurun_out profiles/r01_pmc_summary.txt
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def load(root, name):
+    files = glob.glob(os.path.join(root, f"pmc_{name}", "*", "*counter_collection.csv"))
+    d = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0, 0]))
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            k = k.replace("void ", "")
+            if "sgemm_kernel" in k:
+                k = "msn::sgemm_kernel<*>"
+            e = d[k][r["Counter_Name"]]
+            e[0] += 1
+            e[1] += float(r["Counter_Value"])
+            e[2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    return d
+
+
+def main():
+    root, out = sys.argv[1], sys.argv[2]
+    fs, ws, mf = load(root, "FETCH_SIZE"), load(root, "WRITE_SIZE"), load(root, "SQ_VALU_MFMA_BUSY_CYCLES")
+    lines = ["kernel | launches | fetch GB (2 x FETCH_SIZE) | write GB | MB / launch | MFMA busy / (SIMD-cycles) | eff. clock GHz"]
+    names = sorted(fs, key=lambda k: -fs[k]["FETCH_SIZE"][1])
+    summary = {}
+    for k in names[:25]:
+        n, f, _ = fs[k]["FETCH_SIZE"]
+        w = ws[k]["WRITE_SIZE"][1] if k in ws else 0.0
+        fetch_b, write_b = 2 * f * 1024, w * 1024
+        util = clock = float("nan")
+        if k in mf and mf[k]["GRBM_GUI_ACTIVE"][2]:
+            t = mf[k]["GRBM_GUI_ACTIVE"][2] * 1e-9
+            clock = mf[k]["GRBM_GUI_ACTIVE"][1] / 8 / t
+            util = mf[k]["SQ_VALU_MFMA_BUSY_CYCLES"][1] / (t * clock * 1024)
+            clock /= 1e9
+        lines.append(f"{k[:60]:60s} | {n:5d} | {fetch_b / 1e9:9.2f} | {write_b / 1e9:8.2f} | {(fetch_b + write_b) / n / 1e6:9.1f} | "
+                     f"{util:6.3f} | {clock:5.2f}")
+        summary[k] = {"launches": n, "traffic_bytes_per_launch": (fetch_b + write_b) / n, "mfma_util": util,
+                      "clock_ghz": clock}
+    open(out, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines[:12]))
+    g = summary.get("msn::sgemm_kernel<*>")
+    if g:
+        json.dump({"kernel": "msn::sgemm_kernel", "traffic_bytes_per_launch": g["traffic_bytes_per_launch"],
+                   "mfma_busy_fraction": g["mfma_util"], "effective_clock_ghz": g["clock_ghz"], "launches": g["launches"],
+                   "workload": "bench.py default (ViT-S/8 + LC transformer, per-GPU batch 1024)",
+                   "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES passes, tools/summarize_pmc.py"},
+                  open(os.path.join(os.path.dirname(out), "pmc_sgemm.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
