@@ -253,6 +253,11 @@ int msn_maxpool2d_fwd(const float* x, int B, int H, int W, int C, int k, int s, 
 int msn_maxpool2d_bwd(const float* dy, const int* argmax, int B, int H, int W, int C, int k, int s, int p,
                       float* dx, msn_stream_t stream);
 
+/* feat[r] = (x[r]*m, t[r]*inv_norm*m, m, 0), m = mask[r]: the 4 input channels of the build-defined 1-D CNN
+ * encoder for light curves / spectra (value, normalised time / wavelength, validity, pad). */
+int msn_series_features(const float* x, const float* t, const uint8_t* mask, int64_t rows, float inv_norm,
+                        float* feat, msn_stream_t stream);
+
 /* Build-defined ViT image encoder (not in the reference; fills its `image_encoder` slot):
  * tok[b][0] = cls + pos[0], tok[b][1+i] = patch[b][i] + pos[1+i]  with T = 1 + n_patches, and the
  * compaction dpatch[b][i] = dtok[b][1+i] used by the backward. */

@@ -379,6 +379,16 @@ __global__ void vit_tokens_bwd_kernel(const float* __restrict__ dtok, int64_t B,
     }
 }
 
+// feat[r] = (x*m, t*inv_norm*m, m, 0): the 4 input channels of the build-defined 1-D CNN encoder
+__global__ void series_features_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                       const uint8_t* __restrict__ mask, int64_t rows, float inv_norm,
+                                       float4* __restrict__ feat) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        const float m = mask[r] ? 1.f : 0.f;
+        feat[r] = make_float4(x[r] * m, t[r] * inv_norm * m, m, 0.f);
+    }
+}
+
 static int pick_lpr(int cols) {
     const int chunks = cols / 4;
     if (chunks <= 4 * NCH) return 4;
@@ -560,6 +570,16 @@ extern "C" int msn_vit_tokens_bwd(const float* dtok, int64_t B, int T, int e, fl
     MSN_REQUIRE(dtok && dpatch && B > 0 && T > 1 && e > 0, "msn_vit_tokens_bwd: bad arguments");
     hipLaunchKernelGGL(vit_tokens_bwd_kernel, dim3((unsigned)std::min<int64_t>(cdiv(B * (T - 1) * e, 256), 4096)),
                        dim3(256), 0, static_cast<hipStream_t>(stream), dtok, B, T, e, dpatch);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" int msn_series_features(const float* x, const float* t, const uint8_t* mask, int64_t rows, float inv_norm,
+                                   float* feat, msn_stream_t stream) {
+    MSN_REQUIRE(x && t && mask && feat && rows > 0 && (reinterpret_cast<uintptr_t>(feat) & 15) == 0,
+                "msn_series_features: bad arguments");
+    hipLaunchKernelGGL(series_features_kernel, dim3((unsigned)std::min<int64_t>(cdiv(rows, 256), 4096)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, t, mask, rows, inv_norm, reinterpret_cast<float4*>(feat));
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }

@@ -86,3 +86,102 @@ def vit_s8(img_size=64, n_out=32, channels=3):
 
 def vit_b16(img_size=224, n_out=32, channels=3):
     return VisionTransformer(img_size=img_size, patch_size=16, channels=channels, emb=768, depth=12, heads=12, n_out=n_out)
+
+
+# ------------------------------------------------------------------------------------------ ResNet-18
+class _BasicBlock(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.stride = stride
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):  # x: (B, H, W, C) channels-last
+        tr = self.training
+        h = F_.conv_cl(x, self.conv1.weight, None, (self.stride, self.stride), (1, 1))
+        h = F_.batchnorm_act(h, self.bn1, tr, relu=True)
+        h = F_.conv_cl(h, self.conv2.weight, None, (1, 1), (1, 1))
+        idt = x
+        if self.downsample is not None:
+            idt = F_.conv_cl(x, self.downsample[0].weight, None, (self.stride, self.stride), (0, 0))
+            idt = F_.batchnorm_act(idt, self.downsample[1], tr)
+        return F_.batchnorm_act(h, self.bn2, tr, residual=idt, relu=True)
+
+
+class ResNet18(nn.Module):
+    """torchvision-style ResNet-18 (same parameter names: conv1, bn1, layer{1..4}.{0,1}.*, fc) computing on
+    channels-last tensors: 7x7/2 stem, 3x3/2 max pool, BasicBlock x [2, 2, 2, 2] (64, 128, 256, 512 channels),
+    global average pool, Linear(512, n_out).  Convolutions = im2col + MFMA GEMM; BN(+ReLU, +skip) fused kernels."""
+
+    def __init__(self, n_out=32, channels=3):
+        super().__init__()
+        self.conv1 = nn.Conv2d(channels, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        widths, cin = [64, 128, 256, 512], 64
+        for i, w in enumerate(widths):
+            stride = 1 if i == 0 else 2
+            setattr(self, f"layer{i + 1}", nn.Sequential(_BasicBlock(cin, w, stride), _BasicBlock(w, w, 1)))
+            cin = w
+        self.fc = nn.Linear(512, n_out)
+
+    def forward(self, x):
+        h = F_.to_channels_last(x)
+        h = F_.conv_cl(h, self.conv1.weight, None, (2, 2), (3, 3))
+        h = F_.batchnorm_act(h, self.bn1, self.training, relu=True)
+        h = F_.maxpool_cl(h, 3, 2, 1)
+        for i in range(1, 5):
+            for blk in getattr(self, f"layer{i}"):
+                h = blk(h)
+        B, H, W, C = h.shape
+        ones = torch.ones((B, H * W), dtype=torch.uint8, device=h.device)
+        pooled = F_.masked_pool(h.reshape(B, H * W, C), ones, "mean")
+        return F_.linear(pooled, self.fc.weight, self.fc.bias)
+
+
+# ------------------------------------------------------------------------------- 1-D CNN series encoder
+class Conv1dEncoder(nn.Module):
+    """Build-defined 1-D CNN for the light-curve / spectrum slots: (x (B,T,1), t (B,T), mask (B,T)) -> (B, n_out).
+    Input channels (x*m, t/time_norm*m, m, 0); `len(widths)` x [Conv1d(k, padding=k//2) + ReLU]; masked mean over
+    the valid positions; Linear(widths[-1], n_out).  Parameter names: convs.{i}.{weight,bias}, projection.*."""
+
+    def __init__(self, n_out=32, widths=(64, 128, 128), kernel_size=5, time_norm=100.0):
+        super().__init__()
+        assert kernel_size % 2 == 1
+        self.kernel_size, self.time_norm = kernel_size, float(time_norm)
+        self.convs = nn.ModuleList()
+        cin = 4
+        for w in widths:
+            self.convs.append(nn.Conv1d(cin, w, kernel_size, padding=kernel_size // 2))
+            cin = w
+        self.projection = nn.Linear(cin, n_out)
+
+    def forward(self, x, t, mask=None):
+        if mask is None:
+            raise TypeError("Conv1dEncoder needs the (B, T) padding mask, like the reference's series encoders")
+        from . import ops
+        B, T = t.shape
+        m = ops._mask_u8(mask)
+        h = _SeriesFeatures.apply(x.reshape(B, T).float(), t.float(), m, 1.0 / self.time_norm).view(B, 1, T, 4)
+        k = self.kernel_size
+        for conv in self.convs:
+            h = F_.conv_cl(h, conv.weight.unsqueeze(2), conv.bias, (1, 1), (0, k // 2), relu=True)
+        pooled = F_.masked_pool(h.view(B, T, -1), m, "mean")
+        return F_.linear(pooled, self.projection.weight, self.projection.bias)
+
+
+class _SeriesFeatures(torch.autograd.Function):
+    """Input featurisation; the inputs are data (no gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, t, mask_u8, inv_norm):
+        from . import ops
+        return ops.series_features(x.contiguous(), t.contiguous(), mask_u8, inv_norm)
+
+    @staticmethod
+    def backward(ctx, d):
+        return None, None, None, None

@@ -561,3 +561,102 @@ class _TakeToken(torch.autograd.Function):
 
 def take_token(x, idx):
     return _TakeToken.apply(x, idx)
+
+
+# ------------------------------------------------------ channels-last convolution (build-defined encoders)
+class _ConvCL(torch.autograd.Function):
+    """y = conv(x) (+ bias) (+ ReLU) on channels-last tensors via im2col + the MFMA GEMM; weight keeps
+    torch's (C_out, C_in, kh, kw) layout (the column order matches its flattening)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, relu):
+        B, H, W, C = x.shape
+        co, ci, kh, kw = weight.shape
+        assert ci == C, f"conv expects {ci} input channels, got {C}"
+        (sh, sw), (ph, pw) = stride, padding
+        x = _c(x)
+        plain = kh == 1 and kw == 1 and sh == 1 and sw == 1 and ph == 0 and pw == 0
+        cols = x.view(B * H * W, C) if plain else ops.im2col(x, kh, kw, sh, sw, ph, pw)
+        oh, ow = ops.conv_out(H, kh, sh, ph), ops.conv_out(W, kw, sw, pw)
+        y = sgemm(cols, weight.view(co, -1), OP_N, OP_T, bias=bias, epilogue=EPI_RELU if relu else EPI_NONE)
+        ctx.geom = (B, H, W, C, kh, kw, sh, sw, ph, pw, plain, relu, bias is not None)
+        ctx.save_for_backward(cols, weight, y if relu else torch.empty(0))
+        return y.view(B, oh, ow, co)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, C, kh, kw, sh, sw, ph, pw, plain, relu, has_bias = ctx.geom
+        cols, weight, y = ctx.saved_tensors
+        co = weight.shape[0]
+        d = _c(dy).view(-1, co)
+        if relu:
+            d = ops.relu_mask(d, y)
+        dw = sgemm(d, cols, OP_T, OP_N).view_as(weight)
+        db = colsum(d) if has_bias else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dcols = sgemm(d, weight.view(co, -1), OP_N, OP_N)
+            dx = dcols.view(B, H, W, C) if plain else ops.col2im(dcols, (B, H, W, C), kh, kw, sh, sw, ph, pw)
+        return dx, dw, db, None, None, None
+
+
+def conv_cl(x, weight, bias=None, stride=(1, 1), padding=(0, 0), relu=False):
+    return _ConvCL.apply(x, weight, bias, tuple(stride), tuple(padding), relu)
+
+
+class _BatchNormAct(torch.autograd.Function):
+    """y = [relu](BatchNorm(x) [+ residual]) over the rows of a (rows, C) token matrix (channels-last BN2d)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, residual, relu):
+        shape = x.shape
+        x2 = _c(x).view(-1, shape[-1])
+        r2 = _c(residual).view(-1, shape[-1]) if residual is not None else None
+        y, mean, rstd = ops.batchnorm_fwd(x2, gamma, beta, running_mean, running_var, training, residual=r2, relu=relu)
+        ctx.cfg = (bool(training), bool(relu), residual is not None, shape)
+        ctx.save_for_backward(x2, gamma, mean, rstd, y if relu else torch.empty(0))
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        training, relu, has_res, shape = ctx.cfg
+        x2, gamma, mean, rstd, y = ctx.saved_tensors
+        d = _c(dy).view(-1, shape[-1])
+        if relu:
+            d = ops.relu_mask(d, y)
+        dx, dg, db = ops.batchnorm_bwd(d, x2, None, mean, rstd, gamma, training)
+        return dx.view(shape), dg, db, None, None, None, (d.view(shape) if has_res else None), None
+
+
+def batchnorm_act(x, bn, training, residual=None, relu=False):
+    """`bn` is an nn.BatchNorm2d parameter holder."""
+    out = _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, residual, relu)
+    if training:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+    return out
+
+
+class _MaxPoolCL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, s, p):
+        y, arg = ops.maxpool2d_fwd(_c(x), k, s, p)
+        ctx.cfg = (tuple(x.shape), k, s, p)
+        ctx.save_for_backward(arg)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        shape, k, s, p = ctx.cfg
+        (arg,) = ctx.saved_tensors
+        return ops.maxpool2d_bwd(_c(dy), arg, shape, k, s, p), None, None, None
+
+
+def maxpool_cl(x, k, s, p):
+    return _MaxPoolCL.apply(x, k, s, p)
+
+
+def to_channels_last(img):
+    """(B, C, H, W) -> (B, H, W, C) through the 1x1 patch gather (and its adjoint in backward)."""
+    B, C, H, W = img.shape
+    return patchify(img, 1).view(B, H, W, C)

@@ -365,3 +365,11 @@ def relu_mask(dy, y):
     dm = torch.empty_like(dy)
     check(lib().msn_relu_mask(ptr(_f32c(dy, "dy")), ptr(y), dy.numel(), ptr(dm), stream_ptr()), "msn_relu_mask")
     return dm
+
+
+def series_features(x, t, mask_u8, inv_norm):
+    B, T = x.shape
+    feat = torch.empty((B, T, 4), dtype=torch.float32, device=x.device)
+    check(lib().msn_series_features(ptr(_f32c(x, "x")), ptr(_f32c(t, "t")), ptr(mask_u8), B * T, inv_norm, ptr(feat),
+                                    stream_ptr()), "msn_series_features")
+    return feat
