@@ -114,6 +114,48 @@ struct OperandTile {
             }
         }
     }
+    // ---- fast path (VEC kernels, K-steps that lie completely inside [k_begin, k_end)) ----------------
+    // Per-thread source pointers are computed ONCE: rows / columns beyond the matrix are clamped onto
+    // valid ones (whatever they load only feeds output elements that are never stored), so a full
+    // K-step needs no masks and no address arithmetic beyond one add.
+    __device__ static __forceinline__ void init_ptrs(const float* (&ptr)[kLoads], const float* __restrict__ g,
+                                                     int64_t ld, int64_t row0, int64_t nrows, int64_t k_begin) {
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) {
+            const int idx = t + 256 * i;
+            if (KMAJOR) {
+                const int k = idx / (ROWS / 4), q = idx % (ROWS / 4);
+                int64_t c = row0 + 4 * q;
+                c = c + 3 < nrows ? c : nrows - 4;
+                ptr[i] = g + (k_begin + k) * ld + c;
+            } else {
+                const int r = idx / (BK / 4), q = idx % (BK / 4);
+                int64_t rr = row0 + r;
+                rr = rr < nrows ? rr : nrows - 1;
+                ptr[i] = g + rr * ld + k_begin + 4 * q;
+            }
+        }
+    }
+    __device__ static __forceinline__ void fetch_fast(float4 (&reg)[kLoads], const float* const (&ptr)[kLoads],
+                                                      int64_t step_offset) {
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) reg[i] = *reinterpret_cast<const float4*>(ptr[i] + step_offset);
+    }
+    __device__ static __forceinline__ void stash_fast(const float4 (&reg)[kLoads], float* lds) {
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) {
+            const int idx = t + 256 * i;
+            if (KMAJOR) {
+                const int k = idx / (ROWS / 4), q = idx % (ROWS / 4);
+                *reinterpret_cast<float4*>(lds + k * kStride + 4 * q) = reg[i];
+            } else {
+                const int r = idx / (BK / 4), q = idx % (BK / 4);
+                *reinterpret_cast<float4*>(lds + r * kStride + 4 * q) = reg[i];
+            }
+        }
+    }
     // Fragment for one 32-row MFMA slab and one k-octet `ko`: f.{x,y,z,w} = element k = 8ko+4h+{0..3}.
     __device__ static __forceinline__ float4 frag(const float* lds, int row_in_tile, int ko, int h) {
         if (KMAJOR) {
@@ -168,22 +210,44 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmArgs p) {
     float4 ra[TA::kLoads], rb[TB::kLoads];
     unsigned oka = 0u, okb = 0u;
     const int nkt = (int)((k_end - k_begin + BK - 1) / BK);
+    const int nfull = VEC ? (int)((k_end - k_begin) / BK) : 0;   // K-steps that need no bounds handling
+    const float* pa[TA::kLoads];
+    const float* pb[TB::kLoads];
+    if (VEC) {
+        // VEC guarantees M (or K) % 4 == 0 etc., but a K-major operand narrower than one vector cannot be clamped
+        TA::init_ptrs(pa, p.A, p.lda, m0, p.M, k_begin);
+        TB::init_ptrs(pb, p.B, p.ldb, n0, p.N, k_begin);
+    }
+    const int64_t a_step = AKM ? (int64_t)BK * p.lda : BK, b_step = BKM ? (int64_t)BK * p.ldb : BK;
+    auto fetch_step = [&](int kt) {   // global -> registers for K-step kt
+        if (kt < nfull) {
+            TA::fetch_fast(ra, pa, kt * a_step);
+            TB::fetch_fast(rb, pb, kt * b_step);
+        } else {
+            const int64_t k0 = k_begin + (int64_t)kt * BK;
+            TA::template fetch<VEC>(ra, oka, p.A, p.lda, m0, p.M, k0, k_end);
+            TB::template fetch<VEC>(rb, okb, p.B, p.ldb, n0, p.N, k0, k_end);
+        }
+    };
+    auto stash_step = [&](int kt, int buf) {   // registers -> LDS buffer `buf`
+        if (kt < nfull) {
+            TA::stash_fast(ra, a_buf(buf));
+            TB::stash_fast(rb, b_buf(buf));
+        } else {
+            TA::stash(ra, oka, a_buf(buf));
+            TB::stash(rb, okb, b_buf(buf));
+        }
+    };
     if (nkt > 0) {
-        TA::template fetch<VEC>(ra, oka, p.A, p.lda, m0, p.M, k_begin, k_end);
-        TB::template fetch<VEC>(rb, okb, p.B, p.ldb, n0, p.N, k_begin, k_end);
-        TA::stash(ra, oka, a_buf(0));
-        TB::stash(rb, okb, b_buf(0));
+        fetch_step(0);
+        stash_step(0, 0);
     }
     __syncthreads();
 
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nkt;
-        if (more) {  // prefetch the next K-step into registers while this one is multiplied
-            const int64_t k0 = k_begin + (int64_t)(kt + 1) * BK;
-            TA::template fetch<VEC>(ra, oka, p.A, p.lda, m0, p.M, k0, k_end);
-            TB::template fetch<VEC>(rb, okb, p.B, p.ldb, n0, p.N, k0, k_end);
-        }
+        if (more) fetch_step(kt + 1);   // prefetch the next K-step into registers while this one is multiplied
         const float* as = a_buf(cur);
         const float* bs = b_buf(cur);
 #pragma unroll
@@ -203,10 +267,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmArgs p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        if (more) {
-            TA::stash(ra, oka, a_buf(cur ^ 1));
-            TB::stash(rb, okb, b_buf(cur ^ 1));
-        }
+        if (more) stash_step(kt + 1, cur ^ 1);
         __syncthreads();
     }
 
@@ -310,7 +371,8 @@ static int launch_cfg(const GemmArgs& a, int opA, int opB, hipStream_t st) {
     // K-contiguous operand, M / N for a K-major one)
     const int64_t a_ext = opA == MSN_OP_T ? a.M : a.K, b_ext = opB == MSN_OP_N ? a.N : a.K;
     const bool vec = (a.lda % 4 == 0) && (a_ext % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0) &&
-                     (a.ldb % 4 == 0) && (b_ext % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0);
+                     (a.ldb % 4 == 0) && (b_ext % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0) &&
+                     a_ext >= 4 && b_ext >= 4;
 #define MSN_GEMM_GO(AKM, BKM)                                                                               \
     {                                                                                                       \
         if (vec) hipLaunchKernelGGL((sgemm_kernel<BM, BN, WM, WN, AKM, BKM, true>), grid, block, 0, st, a); \
