@@ -313,15 +313,22 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmArgs p) {
         }
 }
 
-// C[m][n] = sum_s partial[s][m][n]   (split-K finish; fixed order -> deterministic)
-__global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C, int64_t M,
-                                     int64_t N, int64_t ldc, int splits) {
+// C[m][n] = sum_s partial[s][m][n]   (split-K finish; fixed order -> deterministic).  A block covers 64
+// consecutive outputs with 4 thread groups that each sum a quarter of the slabs, combined through LDS.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C,
+                                                            int64_t M, int64_t N, int64_t ldc, int splits) {
+    __shared__ float red[4][64];
     const int64_t total = M * N;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {
+        const int64_t i = base + cl;
         float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += partial[(int64_t)k * total + i];
-        C[(i / N) * ldc + (i % N)] = s;
+        if (i < total)
+            for (int k = g; k < splits; k += 4) s += partial[(int64_t)k * total + i];
+        red[g][cl] = s;
+        __syncthreads();
+        if (g == 0 && i < total) C[(i / N) * ldc + (i % N)] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        __syncthreads();
     }
 }
 
@@ -396,7 +403,7 @@ static void plan(int64_t M, int64_t N, int64_t K, int opA, int* bm, int* bn, int
     int s = 1;
     if (opA == MSN_OP_T && tiles < 512) {
         const int64_t ksteps = cdiv(K, BK);
-        s = (int)std::min<int64_t>(std::min<int64_t>(cdiv(1024, tiles), ksteps / 4 > 0 ? ksteps / 4 : 1), 512);
+        s = (int)std::min<int64_t>(std::min<int64_t>(cdiv(768, tiles), ksteps / 4 > 0 ? ksteps / 4 : 1), 256);
         if (s < 1) s = 1;
     }
     int64_t per = cdiv(cdiv(K, s), BK) * BK;
@@ -464,7 +471,7 @@ extern "C" int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, cons
     if (rc != MSN_OK) return rc;
     if (splits > 1) {
         const int64_t total = M * N;
-        const int blocks = (int)std::min<int64_t>(cdiv(total, 256), 2048);
+        const int blocks = (int)std::min<int64_t>(cdiv(total, 64), 4096);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.partial, C, M, N, ldc, splits);
         MSN_LAUNCH_CHECK();
     }
