@@ -27,6 +27,9 @@ sys.path.insert(0, ROOT)
 LC = dict(n_out=32, emb=64, heads=8, depth=5, dropout=0.0, time_norm=20583.369161312577, agg="mean")
 CONV_PLACEHOLDER = dict(dim=8, depth=1, channels=3, kernel_size=5, patch_size=8, n_out=32, dropout_prob=0.0)
 IMG, T_LC, NBAND, ENC_DIM, N_OUT = 64, 200, 2, 128, 32
+GEMM_KERNEL_NAME = {"f32": "msn::sgemm_kernel (fp32 v_mfma_f32_32x32x2_f32)",
+                    "bf16x3": "msn::bgemm_kernel<planes=2> (3 x v_mfma_f32_32x32x16_bf16 per algorithmic MAC tile)",
+                    "bf16": "msn::bgemm_kernel<planes=1> (v_mfma_f32_32x32x16_bf16)"}
 LR, WD, LOGIT_SCALE = 3.716367614864064e-05, 0.000555522900788888, 19.545966923442453  # maven_pretrain_config.yaml
 
 
@@ -125,13 +128,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--per-gpu-batch", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra split-bf16 measurement")
     ap.add_argument("--gemm-table", action="store_true", help="per-shape GEMM timing of one step on stderr")
+    ap.add_argument("--gemm-precision", default="f32", choices=["f32", "bf16x3", "bf16"],
+                    help="inner-product precision of the GEMMs (bf16x3 = split-bf16, fp32-grade accuracy)")
     ap.add_argument("--cpu-sample-batch", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=2)
     args = ap.parse_args()
 
     from multimodal_supernovae_amd import _lib, distributed as D, ops
     _lib.require_gpu()
+    ops.set_gemm_precision(args.gemm_precision)
     rank, local, world = D.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -180,7 +187,9 @@ def main():
     gemm_flops = sum(e[2] for e in prof)
     gemm_bytes = sum(4.0 * (e[3][2] * e[3][4] + e[3][4] * e[3][3] + e[3][2] * e[3][3]) for e in prof)
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-    peak = 157.3  # TFLOP/s, dense fp32 matrix (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md
+    # dense matrix peak of the instruction the dominant kernel issues (MI355X_MICROARCH.md): fp32 157.3 TFLOP/s;
+    # bf16 2500 TFLOP/s, of which the 3-product split can deliver at most a third as algorithmic flops
+    peak = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}[args.gemm_precision]
 
     if rank == 0 and args.gemm_table:
         table = {}
@@ -202,6 +211,27 @@ def main():
     except (OSError, ValueError, KeyError):
         pass
 
+    # ---- optional second measurement: the same step with the GEMMs on the bf16 matrix cores through the
+    # 3-product split (fp32-grade: ~1e-5 relative per product).  Reported beside the headline, never as it.
+    alt = None
+    if args.gemm_precision == "f32" and not args.no_alt:
+        ops.set_gemm_precision("bf16x3")
+        for _ in range(2):
+            alt_loss = step()
+        fence()
+        t1 = time.perf_counter()
+        n_alt = max(3, args.steps // 2)
+        for _ in range(n_alt):
+            alt_loss = step()
+        fence()
+        dt_alt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+        if world > 1:
+            torch.distributed.all_reduce(dt_alt, op=torch.distributed.ReduceOp.MAX)
+        ops.set_gemm_precision("f32")
+        alt = {"gemm_precision": "bf16x3 (operands split hi+lo into bf16, 3 v_mfma_f32_32x32x16_bf16 products, fp32 accumulate)",
+               "value": b * world * n_alt / float(dt_alt), "unit": "pairs/s", "ms_per_step": float(dt_alt) / n_alt * 1e3,
+               "steps": n_alt, "note": "opt-in (--gemm-precision bf16x3); the headline value above is exact fp32"}
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         pairs = b * world * args.steps / dt
@@ -216,13 +246,15 @@ def main():
                        "per_gpu_batch": b, "global_batch": b * world, "parallelism": f"dp{world}",
                        "loss": loss_value, "algorithmic_gflop_per_pair": flops_per_pair() / 1e9,
                        "model_tflops": pairs * flops_per_pair() / 1e12},
-            "roofline": {"bound": "mfma", "kernel": "msn::sgemm_kernel (fp32 v_mfma_f32_32x32x2_f32)",
+            "roofline": {"bound": "mfma", "kernel": GEMM_KERNEL_NAME[args.gemm_precision],
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_unit": "bytes per launch (mean), 2 x FETCH_SIZE + WRITE_SIZE",
                          "launches_per_step": len(prof), "ms_per_step_in_kernel": gemm_ms,
                          "algorithmic_gflop_per_step": gemm_flops / 1e9,
                          "algorithmic_bytes_per_launch": gemm_bytes / max(len(prof), 1)},
         }
+        if alt is not None:
+            out["alt_split_bf16"] = alt
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_batch, args.cpu_steps)
         elif world == 1:

@@ -65,11 +65,19 @@ int msn_device_count(void);
 #define MSN_EPI_RELU_BWD 3
 #define MSN_EPI_GELU_BWD 4
 #define MSN_EPI_ADD 5
+/* precision of the inner products (inputs / outputs are fp32 in every mode):
+ *   MSN_PREC_F32     exact fp32 on v_mfma_f32_32x32x2_f32 (default; 157 TFLOP/s peak)
+ *   MSN_PREC_BF16X3  each operand split hi + lo into two bf16, three v_mfma_f32_32x32x16_bf16 products with
+ *                    fp32 accumulation: ~1e-5 relative error per product, 5.3x the fp32 matrix rate
+ *   MSN_PREC_BF16    operands rounded to bf16, one product (BASELINE cfg5 "bf16 on MFMA") */
+#define MSN_PREC_F32 0
+#define MSN_PREC_BF16X3 1
+#define MSN_PREC_BF16 2
 
 size_t msn_sgemm_workspace_bytes(int opA, int opB, int64_t M, int64_t N, int64_t K);
 int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
               const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int epilogue,
-              float* aux, int64_t ldaux, void* ws, size_t ws_bytes, msn_stream_t stream);
+              float* aux, int64_t ldaux, int precision, void* ws, size_t ws_bytes, msn_stream_t stream);
 
 /* out[n] = sum_m X[m][n]  (bias gradients).  ws >= msn_colsum_workspace_bytes(M, N). */
 size_t msn_colsum_workspace_bytes(int64_t M, int64_t N);

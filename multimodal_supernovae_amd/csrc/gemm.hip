@@ -13,29 +13,9 @@
 // tiles that walk N fastest (neighbours share the A row-panel in that XCD's L2).
 #include <algorithm>
 
-#include "msn_common.h"
+#include "gemm_common.h"
 
 namespace msn {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BK = 32;
-constexpr int KPAD = 4;  // floats; keeps 16-B alignment and makes b128 fragment reads conflict-free
-
-struct GemmArgs {
-    const float* A;
-    const float* B;
-    float* C;
-    const float* bias;
-    float* aux;
-    int64_t M, N, K;
-    int64_t lda, ldb, ldc, ldaux;
-    int epilogue;
-    int tiles_m, tiles_n;
-    int k_per_split;  // multiple of BK
-    int splits;
-    float* partial;   // [splits][M][N] when splits > 1
-};
 
 // Load 4 consecutive elements (r, c..c+3) of a stored row-major matrix from an address CLAMPED into
 // the matrix; `ok` bit j says whether element j is really inside [nr, nc).  Branch-free and with the
@@ -167,13 +147,6 @@ struct OperandTile {
     }
 };
 
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    // bijective for any nwg: XCD x (= bid % 8) owns a contiguous chunk of logical ids
-    const int q = nwg / 8, r = nwg % 8, x = bid % 8;
-    const int base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-    return base + bid / 8;
-}
-
 template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, bool VEC>
 __global__ __launch_bounds__(256) void sgemm_kernel(const GemmArgs p) {
     using TA = OperandTile<BM, AKM>;
@@ -271,46 +244,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h ----
-    // The aux operand of a 32x32 tile is read as one batch of 16 loads before any arithmetic, so the
-    // loads overlap instead of paying one memory round trip per element.
-    const bool to_partial = p.splits > 1;
-    float* out = to_partial ? p.partial + (int64_t)split * p.M * p.N : p.C;
-    const int64_t ldo = to_partial ? p.N : p.ldc;
-    const int epi = to_partial ? MSN_EPI_NONE : p.epilogue;
-    const bool reads_aux = epi == MSN_EPI_RELU_BWD || epi == MSN_EPI_GELU_BWD || epi == MSN_EPI_ADD;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int64_t col = n0 + wn0 + 32 * j + l32;
-            const bool col_ok = col < p.N;
-            const float bv = (!to_partial && p.bias && col_ok) ? p.bias[col] : 0.f;
-            const int64_t row0 = m0 + wm0 + 32 * i + 4 * h;
-            float av[16];
-            if (reads_aux) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
-                    av[r] = (col_ok && row < p.M) ? p.aux[row * p.ldaux + col] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
-                float v = acc[i][j][r] + bv;
-                if (epi == MSN_EPI_RELU) v = fmaxf(v, 0.f);
-                else if (epi == MSN_EPI_GELU) {
-                    const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
-                    if (p.aux && col_ok && row < p.M)
-                        p.aux[row * p.ldaux + col] = cdf + v * 0.39894228040143268f * __expf(-0.5f * v * v);
-                    v *= cdf;
-                } else if (epi == MSN_EPI_RELU_BWD) v = av[r] > 0.f ? v : 0.f;
-                else if (epi == MSN_EPI_GELU_BWD) v *= av[r];
-                else if (epi == MSN_EPI_ADD) v += av[r];
-                if (col_ok && row < p.M) out[row * ldo + col] = v;
-            }
-        }
+    gemm_epilogue<TM, TN>(acc, p, m0, n0, wm0, wn0, l32, h, split);
 }
 
 // C[m][n] = sum_s partial[s][m][n]   (split-K finish; fixed order -> deterministic).  A block covers 64
@@ -428,7 +362,7 @@ extern "C" size_t msn_sgemm_workspace_bytes(int opA, int opB, int64_t M, int64_t
 
 extern "C" int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                          const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int epilogue,
-                         float* aux, int64_t ldaux, void* ws, size_t ws_bytes, msn_stream_t stream) {
+                         float* aux, int64_t ldaux, int precision, void* ws, size_t ws_bytes, msn_stream_t stream) {
     MSN_REQUIRE(M >= 0 && N >= 0 && K >= 0, "msn_sgemm: negative size M=%lld N=%lld K=%lld", (long long)M,
                 (long long)N, (long long)K);
     if (M == 0 || N == 0) return MSN_OK;
@@ -440,6 +374,7 @@ extern "C" int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, cons
     MSN_REQUIRE(ldb >= (opB == MSN_OP_N ? N : K), "msn_sgemm: ldb %lld too small", (long long)ldb);
     MSN_REQUIRE(ldc >= N, "msn_sgemm: ldc %lld < N", (long long)ldc);
     MSN_REQUIRE(epilogue >= MSN_EPI_NONE && epilogue <= MSN_EPI_ADD, "msn_sgemm: bad epilogue %d", epilogue);
+    MSN_REQUIRE(precision >= MSN_PREC_F32 && precision <= MSN_PREC_BF16, "msn_sgemm: bad precision %d", precision);
     const bool needs_aux = epilogue == MSN_EPI_RELU_BWD || epilogue == MSN_EPI_GELU_BWD || epilogue == MSN_EPI_ADD;
     MSN_REQUIRE(!needs_aux || (aux && ldaux >= N), "msn_sgemm: epilogue %d needs aux with ldaux >= N", epilogue);
     MSN_REQUIRE(!(epilogue == MSN_EPI_GELU && aux) || ldaux >= N, "msn_sgemm: ldaux < N");
@@ -465,7 +400,14 @@ extern "C" int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, cons
     MSN_REQUIRE((int64_t)a.tiles_m * a.tiles_n < (1ll << 31), "msn_sgemm: too many tiles");
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc;
-    if (bn == 128) rc = launch_cfg<128, 128, 64, 64>(a, opA, opB, st);
+    // bf16 matrix-core paths need 16-byte loads on the K-contiguous operands; otherwise stay on fp32
+    bool bf16_ok = precision != MSN_PREC_F32;
+    if (bf16_ok && opA == MSN_OP_N)
+        bf16_ok = (lda % 4 == 0) && (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+    if (bf16_ok && opB == MSN_OP_T)
+        bf16_ok = (ldb % 4 == 0) && (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+    if (bf16_ok) rc = launch_bgemm(a, opA, opB, precision == MSN_PREC_BF16X3 ? 2 : 1, bm, bn, st);
+    else if (bn == 128) rc = launch_cfg<128, 128, 64, 64>(a, opA, opB, st);
     else if (bn == 64) rc = launch_cfg<128, 64, 64, 32>(a, opA, opB, st);
     else rc = launch_cfg<128, 32, 32, 32>(a, opA, opB, st);
     if (rc != MSN_OK) return rc;

@@ -1,0 +1,86 @@
+// Pieces shared by the fp32 (gemm.hip) and bf16 (gemm_bf16.hip) MFMA GEMM kernels.
+#pragma once
+#include "msn_common.h"
+
+namespace msn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int KPAD = 4;  // floats; keeps 16-B alignment and makes b128 fragment reads conflict-free
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    float* aux;
+    int64_t M, N, K;
+    int64_t lda, ldb, ldc, ldaux;
+    int epilogue;
+    int tiles_m, tiles_n;
+    int k_per_split;  // multiple of BK
+    int splits;
+    float* partial;   // [splits][M][N] when splits > 1
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    // bijective for any nwg: XCD x (= bid % 8) owns a contiguous chunk of logical ids
+    const int q = nwg / 8, r = nwg % 8, x = bid % 8;
+    const int base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + bid / 8;
+}
+
+
+// Epilogue of a (TM x TN) grid of 32x32 accumulator tiles (C/D layout of every 32x32 MFMA on gfx950,
+// fp32 and bf16 alike: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h).  The aux operand of a tile
+// is read as one batch of 16 loads before any arithmetic, so the loads overlap instead of paying one
+// memory round trip per element.
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[TM][TN], const GemmArgs& p, int64_t m0, int64_t n0,
+                                              int wm0, int wn0, int l32, int h, int split) {
+    const bool to_partial = p.splits > 1;
+    float* out = to_partial ? p.partial + (int64_t)split * p.M * p.N : p.C;
+    const int64_t ldo = to_partial ? p.N : p.ldc;
+    const int epi = to_partial ? MSN_EPI_NONE : p.epilogue;
+    const bool reads_aux = epi == MSN_EPI_RELU_BWD || epi == MSN_EPI_GELU_BWD || epi == MSN_EPI_ADD;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int64_t col = n0 + wn0 + 32 * j + l32;
+            const bool col_ok = col < p.N;
+            const float bv = (!to_partial && p.bias && col_ok) ? p.bias[col] : 0.f;
+            const int64_t row0 = m0 + wm0 + 32 * i + 4 * h;
+            float av[16];
+            if (reads_aux) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
+                    av[r] = (col_ok && row < p.M) ? p.aux[row * p.ldaux + col] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r] + bv;
+                if (epi == MSN_EPI_RELU) v = fmaxf(v, 0.f);
+                else if (epi == MSN_EPI_GELU) {
+                    const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
+                    if (p.aux && col_ok && row < p.M)
+                        p.aux[row * p.ldaux + col] = cdf + v * 0.39894228040143268f * __expf(-0.5f * v * v);
+                    v *= cdf;
+                } else if (epi == MSN_EPI_RELU_BWD) v = av[r] > 0.f ? v : 0.f;
+                else if (epi == MSN_EPI_GELU_BWD) v *= av[r];
+                else if (epi == MSN_EPI_ADD) v += av[r];
+                if (col_ok && row < p.M) out[row * ldo + col] = v;
+            }
+        }
+}
+
+// bf16 matrix-core variant (gemm_bf16.hip): planes = 1 -> operands rounded to bf16, planes = 2 -> each
+// operand split hi + lo and three products accumulated (fp32-grade accuracy).  Needs the vector-load
+// conditions of the VEC fp32 kernels; the caller falls back to the fp32 kernels otherwise.
+int launch_bgemm(const GemmArgs& a, int opA, int opB, int planes, int bm, int bn, hipStream_t st);
+
+}  // namespace msn

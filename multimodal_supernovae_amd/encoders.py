@@ -46,9 +46,13 @@ class VisionTransformer(nn.Module):
     -> final LN -> class token -> Linear(emb, n_out).  LayerNorm eps 1e-6, softmax scale 1/sqrt(head_dim).
     ViT-S/8: emb 384, heads 6, depth 12, patch 8 (T = 65 at 64x64);  ViT-B/16: 768 / 12 / 12 / 16."""
 
-    def __init__(self, img_size=64, patch_size=8, channels=3, emb=384, depth=12, heads=6, mlp_ratio=4, n_out=32):
+    def __init__(self, img_size=64, patch_size=8, channels=3, emb=384, depth=12, heads=6, mlp_ratio=4, n_out=32,
+                 gemm_precision=None):
         super().__init__()
         assert emb % heads == 0
+        # None = the process default (exact fp32); "bf16" = operands rounded to bf16 on the bf16 matrix cores
+        # (BASELINE cfg5); "bf16x3" = split-bf16, fp32-grade.  Attention, norms and the loss stay fp32.
+        self.gemm_precision = gemm_precision
         self.patch_size, self.emb, self.heads, self.depth = patch_size, emb, heads, depth
         self.grid = img_size // patch_size
         self.num_tokens = 1 + self.grid * self.grid
@@ -62,6 +66,13 @@ class VisionTransformer(nn.Module):
         self.head = nn.Linear(emb, n_out)
 
     def forward(self, x):
+        if self.gemm_precision is None:
+            return self._forward(x)
+        from . import ops
+        with ops.gemm_precision(self.gemm_precision):
+            return self._forward(x)
+
+    def _forward(self, x):
         B = x.shape[0]
         T, e = self.num_tokens, self.emb
         if x.shape[2] // self.patch_size != self.grid or x.shape[3] // self.patch_size != self.grid:
@@ -84,8 +95,10 @@ def vit_s8(img_size=64, n_out=32, channels=3):
     return VisionTransformer(img_size=img_size, patch_size=8, channels=channels, emb=384, depth=12, heads=6, n_out=n_out)
 
 
-def vit_b16(img_size=224, n_out=32, channels=3):
-    return VisionTransformer(img_size=img_size, patch_size=16, channels=channels, emb=768, depth=12, heads=12, n_out=n_out)
+def vit_b16(img_size=224, n_out=32, channels=3, gemm_precision="bf16"):
+    """BASELINE cfg5: ViT-B/16 with its GEMMs on the bf16 matrix cores."""
+    return VisionTransformer(img_size=img_size, patch_size=16, channels=channels, emb=768, depth=12, heads=12, n_out=n_out,
+                             gemm_precision=gemm_precision)
 
 
 # ------------------------------------------------------------------------------------------ ResNet-18

@@ -16,7 +16,25 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _remember_precision(cls):
+    """Class decorator: the GEMM precision in force when a node's forward ran is re-established for its
+    backward (which autograd calls later, outside any ops.gemm_precision(...) scope)."""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *args):
+        ctx._gemm_precision = ops.GEMM_PRECISION
+        return fwd(ctx, *args)
+
+    def backward(ctx, *grads):
+        with ops.gemm_precision(ctx._gemm_precision):
+            return bwd(ctx, *grads)
+
+    cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+    return cls
+
+
 # ------------------------------------------------------------------------------- linear chains
+@_remember_precision
 class _LinearChain(torch.autograd.Function):
     """y = L_n(act_{n-1}(... act_1(L_1(x)))) -- nn.Linear stacks with ReLU / GELU between them
     (MLP, ref models_multimodal.py:853-856; ConvMixer head :85-88; any single Linear).  The
@@ -89,6 +107,7 @@ def linear(x, weight, bias=None):
 
 
 # --------------------------------------------------------------------- projection + L2 normalise
+@_remember_precision
 class _ProjectNormalise(torch.autograd.Function):
     """x -> Linear(n_out, enc_dim) -> x / ||x||  (ref models_multimodal.py:275-304, no epsilon)."""
 
@@ -168,6 +187,7 @@ def _attn_backward_raw(dz, x2, B, T, saved, wq, wk, wv, wu, mask_u8, heads, scal
     return dx, dwq, dwk, dwv, dwu, dbu
 
 
+@_remember_precision
 class _SelfAttention(torch.autograd.Function):
     """ref transformer_utils.py:36-89 as one node (q/k/v GEMMs, fused attention, unifyheads)."""
 
@@ -197,6 +217,7 @@ def self_attention(x, mask, heads, tokeys, toqueries, tovalues, unify_w, unify_b
 
 
 # ---------------------------------------------------------------- post-norm transformer block
+@_remember_precision
 class _PostNormBlock(torch.autograd.Function):
     """ref transformer_utils.py:109-116: x = LN1(attn(x) + x); x = LN2(FF(x) + x), FF = Linear ->
     ReLU -> Linear.  Residual adds ride in the unifyheads / ff.2 GEMM epilogues; in backward the
@@ -306,6 +327,7 @@ def mask_tokens(x, mask_u8):
     return _MaskTokens.apply(x, mask_u8)
 
 
+@_remember_precision
 class _AttnPool(torch.autograd.Function):
     """ref transformer_utils.py:240-246: nn.MultiheadAttention(emb, 2 heads, batch_first) with ONE
     learnable query shared by the batch, keys = values = the (zeroed) tokens, no key mask."""
@@ -364,6 +386,7 @@ def attn_pool(x, query, in_proj_weight, in_proj_bias, out_w, out_b):
 
 
 # ------------------------------------------------------------------------------ ConvMixer trunk
+@_remember_precision
 class _ConvMixerTrunk(torch.autograd.Function):
     """ref models_multimodal.py:52-79 (the `net` Sequential): patch conv -> GELU -> BN, then per
     layer x + BN(GELU(depthwise(x))) followed by BN(GELU(1x1 conv)).  Channels-last token matrices;
@@ -437,6 +460,7 @@ def convmixer_trunk(img, training, depth, patch, flat_params):
 
 
 # ------------------------------------------------------------- pre-norm (ViT) transformer block
+@_remember_precision
 class _PreNormBlock(torch.autograd.Function):
     """Build-defined ViT block (not in the reference): x += Attn(LN1(x)); x += MLP_GELU(LN2(x)),
     packed qkv projection with bias, scale 1/sqrt(head_dim), no mask.  Same fusion plan as the
@@ -564,6 +588,7 @@ def take_token(x, idx):
 
 
 # ------------------------------------------------------ channels-last convolution (build-defined encoders)
+@_remember_precision
 class _ConvCL(torch.autograd.Function):
     """y = conv(x) (+ bias) (+ ReLU) on channels-last tensors via im2col + the MFMA GEMM; weight keeps
     torch's (C_out, C_in, kh, kw) layout (the column order matches its flattening)."""

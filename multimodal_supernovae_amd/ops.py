@@ -9,6 +9,34 @@ from ._lib import check, lib, ptr, stream_ptr
 # launch stream: entries are (start_event, end_event, algorithmic_flops, (opA, opB, M, N, K, epilogue)).  None = no instrumentation.
 GEMM_PROFILE = None
 
+# Inner-product precision used by sgemm() when the caller passes none (include/msn_hip.h):
+# PREC_F32 exact fp32 MFMA (default), PREC_BF16X3 split-bf16 (fp32-grade, ~1e-5), PREC_BF16 plain bf16.
+PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
+_PREC_NAMES = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
+GEMM_PRECISION = _PREC_NAMES[__import__("os").environ.get("MSN_GEMM_PRECISION", "f32").lower()]
+
+
+class gemm_precision:
+    """Context manager: GEMMs issued inside use the given precision; autograd nodes created inside remember
+    it for their backward (functional._remember_precision)."""
+
+    def __init__(self, name):
+        self.value = _PREC_NAMES[name] if isinstance(name, str) else int(name)
+
+    def __enter__(self):
+        global GEMM_PRECISION
+        self.old, GEMM_PRECISION = GEMM_PRECISION, self.value
+
+    def __exit__(self, *exc):
+        global GEMM_PRECISION
+        GEMM_PRECISION = self.old
+
+
+def set_gemm_precision(name):
+    """Default inner-product precision of every GEMM issued from this process: "f32" | "bf16x3" | "bf16"."""
+    global GEMM_PRECISION
+    GEMM_PRECISION = _PREC_NAMES[name]
+
 OP_N, OP_T = 0, 1
 EPI_NONE, EPI_RELU, EPI_GELU, EPI_RELU_BWD, EPI_GELU_BWD, EPI_ADD = range(6)
 
@@ -26,7 +54,7 @@ def _workspace(nbytes, device):
     return torch.empty((max(int(nbytes), 16) + 3) // 4, dtype=torch.float32, device=device)
 
 
-def sgemm(a, b, op_a=OP_N, op_b=OP_T, bias=None, epilogue=EPI_NONE, aux=None, out=None):
+def sgemm(a, b, op_a=OP_N, op_b=OP_T, bias=None, epilogue=EPI_NONE, aux=None, out=None, precision=None):
     """C = epilogue(opA(a) @ opB(b) + bias).  `a`, `b` are 2-D, last-dim contiguous (row stride free)."""
     _f32c(a, "a"), _f32c(b, "b")
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
@@ -48,7 +76,8 @@ def sgemm(a, b, op_a=OP_N, op_b=OP_T, bias=None, epilogue=EPI_NONE, aux=None, ou
         ev0.record()
     check(L.msn_sgemm(op_a, op_b, M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(c),
                       c.stride(0) if c.numel() else max(N, 1), ptr(bias), epilogue, ptr(aux),
-                      aux.stride(0) if aux is not None else 0, ptr(ws), ws_bytes, stream_ptr()), "msn_sgemm")
+                      aux.stride(0) if aux is not None else 0, GEMM_PRECISION if precision is None else precision,
+                      ptr(ws), ws_bytes, stream_ptr()), "msn_sgemm")
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1, 2.0 * M * N * K, (op_a, op_b, M, N, K, epilogue)))

@@ -36,7 +36,7 @@ def test_shape_errors_are_reported_without_a_gpu():
     """Argument validation happens before any launch, so it can be exercised on a CPU-only box."""
     from multimodal_supernovae_amd import _lib
     lib = _lib.lib()
-    rc = lib.msn_sgemm(0, 1, 4, 4, 0, None, 4, None, 4, None, 4, None, 0, None, 0, None, 0, None)
+    rc = lib.msn_sgemm(0, 1, 4, 4, 0, None, 4, None, 4, None, 4, None, 0, None, 0, 0, None, 0, None)
     assert rc == 1 and b"K must be positive" in lib.msn_last_error()
     fake = ctypes.c_void_p(4096)          # never dereferenced: validation rejects the call before any launch
     rc = lib.msn_infonce_fwd(fake, 12, 4, fake, 12, 4, fake, 12, 4, fake, 12, 4, 12, 0, fake, fake, fake, fake, fake,

@@ -52,3 +52,37 @@ def test_vit_fills_the_image_encoder_slot():
     loss = model.training_step(batch, 0)
     loss.backward()
     assert torch.isfinite(loss.detach()) and all(p.grad is not None for p in model.parameters())
+
+
+def _cos(a, b):
+    return float((a.flatten().double() @ b.flatten().double()) / (a.double().norm() * b.double().norm() + 1e-30))
+
+
+@pytest.mark.parametrize("precision,out_tol,cos_min", [("bf16x3", 1e-3, 0.99999), ("bf16", 5e-2, 0.995)])
+def test_vit_on_the_bf16_matrix_cores(precision, out_tol, cos_min):
+    """GEMM precision modes of the build-defined ViT: split-bf16 keeps the outputs inside the 1e-3 parity bar;
+    plain bf16 (BASELINE cfg5) is a bf16-grade result (documented, not a parity claim).  Gradients are compared
+    by direction (cosine), which is what matters to the optimiser."""
+    from multimodal_supernovae_amd.encoders import VisionTransformer
+    from oracle.build_defined import vision_transformer
+    torch.manual_seed(11)
+    m = VisionTransformer(img_size=32, patch_size=16, channels=3, emb=768, depth=2, heads=12, n_out=8,
+                          gemm_precision=precision)
+    P = {k: v.clone().requires_grad_() for k, v in m.state_dict().items()}
+    x, cot = torch.rand(4, 3, 32, 32), torch.randn(4, 8)
+    ref = vision_transformer(P, "", x, patch=16, heads=12, depth=2)
+    (ref * cot).sum().backward()
+    m.cuda()
+    y = m(x.cuda())
+    close(y.detach().cpu(), ref.detach(), "y", rtol=out_tol * 10)      # close() scales atol by 0.1 * rtol * max
+    y.backward(cot.cuda())
+    for k, p in m.named_parameters():
+        assert _cos(p.grad.cpu(), P[k].grad) > cos_min, (k, _cos(p.grad.cpu(), P[k].grad))
+
+
+def test_vit_b16_geometry():
+    from multimodal_supernovae_amd.encoders import vit_b16, vit_s8
+    b, s = vit_b16(), vit_s8()
+    assert (b.num_tokens, b.emb, b.heads, b.depth, b.gemm_precision) == (197, 768, 12, 12, "bf16")
+    assert (s.num_tokens, s.emb, s.heads, s.depth, s.gemm_precision) == (65, 384, 6, 12, None)
+    assert sum(p.numel() for p in b.parameters()) > 85e6
