@@ -128,6 +128,12 @@ int msn_sigmoid_loss_bwd(const float* E1_loc, int64_t ld1, const float* E2_loc, 
                          float* dE1_loc, int64_t ldd1, float* dE2_loc, int64_t ldd2, float* dscale_dbias,
                          void* ws, size_t ws_bytes, msn_stream_t stream);
 
+/* Retrieval rank for the validation "AUC" -- get_ROC_data, src/utils.py:380-411: for unit-norm rows,
+ * rank[i] = #{ j != i : <E2_i, E1_j> > <E2_i, E1_i> } (position of the true partner in row i's similarity
+ * ranking; the reference sorts every row in a host loop).  workspace: msn_infonce_workspace_bytes(n,n,n,n,D). */
+int msn_retrieval_rank(const float* E1, int64_t ld1, const float* E2, int64_t ld2, int n, int D, int* rank,
+                       void* ws, size_t ws_bytes, msn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dimension (rows x cols, cols % 4 == 0, cols <= 1024), eps inside the
  * square root -- nn.LayerNorm as used at src/transformer_utils.py:97-98,111,114 (post-norm; the

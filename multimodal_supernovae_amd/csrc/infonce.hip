@@ -364,6 +364,65 @@ __global__ void nce_bwd_finish_kernel(const NceArgs p, const float* __restrict__
     }
 }
 
+// -------------------------------------------------------------------------- retrieval rank (validation AUC)
+// rank[i] = #{ j != i : <E2_i, E1_j> > <E2_i, E1_i> }  -- the position of the true partner in the
+// similarity ranking, ref src/utils.py:380-411 (get_ROC_data sorts every row on the host in a Python
+// loop).  Same tile machinery: the diagonal score is taken from the SAME MFMA accumulation as the scores
+// it is compared with (first pass over the wave's own 32-key tile), then the key split is swept.
+template <int D>
+__global__ __launch_bounds__(256) void nce_rank_kernel(const NceArgs p, int* __restrict__ part_cnt) {
+    __shared__ __attribute__((aligned(16))) float Ks[KT * (D + 4)];
+    const Side& sd = p.side[0];
+    const int qb0 = blockIdx.x * QB;
+    if (qb0 >= sd.nq) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l32 = lane & 31, h = lane >> 5;
+    const int q_local = qb0 + QT * wave + l32;
+    const bool q_ok = q_local < sd.nq;
+    const bool qvec = (sd.ldq % 4 == 0) && ((reinterpret_cast<uintptr_t>(sd.Q) & 15) == 0);
+    const bool kvec = (sd.ldk % 4 == 0) && ((reinterpret_cast<uintptr_t>(sd.K) & 15) == 0);
+    float4 qf[D / 8];
+    load_q_frags<D>(qf, sd.Q, sd.ldq, q_ok ? q_local : sd.nq - 1, h, qvec);
+
+    float diag = -INFINITY;
+    for (int w = 0; w < 4; ++w) {          // the key tile holding wave w's own partners
+        const int k0 = qb0 + QT * w;
+        __syncthreads();
+        stage_keys<D>(Ks, sd.K, sd.ldk, k0, sd.nk, kvec);
+        __syncthreads();
+        const f32x16 acc = score_tile<D>(Ks, qf, l32, h);
+        if (w == wave) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (row_of(r, h) == l32) diag = acc[r];
+        }
+    }
+    diag = fmaxf(diag, __shfl_xor(diag, 32, 64));
+
+    const int k_begin = blockIdx.y * p.keys_per_split;
+    const int k_end = min(sd.nk, k_begin + p.keys_per_split);
+    int cnt = 0;
+    for (int k0 = k_begin; k0 < k_end; k0 += KT) {
+        __syncthreads();
+        stage_keys<D>(Ks, sd.K, sd.ldk, k0, k_end, kvec);
+        __syncthreads();
+        const f32x16 acc = score_tile<D>(Ks, qf, l32, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kj = k0 + row_of(r, h);
+            cnt += (kj < k_end && kj != q_local && acc[r] > diag) ? 1 : 0;
+        }
+    }
+    cnt += __shfl_xor(cnt, 32, 64);
+    if (h == 0 && q_ok) part_cnt[(int64_t)blockIdx.y * p.maxq + q_local] = cnt;
+}
+__global__ void nce_rank_finish_kernel(const int* __restrict__ part_cnt, int ksplit, int maxq, int n, int* __restrict__ rank) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int s = 0;
+    for (int k = 0; k < ksplit; ++k) s += part_cnt[(int64_t)k * maxq + i];
+    rank[i] = s;
+}
+
 static int pick_ksplit(int maxq, int maxk) {
     const int qblocks = (int)cdiv(maxq, QB);
     int ks = std::max(1, 512 / (2 * qblocks));
@@ -536,6 +595,27 @@ static int infonce_bwd_impl(int mode, const float* E1_loc, int64_t ld1, int b1, 
     const int blocks = (int)std::min<int64_t>(cdiv(total, 256), 1024);
     hipLaunchKernelGGL(nce_bwd_finish_kernel, dim3(blocks), dim3(256), 0, st, a, grad_out, D,
                        pl.ksplit * pl.qblocks, dscale_dbias);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+// rank[i] of the true partner (row i of E1) among all rows of E1 for query row i of E2; rows must be unit
+// vectors (cosine similarity).  n <= 2^31 / D; workspace = msn_infonce_workspace_bytes(n, n, n, n, D).
+extern "C" int msn_retrieval_rank(const float* E1, int64_t ld1, const float* E2, int64_t ld2, int n, int D, int* rank,
+                                  void* ws, size_t ws_bytes, msn_stream_t stream) {
+    if (int rc = check_common("msn_retrieval_rank", n, n, n, n, D, 0)) return rc;
+    MSN_REQUIRE(E1 && E2 && rank && ld1 >= D && ld2 >= D, "msn_retrieval_rank: bad arguments");
+    const Plan pl = make_plan(n, n, n, n, D);
+    MSN_REQUIRE(ws && ws_bytes >= pl.total, "msn_retrieval_rank: workspace %zu < %zu bytes", ws_bytes, pl.total);
+    NceArgs a = {};
+    a.side[0] = Side{E2, E1, nullptr, nullptr, nullptr, ld2, ld1, 0, n, n};
+    a.ksplit = pl.ksplit; a.keys_per_split = pl.keys_per_split; a.maxq = pl.maxq;
+    int* part = reinterpret_cast<int*>(static_cast<char*>(ws) + pl.off_m);   // [ksplit][maxq] ints fit the (m) slab
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(pl.qblocks, pl.ksplit, 1), block(256);
+    MSN_NCE_DISPATCH(nce_rank_kernel, grid, block, 0, st, a, part)
+    MSN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nce_rank_finish_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, part, pl.ksplit, pl.maxq, n, rank);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }

@@ -220,4 +220,19 @@ class LightCurveImageCLIP(nn.Module):
         return loss
 
     def on_validation_epoch_end(self):
+        """ref :519-556: concatenate the stored embeddings and log the retrieval AUC per modality pair."""
+        from .utils import get_AUC
+        if not self.embs_list or not self.embs_list[0]:
+            self.embs_list = None
+            return
+        embs = [torch.cat(e, dim=0) for e in self.embs_list]
+        if len(embs) == 2:
+            self.log("AUC_val", get_AUC(embs[0], embs[1]), on_epoch=True, on_step=False, prog_bar=True, logger=True)
+        else:
+            count = 1
+            for i in range(len(embs) - 1):
+                for j in range(i + 1, len(embs)):
+                    self.log(f"AUC_val{count}", get_AUC(embs[i], embs[j]), on_epoch=True, on_step=False, prog_bar=True,
+                             logger=True)
+                    count += 1
         self.embs_list = None

@@ -99,3 +99,23 @@ class RAdam:
     def zero_grad(self):
         for p in self.params:
             p.grad = None
+
+
+def roc_data(embs1, embs2):
+    """ref src/utils.py:380-411 restated without the per-row loop: rank of the partner = number of rows of
+    embs1 strictly more similar (cosine) to embs2[i] than embs1[i]; 100 thresholds, top-int(thr * N) hits."""
+    import numpy as np
+    a = embs1 / embs1.norm(dim=-1, keepdim=True)
+    b = embs2 / embs2.norm(dim=-1, keepdim=True)
+    sim = b @ a.T                                           # row i: similarities of embs2[i] to every embs1[j]
+    ranks = (sim > sim.diagonal()[:, None]).sum(dim=1).numpy()
+    n = len(ranks)
+    thresholds = np.linspace(0, 1, 100)
+    top = np.array([int(t * n) for t in thresholds])
+    return thresholds, (ranks[None, :] < top[:, None]).sum(axis=1) / n, ranks
+
+
+def auc(embs1, embs2):
+    import numpy as np
+    t, f, _ = roc_data(embs1, embs2)
+    return np.trapz(f, t) if hasattr(np, "trapz") else np.trapezoid(f, t)

@@ -141,3 +141,24 @@ def test_cpu_module_fails_loudly():
     m = MLP(input_dim=4, hidden_dim=4, output_dim=2, num_layers=1, dropout=0.0)
     with pytest.raises(_lib.MsnHipError):
         m(torch.randn(3, 4))
+
+
+def test_real_reference_checkpoint_loads_strict_and_matches():
+    """Row f4: a Lightning-2.2.3 checkpoint shipped with the reference loads strict=True into the HIP-backed
+    module; embeddings / loss on a fixed synthetic lc + spectrum batch (T = 200 / 220, Maven sizes) match."""
+    f = Fixture("real_ckpt_lc_sp")
+    c = f.cfg
+    from multimodal_supernovae_amd.models_multimodal import LightCurveImageCLIP
+    model = LightCurveImageCLIP(enc_dim=c["enc_dim"], logit_scale=19.545966923442453, nband=c["nband"],
+                                transformer_kwargs=c["transformer_kwargs"],
+                                transformer_spectral_kwargs=c["transformer_spectral_kwargs"],
+                                combinations=c["combinations"], loss="softmax")
+    model.load_state_dict(f.P, strict=True)
+    model.cuda().eval()
+    batch = _batch(f.groups["in"])
+    with torch.no_grad():
+        embs = model(*batch)
+        loss = model.validation_step(batch, 0) if model.embs_list is not None else model._loss(embs)
+    for k, e in enumerate(embs):
+        close(e.cpu(), f.out[f"emb{k}"], f"emb{k}")
+    assert abs(float(loss) - float(f.out["loss"])) <= RTOL * abs(float(f.out["loss"]))

@@ -195,3 +195,25 @@ def test_harness_loss_trajectory_and_final_weights():
         if k.endswith("num_batches_tracked"):
             continue
         close(P[k].detach(), v, rtol=2e-3, atol=2e-4, what="after " + k)
+
+
+def test_real_reference_checkpoint_embeddings():
+    """A checkpoint shipped with the reference (real trained weights): embeddings and loss on a fixed synthetic batch."""
+    f = Fixture("real_ckpt_lc_sp")
+    P = f.params(requires_grad=False)
+    batch = _batch(f.groups["in"])
+    embs = oclip.embeddings(P, f.cfg, batch, training=False)
+    for k, e in enumerate(embs):
+        close(e, f.out[f"emb{k}"], rtol=1e-4, atol=2e-5, what=f"emb{k}")
+    close(oclip.training_loss(P, f.cfg, batch, training=False), f.out["loss"], rtol=1e-4, atol=1e-5)
+    assert abs(float(P["logit_scale"].exp()) - 31.02) < 0.01          # SURVEY section 8(c)
+
+
+def test_retrieval_auc_matches_reference():
+    import numpy as np
+    f = Fixture("auc")
+    for n in (50, 137):
+        t, frac, _ = oclip.roc_data(f.groups["in"][f"e1_{n}"], f.groups["in"][f"e2_{n}"])
+        assert np.allclose(t, f.out[f"thresholds_{n}"].numpy())
+        assert np.allclose(frac, f.out[f"fraction_{n}"].numpy())
+        assert abs(oclip.auc(f.groups["in"][f"e1_{n}"], f.groups["in"][f"e2_{n}"]) - float(f.out[f"auc_{n}"])) < 1e-12

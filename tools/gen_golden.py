@@ -365,6 +365,50 @@ def gen_clip(ref_mm):
                                                "after": sd_of(model)})
 
 
+def gen_real_checkpoint(ref_mm):
+    """a SHIPPED reference checkpoint (real trained weights, Lightning 2.2.3 format)
+    loaded strictly into the reference module; embeddings + loss on a fixed synthetic lc + spectrum batch."""
+    ckpt = os.path.join(REF, "models", "clip_finetune", "absurd-sweep-1", "epoch=118-step=12495.ckpt")
+    sd = torch.load(ckpt, map_location="cpu", weights_only=True)["state_dict"]
+    tk = dict(n_out=32, emb=64, heads=8, depth=5, dropout=0.0, time_norm=20583.369161312577, agg="mean")
+    sk = dict(n_out=32, emb=32, heads=2, depth=13, dropout=0.0, time_norm=17945.142213594805, agg="mean")
+    model = ref_mm.LightCurveImageCLIP(enc_dim=128, logit_scale=19.545966923442453, nband=2, transformer_kwargs=tk,
+                                       transformer_spectral_kwargs=sk, combinations=["lightcurve", "spectral"],
+                                       loss="softmax")
+    missing = model.load_state_dict(sd, strict=True)
+    print("real checkpoint:", missing, f"exp(logit_scale) = {float(model.logit_scale.exp()):.3f}")
+    model.eval()
+    g = torch.Generator().manual_seed(71)
+    b = 8
+    batch = _batch(g, b, ["lightcurve", "spectral"], t_lc=200, t_sp=220, nband=2)
+    with torch.no_grad():
+        embs = model(*batch)
+        loss = model.training_step(batch, 0)
+    cfg = {"combinations": ["lightcurve", "spectral"], "nband": 2, "transformer_kwargs": tk,
+           "transformer_spectral_kwargs": sk, "conv_kwargs": None, "meta_kwargs": None, "enc_dim": 128,
+           "loss": "softmax", "lr": 1e-4, "weight_decay": 0.0, "checkpoint": "models/clip_finetune/absurd-sweep-1/"
+           "epoch=118-step=12495.ckpt"}
+    ins = {k: v for k, v in zip(["x_img", "x_lc", "t_lc", "mask_lc", "x_sp", "t_sp", "mask_sp", "redshift",
+                                 "classification"], batch) if v is not None}
+    save("real_ckpt_lc_sp", cfg=cfg, P={k: v for k, v in sd.items()},
+         **{"in": ins, "out": {"emb0": embs[0], "emb1": embs[1], "loss": loss}})
+
+
+def gen_auc():
+    """Row f2: the reference's retrieval metric (src/utils.py:380-426) on correlated random embeddings."""
+    ref_utils = importlib.import_module("src.utils")
+    g = torch.Generator().manual_seed(91)
+    out, ins = {}, {}
+    for n, d, noise in [(50, 16, 0.6), (137, 32, 1.5)]:
+        e1 = torch.randn(n, d, generator=g)
+        e2 = e1 + noise * torch.randn(n, d, generator=g)
+        thr, frac = ref_utils.get_ROC_data(e1, e2)
+        ins[f"e1_{n}"], ins[f"e2_{n}"] = e1, e2
+        out[f"thresholds_{n}"], out[f"fraction_{n}"] = thr, frac
+        out[f"auc_{n}"] = np.float64(ref_utils.get_AUC(e1, e2))
+    save("auc", **{"in": ins, "out": out})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -374,6 +418,8 @@ def main():
     gen_transformer(ref_tr)
     gen_convmixer_mlp(ref_mm)
     gen_clip(ref_mm)
+    gen_real_checkpoint(ref_mm)
+    gen_auc()
 
 
 if __name__ == "__main__":
