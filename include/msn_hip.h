@@ -267,6 +267,14 @@ int msn_maxpool2d_fwd(const float* x, int B, int H, int W, int C, int k, int s, 
 int msn_maxpool2d_bwd(const float* dy, const int* argmax, int B, int H, int W, int C, int k, int s, int p,
                       float* dx, msn_stream_t stream);
 
+/* Masked MSE of the masked-light-curve pretraining objective (src/models_pretraining.py:201-231):
+ * stats[0] = mean over {i : select[i]} of (pred[i] - target[i])^2, stats[1] = number of selected elements;
+ * bwd: dpred = grad_out * 2 (pred - target) / count on the selected elements, 0 elsewhere. */
+int msn_masked_mse_fwd(const float* pred, const float* target, const uint8_t* select, int64_t n, float* stats,
+                       msn_stream_t stream);
+int msn_masked_mse_bwd(const float* pred, const float* target, const uint8_t* select, int64_t n,
+                       const float* stats, const float* grad_out, float* dpred, msn_stream_t stream);
+
 /* feat[r] = (x[r]*m, t[r]*inv_norm*m, m, 0), m = mask[r]: the 4 input channels of the build-defined 1-D CNN
  * encoder for light curves / spectra (value, normalised time / wavelength, validity, pad). */
 int msn_series_features(const float* x, const float* t, const uint8_t* mask, int64_t rows, float inv_norm,

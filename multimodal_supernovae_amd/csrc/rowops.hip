@@ -278,23 +278,36 @@ __global__ __launch_bounds__(256) void time_embed_bwd_kernel(const float* __rest
         }
     }
 }
-// dw[c] = sum_b sdx[b][c]; dband[k][c] = sum_b seg[b][k][c]; dbw[c] = sum_k dband[k][c]
-__global__ void time_embed_bwd_finish_kernel(const float* __restrict__ seg, const float* __restrict__ sdx, int B,
-                                             int e, int nband, float* __restrict__ dw, float* __restrict__ dbw,
-                                             float* __restrict__ dband) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= e) return;
-    float sw = 0.f;
-    for (int b = 0; b < B; ++b) sw += sdx[(int64_t)b * e + c];
-    dw[c] = sw;
+// dw[c] = sum_b sdx[b][c]; dband[k][c] = sum_b seg[b][k][c]; dbw[c] = sum_k dband[k][c].
+// One block per 64 columns; its 4 thread groups each sum a quarter of the samples (fixed order), LDS-combined.
+__global__ __launch_bounds__(256) void time_embed_bwd_finish_kernel(const float* __restrict__ seg,
+                                                                    const float* __restrict__ sdx, int B, int e,
+                                                                    int nband, float* __restrict__ dw,
+                                                                    float* __restrict__ dbw, float* __restrict__ dband) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    auto reduce = [&](float v) {
+        __syncthreads();
+        red[g][cl] = v;
+        __syncthreads();
+        return (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    };
+    float s = 0.f;
+    if (c < e)
+        for (int b = g; b < B; b += 4) s += sdx[(int64_t)b * e + c];
+    const float sw = reduce(s);
+    if (g == 0 && c < e) dw[c] = sw;
     float sb = 0.f;
     for (int k = 0; k < nband; ++k) {
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) s += seg[((int64_t)b * nband + k) * e + c];
-        if (dband) dband[(int64_t)k * e + c] = s;
-        sb += s;
+        s = 0.f;
+        if (c < e)
+            for (int b = g; b < B; b += 4) s += seg[((int64_t)b * nband + k) * e + c];
+        const float t = reduce(s);
+        if (g == 0 && c < e && dband) dband[(int64_t)k * e + c] = t;
+        sb += t;
     }
-    dbw[c] = sb;
+    if (g == 0 && c < e) dbw[c] = sb;
 }
 
 // ---------------------------------------------------------------------------------- masked pooling
@@ -387,6 +400,36 @@ __global__ void series_features_kernel(const float* __restrict__ x, const float*
         const float m = mask[r] ? 1.f : 0.f;
         feat[r] = make_float4(x[r] * m, t[r] * inv_norm * m, m, 0.f);
     }
+}
+
+// ------------------------------------------------------------- masked MSE (masked-light-curve pretraining)
+// loss = mean over {i : sel[i]} of (pred[i] - target[i])^2   (ref src/models_pretraining.py:201-231:
+// nn.MSELoss()(x[mask_pred], x_pred[mask_pred])); stats[0] = loss, stats[1] = number of selected elements.
+__global__ __launch_bounds__(1024) void masked_mse_fwd_kernel(const float* __restrict__ pred,
+                                                              const float* __restrict__ target,
+                                                              const uint8_t* __restrict__ sel, int64_t n,
+                                                              float* __restrict__ stats) {
+    __shared__ float red[16];
+    float s = 0.f, c = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x)
+        if (sel[i]) {
+            const float d = pred[i] - target[i];
+            s = fmaf(d, d, s);
+            c += 1.f;
+        }
+    const float ts = block_sum(s, red);
+    const float tc = block_sum(c, red);
+    if (threadIdx.x == 0) {
+        stats[0] = ts / tc;
+        stats[1] = tc;
+    }
+}
+__global__ void masked_mse_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                      const uint8_t* __restrict__ sel, int64_t n, const float* __restrict__ stats,
+                                      const float* __restrict__ grad_out, float* __restrict__ dpred) {
+    const float f = 2.f * (*grad_out) / stats[1];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dpred[i] = sel[i] ? f * (pred[i] - target[i]) : 0.f;
 }
 
 static int pick_lpr(int cols) {
@@ -520,7 +563,7 @@ extern "C" int msn_time_embed_bwd(const float* dy, const float* x, int64_t B, in
     const size_t lds = sizeof(float) * (256 / cpt) * cpt;
     hipLaunchKernelGGL(time_embed_bwd_kernel, dim3((unsigned)B), dim3(256), lds, st, dy, x, T, e, nband, seg, sdx);
     MSN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(time_embed_bwd_finish_kernel, dim3((unsigned)cdiv(e, 64)), dim3(64), 0, st, seg, sdx, (int)B, e,
+    hipLaunchKernelGGL(time_embed_bwd_finish_kernel, dim3((unsigned)cdiv(e, 64)), dim3(256), 0, st, seg, sdx, (int)B, e,
                        nband, dw, dbw, nband > 1 ? dband : nullptr);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
@@ -580,6 +623,23 @@ extern "C" int msn_series_features(const float* x, const float* t, const uint8_t
                 "msn_series_features: bad arguments");
     hipLaunchKernelGGL(series_features_kernel, dim3((unsigned)std::min<int64_t>(cdiv(rows, 256), 4096)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, t, mask, rows, inv_norm, reinterpret_cast<float4*>(feat));
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" int msn_masked_mse_fwd(const float* pred, const float* target, const uint8_t* select, int64_t n, float* stats,
+                                  msn_stream_t stream) {
+    MSN_REQUIRE(pred && target && select && stats && n > 0, "msn_masked_mse_fwd: bad arguments");
+    hipLaunchKernelGGL(masked_mse_fwd_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), pred, target,
+                       select, n, stats);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+extern "C" int msn_masked_mse_bwd(const float* pred, const float* target, const uint8_t* select, int64_t n,
+                                  const float* stats, const float* grad_out, float* dpred, msn_stream_t stream) {
+    MSN_REQUIRE(pred && target && select && stats && grad_out && dpred && n > 0, "msn_masked_mse_bwd: bad arguments");
+    hipLaunchKernelGGL(masked_mse_bwd_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 2048)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), pred, target, select, n, stats, grad_out, dpred);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }

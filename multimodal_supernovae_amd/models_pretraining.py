@@ -1,0 +1,117 @@
+"""Masked-light-curve pretraining with the reference's surface, src/models_pretraining.py:
+`get_random_mask`, `get_continous_random_mask` (host index plumbing, same RNG calls as the reference) and
+`MaskedLightCurveEncoder` = TransformerWithTimeEmbeddings(agg="pretraining") + Linear(emb, 1), trained with an
+MSE on the hidden points.  The transformer, the read-out GEMM and the masked MSE run on libmsn_hip."""
+import random
+from typing import Dict, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import functional as F_
+from . import ops
+from ._lib import check, lib, ptr, stream_ptr
+from .transformer_utils import TransformerWithTimeEmbeddings
+
+
+def get_random_mask(padding_mask, f_mask=0.15):
+    """Hide a random fraction of the observed points of every sample (ref :17-55).  Returns (mask, mask_pred):
+    `mask` = padding mask minus the hidden points, `mask_pred` = the hidden points."""
+    mask, mask_pred = padding_mask.clone(), padding_mask.clone()
+    for i in range(padding_mask.shape[0]):
+        n_hide = int(padding_mask[i].sum().item() * f_mask)
+        observed = torch.where(padding_mask[i] == True)[0]  # noqa: E712
+        perm = torch.randperm(len(observed))
+        mask_pred[i, observed[perm[n_hide:]]] = False
+        mask[i, observed[perm[:n_hide]]] = False
+    return mask, mask_pred
+
+
+def get_continous_random_mask(padding_mask, nbands, f_mask=0.15):
+    """Hide one random CONTIGUOUS run of observed points per band (ref :58-98)."""
+    mask, mask_pred = padding_mask.clone(), padding_mask.clone()
+    band = padding_mask.shape[1] // nbands
+    for i in range(padding_mask.shape[0]):
+        for k in range(nbands):
+            n_obs = int(padding_mask[i][band * k: band * (k + 1)].sum().item())
+            n_hide = int(n_obs * f_mask)
+            lo = random.randint(band * k, band * k + n_obs - n_hide)
+            hi = lo + n_hide
+            mask_pred[i, band * k: lo] = False
+            mask_pred[i, hi: band * (k + 1)] = False
+            mask[i, lo:hi] = False
+    return mask, mask_pred
+
+
+class _MaskedMSE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, select_u8):
+        pred, target = pred.contiguous(), target.contiguous().float()
+        stats = torch.empty(2, dtype=torch.float32, device=pred.device)
+        check(lib().msn_masked_mse_fwd(ptr(ops._f32c(pred, "pred")), ptr(target), ptr(select_u8), pred.numel(), ptr(stats),
+                                       stream_ptr()), "msn_masked_mse_fwd")
+        ctx.sel = select_u8
+        ctx.save_for_backward(pred, target, stats)
+        return stats[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, stats = ctx.saved_tensors
+        d = torch.empty_like(pred)
+        g = g.to(torch.float32).reshape(()).contiguous()
+        check(lib().msn_masked_mse_bwd(ptr(pred), ptr(target), ptr(ctx.sel), pred.numel(), ptr(stats), ptr(g), ptr(d),
+                                       stream_ptr()), "msn_masked_mse_bwd")
+        return d, None, None
+
+
+def masked_mse(pred, target, select):
+    """mean((pred - target)^2) over the elements where `select` is true == nn.MSELoss()(pred[select], target[select])."""
+    return _MaskedMSE.apply(pred, target, ops._mask_u8(select))
+
+
+class MaskedLightCurveEncoder(nn.Module):
+    """ref src/models_pretraining.py:101-259 (Lightning hooks as plain methods; StepLR scheduling is left to the caller)."""
+
+    def __init__(self, f_mask: float = 0.2, nband: int = 1, transformer_kwargs: Dict = None, optimizer_kwargs: Dict = None,
+                 lr_scheduler_kwargs: Dict = None, lr: float = 1e-3):
+        super().__init__()
+        transformer_kwargs = dict(transformer_kwargs or {"n_out": 1, "emb": 128, "heads": 2, "depth": 4})
+        self.nband, self.lr, self.f_mask = nband, lr, f_mask
+        self.optimizer_kwargs = dict(optimizer_kwargs or {})
+        self.lr_scheduler_kwargs = dict(lr_scheduler_kwargs or {})
+        self.net = TransformerWithTimeEmbeddings(nband=nband, agg="pretraining", **transformer_kwargs)
+        self.last_layer = nn.Linear(transformer_kwargs["emb"], 1)
+        self.logged = {}
+
+    def log(self, name, value, **kwargs):
+        self.logged[name] = value
+
+    def forward(self, x, t, mask=None):
+        h = self.net(x[..., None], t, mask)                                    # (B, T, emb), padded tokens zeroed
+        return F_.linear(h, self.last_layer.weight, self.last_layer.bias).squeeze(2)
+
+    def configure_optimizers(self):
+        from .optim import RAdam
+        return {"optimizer": RAdam(self.parameters(), lr=self.lr, **self.optimizer_kwargs)}
+
+    def masked_loss(self, x, t, padding_mask, mask_in, mask_pred):
+        """MSE on the hidden points given explicit masks (what masked_pred + nn.MSELoss compute, ref :183-231)."""
+        x_masked = x.clone()
+        x_masked[~mask_in] = 0
+        return masked_mse(self(x_masked, t, mask=padding_mask), x, mask_pred)
+
+    def _step(self, batch, name):
+        if len(batch) == 3:
+            t, x, padding_mask = batch
+        else:
+            _, x, t, padding_mask, *_ = batch
+        mask_in, mask_pred = get_continous_random_mask(padding_mask.cpu(), self.nband, f_mask=self.f_mask)
+        loss = self.masked_loss(x, t, padding_mask, mask_in.to(x.device), mask_pred.to(x.device))
+        self.log(name, loss, on_epoch=True, on_step=False, prog_bar=True)
+        return loss
+
+    def training_step(self, batch, batch_idx):
+        return self._step(batch, "train_loss")
+
+    def validation_step(self, batch, batch_idx):
+        return self._step(batch, "val_loss")

@@ -162,3 +162,30 @@ def test_real_reference_checkpoint_loads_strict_and_matches():
     for k, e in enumerate(embs):
         close(e.cpu(), f.out[f"emb{k}"], f"emb{k}")
     assert abs(float(loss) - float(f.out["loss"])) <= RTOL * abs(float(f.out["loss"]))
+
+
+def test_masked_pretraining_matches_reference():
+    """Row f4: MaskedLightCurveEncoder forward, masked MSE and parameter gradients vs the reference golden."""
+    from multimodal_supernovae_amd.models_pretraining import MaskedLightCurveEncoder, get_continous_random_mask
+    f = Fixture("pretraining")
+    c, i = f.cfg, f.groups["in"]
+    m = MaskedLightCurveEncoder(f_mask=c["f_mask"], nband=c["nband"], transformer_kwargs=c["transformer_kwargs"])
+    assert set(m.state_dict().keys()) == set(f.P.keys())
+    m.load_state_dict(f.P, strict=True)
+    m.cuda().train()
+    x, t, pad = i["x"].cuda(), i["t"].cuda(), i["padding_mask"].cuda()
+    xm = x.clone()
+    xm[~i["mask_in"].cuda()] = 0
+    pred = m(xm, t, mask=pad)
+    close(pred.detach().cpu(), f.out["pred"], "pred")
+    loss = m.masked_loss(x, t, pad, i["mask_in"].cuda(), i["mask_pred"].cuda())
+    assert abs(float(loss.detach()) - float(f.out["loss"])) <= RTOL * abs(float(f.out["loss"]))
+    loss.backward()
+    for k, p in m.named_parameters():
+        if k in ("net.projection.weight", "net.projection.bias"):       # unused by agg="pretraining"
+            continue
+        close(p.grad.cpu(), f.grad[k], "grad " + k, rtol=2e-3)
+    # the training hook draws its own contiguous masks: one hidden run per band, inside the observed points
+    mask_in, mask_pred = get_continous_random_mask(i["padding_mask"], c["nband"], f_mask=c["f_mask"])
+    assert not (mask_pred & ~i["padding_mask"]).any() and not (mask_in & mask_pred).any()
+    assert torch.isfinite(m.training_step((t, x, pad), 0).detach())

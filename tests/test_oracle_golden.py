@@ -217,3 +217,23 @@ def test_retrieval_auc_matches_reference():
         assert np.allclose(t, f.out[f"thresholds_{n}"].numpy())
         assert np.allclose(frac, f.out[f"fraction_{n}"].numpy())
         assert abs(oclip.auc(f.groups["in"][f"e1_{n}"], f.groups["in"][f"e2_{n}"]) - float(f.out[f"auc_{n}"])) < 1e-12
+
+
+def test_masked_pretraining_objective():
+    """Row f4: MaskedLightCurveEncoder = transformer (agg="pretraining") + Linear(emb, 1); MSE on the hidden points."""
+    f = Fixture("pretraining")
+    P = f.params()
+    i, c = f.groups["in"], f.cfg
+    tk = c["transformer_kwargs"]
+    xm = i["x"].clone()
+    xm[~i["mask_in"]] = 0
+    h = oenc.transformer_with_time_embeddings(P, "net.", xm[..., None], i["t"], i["padding_mask"], emb=tk["emb"],
+                                              heads=tk["heads"], depth=tk["depth"], time_norm=tk["time_norm"],
+                                              nband=c["nband"], agg="pretraining")
+    pred = oenc.linear(P, "last_layer", h).squeeze(2)
+    close(pred, f.out["pred"], rtol=1e-4, atol=1e-5)
+    loss = ((pred - i["x"]) ** 2)[i["mask_pred"]].mean()
+    close(loss, f.out["loss"], rtol=1e-4, atol=1e-6)
+    loss.backward()
+    for k, g in f.grad.items():
+        close(P[k].grad, g, rtol=2e-3, atol=2e-5, what="grad " + k)

@@ -409,6 +409,34 @@ def gen_auc():
     save("auc", **{"in": ins, "out": out})
 
 
+def gen_pretraining():
+    """Row f4: MaskedLightCurveEncoder forward + masked MSE + gradients with explicit masks from the reference's
+    own get_continous_random_mask (python RNG seeded)."""
+    import random
+    ref_pt = importlib.import_module("src.models_pretraining")
+    g = torch.Generator().manual_seed(101)
+    random.seed(5)
+    b, t, nband = 4, 20, 2
+    tk = dict(n_out=1, emb=16, heads=4, depth=2, dropout=0.0, time_norm=20583.37)
+    m = ref_pt.MaskedLightCurveEncoder(f_mask=0.3, nband=nband, transformer_kwargs=tk, lr_scheduler_kwargs={"step_size": 10})
+    randomise(m, g)
+    x = torch.randn(b, t, generator=g)
+    tt = torch.cat([torch.sort(torch.rand(b, t // nband, generator=g) * 100, dim=1)[0] for _ in range(nband)], 1)
+    pad = ragged_mask(b, t, g, nband)
+    for i in range(b):                      # at least 4 observed points per band so something gets hidden
+        for k in range(nband):
+            pad[i, k * (t // nband): k * (t // nband) + 4] = True
+    mask_in, mask_pred = ref_pt.get_continous_random_mask(pad, nband, f_mask=0.3)
+    xm = x.clone()
+    xm[~mask_in] = 0
+    pred = m(xm, tt, mask=pad)
+    loss = torch.nn.MSELoss()(x[mask_pred], pred[mask_pred])
+    loss.backward()
+    save("pretraining", cfg={"nband": nband, "f_mask": 0.3, "transformer_kwargs": tk}, P=sd_of(m),
+         **{"in": {"x": x, "t": tt, "padding_mask": pad, "mask_in": mask_in, "mask_pred": mask_pred},
+            "out": {"pred": pred, "loss": loss}, "grad": grads_of(m)})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -420,6 +448,7 @@ def main():
     gen_clip(ref_mm)
     gen_real_checkpoint(ref_mm)
     gen_auc()
+    gen_pretraining()
 
 
 if __name__ == "__main__":
