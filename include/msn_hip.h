@@ -267,6 +267,16 @@ int msn_maxpool2d_fwd(const float* x, int B, int H, int W, int C, int k, int s, 
 int msn_maxpool2d_bwd(const float* dy, const int* argmax, int B, int H, int W, int C, int k, int s, int p,
                       float* dx, msn_stream_t stream);
 
+/* On-device form of NoisyDataLoader.__iter__ (src/dataloader.py:88-287), the step right before the path:
+ *   images: out = rot90^{rot[b]}( img + (2 u - 1) * noise_level * std(img) )   (B, C, S, S), std = torch.std of the
+ *           whole batch; u = uniform [0,1) field, rot = quarter turns per sample (both supplied by the caller's RNG);
+ *   series: out = x + g * err * noise_level   (g = standard-normal field). */
+size_t msn_augment_workspace_bytes(void);
+int msn_augment_images(const float* img, const float* u, const int* rot, int64_t B, int C, int S,
+                       float noise_level, float* out, void* ws, size_t ws_bytes, msn_stream_t stream);
+int msn_augment_series(const float* x, const float* g, const float* err, int64_t n, float noise_level,
+                       float* out, msn_stream_t stream);
+
 /* Masked MSE of the masked-light-curve pretraining objective (src/models_pretraining.py:201-231):
  * stats[0] = mean over {i : select[i]} of (pred[i] - target[i])^2, stats[1] = number of selected elements;
  * bwd: dpred = grad_out * 2 (pred - target) / count on the selected elements, 0 elsewhere. */

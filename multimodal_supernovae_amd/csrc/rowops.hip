@@ -432,6 +432,71 @@ __global__ void masked_mse_bwd_kernel(const float* __restrict__ pred, const floa
         dpred[i] = sel[i] ? f * (pred[i] - target[i]) : 0.f;
 }
 
+// ----------------------------------------------------------- on-device augmentation (NoisyDataLoader.__iter__)
+// ref src/dataloader.py:88-287: images  <- rot90^k( img + (2u - 1) * level * std(batch) ), k per sample;
+// series <- x + g * err * level.  The random fields u ~ U[0,1), g ~ N(0,1) and k are INPUTS (any RNG).
+// stats[0] = sum, stats[1] = sum of squared deviations from the mean (two passes -> unbiased std like torch.std)
+__global__ __launch_bounds__(1024) void sum_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ part) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += x[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+        part[blockIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(1024) void sqdev_kernel(const float* __restrict__ x, int64_t n, const double* __restrict__ part,
+                                                     int nparts, double* __restrict__ part2) {
+    __shared__ double red[16];
+    double tot = 0.0;
+    for (int k = 0; k < nparts; ++k) tot += part[k];
+    const double mean = tot / (double)n;
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double d = (double)x[i] - mean;
+        s += d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+        part2[blockIdx.x] = t;
+    }
+}
+__global__ void augment_images_kernel(const float* __restrict__ img, const float* __restrict__ u,
+                                      const int* __restrict__ rot, int64_t B, int C, int S, float level,
+                                      const double* __restrict__ part2, int nparts, int64_t n, float* __restrict__ out) {
+    double ss = 0.0;
+    for (int k = 0; k < nparts; ++k) ss += part2[k];
+    const float range = level * (float)sqrt(ss / (double)(n - 1));
+    const int64_t total = B * C * S * S;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % S), y = (int)((i / S) % S);
+        const int64_t bc = i / ((int64_t)S * S);
+        const int k = rot[bc / C] & 3;
+        // torch.rot90 (counter-clockwise, k times): k=1: out[y][x] = in[x][S-1-y]
+        int sy = y, sx = x;
+        if (k == 1) { sy = x; sx = S - 1 - y; }
+        else if (k == 2) { sy = S - 1 - y; sx = S - 1 - x; }
+        else if (k == 3) { sy = S - 1 - x; sx = y; }
+        const int64_t src = (bc * S + sy) * S + sx;
+        out[i] = img[src] + (2.f * u[src] - 1.f) * range;
+    }
+}
+__global__ void augment_series_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                      const float* __restrict__ err, int64_t n, float level, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = x[i] + g[i] * err[i] * level;
+}
+
 static int pick_lpr(int cols) {
     const int chunks = cols / 4;
     if (chunks <= 4 * NCH) return 4;
@@ -640,6 +705,37 @@ extern "C" int msn_masked_mse_bwd(const float* pred, const float* target, const 
     MSN_REQUIRE(pred && target && select && stats && grad_out && dpred && n > 0, "msn_masked_mse_bwd: bad arguments");
     hipLaunchKernelGGL(masked_mse_bwd_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 2048)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), pred, target, select, n, stats, grad_out, dpred);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+constexpr int AUG_PARTS = 256;
+extern "C" size_t msn_augment_workspace_bytes(void) { return sizeof(double) * 2 * AUG_PARTS; }
+
+// out = rot90^{rot[b]}( img + (2 u - 1) * noise_level * std(img) ), square (B, C, S, S) images, std over the whole
+// batch (unbiased, torch.std);  u: uniform [0,1) field of the same shape;  rot: B ints (quarter turns, CCW).
+extern "C" int msn_augment_images(const float* img, const float* u, const int* rot, int64_t B, int C, int S,
+                                  float noise_level, float* out, void* ws, size_t ws_bytes, msn_stream_t stream) {
+    MSN_REQUIRE(img && u && rot && out && B > 0 && C > 0 && S > 0, "msn_augment_images: bad arguments");
+    MSN_REQUIRE(ws && ws_bytes >= msn_augment_workspace_bytes(), "msn_augment_images: workspace too small");
+    const int64_t n = B * C * S * S;
+    MSN_REQUIRE(n > 1, "msn_augment_images: need more than one pixel for a standard deviation");
+    double* part = static_cast<double*>(ws);
+    double* part2 = part + AUG_PARTS;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(sum_kernel, dim3(AUG_PARTS), dim3(1024), 0, st, img, n, part);
+    hipLaunchKernelGGL(sqdev_kernel, dim3(AUG_PARTS), dim3(1024), 0, st, img, n, part, AUG_PARTS, part2);
+    hipLaunchKernelGGL(augment_images_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 8192)), dim3(256), 0, st, img, u,
+                       rot, B, C, S, noise_level, part2, AUG_PARTS, n, out);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+// out = x + g * err * noise_level   (magnitudes / spectra; g: standard-normal field)
+extern "C" int msn_augment_series(const float* x, const float* g, const float* err, int64_t n, float noise_level,
+                                  float* out, msn_stream_t stream) {
+    MSN_REQUIRE(x && g && err && out && n > 0, "msn_augment_series: bad arguments");
+    hipLaunchKernelGGL(augment_series_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 4096)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, g, err, n, noise_level, out);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }
