@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Two ranks sharing ONE GPU (gloo transport, CUDA tensors): full HIP training step with global negatives vs the
+single-process step at the doubled batch.  A plumbing check for boxes with a single GPU; the real multi-GPU run
+uses RCCL (backend "nccl") through the same code."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+TK = dict(n_out=8, emb=16, heads=4, depth=2, dropout=0.0, time_norm=20583.37, agg="mean")
+SK = dict(n_out=8, emb=8, heads=2, depth=2, dropout=0.0, time_norm=17945.14, agg="mean")
+
+
+def make_model():
+    from multimodal_supernovae_amd.models_multimodal import LightCurveImageCLIP
+    torch.manual_seed(0)
+    return LightCurveImageCLIP(enc_dim=16, nband=2, transformer_kwargs=TK, transformer_spectral_kwargs=SK,
+                               combinations=["lightcurve", "spectral"], loss="softmax", lr=1e-2).cuda().train()
+
+
+def make_batch(n):
+    g = torch.Generator().manual_seed(1)
+    mask = torch.ones(n, 12, dtype=torch.bool)
+    mask[:, 9:] = False
+    return (None, torch.randn(n, 12, generator=g), torch.rand(n, 12, generator=g) * 100, mask,
+            torch.randn(n, 10, generator=g), torch.rand(n, 10, generator=g) * 6000 + 3000,
+            torch.ones(n, 10, dtype=torch.bool), None, None)
+
+
+def worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from multimodal_supernovae_amd import distributed as D
+    D.init_from_env(backend="gloo")
+    b = 8
+    full = make_batch(world * b)
+    local = tuple(t[rank * b:(rank + 1) * b].cuda() if t is not None else None for t in full)
+    model = make_model()
+    D.broadcast_module(model)
+    loss = model.training_step(local, 0)
+    loss.backward()
+    D.allreduce_gradients(model.parameters())
+    torch.cuda.synchronize()
+    if rank == 0:
+        dist.barrier()
+        dist.destroy_process_group()       # single-process reference at the global batch
+        ref = make_model()
+        rl = ref.training_step(tuple(t.cuda() if t is not None else None for t in full), 0)
+        rl.backward()
+        worst, errs = 0.0, []
+        for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+            if k == "logit_bias":          # analytically zero gradient: rounding noise only
+                continue
+            scale = float(q.grad.abs().max()) + 1e-12
+            e = float((p.grad - q.grad).abs().max()) / scale
+            errs.append((e, k))
+            worst = max(worst, e)
+        out["top"] = sorted(errs)[-3:]
+        out["loss"] = (float(loss.detach()), float(rl.detach()))
+        out["worst_rel_grad_err"] = worst
+    else:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    procs = [ctx.Process(target=worker, args=(r, 2, 29611, out)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(300) for p in procs]
+    print(dict(out), [p.exitcode for p in procs])
+    ok = all(p.exitcode == 0 for p in procs) and abs(out["loss"][0] - out["loss"][1]) < 1e-4 * abs(out["loss"][1]) \
+        and out["worst_rel_grad_err"] < 1e-3
+    print("DIST CHECK", "OK" if ok else "FAILED")
+    sys.exit(0 if ok else 1)
