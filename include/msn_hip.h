@@ -267,6 +267,12 @@ int msn_maxpool2d_fwd(const float* x, int B, int H, int W, int C, int k, int s, 
 int msn_maxpool2d_bwd(const float* dy, const int* argmax, int B, int H, int W, int C, int k, int s, int p,
                       float* dx, msn_stream_t stream);
 
+/* nn.Dropout in train mode (src/transformer_utils.py:108,113,116,140; src/models_multimodal.py:71,78,87,850):
+ * y = keep(seed, i) ? x / (1 - p) : 0 (+ residual), keep from a counter-based hash of (seed, element index), so the
+ * same call applied to the gradient reproduces the mask and nothing is stored.  In place allowed. */
+int msn_dropout(const float* x, int64_t n, float p, uint64_t seed, const float* residual, float* y,
+                msn_stream_t stream);
+
 /* On-device form of NoisyDataLoader.__iter__ (src/dataloader.py:88-287), the step right before the path:
  *   images: out = rot90^{rot[b]}( img + (2 u - 1) * noise_level * std(img) )   (B, C, S, S), std = torch.std of the
  *           whole batch; u = uniform [0,1) field, rot = quarter turns per sample (both supplied by the caller's RNG);

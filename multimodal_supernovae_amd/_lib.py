@@ -55,6 +55,7 @@ SIGNATURES = {
     "msn_bn_workspace_bytes": (c_size, [c_i64, c_int]),
     "msn_batchnorm_fwd": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_f32, c_int, c_f32, c_ptr, c_ptr, c_ptr, c_int,
                                   c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "msn_dropout": (c_int, [c_ptr, c_i64, c_f32, ctypes.c_uint64, c_ptr, c_ptr, c_ptr]),
     "msn_augment_workspace_bytes": (c_size, []),
     "msn_augment_images": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_f32, c_ptr, c_ptr, c_size, c_ptr]),
     "msn_augment_series": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_ptr, c_ptr]),

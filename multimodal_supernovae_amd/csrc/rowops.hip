@@ -497,6 +497,26 @@ __global__ void augment_series_kernel(const float* __restrict__ x, const float* 
         out[i] = x[i] + g[i] * err[i] * level;
 }
 
+// -------------------------------------------------------------------------------------------- dropout
+// Counter-based: element i is kept iff hash(seed, i) >= p, so the SAME call on the gradient reproduces the mask
+// (nothing is stored).  y = keep ? x / (1 - p) : 0  (+ res).  nn.Dropout semantics in train mode; the stream of
+// random numbers differs from torch's Philox sequence (only the distribution can match).
+__device__ __forceinline__ float keep_scale(uint64_t seed, int64_t i, float p, float inv_keep) {
+    uint64_t x = (uint64_t)i * 0x9E3779B97F4A7C15ull + seed;
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    const float u = (float)(x >> 40) * (1.f / 16777216.f);   // 24 random bits -> [0, 1)
+    return u >= p ? inv_keep : 0.f;
+}
+__global__ void dropout_kernel(const float* __restrict__ x, int64_t n, float p, uint64_t seed,
+                               const float* __restrict__ res, float* __restrict__ y) {
+    const float inv_keep = 1.f / (1.f - p);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = x[i] * keep_scale(seed, i, p, inv_keep);
+        if (res) v += res[i];
+        y[i] = v;
+    }
+}
+
 static int pick_lpr(int cols) {
     const int chunks = cols / 4;
     if (chunks <= 4 * NCH) return 4;
@@ -736,6 +756,16 @@ extern "C" int msn_augment_series(const float* x, const float* g, const float* e
     MSN_REQUIRE(x && g && err && out && n > 0, "msn_augment_series: bad arguments");
     hipLaunchKernelGGL(augment_series_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 4096)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, g, err, n, noise_level, out);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+// y = dropout(x; p, seed) (+ residual).  In place (y == x) allowed.  0 <= p < 1.
+extern "C" int msn_dropout(const float* x, int64_t n, float p, uint64_t seed, const float* residual, float* y,
+                           msn_stream_t stream) {
+    MSN_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, "msn_dropout: bad arguments (p = %f)", (double)p);
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 8192)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, n, p, seed, residual, y);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }

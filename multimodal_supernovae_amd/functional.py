@@ -33,6 +33,28 @@ def _remember_precision(cls):
     return cls
 
 
+# ------------------------------------------------------------------------------------- dropout
+class _Dropout(torch.autograd.Function):
+    """nn.Dropout in train mode; the mask is a function of (seed, element index) and is recomputed for the
+    gradient instead of being stored."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.cfg = (p, seed)
+        return ops.dropout(x, p, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed = ctx.cfg
+        return ops.dropout(dy, p, seed), None, None
+
+
+def dropout(x, p, training=True):
+    if not training or p <= 0.0:
+        return x
+    return _Dropout.apply(x, float(p), ops.new_seed())
+
+
 # ------------------------------------------------------------------------------- linear chains
 @_remember_precision
 class _LinearChain(torch.autograd.Function):
@@ -41,11 +63,11 @@ class _LinearChain(torch.autograd.Function):
     activation derivative of layer i is applied in the epilogue of layer i+1's dgrad GEMM."""
 
     @staticmethod
-    def forward(ctx, x, acts, *wb):
+    def forward(ctx, x, acts, drop_p, *wb):
         n = len(acts)
         shape = x.shape
         h = _c(x).view(-1, shape[-1])
-        inputs, pres = [], []
+        inputs, pres, seeds = [], [], []
         for i in range(n):
             w, b = wb[2 * i], wb[2 * i + 1]
             inputs.append(h)
@@ -59,9 +81,14 @@ class _LinearChain(torch.autograd.Function):
             else:
                 h = sgemm(h, w, OP_N, OP_T, bias=b)
                 pres.append(None)
+            seeds.append(None)
+            if drop_p > 0.0 and acts[i] != ACT_NONE:       # Linear -> act -> Dropout (ref :850, :87)
+                seeds[i] = ops.new_seed()
+                ops.dropout(h, drop_p, seeds[i], out=h)
         if acts[-1] != ACT_NONE:
             raise ValueError("the last layer of a linear chain carries no activation")
         ctx.acts, ctx.shape = acts, shape
+        ctx.drop = (drop_p, seeds)
         ctx.n_saved_in = n
         ctx.save_for_backward(*inputs, *[p if p is not None else torch.empty(0) for p in pres], *wb)
         return h.view(*shape[:-1], h.shape[-1])
@@ -80,30 +107,34 @@ class _LinearChain(torch.autograd.Function):
                 grads[2 * i + 1] = colsum(d)
             if i > 0:
                 act = ctx.acts[i - 1]
-                if act == ACT_RELU:      # inputs[i] = relu output of layer i-1
+                if act == ACT_RELU:      # inputs[i] = relu output of layer i-1 (zero where dropped: same gate)
                     d = sgemm(d, w, OP_N, OP_N, epilogue=EPI_RELU_BWD, aux=inputs[i])
                 elif act == ACT_GELU:
                     d = sgemm(d, w, OP_N, OP_N, epilogue=EPI_GELU_BWD, aux=pres[i - 1])
                 else:
                     d = sgemm(d, w, OP_N, OP_N)
+                drop_p, seeds = ctx.drop
+                if seeds[i - 1] is not None:     # gradient through the dropout that followed the activation
+                    ops.dropout(d, drop_p, seeds[i - 1], out=d)
             elif ctx.needs_input_grad[0]:
                 d = sgemm(d, w, OP_N, OP_N)
             else:
                 d = None
         dx = d.view(ctx.shape) if d is not None else None
-        return (dx, None, *grads)
+        return (dx, None, None, *grads)
 
 
-def linear_chain(x, layers, acts):
-    """layers: [(weight, bias_or_None), ...]; acts: one of none/relu/gelu per layer (last = none)."""
+def linear_chain(x, layers, acts, drop_p=0.0):
+    """layers: [(weight, bias_or_None), ...]; acts: one of none/relu/gelu per layer (last = none);
+    drop_p > 0 applies dropout after every activation (train mode)."""
     flat = []
     for w, b in layers:
         flat += [w, b]
-    return _LinearChain.apply(x, tuple(acts), *flat)
+    return _LinearChain.apply(x, tuple(acts), float(drop_p), *flat)
 
 
 def linear(x, weight, bias=None):
-    return _LinearChain.apply(x, (ACT_NONE,), weight, bias)
+    return _LinearChain.apply(x, (ACT_NONE,), 0.0, weight, bias)
 
 
 # --------------------------------------------------------------------- projection + L2 normalise
@@ -224,15 +255,22 @@ class _PostNormBlock(torch.autograd.Function):
     residual-branch gradients ride in the dgrad epilogues."""
 
     @staticmethod
-    def forward(ctx, x, mask_u8, heads, wk, wq, wv, wu, bu, g1, b1, w1, c1, w2, c2, g2, b2):
+    def forward(ctx, x, mask_u8, heads, drop_p, wk, wq, wv, wu, bu, g1, b1, w1, c1, w2, c2, g2, b2):
         B, T, e = x.shape
         x2 = _c(x).view(B * T, e)
         scale = 1.0 / math.sqrt(e)
         z1, (qkv, a2, lse) = _attn_forward_raw(x2, B, T, wq, wk, wv, wu, bu, mask_u8, heads, scale, x2)
         y1, m1, r1 = ops.layernorm_fwd(z1, g1, b1)
+        seeds = None
+        if drop_p > 0.0:                 # x = do(norm1(...)) / x = do(norm2(...)), ref :111-116
+            seeds = (ops.new_seed(), ops.new_seed())
+            ops.dropout(y1, drop_p, seeds[0], out=y1)
         hdn = sgemm(y1, w1, OP_N, OP_T, bias=c1, epilogue=EPI_RELU)
         z2 = sgemm(hdn, w2, OP_N, OP_T, bias=c2, epilogue=EPI_ADD, aux=y1)
         y2, m2, r2 = ops.layernorm_fwd(z2, g2, b2)
+        if seeds:
+            ops.dropout(y2, drop_p, seeds[1], out=y2)
+        ctx.drop = (drop_p, seeds)
         ctx.dims = (B, T, e, heads, scale)
         ctx.mask = mask_u8
         ctx.save_for_backward(x2, wq, wk, wv, wu, g1, w1, w2, g2, qkv, a2, lse, z1, m1, r1, y1, hdn, z2, m2, r2)
@@ -243,6 +281,9 @@ class _PostNormBlock(torch.autograd.Function):
         B, T, e, heads, scale = ctx.dims
         (x2, wq, wk, wv, wu, g1, w1, w2, g2, qkv, a2, lse, z1, m1, r1, y1, hdn, z2, m2, r2) = ctx.saved_tensors
         dy2 = _c(dy).view(B * T, e)
+        drop_p, seeds = ctx.drop
+        if seeds:
+            dy2 = ops.dropout(dy2, drop_p, seeds[1])
         dz2, dg2, db2 = ops.layernorm_bwd(dy2, z2, m2, r2, g2)
         dw2 = sgemm(dz2, hdn, OP_T, OP_N)
         dc2 = colsum(dz2)
@@ -250,16 +291,18 @@ class _PostNormBlock(torch.autograd.Function):
         dw1 = sgemm(dpre, y1, OP_T, OP_N)
         dc1 = colsum(dpre)
         dy1 = sgemm(dpre, w1, OP_N, OP_N, epilogue=EPI_ADD, aux=dz2)       # + residual branch of LN2's input
+        if seeds:
+            ops.dropout(dy1, drop_p, seeds[0], out=dy1)
         dz1, dg1, db1 = ops.layernorm_bwd(dy1, z1, m1, r1, g1)
         dx, dwq, dwk, dwv, dwu, dbu = _attn_backward_raw(dz1, x2, B, T, (qkv, a2, lse), wq, wk, wv, wu, ctx.mask,
                                                          heads, scale, dz1)  # + residual branch of LN1's input
-        return (dx.view(B, T, e), None, None, dwk, dwq, dwv, dwu, dbu, dg1, db1, dw1, dc1, dw2, dc2, dg2, db2)
+        return (dx.view(B, T, e), None, None, None, dwk, dwq, dwv, dwu, dbu, dg1, db1, dw1, dc1, dw2, dc2, dg2, db2)
 
 
-def post_norm_block(x, mask_u8, heads, p):
+def post_norm_block(x, mask_u8, heads, p, drop_p=0.0):
     """p: dict with tokeys, toqueries, tovalues, unify_w, unify_b, norm1_w, norm1_b, ff0_w, ff0_b,
-    ff2_w, ff2_b, norm2_w, norm2_b."""
-    return _PostNormBlock.apply(x, mask_u8, heads, p["tokeys"], p["toqueries"], p["tovalues"], p["unify_w"],
+    ff2_w, ff2_b, norm2_w, norm2_b.  drop_p > 0: dropout after both LayerNorms (train mode)."""
+    return _PostNormBlock.apply(x, mask_u8, heads, float(drop_p), p["tokeys"], p["toqueries"], p["tovalues"], p["unify_w"],
                                 p["unify_b"], p["norm1_w"], p["norm1_b"], p["ff0_w"], p["ff0_b"], p["ff2_w"],
                                 p["ff2_b"], p["norm2_w"], p["norm2_b"])
 
@@ -399,8 +442,10 @@ class _ConvMixerTrunk(torch.autograd.Function):
     PER_LAYER = 12
 
     @staticmethod
-    def forward(ctx, img, training, depth, patch, *P):
+    def forward(ctx, img, training, depth, patch, drop_p, *P):
         B, C, H, W = img.shape
+        drop_p = drop_p if training else 0.0
+        seeds = []
         gh, gw = H // patch, W // patch
         img = _c(img.float())
         w0, g0, b0, rm0, rv0 = P[:5]
@@ -414,13 +459,22 @@ class _ConvMixerTrunk(torch.autograd.Function):
         for i in range(depth):
             dw_w, dw_b, gA, bA, rmA, rvA, pw_w, pw_b, gB, bB, rmB, rvB = P[5 + 12 * i: 17 + 12 * i]
             preA, actA = ops.dwconv_gelu_fwd(y, dw_w, dw_b, B, gh, gw)
-            yA, meanA, rstdA = ops.batchnorm_fwd(actA, gA, bA, rmA, rvA, training, residual=y)
+            if drop_p > 0.0:      # x + Dropout(BN(GELU(dw(x)))), then Dropout(BN(GELU(1x1))) -- ref :62-79
+                sA, sB = ops.new_seed(), ops.new_seed()
+                seeds.append((sA, sB))
+                yA, meanA, rstdA = ops.batchnorm_fwd(actA, gA, bA, rmA, rvA, training)
+                ops.dropout(yA, drop_p, sA, residual=y, out=yA)
+            else:
+                yA, meanA, rstdA = ops.batchnorm_fwd(actA, gA, bA, rmA, rvA, training, residual=y)
             preB = torch.empty((M, dim), dtype=torch.float32, device=img.device)
             actB = sgemm(yA, pw_w.view(dim, dim), OP_N, OP_T, bias=pw_b, epilogue=EPI_GELU, aux=preB)
             yB, meanB, rstdB = ops.batchnorm_fwd(actB, gB, bB, rmB, rvB, training)
+            if drop_p > 0.0:
+                ops.dropout(yB, drop_p, sB, out=yB)
             saved += [y, preA, actA, meanA, rstdA, yA, preB, actB, meanB, rstdB]
             y = yB
         ctx.geom = (B, C, H, W, gh, gw, dim, depth, patch, bool(training))
+        ctx.drop = (drop_p, seeds)
         ctx.n_act = len(saved)
         ctx.save_for_backward(*saved, *P)
         return y.view(B, gh * gw, dim)
@@ -436,12 +490,16 @@ class _ConvMixerTrunk(torch.autograd.Function):
             o = 5 + 12 * i
             dw_w, dw_b, gA, bA, rmA, rvA, pw_w, pw_b, gB, bB, rmB, rvB = P[o:o + 12]
             y_in, preA, actA, meanA, rstdA, yA, preB, actB, meanB, rstdB = acts[5 + 10 * i: 15 + 10 * i]
+            drop_p, seeds = ctx.drop
+            if drop_p > 0.0:
+                d = ops.dropout(d, drop_p, seeds[i][1])
             dpreB, dgB, dbB = ops.batchnorm_bwd(d, actB, preB, meanB, rstdB, gB, training)
             grads[o + 6] = sgemm(dpreB, yA, OP_T, OP_N).view_as(pw_w)
             grads[o + 7] = colsum(dpreB)
             grads[o + 8], grads[o + 9] = dgB, dbB
             dyA = sgemm(dpreB, pw_w.view(dim, dim), OP_N, OP_N)
-            dpreA, dgA, dbA = ops.batchnorm_bwd(dyA, actA, preA, meanA, rstdA, gA, training)
+            dbn = ops.dropout(dyA, drop_p, seeds[i][0]) if drop_p > 0.0 else dyA      # branch through the dropout
+            dpreA, dgA, dbA = ops.batchnorm_bwd(dbn, actA, preA, meanA, rstdA, gA, training)
             d, ddw, ddb = ops.dwconv_bwd(dpreA, y_in, dw_w, B, gh, gw, add=dyA)   # + the residual branch
             grads[o], grads[o + 1], grads[o + 2], grads[o + 3] = ddw, ddb, dgA, dbA
         patches, pre0, act0, mean0, rstd0 = acts[:5]
@@ -452,11 +510,11 @@ class _ConvMixerTrunk(torch.autograd.Function):
         dimg = None
         if ctx.needs_input_grad[0]:
             dimg = ops.unpatchify(sgemm(dpre0, w0.view(dim, -1), OP_N, OP_N), (B, C, H, W), patch)
-        return (dimg, None, None, None, *grads)
+        return (dimg, None, None, None, None, *grads)
 
 
-def convmixer_trunk(img, training, depth, patch, flat_params):
-    return _ConvMixerTrunk.apply(img, training, depth, patch, *flat_params)
+def convmixer_trunk(img, training, depth, patch, flat_params, drop_p=0.0):
+    return _ConvMixerTrunk.apply(img, training, depth, patch, float(drop_p), *flat_params)
 
 
 # ------------------------------------------------------------- pre-norm (ViT) transformer block

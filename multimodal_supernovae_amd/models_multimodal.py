@@ -15,7 +15,7 @@ import torch.nn as nn
 from . import functional as F_
 from . import ops
 from .loss import clip_loss_multimodal
-from .transformer_utils import TransformerWithTimeEmbeddings, _warn_dropout
+from .transformer_utils import TransformerWithTimeEmbeddings
 
 
 class Residual(nn.Module):
@@ -62,9 +62,8 @@ class ConvMixer(nn.Module):
             yield self.net[3 + i][3]
 
     def forward(self, x):
-        if self.training:
-            _warn_dropout(self._dropout)
-        tokens = F_.convmixer_trunk(x, self.training, self.depth, self.patch_size, self._flat_params())
+        p_drop = self._dropout if self.training else 0.0
+        tokens = F_.convmixer_trunk(x, self.training, self.depth, self.patch_size, self._flat_params(), drop_p=p_drop)
         if self.training:
             with torch.no_grad():
                 for bn in self._bns():
@@ -73,7 +72,8 @@ class ConvMixer(nn.Module):
         ones = torch.ones((B, hw), dtype=torch.uint8, device=tokens.device)
         pooled = F_.masked_pool(tokens, ones, "mean")                      # AdaptiveAvgPool2d((1, 1)) + Flatten
         p2, p5 = self.projection[2], self.projection[5]
-        return F_.linear_chain(pooled, [(p2.weight, p2.bias), (p5.weight, p5.bias)], [F_.ACT_GELU, F_.ACT_NONE])
+        return F_.linear_chain(pooled, [(p2.weight, p2.bias), (p5.weight, p5.bias)], [F_.ACT_GELU, F_.ACT_NONE],
+                               drop_p=p_drop)
 
 
 class MLP(nn.Module):
@@ -96,7 +96,8 @@ class MLP(nn.Module):
 
     def forward(self, x):
         lin = [m for m in self.layers if isinstance(m, nn.Linear)]
-        return F_.linear_chain(x, [(m.weight, m.bias) for m in lin], [F_.ACT_RELU] * (len(lin) - 1) + [F_.ACT_NONE])
+        return F_.linear_chain(x, [(m.weight, m.bias) for m in lin], [F_.ACT_RELU] * (len(lin) - 1) + [F_.ACT_NONE],
+                               drop_p=self.dropout if self.training else 0.0)
 
 
 class LightCurveImageCLIP(nn.Module):

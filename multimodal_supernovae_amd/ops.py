@@ -402,3 +402,17 @@ def series_features(x, t, mask_u8, inv_norm):
     check(lib().msn_series_features(ptr(_f32c(x, "x")), ptr(_f32c(t, "t")), ptr(mask_u8), B * T, inv_norm, ptr(feat),
                                     stream_ptr()), "msn_series_features")
     return feat
+
+
+# --------------------------------------------------------------------------------------------- dropout
+def new_seed():
+    """A fresh 63-bit dropout seed from torch's CPU generator (reproducible under torch.manual_seed)."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+def dropout(x, p, seed, residual=None, out=None):
+    """y = dropout(x) (+ residual); the same (p, seed) applied to a gradient reproduces the mask."""
+    x = _f32c(x if x.is_contiguous() else x.contiguous(), "x")
+    y = out if out is not None else torch.empty_like(x)
+    check(lib().msn_dropout(ptr(x), x.numel(), float(p), seed, ptr(residual), ptr(y), stream_ptr()), "msn_dropout")
+    return y

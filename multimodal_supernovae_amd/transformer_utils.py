@@ -6,19 +6,12 @@ PARAMETER HOLDERS (same names, shapes and default initialisation as the referenc
 checkpoints load with strict=True); their own forward methods are never called.
 """
 import math
-import warnings
 
 import torch
 import torch.nn as nn
 
 from . import functional as F_
 from . import ops
-
-
-def _warn_dropout(p):
-    if p and p > 0:
-        warnings.warn(f"dropout p={p} requested: this build evaluates the contrastive path with dropout "
-                      "disabled (the shipped configs use p ~ 2e-4)", stacklevel=3)
 
 
 def _mask_bytes(mask):
@@ -52,8 +45,7 @@ class TransformerBlock(nn.Module):
         self.norm1 = nn.LayerNorm(emb)
         self.norm2 = nn.LayerNorm(emb)
         self.ff = nn.Sequential(nn.Linear(emb, ff_hidden_mult * emb), nn.ReLU(), nn.Linear(ff_hidden_mult * emb, emb))
-        self.do = nn.Dropout(dropout)
-        _warn_dropout(dropout)
+        self.do = nn.Dropout(dropout)     # holder of p: the dropout itself runs in the fused block (train mode only)
 
     def _params(self):
         a = self.attention
@@ -65,7 +57,7 @@ class TransformerBlock(nn.Module):
 
     def forward(self, x, mask=None):
         return F_.post_norm_block(x, _mask_bytes(mask) if mask is None or mask.dtype != torch.uint8 else mask,
-                                  self.attention.heads, self._params())
+                                  self.attention.heads, self._params(), drop_p=self.do.p if self.training else 0.0)
 
 
 class Transformer(nn.Module):
@@ -79,6 +71,7 @@ class Transformer(nn.Module):
 
     def forward(self, x, mask=None):
         m = _mask_bytes(mask)
+        x = F_.dropout(x, self.do.p, self.training)           # ref :150
         for blk in self.tblocks:
             x = blk(x, m)
         return x
