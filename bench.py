@@ -56,6 +56,61 @@ def build_model(device, seed=0):
     return model.to(device).train()
 
 
+# ---- the other BASELINE.json configurations (parity-test cases; measured on request with --workload) ------------
+SP_MAVEN = dict(n_out=32, emb=32, heads=2, depth=13, dropout=0.0, time_norm=17945.142213594805, agg="mean")
+WORKLOADS = {
+    "vit_s8_lc": "headline: ViT-S/8 + reference LC transformer (BASELINE cfg3 towers)",
+    "resnet18_cnn1d": "BASELINE cfg2: ResNet-18 @64x64 + 1-D CNN light-curve encoder, local batch 256",
+    "vit_s8_lc_cnn1d_sp": "BASELINE cfg4 towers: ViT-S/8 + LC transformer + 1-D CNN spectrum (1024 bins), 3-way InfoNCE",
+    "vit_b16_bf16_lc": "BASELINE cfg5 towers: ViT-B/16 @224x224 with bf16 MFMA GEMMs + LC transformer",
+    "maven_lc_sp": "reference-native Maven pretraining: LC (T=200, e64, h8, L5) + spectrum (T=220, e32, h2, L13)",
+    "convmixer_lc_sp": "reference-native 3-tower: ConvMixer (64x64, p8, dim 32, depth 2) + LC + spectrum (T=1024)",
+}
+
+
+def build_workload(name, b, seed, device):
+    """(model, batch, flops_per_pair or None) for the non-headline workloads."""
+    from multimodal_supernovae_amd import encoders as E
+    from multimodal_supernovae_amd.models_multimodal import LightCurveImageCLIP
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(0)
+
+    def series(t, nband, lo, hi):
+        per = t // nband
+        x = torch.randn(b, t, generator=g)
+        tt = torch.cat([torch.sort(torch.rand(b, per, generator=g) * (hi - lo) + lo, dim=1)[0] for _ in range(nband)], 1)
+        return x, tt, torch.ones(b, t, dtype=torch.bool)
+
+    img = lambda s: torch.rand(b, 3, s, s, generator=g)
+    kw = dict(enc_dim=ENC_DIM, logit_scale=LOGIT_SCALE, nband=NBAND, transformer_kwargs=LC, transformer_spectral_kwargs=SP_MAVEN,
+              conv_kwargs=CONV_PLACEHOLDER, optimizer_kwargs={"weight_decay": WD}, lr=LR, loss="softmax")
+    lc = series(T_LC, NBAND, 0.0, 100.0)
+    none3 = (None, None, None)
+    if name == "resnet18_cnn1d":
+        m = LightCurveImageCLIP(combinations=["host_galaxy", "lightcurve"], **kw)
+        m.image_encoder, m.lightcurve_encoder = E.ResNet18(n_out=N_OUT), E.Conv1dEncoder(n_out=N_OUT, time_norm=100.0)
+        batch = (img(64), *lc, *none3, None, None)
+    elif name == "vit_s8_lc_cnn1d_sp":
+        m = LightCurveImageCLIP(combinations=["host_galaxy", "lightcurve", "spectral"], **kw)
+        m.image_encoder = E.vit_s8(img_size=64, n_out=N_OUT)
+        m.spectral_encoder = E.Conv1dEncoder(n_out=N_OUT, time_norm=9000.0)
+        batch = (img(64), *lc, *series(1024, 1, 3000.0, 9000.0), None, None)
+    elif name == "vit_b16_bf16_lc":
+        m = LightCurveImageCLIP(combinations=["host_galaxy", "lightcurve"], **kw)
+        m.image_encoder = E.vit_b16(img_size=224, n_out=N_OUT)
+        batch = (img(224), *lc, *none3, None, None)
+    elif name == "maven_lc_sp":
+        m = LightCurveImageCLIP(combinations=["lightcurve", "spectral"], **kw)
+        batch = (None, *lc, *series(220, 1, 3000.0, 9000.0), None, None)
+    elif name == "convmixer_lc_sp":
+        kw["conv_kwargs"] = dict(dim=32, depth=2, channels=3, kernel_size=5, patch_size=8, n_out=N_OUT, dropout_prob=0.0)
+        m = LightCurveImageCLIP(combinations=["host_galaxy", "lightcurve", "spectral"], **kw)
+        batch = (img(64), *lc, *series(1024, 1, 3000.0, 9000.0), None, None)
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    return m.to(device).train(), tuple(t.to(device) if t is not None else None for t in batch)
+
+
 def flops_per_pair():
     """Algorithmic work model of BASELINE.md section 4 (2 flop / MAC, GEMM-shaped work only, train = 3 x fwd)."""
     def f_tr(t, e, l):
@@ -129,6 +184,8 @@ def main():
     ap.add_argument("--per-gpu-batch", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra split-bf16 measurement")
+    ap.add_argument("--workload", default="vit_s8_lc", choices=list(WORKLOADS),
+                    help="vit_s8_lc = the headline (default); the others are the remaining BASELINE.json configurations")
     ap.add_argument("--gemm-table", action="store_true", help="per-shape GEMM timing of one step on stderr")
     ap.add_argument("--gemm-precision", default="f32", choices=["f32", "bf16x3", "bf16"],
                     help="inner-product precision of the GEMMs (bf16x3 = split-bf16, fp32-grade accuracy)")
@@ -144,10 +201,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     device = torch.device("cuda", local)
     b = args.per_gpu_batch
-    model = build_model(device)
+    if args.workload == "vit_s8_lc":
+        model = build_model(device)
+        batch = synthetic_batch(b, 1234 + rank, device)
+    else:
+        model, batch = build_workload(args.workload, b, 1234 + rank, device)
+        args.no_alt, args.no_cpu_baseline = True, True
     D.broadcast_module(model)
     opt = model.configure_optimizers()["optimizer"]
-    batch = synthetic_batch(b, 1234 + rank, device)
     params = [p for p in model.parameters()]
 
     def step():
@@ -240,9 +301,10 @@ def main():
             "value": pairs, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "ViT-S/8 image tower (64x64x3, build-defined) + reference light-curve "
-                                   "transformer (T=200, emb 64, 8 heads, depth 5, 2 bands) -> enc_dim 128, "
-                                   "symmetric InfoNCE with all-gathered global negatives, RAdam; full train step",
+            "config": {"workload": ("ViT-S/8 image tower (64x64x3, build-defined) + reference light-curve "
+                                    "transformer (T=200, emb 64, 8 heads, depth 5, 2 bands) -> enc_dim 128, "
+                                    "symmetric InfoNCE with all-gathered global negatives, RAdam; full train step")
+                       if args.workload == "vit_s8_lc" else WORKLOADS[args.workload] + " (non-headline configuration)",
                        "per_gpu_batch": b, "global_batch": b * world, "parallelism": f"dp{world}",
                        "loss": loss_value, "algorithmic_gflop_per_pair": flops_per_pair() / 1e9,
                        "model_tflops": pairs * flops_per_pair() / 1e12},
