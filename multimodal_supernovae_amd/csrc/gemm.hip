@@ -12,6 +12,7 @@
 // are dealt round-robin over them, so ids are remapped to give each XCD a contiguous run of
 // tiles that walk N fastest (neighbours share the A row-panel in that XCD's L2).
 #include <algorithm>
+#include <type_traits>
 
 #include "gemm_common.h"
 
@@ -247,6 +248,177 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmArgs p) {
     gemm_epilogue<TM, TN>(acc, p, m0, n0, wm0, wn0, l32, h, split);
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant (the default whenever it applies): operand tiles go HBM -> LDS directly with
+// global_load_lds_dwordx4 (no staging registers, no VALU, no ds_write), through a STAGES-deep ring so the
+// loads of K-step kt + STAGES - 1 are in flight while kt is multiplied -- the register-staged kernel above
+// can only run one K-step ahead (a second register set costs the second wave per SIMD), and one K-step of
+// MFMA time is shorter than an HBM round trip under load.  An LDS-DMA instruction writes 64 lanes x 16 B =
+// 1 KB contiguously, so the images are unpadded; bank conflicts of the 16-byte fragment reads of a
+// K-contiguous image ([row][32 floats], 128-B rows) are broken by an XOR swizzle applied on the per-lane
+// SOURCE address and again on the read: chunk c of row r lives at position c ^ (r & 7).  A K-major image
+// ([k][rows]) is read 4 bytes per lane along a row: conflict-free as it is.
+// Waits are counted (each wave leaves the youngest stage in flight) and the barrier is a raw s_barrier: a
+// __syncthreads() would drain the DMA queue.  Needs: 16-B aligned operands, ld % 4 == 0, extents % 4 == 0,
+// and K-ranges that are whole K-steps (K % 32 == 0); anything else takes the register-staged kernel.
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+template <int ROWS, bool KMAJOR, int DBK>
+struct DmaTile {
+    static constexpr int kFloats = ROWS * DBK;            // unpadded image
+    static constexpr int kPieces = ROWS * DBK / 256;      // 1-KB LDS-DMA pieces per K-step
+    static constexpr int CPR = DBK / 4;                   // 16-byte chunks per row of a K-contiguous image
+    // source address of this lane for piece q of the K-step starting at k0
+    __device__ static __forceinline__ const float* src(const float* __restrict__ g, int64_t ld, int64_t row0,
+                                                       int64_t nrows, int64_t k0, int q, int lane) {
+        if (KMAJOR) {   // image [k][ROWS]: piece = 256 / ROWS consecutive k-rows
+            constexpr int LPR = ROWS / 4;                                  // lanes per k-row
+            const int kk = q * (64 / LPR) + lane / LPR;
+            int64_t c = row0 + 4 * (lane % LPR);
+            c = c + 3 < nrows ? c : nrows - 4;
+            return g + (k0 + kk) * ld + c;
+        } else {        // image [ROWS][DBK]: piece = 64 / CPR rows; chunk c of row r sits at position c ^ (r % CPR)
+            const int r = q * (64 / CPR) + lane / CPR, pos = lane % CPR;
+            int64_t rr = row0 + r;
+            rr = rr < nrows ? rr : nrows - 1;
+            return g + rr * ld + k0 + 4 * (pos ^ (r % CPR));
+        }
+    }
+    // LDS reads are issued from inline asm: hipcc's waitcnt pass cannot prove that a ds_read does not alias an
+    // LDS-DMA write still in flight and would put s_waitcnt vmcnt(0) in front of every k-step's first read
+    // (draining the whole ring); an asm read is invisible to that pass, so its completion is counted by hand
+    // (lgkmcnt) in the kernel.  `tile_addr` = LDS byte address of the image.
+    static constexpr int kReads = KMAJOR ? 4 : 1;   // LDS instructions per fragment
+    __device__ static __forceinline__ void frag_issue(float4& f, unsigned tile_addr, int row, int ko, int h) {
+        if (KMAJOR) {
+            const unsigned a = tile_addr + 4u * ((8 * ko + 4 * h) * ROWS + row);
+            asm volatile("ds_read_b32 %0, %1" : "=v"(f.x) : "v"(a));
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.y) : "v"(a), "n"(4 * ROWS));
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.z) : "v"(a), "n"(8 * ROWS));
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.w) : "v"(a), "n"(12 * ROWS));
+        } else {
+            const unsigned a = tile_addr + 4u * (row * DBK + 4 * ((2 * ko + h) ^ (row % CPR)));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(f) : "v"(a));
+        }
+    }
+};
+
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int DBK, int STAGES>
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void sgemm_dma_kernel(const GemmArgs p) {
+    using TA = DmaTile<BM, AKM, DBK>;
+    using TB = DmaTile<BN, BKM, DBK>;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN, NWAVES = (BM / WM) * (BN / WN);
+    constexpr int STAGE = TA::kFloats + TB::kFloats;
+    constexpr int PA = TA::kPieces / NWAVES, PB = TB::kPieces / NWAVES;   // pieces per wave per K-step
+    static_assert(TA::kPieces % NWAVES == 0 && TB::kPieces % NWAVES == 0 && PA > 0 && PB > 0,
+                  "LDS-DMA pieces must divide over the waves");
+    constexpr int INFLIGHT = (STAGES - 2) * (PA + PB);                    // youngest stages left in flight
+    constexpr int NKO = DBK / 8;
+    __shared__ __attribute__((aligned(16))) float smem[STAGES * STAGE];
+    const unsigned smem_addr = (unsigned)(uintptr_t)(lptr_t*)smem;   // LDS byte address of the ring
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int logical = xcd_remap(blockIdx.x, nwg);
+    const int64_t m0 = (int64_t)(logical / p.tiles_n) * BM, n0 = (int64_t)(logical % p.tiles_n) * BN;
+    const int split = blockIdx.y;
+    const int64_t k_begin = (int64_t)split * p.k_per_split;
+    const int64_t k_end = min(p.K, k_begin + (int64_t)p.k_per_split);
+    const int nkt = (int)((k_end - k_begin) / DBK);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, l32 = lane & 31;
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+
+    // this lane's source pointers for K-step 0 (they advance by a constant per K-step)
+    const float* sa[PA];
+    const float* sb[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) sa[i] = TA::src(p.A, p.lda, m0, p.M, k_begin, wave * PA + i, lane);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) sb[i] = TB::src(p.B, p.ldb, n0, p.N, k_begin, wave * PB + i, lane);
+    const int64_t a_step = AKM ? (int64_t)DBK * p.lda : DBK, b_step = BKM ? (int64_t)DBK * p.ldb : DBK;
+    auto issue = [&](int kt) {   // LDS-DMA of K-step kt into ring slot kt % STAGES
+        float* base = smem + (kt % STAGES) * STAGE;
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(sa[i] + kt * a_step), (lptr_t*)(base + (wave * PA + i) * 256), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(sb[i] + kt * b_step),
+                                             (lptr_t*)(base + TA::kFloats + (wave * PB + i) * 256), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nkt) issue(s);
+    // K-step 0 must have landed (for every wave: each waits for its own pieces, then the barrier)
+    if (nkt >= STAGES - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    constexpr int NREADS = TM * TA::kReads + TN * TB::kReads;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + STAGES - 1 < nkt;
+        if (more) issue(kt + STAGES - 1);      // its ring slot held K-step kt - 1: free since the last barrier
+        const unsigned as = smem_addr + 4u * ((kt % STAGES) * STAGE);
+        const unsigned bs = as + 4u * TA::kFloats;
+        // fragments of k-octet ko + 1 are requested before the MFMAs of ko; the counted wait retires exactly the
+        // reads of ko (LDS returns in order) and leaves the younger ones in flight
+        float4 fa[2][TM], fb[2][TN];
+        auto request = [&](auto set, int ko) {
+            constexpr int S = decltype(set)::value;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) TA::frag_issue(fa[S][i], as, wm0 + 32 * i + l32, ko, h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) TB::frag_issue(fb[S][j], bs, wn0 + 32 * j + l32, ko, h);
+        };
+        auto multiply = [&](auto set, bool last) {
+            constexpr int S = decltype(set)::value;
+            if (last) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NREADS) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S][i].x, fb[S][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S][i].y, fb[S][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S][i].z, fb[S][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S][i].w, fb[S][j].w, acc[i][j], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        static_assert(NKO % 2 == 0, "k-octets are processed in pairs");
+        request(S0{}, 0);
+#pragma unroll
+        for (int ko = 0; ko < NKO; ko += 2) {
+            request(S1{}, ko + 1);
+            multiply(S0{}, false);
+            if (ko + 2 < NKO) request(S0{}, ko + 2);
+            multiply(S1{}, ko + 2 >= NKO);
+        }
+        // K-step kt + 1 must be complete before anyone reads it: while further steps were issued, the youngest
+        // STAGES - 2 may stay in flight; near the end of the K range everything outstanding is needed
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    gemm_epilogue<TM, TN>(acc, p, m0, n0, wm0, wn0, l32, h, split);
+}
+
 // C[m][n] = sum_s partial[s][m][n]   (split-K finish; fixed order -> deterministic).  A block covers 64
 // consecutive outputs with 4 thread groups that each sum a quarter of the slabs, combined through LDS.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C,
@@ -304,6 +476,19 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     if (rg == 0 && n < N) out[n] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 static int colsum_blocks(int64_t M) { return (int)std::min<int64_t>(cdiv(M, 16 * CS_RG), CS_MAX_BLOCKS); }
+
+template <int BM, int BN, int WM, int WN, int DBK, int STAGES>
+static int launch_dma(const GemmArgs& a, int opA, int opB, hipStream_t st) {
+    const dim3 grid(a.tiles_m * a.tiles_n, a.splits), block(64 * (BM / WM) * (BN / WN));
+    if (opA == MSN_OP_N && opB == MSN_OP_T) hipLaunchKernelGGL((sgemm_dma_kernel<BM, BN, WM, WN, false, false, DBK, STAGES>), grid, block, 0, st, a);
+    else if (opA == MSN_OP_N && opB == MSN_OP_N) hipLaunchKernelGGL((sgemm_dma_kernel<BM, BN, WM, WN, false, true, DBK, STAGES>), grid, block, 0, st, a);
+    else if (opA == MSN_OP_T && opB == MSN_OP_N) hipLaunchKernelGGL((sgemm_dma_kernel<BM, BN, WM, WN, true, true, DBK, STAGES>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((sgemm_dma_kernel<BM, BN, WM, WN, true, false, DBK, STAGES>), grid, block, 0, st, a);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+static int g_gemm_variant = 0;   // 0 = register-staged kernels, 1 = LDS-DMA ring 3 x BK 32, 2 = LDS-DMA ring 2 x BK 64
 
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const GemmArgs& a, int opA, int opB, hipStream_t st) {
@@ -406,7 +591,16 @@ extern "C" int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, cons
         bf16_ok = (lda % 4 == 0) && (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
     if (bf16_ok && opB == MSN_OP_T)
         bf16_ok = (ldb % 4 == 0) && (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+    // LDS-DMA kernels: every operand 16-B aligned with ld % 4 == 0 and extents % 4 == 0, whole K-steps only
+    const int64_t a_ext = opA == MSN_OP_T ? M : K, b_ext = opB == MSN_OP_N ? N : K;
+    const bool dma_ok = g_gemm_variant != 0 && bn >= 64 && K % BK == 0 && kps % BK == 0 && (lda % 4 == 0) && (ldb % 4 == 0) &&
+                        (a_ext % 4 == 0) && (b_ext % 4 == 0) && a_ext >= 4 && b_ext >= 4 &&
+                        ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
     if (bf16_ok) rc = launch_bgemm(a, opA, opB, precision == MSN_PREC_BF16X3 ? 2 : 1, bm, bn, st);
+    else if (dma_ok && bn == 128 && K % 64 == 0 && kps % 64 == 0 && g_gemm_variant == 2)
+        rc = launch_dma<128, 128, 64, 32, 64, 2>(a, opA, opB, st);
+    else if (dma_ok && bn == 128) rc = launch_dma<128, 128, 64, 32, 32, 3>(a, opA, opB, st);
+    else if (dma_ok && bn == 64) rc = launch_dma<128, 64, 64, 32, 32, 3>(a, opA, opB, st);
     else if (bn == 128) rc = launch_cfg<128, 128, 64, 64>(a, opA, opB, st);
     else if (bn == 64) rc = launch_cfg<128, 64, 64, 32>(a, opA, opB, st);
     else rc = launch_cfg<128, 32, 32, 32>(a, opA, opB, st);
@@ -417,6 +611,12 @@ extern "C" int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, cons
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.partial, C, M, N, ldc, splits);
         MSN_LAUNCH_CHECK();
     }
+    return MSN_OK;
+}
+
+extern "C" int msn_set_gemm_variant(int mode) {
+    MSN_REQUIRE(mode >= 0 && mode <= 2, "msn_set_gemm_variant: mode must be 0 (register-staged), 1 or 2 (LDS-DMA rings)");
+    g_gemm_variant = mode;
     return MSN_OK;
 }
 

@@ -37,6 +37,11 @@ def set_gemm_precision(name):
     global GEMM_PRECISION
     GEMM_PRECISION = _PREC_NAMES[name]
 
+def set_gemm_variant(mode):
+    """fp32 GEMM kernel family (msn_set_gemm_variant): 0 register-staged (default), 1 / 2 LDS-DMA rings."""
+    check(lib().msn_set_gemm_variant(int(mode)))
+
+
 OP_N, OP_T = 0, 1
 EPI_NONE, EPI_RELU, EPI_GELU, EPI_RELU_BWD, EPI_GELU_BWD, EPI_ADD = range(6)
 

@@ -53,6 +53,31 @@ def test_split_bf16_is_fp32_grade():
     torch.testing.assert_close(y.double(), (ref + bias.double()).relu(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("M,N,K,op_a,op_b", [(512, 384, 384, 0, 1), (300, 200, 128, 0, 0), (384, 1536, 4096, 1, 0),
+                                              (256, 128, 192, 1, 1), (130, 70, 33, 0, 1), (640, 64, 256, 0, 1)])
+def test_sgemm_variants_bit_identical(M, N, K, op_a, op_b):
+    """The LDS-DMA kernels (variants 1, 2) accumulate in the same k order as the register-staged default:
+    same bits, also through the epilogues and the split-K wgrad path; shapes they do not take fall back."""
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn((M, K) if op_a == 0 else (K, M), generator=g).cuda()
+    b = torch.randn((K, N) if op_b == 0 else (N, K), generator=g).cuda()
+    bias = torch.randn(N, generator=g).cuda() if op_a == 0 else None
+    epi = ops.EPI_GELU if op_a == 0 else ops.EPI_NONE
+    try:
+        outs = []
+        for v in (0, 1, 2):
+            ops.set_gemm_variant(v)
+            outs.append(ops.sgemm(a, b, op_a, op_b, bias=bias, epilogue=epi))
+    finally:
+        ops.set_gemm_variant(0)
+    ref = _ref(a, b, op_a, op_b)
+    if bias is not None:
+        ref = torch.nn.functional.gelu(ref + bias.double())
+    torch.testing.assert_close(outs[0].double(), ref, rtol=1e-4, atol=1e-4 * K ** 0.5)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_sgemm_asymmetric_identity():
     """A = I with an asymmetric B catches a transposed C write (cdna guide section 3)."""
     from multimodal_supernovae_amd import ops
