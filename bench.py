@@ -187,7 +187,7 @@ def main():
     ap.add_argument("--workload", default="vit_s8_lc", choices=list(WORKLOADS),
                     help="vit_s8_lc = the headline (default); the others are the remaining BASELINE.json configurations")
     ap.add_argument("--gemm-table", action="store_true", help="per-shape GEMM timing of one step on stderr")
-    ap.add_argument("--gemm-variant", type=int, default=0, choices=[0, 1, 2],
+    ap.add_argument("--gemm-variant", type=int, default=0, choices=[0, 1, 2, 3],
                     help="fp32 GEMM kernel family: 0 register-staged (default), 1 / 2 LDS-DMA rings")
     ap.add_argument("--gemm-precision", default="f32", choices=["f32", "bf16x3", "bf16"],
                     help="inner-product precision of the GEMMs (bf16x3 = split-bf16, fp32-grade accuracy)")

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmsn_hip.so")
+LIB_PATH = os.environ.get("MSN_HIP_LIB") or os.path.join(_HERE, "lib", "libmsn_hip.so")
 
 c_i64 = ctypes.c_int64
 c_int = ctypes.c_int

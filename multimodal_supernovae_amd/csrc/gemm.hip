@@ -161,17 +161,19 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmArgs p) {
     auto b_buf = [&](int i) { return smem + 2 * TA::kFloats + i * TB::kFloats; };
 
     const int nwg = p.tiles_m * p.tiles_n;
-    const int logical = xcd_remap(blockIdx.x, nwg);
+    // one flat grid over (split, tile): XCD x owns a contiguous run of it, so the tiles of one K-slab -- which
+    // re-read the same operand rows -- share that XCD's L2 instead of being dealt round-robin over all eight
+    const int flat = xcd_remap(blockIdx.x, nwg * p.splits);
+    const int logical = flat % nwg;
     const int tile_m = logical / p.tiles_n, tile_n = logical % p.tiles_n;
     const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
-    const int split = blockIdx.y;
+    const int split = flat / nwg;
     const int64_t k_begin = (int64_t)split * p.k_per_split;
     const int64_t k_end = min(p.K, k_begin + (int64_t)p.k_per_split);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, l32 = lane & 31;
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
-
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -221,16 +223,29 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmArgs p) {
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nkt;
+#ifndef MSN_ABL_NOFETCH
         if (more) fetch_step(kt + 1);   // prefetch the next K-step into registers while this one is multiplied
+#endif
         const float* as = a_buf(cur);
         const float* bs = b_buf(cur);
+#ifdef MSN_ABL_NOFRAG
+        float4 fa[TM], fb[TN];
+        if (kt == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = TA::frag(as, wm0 + 32 * i + l32, 0, h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = TB::frag(bs, wn0 + 32 * j + l32, 0, h);
+        }
+#endif
 #pragma unroll
         for (int ko = 0; ko < BK / 8; ++ko) {
+#ifndef MSN_ABL_NOFRAG
             float4 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[i] = TA::frag(as, wm0 + 32 * i + l32, ko, h);
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[j] = TB::frag(bs, wn0 + 32 * j + l32, ko, h);
+#endif
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -241,8 +256,12 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmArgs p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
                 }
         }
+#ifndef MSN_ABL_NOSTASH
         if (more) stash_step(kt + 1, cur ^ 1);
+#endif
+#ifndef MSN_ABL_NOBAR
         __syncthreads();
+#endif
     }
 
     gemm_epilogue<TM, TN>(acc, p, m0, n0, wm0, wn0, l32, h, split);
@@ -289,17 +308,27 @@ struct DmaTile {
     // LDS-DMA write still in flight and would put s_waitcnt vmcnt(0) in front of every k-step's first read
     // (draining the whole ring); an asm read is invisible to that pass, so its completion is counted by hand
     // (lgkmcnt) in the kernel.  `tile_addr` = LDS byte address of the image.
-    static constexpr int kReads = KMAJOR ? 4 : 1;   // LDS instructions per fragment
-    __device__ static __forceinline__ void frag_issue(float4& f, unsigned tile_addr, int row, int ko, int h) {
-        if (KMAJOR) {
+    // A fragment = this lane's 4 consecutive k values of one row.  The asm outputs bind straight to the registers
+    // the MFMAs read (no copy may sit between the asynchronous read and the hand-placed s_waitcnt).
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    struct FragKM { f32x2 lo, hi; };
+    struct FragKC { float4 v; };
+    using Frag = std::conditional_t<KMAJOR, FragKM, FragKC>;
+    template <int C>
+    __device__ static __forceinline__ float get(const Frag& f) {
+        if constexpr (KMAJOR) return C == 0 ? f.lo.x : C == 1 ? f.lo.y : C == 2 ? f.hi.x : f.hi.y;
+        else return C == 0 ? f.v.x : C == 1 ? f.v.y : C == 2 ? f.v.z : f.v.w;
+    }
+    static constexpr int kReads = KMAJOR ? 2 : 1;   // LDS instructions per fragment
+    __device__ static __forceinline__ void frag_issue(Frag& f, unsigned tile_addr, int row, int ko, int h) {
+        if constexpr (KMAJOR) {   // k, k+1 | k+2, k+3 of this lane half: two ds_read2_b32 (dword offsets 0, ROWS)
+            static_assert(ROWS <= 255, "ds_read2_b32 offset1 is 8 bits (dwords)");
             const unsigned a = tile_addr + 4u * ((8 * ko + 4 * h) * ROWS + row);
-            asm volatile("ds_read_b32 %0, %1" : "=v"(f.x) : "v"(a));
-            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.y) : "v"(a), "n"(4 * ROWS));
-            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.z) : "v"(a), "n"(8 * ROWS));
-            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.w) : "v"(a), "n"(12 * ROWS));
+            asm volatile("ds_read2_b32 %0, %1 offset1:%2" : "=v"(f.lo) : "v"(a), "n"(ROWS));
+            asm volatile("ds_read2_b32 %0, %1 offset1:%2" : "=v"(f.hi) : "v"(a + 8u * ROWS), "n"(ROWS));
         } else {
             const unsigned a = tile_addr + 4u * (row * DBK + 4 * ((2 * ko + h) ^ (row % CPR)));
-            asm volatile("ds_read_b128 %0, %1" : "=v"(f) : "v"(a));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(f.v) : "v"(a));
         }
     }
 };
@@ -320,9 +349,12 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void sgemm_dma_kernel(c
     const unsigned smem_addr = (unsigned)(uintptr_t)(lptr_t*)smem;   // LDS byte address of the ring
 
     const int nwg = p.tiles_m * p.tiles_n;
-    const int logical = xcd_remap(blockIdx.x, nwg);
+    // one flat grid over (split, tile): XCD x owns a contiguous run of it, so the tiles of one K-slab -- which
+    // re-read the same operand rows -- share that XCD's L2 instead of being dealt round-robin over all eight
+    const int flat = xcd_remap(blockIdx.x, nwg * p.splits);
+    const int logical = flat % nwg;
     const int64_t m0 = (int64_t)(logical / p.tiles_n) * BM, n0 = (int64_t)(logical % p.tiles_n) * BN;
-    const int split = blockIdx.y;
+    const int split = flat / nwg;
     const int64_t k_begin = (int64_t)split * p.k_per_split;
     const int64_t k_end = min(p.K, k_begin + (int64_t)p.k_per_split);
     const int nkt = (int)((k_end - k_begin) / DBK);
@@ -377,7 +409,8 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void sgemm_dma_kernel(c
         const unsigned bs = as + 4u * TA::kFloats;
         // fragments of k-octet ko + 1 are requested before the MFMAs of ko; the counted wait retires exactly the
         // reads of ko (LDS returns in order) and leaves the younger ones in flight
-        float4 fa[2][TM], fb[2][TN];
+        typename TA::Frag fa[2][TM];
+        typename TB::Frag fb[2][TN];
         auto request = [&](auto set, int ko) {
             constexpr int S = decltype(set)::value;
 #pragma unroll
@@ -394,10 +427,10 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void sgemm_dma_kernel(c
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S][i].x, fb[S][j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S][i].y, fb[S][j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S][i].z, fb[S][j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S][i].w, fb[S][j].w, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(TA::template get<0>(fa[S][i]), TB::template get<0>(fb[S][j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(TA::template get<1>(fa[S][i]), TB::template get<1>(fb[S][j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(TA::template get<2>(fa[S][i]), TB::template get<2>(fb[S][j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(TA::template get<3>(fa[S][i]), TB::template get<3>(fb[S][j]), acc[i][j], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -479,7 +512,7 @@ static int colsum_blocks(int64_t M) { return (int)std::min<int64_t>(cdiv(M, 16 *
 
 template <int BM, int BN, int WM, int WN, int DBK, int STAGES>
 static int launch_dma(const GemmArgs& a, int opA, int opB, hipStream_t st) {
-    const dim3 grid(a.tiles_m * a.tiles_n, a.splits), block(64 * (BM / WM) * (BN / WN));
+    const dim3 grid(a.tiles_m * a.tiles_n * a.splits), block(64 * (BM / WM) * (BN / WN));
     if (opA == MSN_OP_N && opB == MSN_OP_T) hipLaunchKernelGGL((sgemm_dma_kernel<BM, BN, WM, WN, false, false, DBK, STAGES>), grid, block, 0, st, a);
     else if (opA == MSN_OP_N && opB == MSN_OP_N) hipLaunchKernelGGL((sgemm_dma_kernel<BM, BN, WM, WN, false, true, DBK, STAGES>), grid, block, 0, st, a);
     else if (opA == MSN_OP_T && opB == MSN_OP_N) hipLaunchKernelGGL((sgemm_dma_kernel<BM, BN, WM, WN, true, true, DBK, STAGES>), grid, block, 0, st, a);
@@ -492,7 +525,7 @@ static int g_gemm_variant = 0;   // 0 = register-staged kernels, 1 = LDS-DMA rin
 
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const GemmArgs& a, int opA, int opB, hipStream_t st) {
-    const dim3 grid(a.tiles_m * a.tiles_n, a.splits), block(256);
+    const dim3 grid(a.tiles_m * a.tiles_n * a.splits), block(256);
     // 16-byte operand loads need: base aligned, ld % 4 == 0, contiguous extent % 4 == 0 (K for a
     // K-contiguous operand, M / N for a K-major one)
     const int64_t a_ext = opA == MSN_OP_T ? a.M : a.K, b_ext = opB == MSN_OP_N ? a.N : a.K;
@@ -513,8 +546,10 @@ static int launch_cfg(const GemmArgs& a, int opA, int opB, hipStream_t st) {
     return MSN_OK;
 }
 
-// Tile shape by N; split-K count so that a reduction-heavy product (wgrad: small M x N, huge K)
-// still fills the 256 CUs.
+// Tile shape by N; split-K count so that a reduction-heavy product (wgrad: small M x N, huge K) fills the chip.
+// The chip holds 512 workgroups at a time (256 CUs x 2); equal-length workgroups run in rounds, so the split count
+// is the one whose tiles x splits comes closest under a whole number of rounds (36 tiles: 14 splits = 504
+// workgroups in one round, where 21 splits = 756 would leave half the chip idle in the second).
 static void plan(int64_t M, int64_t N, int64_t K, int opA, int* bm, int* bn, int* splits, int* kps) {
     *bm = 128;
     *bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
@@ -522,8 +557,13 @@ static void plan(int64_t M, int64_t N, int64_t K, int opA, int* bm, int* bn, int
     int s = 1;
     if (opA == MSN_OP_T && tiles < 512) {
         const int64_t ksteps = cdiv(K, BK);
-        s = (int)std::min<int64_t>(std::min<int64_t>(cdiv(768, tiles), ksteps / 4 > 0 ? ksteps / 4 : 1), 256);
-        if (s < 1) s = 1;
+        const int64_t smax = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(ksteps / 4, 512), 1024 / tiles));
+        double best = 0.0;
+        for (int64_t c = 1; c <= smax; ++c) {
+            const int64_t wg = tiles * c, rounds = cdiv(wg, 512);
+            const double fill = (double)wg / (double)(rounds * 512);
+            if (fill > best + 1e-9) best = fill, s = (int)c;
+        }
     }
     int64_t per = cdiv(cdiv(K, s), BK) * BK;
     if (per < BK) per = BK;
@@ -582,7 +622,7 @@ extern "C" int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, cons
         MSN_REQUIRE(ws && ws_bytes >= need, "msn_sgemm: workspace %zu < %zu bytes", ws_bytes, need);
         a.partial = static_cast<float*>(ws);
     }
-    MSN_REQUIRE((int64_t)a.tiles_m * a.tiles_n < (1ll << 31), "msn_sgemm: too many tiles");
+    MSN_REQUIRE((int64_t)a.tiles_m * a.tiles_n * a.splits < (1ll << 31), "msn_sgemm: too many tiles");
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc;
     // bf16 matrix-core paths need 16-byte loads on the K-contiguous operands; otherwise stay on fp32
@@ -599,6 +639,7 @@ extern "C" int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, cons
     if (bf16_ok) rc = launch_bgemm(a, opA, opB, precision == MSN_PREC_BF16X3 ? 2 : 1, bm, bn, st);
     else if (dma_ok && bn == 128 && K % 64 == 0 && kps % 64 == 0 && g_gemm_variant == 2)
         rc = launch_dma<128, 128, 64, 32, 64, 2>(a, opA, opB, st);
+    else if (dma_ok && bn == 128 && g_gemm_variant == 3) rc = launch_dma<128, 128, 64, 64, 32, 2>(a, opA, opB, st);
     else if (dma_ok && bn == 128) rc = launch_dma<128, 128, 64, 32, 32, 3>(a, opA, opB, st);
     else if (dma_ok && bn == 64) rc = launch_dma<128, 64, 64, 32, 32, 3>(a, opA, opB, st);
     else if (bn == 128) rc = launch_cfg<128, 128, 64, 64>(a, opA, opB, st);
@@ -615,7 +656,7 @@ extern "C" int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, cons
 }
 
 extern "C" int msn_set_gemm_variant(int mode) {
-    MSN_REQUIRE(mode >= 0 && mode <= 2, "msn_set_gemm_variant: mode must be 0 (register-staged), 1 or 2 (LDS-DMA rings)");
+    MSN_REQUIRE(mode >= 0 && mode <= 3, "msn_set_gemm_variant: mode must be 0 (register-staged), 1 or 2 (LDS-DMA rings)");
     g_gemm_variant = mode;
     return MSN_OK;
 }

@@ -66,7 +66,7 @@ def test_sgemm_variants_bit_identical(M, N, K, op_a, op_b):
     epi = ops.EPI_GELU if op_a == 0 else ops.EPI_NONE
     try:
         outs = []
-        for v in (0, 1, 2):
+        for v in (0, 1, 2, 3):
             ops.set_gemm_variant(v)
             outs.append(ops.sgemm(a, b, op_a, op_b, bias=bias, epilogue=epi))
     finally:
@@ -75,7 +75,7 @@ def test_sgemm_variants_bit_identical(M, N, K, op_a, op_b):
     if bias is not None:
         ref = torch.nn.functional.gelu(ref + bias.double())
     torch.testing.assert_close(outs[0].double(), ref, rtol=1e-4, atol=1e-4 * K ** 0.5)
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
 def test_sgemm_asymmetric_identity():

@@ -28,6 +28,8 @@ shapes = [  # (M, N, K, opA, opB, tag)
     (4096, 4096, 4096, 0, 1, "4096^3 NT"), (4096, 4096, 4096, 0, 0, "4096^3 NN"), (4096, 4096, 4096, 1, 0, "4096^3 TN"),
 ]
 precs = [int(v) for v in sys.argv[1:]] or [0]
+if os.environ.get("MSN_GEMM_VARIANT"):
+    ops.set_gemm_variant(int(os.environ["MSN_GEMM_VARIANT"]))
 for prec in precs:
     print(f"--- precision {prec}")
     for M, N, K, oa, ob, tag in shapes:

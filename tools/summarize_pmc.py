@@ -20,12 +20,14 @@ def load(root, name):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
             k = k.replace("void ", "")
-            if "sgemm_kernel" in k:
-                k = "msn::sgemm_kernel<*>"
-            e = d[k][r["Counter_Name"]]
-            e[0] += 1
-            e[1] += float(r["Counter_Value"])
-            e[2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            keys = [k]
+            if "sgemm_kernel" in k:      # per template instance (layout = the two bools) and the aggregate row
+                keys.append("msn::sgemm_kernel<*>")
+            for k in keys:
+                e = d[k][r["Counter_Name"]]
+                e[0] += 1
+                e[1] += float(r["Counter_Value"])
+                e[2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     return d
 
 
@@ -35,7 +37,7 @@ def main():
     lines = ["kernel | launches | fetch GB (2 x FETCH_SIZE) | write GB | MB / launch | MFMA busy / (SIMD-cycles) | eff. clock GHz"]
     names = sorted(fs, key=lambda k: -fs[k]["FETCH_SIZE"][1])
     summary = {}
-    for k in names[:25]:
+    for k in names[:32]:
         n, f, _ = fs[k]["FETCH_SIZE"]
         w = ws[k]["WRITE_SIZE"][1] if k in ws else 0.0
         fetch_b, write_b = 2 * f * 1024, w * 1024
