@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 LC = dict(n_out=32, emb=64, heads=8, depth=5, dropout=0.0, time_norm=20583.369161312577, agg="mean")
 CONV_PLACEHOLDER = dict(dim=8, depth=1, channels=3, kernel_size=5, patch_size=8, n_out=32, dropout_prob=0.0)
 IMG, T_LC, NBAND, ENC_DIM, N_OUT = 64, 200, 2, 128, 32
-GEMM_KERNEL_NAME = {"f32": "msn::sgemm_kernel (fp32 v_mfma_f32_32x32x2_f32)",
+GEMM_KERNEL_NAME = {"f32": "msn::sgemm_dma_kernel + msn::sgemm_kernel (fp32 v_mfma_f32_32x32x2_f32; all msn_sgemm launches)",
                     "bf16x3": "msn::bgemm_kernel<planes=2> (3 x v_mfma_f32_32x32x16_bf16 per algorithmic MAC tile)",
                     "bf16": "msn::bgemm_kernel<planes=1> (v_mfma_f32_32x32x16_bf16)"}
 LR, WD, LOGIT_SCALE = 3.716367614864064e-05, 0.000555522900788888, 19.545966923442453  # maven_pretrain_config.yaml
@@ -187,8 +187,8 @@ def main():
     ap.add_argument("--workload", default="vit_s8_lc", choices=list(WORKLOADS),
                     help="vit_s8_lc = the headline (default); the others are the remaining BASELINE.json configurations")
     ap.add_argument("--gemm-table", action="store_true", help="per-shape GEMM timing of one step on stderr")
-    ap.add_argument("--gemm-variant", type=int, default=0, choices=[0, 1, 2, 3],
-                    help="fp32 GEMM kernel family: 0 register-staged (default), 1 / 2 LDS-DMA rings")
+    ap.add_argument("--gemm-variant", type=int, default=3, choices=[0, 1, 2, 3],
+                    help="fp32 GEMM kernel family: 0 register-staged, 1 / 2 / 3 LDS-DMA rings (3 = default)")
     ap.add_argument("--gemm-precision", default="f32", choices=["f32", "bf16x3", "bf16"],
                     help="inner-product precision of the GEMMs (bf16x3 = split-bf16, fp32-grade accuracy)")
     ap.add_argument("--cpu-sample-batch", type=int, default=32)

@@ -75,12 +75,19 @@ int msn_device_count(void);
 #define MSN_PREC_BF16 2
 
 size_t msn_sgemm_workspace_bytes(int opA, int opB, int64_t M, int64_t N, int64_t K);
-/* Two fp32 kernel families sit behind msn_sgemm.  mode 0 (default): register-staged global->LDS copies
- * with a distance-1 prefetch; takes every shape.  mode 1 / 2: LDS-DMA pipeline (global_load_lds) with a
- * 3 x 32-deep / 2 x 64-deep K ring, used where it applies (N > 32, 16-B aligned operands, K % 32 / 64 == 0)
- * and falling back to mode 0 elsewhere.  All modes give bit-identical results (same k order per
- * accumulator).  Process-wide; the measured difference is within run-to-run noise. */
+/* Two fp32 kernel families sit behind msn_sgemm.
+ *   mode 0: register-staged global->LDS copies with a distance-1 prefetch; takes every shape.
+ *   mode 3 (default): LDS-DMA pipeline (global_load_lds, no staging registers, no ds_write), 4 waves per
+ *           workgroup, 2 x 32-deep K ring, two workgroups per CU.  Used where it applies (N > 32, 16-B aligned
+ *           operands, K % 32 == 0); other shapes take mode 0.
+ *   mode 1 / 2: LDS-DMA with 8 waves per workgroup and a 3 x 32 / 2 x 64 deep ring (one workgroup per CU).
+ * All modes give bit-identical results (same k order per accumulator).  Process-wide. */
 int msn_set_gemm_variant(int mode);
+/* Tail split (default on): a product whose 128 x 128 tiles do not fill a whole number of rounds of the chip's
+ * 512 resident workgroups has the tiles of the last, partly filled round cut into K-slabs (summed in slab order
+ * by a finishing pass that applies the epilogue); msn_sgemm_workspace_bytes covers the slabs.  Results of the
+ * tail tiles then differ from the unsplit order in the last bits.  Process-wide. */
+int msn_set_gemm_tail_split(int enabled);
 int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
               const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int epilogue,
               float* aux, int64_t ldaux, int precision, void* ws, size_t ws_bytes, msn_stream_t stream);

@@ -160,16 +160,12 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmArgs p) {
     auto a_buf = [&](int i) { return smem + i * TA::kFloats; };
     auto b_buf = [&](int i) { return smem + 2 * TA::kFloats + i * TB::kFloats; };
 
-    const int nwg = p.tiles_m * p.tiles_n;
-    // one flat grid over (split, tile): XCD x owns a contiguous run of it, so the tiles of one K-slab -- which
-    // re-read the same operand rows -- share that XCD's L2 instead of being dealt round-robin over all eight
-    const int flat = xcd_remap(blockIdx.x, nwg * p.splits);
-    const int logical = flat % nwg;
+    const TileCoord tc = locate_tile(p);
+    const int logical = tc.logical;
     const int tile_m = logical / p.tiles_n, tile_n = logical % p.tiles_n;
     const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
-    const int split = flat / nwg;
-    const int64_t k_begin = (int64_t)split * p.k_per_split;
-    const int64_t k_end = min(p.K, k_begin + (int64_t)p.k_per_split);
+    const int split = tc.split;
+    const int64_t k_begin = tc.k_begin, k_end = tc.k_end;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, l32 = lane & 31;
@@ -264,7 +260,8 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmArgs p) {
 #endif
     }
 
-    gemm_epilogue<TM, TN>(acc, p, m0, n0, wm0, wn0, l32, h, split);
+    if (tc.tail_slab >= 0) dump_tail<TM, TN>(acc, p, tc.tail_slab, wave, 4, lane);
+    else gemm_epilogue<TM, TN>(acc, p, m0, n0, wm0, wn0, l32, h, split);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -348,15 +345,11 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void sgemm_dma_kernel(c
     __shared__ __attribute__((aligned(16))) float smem[STAGES * STAGE];
     const unsigned smem_addr = (unsigned)(uintptr_t)(lptr_t*)smem;   // LDS byte address of the ring
 
-    const int nwg = p.tiles_m * p.tiles_n;
-    // one flat grid over (split, tile): XCD x owns a contiguous run of it, so the tiles of one K-slab -- which
-    // re-read the same operand rows -- share that XCD's L2 instead of being dealt round-robin over all eight
-    const int flat = xcd_remap(blockIdx.x, nwg * p.splits);
-    const int logical = flat % nwg;
+    const TileCoord tc = locate_tile(p);
+    const int logical = tc.logical;
     const int64_t m0 = (int64_t)(logical / p.tiles_n) * BM, n0 = (int64_t)(logical % p.tiles_n) * BN;
-    const int split = flat / nwg;
-    const int64_t k_begin = (int64_t)split * p.k_per_split;
-    const int64_t k_end = min(p.K, k_begin + (int64_t)p.k_per_split);
+    const int split = tc.split;
+    const int64_t k_begin = tc.k_begin, k_end = tc.k_end;
     const int nkt = (int)((k_end - k_begin) / DBK);
 
     const int lane = threadIdx.x & 63;
@@ -449,7 +442,47 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void sgemm_dma_kernel(c
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
-    gemm_epilogue<TM, TN>(acc, p, m0, n0, wm0, wn0, l32, h, split);
+    if (tc.tail_slab >= 0) dump_tail<TM, TN>(acc, p, tc.tail_slab, wave, NWAVES, lane);
+    else gemm_epilogue<TM, TN>(acc, p, m0, n0, wm0, wn0, l32, h, split);
+}
+
+// Sum of the K-slabs of one tail tile (slab order: deterministic) + the epilogue; same wave / register layout as
+// the kernel that wrote the slabs.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void tail_finish_kernel(const GemmArgs p) {
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN, NWAVES = (BM / WM) * (BN / WN);
+    const int logical = p.tiles_m * p.tiles_n - p.tail_tiles + (int)blockIdx.x;
+    const int64_t m0 = (int64_t)(logical / p.tiles_n) * BM, n0 = (int64_t)(logical % p.tiles_n) * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, l32 = lane & 31;
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int s = 0; s < p.tail_splits; ++s) {
+        const float* base = p.tail_partial +
+                            (((int64_t)blockIdx.x * p.tail_splits + s) * NWAVES + wave) * (TM * TN * 16 * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += base[((i * TN + j) * 16 + r) * 64];
+    }
+    gemm_epilogue<TM, TN>(acc, p, m0, n0, wm0, wn0, l32, h, 0);
+}
+
+int launch_tail_finish(const GemmArgs& a, int bn, int waves, hipStream_t st) {
+    const dim3 grid(a.tail_tiles);
+    if (bn == 128 && waves == 8) hipLaunchKernelGGL((tail_finish_kernel<128, 128, 64, 32>), grid, dim3(512), 0, st, a);
+    else if (bn == 128) hipLaunchKernelGGL((tail_finish_kernel<128, 128, 64, 64>), grid, dim3(256), 0, st, a);
+    else return MSN_OK;   // tails are only planned for 128 x 128 tiles
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
 }
 
 // C[m][n] = sum_s partial[s][m][n]   (split-K finish; fixed order -> deterministic).  A block covers 64
@@ -512,7 +545,7 @@ static int colsum_blocks(int64_t M) { return (int)std::min<int64_t>(cdiv(M, 16 *
 
 template <int BM, int BN, int WM, int WN, int DBK, int STAGES>
 static int launch_dma(const GemmArgs& a, int opA, int opB, hipStream_t st) {
-    const dim3 grid(a.tiles_m * a.tiles_n * a.splits), block(64 * (BM / WM) * (BN / WN));
+    const dim3 grid(gemm_grid(a)), block(64 * (BM / WM) * (BN / WN));
     if (opA == MSN_OP_N && opB == MSN_OP_T) hipLaunchKernelGGL((sgemm_dma_kernel<BM, BN, WM, WN, false, false, DBK, STAGES>), grid, block, 0, st, a);
     else if (opA == MSN_OP_N && opB == MSN_OP_N) hipLaunchKernelGGL((sgemm_dma_kernel<BM, BN, WM, WN, false, true, DBK, STAGES>), grid, block, 0, st, a);
     else if (opA == MSN_OP_T && opB == MSN_OP_N) hipLaunchKernelGGL((sgemm_dma_kernel<BM, BN, WM, WN, true, true, DBK, STAGES>), grid, block, 0, st, a);
@@ -521,11 +554,12 @@ static int launch_dma(const GemmArgs& a, int opA, int opB, hipStream_t st) {
     return MSN_OK;
 }
 
-static int g_gemm_variant = 0;   // 0 = register-staged kernels, 1 = LDS-DMA ring 3 x BK 32, 2 = LDS-DMA ring 2 x BK 64
+static int g_gemm_variant = 3;   // 0 = register-staged kernels; LDS-DMA: 1 = 8 waves, ring 3 x BK 32; 2 = 8 waves, ring 2 x BK 64;
+                                 // 3 (default) = 4 waves, ring 2 x BK 32, two workgroups per CU
 
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const GemmArgs& a, int opA, int opB, hipStream_t st) {
-    const dim3 grid(a.tiles_m * a.tiles_n * a.splits), block(256);
+    const dim3 grid(gemm_grid(a)), block(256);
     // 16-byte operand loads need: base aligned, ld % 4 == 0, contiguous extent % 4 == 0 (K for a
     // K-contiguous operand, M / N for a K-major one)
     const int64_t a_ext = opA == MSN_OP_T ? a.M : a.K, b_ext = opB == MSN_OP_N ? a.N : a.K;
@@ -546,17 +580,33 @@ static int launch_cfg(const GemmArgs& a, int opA, int opB, hipStream_t st) {
     return MSN_OK;
 }
 
-// Tile shape by N; split-K count so that a reduction-heavy product (wgrad: small M x N, huge K) fills the chip.
-// The chip holds 512 workgroups at a time (256 CUs x 2); equal-length workgroups run in rounds, so the split count
-// is the one whose tiles x splits comes closest under a whole number of rounds (36 tiles: 14 splits = 504
-// workgroups in one round, where 21 splits = 756 would leave half the chip idle in the second).
-static void plan(int64_t M, int64_t N, int64_t K, int opA, int* bm, int* bn, int* splits, int* kps) {
-    *bm = 128;
-    *bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
-    const int64_t tiles = cdiv(M, *bm) * cdiv(N, *bn);
+static int g_gemm_tail = 1;      // cut the partly filled last round of tiles into K-slabs (msn_set_gemm_tail_split)
+
+// Launch geometry of one product.
+//  * tile shape by N;
+//  * split-K (opA = T, i.e. wgrad: small M x N, huge K): the chip holds 512 workgroups at a time (256 CUs x 2) and
+//    equal-length workgroups run in rounds, so the split count is the one whose tiles x splits comes closest under a
+//    whole number of rounds (36 tiles: 14 splits = 504 workgroups in one round, where 21 splits = 756 would leave
+//    half the chip idle in the second);
+//  * tail: without split-K, the tiles % 512 tiles of the last, partly filled round are cut into K-slabs
+//    (1560 tiles = 3 rounds + 24 tiles: those 24 would occupy 24 CUs for a whole fourth round).
+struct Plan {
+    int bm, bn, splits, kps, tail_tiles, tail_splits, tail_kps;
+    size_t ws_bytes(int64_t M, int64_t N) const {
+        if (splits > 1) return sizeof(float) * (size_t)splits * (size_t)M * (size_t)N;
+        return sizeof(float) * (size_t)tail_tiles * (size_t)tail_splits * (size_t)bm * (size_t)bn;
+    }
+};
+
+static Plan plan(int64_t M, int64_t N, int64_t K, int opA) {
+    Plan p;
+    p.bm = 128;
+    p.bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
+    p.tail_tiles = 0, p.tail_splits = 1, p.tail_kps = 0;
+    const int64_t tiles = cdiv(M, p.bm) * cdiv(N, p.bn);
+    const int64_t ksteps = cdiv(K, BK);
     int s = 1;
     if (opA == MSN_OP_T && tiles < 512) {
-        const int64_t ksteps = cdiv(K, BK);
         const int64_t smax = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(ksteps / 4, 512), 1024 / tiles));
         double best = 0.0;
         for (int64_t c = 1; c <= smax; ++c) {
@@ -569,9 +619,31 @@ static void plan(int64_t M, int64_t N, int64_t K, int opA, int* bm, int* bn, int
     if (per < BK) per = BK;
     s = (int)cdiv(K, per);
     if (s < 1) s = 1;
-    *splits = s;
-    *kps = (int)per;
+    p.splits = s;
+    p.kps = (int)per;
+    const int64_t r = tiles % 512;
+    if (g_gemm_tail && s == 1 && p.bn == 128 && r > 0 && tiles >= 128 && tiles < (1ll << 30)) {
+        // time of the last round in units of one whole tile: ceil(r c / 512) rounds of 1 / c tile each (+ a small
+        // charge per slab for its prologue, the slab store and the finishing pass)
+        const int64_t cmax = std::min<int64_t>(std::min<int64_t>(ksteps / 4, 16), 1024 / r);
+        double best = 1.0;
+        int c_best = 1;
+        for (int64_t c = 2; c <= cmax; ++c) {
+            const double t = (double)cdiv(r * c, 512) / (double)c + 0.02 * (double)c;
+            if (t < best - 1e-9) best = t, c_best = (int)c;
+        }
+        if (c_best > 1 && best <= 0.85) {
+            const int64_t tper = cdiv(cdiv(K, c_best), 2 * BK) * 2 * BK;   // whole K-steps of every kernel family
+            p.tail_tiles = (int)r;
+            p.tail_kps = (int)tper;
+            p.tail_splits = (int)cdiv(K, tper);
+            if (p.tail_splits < 2) p.tail_tiles = 0, p.tail_splits = 1;
+        }
+    }
+    return p;
 }
+
+int launch_tail_finish(const GemmArgs& a, int bn, int waves, hipStream_t st);
 
 }  // namespace msn
 
@@ -580,9 +652,7 @@ using namespace msn;
 extern "C" size_t msn_sgemm_workspace_bytes(int opA, int opB, int64_t M, int64_t N, int64_t K) {
     (void)opB;
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    int bm, bn, splits, kps;
-    plan(M, N, K, opA, &bm, &bn, &splits, &kps);
-    return splits > 1 ? sizeof(float) * (size_t)splits * (size_t)M * (size_t)N : 0;
+    return plan(M, N, K, opA).ws_bytes(M, N);
 }
 
 extern "C" int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
@@ -608,13 +678,20 @@ extern "C" int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, cons
     a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
     a.epilogue = epilogue;
-    int bm, bn, splits, kps;
-    plan(M, N, K, opA, &bm, &bn, &splits, &kps);
+    const Plan pl = plan(M, N, K, opA);
+    const int bm = pl.bm, bn = pl.bn, splits = pl.splits, kps = pl.kps;
     a.tiles_m = (int)cdiv(M, bm);
     a.tiles_n = (int)cdiv(N, bn);
     a.splits = splits;
     a.k_per_split = kps;
     a.partial = nullptr;
+    a.tail_tiles = pl.tail_tiles, a.tail_splits = pl.tail_splits, a.tail_kps = pl.tail_kps;
+    a.tail_partial = nullptr;
+    if (a.tail_tiles > 0) {
+        const size_t need = pl.ws_bytes(M, N);
+        MSN_REQUIRE(ws && ws_bytes >= need, "msn_sgemm: workspace %zu < %zu bytes", ws_bytes, need);
+        a.tail_partial = static_cast<float*>(ws);
+    }
     if (splits > 1) {
         MSN_REQUIRE(epilogue == MSN_EPI_NONE && bias == nullptr,
                     "msn_sgemm: split-K (opA=T) supports only the plain epilogue without bias");
@@ -622,7 +699,8 @@ extern "C" int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, cons
         MSN_REQUIRE(ws && ws_bytes >= need, "msn_sgemm: workspace %zu < %zu bytes", ws_bytes, need);
         a.partial = static_cast<float*>(ws);
     }
-    MSN_REQUIRE((int64_t)a.tiles_m * a.tiles_n * a.splits < (1ll << 31), "msn_sgemm: too many tiles");
+    MSN_REQUIRE((int64_t)a.tiles_m * a.tiles_n * a.splits + (int64_t)a.tail_tiles * a.tail_splits < (1ll << 31),
+                "msn_sgemm: too many tiles");
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc;
     // bf16 matrix-core paths need 16-byte loads on the K-contiguous operands; otherwise stay on fp32
@@ -636,16 +714,21 @@ extern "C" int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, cons
     const bool dma_ok = g_gemm_variant != 0 && bn >= 64 && K % BK == 0 && kps % BK == 0 && (lda % 4 == 0) && (ldb % 4 == 0) &&
                         (a_ext % 4 == 0) && (b_ext % 4 == 0) && a_ext >= 4 && b_ext >= 4 &&
                         ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
+    int waves = 4;   // per workgroup of the kernel chosen (the tail pass mirrors its register layout)
     if (bf16_ok) rc = launch_bgemm(a, opA, opB, precision == MSN_PREC_BF16X3 ? 2 : 1, bm, bn, st);
     else if (dma_ok && bn == 128 && K % 64 == 0 && kps % 64 == 0 && g_gemm_variant == 2)
-        rc = launch_dma<128, 128, 64, 32, 64, 2>(a, opA, opB, st);
+        rc = launch_dma<128, 128, 64, 32, 64, 2>(a, opA, opB, st), waves = 8;
     else if (dma_ok && bn == 128 && g_gemm_variant == 3) rc = launch_dma<128, 128, 64, 64, 32, 2>(a, opA, opB, st);
-    else if (dma_ok && bn == 128) rc = launch_dma<128, 128, 64, 32, 32, 3>(a, opA, opB, st);
+    else if (dma_ok && bn == 128) rc = launch_dma<128, 128, 64, 32, 32, 3>(a, opA, opB, st), waves = 8;
     else if (dma_ok && bn == 64) rc = launch_dma<128, 64, 64, 32, 32, 3>(a, opA, opB, st);
     else if (bn == 128) rc = launch_cfg<128, 128, 64, 64>(a, opA, opB, st);
     else if (bn == 64) rc = launch_cfg<128, 64, 64, 32>(a, opA, opB, st);
     else rc = launch_cfg<128, 32, 32, 32>(a, opA, opB, st);
     if (rc != MSN_OK) return rc;
+    if (a.tail_tiles > 0) {
+        rc = launch_tail_finish(a, bn, waves, st);
+        if (rc != MSN_OK) return rc;
+    }
     if (splits > 1) {
         const int64_t total = M * N;
         const int blocks = (int)std::min<int64_t>(cdiv(total, 64), 4096);
@@ -655,8 +738,13 @@ extern "C" int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, cons
     return MSN_OK;
 }
 
+extern "C" int msn_set_gemm_tail_split(int enabled) {
+    g_gemm_tail = enabled ? 1 : 0;
+    return MSN_OK;
+}
+
 extern "C" int msn_set_gemm_variant(int mode) {
-    MSN_REQUIRE(mode >= 0 && mode <= 3, "msn_set_gemm_variant: mode must be 0 (register-staged), 1 or 2 (LDS-DMA rings)");
+    MSN_REQUIRE(mode >= 0 && mode <= 3, "msn_set_gemm_variant: mode must be 0 (register-staged) or 1..3 (LDS-DMA rings)");
     g_gemm_variant = mode;
     return MSN_OK;
 }

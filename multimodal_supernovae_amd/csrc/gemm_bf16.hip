@@ -135,16 +135,12 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const GemmArgs p) {
     auto a_buf = [&](int i) { return smem + i * TA::kElems; };
     auto b_buf = [&](int i) { return smem + 2 * TA::kElems + i * TB::kElems; };
 
-    const int nwg = p.tiles_m * p.tiles_n;
-    // one flat grid over (split, tile): XCD x owns a contiguous run of it, so the tiles of one K-slab -- which
-    // re-read the same operand rows -- share that XCD's L2 instead of being dealt round-robin over all eight
-    const int flat = xcd_remap(blockIdx.x, nwg * p.splits);
-    const int logical = flat % nwg;
+    const TileCoord tc = locate_tile(p);
+    const int logical = tc.logical;
     const int tile_m = logical / p.tiles_n, tile_n = logical % p.tiles_n;
     const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
-    const int split = flat / nwg;
-    const int64_t k_begin = (int64_t)split * p.k_per_split;
-    const int64_t k_end = min(p.K, k_begin + (int64_t)p.k_per_split);
+    const int split = tc.split;
+    const int64_t k_begin = tc.k_begin, k_end = tc.k_end;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, l32 = lane & 31;
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
 
@@ -212,12 +208,13 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const GemmArgs p) {
         }
         __syncthreads();
     }
-    gemm_epilogue<TM, TN>(acc, p, m0, n0, wm0, wn0, l32, h, split);
+    if (tc.tail_slab >= 0) dump_tail<TM, TN>(acc, p, tc.tail_slab, wave, 4, lane);
+    else gemm_epilogue<TM, TN>(acc, p, m0, n0, wm0, wn0, l32, h, split);
 }
 
 template <int BM, int BN, int WM, int WN, int PLANES>
 static int launch_b(const GemmArgs& a, int opA, int opB, hipStream_t st) {
-    const dim3 grid(a.tiles_m * a.tiles_n * a.splits), block(256);
+    const dim3 grid(gemm_grid(a)), block(256);
     if (opA == MSN_OP_N && opB == MSN_OP_T) hipLaunchKernelGGL((bgemm_kernel<BM, BN, WM, WN, false, false, PLANES>), grid, block, 0, st, a);
     else if (opA == MSN_OP_N && opB == MSN_OP_N) hipLaunchKernelGGL((bgemm_kernel<BM, BN, WM, WN, false, true, PLANES>), grid, block, 0, st, a);
     else if (opA == MSN_OP_T && opB == MSN_OP_N) hipLaunchKernelGGL((bgemm_kernel<BM, BN, WM, WN, true, true, PLANES>), grid, block, 0, st, a);

@@ -22,6 +22,11 @@ struct GemmArgs {
     int k_per_split;  // multiple of BK
     int splits;
     float* partial;   // [splits][M][N] when splits > 1
+    // The last `tail_tiles` tiles (those that would run as a partly filled final round of workgroups) are cut
+    // into `tail_splits` K-slabs of `tail_kps`; each slab's accumulators go to tail_partial in register order and
+    // tail_finish_kernel sums them in slab order and applies the epilogue.  0 tiles = no tail.
+    int tail_tiles, tail_splits, tail_kps;
+    float* tail_partial;   // [tail_tiles][tail_splits][BM * BN]
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -31,6 +36,48 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + bid / 8;
 }
 
+
+// Which tile and K range this workgroup owns.  Regular workgroups come first in one flat XCD-mapped run over
+// (split, tile): XCD x owns a contiguous piece of it, so the tiles of one K-slab -- which re-read the same operand
+// rows -- share that XCD's L2.  Tail workgroups follow (dispatched last, dealt round-robin over the XCDs).
+struct TileCoord {
+    int logical, split, tail_slab;   // tail_slab < 0: regular workgroup
+    int64_t k_begin, k_end;
+};
+__device__ __forceinline__ TileCoord locate_tile(const GemmArgs& p) {
+    const int nreg = p.tiles_m * p.tiles_n - p.tail_tiles;
+    const int regular = nreg * p.splits;
+    TileCoord c;
+    if ((int)blockIdx.x < regular) {
+        const int flat = xcd_remap(blockIdx.x, regular);
+        c.logical = flat % nreg;
+        c.split = flat / nreg;
+        c.tail_slab = -1;
+        c.k_begin = (int64_t)c.split * p.k_per_split;
+        c.k_end = min(p.K, c.k_begin + (int64_t)p.k_per_split);
+    } else {
+        const int t = (int)blockIdx.x - regular;
+        c.logical = nreg + t / p.tail_splits;
+        c.split = t % p.tail_splits;
+        c.tail_slab = t;
+        c.k_begin = (int64_t)c.split * p.tail_kps;
+        c.k_end = min(p.K, c.k_begin + (int64_t)p.tail_kps);
+    }
+    return c;
+}
+
+// Accumulators of one tail K-slab, in register order (every store instruction writes 256 contiguous bytes).
+template <int TM, int TN>
+__device__ __forceinline__ void dump_tail(const f32x16 (&acc)[TM][TN], const GemmArgs& p, int slab, int wave,
+                                          int nwaves, int lane) {
+    float* base = p.tail_partial + ((int64_t)slab * nwaves + wave) * (TM * TN * 16 * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) base[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
+}
 
 // Epilogue of a (TM x TN) grid of 32x32 accumulator tiles (C/D layout of every 32x32 MFMA on gfx950,
 // fp32 and bf16 alike: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h).  The aux operand of a tile
@@ -82,5 +129,9 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[TM][TN], const
 // operand split hi + lo and three products accumulated (fp32-grade accuracy).  Needs the vector-load
 // conditions of the VEC fp32 kernels; the caller falls back to the fp32 kernels otherwise.
 int launch_bgemm(const GemmArgs& a, int opA, int opB, int planes, int bm, int bn, hipStream_t st);
+
+inline unsigned gemm_grid(const GemmArgs& a) {
+    return (unsigned)((a.tiles_m * a.tiles_n - a.tail_tiles) * a.splits + a.tail_tiles * a.tail_splits);
+}
 
 }  // namespace msn

@@ -38,8 +38,13 @@ def set_gemm_precision(name):
     GEMM_PRECISION = _PREC_NAMES[name]
 
 def set_gemm_variant(mode):
-    """fp32 GEMM kernel family (msn_set_gemm_variant): 0 register-staged (default), 1 / 2 LDS-DMA rings."""
+    """fp32 GEMM kernel family (msn_set_gemm_variant): 0 register-staged, 1 / 2 / 3 LDS-DMA rings (3 = default)."""
     check(lib().msn_set_gemm_variant(int(mode)))
+
+
+def set_gemm_tail_split(enabled):
+    """Cut the partly filled last round of GEMM tiles into K-slabs (msn_set_gemm_tail_split); default on."""
+    check(lib().msn_set_gemm_tail_split(1 if enabled else 0))
 
 
 OP_N, OP_T = 0, 1

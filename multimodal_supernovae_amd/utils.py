@@ -36,4 +36,4 @@ def get_ROC_data(embs1, embs2):
 def get_AUC(embs1, embs2):
     """Area under that curve (ref src/utils.py:414-426)."""
     thresholds, fraction_correct = get_ROC_data(embs1, embs2)
-    return np.trapz(fraction_correct, thresholds) if hasattr(np, "trapz") else np.trapezoid(fraction_correct, thresholds)
+    return np.trapezoid(fraction_correct, thresholds) if hasattr(np, "trapezoid") else np.trapz(fraction_correct, thresholds)

@@ -118,4 +118,4 @@ def roc_data(embs1, embs2):
 def auc(embs1, embs2):
     import numpy as np
     t, f, _ = roc_data(embs1, embs2)
-    return np.trapz(f, t) if hasattr(np, "trapz") else np.trapezoid(f, t)
+    return np.trapezoid(f, t) if hasattr(np, "trapezoid") else np.trapz(f, t)

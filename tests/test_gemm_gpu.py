@@ -70,12 +70,51 @@ def test_sgemm_variants_bit_identical(M, N, K, op_a, op_b):
             ops.set_gemm_variant(v)
             outs.append(ops.sgemm(a, b, op_a, op_b, bias=bias, epilogue=epi))
     finally:
-        ops.set_gemm_variant(0)
+        ops.set_gemm_variant(3)
     ref = _ref(a, b, op_a, op_b)
     if bias is not None:
         ref = torch.nn.functional.gelu(ref + bias.double())
     torch.testing.assert_close(outs[0].double(), ref, rtol=1e-4, atol=1e-4 * K ** 0.5)
     assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+@pytest.mark.parametrize("M,N,K,op_a,op_b", [(4096, 512, 256, 0, 1), (4100, 500, 300, 0, 0), (66560, 384, 384, 0, 1),
+                                              (2048, 1024, 512, 1, 1), (33280, 384, 1536, 0, 0)])
+@pytest.mark.parametrize("epi", ["none", "gelu", "add", "relu_bwd"])
+@pytest.mark.parametrize("variant,precision", [(0, 0), (1, 0), (2, 0), (3, 0), (0, 1), (0, 2)])
+def test_sgemm_tail_split(M, N, K, op_a, op_b, epi, variant, precision):
+    """Tiles of the partly filled last round run as K-slabs + a finishing pass (msn_set_gemm_tail_split): same
+    result as the unsplit launch up to summation order, through every epilogue, layout, kernel family, precision."""
+    from multimodal_supernovae_amd import ops, _lib
+    if epi != "none" and (M > 20000 or variant in (1, 2) or op_a == 1):
+        pytest.skip("epilogues are covered on the smaller opA = N shapes / default families")
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn((M, K) if op_a == 0 else (K, M), generator=g).cuda()
+    b = torch.randn((K, N) if op_b == 0 else (N, K), generator=g).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    aux_in = torch.randn(M, N, generator=g).cuda()
+    kw = {"none": dict(), "gelu": dict(bias=bias, epilogue=ops.EPI_GELU, aux=torch.empty(M, N, device="cuda")),
+          "add": dict(bias=bias, epilogue=ops.EPI_ADD, aux=aux_in), "relu_bwd": dict(epilogue=ops.EPI_RELU_BWD, aux=aux_in)}[epi]
+    if op_a == 0:
+        assert _lib.lib().msn_sgemm_workspace_bytes(op_a, op_b, M, N, K) > 0  # the plan cuts a tail for these shapes
+    outs, auxs = [], []
+    try:
+        ops.set_gemm_variant(variant)
+        for tail in (True, False):
+            ops.set_gemm_tail_split(tail)
+            if epi == "gelu":
+                kw["aux"] = torch.empty(M, N, device="cuda")
+            outs.append(ops.sgemm(a, b, op_a, op_b, precision=precision, **kw))
+            auxs.append(kw.get("aux"))
+    finally:
+        ops.set_gemm_variant(3)
+        ops.set_gemm_tail_split(True)
+    tol = dict(rtol=1e-4, atol=1e-4 * K ** 0.5) if precision < 2 else dict(rtol=2e-2, atol=3e-2 * K ** 0.5)
+    torch.testing.assert_close(outs[0], outs[1], **tol)
+    if epi == "gelu":
+        torch.testing.assert_close(auxs[0], auxs[1], **tol)
+    if epi == "none":
+        torch.testing.assert_close(outs[0].double(), _ref(a, b, op_a, op_b), **tol)
 
 
 def test_sgemm_asymmetric_identity():

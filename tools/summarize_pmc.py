@@ -21,7 +21,7 @@ def load(root, name):
             k = r["Kernel_Name"].split("(")[0]
             k = k.replace("void ", "")
             keys = [k]
-            if "sgemm_kernel" in k:      # per template instance (layout = the two bools) and the aggregate row
+            if "sgemm_kernel" in k or "sgemm_dma_kernel" in k:      # per template instance (layout = the two bools) and the aggregate row
                 keys.append("msn::sgemm_kernel<*>")
             for k in keys:
                 e = d[k][r["Counter_Name"]]
@@ -55,7 +55,7 @@ def main():
     print("\n".join(lines[:12]))
     g = summary.get("msn::sgemm_kernel<*>")
     if g:
-        json.dump({"kernel": "msn::sgemm_kernel", "traffic_bytes_per_launch": g["traffic_bytes_per_launch"],
+        json.dump({"kernel": "msn::sgemm_dma_kernel + msn::sgemm_kernel", "traffic_bytes_per_launch": g["traffic_bytes_per_launch"],
                    "mfma_busy_fraction": g["mfma_util"], "effective_clock_ghz": g["clock_ghz"], "launches": g["launches"],
                    "workload": "bench.py default (ViT-S/8 + LC transformer, per-GPU batch 1024)",
                    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES passes, tools/summarize_pmc.py"},
