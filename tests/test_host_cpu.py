@@ -44,7 +44,9 @@ def test_shape_errors_are_reported_without_a_gpu():
     assert rc == 1 and b"unsupported" in lib.msn_last_error()
     assert lib.msn_set_attention_path(7) == 1
     assert lib.msn_sgemm_workspace_bytes(1, 0, 384, 1536, 66560) > 0      # wgrad takes the split-K path
-    assert lib.msn_sgemm_workspace_bytes(0, 1, 66560, 1536, 384) == 0
+    # 6240 tiles = 12 rounds of 512 + 96: those 96 run as 3 K-slabs each (tail split)
+    assert lib.msn_sgemm_workspace_bytes(0, 1, 66560, 1536, 384) == 96 * 3 * 128 * 128 * 4
+    assert lib.msn_sgemm_workspace_bytes(0, 1, 4096, 4096, 4096) == 0      # 1024 tiles: two full rounds
 
 
 def test_no_cpu_fallback():
