@@ -345,6 +345,13 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void sgemm_dma_kernel(c
     __shared__ __attribute__((aligned(16))) float smem[STAGES * STAGE];
     const unsigned smem_addr = (unsigned)(uintptr_t)(lptr_t*)smem;   // LDS byte address of the ring
 
+#ifdef MSN_TIMELINE
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef MSN_STAGGER
+    if (blockIdx.x >= 256u && blockIdx.x < 512u)
+        for (int i = 0; i < MSN_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     const TileCoord tc = locate_tile(p);
     const int logical = tc.logical;
     const int64_t m0 = (int64_t)(logical / p.tiles_n) * BM, n0 = (int64_t)(logical % p.tiles_n) * BN;
@@ -391,6 +398,9 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void sgemm_dma_kernel(c
     if (nkt >= STAGES - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#ifdef MSN_TIMELINE
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
@@ -442,8 +452,21 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void sgemm_dma_kernel(c
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
+#ifdef MSN_TIMELINE
+    const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (tc.tail_slab >= 0) dump_tail<TM, TN>(acc, p, tc.tail_slab, wave, NWAVES, lane);
     else gemm_epilogue<TM, TN>(acc, p, m0, n0, wm0, wn0, l32, h, split);
+#ifdef MSN_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
+    if (p.dbg && threadIdx.x == 0) {
+        unsigned long long* d = p.dbg + (size_t)blockIdx.x * 6;
+        d[0] = t0, d[1] = t1, d[2] = t2, d[3] = t3;
+        d[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));      // HW_ID
+        d[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));     // XCC_ID
+    }
+#endif
 }
 
 // Sum of the K-slabs of one tail tile (slab order: deterministic) + the epilogue; same wave / register layout as
@@ -649,6 +672,14 @@ int launch_tail_finish(const GemmArgs& a, int bn, int waves, hipStream_t st);
 
 using namespace msn;
 
+#ifdef MSN_TIMELINE
+static unsigned long long* g_timeline = nullptr;
+extern "C" int msn_debug_timeline(unsigned long long* buf) {
+    g_timeline = buf;
+    return MSN_OK;
+}
+#endif
+
 extern "C" size_t msn_sgemm_workspace_bytes(int opA, int opB, int64_t M, int64_t N, int64_t K) {
     (void)opB;
     if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -687,6 +718,9 @@ extern "C" int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, cons
     a.partial = nullptr;
     a.tail_tiles = pl.tail_tiles, a.tail_splits = pl.tail_splits, a.tail_kps = pl.tail_kps;
     a.tail_partial = nullptr;
+#ifdef MSN_TIMELINE
+    a.dbg = g_timeline;
+#endif
     if (a.tail_tiles > 0) {
         const size_t need = pl.ws_bytes(M, N);
         MSN_REQUIRE(ws && ws_bytes >= need, "msn_sgemm: workspace %zu < %zu bytes", ws_bytes, need);

@@ -27,6 +27,9 @@ struct GemmArgs {
     // tail_finish_kernel sums them in slab order and applies the epilogue.  0 tiles = no tail.
     int tail_tiles, tail_splits, tail_kps;
     float* tail_partial;   // [tail_tiles][tail_splits][BM * BN]
+#ifdef MSN_TIMELINE
+    unsigned long long* dbg;   // per workgroup: 4 timestamps + HW_ID + XCC_ID (diagnostic builds only)
+#endif
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -80,49 +83,75 @@ __device__ __forceinline__ void dump_tail(const f32x16 (&acc)[TM][TN], const Gem
 }
 
 // Epilogue of a (TM x TN) grid of 32x32 accumulator tiles (C/D layout of every 32x32 MFMA on gfx950,
-// fp32 and bf16 alike: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h).  The aux operand of a tile
-// is read as one batch of 16 loads before any arithmetic, so the loads overlap instead of paying one
-// memory round trip per element.
-template <int TM, int TN>
-__device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[TM][TN], const GemmArgs& p, int64_t m0, int64_t n0,
-                                              int wm0, int wn0, int l32, int h, int split) {
-    const bool to_partial = p.splits > 1;
-    float* out = to_partial ? p.partial + (int64_t)split * p.M * p.N : p.C;
-    const int64_t ldo = to_partial ? p.N : p.ldc;
-    const int epi = to_partial ? MSN_EPI_NONE : p.epilogue;
-    const bool reads_aux = epi == MSN_EPI_RELU_BWD || epi == MSN_EPI_GELU_BWD || epi == MSN_EPI_ADD;
+// fp32 and bf16 alike: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h).
+// The epilogue kind and "this wave's tile lies wholly inside C" are template parameters, selected once per wave by
+// a uniform switch: the interior case is straight-line code (no per-element compare / exec mask), and each kind
+// carries only its own arithmetic.  The aux operand of a tile is read as one batch of 16 loads before any
+// arithmetic, so the loads overlap instead of paying one memory round trip per element.
+template <int TM, int TN, int EPI, bool FULL>
+__device__ __forceinline__ void epilogue_body(const f32x16 (&acc)[TM][TN], const GemmArgs& p, float* __restrict__ out,
+                                              int64_t ldo, int64_t m0, int64_t n0, int wm0, int wn0, int l32, int h) {
+    constexpr bool READS_AUX = EPI == MSN_EPI_RELU_BWD || EPI == MSN_EPI_GELU_BWD || EPI == MSN_EPI_ADD;
+    const bool saves_aux = EPI == MSN_EPI_GELU && p.aux != nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int64_t col = n0 + wn0 + 32 * j + l32;
-            const bool col_ok = col < p.N;
-            const float bv = (!to_partial && p.bias && col_ok) ? p.bias[col] : 0.f;
+            const bool col_ok = FULL || col < p.N;
+            const float bv = (p.bias && col_ok) ? p.bias[col] : 0.f;
             const int64_t row0 = m0 + wm0 + 32 * i + 4 * h;
+            float* __restrict__ o = out + row0 * ldo + col;
+            float* __restrict__ x = p.aux + row0 * p.ldaux + col;   // only dereferenced by the kinds that use aux
             float av[16];
-            if (reads_aux) {
+            if (READS_AUX) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
-                    av[r] = (col_ok && row < p.M) ? p.aux[row * p.ldaux + col] : 0.f;
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    av[r] = (FULL || (col_ok && row0 + dr < p.M)) ? x[dr * p.ldaux] : 0.f;
                 }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
+                const int dr = (r & 3) + 8 * (r >> 2);
+                const bool ok = FULL || (col_ok && row0 + dr < p.M);
                 float v = acc[i][j][r] + bv;
-                if (epi == MSN_EPI_RELU) v = fmaxf(v, 0.f);
-                else if (epi == MSN_EPI_GELU) {
+                if (EPI == MSN_EPI_RELU) v = fmaxf(v, 0.f);
+                else if (EPI == MSN_EPI_GELU) {
                     const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
-                    if (p.aux && col_ok && row < p.M)
-                        p.aux[row * p.ldaux + col] = cdf + v * 0.39894228040143268f * __expf(-0.5f * v * v);
+                    if (saves_aux && ok) x[dr * p.ldaux] = cdf + v * 0.39894228040143268f * __expf(-0.5f * v * v);
                     v *= cdf;
-                } else if (epi == MSN_EPI_RELU_BWD) v = av[r] > 0.f ? v : 0.f;
-                else if (epi == MSN_EPI_GELU_BWD) v *= av[r];
-                else if (epi == MSN_EPI_ADD) v += av[r];
-                if (col_ok && row < p.M) out[row * ldo + col] = v;
+                } else if (EPI == MSN_EPI_RELU_BWD) v = av[r] > 0.f ? v : 0.f;
+                else if (EPI == MSN_EPI_GELU_BWD) v *= av[r];
+                else if (EPI == MSN_EPI_ADD) v += av[r];
+                if (ok) o[dr * ldo] = v;
             }
         }
+}
+
+template <int TM, int TN, int EPI>
+__device__ __forceinline__ void epilogue_kind(const f32x16 (&acc)[TM][TN], const GemmArgs& p, float* out, int64_t ldo,
+                                              int64_t m0, int64_t n0, int wm0, int wn0, int l32, int h) {
+    const bool full = m0 + wm0 + 32 * TM <= p.M && n0 + wn0 + 32 * TN <= p.N;   // wave-uniform
+    if (full) epilogue_body<TM, TN, EPI, true>(acc, p, out, ldo, m0, n0, wm0, wn0, l32, h);
+    else epilogue_body<TM, TN, EPI, false>(acc, p, out, ldo, m0, n0, wm0, wn0, l32, h);
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[TM][TN], const GemmArgs& p, int64_t m0, int64_t n0,
+                                              int wm0, int wn0, int l32, int h, int split) {
+    if (p.splits > 1) {   // split-K slab: plain store into this split's [M][N] partial (bias is null by contract)
+        epilogue_kind<TM, TN, MSN_EPI_NONE>(acc, p, p.partial + (int64_t)split * p.M * p.N, p.N, m0, n0, wm0, wn0, l32, h);
+        return;
+    }
+    switch (p.epilogue) {
+        case MSN_EPI_RELU: epilogue_kind<TM, TN, MSN_EPI_RELU>(acc, p, p.C, p.ldc, m0, n0, wm0, wn0, l32, h); break;
+        case MSN_EPI_GELU: epilogue_kind<TM, TN, MSN_EPI_GELU>(acc, p, p.C, p.ldc, m0, n0, wm0, wn0, l32, h); break;
+        case MSN_EPI_RELU_BWD: epilogue_kind<TM, TN, MSN_EPI_RELU_BWD>(acc, p, p.C, p.ldc, m0, n0, wm0, wn0, l32, h); break;
+        case MSN_EPI_GELU_BWD: epilogue_kind<TM, TN, MSN_EPI_GELU_BWD>(acc, p, p.C, p.ldc, m0, n0, wm0, wn0, l32, h); break;
+        case MSN_EPI_ADD: epilogue_kind<TM, TN, MSN_EPI_ADD>(acc, p, p.C, p.ldc, m0, n0, wm0, wn0, l32, h); break;
+        default: epilogue_kind<TM, TN, MSN_EPI_NONE>(acc, p, p.C, p.ldc, m0, n0, wm0, wn0, l32, h); break;
+    }
 }
 
 // bf16 matrix-core variant (gemm_bf16.hip): planes = 1 -> operands rounded to bf16, planes = 2 -> each
