@@ -391,11 +391,17 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void sgemm_dma_kernel(c
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Ring protocol: one barrier per K-step, placed before the MFMAs of the step's LAST k-octet.  At that point
+    // every wave has received all its fragment reads of this step (lgkmcnt(0)), so after the barrier
+    //   * the slot just read is free: the DMA of K-step kt + STAGES is issued into it (write-after-read safe);
+    //   * the DMA pieces of K-step kt + 1 have landed for every wave (each waited for its own: vmcnt), so the first
+    //     fragments of kt + 1 are requested right away and their LDS latency hides under the last octet's MFMAs
+    //     -- no wave leaves a barrier with nothing to multiply.
 #pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
+    for (int s = 0; s < STAGES; ++s)
         if (s < nkt) issue(s);
     // K-step 0 must have landed (for every wave: each waits for its own pieces, then the barrier)
-    if (nkt >= STAGES - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+    if (nkt >= STAGES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 1) * (PA + PB)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #ifdef MSN_TIMELINE
@@ -405,52 +411,57 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void sgemm_dma_kernel(c
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     constexpr int NREADS = TM * TA::kReads + TN * TB::kReads;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = kt + STAGES - 1 < nkt;
-        if (more) issue(kt + STAGES - 1);      // its ring slot held K-step kt - 1: free since the last barrier
-        const unsigned as = smem_addr + 4u * ((kt % STAGES) * STAGE);
+    static_assert(NKO % 2 == 0, "k-octets are processed in pairs");
+    // fragments of the next k-octet are requested before the MFMAs of the current one; the counted wait retires
+    // exactly the reads of the current octet (LDS returns in order) and leaves the younger ones in flight
+    typename TA::Frag fa[2][TM];
+    typename TB::Frag fb[2][TN];
+    auto request = [&](auto set, int slot, int ko) {
+        constexpr int S = decltype(set)::value;
+        const unsigned as = smem_addr + 4u * (slot * STAGE);
         const unsigned bs = as + 4u * TA::kFloats;
-        // fragments of k-octet ko + 1 are requested before the MFMAs of ko; the counted wait retires exactly the
-        // reads of ko (LDS returns in order) and leaves the younger ones in flight
-        typename TA::Frag fa[2][TM];
-        typename TB::Frag fb[2][TN];
-        auto request = [&](auto set, int ko) {
-            constexpr int S = decltype(set)::value;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) TA::frag_issue(fa[S][i], as, wm0 + 32 * i + l32, ko, h);
+        for (int i = 0; i < TM; ++i) TA::frag_issue(fa[S][i], as, wm0 + 32 * i + l32, ko, h);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) TB::frag_issue(fb[S][j], bs, wn0 + 32 * j + l32, ko, h);
-        };
-        auto multiply = [&](auto set, bool last) {
-            constexpr int S = decltype(set)::value;
-            if (last) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NREADS) : "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(TA::template get<0>(fa[S][i]), TB::template get<0>(fb[S][j]), acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(TA::template get<1>(fa[S][i]), TB::template get<1>(fb[S][j]), acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(TA::template get<2>(fa[S][i]), TB::template get<2>(fb[S][j]), acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(TA::template get<3>(fa[S][i]), TB::template get<3>(fb[S][j]), acc[i][j], 0, 0, 0);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        static_assert(NKO % 2 == 0, "k-octets are processed in pairs");
-        request(S0{}, 0);
+        for (int j = 0; j < TN; ++j) TB::frag_issue(fb[S][j], bs, wn0 + 32 * j + l32, ko, h);
+    };
+    auto multiply = [&](auto set, bool younger_in_flight) {
+        constexpr int S = decltype(set)::value;
+        if (younger_in_flight) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NREADS) : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // consecutive MFMAs go to different accumulators (no back-to-back dependent issue)
+#define MSN_MFMA_SWEEP(C)                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                 \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(TA::template get<C>(fa[S][i]), TB::template get<C>(fb[S][j]), \
+                                                         acc[i][j], 0, 0, 0);
+        MSN_MFMA_SWEEP(0) MSN_MFMA_SWEEP(1) MSN_MFMA_SWEEP(2) MSN_MFMA_SWEEP(3)
+#undef MSN_MFMA_SWEEP
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int slot = 0;
+    if (nkt > 0) request(S0{}, 0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int next_slot = slot + 1 == STAGES ? 0 : slot + 1;
 #pragma unroll
         for (int ko = 0; ko < NKO; ko += 2) {
-            request(S1{}, ko + 1);
-            multiply(S0{}, false);
-            if (ko + 2 < NKO) request(S0{}, ko + 2);
-            multiply(S1{}, ko + 2 >= NKO);
+            request(S1{}, slot, ko + 1);
+            multiply(S0{}, true);
+            if (ko + 2 < NKO) {
+                request(S0{}, slot, ko + 2);
+                multiply(S1{}, true);
+            } else {
+                const bool has_next = kt + 1 < nkt;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all fragment reads of this K-step are in
+                if (kt + STAGES - 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (kt + STAGES < nkt) issue(kt + STAGES);           // into `slot`
+                if (has_next) request(S0{}, next_slot, 0);
+                multiply(S1{}, has_next);
+            }
         }
-        // K-step kt + 1 must be complete before anyone reads it: while further steps were issued, the youngest
-        // STAGES - 2 may stay in flight; near the end of the K range everything outstanding is needed
-        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        slot = next_slot;
     }
 #ifdef MSN_TIMELINE
     const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
