@@ -290,7 +290,9 @@ struct MAttn {
 bool mattn_applicable(const MAttn& a);
 int mattn_forward(const MAttn& a, hipStream_t st);
 int mattn_backward(const MAttn& a, hipStream_t st);
-static int g_attn_path = 0;  // 0 = automatic, 1 = always the vector-ALU kernels, 2 = matrix cores whenever applicable
+static int g_attn_path = 0;  // 0 = automatic (matrix cores for head widths >= 16: narrower heads measured no faster
+                             // there, tools/bench_attention.py), 1 = always the vector-ALU kernels, 2 = matrix cores
+                             // whenever applicable
 
 static int pad_head(int s) {
     for (int c : {4, 8, 16, 32, 64, 128})
@@ -338,7 +340,7 @@ extern "C" int msn_attention_fwd(const float* q, int64_t ldq, int64_t q_bstride,
         m.ldq = ldq; m.ldk = ldk; m.ldv = ldv; m.ldo = ldo;
         m.q_bs = q_bstride; m.k_bs = k_bstride; m.v_bs = v_bstride; m.o_bs = o_bstride;
         m.B = B; m.H = H; m.Tq = Tq; m.Tk = Tk; m.hd = head_dim; m.scale = scale;
-        if (mattn_applicable(m)) return mattn_forward(m, st);
+        if (mattn_applicable(m) && (head_dim >= 16 || g_attn_path == 2)) return mattn_forward(m, st);
     }
     const int S = pad_head(head_dim);
     const unsigned bs = block_for(Tq);
@@ -380,7 +382,7 @@ extern "C" int msn_attention_bwd(const float* q, int64_t ldq, int64_t q_bstride,
         m.q_bs = q_bstride; m.k_bs = k_bstride; m.v_bs = v_bstride; m.o_bs = o_bstride; m.d_bs = d_bstride;
         m.dq_bs = dq_bstride; m.dk_bs = dk_bstride; m.dv_bs = dv_bstride;
         m.B = B; m.H = H; m.Tq = Tq; m.Tk = Tk; m.hd = head_dim; m.scale = scale;
-        if (mattn_applicable(m)) return mattn_backward(m, st);
+        if (mattn_applicable(m) && (head_dim >= 16 || g_attn_path == 2)) return mattn_backward(m, st);
     }
     const int S = pad_head(head_dim);
     {

@@ -1,5 +1,6 @@
-// Matrix-core attention for wide heads (head_dim 16..64, multiple of 16; sequences up to 256
-// tokens): the ViT image tower.  Exact fp32 on v_mfma_f32_16x16x4_f32.
+// Matrix-core attention (sequences up to 256 tokens; head_dim 16..64 in multiples of 16: the ViT image
+// tower; head_dim 4 / 8 / 12: the light-curve transformer, run as 16-wide heads whose missing columns
+// are zeros in LDS / registers only).  Exact fp32 on v_mfma_f32_16x16x4_f32.
 //
 // One workgroup per (batch, head); one wave per 16-row tile of the "fixed" operand, every wave
 // sweeping the 16-row tiles of the "streamed" operand, which sits in LDS for the whole workgroup:
@@ -41,24 +42,26 @@ struct MAttn {
 
 // rows [0, T) of src (row stride ld, columns col0..col0+HD-1) -> LDS [TP][HD + 4], zero rows beyond T
 template <int HD>
-__device__ __forceinline__ void stage(float* dst, const float* __restrict__ src, int64_t ld, int col0, int T, int TP) {
+__device__ __forceinline__ void stage(float* dst, const float* __restrict__ src, int64_t ld, int col0, int T, int TP,
+                                      int hd) {
     constexpr int LS = HD + 4, Q4 = HD / 4;
     for (int idx = threadIdx.x; idx < TP * Q4; idx += blockDim.x) {
         const int r = idx / Q4, c = 4 * (idx % Q4);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < T) v = *reinterpret_cast<const float4*>(src + (int64_t)r * ld + col0 + c);
+        if (r < T && c < hd) v = *reinterpret_cast<const float4*>(src + (int64_t)r * ld + col0 + c);
         *reinterpret_cast<float4*>(dst + r * LS + c) = v;
     }
 }
 // fragments of one 16-row tile held by this wave as the B operand: row = lane & 15, d = 16x + 4g + j
 template <int HD>
 __device__ __forceinline__ void load_frags(float4 (&f)[HD / 16], const float* __restrict__ src, int64_t ld, int col0,
-                                           int row, int T, int g, float mul) {
-    const float* p = src + (int64_t)(row < T ? row : T - 1) * ld + col0 + 4 * g;
+                                           int row, int T, int g, float mul, int hd) {
+    const float* p = src + (int64_t)(row < T ? row : T - 1) * ld + col0;
 #pragma unroll
     for (int x = 0; x < HD / 16; ++x) {
-        float4 v = *reinterpret_cast<const float4*>(p + 16 * x);
-        if (row >= T) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int d0 = 16 * x + 4 * g;
+        float4 v = *reinterpret_cast<const float4*>(p + (d0 < hd ? d0 : 0));
+        if (row >= T || d0 >= hd) v = make_float4(0.f, 0.f, 0.f, 0.f);
         f[x] = make_float4(v.x * mul, v.y * mul, v.z * mul, v.w * mul);
     }
 }
@@ -108,15 +111,15 @@ __global__ __launch_bounds__(1024) void mattn_fwd_kernel(const MAttn p) {
     float* Vs = smem + (size_t)TPk * LS;
     uint8_t* Ms = reinterpret_cast<uint8_t*>(Vs + (size_t)TPk * LS);
     const int b = blockIdx.x / p.H, hh = blockIdx.x % p.H, col0 = hh * p.hd;
-    stage<HD>(Ks, p.k + (int64_t)b * p.k_bs, p.ldk, col0, p.Tk, TPk);
-    stage<HD>(Vs, p.v + (int64_t)b * p.v_bs, p.ldv, col0, p.Tk, TPk);
+    stage<HD>(Ks, p.k + (int64_t)b * p.k_bs, p.ldk, col0, p.Tk, TPk, p.hd);
+    stage<HD>(Vs, p.v + (int64_t)b * p.v_bs, p.ldv, col0, p.Tk, TPk, p.hd);
     for (int j = threadIdx.x; j < TPk; j += blockDim.x) Ms[j] = (j < p.Tk && p.mask) ? p.mask[(int64_t)b * p.Tk + j] : 1;
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
     const int q0 = wave * 16, qrow = q0 + c;
     float4 qf[DT];
-    load_frags<HD>(qf, p.q + (int64_t)b * p.q_bs, p.ldq, col0, qrow, p.Tq, g, p.scale);
+    load_frags<HD>(qf, p.q + (int64_t)b * p.q_bs, p.ldq, col0, qrow, p.Tq, g, p.scale, p.hd);
     const int nkt = TPk / 16;
 
     float m = -INFINITY;
@@ -154,7 +157,8 @@ __global__ __launch_bounds__(1024) void mattn_fwd_kernel(const MAttn p) {
             float* op = p.out + (int64_t)b * p.o_bs + (int64_t)q * p.ldo + col0 + c;
             const float inv = 1.f / lq;
 #pragma unroll
-            for (int t = 0; t < DT; ++t) op[16 * t] = o[t][r] * inv;
+            for (int t = 0; t < DT; ++t)
+                if (16 * t + c < p.hd) op[16 * t] = o[t][r] * inv;
         }
     }
     if (g == 0 && qrow < p.Tq) {
@@ -174,8 +178,8 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dq_kernel(const MAttn p) {
     float* Vs = smem + (size_t)TPk * LS;
     uint8_t* Ms = reinterpret_cast<uint8_t*>(Vs + (size_t)TPk * LS);
     const int b = blockIdx.x / p.H, hh = blockIdx.x % p.H, col0 = hh * p.hd;
-    stage<HD>(Ks, p.k + (int64_t)b * p.k_bs, p.ldk, col0, p.Tk, TPk);
-    stage<HD>(Vs, p.v + (int64_t)b * p.v_bs, p.ldv, col0, p.Tk, TPk);
+    stage<HD>(Ks, p.k + (int64_t)b * p.k_bs, p.ldk, col0, p.Tk, TPk, p.hd);
+    stage<HD>(Vs, p.v + (int64_t)b * p.v_bs, p.ldv, col0, p.Tk, TPk, p.hd);
     for (int j = threadIdx.x; j < TPk; j += blockDim.x) Ms[j] = (j < p.Tk && p.mask) ? p.mask[(int64_t)b * p.Tk + j] : 1;
     __syncthreads();
 
@@ -183,9 +187,9 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dq_kernel(const MAttn p) {
     const int q0 = wave * 16, qrow = q0 + c;
     const bool q_ok = qrow < p.Tq;
     float4 qf[DT], df[DT], of[DT];
-    load_frags<HD>(qf, p.q + (int64_t)b * p.q_bs, p.ldq, col0, qrow, p.Tq, g, p.scale);
-    load_frags<HD>(df, p.dout + (int64_t)b * p.d_bs, p.ldd, col0, qrow, p.Tq, g, 1.f);
-    load_frags<HD>(of, p.o + (int64_t)b * p.o_bs, p.ldo, col0, qrow, p.Tq, g, 1.f);
+    load_frags<HD>(qf, p.q + (int64_t)b * p.q_bs, p.ldq, col0, qrow, p.Tq, g, p.scale, p.hd);
+    load_frags<HD>(df, p.dout + (int64_t)b * p.d_bs, p.ldd, col0, qrow, p.Tq, g, 1.f, p.hd);
+    load_frags<HD>(of, p.o + (int64_t)b * p.o_bs, p.ldo, col0, qrow, p.Tq, g, 1.f, p.hd);
     float delta = 0.f;
 #pragma unroll
     for (int x = 0; x < DT; ++x)
@@ -218,7 +222,8 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dq_kernel(const MAttn p) {
         if (q < p.Tq) {
             float* op = p.dq + (int64_t)b * p.dq_bs + (int64_t)q * p.lddq + col0 + c;
 #pragma unroll
-            for (int t = 0; t < DT; ++t) op[16 * t] = dq[t][r] * p.scale;
+            for (int t = 0; t < DT; ++t)
+                if (16 * t + c < p.hd) op[16 * t] = dq[t][r] * p.scale;
         }
     }
 }
@@ -235,8 +240,8 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dkv_kernel(const MAttn p) {
     float* Ll = Lm + TPq;
     float* Dl = Ll + TPq;
     const int b = blockIdx.x / p.H, hh = blockIdx.x % p.H, col0 = hh * p.hd;
-    stage<HD>(Qs, p.q + (int64_t)b * p.q_bs, p.ldq, col0, p.Tq, TPq);
-    stage<HD>(Ds, p.dout + (int64_t)b * p.d_bs, p.ldd, col0, p.Tq, TPq);
+    stage<HD>(Qs, p.q + (int64_t)b * p.q_bs, p.ldq, col0, p.Tq, TPq, p.hd);
+    stage<HD>(Ds, p.dout + (int64_t)b * p.d_bs, p.ldd, col0, p.Tq, TPq, p.hd);
     for (int t = threadIdx.x; t < TPq; t += blockDim.x) {
         const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + (t < p.Tq ? t : 0);
         Lm[t] = t < p.Tq ? p.lse[2 * stat] : INFINITY;     // +inf: a padded query row gets p = exp(-inf) = 0
@@ -248,8 +253,8 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dkv_kernel(const MAttn p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
     const int k0 = wave * 16, krow = k0 + c;
     float4 kf[DT], vf[DT];
-    load_frags<HD>(kf, p.k + (int64_t)b * p.k_bs, p.ldk, col0, krow, p.Tk, g, p.scale);
-    load_frags<HD>(vf, p.v + (int64_t)b * p.v_bs, p.ldv, col0, krow, p.Tk, g, 1.f);
+    load_frags<HD>(kf, p.k + (int64_t)b * p.k_bs, p.ldk, col0, krow, p.Tk, g, p.scale, p.hd);
+    load_frags<HD>(vf, p.v + (int64_t)b * p.v_bs, p.ldv, col0, krow, p.Tk, g, 1.f, p.hd);
     const bool keep = krow < p.Tk && (p.mask ? p.mask[(int64_t)b * p.Tk + krow] != 0 : true);
 
     f32x4 dk[DT], dv[DT];
@@ -277,10 +282,11 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dkv_kernel(const MAttn p) {
             float* ok = p.dk + (int64_t)b * p.dk_bs + (int64_t)k * p.lddk + col0 + c;
             float* ov = p.dv + (int64_t)b * p.dv_bs + (int64_t)k * p.lddv + col0 + c;
 #pragma unroll
-            for (int t = 0; t < DT; ++t) {
-                ok[16 * t] = dk[t][r] * p.scale;
-                ov[16 * t] = dv[t][r];
-            }
+            for (int t = 0; t < DT; ++t)
+                if (16 * t + c < p.hd) {
+                    ok[16 * t] = dk[t][r] * p.scale;
+                    ov[16 * t] = dv[t][r];
+                }
         }
     }
 }
@@ -299,9 +305,12 @@ static int launch_big_lds(K kernel, dim3 grid, dim3 block, size_t lds, hipStream
     return MSN_OK;
 }
 
-// Is the matrix-core path applicable?  (16-B aligned operands, head width 16/32/48/64, <= 256 tokens.)
+// Is the matrix-core path applicable?  (16-B aligned operands, head width 4/8/12/16/32/48/64, <= 256 tokens.)
+static int padded_hd(int hd) { return hd < 16 ? 16 : hd; }
 bool mattn_applicable(const MAttn& a) {
-    if (a.hd % 16 != 0 || a.hd > 64 || a.Tq > 256 || a.Tk > 256 || a.q_bs == 0) return false;
+    if (!(a.hd % 16 == 0 || (a.hd < 16 && a.hd % 4 == 0)) || a.hd > 64 || a.hd < 4 || a.Tq > 256 || a.Tk > 256 ||
+        a.q_bs == 0)
+        return false;
     if ((int64_t)a.B * a.H > 0x7fffffffLL) return false;
     const int64_t lds[] = {a.ldq, a.ldk, a.ldv, a.q_bs, a.k_bs, a.v_bs};
     for (int64_t v : lds)
@@ -313,7 +322,7 @@ bool mattn_applicable(const MAttn& a) {
 }
 
 #define MSN_MATTN_DISPATCH(KERNEL, ...)                                                    \
-    switch (a.hd) {                                                                        \
+    switch (padded_hd(a.hd)) {                                                                      \
         case 16: rc = launch_big_lds(KERNEL<16>, __VA_ARGS__); break;                      \
         case 32: rc = launch_big_lds(KERNEL<32>, __VA_ARGS__); break;                      \
         case 48: rc = launch_big_lds(KERNEL<48>, __VA_ARGS__); break;                      \
@@ -322,7 +331,7 @@ bool mattn_applicable(const MAttn& a) {
 
 int mattn_forward(const MAttn& a, hipStream_t st) {
     const int TPk = (a.Tk + 15) / 16 * 16, nq = (a.Tq + 15) / 16;
-    const size_t lds = sizeof(float) * 2 * (size_t)TPk * (a.hd + 4) + (size_t)TPk;
+    const size_t lds = sizeof(float) * 2 * (size_t)TPk * (padded_hd(a.hd) + 4) + (size_t)TPk;
     int rc;
     MSN_MATTN_DISPATCH(mattn_fwd_kernel, dim3(a.B * a.H), dim3(64 * nq), lds, st, a)
     return rc;
@@ -339,12 +348,12 @@ int mattn_backward(const MAttn& a, hipStream_t st) {
         return MSN_ERR_SHAPE;
     }
     {
-        const size_t lds = sizeof(float) * 2 * (size_t)TPk * (a.hd + 4) + (size_t)TPk;
+        const size_t lds = sizeof(float) * 2 * (size_t)TPk * (padded_hd(a.hd) + 4) + (size_t)TPk;
         MSN_MATTN_DISPATCH(mattn_bwd_dq_kernel, dim3(a.B * a.H), dim3(64 * (TPq / 16)), lds, st, a)
         if (rc != MSN_OK) return rc;
     }
     {
-        const size_t lds = sizeof(float) * (2 * (size_t)TPq * (a.hd + 4) + 3 * (size_t)TPq);
+        const size_t lds = sizeof(float) * (2 * (size_t)TPq * (padded_hd(a.hd) + 4) + 3 * (size_t)TPq);
         MSN_MATTN_DISPATCH(mattn_bwd_dkv_kernel, dim3(a.B * a.H), dim3(64 * (TPk / 16)), lds, st, a)
     }
     return rc;
