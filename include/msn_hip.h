@@ -92,6 +92,16 @@ int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, const float* A,
               const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int epilogue,
               float* aux, int64_t ldaux, int precision, void* ws, size_t ws_bytes, msn_stream_t stream);
 
+/* Weight + bias gradient of a Linear in one launch (the backward of torch.nn.functional.linear as used at
+ * ref src/transformer_utils.py:33-36, :103-107 and every nn.Linear of src/models_multimodal.py):
+ *   dW[M x N] = dY^T X,   db[M] = column sums of dY,   dY: K x M (row stride lddy), X: K x N (row stride ldx).
+ * On the LDS-DMA kernels the column sums ride on the A fragments the product already holds (no second pass over
+ * dY); other shapes / precisions run msn_sgemm + msn_colsum.  Workspace: msn_wgrad_bias_workspace_bytes. */
+size_t msn_wgrad_bias_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int msn_wgrad_bias(int64_t M, int64_t N, int64_t K, const float* dY, int64_t lddy, const float* X, int64_t ldx,
+                   float* dW, int64_t lddw, float* db, int precision, void* ws, size_t ws_bytes,
+                   msn_stream_t stream);
+
 /* out[n] = sum_m X[m][n]  (bias gradients).  ws >= msn_colsum_workspace_bytes(M, N). */
 size_t msn_colsum_workspace_bytes(int64_t M, int64_t N);
 int msn_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, float* out, void* ws, size_t ws_bytes,

@@ -330,8 +330,9 @@ struct DmaTile {
     }
 };
 
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int DBK, int STAGES>
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int DBK, int STAGES, bool CSUM = false>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void sgemm_dma_kernel(const GemmArgs p) {
+    static_assert(!CSUM || AKM, "the fused column sums are those of a K-major A operand (wgrad: A = dY)");
     using TA = DmaTile<BM, AKM, DBK>;
     using TB = DmaTile<BN, BKM, DBK>;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -416,6 +417,11 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void sgemm_dma_kernel(c
     // exactly the reads of the current octet (LDS returns in order) and leaves the younger ones in flight
     typename TA::Frag fa[2][TM];
     typename TB::Frag fb[2][TN];
+    // CSUM (wgrad with bias gradient): the A fragments this wave multiplies are dY[k][row]; their running sum over
+    // k is the bias gradient of `row` -- a few v_add per 16 MFMAs instead of a separate pass over dY
+    float csum[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) csum[i] = 0.f;
     auto request = [&](auto set, int slot, int ko) {
         constexpr int S = decltype(set)::value;
         const unsigned as = smem_addr + 4u * (slot * STAGE);
@@ -430,6 +436,12 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void sgemm_dma_kernel(c
         if (younger_in_flight) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NREADS) : "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (CSUM) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                csum[i] += (TA::template get<0>(fa[S][i]) + TA::template get<1>(fa[S][i])) +
+                           (TA::template get<2>(fa[S][i]) + TA::template get<3>(fa[S][i]));
+        }
         // consecutive MFMAs go to different accumulators (no back-to-back dependent issue)
 #define MSN_MFMA_SWEEP(C)                                                                                        \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                 \
@@ -466,6 +478,16 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void sgemm_dma_kernel(c
 #ifdef MSN_TIMELINE
     const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
 #endif
+    if constexpr (CSUM) {
+        if (wn0 == 0 && logical % p.tiles_n == 0) {   // one wave column of the first tile column owns each row
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float v = csum[i] + __shfl_xor(csum[i], 32, 64);   // lane halves hold k = 4h .. 4h + 3
+                const int64_t row = m0 + wm0 + 32 * i + l32;
+                if (h == 0 && row < p.M) p.colsum[(int64_t)split * p.M + row] = v;
+            }
+        }
+    }
     if (tc.tail_slab >= 0) dump_tail<TM, TN>(acc, p, tc.tail_slab, wave, NWAVES, lane);
     else gemm_epilogue<TM, TN>(acc, p, m0, n0, wm0, wn0, l32, h, split);
 #ifdef MSN_TIMELINE
@@ -582,6 +604,7 @@ static int launch_dma(const GemmArgs& a, int opA, int opB, hipStream_t st) {
     const dim3 grid(gemm_grid(a)), block(64 * (BM / WM) * (BN / WN));
     if (opA == MSN_OP_N && opB == MSN_OP_T) hipLaunchKernelGGL((sgemm_dma_kernel<BM, BN, WM, WN, false, false, DBK, STAGES>), grid, block, 0, st, a);
     else if (opA == MSN_OP_N && opB == MSN_OP_N) hipLaunchKernelGGL((sgemm_dma_kernel<BM, BN, WM, WN, false, true, DBK, STAGES>), grid, block, 0, st, a);
+    else if (opA == MSN_OP_T && opB == MSN_OP_N && a.colsum) hipLaunchKernelGGL((sgemm_dma_kernel<BM, BN, WM, WN, true, true, DBK, STAGES, true>), grid, block, 0, st, a);
     else if (opA == MSN_OP_T && opB == MSN_OP_N) hipLaunchKernelGGL((sgemm_dma_kernel<BM, BN, WM, WN, true, true, DBK, STAGES>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((sgemm_dma_kernel<BM, BN, WM, WN, true, false, DBK, STAGES>), grid, block, 0, st, a);
     MSN_LAUNCH_CHECK();
@@ -632,7 +655,7 @@ struct Plan {
     }
 };
 
-static Plan plan(int64_t M, int64_t N, int64_t K, int opA) {
+static Plan plan(int64_t M, int64_t N, int64_t K, int opA, bool allow_tail = true) {
     Plan p;
     p.bm = 128;
     p.bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
@@ -656,7 +679,7 @@ static Plan plan(int64_t M, int64_t N, int64_t K, int opA) {
     p.splits = s;
     p.kps = (int)per;
     const int64_t r = tiles % 512;
-    if (g_gemm_tail && s == 1 && p.bn == 128 && r > 0 && tiles >= 128 && tiles < (1ll << 30)) {
+    if (g_gemm_tail && allow_tail && s == 1 && p.bn == 128 && r > 0 && tiles >= 128 && tiles < (1ll << 30)) {
         // time of the last round in units of one whole tile: ceil(r c / 512) rounds of 1 / c tile each (+ a small
         // charge per slab for its prologue, the slab store and the finishing pass)
         const int64_t cmax = std::min<int64_t>(std::min<int64_t>(ksteps / 4, 16), 1024 / r);
@@ -683,6 +706,10 @@ int launch_tail_finish(const GemmArgs& a, int bn, int waves, hipStream_t st);
 
 using namespace msn;
 
+extern "C" size_t msn_colsum_workspace_bytes(int64_t M, int64_t N);
+extern "C" int msn_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, float* out, void* ws, size_t ws_bytes,
+                          msn_stream_t stream);
+
 #ifdef MSN_TIMELINE
 static unsigned long long* g_timeline = nullptr;
 extern "C" int msn_debug_timeline(unsigned long long* buf) {
@@ -697,9 +724,12 @@ extern "C" size_t msn_sgemm_workspace_bytes(int opA, int opB, int64_t M, int64_t
     return plan(M, N, K, opA).ws_bytes(M, N);
 }
 
-extern "C" int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
-                         const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int epilogue,
-                         float* aux, int64_t ldaux, int precision, void* ws, size_t ws_bytes, msn_stream_t stream) {
+// The launch behind msn_sgemm and msn_wgrad_bias.  `colsum_out` (opA = T only): also produce out[m] = sum_k A[k][m]
+// inside the product kernel when the LDS-DMA kernels take the shape; *colsum_done tells the caller whether it was.
+static int sgemm_impl(int opA, int opB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                      int64_t ldb, float* C, int64_t ldc, const float* bias, int epilogue, float* aux, int64_t ldaux,
+                      int precision, void* ws, size_t ws_bytes, msn_stream_t stream, float* colsum_out,
+                      bool* colsum_done) {
     MSN_REQUIRE(M >= 0 && N >= 0 && K >= 0, "msn_sgemm: negative size M=%lld N=%lld K=%lld", (long long)M,
                 (long long)N, (long long)K);
     if (M == 0 || N == 0) return MSN_OK;
@@ -720,8 +750,9 @@ extern "C" int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, cons
     a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
     a.epilogue = epilogue;
-    const Plan pl = plan(M, N, K, opA);
+    const Plan pl = plan(M, N, K, opA, colsum_out == nullptr);
     const int bm = pl.bm, bn = pl.bn, splits = pl.splits, kps = pl.kps;
+    a.colsum = nullptr;
     a.tiles_m = (int)cdiv(M, bm);
     a.tiles_n = (int)cdiv(N, bn);
     a.splits = splits;
@@ -759,6 +790,17 @@ extern "C" int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, cons
     const bool dma_ok = g_gemm_variant != 0 && bn >= 64 && K % BK == 0 && kps % BK == 0 && (lda % 4 == 0) && (ldb % 4 == 0) &&
                         (a_ext % 4 == 0) && (b_ext % 4 == 0) && a_ext >= 4 && b_ext >= 4 &&
                         ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
+    const bool fuse_colsum = colsum_out && !bf16_ok && dma_ok && opA == MSN_OP_T && opB == MSN_OP_N;
+    if (fuse_colsum) {   // slabs of partial sums behind the product's own split-K slabs, or the result itself
+        if (splits > 1) {
+            const size_t need = pl.ws_bytes(M, N) + sizeof(float) * (size_t)splits * (size_t)M;
+            MSN_REQUIRE(ws && ws_bytes >= need, "msn_wgrad_bias: workspace %zu < %zu bytes", ws_bytes, need);
+            a.colsum = a.partial + (size_t)splits * (size_t)M * (size_t)N;
+        } else {
+            a.colsum = colsum_out;
+        }
+    }
+    if (colsum_done) *colsum_done = fuse_colsum;
     int waves = 4;   // per workgroup of the kernel chosen (the tail pass mirrors its register layout)
     if (bf16_ok) rc = launch_bgemm(a, opA, opB, precision == MSN_PREC_BF16X3 ? 2 : 1, bm, bn, st);
     else if (dma_ok && bn == 128 && K % 64 == 0 && kps % 64 == 0 && g_gemm_variant == 2)
@@ -779,8 +821,39 @@ extern "C" int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, cons
         const int blocks = (int)std::min<int64_t>(cdiv(total, 64), 4096);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.partial, C, M, N, ldc, splits);
         MSN_LAUNCH_CHECK();
+        if (fuse_colsum) {
+            hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(M, CS_COLS)), dim3(256), 0, st, a.colsum,
+                               (int64_t)splits, M, colsum_out);
+            MSN_LAUNCH_CHECK();
+        }
     }
     return MSN_OK;
+}
+
+extern "C" int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                         const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int epilogue,
+                         float* aux, int64_t ldaux, int precision, void* ws, size_t ws_bytes, msn_stream_t stream) {
+    return sgemm_impl(opA, opB, M, N, K, A, lda, B, ldb, C, ldc, bias, epilogue, aux, ldaux, precision, ws, ws_bytes,
+                      stream, nullptr, nullptr);
+}
+
+extern "C" size_t msn_wgrad_bias_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const Plan pl = plan(M, N, K, MSN_OP_T, false);
+    const size_t fused = pl.ws_bytes(M, N) + sizeof(float) * (size_t)pl.splits * (size_t)M;
+    const size_t separate = std::max(pl.ws_bytes(M, N), msn_colsum_workspace_bytes(K, M));
+    return std::max(fused, separate);
+}
+
+extern "C" int msn_wgrad_bias(int64_t M, int64_t N, int64_t K, const float* dY, int64_t lddy, const float* X, int64_t ldx,
+                              float* dW, int64_t lddw, float* db, int precision, void* ws, size_t ws_bytes,
+                              msn_stream_t stream) {
+    MSN_REQUIRE(db, "msn_wgrad_bias: null db");
+    bool fused = false;
+    const int rc = sgemm_impl(MSN_OP_T, MSN_OP_N, M, N, K, dY, lddy, X, ldx, dW, lddw, nullptr, MSN_EPI_NONE, nullptr, 0,
+                              precision, ws, ws_bytes, stream, db, &fused);
+    if (rc != MSN_OK || fused || M == 0 || N == 0) return rc;
+    return msn_colsum(dY, lddy, K, M, db, ws, ws_bytes, stream);   // shapes / precisions the fused kernel does not take
 }
 
 extern "C" int msn_set_gemm_tail_split(int enabled) {

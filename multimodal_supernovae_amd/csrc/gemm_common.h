@@ -27,6 +27,7 @@ struct GemmArgs {
     // tail_finish_kernel sums them in slab order and applies the epilogue.  0 tiles = no tail.
     int tail_tiles, tail_splits, tail_kps;
     float* tail_partial;   // [tail_tiles][tail_splits][BM * BN]
+    float* colsum;         // wgrad + bias grad: [splits][M] sums over k of A (opA = T) or null
 #ifdef MSN_TIMELINE
     unsigned long long* dbg;   // per workgroup: 4 timestamps + HW_ID + XCC_ID (diagnostic builds only)
 #endif

@@ -102,9 +102,10 @@ class _LinearChain(torch.autograd.Function):
         grads = [None] * (2 * n)
         for i in range(n - 1, -1, -1):
             w, b = wb[2 * i], wb[2 * i + 1]
-            grads[2 * i] = sgemm(d, inputs[i], OP_T, OP_N)            # dW = d^T . input
             if b is not None:
-                grads[2 * i + 1] = colsum(d)
+                grads[2 * i], grads[2 * i + 1] = ops.wgrad_bias(d, inputs[i])     # dW = d^T . input, db = sum d
+            else:
+                grads[2 * i] = sgemm(d, inputs[i], OP_T, OP_N)
             if i > 0:
                 act = ctx.acts[i - 1]
                 if act == ACT_RELU:      # inputs[i] = relu output of layer i-1 (zero where dropped: same gate)
@@ -200,8 +201,7 @@ def _attn_backward_raw(dz, x2, B, T, saved, wq, wk, wv, wu, mask_u8, heads, scal
     """dz: grad of unify output.  Returns dx (+ add_to fused) and the parameter grads."""
     qkv, a2, lse = saved
     M, e = x2.shape
-    dwu = sgemm(dz, a2, OP_T, OP_N)
-    dbu = colsum(dz)
+    dwu, dbu = ops.wgrad_bias(dz, a2)
     da = sgemm(dz, wu, OP_N, OP_N)
     dqkv = torch.empty_like(qkv)
     q3, d3 = qkv.view(B, T, 3 * e), dqkv.view(B, T, 3 * e)
@@ -285,11 +285,9 @@ class _PostNormBlock(torch.autograd.Function):
         if seeds:
             dy2 = ops.dropout(dy2, drop_p, seeds[1])
         dz2, dg2, db2 = ops.layernorm_bwd(dy2, z2, m2, r2, g2)
-        dw2 = sgemm(dz2, hdn, OP_T, OP_N)
-        dc2 = colsum(dz2)
+        dw2, dc2 = ops.wgrad_bias(dz2, hdn)
         dpre = sgemm(dz2, w2, OP_N, OP_N, epilogue=EPI_RELU_BWD, aux=hdn)
-        dw1 = sgemm(dpre, y1, OP_T, OP_N)
-        dc1 = colsum(dpre)
+        dw1, dc1 = ops.wgrad_bias(dpre, y1)
         dy1 = sgemm(dpre, w1, OP_N, OP_N, epilogue=EPI_ADD, aux=dz2)       # + residual branch of LN2's input
         if seeds:
             ops.dropout(dy1, drop_p, seeds[0], out=dy1)
@@ -401,8 +399,7 @@ class _AttnPool(torch.autograd.Function):
         B, T, e, scale = ctx.dims
         x2, q0, w_in, w_out, qp, kv, a2, lse = ctx.saved_tensors
         dout = _c(dout)
-        dw_out = sgemm(dout, a2, OP_T, OP_N)
-        db_out = colsum(dout)
+        dw_out, db_out = ops.wgrad_bias(dout, a2)
         da = sgemm(dout, w_out, OP_N, OP_N)
         kv3 = kv.view(B, T, 2 * e)
         dq = torch.empty((B, 1, e), dtype=torch.float32, device=dout.device)
@@ -494,8 +491,8 @@ class _ConvMixerTrunk(torch.autograd.Function):
             if drop_p > 0.0:
                 d = ops.dropout(d, drop_p, seeds[i][1])
             dpreB, dgB, dbB = ops.batchnorm_bwd(d, actB, preB, meanB, rstdB, gB, training)
-            grads[o + 6] = sgemm(dpreB, yA, OP_T, OP_N).view_as(pw_w)
-            grads[o + 7] = colsum(dpreB)
+            dpw, grads[o + 7] = ops.wgrad_bias(dpreB, yA)
+            grads[o + 6] = dpw.view_as(pw_w)
             grads[o + 8], grads[o + 9] = dgB, dbB
             dyA = sgemm(dpreB, pw_w.view(dim, dim), OP_N, OP_N)
             dbn = ops.dropout(dyA, drop_p, seeds[i][0]) if drop_p > 0.0 else dyA      # branch through the dropout
@@ -548,22 +545,18 @@ class _PreNormBlock(torch.autograd.Function):
         B, T, e, heads, scale = ctx.dims
         (x2, g1, wqkv, wo, g2, w1, w2, m1, r1, h1, qkv, a2, lse, x1, m2, r2, h2, pre, f) = ctx.saved_tensors
         d2 = _c(dy).view(B * T, e)
-        dw2 = sgemm(d2, f, OP_T, OP_N)
-        dc2 = colsum(d2)
+        dw2, dc2 = ops.wgrad_bias(d2, f)
         dpre = sgemm(d2, w2, OP_N, OP_N, epilogue=EPI_GELU_BWD, aux=pre)
-        dw1 = sgemm(dpre, h2, OP_T, OP_N)
-        dc1 = colsum(dpre)
+        dw1, dc1 = ops.wgrad_bias(dpre, h2)
         dh2 = sgemm(dpre, w1, OP_N, OP_N)
         dx1, dg2, db2 = ops.layernorm_bwd(dh2, x1, m2, r2, g2, add=d2)        # + skip connection
-        dwo = sgemm(dx1, a2, OP_T, OP_N)
-        dbo = colsum(dx1)
+        dwo, dbo = ops.wgrad_bias(dx1, a2)
         da = sgemm(dx1, wo, OP_N, OP_N)
         dqkv = torch.empty_like(qkv)
         q3, d3 = qkv.view(B, T, 3 * e), dqkv.view(B, T, 3 * e)
         ops.attention_bwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], None, heads, scale, a2.view(B, T, e), lse,
                           da.view(B, T, e), d3[..., :e], d3[..., e:2 * e], d3[..., 2 * e:])
-        dwqkv = sgemm(dqkv, h1, OP_T, OP_N)
-        dbqkv = colsum(dqkv)
+        dwqkv, dbqkv = ops.wgrad_bias(dqkv, h1)
         dh1 = sgemm(dqkv, wqkv, OP_N, OP_N)
         dx, dg1, db1 = ops.layernorm_bwd(dh1, x2, m1, r1, g1, add=dx1)          # + skip connection
         return (dx.view(B, T, e), None, None, dg1, db1, dwqkv, dbqkv, dwo, dbo, dg2, db2, dw1, dc1, dw2, dc2)
@@ -674,8 +667,11 @@ class _ConvCL(torch.autograd.Function):
         d = _c(dy).view(-1, co)
         if relu:
             d = ops.relu_mask(d, y)
-        dw = sgemm(d, cols, OP_T, OP_N).view_as(weight)
-        db = colsum(d) if has_bias else None
+        if has_bias:
+            dw, db = ops.wgrad_bias(d, cols)
+        else:
+            dw, db = sgemm(d, cols, OP_T, OP_N), None
+        dw = dw.view_as(weight)
         dx = None
         if ctx.needs_input_grad[0]:
             dcols = sgemm(d, weight.view(co, -1), OP_N, OP_N)

@@ -94,6 +94,31 @@ def sgemm(a, b, op_a=OP_N, op_b=OP_T, bias=None, epilogue=EPI_NONE, aux=None, ou
     return c
 
 
+def wgrad_bias(dy, x, precision=None):
+    """Weight and bias gradient of y = x W^T + b in one call: (dy^T x, column sums of dy) (msn_wgrad_bias)."""
+    _f32c(dy, "dy"), _f32c(x, "x")
+    assert dy.dim() == 2 and x.dim() == 2 and dy.stride(1) == 1 and x.stride(1) == 1
+    K, M = dy.shape
+    if x.shape[0] != K:
+        raise _lib.MsnHipError(f"wgrad_bias: row counts differ ({K} vs {x.shape[0]})")
+    N = x.shape[1]
+    dw = torch.empty((M, N), dtype=torch.float32, device=dy.device)
+    db = torch.empty(M, dtype=torch.float32, device=dy.device)
+    L = lib()
+    nb = L.msn_wgrad_bias_workspace_bytes(M, N, K)
+    ws = _workspace(nb, dy.device)
+    prof = GEMM_PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(L.msn_wgrad_bias(M, N, K, ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(dw), max(N, 1), ptr(db),
+                           GEMM_PRECISION if precision is None else precision, ptr(ws), nb, stream_ptr()), "msn_wgrad_bias")
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, 2.0 * M * N * K, (OP_T, OP_N, M, N, K, EPI_NONE)))
+    return dw, db
+
+
 def colsum(x):
     """Sum over rows of a 2-D tensor -> (N,)."""
     _f32c(x, "x")

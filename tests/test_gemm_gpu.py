@@ -117,6 +117,26 @@ def test_sgemm_tail_split(M, N, K, op_a, op_b, epi, variant, precision):
         torch.testing.assert_close(outs[0].double(), _ref(a, b, op_a, op_b), **tol)
 
 
+@pytest.mark.parametrize("K,M,N", [(66560, 384, 1536), (4096, 1536, 384), (2048, 64, 256), (1000, 130, 70),
+                                   (8192, 1024, 1024), (640, 96, 33), (51200, 64, 64)])
+@pytest.mark.parametrize("variant,precision", [(3, 0), (0, 0), (1, 0), (3, 1)])
+def test_wgrad_bias(K, M, N, variant, precision):
+    """msn_wgrad_bias = (dY^T X, column sums of dY); the fused LDS-DMA path, the split-K slabs of both results and
+    the fallback (register-staged family, unaligned shapes, bf16 split) all agree with fp64."""
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(K + M + N)
+    dy, x = torch.randn(K, M, generator=g).cuda(), torch.randn(K, N, generator=g).cuda()
+    try:
+        ops.set_gemm_variant(variant)
+        dw, db = ops.wgrad_bias(dy, x, precision=precision)
+        dw0 = ops.sgemm(dy, x, 1, 0, precision=precision)
+    finally:
+        ops.set_gemm_variant(3)
+    torch.testing.assert_close(dw.double(), dy.double().T @ x.double(), rtol=1e-4, atol=1e-4 * K ** 0.5)
+    torch.testing.assert_close(db.double(), dy.double().sum(0), rtol=1e-4, atol=2e-5 * K ** 0.5)
+    assert torch.equal(dw, dw0)          # the product itself is unchanged by the fused sums
+
+
 def test_sgemm_asymmetric_identity():
     """A = I with an asymmetric B catches a transposed C write (cdna guide section 3)."""
     from multimodal_supernovae_amd import ops
