@@ -33,6 +33,7 @@ struct AttnArgs {
     int64_t q_bstride, k_bstride, v_bstride, o_bstride;   // batch strides in elements (q: 0 = shared query)
     int64_t ldq, ldk, ldv, ldo;
     int B, H, Tq, Tk, s;
+    int tile_rows;                                    // rows of the streamed operand per LDS tile
     float scale;
     // backward only
     const float* dout; int64_t ldd, d_bstride;
@@ -69,25 +70,35 @@ __device__ __forceinline__ bool vec4_ok(const float* p, int64_t ld, int64_t bstr
     return (s % 4 == 0) && (ld % 4 == 0) && (bstride % 4 == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
 }
 
-template <int S>
+// R = query (or key) rows per lane.  Every key row is read from LDS as a wave-wide broadcast, 8 LDS cycles per 16
+// bytes whatever the number of distinct addresses -- with one row per lane those 4 reads per key bound the kernel
+// (328 M query-key pairs per light-curve layer: 340 us of LDS time per CU against 160 us of vector ALU).  A lane that
+// owns R consecutive rows re-uses each broadcast R times; narrow heads fit that in registers (<= 8 floats: R = 4,
+// 16 floats: R = 2).
+template <int S, int R>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
-    constexpr int KTILE = 4096 / S;
-    __shared__ __attribute__((aligned(16))) float Ks[KTILE * S];
-    __shared__ __attribute__((aligned(16))) float Vs[KTILE * S];
-    __shared__ uint8_t Ms[KTILE];
+    // LDS sized by the launch: KTILE = min(4096 / S, keys rounded up to 8) rows each of K and V + the mask bytes
+    extern __shared__ __attribute__((aligned(16))) float attn_smem[];
+    const int KTILE = p.tile_rows;
+    float* Ks = attn_smem;
+    float* Vs = attn_smem + KTILE * S;
+    uint8_t* Ms = reinterpret_cast<uint8_t*>(Vs + KTILE * S);
     const int b = blockIdx.z, hh = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool on = i < p.Tq;
+    const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * R;
     const int col0 = hh * p.s;
     const float* kb = p.k + (int64_t)b * p.k_bstride;
     const float* vb = p.v + (int64_t)b * p.v_bstride;
     const bool kvec = vec4_ok(p.k, p.ldk, p.k_bstride, p.s), vvec = vec4_ok(p.v, p.ldv, p.v_bstride, p.s);
 
-    float q[S], o[S];
-    load_vec<S>(q, p.q + (int64_t)b * p.q_bstride + (int64_t)(on ? i : 0) * p.ldq + col0, p.s, on);
+    float q[R][S], o[R][S], m[R], l[R];
 #pragma unroll
-    for (int d = 0; d < S; ++d) { q[d] *= p.scale; o[d] = 0.f; }
-    float m = -INFINITY, l = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const bool on = i0 + r < p.Tq;
+        load_vec<S>(q[r], p.q + (int64_t)b * p.q_bstride + (int64_t)(on ? i0 + r : 0) * p.ldq + col0, p.s, on);
+#pragma unroll
+        for (int d = 0; d < S; ++d) { q[r][d] *= p.scale; o[r][d] = 0.f; }
+        m[r] = -INFINITY, l[r] = 0.f;
+    }
 
     for (int k0 = 0; k0 < p.Tk; k0 += KTILE) {
         const int nt = min(KTILE, p.Tk - k0);
@@ -97,86 +108,115 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         for (int j = threadIdx.x; j < nt; j += blockDim.x) Ms[j] = p.mask ? p.mask[(int64_t)b * p.Tk + k0 + j] : 1;
         __syncthreads();
         for (int j0 = 0; j0 < nt; j0 += KB) {
-            float sc[KB];
-            float mx = -INFINITY;
+            float sc[R][KB], mx[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) mx[r] = -INFINITY;
 #pragma unroll
             for (int jj = 0; jj < KB; ++jj) {
                 const int j = j0 + jj;
-                float a = -INFINITY;
                 if (j < nt) {
                     const float* kr = Ks + j * S;
-                    a = 0.f;
+                    float kv[S];
 #pragma unroll
-                    for (int d = 0; d < S; ++d) a = fmaf(q[d], kr[d], a);
-                    if (!Ms[j]) a = kMaskFill;
+                    for (int d = 0; d < S; ++d) kv[d] = kr[d];
+                    const bool live = Ms[j] != 0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        float a = 0.f;
+#pragma unroll
+                        for (int d = 0; d < S; ++d) a = fmaf(q[r][d], kv[d], a);
+                        a = live ? a : kMaskFill;
+                        sc[r][jj] = a;
+                        mx[r] = fmaxf(mx[r], a);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) sc[r][jj] = -INFINITY;
                 }
-                sc[jj] = a;
-                mx = fmaxf(mx, a);
             }
-            const float mn = fmaxf(m, mx);
-            const float alpha = __expf(m - mn);
-            l *= alpha;
+            float mn[R];
 #pragma unroll
-            for (int d = 0; d < S; ++d) o[d] *= alpha;
+            for (int r = 0; r < R; ++r) {
+                mn[r] = fmaxf(m[r], mx[r]);
+                const float alpha = __expf(m[r] - mn[r]);
+                l[r] *= alpha;
+#pragma unroll
+                for (int d = 0; d < S; ++d) o[r][d] *= alpha;
+                m[r] = mn[r];
+            }
 #pragma unroll
             for (int jj = 0; jj < KB; ++jj) {
                 const int j = j0 + jj;
                 if (j < nt) {
-                    const float pj = __expf(sc[jj] - mn);
-                    l += pj;
                     const float* vr = Vs + j * S;
+                    float vv[S];
 #pragma unroll
-                    for (int d = 0; d < S; ++d) o[d] = fmaf(pj, vr[d], o[d]);
+                    for (int d = 0; d < S; ++d) vv[d] = vr[d];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const float pj = __expf(sc[r][jj] - mn[r]);
+                        l[r] += pj;
+#pragma unroll
+                        for (int d = 0; d < S; ++d) o[r][d] = fmaf(pj, vv[d], o[r][d]);
+                    }
                 }
             }
-            m = mn;
         }
     }
-    if (on) {
-        const float inv = 1.f / l;
-        float* op = p.o + (int64_t)b * p.o_bstride + (int64_t)i * p.ldo + col0;
 #pragma unroll
-        for (int d = 0; d < S; ++d)
-            if (d < p.s) op[d] = o[d] * inv;
-        // (max, log-sum) kept apart: with every key padded the max is -1e7, where one fp32 ulp is 1.0
-        float* st = p.lse + 2 * (((int64_t)b * p.H + hh) * p.Tq + i);
-        st[0] = m;
-        st[1] = __logf(l);
+    for (int r = 0; r < R; ++r) {
+        const int i = i0 + r;
+        if (i < p.Tq) {
+            const float inv = 1.f / l[r];
+            float* op = p.o + (int64_t)b * p.o_bstride + (int64_t)i * p.ldo + col0;
+#pragma unroll
+            for (int d = 0; d < S; ++d)
+                if (d < p.s) op[d] = o[r][d] * inv;
+            // (max, log-sum) kept apart: with every key padded the max is -1e7, where one fp32 ulp is 1.0
+            float* st = p.lse + 2 * (((int64_t)b * p.H + hh) * p.Tq + i);
+            st[0] = m[r];
+            st[1] = __logf(l[r]);
+        }
     }
 }
 
-// lane = query: dQ_i = scale * sum_j dS_ij k_j,  dS_ij = p_ij (dO_i . v_j - delta_i) (0 through masked keys)
-template <int S>
+// lane = R queries: dQ_i = scale * sum_j dS_ij k_j,  dS_ij = p_ij (dO_i . v_j - delta_i) (0 through masked keys)
+template <int S, int R>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
-    constexpr int KTILE = 4096 / S;
-    __shared__ __attribute__((aligned(16))) float Ks[KTILE * S];
-    __shared__ __attribute__((aligned(16))) float Vs[KTILE * S];
-    __shared__ uint8_t Ms[KTILE];
+    // LDS sized by the launch: KTILE = min(4096 / S, keys rounded up to 8) rows each of K and V + the mask bytes
+    extern __shared__ __attribute__((aligned(16))) float attn_smem[];
+    const int KTILE = p.tile_rows;
+    float* Ks = attn_smem;
+    float* Vs = attn_smem + KTILE * S;
+    uint8_t* Ms = reinterpret_cast<uint8_t*>(Vs + KTILE * S);
     const int b = blockIdx.z, hh = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool on = i < p.Tq;
+    const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * R;
     const int col0 = hh * p.s;
     const float* kb = p.k + (int64_t)b * p.k_bstride;
     const float* vb = p.v + (int64_t)b * p.v_bstride;
     const bool kvec = vec4_ok(p.k, p.ldk, p.k_bstride, p.s), vvec = vec4_ok(p.v, p.ldv, p.v_bstride, p.s);
-    const int ii = on ? i : 0;
 
-    float q[S], dO[S], dq[S];
-    load_vec<S>(q, p.q + (int64_t)b * p.q_bstride + (int64_t)ii * p.ldq + col0, p.s, on);
-    load_vec<S>(dO, p.dout + (int64_t)b * p.d_bstride + (int64_t)ii * p.ldd + col0, p.s, on);
-    float delta = 0.f;
-    {
+    float q[R][S], dO[R][S], dq[R][S], delta[R], lse_m[R], lse_l[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bool on = i0 + r < p.Tq;
+        const int ii = on ? i0 + r : 0;
+        load_vec<S>(q[r], p.q + (int64_t)b * p.q_bstride + (int64_t)ii * p.ldq + col0, p.s, on);
+        load_vec<S>(dO[r], p.dout + (int64_t)b * p.d_bstride + (int64_t)ii * p.ldd + col0, p.s, on);
+        delta[r] = 0.f;
         const float* op = p.o + (int64_t)b * p.o_bstride + (int64_t)ii * p.ldo + col0;
 #pragma unroll
         for (int d = 0; d < S; ++d) {
-            if (on && d < p.s) delta = fmaf(dO[d], op[d], delta);
-            q[d] *= p.scale;
-            dq[d] = 0.f;
+            if (on && d < p.s) delta[r] = fmaf(dO[r][d], op[d], delta[r]);
+            q[r][d] *= p.scale;
+            dq[r][d] = 0.f;
         }
+        const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + ii;
+        // a row beyond Tq keeps p = exp(-inf) = 0
+        lse_m[r] = on ? p.lse[2 * stat] : INFINITY;
+        lse_l[r] = on ? p.lse[2 * stat + 1] : 0.f;
+        if (on) p.delta[stat] = delta[r];
     }
-    const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + ii;
-    const float lse_m = on ? p.lse[2 * stat] : 0.f, lse_l = on ? p.lse[2 * stat + 1] : 0.f;
-    if (on) p.delta[stat] = delta;
 
     for (int k0 = 0; k0 < p.Tk; k0 += KTILE) {
         const int nt = min(KTILE, p.Tk - k0);
@@ -189,47 +229,64 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
             if (!Ms[j]) continue;  // masked_fill: no gradient flows to q / k through a padded key
             const float* kr = Ks + j * S;
             const float* vr = Vs + j * S;
-            float a = 0.f, dp = 0.f;
+            float kv[S], vv[S];
 #pragma unroll
-            for (int d = 0; d < S; ++d) {
-                a = fmaf(q[d], kr[d], a);
-                dp = fmaf(dO[d], vr[d], dp);
+            for (int d = 0; d < S; ++d) kv[d] = kr[d], vv[d] = vr[d];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float a = 0.f, dp = 0.f;
+#pragma unroll
+                for (int d = 0; d < S; ++d) {
+                    a = fmaf(q[r][d], kv[d], a);
+                    dp = fmaf(dO[r][d], vv[d], dp);
+                }
+                const float ds = __expf((a - lse_m[r]) - lse_l[r]) * (dp - delta[r]);
+#pragma unroll
+                for (int d = 0; d < S; ++d) dq[r][d] = fmaf(ds, kv[d], dq[r][d]);
             }
-            const float ds = __expf((a - lse_m) - lse_l) * (dp - delta);
-#pragma unroll
-            for (int d = 0; d < S; ++d) dq[d] = fmaf(ds, kr[d], dq[d]);
         }
     }
-    if (on) {
-        float* out = p.dq + (int64_t)b * p.dq_bstride + (int64_t)i * p.lddq + col0;
 #pragma unroll
-        for (int d = 0; d < S; ++d)
-            if (d < p.s) out[d] = dq[d] * p.scale;
+    for (int r = 0; r < R; ++r) {
+        const int i = i0 + r;
+        if (i < p.Tq) {
+            float* out = p.dq + (int64_t)b * p.dq_bstride + (int64_t)i * p.lddq + col0;
+#pragma unroll
+            for (int d = 0; d < S; ++d)
+                if (d < p.s) out[d] = dq[r][d] * p.scale;
+        }
     }
 }
 
-// lane = key: dV_j = sum_i p_ij dO_i ;  dK_j = scale * sum_i dS_ij q_i  (0 for a padded key)
-template <int S>
+// lane = R keys: dV_j = sum_i p_ij dO_i ;  dK_j = scale * sum_i dS_ij q_i  (0 for a padded key)
+template <int S, int R>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
-    constexpr int QTILE = 4096 / S;
-    __shared__ __attribute__((aligned(16))) float Qs[QTILE * S];
-    __shared__ __attribute__((aligned(16))) float Ds[QTILE * S];
-    __shared__ float Lm[QTILE], Ll[QTILE], Dl[QTILE];
+    extern __shared__ __attribute__((aligned(16))) float attn_smem[];
+    const int QTILE = p.tile_rows;
+    float* Qs = attn_smem;
+    float* Ds = attn_smem + QTILE * S;
+    float* Lm = Ds + QTILE * S;
+    float* Ll = Lm + QTILE;
+    float* Dl = Ll + QTILE;
     const int b = blockIdx.z, hh = blockIdx.y;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool on = j < p.Tk;
+    const int j0 = (blockIdx.x * blockDim.x + threadIdx.x) * R;
     const int col0 = hh * p.s;
-    const int jj = on ? j : 0;
     const float* qb = p.q + (int64_t)b * p.q_bstride;
     const float* db = p.dout + (int64_t)b * p.d_bstride;
     const bool qvec = vec4_ok(p.q, p.ldq, p.q_bstride, p.s), dvec = vec4_ok(p.dout, p.ldd, p.d_bstride, p.s);
 
-    float k[S], v[S], dk[S], dv[S];
-    load_vec<S>(k, p.k + (int64_t)b * p.k_bstride + (int64_t)jj * p.ldk + col0, p.s, on);
-    load_vec<S>(v, p.v + (int64_t)b * p.v_bstride + (int64_t)jj * p.ldv + col0, p.s, on);
+    float k[R][S], v[R][S], dk[R][S], dv[R][S];
+    bool keep[R], on[R];
 #pragma unroll
-    for (int d = 0; d < S; ++d) { k[d] *= p.scale; dk[d] = 0.f; dv[d] = 0.f; }
-    const bool keep = on && (p.mask ? p.mask[(int64_t)b * p.Tk + jj] != 0 : true);
+    for (int r = 0; r < R; ++r) {
+        on[r] = j0 + r < p.Tk;
+        const int jj = on[r] ? j0 + r : 0;
+        load_vec<S>(k[r], p.k + (int64_t)b * p.k_bstride + (int64_t)jj * p.ldk + col0, p.s, on[r]);
+        load_vec<S>(v[r], p.v + (int64_t)b * p.v_bstride + (int64_t)jj * p.ldv + col0, p.s, on[r]);
+#pragma unroll
+        for (int d = 0; d < S; ++d) { k[r][d] *= p.scale; dk[r][d] = 0.f; dv[r][d] = 0.f; }
+        keep[r] = on[r] && (p.mask ? p.mask[(int64_t)b * p.Tk + jj] != 0 : true);
+    }
 
     for (int q0 = 0; q0 < p.Tq; q0 += QTILE) {
         const int nt = min(QTILE, p.Tq - q0);
@@ -246,32 +303,40 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
         for (int t = 0; t < nt; ++t) {
             const float* qr = Qs + t * S;
             const float* dr = Ds + t * S;
-            float a = 0.f, dp = 0.f;
+            float qv[S], dvv[S];
 #pragma unroll
-            for (int d = 0; d < S; ++d) {
-                a = fmaf(qr[d], k[d], a);
-                dp = fmaf(dr[d], v[d], dp);
-            }
-            if (!keep) a = kMaskFill;
-            const float pr = __expf((a - Lm[t]) - Ll[t]);
+            for (int d = 0; d < S; ++d) qv[d] = qr[d], dvv[d] = dr[d];
+            const float lm = Lm[t], ll = Ll[t], dl = Dl[t];
 #pragma unroll
-            for (int d = 0; d < S; ++d) dv[d] = fmaf(pr, dr[d], dv[d]);
-            if (keep) {
-                const float ds = pr * (dp - Dl[t]);
+            for (int r = 0; r < R; ++r) {
+                float a = 0.f, dp = 0.f;
 #pragma unroll
-                for (int d = 0; d < S; ++d) dk[d] = fmaf(ds, qr[d], dk[d]);
+                for (int d = 0; d < S; ++d) {
+                    a = fmaf(qv[d], k[r][d], a);
+                    dp = fmaf(dvv[d], v[r][d], dp);
+                }
+                if (!keep[r]) a = kMaskFill;
+                const float pr = __expf((a - lm) - ll);
+#pragma unroll
+                for (int d = 0; d < S; ++d) dv[r][d] = fmaf(pr, dvv[d], dv[r][d]);
+                const float ds = keep[r] ? pr * (dp - dl) : 0.f;
+#pragma unroll
+                for (int d = 0; d < S; ++d) dk[r][d] = fmaf(ds, qv[d], dk[r][d]);
             }
         }
     }
-    if (on) {
-        float* ok = p.dk + (int64_t)b * p.dk_bstride + (int64_t)j * p.lddk + col0;
-        float* ov = p.dv + (int64_t)b * p.dv_bstride + (int64_t)j * p.lddv + col0;
 #pragma unroll
-        for (int d = 0; d < S; ++d)
-            if (d < p.s) {
-                ok[d] = dk[d] * p.scale;
-                ov[d] = dv[d];
-            }
+    for (int r = 0; r < R; ++r) {
+        if (on[r]) {
+            float* ok = p.dk + (int64_t)b * p.dk_bstride + (int64_t)(j0 + r) * p.lddk + col0;
+            float* ov = p.dv + (int64_t)b * p.dv_bstride + (int64_t)(j0 + r) * p.lddv + col0;
+#pragma unroll
+            for (int d = 0; d < S; ++d)
+                if (d < p.s) {
+                    ok[d] = dk[r][d] * p.scale;
+                    ov[d] = dv[r][d];
+                }
+        }
     }
 }
 
@@ -301,14 +366,25 @@ static int pad_head(int s) {
 }
 static unsigned block_for(int t) { return (unsigned)std::min(256, (t + 63) / 64 * 64); }
 
-#define MSN_ATTN_DISPATCH(KERNEL, S, grid, block, st, args)                                   \
-    switch (S) {                                                                              \
-        case 4: hipLaunchKernelGGL((KERNEL<4>), grid, block, 0, st, args); break;             \
-        case 8: hipLaunchKernelGGL((KERNEL<8>), grid, block, 0, st, args); break;             \
-        case 16: hipLaunchKernelGGL((KERNEL<16>), grid, block, 0, st, args); break;           \
-        case 32: hipLaunchKernelGGL((KERNEL<32>), grid, block, 0, st, args); break;           \
-        case 64: hipLaunchKernelGGL((KERNEL<64>), grid, block, 0, st, args); break;           \
-        default: hipLaunchKernelGGL((KERNEL<128>), grid, block, 0, st, args); break;          \
+// rows per lane: 4 for narrow heads once the sequence would fill more than two waves at one row per lane
+static int rows_per_lane(int S, int t) { return t <= 128 ? 1 : (S <= 8 ? 4 : (S == 16 ? 2 : 1)); }
+#define MSN_ATTN_DISPATCH(KERNEL, S, R, grid, block, lds, st, args)                                   \
+    switch (S) {                                                                                 \
+        case 4:                                                                                  \
+            if (R == 4) hipLaunchKernelGGL((KERNEL<4, 4>), grid, block, lds, st, args);            \
+            else hipLaunchKernelGGL((KERNEL<4, 1>), grid, block, lds, st, args);                   \
+            break;                                                                               \
+        case 8:                                                                                  \
+            if (R == 4) hipLaunchKernelGGL((KERNEL<8, 4>), grid, block, lds, st, args);            \
+            else hipLaunchKernelGGL((KERNEL<8, 1>), grid, block, lds, st, args);                   \
+            break;                                                                               \
+        case 16:                                                                                 \
+            if (R == 2) hipLaunchKernelGGL((KERNEL<16, 2>), grid, block, lds, st, args);           \
+            else hipLaunchKernelGGL((KERNEL<16, 1>), grid, block, lds, st, args);                  \
+            break;                                                                               \
+        case 32: hipLaunchKernelGGL((KERNEL<32, 1>), grid, block, lds, st, args); break;           \
+        case 64: hipLaunchKernelGGL((KERNEL<64, 1>), grid, block, lds, st, args); break;           \
+        default: hipLaunchKernelGGL((KERNEL<128, 1>), grid, block, lds, st, args); break;          \
     }
 
 static int check_attn(const char* who, int B, int H, int Tq, int Tk, int s) {
@@ -343,9 +419,12 @@ extern "C" int msn_attention_fwd(const float* q, int64_t ldq, int64_t q_bstride,
         if (mattn_applicable(m) && (head_dim >= 16 || g_attn_path == 2)) return mattn_forward(m, st);
     }
     const int S = pad_head(head_dim);
-    const unsigned bs = block_for(Tq);
-    const dim3 grid((unsigned)cdiv(Tq, bs), H, B), block(bs);
-    MSN_ATTN_DISPATCH(attn_fwd_kernel, S, grid, block, st, a)
+    const int R = rows_per_lane(S, Tq);
+    const unsigned bs = block_for((int)cdiv(Tq, R));
+    const dim3 grid((unsigned)cdiv(Tq, (int64_t)bs * R), H, B), block(bs);
+    a.tile_rows = std::min(4096 / S, (Tk + 7) / 8 * 8);
+    const size_t lds = sizeof(float) * 2 * (size_t)a.tile_rows * S + (size_t)a.tile_rows;
+    MSN_ATTN_DISPATCH(attn_fwd_kernel, S, R, grid, block, lds, st, a)
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }
@@ -386,15 +465,21 @@ extern "C" int msn_attention_bwd(const float* q, int64_t ldq, int64_t q_bstride,
     }
     const int S = pad_head(head_dim);
     {
-        const unsigned bs = block_for(Tq);
-        const dim3 grid((unsigned)cdiv(Tq, bs), H, B), block(bs);
-        MSN_ATTN_DISPATCH(attn_bwd_dq_kernel, S, grid, block, st, a)
+        const int R = rows_per_lane(S, Tq);
+        const unsigned bs = block_for((int)cdiv(Tq, R));
+        const dim3 grid((unsigned)cdiv(Tq, (int64_t)bs * R), H, B), block(bs);
+        a.tile_rows = std::min(4096 / S, (Tk + 7) / 8 * 8);
+        const size_t lds = sizeof(float) * 2 * (size_t)a.tile_rows * S + (size_t)a.tile_rows;
+        MSN_ATTN_DISPATCH(attn_bwd_dq_kernel, S, R, grid, block, lds, st, a)
         MSN_LAUNCH_CHECK();
     }
     {
-        const unsigned bs = block_for(Tk);
-        const dim3 grid((unsigned)cdiv(Tk, bs), H, B), block(bs);
-        MSN_ATTN_DISPATCH(attn_bwd_dkv_kernel, S, grid, block, st, a)
+        const int R = rows_per_lane(S, Tk);
+        const unsigned bs = block_for((int)cdiv(Tk, R));
+        const dim3 grid((unsigned)cdiv(Tk, (int64_t)bs * R), H, B), block(bs);
+        a.tile_rows = std::min(4096 / S, (Tq + 7) / 8 * 8);
+        const size_t lds = sizeof(float) * (2 * (size_t)a.tile_rows * S + 3 * (size_t)a.tile_rows);
+        MSN_ATTN_DISPATCH(attn_bwd_dkv_kernel, S, R, grid, block, lds, st, a)
         MSN_LAUNCH_CHECK();
     }
     return MSN_OK;
