@@ -547,21 +547,42 @@ int launch_tail_finish(const GemmArgs& a, int bn, int waves, hipStream_t st) {
     return MSN_OK;
 }
 
-// C[m][n] = sum_s partial[s][m][n]   (split-K finish; fixed order -> deterministic).  A block covers 64
-// consecutive outputs with 4 thread groups that each sum a quarter of the slabs, combined through LDS.
+// C[m][n] = sum_s partial[s][m][n]   (split-K finish; fixed order -> deterministic).  A block covers 64 x V
+// consecutive outputs (V = 4: one 16-byte load per slab and lane when N and ldc allow, else V = 1) with 4 thread
+// groups that each sum a quarter of the slabs, combined through LDS.
+template <int V>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C,
                                                             int64_t M, int64_t N, int64_t ldc, int splits) {
-    __shared__ float red[4][64];
+    __shared__ float red[4][64 * V];
     const int64_t total = M * N;
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
-    for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {
-        const int64_t i = base + cl;
-        float s = 0.f;
-        if (i < total)
-            for (int k = g; k < splits; k += 4) s += partial[(int64_t)k * total + i];
-        red[g][cl] = s;
+    for (int64_t base = (int64_t)blockIdx.x * 64 * V; base < total; base += (int64_t)gridDim.x * 64 * V) {
+        const int64_t i = base + (int64_t)cl * V;
+        float s[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) s[v] = 0.f;
+        if (i < total) {
+            for (int k = g; k < splits; k += 4) {
+                if (V == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(partial + (int64_t)k * total + i);
+                    s[0] += t.x, s[1 % V] += t.y, s[2 % V] += t.z, s[3 % V] += t.w;
+                } else {
+                    s[0] += partial[(int64_t)k * total + i];
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) red[g][cl * V + v] = s[v];
         __syncthreads();
-        if (g == 0 && i < total) C[(i / N) * ldc + (i % N)] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        if (g == 0 && i < total) {
+            float t[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+                t[v] = (red[0][cl * V + v] + red[1][cl * V + v]) + (red[2][cl * V + v] + red[3][cl * V + v]);
+            float* out = C + (i / N) * ldc + (i % N);
+            if (V == 4) *reinterpret_cast<float4*>(out) = make_float4(t[0], t[1 % V], t[2 % V], t[3 % V]);
+            else out[0] = t[0];
+        }
         __syncthreads();
     }
 }
@@ -824,8 +845,15 @@ static int sgemm_impl(int opA, int opB, int64_t M, int64_t N, int64_t K, const f
     }
     if (splits > 1) {
         const int64_t total = M * N;
-        const int blocks = (int)std::min<int64_t>(cdiv(total, 64), 4096);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.partial, C, M, N, ldc, splits);
+        // 16-byte path: a group of 4 outputs never straddles a row (N % 4 == 0) and C rows stay 16-byte aligned
+        const bool v4 = N % 4 == 0 && ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+        if (v4) {
+            const int blocks = (int)std::min<int64_t>(cdiv(total, 256), 4096);
+            hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, a.partial, C, M, N, ldc, splits);
+        } else {
+            const int blocks = (int)std::min<int64_t>(cdiv(total, 64), 4096);
+            hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, st, a.partial, C, M, N, ldc, splits);
+        }
         MSN_LAUNCH_CHECK();
         if (fuse_colsum) {
             hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(M, CS_COLS)), dim3(256), 0, st, a.colsum,

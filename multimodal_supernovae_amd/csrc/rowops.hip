@@ -4,6 +4,7 @@
 // wave-shuffle reductions; column reductions (d gamma, d beta, d embedding weights) are
 // block partials in caller scratch + a fixed-order final pass (deterministic, no atomics).
 #include <algorithm>
+#include <cstdlib>
 #include <math.h>
 
 #include "msn_common.h"
@@ -150,19 +151,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
-// out[i] = sum_b part[b][i], i < n : 4 slab groups x 64 columns per block, LDS-combined
-__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ part, int nslabs, int n,
-                                                        float* __restrict__ out0, float* __restrict__ out1, int split) {
-    __shared__ float red[4][64];
+// out[i] = sum_b part[b][i], i < n : 16 slab groups x 64 columns per block (each thread keeps 4 independent loads
+// in flight), LDS-combined in a fixed order
+__global__ __launch_bounds__(1024) void sum_slabs_kernel(const float* __restrict__ part, int nslabs, int n,
+                                                         float* __restrict__ out0, float* __restrict__ out1, int split) {
+    __shared__ float red[16][64];
     const int cl = threadIdx.x % 64, g = threadIdx.x / 64;
     const int i = blockIdx.x * 64 + cl;
-    float s = 0.f;
-    if (i < n)
-        for (int b = g; b < nslabs; b += 4) s += part[(int64_t)b * n + i];
-    red[g][cl] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+        int b = g;
+        for (; b + 48 < nslabs; b += 64) {
+            s0 += part[(int64_t)b * n + i];
+            s1 += part[(int64_t)(b + 16) * n + i];
+            s2 += part[(int64_t)(b + 32) * n + i];
+            s3 += part[(int64_t)(b + 48) * n + i];
+        }
+        for (; b < nslabs; b += 16) s0 += part[(int64_t)b * n + i];
+    }
+    red[g][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (g == 0 && i < n) {
-        const float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
         if (i < split) out0[i] = t;
         else out1[i - split] = t;
     }
@@ -543,7 +555,8 @@ static int ln_grid(int64_t rows, int lpr) {
     return (int)std::min<int64_t>(cdiv(rows, 256 / lpr), 2048);
 }
 static int ln_bwd_grid(int64_t rows, int lpr) {
-    return (int)std::min<int64_t>(cdiv(rows, 4 * (256 / lpr)), 256);
+    // 2 workgroups per CU (8 waves): measured optimum with the 16-group slab sum behind it (tools/bench_rowops.py)
+    return (int)std::min<int64_t>(cdiv(rows, 4 * (256 / lpr)), 512);
 }
 
 }  // namespace msn
@@ -585,7 +598,7 @@ extern "C" int msn_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
     const size_t lds = sizeof(float) * 2 * (size_t)cols * (256 / lpr);
     MSN_LPR_DISPATCH(ln_bwd_kernel, lpr, dim3(grid), lds, st, dy, lddy, x, ldx, g, mean, rstd, gamma, dx, lddx, part, add, ldadd)
     MSN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)cdiv(2 * cols, 64)), dim3(256), 0, st, part, grid, 2 * cols,
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)cdiv(2 * cols, 64)), dim3(1024), 0, st, part, grid, 2 * cols,
                        dgamma, dbeta, cols);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
