@@ -457,6 +457,10 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void sgemm_dma_kernel(c
 #undef MSN_MFMA_SWEEP
         __builtin_amdgcn_sched_barrier(0);
     };
+#ifdef MSN_TIMELINE
+    unsigned long long w_lds = 0, w_vm = 0, w_bar = 0;
+    const unsigned long long tl0 = __builtin_readcyclecounter();
+#endif
     int slot = 0;
     if (nkt > 0) request(S0{}, 0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
@@ -470,10 +474,23 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void sgemm_dma_kernel(c
                 multiply(S1{}, true);
             } else {
                 const bool has_next = kt + 1 < nkt;
+#if MSN_TIMELINE >= 2
+                const unsigned long long ta = __builtin_readcyclecounter();
+#endif
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all fragment reads of this K-step are in
+#if MSN_TIMELINE >= 2
+                const unsigned long long tb = __builtin_readcyclecounter();
+#endif
                 if (kt + STAGES - 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if MSN_TIMELINE >= 2
+                const unsigned long long tcc = __builtin_readcyclecounter();
+#endif
                 __builtin_amdgcn_s_barrier();
+#if MSN_TIMELINE >= 2
+                const unsigned long long td = __builtin_readcyclecounter();
+                w_lds += tb - ta, w_vm += tcc - tb, w_bar += td - tcc;
+#endif
                 if (kt + STAGES < nkt) issue(kt + STAGES);           // into `slot`
                 if (has_next) request(S0{}, next_slot, 0);
                 multiply(S1{}, has_next);
@@ -483,6 +500,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void sgemm_dma_kernel(c
     }
 #ifdef MSN_TIMELINE
     const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long tl2 = __builtin_readcyclecounter();
 #endif
     if constexpr (CSUM) {
         if (wn0 == 0 && logical % p.tiles_n == 0) {   // one wave column of the first tile column owns each row
@@ -500,10 +518,11 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void sgemm_dma_kernel(c
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
     if (p.dbg && threadIdx.x == 0) {
-        unsigned long long* d = p.dbg + (size_t)blockIdx.x * 6;
+        unsigned long long* d = p.dbg + (size_t)blockIdx.x * 10;
         d[0] = t0, d[1] = t1, d[2] = t2, d[3] = t3;
         d[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));      // HW_ID
         d[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));     // XCC_ID
+        d[6] = w_lds, d[7] = w_vm, d[8] = w_bar, d[9] = tl2 - tl0;   // shader-clock cycles inside the K loop
     }
 #endif
 }

@@ -2,7 +2,7 @@
 """Per-workgroup timeline of one msn_sgemm launch (diagnostic build: csrc/gemm.hip compiled with -DMSN_TIMELINE
 into tools/microbench/ablate/libmsn_timeline.so).  Prints where a tile's time goes: start -> first K-step landed ->
 K loop done -> stores acknowledged, and how the workgroups spread over XCDs / CUs / rounds.
-usage: MSN_HIP_LIB=.../libmsn_timeline.so python tools/microbench/gemm_timeline.py M N K opA opB"""
+usage: MSN_HIP_LIB=.../libmsn_timeline.so python tools/microbench/gemm_timeline.py M N K opA opB [warm-up launches]"""
 import ctypes
 import os
 import sys
@@ -18,20 +18,31 @@ L = _lib.lib()
 L.msn_debug_timeline.restype = ctypes.c_int
 L.msn_debug_timeline.argtypes = [ctypes.c_void_p]
 nblk = 1 << 16
-dbg = torch.zeros(nblk * 6, dtype=torch.int64, device="cuda")
-for _ in range(3):
+dbg = torch.zeros(nblk * 10, dtype=torch.int64, device="cuda")
+warm = int(sys.argv[6]) if len(sys.argv) > 6 else 3      # launches before the recorded one (sustained-load clock)
+for _ in range(warm):
     ops.sgemm(a, b, oa, ob)
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    ops.sgemm(a, b, oa, ob)
+e1.record()
+torch.cuda.synchronize()
+print(f"{2.0 * M * N * K * 20 / e0.elapsed_time(e1) / 1e9:.1f} TFLOP/s over 20 launches after {warm} warm-up launches")
 L.msn_debug_timeline(dbg.data_ptr())
 ops.sgemm(a, b, oa, ob)
 torch.cuda.synchronize()
 L.msn_debug_timeline(None)
-d = dbg.cpu().numpy().reshape(-1, 6)
+d = dbg.cpu().numpy().reshape(-1, 10)
 d = d[d[:, 0] != 0]
 t = (d[:, :4] - d[:, 0].min()) * 0.01          # us (100 MHz)
 hw, xcc = d[:, 4], d[:, 5] & 0xF
 cu, se = (hw >> 8) & 0xF, (hw >> 13) & 0x7
 print(f"{len(d)} workgroups; kernel span {t[:, 3].max():.1f} us")
+loop = d[:, 9].astype(float)
+print(f"core clock inside the K loop: {(loop / ((d[:,2] - d[:,1]) * 10.0)).mean():.3f} GHz (s_memtime / s_memrealtime)")
+print(f"wave 0 inside the K loop: {loop.mean():.0f} cycles; waiting for fragments {100 * (d[:,6] / loop).mean():.1f} %, for its LDS-DMA pieces {100 * (d[:,7] / loop).mean():.1f} %, at the barrier {100 * (d[:,8] / loop).mean():.1f} %")
 print(f"mean per workgroup: prologue {np.mean(t[:,1]-t[:,0]):.2f} us | K loop {np.mean(t[:,2]-t[:,1]):.2f} us | epilogue {np.mean(t[:,3]-t[:,2]):.2f} us")
 order = np.argsort(t[:, 0])
 starts = t[order, 0]
