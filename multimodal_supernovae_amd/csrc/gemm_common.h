@@ -48,19 +48,21 @@ struct TileCoord {
     int logical, split, tail_slab;   // tail_slab < 0: regular workgroup
     int64_t k_begin, k_end;
 };
-__device__ __forceinline__ TileCoord locate_tile(const GemmArgs& p) {
+// `w` = position in the launch-order list of workgroups (blockIdx.x for one workgroup per item; a persistent
+// workgroup walks w = blockIdx.x, + gridDim.x, ... -- gridDim.x is a multiple of 8, so it stays on its XCD's run).
+__device__ __forceinline__ TileCoord locate_tile(const GemmArgs& p, int w) {
     const int nreg = p.tiles_m * p.tiles_n - p.tail_tiles;
     const int regular = nreg * p.splits;
     TileCoord c;
-    if ((int)blockIdx.x < regular) {
-        const int flat = xcd_remap(blockIdx.x, regular);
+    if (w < regular) {
+        const int flat = xcd_remap(w, regular);
         c.logical = flat % nreg;
         c.split = flat / nreg;
         c.tail_slab = -1;
         c.k_begin = (int64_t)c.split * p.k_per_split;
         c.k_end = min(p.K, c.k_begin + (int64_t)p.k_per_split);
     } else {
-        const int t = (int)blockIdx.x - regular;
+        const int t = w - regular;
         c.logical = nreg + t / p.tail_splits;
         c.split = t % p.tail_splits;
         c.tail_slab = t;
@@ -68,6 +70,10 @@ __device__ __forceinline__ TileCoord locate_tile(const GemmArgs& p) {
         c.k_end = min(p.K, c.k_begin + (int64_t)p.tail_kps);
     }
     return c;
+}
+__device__ __forceinline__ TileCoord locate_tile(const GemmArgs& p) { return locate_tile(p, (int)blockIdx.x); }
+__device__ __forceinline__ int work_items(const GemmArgs& p) {
+    return (p.tiles_m * p.tiles_n - p.tail_tiles) * p.splits + p.tail_tiles * p.tail_splits;
 }
 
 // Accumulators of one tail K-slab, in register order (every store instruction writes 256 contiguous bytes).
