@@ -22,7 +22,7 @@ def load(root, name):
             k = k.replace("void ", "")
             keys = [k]
             if "sgemm_kernel" in k or "sgemm_dma_kernel" in k:      # per template instance (layout = the two bools) and the aggregate row
-                keys.append("msn::sgemm_kernel<*>")
+                keys.append("msn::sgemm_*_kernel<*>")
             for k in keys:
                 e = d[k][r["Counter_Name"]]
                 e[0] += 1
@@ -53,7 +53,7 @@ def main():
                       "clock_ghz": clock}
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines[:12]))
-    g = summary.get("msn::sgemm_kernel<*>")
+    g = summary.get("msn::sgemm_*_kernel<*>")
     if g:
         json.dump({"kernel": "msn::sgemm_dma_kernel + msn::sgemm_kernel", "traffic_bytes_per_launch": g["traffic_bytes_per_launch"],
                    "mfma_busy_fraction": g["mfma_util"], "effective_clock_ghz": g["clock_ghz"], "launches": g["launches"],
