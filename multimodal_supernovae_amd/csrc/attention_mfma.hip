@@ -44,12 +44,22 @@ struct MAttn {
 template <int HD>
 __device__ __forceinline__ void stage(float* dst, const float* __restrict__ src, int64_t ld, int col0, int T, int TP,
                                       int hd) {
-    constexpr int LS = HD + 4, Q4 = HD / 4;
-    for (int idx = threadIdx.x; idx < TP * Q4; idx += blockDim.x) {
-        const int r = idx / Q4, c = 4 * (idx % Q4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < T && c < hd) v = *reinterpret_cast<const float4*>(src + (int64_t)r * ld + col0 + c);
-        *reinterpret_cast<float4*>(dst + r * LS + c) = v;
+    constexpr int LS = HD + 4, Q4 = HD / 4, U = 4;   // U independent 16-byte loads in flight per thread
+    const int total = TP * Q4;
+    for (int base = threadIdx.x; base < total; base += U * blockDim.x) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * blockDim.x;
+            const int r = idx / Q4, c = 4 * (idx % Q4);
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < total && r < T && c < hd) v[u] = *reinterpret_cast<const float4*>(src + (int64_t)r * ld + col0 + c);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * blockDim.x;
+            if (idx < total) *reinterpret_cast<float4*>(dst + (idx / Q4) * LS + 4 * (idx % Q4)) = v[u];
+        }
     }
 }
 // fragments of one 16-row tile held by this wave as the B operand: row = lane & 15, d = 16x + 4g + j
@@ -123,29 +133,61 @@ __global__ __launch_bounds__(1024) void mattn_fwd_kernel(const MAttn p) {
     const int nkt = TPk / 16;
 
     float m = -INFINITY;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const f32x4 s = score16<HD>(Ks + kt * 16 * LS, qf, c, g);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = 16 * kt + 4 * g + r;
-            if (key < p.Tk) m = fmaxf(m, Ms[key] ? s[r] : kFill);
-        }
-    }
-    m = group_max4(m);
     f32x4 o[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float l = 0.f;
-    for (int kt = 0; kt < nkt; ++kt) {
-        f32x4 s = score16<HD>(Ks + kt * 16 * LS, qf, c, g);
+    constexpr int KEEP = 8;   // key tiles whose scores fit in registers (4 per tile): sequences up to 128 tokens
+    if (nkt <= KEEP) {
+        // one pass: every score tile is computed once and kept (ViT-S/8 at 64x64: 65 tokens -> 5 tiles)
+        f32x4 sc[KEEP];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = 16 * kt + 4 * g + r;
-            const float e = key < p.Tk ? __expf((Ms[key] ? s[r] : kFill) - m) : 0.f;
-            s[r] = e;
-            l += e;
+        for (int kt = 0; kt < KEEP; ++kt) {
+            if (kt < nkt) {
+                sc[kt] = score16<HD>(Ks + kt * 16 * LS, qf, c, g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = 16 * kt + 4 * g + r;
+                    sc[kt][r] = key < p.Tk ? (Ms[key] ? sc[kt][r] : kFill) : -INFINITY;
+                    m = fmaxf(m, sc[kt][r]);
+                }
+            }
         }
-        accum16<HD>(s, Vs + kt * 16 * LS, o, c, g);
+        m = group_max4(m);
+#pragma unroll
+        for (int kt = 0; kt < KEEP; ++kt) {
+            if (kt < nkt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __expf(sc[kt][r] - m);   // exp(-inf) = 0 for the padded keys
+                    sc[kt][r] = e;
+                    l += e;
+                }
+                accum16<HD>(sc[kt], Vs + kt * 16 * LS, o, c, g);
+            }
+        }
+    } else {
+        // two passes over the key tiles (row maximum, then exponentials + P.V), recomputing the 16x16 score tiles
+        for (int kt = 0; kt < nkt; ++kt) {
+            const f32x4 s = score16<HD>(Ks + kt * 16 * LS, qf, c, g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * kt + 4 * g + r;
+                if (key < p.Tk) m = fmaxf(m, Ms[key] ? s[r] : kFill);
+            }
+        }
+        m = group_max4(m);
+        for (int kt = 0; kt < nkt; ++kt) {
+            f32x4 s = score16<HD>(Ks + kt * 16 * LS, qf, c, g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * kt + 4 * g + r;
+                const float e = key < p.Tk ? __expf((Ms[key] ? s[r] : kFill) - m) : 0.f;
+                s[r] = e;
+                l += e;
+            }
+            accum16<HD>(s, Vs + kt * 16 * LS, o, c, g);
+        }
     }
     l = group_sum4(l);
     // o[t][r] belongs to query q0 + 4g + r: fetch that query's normaliser from its column-owner lane
