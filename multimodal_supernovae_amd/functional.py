@@ -183,10 +183,9 @@ def l2_normalise(x):
 def _attn_forward_raw(x2, B, T, wq, wk, wv, wu, bu, mask_u8, heads, scale, residual):
     """x2: (B*T, e).  Returns z = unify(attn) (+ residual) and what backward needs."""
     M, e = x2.shape
-    qkv = torch.empty((M, 3 * e), dtype=torch.float32, device=x2.device)
-    sgemm(x2, wq, OP_N, OP_T, out=qkv[:, :e])
-    sgemm(x2, wk, OP_N, OP_T, out=qkv[:, e:2 * e])
-    sgemm(x2, wv, OP_N, OP_T, out=qkv[:, 2 * e:])
+    # the three bias-free projections read the same tokens: one product against the stacked (3e, e) weight
+    # (a 3 x e x e copy per call) instead of three passes over x2
+    qkv = sgemm(x2, torch.cat([wq, wk, wv], 0), OP_N, OP_T)
     q3 = qkv.view(B, T, 3 * e)
     a, lse = ops.attention_fwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], mask_u8, heads, scale)
     a2 = a.view(M, e)
@@ -207,15 +206,13 @@ def _attn_backward_raw(dz, x2, B, T, saved, wq, wk, wv, wu, mask_u8, heads, scal
     q3, d3 = qkv.view(B, T, 3 * e), dqkv.view(B, T, 3 * e)
     ops.attention_bwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], mask_u8, heads, scale, a2.view(B, T, e), lse,
                       da.view(B, T, e), d3[..., :e], d3[..., e:2 * e], d3[..., 2 * e:])
-    dq, dk, dv = dqkv[:, :e], dqkv[:, e:2 * e], dqkv[:, 2 * e:]
-    dwq, dwk, dwv = sgemm(dq, x2, OP_T, OP_N), sgemm(dk, x2, OP_T, OP_N), sgemm(dv, x2, OP_T, OP_N)
+    dw = sgemm(dqkv, x2, OP_T, OP_N)                       # stacked (3e, e): rows = dWq | dWk | dWv
+    wcat = torch.cat([wq, wk, wv], 0)
     if add_to is not None:
-        dx = sgemm(dq, wq, OP_N, OP_N, epilogue=EPI_ADD, aux=add_to)
+        dx = sgemm(dqkv, wcat, OP_N, OP_N, epilogue=EPI_ADD, aux=add_to)
     else:
-        dx = sgemm(dq, wq, OP_N, OP_N)
-    sgemm(dk, wk, OP_N, OP_N, epilogue=EPI_ADD, aux=dx, out=dx)
-    sgemm(dv, wv, OP_N, OP_N, epilogue=EPI_ADD, aux=dx, out=dx)
-    return dx, dwq, dwk, dwv, dwu, dbu
+        dx = sgemm(dqkv, wcat, OP_N, OP_N)
+    return dx, dw[:e], dw[e:2 * e], dw[2 * e:], dwu, dbu
 
 
 @_remember_precision
