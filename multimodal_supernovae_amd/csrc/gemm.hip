@@ -569,13 +569,27 @@ int launch_tail_finish(const GemmArgs& a, int bn, int waves, hipStream_t st) {
 // C[m][n] = sum_s partial[s][m][n]   (split-K finish; fixed order -> deterministic).  A block covers 64 x V
 // consecutive outputs (V = 4: one 16-byte load per slab and lane when N and ldc allow, else V = 1) with 4 thread
 // groups that each sum a quarter of the slabs, combined through LDS.
+// The last `cs_blocks` workgroups of the grid (fused bias gradient, msn_wgrad_bias) sum the [splits][M] column-sum
+// slabs instead: 256 rows per workgroup, slabs in order.
 template <int V>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C,
-                                                            int64_t M, int64_t N, int64_t ldc, int splits) {
+                                                            int64_t M, int64_t N, int64_t ldc, int splits,
+                                                            const float* __restrict__ cs_partial,
+                                                            float* __restrict__ cs_out, int cs_blocks) {
     __shared__ float red[4][64 * V];
+    const int main_blocks = (int)gridDim.x - cs_blocks;
+    if ((int)blockIdx.x >= main_blocks) {
+        const int64_t row = (int64_t)((int)blockIdx.x - main_blocks) * 256 + threadIdx.x;
+        if (row < M) {
+            float s = 0.f;
+            for (int k = 0; k < splits; ++k) s += cs_partial[(int64_t)k * M + row];
+            cs_out[row] = s;
+        }
+        return;
+    }
     const int64_t total = M * N;
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
-    for (int64_t base = (int64_t)blockIdx.x * 64 * V; base < total; base += (int64_t)gridDim.x * 64 * V) {
+    for (int64_t base = (int64_t)blockIdx.x * 64 * V; base < total; base += (int64_t)main_blocks * 64 * V) {
         const int64_t i = base + (int64_t)cl * V;
         float s[V];
 #pragma unroll
@@ -866,19 +880,17 @@ static int sgemm_impl(int opA, int opB, int64_t M, int64_t N, int64_t K, const f
         const int64_t total = M * N;
         // 16-byte path: a group of 4 outputs never straddles a row (N % 4 == 0) and C rows stay 16-byte aligned
         const bool v4 = N % 4 == 0 && ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+        const int cs_blocks = fuse_colsum ? (int)cdiv(M, 256) : 0;   // the column-sum slabs ride in the same launch
         if (v4) {
             const int blocks = (int)std::min<int64_t>(cdiv(total, 256), 4096);
-            hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, a.partial, C, M, N, ldc, splits);
+            hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks + cs_blocks), dim3(256), 0, st, a.partial, C, M, N, ldc,
+                               splits, a.colsum, colsum_out, cs_blocks);
         } else {
             const int blocks = (int)std::min<int64_t>(cdiv(total, 64), 4096);
-            hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, st, a.partial, C, M, N, ldc, splits);
+            hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks + cs_blocks), dim3(256), 0, st, a.partial, C, M, N, ldc,
+                               splits, a.colsum, colsum_out, cs_blocks);
         }
         MSN_LAUNCH_CHECK();
-        if (fuse_colsum) {
-            hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(M, CS_COLS)), dim3(256), 0, st, a.colsum,
-                               (int64_t)splits, M, colsum_out);
-            MSN_LAUNCH_CHECK();
-        }
     }
     return MSN_OK;
 }

@@ -222,14 +222,17 @@ __global__ void nce_fwd_finish_kernel(const NceArgs p, float* __restrict__ lse_r
     __syncthreads();
     // rows of S come from side[0].Q (E2), columns from side[1].Q (E1); local row i <-> global q_offset + i
     const int nb = min(p.side[0].nq, p.side[1].nq);
+    // positives: one wave per row (coalesced reads of the two embeddings, wave-shuffle sum), rows dealt to the waves
     float acc = 0.f;
-    for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (int i = wave; i < nb; i += nwaves) {
         if (p.q_offset + i >= p.n_diag) continue;
         const float* a = p.side[0].Q + (int64_t)i * p.side[0].ldq;
         const float* b = p.side[1].Q + (int64_t)i * p.side[1].ldq;
         float dot = 0.f;
-        for (int d = 0; d < D; ++d) dot = fmaf(a[d], b[d], dot);
-        acc += lse_row[i] + lse_col[i] - 2.f * (dot * scale + bias);
+        for (int d = lane; d < D; d += 64) dot = fmaf(a[d], b[d], dot);
+        dot = wave_sum(dot);
+        if (lane == 0) acc += lse_row[i] + lse_col[i] - 2.f * (dot * scale + bias);
     }
     const float tot = block_sum(acc, red);
     if (threadIdx.x == 0) *loss = tot / (2.f * (float)p.n_diag);

@@ -291,31 +291,40 @@ __global__ __launch_bounds__(256) void time_embed_bwd_kernel(const float* __rest
     }
 }
 // dw[c] = sum_b sdx[b][c]; dband[k][c] = sum_b seg[b][k][c]; dbw[c] = sum_k dband[k][c].
-// One block per 64 columns; its 4 thread groups each sum a quarter of the samples (fixed order), LDS-combined.
-__global__ __launch_bounds__(256) void time_embed_bwd_finish_kernel(const float* __restrict__ seg,
-                                                                    const float* __restrict__ sdx, int B, int e,
-                                                                    int nband, float* __restrict__ dw,
-                                                                    float* __restrict__ dbw, float* __restrict__ dband) {
-    __shared__ float red[4][64];
+// One block per 64 columns; its 16 thread groups each sum a sixteenth of the samples (fixed order, 4 independent
+// partial sums in flight per thread), LDS-combined.
+__global__ __launch_bounds__(1024) void time_embed_bwd_finish_kernel(const float* __restrict__ seg,
+                                                                     const float* __restrict__ sdx, int B, int e,
+                                                                     int nband, float* __restrict__ dw,
+                                                                     float* __restrict__ dbw, float* __restrict__ dband) {
+    __shared__ float red[16][64];
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
-    auto reduce = [&](float v) {
+    auto column_sum = [&](const float* __restrict__ src, int64_t stride) {   // sum over b of src[b * stride + c]
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (c < e) {
+            int b = g;
+            for (; b + 48 < B; b += 64) {
+                s0 += src[(int64_t)b * stride + c];
+                s1 += src[(int64_t)(b + 16) * stride + c];
+                s2 += src[(int64_t)(b + 32) * stride + c];
+                s3 += src[(int64_t)(b + 48) * stride + c];
+            }
+            for (; b < B; b += 16) s0 += src[(int64_t)b * stride + c];
+        }
         __syncthreads();
-        red[g][cl] = v;
+        red[g][cl] = (s0 + s1) + (s2 + s3);
         __syncthreads();
-        return (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
+        return t;
     };
-    float s = 0.f;
-    if (c < e)
-        for (int b = g; b < B; b += 4) s += sdx[(int64_t)b * e + c];
-    const float sw = reduce(s);
+    const float sw = column_sum(sdx, e);
     if (g == 0 && c < e) dw[c] = sw;
     float sb = 0.f;
     for (int k = 0; k < nband; ++k) {
-        s = 0.f;
-        if (c < e)
-            for (int b = g; b < B; b += 4) s += seg[((int64_t)b * nband + k) * e + c];
-        const float t = reduce(s);
+        const float t = column_sum(seg + (int64_t)k * e, (int64_t)nband * e);
         if (g == 0 && c < e && dband) dband[(int64_t)k * e + c] = t;
         sb += t;
     }
@@ -661,7 +670,7 @@ extern "C" int msn_time_embed_bwd(const float* dy, const float* x, int64_t B, in
     const size_t lds = sizeof(float) * (256 / cpt) * cpt;
     hipLaunchKernelGGL(time_embed_bwd_kernel, dim3((unsigned)B), dim3(256), lds, st, dy, x, T, e, nband, seg, sdx);
     MSN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(time_embed_bwd_finish_kernel, dim3((unsigned)cdiv(e, 64)), dim3(256), 0, st, seg, sdx, (int)B, e,
+    hipLaunchKernelGGL(time_embed_bwd_finish_kernel, dim3((unsigned)cdiv(e, 64)), dim3(1024), 0, st, seg, sdx, (int)B, e,
                        nband, dw, dbw, nband > 1 ? dband : nullptr);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
