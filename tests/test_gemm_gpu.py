@@ -22,7 +22,8 @@ SHAPES = [(128, 128, 32), (256, 384, 192), (130, 70, 33), (1, 1, 1), (65, 32, 8)
 PREC_ATOL = {0: 1e-4, 1: 1e-4, 2: 3e-2}
 
 
-@pytest.mark.parametrize("M,N,K", SHAPES + [(260, 200, 100), (500, 136, 36)])
+# the last three take the LDS-DMA kernels (K % 32 == 0, extents % 4 == 0) with ragged edge tiles in M and N
+@pytest.mark.parametrize("M,N,K", SHAPES + [(260, 200, 100), (500, 136, 36), (1000, 136, 64), (132, 260, 96), (4, 68, 32)])
 @pytest.mark.parametrize("op_a,op_b", [(0, 1), (0, 0), (1, 0), (1, 1)])
 @pytest.mark.parametrize("precision", [0, 1, 2])
 def test_sgemm_layouts(M, N, K, op_a, op_b, precision):
