@@ -213,12 +213,13 @@ def main():
     D.broadcast_module(model)
     opt = model.configure_optimizers()["optimizer"]
     params = [p for p in model.parameters()]
+    reducer = D.GradientReducer(params)     # N > 1: bucketed SUM all-reduce launched from autograd hooks, under backward
 
     def step():
         opt.zero_grad(set_to_none=True)
         loss = model.training_step(batch, 0)
         loss.backward()
-        D.allreduce_gradients(params)
+        reducer.finish()
         opt.step()
         return loss
 

@@ -41,6 +41,7 @@ class Trainer:
         D.broadcast_module(model, group=self.group)
         optimizer = model.configure_optimizers()["optimizer"]
         self.optimizer = optimizer
+        reducer = D.GradientReducer(model.parameters(), group=self.group)   # bucket all-reduces run under backward
         for epoch in range(self.max_epochs):
             model.train()
             model.on_train_epoch_start()
@@ -50,7 +51,7 @@ class Trainer:
                 optimizer.zero_grad(set_to_none=True)
                 loss = model.training_step(batch, batch_idx)
                 loss.backward()
-                D.allreduce_gradients(model.parameters(), group=self.group)
+                reducer.finish()
                 optimizer.step()
                 losses.append(loss.detach())
                 self.global_step += 1
@@ -70,4 +71,5 @@ class Trainer:
                     self.history["val_loss"].append(float(torch.stack(vlosses).mean()))
             if self.log_fn:
                 self.log_fn(epoch, {k: v[-1] for k, v in self.history.items() if v})
+        reducer.remove()
         return self

@@ -97,3 +97,64 @@ def test_global_negatives_two_ranks_gloo(n_mod):
         p.join(180)
         assert p.exitcode == 0, f"rank exited with {p.exitcode}"
     assert dict(out) == {0: True, 1: True}
+
+
+def _reducer_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from multimodal_supernovae_amd import distributed as D
+    torch.set_num_threads(1)
+    D.init_from_env(backend="gloo")
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(),
+                              torch.nn.Linear(16, 4))
+    unused = torch.nn.Parameter(torch.ones(3))                 # never reached by backward: contributes zeros
+    params = list(net.parameters()) + [unused]
+    D.broadcast_module(net)
+    import copy
+    ref_net = copy.deepcopy(net)                               # hook-free twin for the single-process gradients
+    g = torch.Generator().manual_seed(11)
+    x_all = torch.randn(world * 5, 7, generator=g)
+    ok = True
+    reducer = D.GradientReducer(params, bucket_bytes=300)      # several small buckets
+    ok = ok and len(reducer.buckets) >= 3
+    for step in range(3):                                      # the flat buffers are reused step after step
+        for p in params:
+            p.grad = None
+        (net(x_all[rank * 5:(rank + 1) * 5] * (step + 1)).square().sum()).backward()
+        reducer.finish()
+        got = [p.grad.clone() for p in params]
+        ref_net.zero_grad(set_to_none=True)
+        (ref_net(x_all * (step + 1)).square().sum()).backward()    # single-process gradient over the global batch
+        for gp, p in zip(got[:-1], ref_net.parameters()):
+            ok = ok and torch.allclose(gp, p.grad, rtol=1e-4, atol=1e-5)
+        ok = ok and bool((got[-1] == 0).all())
+    # the after-backward form gives the same sums
+    for p in params:
+        p.grad = None
+    reducer.remove()
+    (net(x_all[rank * 5:(rank + 1) * 5]).square().sum()).backward()
+    D.allreduce_gradients(params, bucket_bytes=300)
+    ref = [p.grad.clone() for p in params]
+    ref_net.zero_grad(set_to_none=True)
+    (ref_net(x_all).square().sum()).backward()
+    for gp, p in zip(ref[:-1], ref_net.parameters()):
+        ok = ok and torch.allclose(gp, p.grad, rtol=1e-4, atol=1e-5)
+    out[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_gradient_reducer_two_ranks_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    assert dict(out) == {0: True, 1: True}

@@ -40,9 +40,10 @@ def worker(rank, world, port, out):
     local = tuple(t[rank * b:(rank + 1) * b].cuda() if t is not None else None for t in full)
     model = make_model()
     D.broadcast_module(model)
+    reducer = D.GradientReducer(model.parameters(), bucket_bytes=64 << 10)   # several buckets, launched under backward
     loss = model.training_step(local, 0)
     loss.backward()
-    D.allreduce_gradients(model.parameters())
+    reducer.finish()
     torch.cuda.synchronize()
     if rank == 0:
         dist.barrier()
