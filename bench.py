@@ -182,6 +182,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--per-gpu-batch", type=int, default=1024)
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling instead of the default weak scaling: fix the GLOBAL batch (e.g. 1024) and "
+                         "give each rank global / N rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra split-bf16 measurement")
     ap.add_argument("--workload", default="vit_s8_lc", choices=list(WORKLOADS),
@@ -204,6 +207,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     device = torch.device("cuda", local)
     b = args.per_gpu_batch
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} is not divisible by {world} ranks")
+        b = args.global_batch // world
     if args.workload == "vit_s8_lc":
         model = build_model(device)
         batch = synthetic_batch(b, 1234 + rank, device)
@@ -303,7 +310,8 @@ def main():
         out = {
             "metric": "contrastive pairs/sec (image+light-curve) at global batch 1024, 1/2/4/8 GPUs",
             "value": pairs, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak",
+            "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("ViT-S/8 image tower (64x64x3, build-defined) + reference light-curve "
                                     "transformer (T=200, emb 64, 8 heads, depth 5, 2 bands) -> enc_dim 128, "
