@@ -567,23 +567,38 @@ int launch_tail_finish(const GemmArgs& a, int bn, int waves, hipStream_t st) {
 }
 
 // C[m][n] = sum_s partial[s][m][n]   (split-K finish; fixed order -> deterministic).  A block covers 64 x V
-// consecutive outputs (V = 4: one 16-byte load per slab and lane when N and ldc allow, else V = 1) with 4 thread
-// groups that each sum a quarter of the slabs, combined through LDS.
+// consecutive outputs (V = 4: one 16-byte load per slab and lane when N and ldc allow, else V = 1) with G thread
+// groups that each sum every G-th slab (four independent partial sums in flight), combined through LDS.  G = 16 for
+// many slabs of a small output (a 32 x 32 weight gradient cut into 512 K-slabs would otherwise be 4 workgroups
+// walking 128 dependent loads each), G = 4 otherwise.
 // The last `cs_blocks` workgroups of the grid (fused bias gradient, msn_wgrad_bias) sum the [splits][M] column-sum
-// slabs instead: 256 rows per workgroup, slabs in order.
-template <int V>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C,
-                                                            int64_t M, int64_t N, int64_t ldc, int splits,
-                                                            const float* __restrict__ cs_partial,
-                                                            float* __restrict__ cs_out, int cs_blocks) {
-    __shared__ float red[4][64 * V];
+// slabs instead: 64 rows per workgroup, the G groups sharing the slabs the same way.
+template <int V, int G>
+__global__ __launch_bounds__(64 * G) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C,
+                                                               int64_t M, int64_t N, int64_t ldc, int splits,
+                                                               const float* __restrict__ cs_partial,
+                                                               float* __restrict__ cs_out, int cs_blocks) {
+    __shared__ float red[G][64 * V];
     const int main_blocks = (int)gridDim.x - cs_blocks;
-    if ((int)blockIdx.x >= main_blocks) {
-        const int64_t row = (int64_t)((int)blockIdx.x - main_blocks) * 256 + threadIdx.x;
+    if ((int)blockIdx.x >= main_blocks) {   // 64 rows of the column-sum slabs, the G groups sharing the slabs
+        const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+        const int64_t row = (int64_t)((int)blockIdx.x - main_blocks) * 64 + cl;
+        float s0 = 0.f, s1 = 0.f;
         if (row < M) {
-            float s = 0.f;
-            for (int k = 0; k < splits; ++k) s += cs_partial[(int64_t)k * M + row];
-            cs_out[row] = s;
+            int k = g;
+            for (; k + G < splits; k += 2 * G) {
+                s0 += cs_partial[(int64_t)k * M + row];
+                s1 += cs_partial[(int64_t)(k + G) * M + row];
+            }
+            if (k < splits) s0 += cs_partial[(int64_t)k * M + row];
+        }
+        red[g][cl] = s0 + s1;
+        __syncthreads();
+        if (g == 0 && row < M) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < G; ++q) t += red[q][cl];
+            cs_out[row] = t;
         }
         return;
     }
@@ -591,27 +606,42 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
     for (int64_t base = (int64_t)blockIdx.x * 64 * V; base < total; base += (int64_t)main_blocks * 64 * V) {
         const int64_t i = base + (int64_t)cl * V;
-        float s[V];
+        float s[4][V];
 #pragma unroll
-        for (int v = 0; v < V; ++v) s[v] = 0.f;
+        for (int v = 0; v < V; ++v) s[0][v] = s[1][v] = s[2][v] = s[3][v] = 0.f;
         if (i < total) {
-            for (int k = g; k < splits; k += 4) {
+            auto add = [&](float (&acc)[V], int k) {
                 if (V == 4) {
                     const float4 t = *reinterpret_cast<const float4*>(partial + (int64_t)k * total + i);
-                    s[0] += t.x, s[1 % V] += t.y, s[2 % V] += t.z, s[3 % V] += t.w;
+                    acc[0] += t.x, acc[1 % V] += t.y, acc[2 % V] += t.z, acc[3 % V] += t.w;
                 } else {
-                    s[0] += partial[(int64_t)k * total + i];
+                    acc[0] += partial[(int64_t)k * total + i];
                 }
+            };
+            int k = g;
+            for (; k + 3 * G < splits; k += 4 * G) {   // four independent loads in flight
+                add(s[0], k);
+                add(s[1], k + G);
+                add(s[2], k + 2 * G);
+                add(s[3], k + 3 * G);
             }
+            for (; k < splits; k += G) add(s[0], k);
         }
 #pragma unroll
-        for (int v = 0; v < V; ++v) red[g][cl * V + v] = s[v];
+        for (int v = 0; v < V; ++v) red[g][cl * V + v] = (s[0][v] + s[1][v]) + (s[2][v] + s[3][v]);
         __syncthreads();
         if (g == 0 && i < total) {
             float t[V];
 #pragma unroll
-            for (int v = 0; v < V; ++v)
-                t[v] = (red[0][cl * V + v] + red[1][cl * V + v]) + (red[2][cl * V + v] + red[3][cl * V + v]);
+            for (int v = 0; v < V; ++v) {
+                if (G == 4) {
+                    t[v] = (red[0][cl * V + v] + red[1][cl * V + v]) + (red[2 % G][cl * V + v] + red[3 % G][cl * V + v]);
+                } else {
+                    t[v] = 0.f;
+#pragma unroll
+                    for (int q = 0; q < G; ++q) t[v] += red[q][cl * V + v];
+                }
+            }
             float* out = C + (i / N) * ldc + (i % N);
             if (V == 4) *reinterpret_cast<float4*>(out) = make_float4(t[0], t[1 % V], t[2 % V], t[3 % V]);
             else out[0] = t[0];
@@ -880,16 +910,22 @@ static int sgemm_impl(int opA, int opB, int64_t M, int64_t N, int64_t K, const f
         const int64_t total = M * N;
         // 16-byte path: a group of 4 outputs never straddles a row (N % 4 == 0) and C rows stay 16-byte aligned
         const bool v4 = N % 4 == 0 && ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
-        const int cs_blocks = fuse_colsum ? (int)cdiv(M, 256) : 0;   // the column-sum slabs ride in the same launch
-        if (v4) {
-            const int blocks = (int)std::min<int64_t>(cdiv(total, 256), 4096);
-            hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks + cs_blocks), dim3(256), 0, st, a.partial, C, M, N, ldc,
-                               splits, a.colsum, colsum_out, cs_blocks);
-        } else {
-            const int blocks = (int)std::min<int64_t>(cdiv(total, 64), 4096);
-            hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks + cs_blocks), dim3(256), 0, st, a.partial, C, M, N, ldc,
-                               splits, a.colsum, colsum_out, cs_blocks);
-        }
+        const int cs_blocks = fuse_colsum ? (int)cdiv(M, 64) : 0;   // the column-sum slabs ride in the same launch
+        const bool deep = splits >= 64;   // many slabs: 16 thread groups share them
+        const int blocks = (int)std::min<int64_t>(cdiv(total, v4 ? 256 : 64), 4096);
+        const dim3 grid(blocks + cs_blocks);
+        if (v4 && deep)
+            hipLaunchKernelGGL((splitk_reduce_kernel<4, 16>), grid, dim3(1024), 0, st, a.partial, C, M, N, ldc, splits,
+                               a.colsum, colsum_out, cs_blocks);
+        else if (v4)
+            hipLaunchKernelGGL((splitk_reduce_kernel<4, 4>), grid, dim3(256), 0, st, a.partial, C, M, N, ldc, splits,
+                               a.colsum, colsum_out, cs_blocks);
+        else if (deep)
+            hipLaunchKernelGGL((splitk_reduce_kernel<1, 16>), grid, dim3(1024), 0, st, a.partial, C, M, N, ldc, splits,
+                               a.colsum, colsum_out, cs_blocks);
+        else
+            hipLaunchKernelGGL((splitk_reduce_kernel<1, 4>), grid, dim3(256), 0, st, a.partial, C, M, N, ldc, splits,
+                               a.colsum, colsum_out, cs_blocks);
         MSN_LAUNCH_CHECK();
     }
     return MSN_OK;
