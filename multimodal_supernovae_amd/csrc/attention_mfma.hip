@@ -137,7 +137,9 @@ __global__ __launch_bounds__(1024) void mattn_fwd_kernel(const MAttn p) {
 #pragma unroll
     for (int t = 0; t < DT; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float l = 0.f;
-    constexpr int KEEP = 8;   // key tiles whose scores fit in registers (4 per tile): sequences up to 128 tokens
+    // key tiles whose scores fit in registers (4 per tile) next to the output accumulators: sequences up to 256
+    // tokens for 16-wide heads (the reference's spectrum tower: 220 tokens), 128 tokens for wider heads
+    constexpr int KEEP = HD <= 16 ? 16 : 8;
     if (nkt <= KEEP) {
         // one pass: every score tile is computed once and kept (ViT-S/8 at 64x64: 65 tokens -> 5 tiles)
         f32x4 sc[KEEP];
