@@ -43,15 +43,17 @@ struct AttnArgs {
 };
 
 // rows r0..r0+n-1 of a [T][ld] matrix, columns col0..col0+s-1 -> LDS [n][S] (zero padded to S)
+// rows n .. npad-1 (the tile is padded to a whole number of inner-loop chunks) are zero-filled
 template <int S>
 __device__ __forceinline__ void stage_rows(float* dst, const float* __restrict__ src, int64_t ld, int col0, int s,
-                                           int r0, int n, bool vec_ok) {
+                                           int r0, int n, bool vec_ok, int npad) {
     constexpr int Q4 = S / 4;
-    for (int idx = threadIdx.x; idx < n * Q4; idx += blockDim.x) {
+    for (int idx = threadIdx.x; idx < npad * Q4; idx += blockDim.x) {
         const int r = idx / Q4, c = 4 * (idx % Q4);
         const float* p = src + (int64_t)(r0 + r) * ld + col0 + c;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (vec_ok && c + 3 < s) v = *reinterpret_cast<const float4*>(p);
+        if (r >= n) {
+        } else if (vec_ok && c + 3 < s) v = *reinterpret_cast<const float4*>(p);
         else {
             if (c < s) v.x = p[0];
             if (c + 1 < s) v.y = p[1];
@@ -77,12 +79,13 @@ __device__ __forceinline__ bool vec4_ok(const float* p, int64_t ld, int64_t bstr
 // 16 floats: R = 2).
 template <int S, int R>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
-    // LDS sized by the launch: KTILE = min(4096 / S, keys rounded up to 8) rows each of K and V + the mask bytes
+    // LDS sized by the launch: KTILE = min(4096 / S, keys rounded up to KB) rows each of K and V + one float per key:
+    // 0 = live key, -1e7 = padded-out key (masked_fill value), -inf = beyond the sequence (tile padding)
     extern __shared__ __attribute__((aligned(16))) float attn_smem[];
     const int KTILE = p.tile_rows;
     float* Ks = attn_smem;
     float* Vs = attn_smem + KTILE * S;
-    uint8_t* Ms = reinterpret_cast<uint8_t*>(Vs + KTILE * S);
+    float* Fs = Vs + KTILE * S;
     const int b = blockIdx.z, hh = blockIdx.y;
     const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * R;
     const int col0 = hh * p.s;
@@ -101,37 +104,34 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     }
 
     for (int k0 = 0; k0 < p.Tk; k0 += KTILE) {
-        const int nt = min(KTILE, p.Tk - k0);
+        const int nt = min(KTILE, p.Tk - k0), ntp = (nt + KB - 1) / KB * KB;
         __syncthreads();
-        stage_rows<S>(Ks, kb, p.ldk, col0, p.s, k0, nt, kvec);
-        stage_rows<S>(Vs, vb, p.ldv, col0, p.s, k0, nt, vvec);
-        for (int j = threadIdx.x; j < nt; j += blockDim.x) Ms[j] = p.mask ? p.mask[(int64_t)b * p.Tk + k0 + j] : 1;
+        stage_rows<S>(Ks, kb, p.ldk, col0, p.s, k0, nt, kvec, ntp);
+        stage_rows<S>(Vs, vb, p.ldv, col0, p.s, k0, nt, vvec, ntp);
+        for (int j = threadIdx.x; j < ntp; j += blockDim.x)
+            Fs[j] = j >= nt ? -INFINITY : ((p.mask && !p.mask[(int64_t)b * p.Tk + k0 + j]) ? kMaskFill : 0.f);
         __syncthreads();
-        for (int j0 = 0; j0 < nt; j0 += KB) {
+        // whole chunks of KB keys, no per-key control flow: the compiler interleaves the KB x R independent dot
+        // products; a key beyond the sequence scores -inf (probability exactly 0)
+        for (int j0 = 0; j0 < ntp; j0 += KB) {
             float sc[R][KB], mx[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) mx[r] = -INFINITY;
 #pragma unroll
             for (int jj = 0; jj < KB; ++jj) {
-                const int j = j0 + jj;
-                if (j < nt) {
-                    const float* kr = Ks + j * S;
-                    float kv[S];
+                const float* kr = Ks + (j0 + jj) * S;
+                float kv[S];
 #pragma unroll
-                    for (int d = 0; d < S; ++d) kv[d] = kr[d];
-                    const bool live = Ms[j] != 0;
+                for (int d = 0; d < S; ++d) kv[d] = kr[d];
+                const float fill = Fs[j0 + jj];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        float a = 0.f;
+                for (int r = 0; r < R; ++r) {
+                    float a = 0.f;
 #pragma unroll
-                        for (int d = 0; d < S; ++d) a = fmaf(q[r][d], kv[d], a);
-                        a = live ? a : kMaskFill;
-                        sc[r][jj] = a;
-                        mx[r] = fmaxf(mx[r], a);
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) sc[r][jj] = -INFINITY;
+                    for (int d = 0; d < S; ++d) a = fmaf(q[r][d], kv[d], a);
+                    a = fill == 0.f ? a : fill;
+                    sc[r][jj] = a;
+                    mx[r] = fmaxf(mx[r], a);
                 }
             }
             float mn[R];
@@ -146,19 +146,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
             }
 #pragma unroll
             for (int jj = 0; jj < KB; ++jj) {
-                const int j = j0 + jj;
-                if (j < nt) {
-                    const float* vr = Vs + j * S;
-                    float vv[S];
+                const float* vr = Vs + (j0 + jj) * S;
+                float vv[S];
 #pragma unroll
-                    for (int d = 0; d < S; ++d) vv[d] = vr[d];
+                for (int d = 0; d < S; ++d) vv[d] = vr[d];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const float pj = __expf(sc[r][jj] - mn[r]);
-                        l[r] += pj;
+                for (int r = 0; r < R; ++r) {
+                    const float pj = __expf(sc[r][jj] - mn[r]);
+                    l[r] += pj;
 #pragma unroll
-                        for (int d = 0; d < S; ++d) o[r][d] = fmaf(pj, vv[d], o[r][d]);
-                    }
+                    for (int d = 0; d < S; ++d) o[r][d] = fmaf(pj, vv[d], o[r][d]);
                 }
             }
         }
@@ -188,7 +185,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
     const int KTILE = p.tile_rows;
     float* Ks = attn_smem;
     float* Vs = attn_smem + KTILE * S;
-    uint8_t* Ms = reinterpret_cast<uint8_t*>(Vs + KTILE * S);
+    float* Fs = Vs + KTILE * S;          // 1 = live key, 0 = masked or beyond the sequence (no gradient through it)
     const int b = blockIdx.z, hh = blockIdx.y;
     const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * R;
     const int col0 = hh * p.s;
@@ -218,31 +215,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
         if (on) p.delta[stat] = delta[r];
     }
 
+    constexpr int KC = 4;   // keys per unrolled chunk
     for (int k0 = 0; k0 < p.Tk; k0 += KTILE) {
-        const int nt = min(KTILE, p.Tk - k0);
+        const int nt = min(KTILE, p.Tk - k0), ntp = (nt + KC - 1) / KC * KC;
         __syncthreads();
-        stage_rows<S>(Ks, kb, p.ldk, col0, p.s, k0, nt, kvec);
-        stage_rows<S>(Vs, vb, p.ldv, col0, p.s, k0, nt, vvec);
-        for (int j = threadIdx.x; j < nt; j += blockDim.x) Ms[j] = p.mask ? p.mask[(int64_t)b * p.Tk + k0 + j] : 1;
+        stage_rows<S>(Ks, kb, p.ldk, col0, p.s, k0, nt, kvec, ntp);
+        stage_rows<S>(Vs, vb, p.ldv, col0, p.s, k0, nt, vvec, ntp);
+        for (int j = threadIdx.x; j < ntp; j += blockDim.x)
+            Fs[j] = (j < nt && (!p.mask || p.mask[(int64_t)b * p.Tk + k0 + j])) ? 1.f : 0.f;
         __syncthreads();
-        for (int j = 0; j < nt; ++j) {
-            if (!Ms[j]) continue;  // masked_fill: no gradient flows to q / k through a padded key
-            const float* kr = Ks + j * S;
-            const float* vr = Vs + j * S;
-            float kv[S], vv[S];
+        for (int j0 = 0; j0 < ntp; j0 += KC) {
 #pragma unroll
-            for (int d = 0; d < S; ++d) kv[d] = kr[d], vv[d] = vr[d];
+            for (int jj = 0; jj < KC; ++jj) {
+                const float* kr = Ks + (j0 + jj) * S;
+                const float* vr = Vs + (j0 + jj) * S;
+                float kv[S], vv[S];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                float a = 0.f, dp = 0.f;
+                for (int d = 0; d < S; ++d) kv[d] = kr[d], vv[d] = vr[d];
+                const bool live = Fs[j0 + jj] != 0.f;   // masked_fill: no gradient flows to q / k through a padded key
 #pragma unroll
-                for (int d = 0; d < S; ++d) {
-                    a = fmaf(q[r][d], kv[d], a);
-                    dp = fmaf(dO[r][d], vv[d], dp);
+                for (int r = 0; r < R; ++r) {
+                    float a = 0.f, dp = 0.f;
+#pragma unroll
+                    for (int d = 0; d < S; ++d) {
+                        a = fmaf(q[r][d], kv[d], a);
+                        dp = fmaf(dO[r][d], vv[d], dp);
+                    }
+                    const float ds = live ? __expf((a - lse_m[r]) - lse_l[r]) * (dp - delta[r]) : 0.f;
+#pragma unroll
+                    for (int d = 0; d < S; ++d) dq[r][d] = fmaf(ds, kv[d], dq[r][d]);
                 }
-                const float ds = __expf((a - lse_m[r]) - lse_l[r]) * (dp - delta[r]);
-#pragma unroll
-                for (int d = 0; d < S; ++d) dq[r][d] = fmaf(ds, kv[d], dq[r][d]);
             }
         }
     }
@@ -288,40 +290,45 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
         keep[r] = on[r] && (p.mask ? p.mask[(int64_t)b * p.Tk + jj] != 0 : true);
     }
 
+    constexpr int QC = 4;   // queries per unrolled chunk
     for (int q0 = 0; q0 < p.Tq; q0 += QTILE) {
-        const int nt = min(QTILE, p.Tq - q0);
+        const int nt = min(QTILE, p.Tq - q0), ntp = (nt + QC - 1) / QC * QC;
         __syncthreads();
-        stage_rows<S>(Qs, qb, p.ldq, col0, p.s, q0, nt, qvec);
-        stage_rows<S>(Ds, db, p.ldd, col0, p.s, q0, nt, dvec);
-        for (int t = threadIdx.x; t < nt; t += blockDim.x) {
-            const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + q0 + t;
-            Lm[t] = p.lse[2 * stat];
-            Ll[t] = p.lse[2 * stat + 1];
-            Dl[t] = p.delta[stat];
+        stage_rows<S>(Qs, qb, p.ldq, col0, p.s, q0, nt, qvec, ntp);
+        stage_rows<S>(Ds, db, p.ldd, col0, p.s, q0, nt, dvec, ntp);
+        for (int t = threadIdx.x; t < ntp; t += blockDim.x) {
+            const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + q0 + (t < nt ? t : 0);
+            Lm[t] = t < nt ? p.lse[2 * stat] : INFINITY;      // +inf: a query beyond the sequence gets p = exp(-inf) = 0
+            Ll[t] = t < nt ? p.lse[2 * stat + 1] : 0.f;
+            Dl[t] = t < nt ? p.delta[stat] : 0.f;
         }
         __syncthreads();
-        for (int t = 0; t < nt; ++t) {
-            const float* qr = Qs + t * S;
-            const float* dr = Ds + t * S;
-            float qv[S], dvv[S];
+        for (int t0 = 0; t0 < ntp; t0 += QC) {
 #pragma unroll
-            for (int d = 0; d < S; ++d) qv[d] = qr[d], dvv[d] = dr[d];
-            const float lm = Lm[t], ll = Ll[t], dl = Dl[t];
+            for (int tt = 0; tt < QC; ++tt) {
+                const int t = t0 + tt;
+                const float* qr = Qs + t * S;
+                const float* dr = Ds + t * S;
+                float qv[S], dvv[S];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                float a = 0.f, dp = 0.f;
+                for (int d = 0; d < S; ++d) qv[d] = qr[d], dvv[d] = dr[d];
+                const float lm = Lm[t], ll = Ll[t], dl = Dl[t];
 #pragma unroll
-                for (int d = 0; d < S; ++d) {
-                    a = fmaf(qv[d], k[r][d], a);
-                    dp = fmaf(dvv[d], v[r][d], dp);
+                for (int r = 0; r < R; ++r) {
+                    float a = 0.f, dp = 0.f;
+#pragma unroll
+                    for (int d = 0; d < S; ++d) {
+                        a = fmaf(qv[d], k[r][d], a);
+                        dp = fmaf(dvv[d], v[r][d], dp);
+                    }
+                    a = keep[r] ? a : kMaskFill;
+                    const float pr = __expf((a - lm) - ll);
+#pragma unroll
+                    for (int d = 0; d < S; ++d) dv[r][d] = fmaf(pr, dvv[d], dv[r][d]);
+                    const float ds = keep[r] ? pr * (dp - dl) : 0.f;
+#pragma unroll
+                    for (int d = 0; d < S; ++d) dk[r][d] = fmaf(ds, qv[d], dk[r][d]);
                 }
-                if (!keep[r]) a = kMaskFill;
-                const float pr = __expf((a - lm) - ll);
-#pragma unroll
-                for (int d = 0; d < S; ++d) dv[r][d] = fmaf(pr, dvv[d], dv[r][d]);
-                const float ds = keep[r] ? pr * (dp - dl) : 0.f;
-#pragma unroll
-                for (int d = 0; d < S; ++d) dk[r][d] = fmaf(ds, qv[d], dk[r][d]);
             }
         }
     }
@@ -423,7 +430,7 @@ extern "C" int msn_attention_fwd(const float* q, int64_t ldq, int64_t q_bstride,
     const unsigned bs = block_for((int)cdiv(Tq, R));
     const dim3 grid((unsigned)cdiv(Tq, (int64_t)bs * R), H, B), block(bs);
     a.tile_rows = std::min(4096 / S, (Tk + 7) / 8 * 8);
-    const size_t lds = sizeof(float) * 2 * (size_t)a.tile_rows * S + (size_t)a.tile_rows;
+    const size_t lds = sizeof(float) * (2 * (size_t)a.tile_rows * S + (size_t)a.tile_rows);
     MSN_ATTN_DISPATCH(attn_fwd_kernel, S, R, grid, block, lds, st, a)
     MSN_LAUNCH_CHECK();
     return MSN_OK;
@@ -469,7 +476,7 @@ extern "C" int msn_attention_bwd(const float* q, int64_t ldq, int64_t q_bstride,
         const unsigned bs = block_for((int)cdiv(Tq, R));
         const dim3 grid((unsigned)cdiv(Tq, (int64_t)bs * R), H, B), block(bs);
         a.tile_rows = std::min(4096 / S, (Tk + 7) / 8 * 8);
-        const size_t lds = sizeof(float) * 2 * (size_t)a.tile_rows * S + (size_t)a.tile_rows;
+        const size_t lds = sizeof(float) * (2 * (size_t)a.tile_rows * S + (size_t)a.tile_rows);
         MSN_ATTN_DISPATCH(attn_bwd_dq_kernel, S, R, grid, block, lds, st, a)
         MSN_LAUNCH_CHECK();
     }
