@@ -23,6 +23,28 @@
 namespace msn {
 
 constexpr float kMaskFill = -1e7f;
+// Pairs of head-dimension elements: spelling the inner products on 2-vectors makes the compiler emit packed fp32
+// FMAs (v_pk_fma_f32: two lanes of arithmetic per instruction slot), which it does not reliably do from scalar code.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+template <int S>
+__device__ __forceinline__ void load_row2(f2 (&dst)[S / 2], const float* __restrict__ lds_row) {   // LDS row -> pairs
+#pragma unroll
+    for (int d = 0; d < S / 2; ++d) dst[d] = f2{lds_row[2 * d], lds_row[2 * d + 1]};
+}
+template <int S>
+__device__ __forceinline__ float dot2(const f2 (&a)[S / 2], const f2 (&b)[S / 2]) {
+    f2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < S / 2; ++d) acc = fma2(a[d], b[d], acc);
+    return acc.x + acc.y;
+}
+template <int S>
+__device__ __forceinline__ void axpy2(f2 (&y)[S / 2], float a, const f2 (&x)[S / 2]) {   // y += a * x
+    const f2 aa = {a, a};
+#pragma unroll
+    for (int d = 0; d < S / 2; ++d) y[d] = fma2(aa, x[d], y[d]);
+}
 constexpr int KB = 8;  // keys per online-softmax micro-step
 
 struct AttnArgs {
@@ -68,6 +90,37 @@ __device__ __forceinline__ void load_vec(float (&dst)[S], const float* __restric
 #pragma unroll
     for (int d = 0; d < S; ++d) dst[d] = (on && d < s) ? p[d] : 0.f;
 }
+// Exact head width + 16-byte aligned rows: S / 4 unconditional 16-byte loads (the caller passes a valid, clamped row
+// address) and a select afterwards.  The guarded scalar form above costs one branch and one memory round trip per
+// element -- with one wave per workgroup that prologue, not the key loop, set the kernels' time.
+template <int S>
+__device__ __forceinline__ void load_vec4(float (&dst)[S], const float* __restrict__ p, bool on) {
+#pragma unroll
+    for (int c = 0; c < S / 4; ++c) {
+        const float4 v = reinterpret_cast<const float4*>(p)[c];
+        dst[4 * c] = on ? v.x : 0.f;
+        dst[4 * c + 1] = on ? v.y : 0.f;
+        dst[4 * c + 2] = on ? v.z : 0.f;
+        dst[4 * c + 3] = on ? v.w : 0.f;
+    }
+}
+template <int S>
+__device__ __forceinline__ void load_row_any(float (&dst)[S], const float* __restrict__ p, int s, bool on, bool vec) {
+    if (vec) load_vec4<S>(dst, p, on);
+    else load_vec<S>(dst, p, s, on);
+}
+template <int S>
+__device__ __forceinline__ void store_row_any(float* __restrict__ p, const float (&src)[S], int s, bool vec) {
+    if (vec) {
+#pragma unroll
+        for (int c = 0; c < S / 4; ++c)
+            reinterpret_cast<float4*>(p)[c] = make_float4(src[4 * c], src[4 * c + 1], src[4 * c + 2], src[4 * c + 3]);
+    } else {
+#pragma unroll
+        for (int d = 0; d < S; ++d)
+            if (d < s) p[d] = src[d];
+    }
+}
 __device__ __forceinline__ bool vec4_ok(const float* p, int64_t ld, int64_t bstride, int s) {
     return (s % 4 == 0) && (ld % 4 == 0) && (bstride % 4 == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
 }
@@ -92,14 +145,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     const float* kb = p.k + (int64_t)b * p.k_bstride;
     const float* vb = p.v + (int64_t)b * p.v_bstride;
     const bool kvec = vec4_ok(p.k, p.ldk, p.k_bstride, p.s), vvec = vec4_ok(p.v, p.ldv, p.v_bstride, p.s);
+    const bool qfast = p.s == S && vec4_ok(p.q, p.ldq, p.q_bstride, p.s);
+    const bool ofast = p.s == S && vec4_ok(p.o, p.ldo, p.o_bstride, p.s);
 
-    float q[R][S], o[R][S], m[R], l[R];
+    f2 q[R][S / 2], o[R][S / 2];
+    float m[R], l[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const bool on = i0 + r < p.Tq;
-        load_vec<S>(q[r], p.q + (int64_t)b * p.q_bstride + (int64_t)(on ? i0 + r : 0) * p.ldq + col0, p.s, on);
+        float qs[S];
+        load_row_any<S>(qs, p.q + (int64_t)b * p.q_bstride + (int64_t)(on ? i0 + r : 0) * p.ldq + col0, p.s, on, qfast);
 #pragma unroll
-        for (int d = 0; d < S; ++d) { q[r][d] *= p.scale; o[r][d] = 0.f; }
+        for (int d = 0; d < S / 2; ++d) {
+            q[r][d] = f2{qs[2 * d] * p.scale, qs[2 * d + 1] * p.scale};
+            o[r][d] = f2{0.f, 0.f};
+        }
         m[r] = -INFINITY, l[r] = 0.f;
     }
 
@@ -119,16 +179,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
             for (int r = 0; r < R; ++r) mx[r] = -INFINITY;
 #pragma unroll
             for (int jj = 0; jj < KB; ++jj) {
-                const float* kr = Ks + (j0 + jj) * S;
-                float kv[S];
-#pragma unroll
-                for (int d = 0; d < S; ++d) kv[d] = kr[d];
+                f2 kv[S / 2];
+                load_row2<S>(kv, Ks + (j0 + jj) * S);
                 const float fill = Fs[j0 + jj];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    float a = 0.f;
-#pragma unroll
-                    for (int d = 0; d < S; ++d) a = fmaf(q[r][d], kv[d], a);
+                    float a = dot2<S>(q[r], kv);
                     a = fill == 0.f ? a : fill;
                     sc[r][jj] = a;
                     mx[r] = fmaxf(mx[r], a);
@@ -141,21 +197,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
                 const float alpha = __expf(m[r] - mn[r]);
                 l[r] *= alpha;
 #pragma unroll
-                for (int d = 0; d < S; ++d) o[r][d] *= alpha;
+                for (int d = 0; d < S / 2; ++d) o[r][d] *= alpha;
                 m[r] = mn[r];
             }
 #pragma unroll
             for (int jj = 0; jj < KB; ++jj) {
-                const float* vr = Vs + (j0 + jj) * S;
-                float vv[S];
-#pragma unroll
-                for (int d = 0; d < S; ++d) vv[d] = vr[d];
+                f2 vv[S / 2];
+                load_row2<S>(vv, Vs + (j0 + jj) * S);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const float pj = __expf(sc[r][jj] - mn[r]);
                     l[r] += pj;
-#pragma unroll
-                    for (int d = 0; d < S; ++d) o[r][d] = fmaf(pj, vv[d], o[r][d]);
+                    axpy2<S>(o[r], pj, vv);
                 }
             }
         }
@@ -166,9 +219,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         if (i < p.Tq) {
             const float inv = 1.f / l[r];
             float* op = p.o + (int64_t)b * p.o_bstride + (int64_t)i * p.ldo + col0;
+            float os[S];
 #pragma unroll
-            for (int d = 0; d < S; ++d)
-                if (d < p.s) op[d] = o[r][d] * inv;
+            for (int d = 0; d < S; ++d) os[d] = (d & 1 ? o[r][d / 2].y : o[r][d / 2].x) * inv;
+            store_row_any<S>(op, os, p.s, ofast);
             // (max, log-sum) kept apart: with every key padded the max is -1e7, where one fp32 ulp is 1.0
             float* st = p.lse + 2 * (((int64_t)b * p.H + hh) * p.Tq + i);
             st[0] = m[r];
@@ -193,20 +247,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
     const float* vb = p.v + (int64_t)b * p.v_bstride;
     const bool kvec = vec4_ok(p.k, p.ldk, p.k_bstride, p.s), vvec = vec4_ok(p.v, p.ldv, p.v_bstride, p.s);
 
-    float q[R][S], dO[R][S], dq[R][S], delta[R], lse_m[R], lse_l[R];
+    const bool qfast = p.s == S && vec4_ok(p.q, p.ldq, p.q_bstride, p.s);
+    const bool dfast = p.s == S && vec4_ok(p.dout, p.ldd, p.d_bstride, p.s);
+    const bool ofast = p.s == S && vec4_ok(p.o, p.ldo, p.o_bstride, p.s);
+    const bool gfast = p.s == S && vec4_ok(p.dq, p.lddq, p.dq_bstride, p.s);
+    f2 q[R][S / 2], dO[R][S / 2], dq[R][S / 2];
+    float delta[R], lse_m[R], lse_l[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const bool on = i0 + r < p.Tq;
         const int ii = on ? i0 + r : 0;
-        load_vec<S>(q[r], p.q + (int64_t)b * p.q_bstride + (int64_t)ii * p.ldq + col0, p.s, on);
-        load_vec<S>(dO[r], p.dout + (int64_t)b * p.d_bstride + (int64_t)ii * p.ldd + col0, p.s, on);
+        float qs[S], ds_[S], os[S];
+        load_row_any<S>(qs, p.q + (int64_t)b * p.q_bstride + (int64_t)ii * p.ldq + col0, p.s, on, qfast);
+        load_row_any<S>(ds_, p.dout + (int64_t)b * p.d_bstride + (int64_t)ii * p.ldd + col0, p.s, on, dfast);
+        load_row_any<S>(os, p.o + (int64_t)b * p.o_bstride + (int64_t)ii * p.ldo + col0, p.s, on, ofast);
         delta[r] = 0.f;
-        const float* op = p.o + (int64_t)b * p.o_bstride + (int64_t)ii * p.ldo + col0;
 #pragma unroll
-        for (int d = 0; d < S; ++d) {
-            if (on && d < p.s) delta[r] = fmaf(dO[r][d], op[d], delta[r]);
-            q[r][d] *= p.scale;
-            dq[r][d] = 0.f;
+        for (int d = 0; d < S; ++d) delta[r] = fmaf(ds_[d], os[d], delta[r]);
+#pragma unroll
+        for (int d = 0; d < S / 2; ++d) {
+            q[r][d] = f2{qs[2 * d] * p.scale, qs[2 * d + 1] * p.scale};
+            dO[r][d] = f2{ds_[2 * d], ds_[2 * d + 1]};
+            dq[r][d] = f2{0.f, 0.f};
         }
         const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + ii;
         // a row beyond Tq keeps p = exp(-inf) = 0
@@ -227,23 +289,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
         for (int j0 = 0; j0 < ntp; j0 += KC) {
 #pragma unroll
             for (int jj = 0; jj < KC; ++jj) {
-                const float* kr = Ks + (j0 + jj) * S;
-                const float* vr = Vs + (j0 + jj) * S;
-                float kv[S], vv[S];
-#pragma unroll
-                for (int d = 0; d < S; ++d) kv[d] = kr[d], vv[d] = vr[d];
-                const bool live = Fs[j0 + jj] != 0.f;   // masked_fill: no gradient flows to q / k through a padded key
+                f2 kv[S / 2], vv[S / 2];
+                load_row2<S>(kv, Ks + (j0 + jj) * S);
+                load_row2<S>(vv, Vs + (j0 + jj) * S);
+                const float live = Fs[j0 + jj];   // 0 for a masked / padded key: no gradient flows through it
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    float a = 0.f, dp = 0.f;
-#pragma unroll
-                    for (int d = 0; d < S; ++d) {
-                        a = fmaf(q[r][d], kv[d], a);
-                        dp = fmaf(dO[r][d], vv[d], dp);
-                    }
-                    const float ds = live ? __expf((a - lse_m[r]) - lse_l[r]) * (dp - delta[r]) : 0.f;
-#pragma unroll
-                    for (int d = 0; d < S; ++d) dq[r][d] = fmaf(ds, kv[d], dq[r][d]);
+                    const float a = dot2<S>(q[r], kv), dp = dot2<S>(dO[r], vv);
+                    // A probability never exceeds 1, so the exponent is clamped at 0: nothing changes for live keys,
+                    // and a masked key of a fully padded sample (row max -1e7, raw score here) cannot overflow
+                    // into inf * 0.  The product with `live` keeps the chunk free of control flow.
+                    const float ds = live * (__expf(fminf((a - lse_m[r]) - lse_l[r], 0.f)) * (dp - delta[r]));
+                    axpy2<S>(dq[r], ds, kv);
                 }
             }
         }
@@ -253,9 +310,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
         const int i = i0 + r;
         if (i < p.Tq) {
             float* out = p.dq + (int64_t)b * p.dq_bstride + (int64_t)i * p.lddq + col0;
+            float gs[S];
 #pragma unroll
-            for (int d = 0; d < S; ++d)
-                if (d < p.s) out[d] = dq[r][d] * p.scale;
+            for (int d = 0; d < S; ++d) gs[d] = (d & 1 ? dq[r][d / 2].y : dq[r][d / 2].x) * p.scale;
+            store_row_any<S>(out, gs, p.s, gfast);
         }
     }
 }
@@ -277,16 +335,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     const float* db = p.dout + (int64_t)b * p.d_bstride;
     const bool qvec = vec4_ok(p.q, p.ldq, p.q_bstride, p.s), dvec = vec4_ok(p.dout, p.ldd, p.d_bstride, p.s);
 
-    float k[R][S], v[R][S], dk[R][S], dv[R][S];
+    const bool kfast = p.s == S && vec4_ok(p.k, p.ldk, p.k_bstride, p.s);
+    const bool vfast = p.s == S && vec4_ok(p.v, p.ldv, p.v_bstride, p.s);
+    const bool gkfast = p.s == S && vec4_ok(p.dk, p.lddk, p.dk_bstride, p.s);
+    const bool gvfast = p.s == S && vec4_ok(p.dv, p.lddv, p.dv_bstride, p.s);
+    f2 k[R][S / 2], v[R][S / 2], dk[R][S / 2], dv[R][S / 2];
     bool keep[R], on[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         on[r] = j0 + r < p.Tk;
         const int jj = on[r] ? j0 + r : 0;
-        load_vec<S>(k[r], p.k + (int64_t)b * p.k_bstride + (int64_t)jj * p.ldk + col0, p.s, on[r]);
-        load_vec<S>(v[r], p.v + (int64_t)b * p.v_bstride + (int64_t)jj * p.ldv + col0, p.s, on[r]);
+        float ks[S], vs[S];
+        load_row_any<S>(ks, p.k + (int64_t)b * p.k_bstride + (int64_t)jj * p.ldk + col0, p.s, on[r], kfast);
+        load_row_any<S>(vs, p.v + (int64_t)b * p.v_bstride + (int64_t)jj * p.ldv + col0, p.s, on[r], vfast);
 #pragma unroll
-        for (int d = 0; d < S; ++d) { k[r][d] *= p.scale; dk[r][d] = 0.f; dv[r][d] = 0.f; }
+        for (int d = 0; d < S / 2; ++d) {
+            k[r][d] = f2{ks[2 * d] * p.scale, ks[2 * d + 1] * p.scale};
+            v[r][d] = f2{vs[2 * d], vs[2 * d + 1]};
+            dk[r][d] = dv[r][d] = f2{0.f, 0.f};
+        }
         keep[r] = on[r] && (p.mask ? p.mask[(int64_t)b * p.Tk + jj] != 0 : true);
     }
 
@@ -307,27 +374,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
 #pragma unroll
             for (int tt = 0; tt < QC; ++tt) {
                 const int t = t0 + tt;
-                const float* qr = Qs + t * S;
-                const float* dr = Ds + t * S;
-                float qv[S], dvv[S];
-#pragma unroll
-                for (int d = 0; d < S; ++d) qv[d] = qr[d], dvv[d] = dr[d];
+                f2 qv[S / 2], dvv[S / 2];
+                load_row2<S>(qv, Qs + t * S);
+                load_row2<S>(dvv, Ds + t * S);
                 const float lm = Lm[t], ll = Ll[t], dl = Dl[t];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    float a = 0.f, dp = 0.f;
-#pragma unroll
-                    for (int d = 0; d < S; ++d) {
-                        a = fmaf(qv[d], k[r][d], a);
-                        dp = fmaf(dvv[d], v[r][d], dp);
-                    }
+                    float a = dot2<S>(qv, k[r]);
+                    const float dp = dot2<S>(dvv, v[r]);
                     a = keep[r] ? a : kMaskFill;
                     const float pr = __expf((a - lm) - ll);
-#pragma unroll
-                    for (int d = 0; d < S; ++d) dv[r][d] = fmaf(pr, dvv[d], dv[r][d]);
+                    axpy2<S>(dv[r], pr, dvv);
                     const float ds = keep[r] ? pr * (dp - dl) : 0.f;
-#pragma unroll
-                    for (int d = 0; d < S; ++d) dk[r][d] = fmaf(ds, qv[d], dk[r][d]);
+                    axpy2<S>(dk[r], ds, qv);
                 }
             }
         }
@@ -337,12 +396,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
         if (on[r]) {
             float* ok = p.dk + (int64_t)b * p.dk_bstride + (int64_t)(j0 + r) * p.lddk + col0;
             float* ov = p.dv + (int64_t)b * p.dv_bstride + (int64_t)(j0 + r) * p.lddv + col0;
+            float gk[S], gv[S];
 #pragma unroll
-            for (int d = 0; d < S; ++d)
-                if (d < p.s) {
-                    ok[d] = dk[r][d] * p.scale;
-                    ov[d] = dv[r][d];
-                }
+            for (int d = 0; d < S; ++d) {
+                gk[d] = (d & 1 ? dk[r][d / 2].y : dk[r][d / 2].x) * p.scale;
+                gv[d] = d & 1 ? dv[r][d / 2].y : dv[r][d / 2].x;
+            }
+            store_row_any<S>(ok, gk, p.s, gkfast);
+            store_row_any<S>(ov, gv, p.s, gvfast);
         }
     }
 }
