@@ -355,10 +355,6 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void sgemm_dma_kernel(c
 #ifdef MSN_TIMELINE
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 #endif
-#ifdef MSN_STAGGER
-    if (blockIdx.x >= 256u && blockIdx.x < 512u)
-        for (int i = 0; i < MSN_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
     const TileCoord tc = locate_tile(p);
     const int logical = tc.logical;
     const int64_t m0 = (int64_t)(logical / p.tiles_n) * BM, n0 = (int64_t)(logical % p.tiles_n) * BN;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Per-workgroup timeline of one msn_sgemm launch (diagnostic build: csrc/gemm.hip compiled with -DMSN_TIMELINE
-into tools/microbench/ablate/libmsn_timeline.so).  Prints where a tile's time goes: start -> first K-step landed ->
+"""Per-workgroup timeline of one msn_sgemm launch (diagnostic build: `bash tools/microbench/build_timeline.sh [1|2]`
+compiles csrc/gemm.hip with -DMSN_TIMELINE into tools/microbench/ablate/libmsn_timeline.so).  Prints where a tile's time goes: start -> first K-step landed ->
 K loop done -> stores acknowledged, and how the workgroups spread over XCDs / CUs / rounds.
 usage: MSN_HIP_LIB=.../libmsn_timeline.so python tools/microbench/gemm_timeline.py M N K opA opB [warm-up launches]"""
 import ctypes
