@@ -125,8 +125,16 @@ __device__ __forceinline__ void epilogue_body(const f32x16 (&acc)[TM][TN], const
                 float v = acc[i][j][r] + bv;
                 if (EPI == MSN_EPI_RELU) v = fmaxf(v, 0.f);
                 else if (EPI == MSN_EPI_GELU) {
-                    const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
-                    if (saves_aux && ok) x[dr * p.ldaux] = cdf + v * 0.39894228040143268f * __expf(-0.5f * v * v);
+                    // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7: measured 4.6e-7 / 2.7e-7 on gelu / gelu' for
+                    // |x| <= 12 against fp64), sharing exp(-v^2 / 2) with the pdf term: 1 rcp + 1 exp + ~12 FMAs per
+                    // element instead of the ~40 instructions of erff + a second exp -- 8 % of the ff1 product's time
+                    const float z = v * 0.70710678118654752f, az = fabsf(z);
+                    const float t = __frcp_rn(fmaf(0.3275911f, az, 1.f));
+                    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f),
+                                                        -0.284496736f), 0.254829592f);
+                    const float e = __expf(-z * z);
+                    const float cdf = 0.5f + 0.5f * copysignf(1.f - poly * e, z);
+                    if (saves_aux && ok) x[dr * p.ldaux] = cdf + v * 0.39894228040143268f * e;
                     v *= cdf;
                 } else if (EPI == MSN_EPI_RELU_BWD) v = av[r] > 0.f ? v : 0.f;
                 else if (EPI == MSN_EPI_GELU_BWD) v *= av[r];

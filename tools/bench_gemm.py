@@ -39,3 +39,7 @@ for prec in precs:
         t = timeit(lambda: ops.sgemm(a, b, oa, ob, out=out, precision=prec))
         print(f"{tag:18s} M={M:6d} N={N:5d} K={K:6d}  {t*1e3:8.3f} ms  {2*M*N*K/t/1e12:7.1f} TFLOP/s  "
               f"{(M*K+K*N+M*N)*4/t/1e9:8.0f} GB/s", flush=True)
+        if tag == "vit-s ff1 fwd":      # the same product with its training epilogue: + bias, GELU, gelu' saved
+            bias, aux = torch.randn(N, device="cuda"), torch.empty(M, N, device="cuda")
+            t = timeit(lambda: ops.sgemm(a, b, oa, ob, out=out, precision=prec, bias=bias, epilogue=ops.EPI_GELU, aux=aux))
+            print(f"{'  + bias/GELU/aux':18s} M={M:6d} N={N:5d} K={K:6d}  {t*1e3:8.3f} ms  {2*M*N*K/t/1e12:7.1f} TFLOP/s", flush=True)
