@@ -167,6 +167,8 @@ def cpu_baseline(sample_b, steps):
     if first > 12.0:                        # keep the whole leg bounded (~10-30 s of CPU work)
         steps, dt = 1, first
     else:
+        if steps <= 0:                      # default: as many steps as fit in ~12 s, judged by the first one
+            steps = max(2, min(40, int(12.0 / max(first, 1e-3))))
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
@@ -195,7 +197,7 @@ def main():
     ap.add_argument("--gemm-precision", default="f32", choices=["f32", "bf16x3", "bf16"],
                     help="inner-product precision of the GEMMs (bf16x3 = split-bf16, fp32-grade accuracy)")
     ap.add_argument("--cpu-sample-batch", type=int, default=32)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=0, help="timed oracle steps (0 = fill about 12 s)")
     args = ap.parse_args()
 
     from multimodal_supernovae_amd import _lib, distributed as D, ops
