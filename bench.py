@@ -253,9 +253,13 @@ def main():
 
     # ---- roofline of the dominant kernel (sgemm_kernel: every dense product of both towers) -----------
     # One extra, identical step with HIP events recorded on the launch stream around every msn_sgemm call.
+    # (towers one after the other for this step: with the light-curve tower on its own stream, as in the timed
+    # steps, an event pair around a GEMM would also span whatever the other stream ran meanwhile)
     ops.GEMM_PROFILE = []
+    concurrent, model.concurrent_towers = getattr(model, "concurrent_towers", False), False
     step()
     torch.cuda.synchronize()
+    model.concurrent_towers = concurrent
     prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
     gemm_ms = sum(e[0].elapsed_time(e[1]) for e in prof)
     gemm_flops = sum(e[2] for e in prof)

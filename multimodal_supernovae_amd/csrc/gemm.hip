@@ -337,7 +337,7 @@ struct DmaTile {
 };
 
 template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int DBK, int STAGES, bool CSUM = false>
-__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN)) void sgemm_dma_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM / WM) * (BN / WN) == 4 ? 2 : 1) void sgemm_dma_kernel(const GemmArgs p) {
     static_assert(!CSUM || AKM, "the fused column sums are those of a K-major A operand (wgrad: A = dY)");
     using TA = DmaTile<BM, AKM, DBK>;
     using TB = DmaTile<BN, BKM, DBK>;

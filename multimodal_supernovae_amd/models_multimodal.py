@@ -152,17 +152,43 @@ class LightCurveImageCLIP(nn.Module):
         self.logged[name] = value
 
     # -- forward: list of unit-norm embeddings in the FIXED order img, lc, sp, meta (ref :259-273) --
+    # Towers are independent until the loss: every tower after the first is enqueued on its own HIP stream, so the
+    # vector-ALU / HBM-bound kernels of a light-curve or spectrum tower fill the CUs a matrix-core GEMM of the image
+    # tower leaves idle (round tails, launch gaps).  autograd replays each tower's backward on the stream its forward
+    # ran on, with the joins it needs; results are unchanged (no cross-stream reductions).
+    concurrent_towers = True
+
+    def _side_streams(self, n, device):
+        pool = getattr(self, "_tower_streams", None)
+        if pool is None or len(pool) < n or pool[0].device != device:
+            pool = self._tower_streams = [torch.cuda.Stream(device=device) for _ in range(n)]
+        return pool[:n]
+
     def forward(self, x_img, x_lc, t_lc, mask_lc, x_sp, t_sp, mask_sp, redshift=None, classification=None):
-        x = []
+        towers = []
         if "host_galaxy" in self.combinations:
-            x.append(self.image_embeddings_with_projection(x_img))
+            towers.append(lambda: self.image_embeddings_with_projection(x_img))
         if "lightcurve" in self.combinations:
-            x.append(self.lightcurve_embeddings_with_projection(x_lc, t_lc, mask_lc))
+            towers.append(lambda: self.lightcurve_embeddings_with_projection(x_lc, t_lc, mask_lc))
         if "spectral" in self.combinations:
-            x.append(self.spectral_embeddings_with_projection(x_sp, t_sp, mask_sp))
+            towers.append(lambda: self.spectral_embeddings_with_projection(x_sp, t_sp, mask_sp))
         if "meta" in self.combinations:
-            x.append(self.meta_embeddings_with_projection(classification, redshift))
-        return x
+            towers.append(lambda: self.meta_embeddings_with_projection(classification, redshift))
+        device = self.logit_scale.device
+        if not (self.concurrent_towers and device.type == "cuda" and len(towers) > 1):
+            return [t() for t in towers]
+        main = torch.cuda.current_stream(device)
+        side = self._side_streams(len(towers) - 1, device)
+        out = [None] * len(towers)
+        for i in range(1, len(towers)):           # the later (smaller) towers first: their queues fill while the
+            side[i - 1].wait_stream(main)         # first tower's launches follow on the caller's stream
+            with torch.cuda.stream(side[i - 1]):
+                out[i] = towers[i]()
+        out[0] = towers[0]()
+        for i in range(1, len(towers)):
+            main.wait_stream(side[i - 1])
+            out[i].record_stream(main)
+        return out
 
     def image_embeddings_with_projection(self, x_img):
         h = self.image_encoder(x_img)
