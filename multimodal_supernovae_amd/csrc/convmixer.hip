@@ -87,23 +87,48 @@ __global__ __launch_bounds__(256) void bn_sqdev_kernel(const float* __restrict__
         b = 0.f;
     });
 }
+// Sum of the per-block partials of one channel: the finish kernels run 1024 threads = 16 groups x 64 channels, every
+// group walks a sixteenth of the blocks with 4 independent loads in flight, groups combined through LDS in a fixed order
+// (a single thread per channel walking all blocks was ~60 us of dependent loads per BatchNorm).
+__device__ __forceinline__ float slab_sum16(const float* __restrict__ part, int64_t stride, int nblocks, int c, int C,
+                                            float (*red)[64]) {
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C) {
+        int b = g;
+        for (; b + 48 < nblocks; b += 64) {
+            s0 += part[(int64_t)b * stride + c];
+            s1 += part[(int64_t)(b + 16) * stride + c];
+            s2 += part[(int64_t)(b + 32) * stride + c];
+            s3 += part[(int64_t)(b + 48) * stride + c];
+        }
+        for (; b < nblocks; b += 16) s0 += part[(int64_t)b * stride + c];
+    }
+    __syncthreads();
+    red[g][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][cl];
+    return t;
+}
 // stage 1 finish: mean = sum / rows
-__global__ void bn_mean_finish_kernel(const float* __restrict__ part, int nblocks, int64_t rows, int C,
-                                      float* __restrict__ mean) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += part[((int64_t)b * 2) * C + c];
-    mean[c] = s / (float)rows;
+__global__ __launch_bounds__(1024) void bn_mean_finish_kernel(const float* __restrict__ part, int nblocks, int64_t rows,
+                                                              int C, float* __restrict__ mean) {
+    __shared__ float red[16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const float s = slab_sum16(part, 2 * (int64_t)C, nblocks, c, C, red);
+    if (threadIdx.x < 64 && c < C) mean[c] = s / (float)rows;
 }
 // stage 2 finish: biased var -> rstd; running stats (unbiased var) as nn.BatchNorm2d in train mode
-__global__ void bn_var_finish_kernel(const float* __restrict__ part, int nblocks, int64_t rows, int C, float eps,
-                                     const float* __restrict__ mean, float* __restrict__ rstd,
-                                     float* __restrict__ running_mean, float* __restrict__ running_var, float momentum) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += part[((int64_t)b * 2) * C + c];
+__global__ __launch_bounds__(1024) void bn_var_finish_kernel(const float* __restrict__ part, int nblocks, int64_t rows,
+                                                             int C, float eps, const float* __restrict__ mean,
+                                                             float* __restrict__ rstd, float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var, float momentum) {
+    __shared__ float red[16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const float s = slab_sum16(part, 2 * (int64_t)C, nblocks, c, C, red);
+    if (threadIdx.x >= 64 || c >= C) return;
     const float var = s / (float)rows;
     rstd[c] = 1.f / sqrtf(var + eps);
     if (running_mean) {
@@ -148,17 +173,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         b = d * (x[r * C + c] - mean[c]) * rstd[c];
     });
 }
-__global__ void bn_bwd_finish_kernel(const float* __restrict__ part, int nblocks, int C, float* __restrict__ dbeta,
-                                     float* __restrict__ dgamma) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float sa = 0.f, sb = 0.f;
-    for (int b = 0; b < nblocks; ++b) {
-        sa += part[((int64_t)b * 2 + 0) * C + c];
-        sb += part[((int64_t)b * 2 + 1) * C + c];
+__global__ __launch_bounds__(1024) void bn_bwd_finish_kernel(const float* __restrict__ part, int nblocks, int C,
+                                                             float* __restrict__ dbeta, float* __restrict__ dgamma) {
+    __shared__ float red[16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const float sa = slab_sum16(part, 2 * (int64_t)C, nblocks, c, C, red);
+    const float sb = slab_sum16(part + C, 2 * (int64_t)C, nblocks, c, C, red);
+    if (threadIdx.x < 64 && c < C) {
+        dbeta[c] = sa;
+        dgamma[c] = sb;
     }
-    dbeta[c] = sa;
-    dgamma[c] = sb;
 }
 // dx = gamma * rstd * (dy - [train](dbeta + xhat * dgamma) / rows), then * pre[] (= saved gelu') when non-null
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -311,9 +335,9 @@ extern "C" int msn_batchnorm_fwd(const float* x, int64_t rows, int C, const floa
         const int nb = red_blocks(rows);
         const dim3 grid(nb, (unsigned)cdiv(C, RED_CP));
         hipLaunchKernelGGL(bn_sum_kernel, grid, dim3(256), 0, st, x, rows, C, part);
-        hipLaunchKernelGGL(bn_mean_finish_kernel, dim3(cb), dim3(64), 0, st, part, nb, rows, C, mean);
+        hipLaunchKernelGGL(bn_mean_finish_kernel, dim3(cb), dim3(1024), 0, st, part, nb, rows, C, mean);
         hipLaunchKernelGGL(bn_sqdev_kernel, grid, dim3(256), 0, st, x, mean, rows, C, part);
-        hipLaunchKernelGGL(bn_var_finish_kernel, dim3(cb), dim3(64), 0, st, part, nb, rows, C, eps, mean, rstd,
+        hipLaunchKernelGGL(bn_var_finish_kernel, dim3(cb), dim3(1024), 0, st, part, nb, rows, C, eps, mean, rstd,
                            running_mean, running_var, momentum);
     } else {
         MSN_REQUIRE(running_mean && running_var, "msn_batchnorm_fwd: eval mode needs the running statistics");
@@ -341,7 +365,7 @@ extern "C" int msn_batchnorm_bwd(const float* dy, const float* x, const float* p
     const int nb = red_blocks(rows);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, (unsigned)cdiv(C, RED_CP)), dim3(256), 0, st, dy, x, mean, rstd,
                        rows, C, part);
-    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, st, part, nb, C, dbeta, dgamma);
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((unsigned)cdiv(C, 64)), dim3(1024), 0, st, part, nb, C, dbeta, dgamma);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * C)), dim3(256), 0, st, dy, x, pre, mean, rstd, gamma,
                        dbeta, dgamma, rows, C, training, dx);
     MSN_LAUNCH_CHECK();
