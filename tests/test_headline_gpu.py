@@ -1,0 +1,79 @@
+"""The benchmarked configuration itself (bench.py: ViT-S/8 image tower + the reference light-curve transformer,
+symmetric InfoNCE, RAdam): one training step of the HIP path against the oracle on the same synthetic batch, and
+size-independent properties at the full per-GPU batch of 1024."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _oracle_step(P, batch):
+    import bench
+    from oracle import clip as oclip
+    from oracle import encoders as oenc
+    from oracle import loss as oloss
+    from oracle.build_defined import vision_transformer
+    h = vision_transformer(P, "image_encoder.", batch[0], patch=8, heads=6, depth=12)
+    e_img = oclip.l2_normalise(oenc.linear(P, "image_projection", h))
+    h = oenc.transformer_with_time_embeddings(P, "lightcurve_encoder.", batch[1][..., None], batch[2], batch[3],
+                                              emb=bench.LC["emb"], heads=bench.LC["heads"], depth=bench.LC["depth"],
+                                              time_norm=bench.LC["time_norm"], nband=bench.NBAND, agg="mean")
+    e_lc = oclip.l2_normalise(oenc.linear(P, "lightcurve_projection", h))
+    return oloss.clip_loss_multimodal([e_img, e_lc], P["logit_scale"], P["logit_bias"]), e_img, e_lc
+
+
+def test_headline_step_matches_oracle():
+    """fp32 tolerance of the north star: loss and embeddings within 1e-3 relative (observed ~1e-6); gradients of every
+    parameter within 2e-3 of their own scale."""
+    import bench
+    model = bench.build_model("cpu", seed=3)
+    P = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    batch = bench.synthetic_batch(24, 99, "cpu")
+    ref, e_img_ref, e_lc_ref = _oracle_step(P, batch)
+    ref.backward()
+    model.cuda()
+    gb = tuple(t.cuda() if torch.is_tensor(t) else t for t in batch)
+    embs = model(*gb)
+    torch.testing.assert_close(embs[0].detach().cpu(), e_img_ref.detach(), rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(embs[1].detach().cpu(), e_lc_ref.detach(), rtol=1e-3, atol=1e-5)
+    loss = model.training_step(gb, 0)
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-3 * abs(float(ref.detach()))
+    loss.backward()
+    worst = 0.0
+    for k, p in model.named_parameters():
+        if k == "logit_bias":      # analytically zero gradient
+            continue
+        g_ref = P[k].grad
+        scale = float(g_ref.abs().max()) + 1e-12
+        worst = max(worst, float((p.grad.cpu() - g_ref).abs().max()) / scale)
+    assert worst < 2e-3, worst
+
+
+def test_full_batch_properties():
+    """Per-GPU batch 1024 (the bench size): the symmetric InfoNCE is invariant under a common permutation of the pairs,
+    embeddings are unit vectors, and a sample's embedding does not depend on the rest of the batch (LayerNorm
+    towers): its value inside the 1024-batch equals its value in a 16-sample batch."""
+    import bench
+    model = bench.build_model("cuda", seed=5)
+    batch = bench.synthetic_batch(1024, 7, "cuda")
+    with torch.no_grad():
+        e = model(*batch)
+        loss = model._loss(e)
+        perm = torch.randperm(1024, device="cuda")
+        pb = tuple(t[perm] if torch.is_tensor(t) and t.dim() > 0 and t.shape[0] == 1024 else t for t in batch)
+        ep = model(*pb)
+        loss_p = model._loss(ep)
+        small = tuple(t[:16] if torch.is_tensor(t) and t.dim() > 0 and t.shape[0] == 1024 else t for t in batch)
+        es = model(*small)
+    for t in e:
+        torch.testing.assert_close(t.norm(dim=-1), torch.ones(1024, device="cuda"), rtol=0, atol=2e-6)
+    assert abs(float(loss) - float(loss_p)) <= 2e-6 * abs(float(loss))
+    for a, b in zip(e, ep):
+        torch.testing.assert_close(a[perm], b, rtol=1e-5, atol=1e-6)
+    for a, b in zip(e, es):
+        torch.testing.assert_close(a[:16], b, rtol=1e-5, atol=2e-6)
