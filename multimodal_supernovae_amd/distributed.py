@@ -123,19 +123,30 @@ class GradientReducer:
                 views.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
             bi = len(self.buckets)
-            self.buckets.append({"params": plist, "flat": flat, "views": views, "ready": 0, "work": None})
+            self.buckets.append({"params": plist, "flat": flat, "views": views, "ready": 0, "work": None, "events": []})
             for p in plist:
                 self._where[p] = bi
                 self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     def _on_grad(self, p):
         b = self.buckets[self._where[p]]
+        if p.grad is not None and p.grad.is_cuda:
+            # towers run on their own streams (models_multimodal.forward): the gradient exists on the stream this hook
+            # runs under, which need not be the stream the bucket is finally gathered on
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(p.grad.device))
+            b["events"].append(ev)
         b["ready"] += 1
         if b["ready"] == len(b["params"]) and b["work"] is None:
             self._launch(b)
 
     @torch.no_grad()
     def _launch(self, b):
+        if b["events"]:
+            cur = torch.cuda.current_stream(b["flat"].device)
+            for ev in b["events"]:
+                cur.wait_event(ev)
+            b["events"] = []
         have = [(v, p.grad) for v, p in zip(b["views"], b["params"]) if p.grad is not None]
         if len(have) < len(b["params"]):
             b["flat"].zero_()
@@ -151,7 +162,7 @@ class GradientReducer:
                 self._launch(b)
         for b in self.buckets:
             b["work"].wait()
-            b["work"], b["ready"] = None, 0
+            b["work"], b["ready"], b["events"] = None, 0, []
 
     def remove(self):
         for h in self._handles:
