@@ -191,6 +191,9 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the extra split-bf16 measurement")
     ap.add_argument("--workload", default="vit_s8_lc", choices=list(WORKLOADS),
                     help="vit_s8_lc = the headline (default); the others are the remaining BASELINE.json configurations")
+    ap.add_argument("--serial-towers", action="store_true",
+                    help="towers one after the other on one stream (profiling: with a tower per stream rocprofv3's "
+                         "per-kernel durations include whatever the other stream ran meanwhile)")
     ap.add_argument("--gemm-table", action="store_true", help="per-shape GEMM timing of one step on stderr")
     ap.add_argument("--gemm-variant", type=int, default=3, choices=[0, 1, 2, 3],
                     help="fp32 GEMM kernel family: 0 register-staged, 1 / 2 / 3 LDS-DMA rings (3 = default)")
@@ -219,6 +222,8 @@ def main():
     else:
         model, batch = build_workload(args.workload, b, 1234 + rank, device)
         args.no_alt, args.no_cpu_baseline = True, True
+    if args.serial_towers:
+        model.concurrent_towers = False
     D.broadcast_module(model)
     opt = model.configure_optimizers()["optimizer"]
     params = [p for p in model.parameters()]
