@@ -1,0 +1,62 @@
+"""Seeded fuzz of msn_attention_fwd / _bwd over head widths, sequence lengths (also Tq != Tk), masks and both kernel
+families.  Reference: the reference's formula in fp64 (scores * scale, -1e7 key fill, softmax, @ v)."""
+import math
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(q, k, v, mask, heads, scale):
+    B, Tq, E = q.shape
+    s = E // heads
+    qh, kh, vh = (t.view(B, -1, heads, s) for t in (q, k, v))
+    dot = torch.einsum("bihs,bjhs->bhij", qh, kh) * scale
+    if mask is not None:
+        dot = torch.where(mask[:, None, None, :], dot, torch.full_like(dot, -1e7))
+    return torch.einsum("bhij,bjhs->bihs", torch.softmax(dot, dim=-1), vh).reshape(B, Tq, E)
+
+
+@pytest.mark.parametrize("seed", range(5))
+@pytest.mark.parametrize("path", [1, 2])
+def test_attention_fuzz(seed, path):
+    from multimodal_supernovae_amd import _lib, ops
+    rng = random.Random(300 + seed)
+    g = torch.Generator().manual_seed(seed)
+    _lib.check(_lib.lib().msn_set_attention_path(path))
+    try:
+        for _ in range(14):
+            heads = rng.choice([1, 2, 3, 4, 6, 8])
+            hd = rng.choice([4, 8, 8, 12, 16, 16, 24, 32, 64])
+            E = heads * hd
+            B = rng.randint(1, 3)
+            lengths = [1, 2, 7, 8, 9, 15, 16, 17, 31, 33, 64, 65, 127, 129, 200, 220, 255, 256, 257, 300]
+            Tk = rng.choice(lengths) if rng.random() < 0.8 else rng.randint(300, 1100)
+            Tq = Tk if rng.random() < 0.8 else rng.randint(1, Tk)
+            q = torch.randn(B, Tq, E, generator=g)
+            k, v = torch.randn(B, Tk, E, generator=g), torch.randn(B, Tk, E, generator=g)
+            dout = torch.randn(B, Tq, E, generator=g)
+            mask = None
+            if rng.random() < 0.6:
+                mask = torch.rand(B, Tk, generator=g) > 0.3
+                mask[:, 0] = True
+                if rng.random() < 0.3:
+                    mask[-1] = False          # a fully padded sample
+            scale = 1.0 / math.sqrt(E)
+            qr, kr, vr = (t.double().requires_grad_() for t in (q, k, v))
+            ref = _ref(qr, kr, vr, mask, heads, scale)
+            ref.backward(dout.double())
+            qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+            mu8 = ops._mask_u8(mask.cuda()) if mask is not None else None
+            out, lse = ops.attention_fwd(qc, kc, vc, mu8, heads, scale)
+            what = (B, Tq, Tk, heads, hd, mask is not None, path)
+            torch.testing.assert_close(out.cpu().double(), ref.detach(), rtol=1e-4, atol=3e-5, msg=lambda m: f"{what}: {m}")
+            dq, dk, dv = torch.empty_like(qc), torch.empty_like(kc), torch.empty_like(vc)
+            ops.attention_bwd(qc, kc, vc, mu8, heads, scale, out, lse, dout.cuda(), dq, dk, dv)
+            for got, want, name in ((dq, qr.grad, "dq"), (dk, kr.grad, "dk"), (dv, vr.grad, "dv")):
+                torch.testing.assert_close(got.cpu().double(), want, rtol=3e-4, atol=3e-5,
+                                           msg=lambda m: f"{name} {what}: {m}")
+    finally:
+        _lib.lib().msn_set_attention_path(0)
