@@ -189,3 +189,38 @@ def test_masked_pretraining_matches_reference():
     mask_in, mask_pred = get_continous_random_mask(i["padding_mask"], c["nband"], f_mask=c["f_mask"])
     assert not (mask_pred & ~i["padding_mask"]).any() and not (mask_in & mask_pred).any()
     assert torch.isfinite(m.training_step((t, x, pad), 0).detach())
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 7])
+def test_small_and_odd_batches_match_oracle(B):
+    """Edge sizes of the step itself: a single pair (the InfoNCE of one pair is 0 with gradient 0 to the
+    embeddings), odd batches, ragged masks down to one valid time step -- HIP module against the oracle."""
+    from oracle import clip as oclip
+    cfg = dict(enc_dim=16, nband=2, combinations=["lightcurve", "spectral"],
+               transformer_kwargs=dict(n_out=8, emb=16, heads=2, depth=2, dropout=0.0, time_norm=1000.0, agg="mean"),
+               transformer_spectral_kwargs=dict(n_out=8, emb=16, heads=4, depth=1, dropout=0.0, time_norm=5000.0, agg="max"),
+               conv_kwargs=dict(dim=8, depth=1, channels=3, kernel_size=5, patch_size=8, n_out=8, dropout_prob=0.0),
+               meta_kwargs=None, weight_decay=0.0, lr=1e-3, loss="softmax")
+    torch.manual_seed(40 + B)
+    model = _build(cfg)
+    P = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(B)
+    T_lc, T_sp = 10, 9
+    mask_lc = torch.arange(T_lc)[None, :] < torch.randint(1, T_lc + 1, (B, 1), generator=g)
+    mask_sp = torch.arange(T_sp)[None, :] < torch.randint(1, T_sp + 1, (B, 1), generator=g)
+    batch = (None, torch.randn(B, T_lc, generator=g), torch.rand(B, T_lc, generator=g) * 100, mask_lc,
+             torch.randn(B, T_sp, generator=g), torch.rand(B, T_sp, generator=g) * 6000 + 3000, mask_sp, None, None)
+    ref = oclip.training_loss(P, cfg, batch, loss="softmax")
+    ref.backward()
+    model.cuda().train()
+    loss = model.training_step(tuple(t.cuda() if torch.is_tensor(t) else t for t in batch), 0)
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-5 + RTOL * abs(float(ref.detach()))
+    loss.backward()
+    for k, p in model.named_parameters():
+        want = P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])
+        got = p.grad.cpu() if p.grad is not None else torch.zeros_like(want)
+        if k == "logit_bias":
+            assert abs(float(got)) < 1e-5
+            continue
+        scale = float(want.abs().max()) + 1e-6
+        assert float((got - want).abs().max()) <= 2e-3 * scale + 1e-6, (k, B)
