@@ -189,3 +189,32 @@ def test_attention_single_shared_query():
     torch.testing.assert_close(dq.sum(0, keepdim=True).cpu().double(), qr.grad, rtol=2e-4, atol=2e-5)
     torch.testing.assert_close(dk.cpu().double(), kr.grad, rtol=2e-4, atol=2e-5)
     torch.testing.assert_close(dv.cpu().double(), vr.grad, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("rows,C", [(7, 8), (1000, 32), (65536, 64), (200001, 130), (300000, 4)])
+@pytest.mark.parametrize("training", [True, False])
+def test_batchnorm_kernels_direct(rows, C, training):
+    """msn_batchnorm_fwd / _bwd on channels-last (rows, C) matrices against torch's batch_norm in fp64, from a handful
+    of rows to the many-block regime where the per-channel partials are summed by 16 thread groups; running statistics
+    (momentum 0.1, unbiased variance) included."""
+    from multimodal_supernovae_amd import ops
+    g = _g(rows + C)
+    x = torch.randn(rows, C, generator=g) * 1.5 + 0.3
+    gamma, beta = torch.randn(C, generator=g) + 1, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    dy = torch.randn(rows, C, generator=g)
+    xr, gr, br = x.double().requires_grad_(), gamma.double().requires_grad_(), beta.double().requires_grad_()
+    rm_ref, rv_ref = rm.double().clone(), rv.double().clone()
+    yr = F.batch_norm(xr, rm_ref, rv_ref, gr, br, training=training, momentum=0.1, eps=1e-5)
+    yr.backward(dy.double())
+    rm_d, rv_d = rm.cuda(), rv.cuda()
+    y, mean, rstd = ops.batchnorm_fwd(x.cuda(), gamma.cuda(), beta.cuda(), rm_d, rv_d, training)
+    torch.testing.assert_close(y.cpu().double(), yr.detach(), rtol=1e-4, atol=2e-5)
+    if training and rows > 1:
+        torch.testing.assert_close(rm_d.cpu().double(), rm_ref, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(rv_d.cpu().double(), rv_ref, rtol=1e-4, atol=1e-6)
+    dx, dg, db = ops.batchnorm_bwd(dy.cuda(), x.cuda(), None, mean, rstd, gamma.cuda(), training)
+    col = dict(rtol=1e-4, atol=1e-4 * max(1.0, rows ** 0.5 / 30))
+    torch.testing.assert_close(dx.cpu().double(), xr.grad, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(dg.cpu().double(), gr.grad, **col)
+    torch.testing.assert_close(db.cpu().double(), br.grad, **col)
