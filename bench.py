@@ -199,6 +199,8 @@ def main():
                     help="fp32 GEMM kernel family: 0 register-staged, 1 / 2 / 3 LDS-DMA rings (3 = default)")
     ap.add_argument("--gemm-precision", default="f32", choices=["f32", "bf16x3", "bf16"],
                     help="inner-product precision of the GEMMs (bf16x3 = split-bf16, fp32-grade accuracy)")
+    ap.add_argument("--sync-batchnorm", action="store_true",
+                    help="N > 1, BatchNorm towers (resnet18_cnn1d, convmixer_lc_sp): batch statistics over all ranks")
     ap.add_argument("--cpu-sample-batch", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=0, help="timed oracle steps (0 = fill about 12 s)")
     args = ap.parse_args()
@@ -225,6 +227,8 @@ def main():
     if args.serial_towers:
         model.concurrent_towers = False
     D.broadcast_module(model)
+    if args.sync_batchnorm and world > 1:
+        D.enable_sync_batchnorm()
     opt = model.configure_optimizers()["optimizer"]
     params = [p for p in model.parameters()]
     reducer = D.GradientReducer(params)     # N > 1: bucketed SUM all-reduce launched from autograd hooks, under backward

@@ -261,6 +261,29 @@ int msn_batchnorm_bwd(const float* dy, const float* x, const float* dact, int64_
                       const float* mean, const float* rstd, const float* gamma, int training, float* dx,
                       float* dgamma, float* dbeta, void* ws, size_t ws_bytes, msn_stream_t stream);
 
+/* Synchronised BatchNorm for data-parallel replicas (per-replica statistics differ from the
+ * single-process statistics at the global batch).  The same two-pass statistics as msn_batchnorm_fwd / _bwd, cut at
+ * the points where the CALLER all-reduces (SUM, RCCL) C floats (forward, twice) or 2C floats (backward):
+ *   fwd: colsum(center = NULL) -> all-reduce -> mean_from_sum(count = global rows)
+ *        -> colsum(center = mean) -> all-reduce -> rstd_from_sqdev (running statistics from the global batch)
+ *        -> msn_batchnorm_apply
+ *   bwd: bwd_sums (sums[0..C) = sum dy = the LOCAL d beta, sums[C..2C) = sum dy * xhat = the LOCAL d gamma; parameter
+ *        gradients stay local sums, the gradient all-reduce adds the other ranks) -> all-reduce of a copy
+ *        -> bwd_apply with the global sums and count. */
+int msn_bn_colsum(const float* x, int64_t rows, int C, const float* center, float* out, void* ws, size_t ws_bytes,
+                  msn_stream_t stream);
+int msn_bn_mean_from_sum(const float* sum, int64_t count, int C, float* mean, msn_stream_t stream);
+int msn_bn_rstd_from_sqdev(const float* sqdev, int64_t count, int C, float eps, float momentum, const float* mean,
+                           float* running_mean, float* running_var, float* rstd, msn_stream_t stream);
+int msn_batchnorm_apply(const float* x, int64_t rows, int C, const float* mean, const float* rstd,
+                        const float* gamma, const float* beta, const float* residual, int relu, float* y,
+                        msn_stream_t stream);
+int msn_bn_bwd_sums(const float* dy, const float* x, int64_t rows, int C, const float* mean, const float* rstd,
+                    float* sums, void* ws, size_t ws_bytes, msn_stream_t stream);
+int msn_bn_bwd_apply(const float* dy, const float* x, const float* dact, int64_t rows, int64_t count, int C,
+                     const float* mean, const float* rstd, const float* gamma, const float* sums, float* dx,
+                     msn_stream_t stream);
+
 /* depthwise k x k conv, padding='same', + bias, + GELU (:65-69): x (B, gh, gw, C) channels-last,
  * w (C, 1, k, k).  fwd writes act = gelu(pre) and dact = gelu'(pre) with pre = conv + bias.
  * bwd: dx = conv^T(dpre) (+ add), dw (C,1,k,k), dbias (C; may be NULL). */

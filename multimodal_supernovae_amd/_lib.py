@@ -73,6 +73,12 @@ SIGNATURES = {
     "msn_maxpool2d_bwd": (c_int, [c_ptr, c_ptr] + [c_int] * 7 + [c_ptr, c_ptr]),
     "msn_batchnorm_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr,
                                   c_ptr, c_size, c_ptr]),
+    "msn_bn_colsum": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "msn_bn_mean_from_sum": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr]),
+    "msn_bn_rstd_from_sqdev": (c_int, [c_ptr, c_i64, c_int, c_f32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "msn_batchnorm_apply": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr]),
+    "msn_bn_bwd_sums": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "msn_bn_bwd_apply": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "msn_dwconv_gelu_fwd": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     "msn_dwconv_bwd_workspace_bytes": (c_size, [c_int, c_int, c_int]),
     "msn_dwconv_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr,

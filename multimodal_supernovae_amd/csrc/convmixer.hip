@@ -189,9 +189,9 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ pre, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                     const float* __restrict__ dbeta, const float* __restrict__ dgamma, int64_t rows,
-                                    int C, int training, float* __restrict__ dx) {
+                                    int64_t count, int C, int training, float* __restrict__ dx) {
     const int64_t total = rows * C;
-    const float inv_n = 1.f / (float)rows;
+    const float inv_n = 1.f / (float)count;   // count = rows, or the rows of ALL ranks under synchronised BN
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         float d = dy[i];
@@ -367,7 +367,107 @@ extern "C" int msn_batchnorm_bwd(const float* dy, const float* x, const float* p
                        rows, C, part);
     hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((unsigned)cdiv(C, 64)), dim3(1024), 0, st, part, nb, C, dbeta, dgamma);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * C)), dim3(256), 0, st, dy, x, pre, mean, rstd, gamma,
-                       dbeta, dgamma, rows, C, training, dx);
+                       dbeta, dgamma, rows, rows, C, training, dx);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+// ---- synchronised (data-parallel) BatchNorm: the same two-pass statistics cut at the points where the caller
+// all-reduces C (forward, twice) or 2C (backward) floats across the ranks -------------------------------------------
+__global__ __launch_bounds__(1024) void bn_sum_finish_kernel(const float* __restrict__ part, int nblocks, int C,
+                                                             float* __restrict__ out) {
+    __shared__ float red[16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const float s = slab_sum16(part, 2 * (int64_t)C, nblocks, c, C, red);
+    if (threadIdx.x < 64 && c < C) out[c] = s;
+}
+__global__ void bn_mean_from_sum_kernel(const float* __restrict__ sum, int64_t count, int C, float* __restrict__ mean) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) mean[c] = sum[c] / (float)count;
+}
+__global__ void bn_rstd_from_sqdev_kernel(const float* __restrict__ sqdev, int64_t count, int C, float eps,
+                                          const float* __restrict__ mean, float* __restrict__ rstd,
+                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                          float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float s = sqdev[c], var = s / (float)count;
+    rstd[c] = 1.f / sqrtf(var + eps);
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[c];
+        const float unbiased = count > 1 ? s / (float)(count - 1) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+extern "C" int msn_bn_colsum(const float* x, int64_t rows, int C, const float* center, float* out, void* ws,
+                             size_t ws_bytes, msn_stream_t stream) {
+    MSN_REQUIRE(x && out && rows > 0 && C > 0, "msn_bn_colsum: bad arguments");
+    MSN_REQUIRE(ws && ws_bytes >= msn_bn_workspace_bytes(rows, C), "msn_bn_colsum: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(ws);
+    const int nb = red_blocks(rows);
+    const dim3 grid(nb, (unsigned)cdiv(C, RED_CP));
+    if (center)
+        hipLaunchKernelGGL(bn_sqdev_kernel, grid, dim3(256), 0, st, x, center, rows, C, part);
+    else
+        hipLaunchKernelGGL(bn_sum_kernel, grid, dim3(256), 0, st, x, rows, C, part);
+    hipLaunchKernelGGL(bn_sum_finish_kernel, dim3((unsigned)cdiv(C, 64)), dim3(1024), 0, st, part, nb, C, out);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" int msn_bn_mean_from_sum(const float* sum, int64_t count, int C, float* mean, msn_stream_t stream) {
+    MSN_REQUIRE(sum && mean && count > 0 && C > 0, "msn_bn_mean_from_sum: bad arguments");
+    hipLaunchKernelGGL(bn_mean_from_sum_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       sum, count, C, mean);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" int msn_bn_rstd_from_sqdev(const float* sqdev, int64_t count, int C, float eps, float momentum,
+                                      const float* mean, float* running_mean, float* running_var, float* rstd,
+                                      msn_stream_t stream) {
+    MSN_REQUIRE(sqdev && mean && rstd && count > 0 && C > 0, "msn_bn_rstd_from_sqdev: bad arguments");
+    MSN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "msn_bn_rstd_from_sqdev: running stats come in pairs");
+    hipLaunchKernelGGL(bn_rstd_from_sqdev_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0,
+                       static_cast<hipStream_t>(stream), sqdev, count, C, eps, mean, rstd, running_mean, running_var,
+                       momentum);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" int msn_batchnorm_apply(const float* x, int64_t rows, int C, const float* mean, const float* rstd,
+                                   const float* gamma, const float* beta, const float* residual, int relu, float* y,
+                                   msn_stream_t stream) {
+    MSN_REQUIRE(x && mean && rstd && gamma && beta && y && rows > 0 && C > 0, "msn_batchnorm_apply: bad arguments");
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(rows * C)), dim3(256), 0, static_cast<hipStream_t>(stream), x, rows,
+                       C, mean, rstd, gamma, beta, residual, relu, y);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" int msn_bn_bwd_sums(const float* dy, const float* x, int64_t rows, int C, const float* mean,
+                               const float* rstd, float* sums, void* ws, size_t ws_bytes, msn_stream_t stream) {
+    MSN_REQUIRE(dy && x && mean && rstd && sums && rows > 0 && C > 0, "msn_bn_bwd_sums: bad arguments");
+    MSN_REQUIRE(ws && ws_bytes >= msn_bn_workspace_bytes(rows, C), "msn_bn_bwd_sums: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(ws);
+    const int nb = red_blocks(rows);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, (unsigned)cdiv(C, RED_CP)), dim3(256), 0, st, dy, x, mean, rstd,
+                       rows, C, part);
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((unsigned)cdiv(C, 64)), dim3(1024), 0, st, part, nb, C, sums, sums + C);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" int msn_bn_bwd_apply(const float* dy, const float* x, const float* dact, int64_t rows, int64_t count, int C,
+                                const float* mean, const float* rstd, const float* gamma, const float* sums, float* dx,
+                                msn_stream_t stream) {
+    MSN_REQUIRE(dy && x && mean && rstd && gamma && sums && dx && rows > 0 && count >= rows && C > 0,
+                "msn_bn_bwd_apply: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * C)), dim3(256), 0, static_cast<hipStream_t>(stream), dy, x,
+                       dact, mean, rstd, gamma, sums, sums + C, rows, count, C, 1, dx);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }

@@ -51,6 +51,16 @@ def broadcast_module(module, src=0, group=None):
         dist.broadcast(t.data, src=src, group=group)
 
 
+def enable_sync_batchnorm(group=None, enabled=True):
+    """Batch statistics of every BatchNorm on the path (ConvMixer / ResNet-18 / 1-D CNN towers) over the rows of ALL
+    ranks of `group` instead of per replica -- the counterpart of Lightning's `Trainer(sync_batchnorm=True)`; with it a
+    data-parallel step equals the single-process step at the global batch.  The kernels are
+    the single-process two-pass statistics cut where C (forward, twice) or 2C (backward) floats are all-reduced
+    (ops.batchnorm_fwd / batchnorm_bwd).  Equal rows per rank are assumed.  Off by default."""
+    from . import ops
+    ops.BN_SYNC_GROUP = (group if group is not None else True) if enabled else None
+
+
 @torch.no_grad()
 def allreduce_gradients(params, group=None, bucket_bytes=32 << 20):
     """SUM-all-reduce the .grad of `params` in flat buckets of ~bucket_bytes.  Every rank must call it

@@ -314,6 +314,24 @@ def unpatchify(dpatches, shape, p):
     return dimg
 
 
+# Synchronised BatchNorm (data parallel): `distributed.enable_sync_batchnorm(group)` sets this to the process group
+# whose ranks share batch statistics; None = per-replica statistics (what Lightning's DDP does by default).
+BN_SYNC_GROUP = None
+
+
+def _bn_sync_world():
+    import torch.distributed as dist
+    if BN_SYNC_GROUP is None or not (dist.is_available() and dist.is_initialized()):
+        return 1
+    return dist.get_world_size(None if BN_SYNC_GROUP is True else BN_SYNC_GROUP)
+
+
+def _bn_allreduce(t):
+    import torch.distributed as dist
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=None if BN_SYNC_GROUP is True else BN_SYNC_GROUP)
+    return t
+
+
 def batchnorm_fwd(x, gamma, beta, running_mean, running_var, training, residual=None, momentum=0.1, eps=1e-5,
                   relu=False):
     rows, C = x.shape
@@ -324,6 +342,23 @@ def batchnorm_fwd(x, gamma, beta, running_mean, running_var, training, residual=
     L = lib()
     nb = L.msn_bn_workspace_bytes(rows, C)
     ws = _workspace(nb, dev)
+    world = _bn_sync_world() if training else 1
+    if world > 1:
+        # batch statistics over the rows of every rank (equal rows per rank): the two-pass scheme of the
+        # single-process kernel with an all-reduce of C floats after each local column sum
+        count = rows * world
+        acc = torch.empty(C, dtype=torch.float32, device=dev)
+        st = stream_ptr()
+        check(L.msn_bn_colsum(ptr(_f32c(x, "x")), rows, C, None, ptr(acc), ptr(ws), nb, st), "msn_bn_colsum")
+        _bn_allreduce(acc)
+        check(L.msn_bn_mean_from_sum(ptr(acc), count, C, ptr(mean), st), "msn_bn_mean_from_sum")
+        check(L.msn_bn_colsum(ptr(x), rows, C, ptr(mean), ptr(acc), ptr(ws), nb, st), "msn_bn_colsum")
+        _bn_allreduce(acc)
+        check(L.msn_bn_rstd_from_sqdev(ptr(acc), count, C, eps, momentum, ptr(mean), ptr(running_mean), ptr(running_var),
+                                       ptr(rstd), st), "msn_bn_rstd_from_sqdev")
+        check(L.msn_batchnorm_apply(ptr(x), rows, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(residual),
+                                    1 if relu else 0, ptr(y), st), "msn_batchnorm_apply")
+        return y, mean, rstd
     check(L.msn_batchnorm_fwd(ptr(_f32c(x, "x")), rows, C, ptr(gamma), ptr(beta), eps, 1 if training else 0, momentum,
                               ptr(running_mean), ptr(running_var), ptr(residual), 1 if relu else 0, ptr(y), ptr(mean),
                               ptr(rstd), ptr(ws), nb, stream_ptr()), "msn_batchnorm_fwd")
@@ -334,11 +369,23 @@ def batchnorm_bwd(dy, x, pre, mean, rstd, gamma, training):
     rows, C = x.shape
     dev = x.device
     dx = torch.empty_like(x)
-    dg = torch.empty(C, dtype=torch.float32, device=dev)
-    db = torch.empty(C, dtype=torch.float32, device=dev)
     L = lib()
     nb = L.msn_bn_workspace_bytes(rows, C)
     ws = _workspace(nb, dev)
+    world = _bn_sync_world() if training else 1
+    if world > 1:
+        # d beta / d gamma stay LOCAL sums (the gradient all-reduce adds the other ranks' share); dx needs the sums
+        # over every rank's rows
+        st = stream_ptr()
+        sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
+        check(L.msn_bn_bwd_sums(ptr(_f32c(dy, "dy")), ptr(x), rows, C, ptr(mean), ptr(rstd), ptr(sums), ptr(ws), nb, st),
+              "msn_bn_bwd_sums")
+        total = _bn_allreduce(sums.clone())
+        check(L.msn_bn_bwd_apply(ptr(dy), ptr(x), ptr(pre), rows, rows * world, C, ptr(mean), ptr(rstd), ptr(gamma),
+                                 ptr(total), ptr(dx), st), "msn_bn_bwd_apply")
+        return dx, sums[C:], sums[:C]
+    dg = torch.empty(C, dtype=torch.float32, device=dev)
+    db = torch.empty(C, dtype=torch.float32, device=dev)
     check(L.msn_batchnorm_bwd(ptr(_f32c(dy, "dy")), ptr(x), ptr(pre), rows, C, ptr(mean), ptr(rstd), ptr(gamma),
                               1 if training else 0, ptr(dx), ptr(dg), ptr(db), ptr(ws), nb, stream_ptr()),
           "msn_batchnorm_bwd")

@@ -27,11 +27,12 @@ def _to_device(batch, device):
 
 
 class Trainer:
-    def __init__(self, max_epochs=1, device=None, group=None, log_fn=None):
+    def __init__(self, max_epochs=1, device=None, group=None, log_fn=None, sync_batchnorm=False):
         self.max_epochs = max_epochs
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.group = group
         self.log_fn = log_fn
+        self.sync_batchnorm = sync_batchnorm   # pl.Trainer(sync_batchnorm=...): batch statistics over all ranks
         self.history = {"train_loss": [], "val_loss": []}
         self.step_losses = []
         self.global_step = 0
@@ -39,6 +40,7 @@ class Trainer:
     def fit(self, model, train_dataloaders, val_dataloaders=None):
         model.to(self.device)
         D.broadcast_module(model, group=self.group)
+        D.enable_sync_batchnorm(self.group, enabled=self.sync_batchnorm and D.world_size(self.group) > 1)
         optimizer = model.configure_optimizers()["optimizer"]
         self.optimizer = optimizer
         reducer = D.GradientReducer(model.parameters(), group=self.group)   # bucket all-reduces run under backward

@@ -16,3 +16,11 @@ def test_two_rank_step_equals_single_process_global_batch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dist_check.py")], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "DIST CHECK OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_two_rank_synchronised_batchnorm_equals_single_process_global_batch():
+    """ConvMixer tower (three BatchNorms per layer) under data parallel with `enable_sync_batchnorm`: loss, gradients
+    and running statistics of two ranks equal the single-process step at the doubled batch."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dist_check.py"), "--batchnorm"], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "DIST CHECK OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

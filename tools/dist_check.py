@@ -15,9 +15,16 @@ TK = dict(n_out=8, emb=16, heads=4, depth=2, dropout=0.0, time_norm=20583.37, ag
 SK = dict(n_out=8, emb=8, heads=2, depth=2, dropout=0.0, time_norm=17945.14, agg="mean")
 
 
+CK = dict(dim=8, depth=2, channels=3, kernel_size=5, patch_size=4, n_out=8, dropout_prob=0.0)
+BATCHNORM = "--batchnorm" in sys.argv     # ConvMixer image tower + light curves, synchronised BatchNorm
+
+
 def make_model():
     from multimodal_supernovae_amd.models_multimodal import LightCurveImageCLIP
     torch.manual_seed(0)
+    if BATCHNORM:
+        return LightCurveImageCLIP(enc_dim=16, nband=2, transformer_kwargs=TK, conv_kwargs=CK,
+                                   combinations=["host_galaxy", "lightcurve"], loss="softmax", lr=1e-2).cuda().train()
     return LightCurveImageCLIP(enc_dim=16, nband=2, transformer_kwargs=TK, transformer_spectral_kwargs=SK,
                                combinations=["lightcurve", "spectral"], loss="softmax", lr=1e-2).cuda().train()
 
@@ -26,6 +33,9 @@ def make_batch(n):
     g = torch.Generator().manual_seed(1)
     mask = torch.ones(n, 12, dtype=torch.bool)
     mask[:, 9:] = False
+    if BATCHNORM:
+        return (torch.rand(n, 3, 16, 16, generator=g), torch.randn(n, 12, generator=g), torch.rand(n, 12, generator=g) * 100,
+                mask, None, None, None, None, None)
     return (None, torch.randn(n, 12, generator=g), torch.rand(n, 12, generator=g) * 100, mask,
             torch.randn(n, 10, generator=g), torch.rand(n, 10, generator=g) * 6000 + 3000,
             torch.ones(n, 10, dtype=torch.bool), None, None)
@@ -35,6 +45,8 @@ def worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     from multimodal_supernovae_amd import distributed as D
     D.init_from_env(backend="gloo")
+    if BATCHNORM:
+        D.enable_sync_batchnorm()
     b = 8
     full = make_batch(world * b)
     local = tuple(t[rank * b:(rank + 1) * b].cuda() if t is not None else None for t in full)
@@ -48,6 +60,7 @@ def worker(rank, world, port, out):
     if rank == 0:
         dist.barrier()
         dist.destroy_process_group()       # single-process reference at the global batch
+        D.enable_sync_batchnorm(enabled=False)
         ref = make_model()
         rl = ref.training_step(tuple(t.cuda() if t is not None else None for t in full), 0)
         rl.backward()
@@ -62,6 +75,9 @@ def worker(rank, world, port, out):
         out["top"] = sorted(errs)[-3:]
         out["loss"] = (float(loss.detach()), float(rl.detach()))
         out["worst_rel_grad_err"] = worst
+        if BATCHNORM:                      # running statistics come from the global batch too
+            sd, rd = model.state_dict(), ref.state_dict()
+            out["worst_running_stat_err"] = max(float((sd[k] - rd[k]).abs().max()) for k in sd if "running_" in k)
     else:
         dist.barrier()
         dist.destroy_process_group()
@@ -75,6 +91,6 @@ if __name__ == "__main__":
     [p.join(300) for p in procs]
     print(dict(out), [p.exitcode for p in procs])
     ok = all(p.exitcode == 0 for p in procs) and abs(out["loss"][0] - out["loss"][1]) < 1e-4 * abs(out["loss"][1]) \
-        and out["worst_rel_grad_err"] < 1e-3
+        and out["worst_rel_grad_err"] < 1e-3 and out.get("worst_running_stat_err", 0.0) < 1e-5
     print("DIST CHECK", "OK" if ok else "FAILED")
     sys.exit(0 if ok else 1)
