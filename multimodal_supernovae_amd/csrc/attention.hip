@@ -419,6 +419,7 @@ struct MAttn {
     int64_t q_bs, k_bs, v_bs, o_bs, d_bs, dq_bs, dk_bs, dv_bs;
     int B, H, Tq, Tk, hd;
     float scale;
+    int tail;
 };
 bool mattn_applicable(const MAttn& a);
 int mattn_forward(const MAttn& a, hipStream_t st);

@@ -38,6 +38,7 @@ struct MAttn {
     int64_t q_bs, k_bs, v_bs, o_bs, d_bs, dq_bs, dk_bs, dv_bs;
     int B, H, Tq, Tk, hd;
     float scale;
+    int tail;                 // set by mattn_forward / mattn_backward: ragged last token on the vector ALU (see below)
 };
 
 // rows [0, T) of src (row stride ld, columns col0..col0+HD-1) -> LDS [TP][HD + 4], zero rows beyond T
@@ -111,6 +112,71 @@ __device__ __forceinline__ float group_sum4(float v) {
     return v + __shfl_xor(v, 32, 64);
 }
 
+// ---- ragged last token (self-attention over T = 16n + 1 tokens: a ViT's class token + a 2^k patch grid) -------------
+// Padded to n + 1 tiles, the one extra token costs 2n + 1 of the (n + 1)^2 tile products (9 of 25 at T = 65: the kernels
+// took 1.5x the time of T = 64 on the same bytes).  With `tail` set the matrix cores only see the n x n full tiles;
+// token z = 16n is done on the vector ALU:
+//   * as a streamed row (key z in forward / dQ, query z in dK,dV): every wave adds its rank-1 contribution -- two
+//     16-term inner products per lane, shared over the 4 lane groups, and 16 multiply-adds per output product;
+//   * as a fixed row (query z / key z): the extra wave n runs lane = streamed row (inner products against the LDS
+//     images), then lane = output column (sums over the streamed rows); a few hundred instructions, beside the MFMAs.
+// dot of this lane's fragment slice (d = 16x + 4g .. +3) with row `row` of an LDS image, summed over the 4 lane groups
+template <int HD>
+__device__ __forceinline__ float frag_dot_row(const float4 (&f)[HD / 16], const float* row, int g) {
+    float acc = 0.f;
+#pragma unroll
+    for (int x = 0; x < HD / 16; ++x) {
+        const float4 r4 = *reinterpret_cast<const float4*>(row + 16 * x + 4 * g);
+        acc += f[x].x * r4.x + f[x].y * r4.y + f[x].z * r4.z + f[x].w * r4.w;
+    }
+    return group_sum4(acc);
+}
+// out[t][r] += a[row 4g + r of this wave's tile] * row[16t + c]   (a lives in the lane whose column is that row)
+template <int HD>
+__device__ __forceinline__ void rank1_update(float a, const float* row, f32x4 (&out)[HD / 16], int c, int g) {
+    float ar[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ar[r] = __shfl(a, 4 * g + r, 64);
+#pragma unroll
+    for (int t = 0; t < HD / 16; ++t) {
+        const float v = row[16 * t + c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[t][r] += ar[r] * v;
+    }
+}
+// lane = streamed row j (two passes: j = lane, 64 + lane): inner product of LDS row j of `img` with the broadcast row z
+template <int HD>
+__device__ __forceinline__ float row_dot(const float* img, int j, const float* z) {
+    constexpr int LS = HD + 4;
+    float acc = 0.f;
+#pragma unroll
+    for (int x = 0; x < HD / 4; ++x) {
+        const float4 a = *reinterpret_cast<const float4*>(img + j * LS + 4 * x);
+        const float4 b = *reinterpret_cast<const float4*>(z + 4 * x);
+        acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+    return acc;
+}
+// lane = output column d: sum_j w[j] * img[j][d] over the first `rows` (a multiple of 4, zero-weighted beyond T) rows
+template <int HD>
+__device__ __forceinline__ float col_sum(const float* img, const float* w, int rows, int d) {
+    constexpr int LS = HD + 4;
+    float a0 = 0.f, a1 = 0.f;
+    for (int j = 0; j < rows; j += 4) {
+        const float4 w4 = *reinterpret_cast<const float4*>(w + j);
+        a0 += w4.x * img[j * LS + d] + w4.z * img[(j + 2) * LS + d];
+        a1 += w4.y * img[(j + 1) * LS + d] + w4.w * img[(j + 3) * LS + d];
+    }
+    return a0 + a1;
+}
+// lane = column d: inner product of two LDS rows over the wave (the z-th streamed row against the broadcast row: one
+// element, not worth a lane = row pass)
+template <int HD>
+__device__ __forceinline__ float wave_dot(const float* a, const float* b, int lane) {
+    return wave_sum(lane < HD ? a[lane] * b[lane] : 0.f);
+}
+constexpr int kTailScratch = 512;   // floats of LDS behind the images: 2 broadcast rows (64 each) + 3 weight vectors (128)
+
 // ------------------------------------------------------------------------------------------ forward
 template <int HD>
 __global__ __launch_bounds__(1024) void mattn_fwd_kernel(const MAttn p) {
@@ -120,17 +186,60 @@ __global__ __launch_bounds__(1024) void mattn_fwd_kernel(const MAttn p) {
     float* Ks = smem;
     float* Vs = smem + (size_t)TPk * LS;
     uint8_t* Ms = reinterpret_cast<uint8_t*>(Vs + (size_t)TPk * LS);
+    float* Zs = reinterpret_cast<float*>(Ms + TPk);      // tail scratch (TPk % 16 == 0: 16-byte aligned)
     const int b = blockIdx.x / p.H, hh = blockIdx.x % p.H, col0 = hh * p.hd;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int z = p.Tk - 1;                               // the ragged token (tail only)
+    const bool tail_wave = p.tail && wave == TPk / 16 - 1;
     stage<HD>(Ks, p.k + (int64_t)b * p.k_bs, p.ldk, col0, p.Tk, TPk, p.hd);
     stage<HD>(Vs, p.v + (int64_t)b * p.v_bs, p.ldv, col0, p.Tk, TPk, p.hd);
     for (int j = threadIdx.x; j < TPk; j += blockDim.x) Ms[j] = (j < p.Tk && p.mask) ? p.mask[(int64_t)b * p.Tk + j] : 1;
+    if (tail_wave && lane < HD / 4) {                     // query z, scaled, as a broadcast row
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (4 * lane < p.hd) v = *reinterpret_cast<const float4*>(p.q + (int64_t)b * p.q_bs + (int64_t)z * p.ldq + col0 + 4 * lane);
+        *reinterpret_cast<float4*>(Zs + 4 * lane) = make_float4(v.x * p.scale, v.y * p.scale, v.z * p.scale, v.w * p.scale);
+    }
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    if (tail_wave) {
+        float* Ps = Zs + 128;
+        float sj[2], m = -INFINITY;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {                  // keys before z, lane = key (a pass without keys is skipped)
+            const int j = 64 * h2 + lane;
+            sj[h2] = -INFINITY;
+            if (j < z) sj[h2] = Ms[j] ? row_dot<HD>(Ks, j, Zs) : kFill;
+            m = fmaxf(m, sj[h2]);
+        }
+        float sz = wave_dot<HD>(Ks + z * LS, Zs, lane);   // key z itself
+        sz = Ms[z] ? sz : kFill;
+        m = fmaxf(wave_max(m), sz);
+        float l = 0.f;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const float e = __expf(sj[h2] - m);           // 0 from z on
+            Ps[64 * h2 + lane] = e;
+            l += e;
+        }
+        const float ez = __expf(sz - m);
+        if (lane == 0) Ps[z] = ez;
+        l = wave_sum(l) + ez;
+        if (lane < p.hd) {
+            const float o = col_sum<HD>(Vs, Ps, (p.Tk + 3) / 4 * 4, lane);
+            p.out[(int64_t)b * p.o_bs + (int64_t)z * p.ldo + col0 + lane] = o / l;
+        }
+        if (lane == 0) {
+            float* st = p.lse + 2 * (((int64_t)b * p.H + hh) * p.Tq + z);
+            st[0] = m;
+            st[1] = __logf(l);
+        }
+        return;
+    }
+
     const int q0 = wave * 16, qrow = q0 + c;
     float4 qf[DT];
     load_frags<HD>(qf, p.q + (int64_t)b * p.q_bs, p.ldq, col0, qrow, p.Tq, g, p.scale, p.hd);
-    const int nkt = TPk / 16;
+    const int nkt = TPk / 16 - (p.tail ? 1 : 0);          // full key tiles on the matrix cores
 
     float m = -INFINITY;
     f32x4 o[DT];
@@ -156,6 +265,12 @@ __global__ __launch_bounds__(1024) void mattn_fwd_kernel(const MAttn p) {
             }
         }
         m = group_max4(m);
+        float sz = -INFINITY;
+        if (p.tail) {                                     // key z: this query column's score, the same in all 4 groups
+            sz = frag_dot_row<HD>(qf, Ks + z * LS, g);
+            sz = Ms[z] ? sz : kFill;
+            m = fmaxf(m, sz);
+        }
 #pragma unroll
         for (int kt = 0; kt < KEEP; ++kt) {
             if (kt < nkt) {
@@ -167,6 +282,11 @@ __global__ __launch_bounds__(1024) void mattn_fwd_kernel(const MAttn p) {
                 }
                 accum16<HD>(sc[kt], Vs + kt * 16 * LS, o, c, g);
             }
+        }
+        if (p.tail) {
+            const float ez = __expf(sz - m);
+            if (g == 0) l += ez;                          // once per query (l is summed over the groups below)
+            rank1_update<HD>(ez, Vs + z * LS, o, c, g);
         }
     } else {
         // two passes over the key tiles (row maximum, then exponentials + P.V), recomputing the 16x16 score tiles
@@ -221,13 +341,57 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dq_kernel(const MAttn p) {
     float* Ks = smem;
     float* Vs = smem + (size_t)TPk * LS;
     uint8_t* Ms = reinterpret_cast<uint8_t*>(Vs + (size_t)TPk * LS);
+    float* Zs = reinterpret_cast<float*>(Ms + TPk);      // tail scratch
     const int b = blockIdx.x / p.H, hh = blockIdx.x % p.H, col0 = hh * p.hd;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int z = p.Tk - 1;
+    const bool tail_wave = p.tail && wave == TPk / 16 - 1;
     stage<HD>(Ks, p.k + (int64_t)b * p.k_bs, p.ldk, col0, p.Tk, TPk, p.hd);
     stage<HD>(Vs, p.v + (int64_t)b * p.v_bs, p.ldv, col0, p.Tk, TPk, p.hd);
     for (int j = threadIdx.x; j < TPk; j += blockDim.x) Ms[j] = (j < p.Tk && p.mask) ? p.mask[(int64_t)b * p.Tk + j] : 1;
+    float dz = 0.f;                                       // tail wave: lane d's term of delta_z = dO_z . O_z
+    if (tail_wave) {
+        if (lane < HD / 4) {                              // query z (scaled) and its dO row as broadcast rows
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f), w = v;
+            if (4 * lane < p.hd) {
+                v = *reinterpret_cast<const float4*>(p.q + (int64_t)b * p.q_bs + (int64_t)z * p.ldq + col0 + 4 * lane);
+                w = *reinterpret_cast<const float4*>(p.dout + (int64_t)b * p.d_bs + (int64_t)z * p.ldd + col0 + 4 * lane);
+            }
+            *reinterpret_cast<float4*>(Zs + 4 * lane) = make_float4(v.x * p.scale, v.y * p.scale, v.z * p.scale, v.w * p.scale);
+            *reinterpret_cast<float4*>(Zs + 64 + 4 * lane) = w;
+        }
+        if (lane < p.hd)
+            dz = p.dout[(int64_t)b * p.d_bs + (int64_t)z * p.ldd + col0 + lane] *
+                 p.o[(int64_t)b * p.o_bs + (int64_t)z * p.ldo + col0 + lane];
+    }
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    if (tail_wave) {
+        float* Ps = Zs + 128;
+        const float delta = wave_sum(dz);
+        const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + z;
+        const float lm = p.lse[2 * stat], ll = p.lse[2 * stat + 1];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int j = 64 * h2 + lane;
+            float ds = 0.f;
+            if (j < z && Ms[j]) {
+                const float sj = row_dot<HD>(Ks, j, Zs), dp = row_dot<HD>(Vs, j, Zs + 64);
+                ds = __expf((sj - lm) - ll) * (dp - delta);
+            }
+            Ps[j] = ds;
+        }
+        {
+            const float sz = wave_dot<HD>(Ks + z * LS, Zs, lane), dpz = wave_dot<HD>(Vs + z * LS, Zs + 64, lane);
+            if (lane == 0) Ps[z] = Ms[z] ? __expf((sz - lm) - ll) * (dpz - delta) : 0.f;
+        }
+        if (lane < p.hd)
+            p.dq[(int64_t)b * p.dq_bs + (int64_t)z * p.lddq + col0 + lane] =
+                col_sum<HD>(Ks, Ps, (p.Tk + 3) / 4 * 4, lane) * p.scale;
+        if (lane == 0) p.delta[stat] = delta;
+        return;
+    }
+
     const int q0 = wave * 16, qrow = q0 + c;
     const bool q_ok = qrow < p.Tq;
     float4 qf[DT], df[DT], of[DT];
@@ -246,7 +410,7 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dq_kernel(const MAttn p) {
     f32x4 dq[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) dq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nkt = TPk / 16;
+    const int nkt = TPk / 16 - (p.tail ? 1 : 0);
     for (int kt = 0; kt < nkt; ++kt) {
         const f32x4 s = score16<HD>(Ks + kt * 16 * LS, qf, c, g);
         const f32x4 dp = score16<HD>(Vs + kt * 16 * LS, df, c, g);
@@ -259,6 +423,11 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dq_kernel(const MAttn p) {
             ds[r] = live ? __expf((s[r] - lm) - ll) * (dp[r] - delta) : 0.f;
         }
         accum16<HD>(ds, Ks + kt * 16 * LS, dq, c, g);
+    }
+    if (p.tail) {                                         // key z
+        const float sz = frag_dot_row<HD>(qf, Ks + z * LS, g), dpz = frag_dot_row<HD>(df, Vs + z * LS, g);
+        const float dsz = (q_ok && Ms[z]) ? __expf((sz - lm) - ll) * (dpz - delta) : 0.f;
+        rank1_update<HD>(dsz, Ks + z * LS, dq, c, g);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -283,9 +452,22 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dkv_kernel(const MAttn p) {
     float* Lm = Ds + (size_t)TPq * LS;
     float* Ll = Lm + TPq;
     float* Dl = Ll + TPq;
+    float* Zs = Dl + TPq;                                 // tail scratch
     const int b = blockIdx.x / p.H, hh = blockIdx.x % p.H, col0 = hh * p.hd;
+    const int z = p.Tq - 1;
+    const bool tail_wave = p.tail && (int)(threadIdx.x >> 6) == TPq / 16 - 1;
     stage<HD>(Qs, p.q + (int64_t)b * p.q_bs, p.ldq, col0, p.Tq, TPq, p.hd);
     stage<HD>(Ds, p.dout + (int64_t)b * p.d_bs, p.ldd, col0, p.Tq, TPq, p.hd);
+    if (tail_wave && (threadIdx.x & 63) < HD / 4) {       // key z (scaled) and value z as broadcast rows
+        const int l4 = 4 * (threadIdx.x & 63);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f), w = v;
+        if (l4 < p.hd) {
+            v = *reinterpret_cast<const float4*>(p.k + (int64_t)b * p.k_bs + (int64_t)z * p.ldk + col0 + l4);
+            w = *reinterpret_cast<const float4*>(p.v + (int64_t)b * p.v_bs + (int64_t)z * p.ldv + col0 + l4);
+        }
+        *reinterpret_cast<float4*>(Zs + l4) = make_float4(v.x * p.scale, v.y * p.scale, v.z * p.scale, v.w * p.scale);
+        *reinterpret_cast<float4*>(Zs + 64 + l4) = w;
+    }
     for (int t = threadIdx.x; t < TPq; t += blockDim.x) {
         const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + (t < p.Tq ? t : 0);
         Lm[t] = t < p.Tq ? p.lse[2 * stat] : INFINITY;     // +inf: a padded query row gets p = exp(-inf) = 0
@@ -295,6 +477,36 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dkv_kernel(const MAttn p) {
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    if (tail_wave) {
+        float* Pp = Zs + 128;
+        float* Pd = Zs + 256;
+        const bool keep_z = p.mask ? p.mask[(int64_t)b * p.Tk + z] != 0 : true;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int i = 64 * h2 + lane;
+            float pr = 0.f, ds = 0.f;
+            if (i < z) {
+                const float si = row_dot<HD>(Qs, i, Zs), dp = row_dot<HD>(Ds, i, Zs + 64);
+                pr = __expf(((keep_z ? si : kFill) - Lm[i]) - Ll[i]);
+                ds = keep_z ? pr * (dp - Dl[i]) : 0.f;
+            }
+            Pp[i] = pr;
+            Pd[i] = ds;
+        }
+        {
+            const float sz = wave_dot<HD>(Qs + z * LS, Zs, lane), dpz = wave_dot<HD>(Ds + z * LS, Zs + 64, lane);
+            const float pr = __expf(((keep_z ? sz : kFill) - Lm[z]) - Ll[z]);
+            if (lane == 0) {
+                Pp[z] = pr;
+                Pd[z] = keep_z ? pr * (dpz - Dl[z]) : 0.f;
+            }
+        }
+        if (lane < p.hd) {
+            p.dk[(int64_t)b * p.dk_bs + (int64_t)z * p.lddk + col0 + lane] = col_sum<HD>(Qs, Pd, (p.Tq + 3) / 4 * 4, lane) * p.scale;
+            p.dv[(int64_t)b * p.dv_bs + (int64_t)z * p.lddv + col0 + lane] = col_sum<HD>(Ds, Pp, (p.Tq + 3) / 4 * 4, lane);
+        }
+        return;
+    }
     const int k0 = wave * 16, krow = k0 + c;
     float4 kf[DT], vf[DT];
     load_frags<HD>(kf, p.k + (int64_t)b * p.k_bs, p.ldk, col0, krow, p.Tk, g, p.scale, p.hd);
@@ -304,7 +516,7 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dkv_kernel(const MAttn p) {
     f32x4 dk[DT], dv[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) dk[t] = dv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nqt = TPq / 16;
+    const int nqt = TPq / 16 - (p.tail ? 1 : 0);
     for (int qt = 0; qt < nqt; ++qt) {
         const f32x4 s = score16<HD>(Qs + qt * 16 * LS, kf, c, g);     // rows = queries, col = this lane's key
         const f32x4 dp = score16<HD>(Ds + qt * 16 * LS, vf, c, g);
@@ -318,6 +530,12 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dkv_kernel(const MAttn p) {
         }
         accum16<HD>(pr, Ds + qt * 16 * LS, dv, c, g);
         accum16<HD>(ds, Qs + qt * 16 * LS, dk, c, g);
+    }
+    if (p.tail) {                                         // query z against this lane's key
+        const float sz = frag_dot_row<HD>(kf, Qs + z * LS, g), dpz = frag_dot_row<HD>(vf, Ds + z * LS, g);
+        const float e = __expf(((keep ? sz : kFill) - Lm[z]) - Ll[z]);
+        rank1_update<HD>(krow < p.Tk ? e : 0.f, Ds + z * LS, dv, c, g);
+        rank1_update<HD>(keep ? e * (dpz - Dl[z]) : 0.f, Qs + z * LS, dk, c, g);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -373,15 +591,23 @@ bool mattn_applicable(const MAttn& a) {
         default: rc = launch_big_lds(KERNEL<64>, __VA_ARGS__); break;                      \
     }
 
-int mattn_forward(const MAttn& a, hipStream_t st) {
+// ragged-token path: self-attention over 16n + 1 tokens, one-pass forward (n + 1 <= 8 tiles), both weight passes of
+// the tail wave inside 128 rows
+static bool use_tail(const MAttn& a) { return a.Tq == a.Tk && a.Tk % 16 == 1 && a.Tk > 16 && a.Tk <= 113; }
+
+int mattn_forward(const MAttn& a0, hipStream_t st) {
+    MAttn a = a0;
+    a.tail = use_tail(a) ? 1 : 0;
     const int TPk = (a.Tk + 15) / 16 * 16, nq = (a.Tq + 15) / 16;
-    const size_t lds = sizeof(float) * 2 * (size_t)TPk * (padded_hd(a.hd) + 4) + (size_t)TPk;
+    const size_t lds = sizeof(float) * (2 * (size_t)TPk * (padded_hd(a.hd) + 4) + kTailScratch) + (size_t)TPk;
     int rc;
     MSN_MATTN_DISPATCH(mattn_fwd_kernel, dim3(a.B * a.H), dim3(64 * nq), lds, st, a)
     return rc;
 }
 
-int mattn_backward(const MAttn& a, hipStream_t st) {
+int mattn_backward(const MAttn& a0, hipStream_t st) {
+    MAttn a = a0;
+    a.tail = use_tail(a) ? 1 : 0;
     const int TPk = (a.Tk + 15) / 16 * 16, TPq = (a.Tq + 15) / 16 * 16;
     int rc;
     const int64_t al[] = {a.ldd, a.d_bs, a.ldo, a.o_bs};
@@ -392,12 +618,12 @@ int mattn_backward(const MAttn& a, hipStream_t st) {
         return MSN_ERR_SHAPE;
     }
     {
-        const size_t lds = sizeof(float) * 2 * (size_t)TPk * (padded_hd(a.hd) + 4) + (size_t)TPk;
+        const size_t lds = sizeof(float) * (2 * (size_t)TPk * (padded_hd(a.hd) + 4) + kTailScratch) + (size_t)TPk;
         MSN_MATTN_DISPATCH(mattn_bwd_dq_kernel, dim3(a.B * a.H), dim3(64 * (TPq / 16)), lds, st, a)
         if (rc != MSN_OK) return rc;
     }
     {
-        const size_t lds = sizeof(float) * (2 * (size_t)TPq * (padded_hd(a.hd) + 4) + 3 * (size_t)TPq);
+        const size_t lds = sizeof(float) * (2 * (size_t)TPq * (padded_hd(a.hd) + 4) + 3 * (size_t)TPq + kTailScratch);
         MSN_MATTN_DISPATCH(mattn_bwd_dkv_kernel, dim3(a.B * a.H), dim3(64 * (TPk / 16)), lds, st, a)
     }
     return rc;

@@ -60,3 +60,39 @@ def test_attention_fuzz(seed, path):
                                            msg=lambda m: f"{name} {what}: {m}")
     finally:
         _lib.lib().msn_set_attention_path(0)
+
+
+@pytest.mark.parametrize("T", [17, 33, 49, 65, 81, 97, 113])
+@pytest.mark.parametrize("hd,heads", [(64, 6), (32, 2), (16, 2), (8, 4), (48, 1)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_ragged_last_token_path(T, hd, heads, masked):
+    """Self-attention over 16n + 1 tokens (class token + patch grid): the matrix-core kernels run the n x n full tiles and
+    the last token goes through their vector-ALU tail (attention_mfma.hip).  Same fp64 reference, incl. a fully padded
+    sample and a masked-out last token."""
+    from multimodal_supernovae_amd import _lib, ops
+    g = torch.Generator().manual_seed(1000 * T + hd)
+    B, E = 3, heads * hd
+    q, k, v, dout = (torch.randn(B, T, E, generator=g) for _ in range(4))
+    mask = None
+    if masked:
+        mask = torch.rand(B, T, generator=g) > 0.3
+        mask[:, 0] = True
+        mask[0, -1] = False            # the ragged token itself masked out as a key
+        mask[1, -1] = True
+        mask[2] = False                # a fully padded sample (uniform attention over the -1e7 scores)
+    scale = 1.0 / math.sqrt(E)
+    qr, kr, vr = (t.double().requires_grad_() for t in (q, k, v))
+    ref = _ref(qr, kr, vr, mask, heads, scale)
+    ref.backward(dout.double())
+    _lib.check(_lib.lib().msn_set_attention_path(2))
+    try:
+        qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+        mu8 = ops._mask_u8(mask.cuda()) if mask is not None else None
+        out, lse = ops.attention_fwd(qc, kc, vc, mu8, heads, scale)
+        torch.testing.assert_close(out.cpu().double(), ref.detach(), rtol=1e-4, atol=3e-5)
+        dq, dk, dv = torch.empty_like(qc), torch.empty_like(kc), torch.empty_like(vc)
+        ops.attention_bwd(qc, kc, vc, mu8, heads, scale, out, lse, dout.cuda(), dq, dk, dv)
+        for got, want, name in ((dq, qr.grad, "dq"), (dk, kr.grad, "dk"), (dv, vr.grad, "dv")):
+            torch.testing.assert_close(got.cpu().double(), want, rtol=3e-4, atol=3e-5, msg=lambda m: f"{name}: {m}")
+    finally:
+        _lib.lib().msn_set_attention_path(0)
