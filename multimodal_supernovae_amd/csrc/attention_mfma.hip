@@ -175,7 +175,7 @@ template <int HD>
 __device__ __forceinline__ float wave_dot(const float* a, const float* b, int lane) {
     return wave_sum(lane < HD ? a[lane] * b[lane] : 0.f);
 }
-constexpr int kTailScratch = 512;   // floats of LDS behind the images: 2 broadcast rows (64 each) + 3 weight vectors (128)
+constexpr int kTailScratch = 384;   // floats of LDS behind the images: 2 broadcast rows (64 each) + 2 weight vectors (128)
 
 // ------------------------------------------------------------------------------------------ forward
 template <int HD>
@@ -184,15 +184,18 @@ __global__ __launch_bounds__(1024) void mattn_fwd_kernel(const MAttn p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int TPk = (p.Tk + 15) / 16 * 16;
     float* Ks = smem;
-    float* Vs = smem + (size_t)TPk * LS;
-    uint8_t* Ms = reinterpret_cast<uint8_t*>(Vs + (size_t)TPk * LS);
+    // LDS image rows: whole tiles, or -- with the ragged token on the vector ALU -- only the rows that path reads (68 of
+    // 80 at T = 65: a fourth workgroup fits on the CU)
+    const int rows = p.tail ? (p.Tk + 3) / 4 * 4 : TPk;
+    float* Vs = smem + (size_t)rows * LS;
+    uint8_t* Ms = reinterpret_cast<uint8_t*>(Vs + (size_t)rows * LS);
     float* Zs = reinterpret_cast<float*>(Ms + TPk);      // tail scratch (TPk % 16 == 0: 16-byte aligned)
     const int b = blockIdx.x / p.H, hh = blockIdx.x % p.H, col0 = hh * p.hd;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
     const int z = p.Tk - 1;                               // the ragged token (tail only)
     const bool tail_wave = p.tail && wave == TPk / 16 - 1;
-    stage<HD>(Ks, p.k + (int64_t)b * p.k_bs, p.ldk, col0, p.Tk, TPk, p.hd);
-    stage<HD>(Vs, p.v + (int64_t)b * p.v_bs, p.ldv, col0, p.Tk, TPk, p.hd);
+    stage<HD>(Ks, p.k + (int64_t)b * p.k_bs, p.ldk, col0, p.Tk, rows, p.hd);
+    stage<HD>(Vs, p.v + (int64_t)b * p.v_bs, p.ldv, col0, p.Tk, rows, p.hd);
     for (int j = threadIdx.x; j < TPk; j += blockDim.x) Ms[j] = (j < p.Tk && p.mask) ? p.mask[(int64_t)b * p.Tk + j] : 1;
     if (tail_wave && lane < HD / 4) {                     // query z, scaled, as a broadcast row
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -339,15 +342,18 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dq_kernel(const MAttn p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int TPk = (p.Tk + 15) / 16 * 16;
     float* Ks = smem;
-    float* Vs = smem + (size_t)TPk * LS;
-    uint8_t* Ms = reinterpret_cast<uint8_t*>(Vs + (size_t)TPk * LS);
+    // LDS image rows: whole tiles, or -- with the ragged token on the vector ALU -- only the rows that path reads (68 of
+    // 80 at T = 65: a fourth workgroup fits on the CU)
+    const int rows = p.tail ? (p.Tk + 3) / 4 * 4 : TPk;
+    float* Vs = smem + (size_t)rows * LS;
+    uint8_t* Ms = reinterpret_cast<uint8_t*>(Vs + (size_t)rows * LS);
     float* Zs = reinterpret_cast<float*>(Ms + TPk);      // tail scratch
     const int b = blockIdx.x / p.H, hh = blockIdx.x % p.H, col0 = hh * p.hd;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
     const int z = p.Tk - 1;
     const bool tail_wave = p.tail && wave == TPk / 16 - 1;
-    stage<HD>(Ks, p.k + (int64_t)b * p.k_bs, p.ldk, col0, p.Tk, TPk, p.hd);
-    stage<HD>(Vs, p.v + (int64_t)b * p.v_bs, p.ldv, col0, p.Tk, TPk, p.hd);
+    stage<HD>(Ks, p.k + (int64_t)b * p.k_bs, p.ldk, col0, p.Tk, rows, p.hd);
+    stage<HD>(Vs, p.v + (int64_t)b * p.v_bs, p.ldv, col0, p.Tk, rows, p.hd);
     for (int j = threadIdx.x; j < TPk; j += blockDim.x) Ms[j] = (j < p.Tk && p.mask) ? p.mask[(int64_t)b * p.Tk + j] : 1;
     float dz = 0.f;                                       // tail wave: lane d's term of delta_z = dO_z . O_z
     if (tail_wave) {
@@ -448,16 +454,17 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dkv_kernel(const MAttn p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int TPq = (p.Tq + 15) / 16 * 16;
     float* Qs = smem;
-    float* Ds = smem + (size_t)TPq * LS;
-    float* Lm = Ds + (size_t)TPq * LS;
+    const int rows = p.tail ? (p.Tq + 3) / 4 * 4 : TPq;   // LDS image rows (see the forward kernel)
+    float* Ds = smem + (size_t)rows * LS;
+    float* Lm = Ds + (size_t)rows * LS;
     float* Ll = Lm + TPq;
     float* Dl = Ll + TPq;
     float* Zs = Dl + TPq;                                 // tail scratch
     const int b = blockIdx.x / p.H, hh = blockIdx.x % p.H, col0 = hh * p.hd;
     const int z = p.Tq - 1;
     const bool tail_wave = p.tail && (int)(threadIdx.x >> 6) == TPq / 16 - 1;
-    stage<HD>(Qs, p.q + (int64_t)b * p.q_bs, p.ldq, col0, p.Tq, TPq, p.hd);
-    stage<HD>(Ds, p.dout + (int64_t)b * p.d_bs, p.ldd, col0, p.Tq, TPq, p.hd);
+    stage<HD>(Qs, p.q + (int64_t)b * p.q_bs, p.ldq, col0, p.Tq, rows, p.hd);
+    stage<HD>(Ds, p.dout + (int64_t)b * p.d_bs, p.ldd, col0, p.Tq, rows, p.hd);
     if (tail_wave && (threadIdx.x & 63) < HD / 4) {       // key z (scaled) and value z as broadcast rows
         const int l4 = 4 * (threadIdx.x & 63);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f), w = v;
@@ -599,7 +606,8 @@ int mattn_forward(const MAttn& a0, hipStream_t st) {
     MAttn a = a0;
     a.tail = use_tail(a) ? 1 : 0;
     const int TPk = (a.Tk + 15) / 16 * 16, nq = (a.Tq + 15) / 16;
-    const size_t lds = sizeof(float) * (2 * (size_t)TPk * (padded_hd(a.hd) + 4) + kTailScratch) + (size_t)TPk;
+    const int rows = a.tail ? (a.Tk + 3) / 4 * 4 : TPk;
+    const size_t lds = sizeof(float) * (2 * (size_t)rows * (padded_hd(a.hd) + 4) + kTailScratch) + (size_t)TPk;
     int rc;
     MSN_MATTN_DISPATCH(mattn_fwd_kernel, dim3(a.B * a.H), dim3(64 * nq), lds, st, a)
     return rc;
@@ -618,12 +626,14 @@ int mattn_backward(const MAttn& a0, hipStream_t st) {
         return MSN_ERR_SHAPE;
     }
     {
-        const size_t lds = sizeof(float) * (2 * (size_t)TPk * (padded_hd(a.hd) + 4) + kTailScratch) + (size_t)TPk;
+        const int rows = a.tail ? (a.Tk + 3) / 4 * 4 : TPk;
+        const size_t lds = sizeof(float) * (2 * (size_t)rows * (padded_hd(a.hd) + 4) + kTailScratch) + (size_t)TPk;
         MSN_MATTN_DISPATCH(mattn_bwd_dq_kernel, dim3(a.B * a.H), dim3(64 * (TPq / 16)), lds, st, a)
         if (rc != MSN_OK) return rc;
     }
     {
-        const size_t lds = sizeof(float) * (2 * (size_t)TPq * (padded_hd(a.hd) + 4) + 3 * (size_t)TPq + kTailScratch);
+        const int rows = a.tail ? (a.Tq + 3) / 4 * 4 : TPq;
+        const size_t lds = sizeof(float) * (2 * (size_t)rows * (padded_hd(a.hd) + 4) + 3 * (size_t)TPq + kTailScratch);
         MSN_MATTN_DISPATCH(mattn_bwd_dkv_kernel, dim3(a.B * a.H), dim3(64 * (TPk / 16)), lds, st, a)
     }
     return rc;
