@@ -125,6 +125,22 @@ __device__ __forceinline__ bool vec4_ok(const float* p, int64_t ld, int64_t bstr
     return (s % 4 == 0) && (ld % 4 == 0) && (bstride % 4 == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
 }
 
+// (batch, head) of a workgroup.  Workgroups go to the 8 XCDs round-robin by their linear id, and a narrow head reads
+// only s * 4 bytes (32 for the reference's 8-wide heads) of every 128-byte line of the q|k|v rows: with the natural
+// order (head fastest) XCD x serves head x of EVERY sample and each line is fetched from HBM by up to four XCDs
+// (rocprofv3 FETCH_SIZE: 3.3-3.7 x the algorithmic bytes on the light-curve tower).  With one workgroup per (b, h)
+// and B % 8 == 0 the ids are re-read so that the H heads of a sample are consecutive workgroups of ONE XCD: the first
+// toucher fetches the line into that XCD's L2, the other heads hit it.
+__device__ __forceinline__ void locate_head(int& b, int& hh) {
+    b = blockIdx.z, hh = blockIdx.y;
+    if (gridDim.x == 1 && (gridDim.z & 7) == 0) {
+        const unsigned id = blockIdx.y + gridDim.y * blockIdx.z;   // linear workgroup id (x is 0)
+        const unsigned xcd = id & 7, j = id >> 3;                  // j-th workgroup of this XCD
+        b = (int)((j / gridDim.y) * 8 + xcd);
+        hh = (int)(j % gridDim.y);
+    }
+}
+
 // R = query (or key) rows per lane.  Every key row is read from LDS as a wave-wide broadcast, 8 LDS cycles per 16
 // bytes whatever the number of distinct addresses -- with one row per lane those 4 reads per key bound the kernel
 // (328 M query-key pairs per light-curve layer: 340 us of LDS time per CU against 160 us of vector ALU).  A lane that
@@ -139,7 +155,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     float* Ks = attn_smem;
     float* Vs = attn_smem + KTILE * S;
     float* Fs = Vs + KTILE * S;
-    const int b = blockIdx.z, hh = blockIdx.y;
+    int b, hh;
+    locate_head(b, hh);
     const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * R;
     const int col0 = hh * p.s;
     const float* kb = p.k + (int64_t)b * p.k_bstride;
@@ -240,7 +257,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
     float* Ks = attn_smem;
     float* Vs = attn_smem + KTILE * S;
     float* Fs = Vs + KTILE * S;          // 1 = live key, 0 = masked or beyond the sequence (no gradient through it)
-    const int b = blockIdx.z, hh = blockIdx.y;
+    int b, hh;
+    locate_head(b, hh);
     const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * R;
     const int col0 = hh * p.s;
     const float* kb = p.k + (int64_t)b * p.k_bstride;
@@ -328,7 +346,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     float* Lm = Ds + QTILE * S;
     float* Ll = Lm + QTILE;
     float* Dl = Ll + QTILE;
-    const int b = blockIdx.z, hh = blockIdx.y;
+    int b, hh;
+    locate_head(b, hh);
     const int j0 = (blockIdx.x * blockDim.x + threadIdx.x) * R;
     const int col0 = hh * p.s;
     const float* qb = p.q + (int64_t)b * p.q_bstride;

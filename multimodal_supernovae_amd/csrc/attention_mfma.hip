@@ -41,6 +41,18 @@ struct MAttn {
     int tail;                 // set by mattn_forward / mattn_backward: ragged last token on the vector ALU (see below)
 };
 
+// (batch, head) of workgroup blockIdx.x.  Workgroups go to the 8 XCDs round-robin; when B % 8 == 0 the ids are re-read so
+// that the H heads of a sample are consecutive workgroups of ONE XCD and share the 128-byte lines of its q|k|v rows in
+// that XCD's L2 (heads narrower than 32 floats use only part of a line: see attention.hip locate_head).
+__device__ __forceinline__ void locate_head(const MAttn& p, int& b, int& hh) {
+    b = blockIdx.x / p.H, hh = blockIdx.x % p.H;
+    if ((p.B & 7) == 0) {
+        const unsigned xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        b = (int)((j / p.H) * 8 + xcd);
+        hh = (int)(j % p.H);
+    }
+}
+
 // rows [0, T) of src (row stride ld, columns col0..col0+HD-1) -> LDS [TP][HD + 4], zero rows beyond T
 template <int HD>
 __device__ __forceinline__ void stage(float* dst, const float* __restrict__ src, int64_t ld, int col0, int T, int TP,
@@ -190,7 +202,9 @@ __global__ __launch_bounds__(1024) void mattn_fwd_kernel(const MAttn p) {
     float* Vs = smem + (size_t)rows * LS;
     uint8_t* Ms = reinterpret_cast<uint8_t*>(Vs + (size_t)rows * LS);
     float* Zs = reinterpret_cast<float*>(Ms + TPk);      // tail scratch (TPk % 16 == 0: 16-byte aligned)
-    const int b = blockIdx.x / p.H, hh = blockIdx.x % p.H, col0 = hh * p.hd;
+    int b, hh;
+    locate_head(p, b, hh);
+    const int col0 = hh * p.hd;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
     const int z = p.Tk - 1;                               // the ragged token (tail only)
     const bool tail_wave = p.tail && wave == TPk / 16 - 1;
@@ -348,7 +362,9 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dq_kernel(const MAttn p) {
     float* Vs = smem + (size_t)rows * LS;
     uint8_t* Ms = reinterpret_cast<uint8_t*>(Vs + (size_t)rows * LS);
     float* Zs = reinterpret_cast<float*>(Ms + TPk);      // tail scratch
-    const int b = blockIdx.x / p.H, hh = blockIdx.x % p.H, col0 = hh * p.hd;
+    int b, hh;
+    locate_head(p, b, hh);
+    const int col0 = hh * p.hd;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
     const int z = p.Tk - 1;
     const bool tail_wave = p.tail && wave == TPk / 16 - 1;
@@ -460,7 +476,9 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dkv_kernel(const MAttn p) {
     float* Ll = Lm + TPq;
     float* Dl = Ll + TPq;
     float* Zs = Dl + TPq;                                 // tail scratch
-    const int b = blockIdx.x / p.H, hh = blockIdx.x % p.H, col0 = hh * p.hd;
+    int b, hh;
+    locate_head(p, b, hh);
+    const int col0 = hh * p.hd;
     const int z = p.Tq - 1;
     const bool tail_wave = p.tail && (int)(threadIdx.x >> 6) == TPq / 16 - 1;
     stage<HD>(Qs, p.q + (int64_t)b * p.q_bs, p.ldq, col0, p.Tq, rows, p.hd);

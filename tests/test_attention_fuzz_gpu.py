@@ -96,3 +96,33 @@ def test_ragged_last_token_path(T, hd, heads, masked):
             torch.testing.assert_close(got.cpu().double(), want, rtol=3e-4, atol=3e-5, msg=lambda m: f"{name}: {m}")
     finally:
         _lib.lib().msn_set_attention_path(0)
+
+
+@pytest.mark.parametrize("B,heads,hd,T", [(8, 8, 8, 50), (16, 3, 8, 200), (24, 2, 16, 220), (8, 5, 4, 33), (16, 6, 64, 65), (8, 2, 16, 220), (32, 8, 8, 12)])
+def test_xcd_grouped_head_order(B, heads, hd, T):
+    """Batches that are multiples of 8 take the XCD-grouped (batch, head) order of the vector-ALU kernels (the heads of a
+    sample on one XCD, attention.hip locate_head): every (b, h) must still be computed exactly once."""
+    from multimodal_supernovae_amd import _lib, ops
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    E = heads * hd
+    q, k, v, dout = (torch.randn(B, T, E, generator=g) for _ in range(4))
+    mask = torch.rand(B, T, generator=g) > 0.3
+    mask[:, 0] = True
+    scale = 1.0 / math.sqrt(E)
+    qr, kr, vr = (t.double().requires_grad_() for t in (q, k, v))
+    ref = _ref(qr, kr, vr, mask, heads, scale)
+    ref.backward(dout.double())
+    qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+    mu8 = ops._mask_u8(mask.cuda())
+    try:
+        for path in (1, 2):            # vector-ALU kernels, matrix-core kernels (same re-ordering in both families)
+            _lib.check(_lib.lib().msn_set_attention_path(path))
+            out, lse = ops.attention_fwd(qc, kc, vc, mu8, heads, scale)
+            torch.testing.assert_close(out.cpu().double(), ref.detach(), rtol=1e-4, atol=3e-5)
+            dq, dk, dv = torch.empty_like(qc), torch.empty_like(kc), torch.empty_like(vc)
+            ops.attention_bwd(qc, kc, vc, mu8, heads, scale, out, lse, dout.cuda(), dq, dk, dv)
+            for got, want, name in ((dq, qr.grad, "dq"), (dk, kr.grad, "dk"), (dv, vr.grad, "dv")):
+                torch.testing.assert_close(got.cpu().double(), want, rtol=3e-4, atol=3e-5,
+                                           msg=lambda m: f"{name} path {path}: {m}")
+    finally:
+        _lib.lib().msn_set_attention_path(0)
