@@ -578,6 +578,224 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dkv_kernel(const MAttn p) {
     }
 }
 
+
+// =====================================================================================================================
+// Long sequences (more than 256 tokens: the reference's spectrum transformer on 1024-bin spectra).  Same tile products;
+// a workgroup owns a block of up to 128 rows of the fixed operand (8 waves, compiled for two workgroups per CU so that one
+// multiplies while the other stages its next chunk) and the streamed operand passes through
+// LDS in chunks of CH = 16 * KEEP rows (256 for heads up to 16 wide, 128 beyond), so the score tiles of a chunk still
+// fit in registers.  Forward: online softmax ACROSS chunks (running maximum; the output accumulators -- rows are
+// queries 4g + r -- take the rescale factor of their query from its column-owner lane), one pass WITHIN a chunk.
+// The backward kernels only accumulate over the chunks (probabilities come from the saved row statistics).
+// blockIdx.x = (b * H + h) * NB + block: the row blocks of a (b, h) are neighbours and share its K / V lines in L2.
+template <int HD>
+__global__ __launch_bounds__(512, 4) void mattn_fwd_long_kernel(const MAttn p) {
+    constexpr int LS = HD + 4, DT = HD / 16, KEEP = HD <= 16 ? 16 : 8, CH = 16 * KEEP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;
+    float* Vs = smem + (size_t)CH * LS;
+    uint8_t* Ms = reinterpret_cast<uint8_t*>(Vs + (size_t)CH * LS);
+    const int NB = (p.Tq + 127) / 128;
+    const int blk = blockIdx.x % NB, bh = blockIdx.x / NB, b = bh / p.H, hh = bh % p.H, col0 = hh * p.hd;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int q0 = blk * 128 + wave * 16, qrow = q0 + c;
+    float4 qf[DT];
+    load_frags<HD>(qf, p.q + (int64_t)b * p.q_bs, p.ldq, col0, qrow, p.Tq, g, p.scale, p.hd);
+    float m = -INFINITY, l = 0.f;
+    f32x4 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < p.Tk; k0 += CH) {
+        const int nt = min(CH, p.Tk - k0), TPc = (nt + 15) / 16 * 16, nkt = TPc / 16;
+        __syncthreads();                                  // every wave is done with the previous chunk
+        stage<HD>(Ks, p.k + (int64_t)b * p.k_bs + (int64_t)k0 * p.ldk, p.ldk, col0, nt, TPc, p.hd);
+        stage<HD>(Vs, p.v + (int64_t)b * p.v_bs + (int64_t)k0 * p.ldv, p.ldv, col0, nt, TPc, p.hd);
+        for (int j = threadIdx.x; j < TPc; j += blockDim.x)   // key codes: 1 live, 0 masked out, 2 beyond the sequence
+            Ms[j] = j < nt ? (p.mask ? (p.mask[(int64_t)b * p.Tk + k0 + j] ? 1 : 0) : 1) : 2;
+        __syncthreads();
+        f32x4 sc[KEEP];
+        float mc = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < KEEP; ++kt) {
+            if (kt < nkt) {
+                const uint32_t codes = reinterpret_cast<const uint32_t*>(Ms)[4 * kt + g];   // this lane group's 4 keys
+                sc[kt] = score16<HD>(Ks + kt * 16 * LS, qf, c, g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t code = (codes >> (8 * r)) & 0xffu;     // branch-free selection
+                    sc[kt][r] = code == 1u ? sc[kt][r] : (code == 0u ? kFill : -INFINITY);
+                    mc = fmaxf(mc, sc[kt][r]);
+                }
+            }
+        }
+        mc = group_max4(mc);
+        const float mn = fmaxf(m, mc);                    // finite: a chunk holds at least one key, masked ones score -1e7
+        const float alpha = __expf(m - mn);               // exp(-inf) = 0 on the first chunk
+        m = mn;
+        l *= alpha;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ar = __shfl(alpha, 4 * g + r, 64);
+#pragma unroll
+            for (int t = 0; t < DT; ++t) o[t][r] *= ar;
+        }
+#pragma unroll
+        for (int kt = 0; kt < KEEP; ++kt) {
+            if (kt < nkt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __expf(sc[kt][r] - m);
+                    sc[kt][r] = e;
+                    l += e;
+                }
+                accum16<HD>(sc[kt], Vs + kt * 16 * LS, o, c, g);
+            }
+        }
+    }
+    l = group_sum4(l);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float lq = __shfl(l, 4 * g + r, 64);
+        const int q = q0 + 4 * g + r;
+        if (q < p.Tq) {
+            float* op = p.out + (int64_t)b * p.o_bs + (int64_t)q * p.ldo + col0 + c;
+            const float inv = 1.f / lq;
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
+                if (16 * t + c < p.hd) op[16 * t] = o[t][r] * inv;
+        }
+    }
+    if (g == 0 && qrow < p.Tq) {
+        float* st = p.lse + 2 * (((int64_t)b * p.H + hh) * p.Tq + qrow);
+        st[0] = m;
+        st[1] = __logf(l);
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(512, 4) void mattn_bwd_dq_long_kernel(const MAttn p) {
+    constexpr int LS = HD + 4, DT = HD / 16, KEEP = HD <= 16 ? 16 : 8, CH = 16 * KEEP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;
+    float* Vs = smem + (size_t)CH * LS;
+    uint8_t* Ms = reinterpret_cast<uint8_t*>(Vs + (size_t)CH * LS);
+    const int NB = (p.Tq + 127) / 128;
+    const int blk = blockIdx.x % NB, bh = blockIdx.x / NB, b = bh / p.H, hh = bh % p.H, col0 = hh * p.hd;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int q0 = blk * 128 + wave * 16, qrow = q0 + c;
+    const bool q_ok = qrow < p.Tq;
+    float4 qf[DT], df[DT], of[DT];
+    load_frags<HD>(qf, p.q + (int64_t)b * p.q_bs, p.ldq, col0, qrow, p.Tq, g, p.scale, p.hd);
+    load_frags<HD>(df, p.dout + (int64_t)b * p.d_bs, p.ldd, col0, qrow, p.Tq, g, 1.f, p.hd);
+    load_frags<HD>(of, p.o + (int64_t)b * p.o_bs, p.ldo, col0, qrow, p.Tq, g, 1.f, p.hd);
+    float delta = 0.f;
+#pragma unroll
+    for (int x = 0; x < DT; ++x)
+        delta += df[x].x * of[x].x + df[x].y * of[x].y + df[x].z * of[x].z + df[x].w * of[x].w;
+    delta = group_sum4(delta);
+    const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + (q_ok ? qrow : 0);
+    const float lm = q_ok ? p.lse[2 * stat] : 0.f, ll = q_ok ? p.lse[2 * stat + 1] : 0.f;
+    if (g == 0 && q_ok) p.delta[stat] = delta;
+    f32x4 dq[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) dq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < p.Tk; k0 += CH) {
+        const int nt = min(CH, p.Tk - k0), TPc = (nt + 15) / 16 * 16, nkt = TPc / 16;
+        __syncthreads();
+        stage<HD>(Ks, p.k + (int64_t)b * p.k_bs + (int64_t)k0 * p.ldk, p.ldk, col0, nt, TPc, p.hd);
+        stage<HD>(Vs, p.v + (int64_t)b * p.v_bs + (int64_t)k0 * p.ldv, p.ldv, col0, nt, TPc, p.hd);
+        for (int j = threadIdx.x; j < TPc; j += blockDim.x)   // key codes: 1 live, 0 masked out, 2 beyond the sequence
+            Ms[j] = j < nt ? (p.mask ? (p.mask[(int64_t)b * p.Tk + k0 + j] ? 1 : 0) : 1) : 2;
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const uint32_t codes = reinterpret_cast<const uint32_t*>(Ms)[4 * kt + g];
+            const f32x4 s = score16<HD>(Ks + kt * 16 * LS, qf, c, g);
+            const f32x4 dp = score16<HD>(Vs + kt * 16 * LS, df, c, g);
+            f32x4 ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool live = q_ok && ((codes >> (8 * r)) & 0xffu) == 1u;
+                ds[r] = live ? __expf((s[r] - lm) - ll) * (dp[r] - delta) : 0.f;
+            }
+            accum16<HD>(ds, Ks + kt * 16 * LS, dq, c, g);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int q = q0 + 4 * g + r;
+        if (q < p.Tq) {
+            float* op = p.dq + (int64_t)b * p.dq_bs + (int64_t)q * p.lddq + col0 + c;
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
+                if (16 * t + c < p.hd) op[16 * t] = dq[t][r] * p.scale;
+        }
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(512, 4) void mattn_bwd_dkv_long_kernel(const MAttn p) {
+    constexpr int LS = HD + 4, DT = HD / 16, KEEP = HD <= 16 ? 16 : 8, CH = 16 * KEEP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Qs = smem;
+    float* Ds = smem + (size_t)CH * LS;
+    float* Lm = Ds + (size_t)CH * LS;
+    float* Ll = Lm + CH;
+    float* Dl = Ll + CH;
+    const int NB = (p.Tk + 127) / 128;
+    const int blk = blockIdx.x % NB, bh = blockIdx.x / NB, b = bh / p.H, hh = bh % p.H, col0 = hh * p.hd;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int k0 = blk * 128 + wave * 16, krow = k0 + c;
+    float4 kf[DT], vf[DT];
+    load_frags<HD>(kf, p.k + (int64_t)b * p.k_bs, p.ldk, col0, krow, p.Tk, g, p.scale, p.hd);
+    load_frags<HD>(vf, p.v + (int64_t)b * p.v_bs, p.ldv, col0, krow, p.Tk, g, 1.f, p.hd);
+    const bool in_seq = krow < p.Tk;
+    const bool keep = in_seq && (p.mask ? p.mask[(int64_t)b * p.Tk + krow] != 0 : true);
+    f32x4 dk[DT], dv[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) dk[t] = dv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i0 = 0; i0 < p.Tq; i0 += CH) {
+        const int nt = min(CH, p.Tq - i0), TPc = (nt + 15) / 16 * 16, nqt = TPc / 16;
+        __syncthreads();
+        stage<HD>(Qs, p.q + (int64_t)b * p.q_bs + (int64_t)i0 * p.ldq, p.ldq, col0, nt, TPc, p.hd);
+        stage<HD>(Ds, p.dout + (int64_t)b * p.d_bs + (int64_t)i0 * p.ldd, p.ldd, col0, nt, TPc, p.hd);
+        for (int t = threadIdx.x; t < TPc; t += blockDim.x) {
+            const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + i0 + (t < nt ? t : 0);
+            Lm[t] = t < nt ? p.lse[2 * stat] : INFINITY;     // +inf: a padded query row gets p = exp(-inf) = 0
+            Ll[t] = t < nt ? p.lse[2 * stat + 1] : 0.f;
+            Dl[t] = t < nt ? p.delta[stat] : 0.f;
+        }
+        __syncthreads();
+        for (int qt = 0; qt < nqt; ++qt) {
+            const f32x4 s = score16<HD>(Qs + qt * 16 * LS, kf, c, g);     // rows = queries, col = this lane's key
+            const f32x4 dp = score16<HD>(Ds + qt * 16 * LS, vf, c, g);
+            f32x4 pr, ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = 16 * qt + 4 * g + r;
+                const float e = __expf(((keep ? s[r] : kFill) - Lm[q]) - Ll[q]);
+                pr[r] = in_seq ? e : 0.f;
+                ds[r] = keep ? e * (dp[r] - Dl[q]) : 0.f;
+            }
+            accum16<HD>(pr, Ds + qt * 16 * LS, dv, c, g);
+            accum16<HD>(ds, Qs + qt * 16 * LS, dk, c, g);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = k0 + 4 * g + r;
+        if (k < p.Tk) {
+            float* ok = p.dk + (int64_t)b * p.dk_bs + (int64_t)k * p.lddk + col0 + c;
+            float* ov = p.dv + (int64_t)b * p.dv_bs + (int64_t)k * p.lddv + col0 + c;
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
+                if (16 * t + c < p.hd) {
+                    ok[16 * t] = dk[t][r] * p.scale;
+                    ov[16 * t] = dv[t][r];
+                }
+        }
+    }
+}
+
 template <typename K>
 static int launch_big_lds(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, const MAttn& a) {
     if (lds > 64 * 1024) {
@@ -595,10 +813,10 @@ static int launch_big_lds(K kernel, dim3 grid, dim3 block, size_t lds, hipStream
 // Is the matrix-core path applicable?  (16-B aligned operands, head width 4/8/12/16/32/48/64, <= 256 tokens.)
 static int padded_hd(int hd) { return hd < 16 ? 16 : hd; }
 bool mattn_applicable(const MAttn& a) {
-    if (!(a.hd % 16 == 0 || (a.hd < 16 && a.hd % 4 == 0)) || a.hd > 64 || a.hd < 4 || a.Tq > 256 || a.Tk > 256 ||
+    if (!(a.hd % 16 == 0 || (a.hd < 16 && a.hd % 4 == 0)) || a.hd > 64 || a.hd < 4 || a.Tq > 65535 || a.Tk > 65535 ||
         a.q_bs == 0)
         return false;
-    if ((int64_t)a.B * a.H > 0x7fffffffLL) return false;
+    if ((int64_t)a.B * a.H * ((std::max(a.Tq, a.Tk) + 127) / 128) > 0x7fffffffLL) return false;
     const int64_t lds[] = {a.ldq, a.ldk, a.ldv, a.q_bs, a.k_bs, a.v_bs};
     for (int64_t v : lds)
         if (v % 4 != 0) return false;
@@ -620,9 +838,20 @@ bool mattn_applicable(const MAttn& a) {
 // the tail wave inside 128 rows
 static bool use_tail(const MAttn& a) { return a.Tq == a.Tk && a.Tk % 16 == 1 && a.Tk > 16 && a.Tk <= 113; }
 
+static bool is_long(const MAttn& a) { return a.Tq > 256 || a.Tk > 256; }
+static int chunk_rows(int hd) { return padded_hd(hd) <= 16 ? 256 : 128; }
+static unsigned long_block(int T) { return 64u * (unsigned)std::min(8, (T + 15) / 16); }
+
 int mattn_forward(const MAttn& a0, hipStream_t st) {
     MAttn a = a0;
     a.tail = use_tail(a) ? 1 : 0;
+    if (is_long(a)) {
+        const int CH = chunk_rows(a.hd), NB = (a.Tq + 127) / 128;
+        const size_t lds = sizeof(float) * 2 * (size_t)CH * (padded_hd(a.hd) + 4) + (size_t)CH;
+        int rc;
+        MSN_MATTN_DISPATCH(mattn_fwd_long_kernel, dim3(a.B * a.H * NB), dim3(long_block(a.Tq)), lds, st, a)
+        return rc;
+    }
     const int TPk = (a.Tk + 15) / 16 * 16, nq = (a.Tq + 15) / 16;
     const int rows = a.tail ? (a.Tk + 3) / 4 * 4 : TPk;
     const size_t lds = sizeof(float) * (2 * (size_t)rows * (padded_hd(a.hd) + 4) + kTailScratch) + (size_t)TPk;
@@ -642,6 +871,17 @@ int mattn_backward(const MAttn& a0, hipStream_t st) {
     if (!ok) {
         set_error("attention backward: out / dout must be 16-byte aligned with strides %% 4 == 0");
         return MSN_ERR_SHAPE;
+    }
+    if (is_long(a)) {
+        const int CH = chunk_rows(a.hd);
+        {
+            const size_t lds = sizeof(float) * 2 * (size_t)CH * (padded_hd(a.hd) + 4) + (size_t)CH;
+            MSN_MATTN_DISPATCH(mattn_bwd_dq_long_kernel, dim3(a.B * a.H * ((a.Tq + 127) / 128)), dim3(long_block(a.Tq)), lds, st, a)
+            if (rc != MSN_OK) return rc;
+        }
+        const size_t lds = sizeof(float) * (2 * (size_t)CH * (padded_hd(a.hd) + 4) + 3 * (size_t)CH);
+        MSN_MATTN_DISPATCH(mattn_bwd_dkv_long_kernel, dim3(a.B * a.H * ((a.Tk + 127) / 128)), dim3(long_block(a.Tk)), lds, st, a)
+        return rc;
     }
     {
         const int rows = a.tail ? (a.Tk + 3) / 4 * 4 : TPk;

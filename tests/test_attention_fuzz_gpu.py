@@ -126,3 +126,36 @@ def test_xcd_grouped_head_order(B, heads, hd, T):
                                            msg=lambda m: f"{name} path {path}: {m}")
     finally:
         _lib.lib().msn_set_attention_path(0)
+
+
+@pytest.mark.parametrize("B,heads,hd,Tq,Tk", [(2, 2, 16, 1024, 1024), (1, 2, 16, 300, 300), (2, 1, 64, 257, 257),
+                                               (1, 3, 32, 520, 390), (2, 2, 16, 100, 700), (1, 2, 8, 513, 513)])
+def test_long_sequence_matrix_core_path(B, heads, hd, Tq, Tk):
+    """More than 256 tokens (the reference's spectrum transformer on 1024-bin spectra): the chunked matrix-core kernels
+    (online softmax across key chunks; attention_mfma.hip) against the fp64 reference, incl. a fully padded sample."""
+    from multimodal_supernovae_amd import _lib, ops
+    g = torch.Generator().manual_seed(Tq * 7 + Tk)
+    E = heads * hd
+    q = torch.randn(B, Tq, E, generator=g)
+    k, v = torch.randn(B, Tk, E, generator=g), torch.randn(B, Tk, E, generator=g)
+    dout = torch.randn(B, Tq, E, generator=g)
+    mask = torch.rand(B, Tk, generator=g) > 0.3
+    mask[:, 0] = True
+    mask[-1] = B > 1              # last sample fully padded when there is more than one
+    mask[0, 256:300] = False      # a masked stretch across the first chunk boundary
+    scale = 1.0 / math.sqrt(E)
+    qr, kr, vr = (t.double().requires_grad_() for t in (q, k, v))
+    ref = _ref(qr, kr, vr, mask, heads, scale)
+    ref.backward(dout.double())
+    _lib.check(_lib.lib().msn_set_attention_path(2))
+    try:
+        qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+        mu8 = ops._mask_u8(mask.cuda())
+        out, lse = ops.attention_fwd(qc, kc, vc, mu8, heads, scale)
+        torch.testing.assert_close(out.cpu().double(), ref.detach(), rtol=1e-4, atol=3e-5)
+        dq, dk, dv = torch.empty_like(qc), torch.empty_like(kc), torch.empty_like(vc)
+        ops.attention_bwd(qc, kc, vc, mu8, heads, scale, out, lse, dout.cuda(), dq, dk, dv)
+        for got, want, name in ((dq, qr.grad, "dq"), (dk, kr.grad, "dk"), (dv, vr.grad, "dv")):
+            torch.testing.assert_close(got.cpu().double(), want, rtol=3e-4, atol=3e-5, msg=lambda m: f"{name}: {m}")
+    finally:
+        _lib.lib().msn_set_attention_path(0)
