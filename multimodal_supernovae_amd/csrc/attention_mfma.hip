@@ -838,7 +838,7 @@ bool mattn_applicable(const MAttn& a) {
 // the tail wave inside 128 rows
 static bool use_tail(const MAttn& a) { return a.Tq == a.Tk && a.Tk % 16 == 1 && a.Tk > 16 && a.Tk <= 113; }
 
-static bool is_long(const MAttn& a) { return a.Tq > 256 || a.Tk > 256; }
+static bool is_long(const MAttn& a) { return a.Tq > 128 || a.Tk > 128; }
 static int chunk_rows(int hd) { return padded_hd(hd) <= 16 ? 256 : 128; }
 static unsigned long_block(int T) { return 64u * (unsigned)std::min(8, (T + 15) / 16); }
 
