@@ -266,6 +266,10 @@ def main():
     # steps, an event pair around a GEMM would also span whatever the other stream ran meanwhile)
     ops.GEMM_PROFILE = []
     concurrent, model.concurrent_towers = getattr(model, "concurrent_towers", False), False
+    try:    # this one step replays the side-stream towers on the caller's stream: autograd's stream-mismatch note is expected
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+    except AttributeError:
+        pass
     step()
     torch.cuda.synchronize()
     model.concurrent_towers = concurrent
