@@ -103,6 +103,73 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const int* __re
     }
 }
 
+
+// ---- tap-major columns: cols[(b,oh,ow)][(u,v,c)] -- channels fastest -------------------------------------------
+// With the (c,u,v) order above neighbouring threads read neighbouring PIXELS of one channel (C * 4 bytes apart) and
+// col2im reads its columns kh*kw floats apart: 2.7 TB/s on the ResNet stages.  With the channel fastest both kernels
+// move whole 16-byte groups of channels of one pixel / one tap (C % 4 == 0; every conv but a 3-channel stem), and the
+// weight is re-laid once per step to (C_out, kh, kw, C_in) -- a few MB.
+__global__ void im2col_tap_kernel(const float* __restrict__ x, ConvGeom g, float* __restrict__ cols) {
+    const int C4 = g.C / 4;
+    const int64_t K4 = (int64_t)C4 * g.kh * g.kw;
+    const int64_t total = (int64_t)g.B * g.OH * g.OW * K4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / K4;
+        const int kk = (int)(i % K4);
+        const int c4 = kk % C4, tap = kk / C4, v = tap % g.kw, u = tap / g.kw;
+        const int ow = (int)(row % g.OW), oh = (int)((row / g.OW) % g.OH);
+        const int64_t b = row / ((int64_t)g.OW * g.OH);
+        const int y = oh * g.sh + u - g.ph, xx = ow * g.sw + v - g.pw;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y >= 0 && y < g.H && xx >= 0 && xx < g.W)
+            val = *reinterpret_cast<const float4*>(x + ((b * g.H + y) * g.W + xx) * g.C + 4 * c4);
+        reinterpret_cast<float4*>(cols)[i] = val;
+    }
+}
+__global__ void col2im_tap_kernel(const float* __restrict__ dcols, ConvGeom g, float* __restrict__ dx) {
+    const int C4 = g.C / 4;
+    const int64_t K = (int64_t)g.C * g.kh * g.kw;
+    const int64_t total = (int64_t)g.B * g.H * g.W * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const int xx = (int)((i / C4) % g.W), y = (int)((i / ((int64_t)C4 * g.W)) % g.H);
+        const int64_t b = i / ((int64_t)C4 * g.W * g.H);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < g.kh; ++u) {
+            const int ty = y + g.ph - u;
+            if (ty < 0 || ty % g.sh != 0) continue;
+            const int oh = ty / g.sh;
+            if (oh >= g.OH) continue;
+            for (int v = 0; v < g.kw; ++v) {
+                const int tx = xx + g.pw - v;
+                if (tx < 0 || tx % g.sw != 0) continue;
+                const int ow = tx / g.sw;
+                if (ow >= g.OW) continue;
+                const float4 t = *reinterpret_cast<const float4*>(dcols + ((b * g.OH + oh) * g.OW + ow) * K +
+                                                                  (int64_t)(u * g.kw + v) * g.C + 4 * c4);
+                s.x += t.x, s.y += t.y, s.z += t.z, s.w += t.w;
+            }
+        }
+        reinterpret_cast<float4*>(dx)[i] = s;
+    }
+}
+// (C_out, C_in, taps) <-> (C_out, taps, C_in); to_tap != 0: src is torch's layout
+__global__ void conv_weight_relayout_kernel(const float* __restrict__ src, int64_t co, int ci, int taps, int to_tap,
+                                            float* __restrict__ dst) {
+    const int64_t total = co * ci * taps;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o = i / ((int64_t)ci * taps);
+        const int rem = (int)(i % ((int64_t)ci * taps));
+        if (to_tap) {   // i indexes dst (o, tap, c)
+            const int c = rem % ci, t = rem / ci;
+            dst[i] = src[(o * ci + c) * taps + t];
+        } else {        // i indexes dst (o, c, tap)
+            const int t = rem % taps, c = rem / taps;
+            dst[i] = src[(o * taps + t) * ci + c];
+        }
+    }
+}
+
 static int make_geom(const char* who, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
                      ConvGeom* g) {
     MSN_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0,
@@ -135,6 +202,38 @@ extern "C" int msn_col2im(const float* dcols, int B, int H, int W, int C, int kh
     MSN_REQUIRE(dx && dcols, "msn_col2im: null pointer");
     hipLaunchKernelGGL(col2im_kernel, dim3(grid_for((int64_t)B * H * W * C)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        dcols, g, dx);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+extern "C" int msn_im2col_tap(const float* x, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
+                              float* cols, msn_stream_t stream) {
+    ConvGeom g;
+    if (int rc = make_geom("msn_im2col_tap", B, H, W, C, kh, kw, sh, sw, ph, pw, &g)) return rc;
+    MSN_REQUIRE(x && cols, "msn_im2col_tap: null pointer");
+    MSN_REQUIRE(C % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(cols)) & 15) == 0,
+                "msn_im2col_tap: needs C %% 4 == 0 and 16-byte aligned tensors");
+    hipLaunchKernelGGL(im2col_tap_kernel, dim3(grid_for((int64_t)B * g.OH * g.OW * (C / 4) * kh * kw)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, g, cols);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+extern "C" int msn_col2im_tap(const float* dcols, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int ph,
+                              int pw, float* dx, msn_stream_t stream) {
+    ConvGeom g;
+    if (int rc = make_geom("msn_col2im_tap", B, H, W, C, kh, kw, sh, sw, ph, pw, &g)) return rc;
+    MSN_REQUIRE(dx && dcols, "msn_col2im_tap: null pointer");
+    MSN_REQUIRE(C % 4 == 0 && ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dcols)) & 15) == 0,
+                "msn_col2im_tap: needs C %% 4 == 0 and 16-byte aligned tensors");
+    hipLaunchKernelGGL(col2im_tap_kernel, dim3(grid_for((int64_t)B * H * W * (C / 4))), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), dcols, g, dx);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+extern "C" int msn_conv_weight_relayout(const float* src, int64_t co, int ci, int taps, int to_tap, float* dst,
+                                        msn_stream_t stream) {
+    MSN_REQUIRE(src && dst && co > 0 && ci > 0 && taps > 0, "msn_conv_weight_relayout: bad arguments");
+    hipLaunchKernelGGL(conv_weight_relayout_kernel, dim3(grid_for(co * ci * taps)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), src, co, ci, taps, to_tap, dst);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }

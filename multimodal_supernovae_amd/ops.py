@@ -454,6 +454,32 @@ def col2im(dcols, shape, kh, kw, sh, sw, ph, pw):
     return dx
 
 
+def im2col_tap(x, kh, kw, sh, sw, ph, pw):
+    """x: (B, H, W, C) channels-last, C % 4 == 0 -> (B*OH*OW, kh*kw*C), tap-major columns (channels fastest)."""
+    B, H, W, C = x.shape
+    oh, ow = conv_out(H, kh, sh, ph), conv_out(W, kw, sw, pw)
+    cols = torch.empty((B * oh * ow, C * kh * kw), dtype=torch.float32, device=x.device)
+    check(lib().msn_im2col_tap(ptr(_f32c(x, "x")), B, H, W, C, kh, kw, sh, sw, ph, pw, ptr(cols), stream_ptr()),
+          "msn_im2col_tap")
+    return cols
+
+
+def col2im_tap(dcols, shape, kh, kw, sh, sw, ph, pw):
+    B, H, W, C = shape
+    dx = torch.empty(shape, dtype=torch.float32, device=dcols.device)
+    check(lib().msn_col2im_tap(ptr(_f32c(dcols, "dcols")), B, H, W, C, kh, kw, sh, sw, ph, pw, ptr(dx), stream_ptr()),
+          "msn_col2im_tap")
+    return dx
+
+
+def conv_weight_relayout(w, co, ci, taps, to_tap):
+    """(co, ci, taps) -> (co, taps, ci) when to_tap, the inverse otherwise; returns a flat (co, ci * taps) matrix."""
+    out = torch.empty((co, ci * taps), dtype=torch.float32, device=w.device)
+    check(lib().msn_conv_weight_relayout(ptr(_f32c(w, "w")), co, ci, taps, 1 if to_tap else 0, ptr(out), stream_ptr()),
+          "msn_conv_weight_relayout")
+    return out
+
+
 def maxpool2d_fwd(x, k, s, p):
     B, H, W, C = x.shape
     oh, ow = conv_out(H, k, s, p), conv_out(W, k, s, p)

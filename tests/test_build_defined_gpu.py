@@ -13,7 +13,8 @@ def close(a, b, what, rtol=1e-3):
 
 
 @pytest.mark.parametrize("H,W,C,co,k,s,p", [(8, 8, 4, 8, 3, 1, 1), (9, 7, 3, 5, 3, 2, 1), (16, 16, 3, 8, 7, 2, 3),
-                                           (6, 6, 8, 16, 1, 2, 0), (5, 5, 4, 4, 1, 1, 0), (1, 20, 4, 8, 5, 1, 2)])
+                                           (6, 6, 8, 16, 1, 2, 0), (5, 5, 4, 4, 1, 1, 0), (1, 20, 4, 8, 5, 1, 2),
+                                           (12, 10, 16, 8, 3, 2, 1), (7, 7, 64, 32, 3, 1, 1), (1, 33, 8, 4, 7, 2, 3)])
 def test_conv_channels_last_matches_torch(H, W, C, co, k, s, p):
     from multimodal_supernovae_amd import functional as F_
     g = torch.Generator().manual_seed(H * W + C + k)
