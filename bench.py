@@ -276,7 +276,9 @@ def main():
     prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
     gemm_ms = sum(e[0].elapsed_time(e[1]) for e in prof)
     gemm_flops = sum(e[2] for e in prof)
-    gemm_bytes = sum(4.0 * (e[3][2] * e[3][4] + e[3][4] * e[3][3] + e[3][2] * e[3][3]) for e in prof)
+    # operands + result, plus the M x N aux matrix an epilogue writes (gelu' saved by the forward) or reads (gelu' / ReLU
+    # output / residual in the backward and residual-add epilogues)
+    gemm_bytes = sum(4.0 * (e[3][2] * e[3][4] + e[3][4] * e[3][3] + e[3][2] * e[3][3] * (2 if e[4] else 1)) for e in prof)
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     # dense matrix peak of the instruction the dominant kernel issues (MI355X_MICROARCH.md): fp32 157.3 TFLOP/s;
     # bf16 2500 TFLOP/s, of which the 3-product split can deliver at most a third as algorithmic flops

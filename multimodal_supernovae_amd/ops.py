@@ -6,7 +6,8 @@ from . import _lib
 from ._lib import check, lib, ptr, stream_ptr
 
 # bench.py sets this to a list to time every GEMM launch of one step with HIP events recorded on the
-# launch stream: entries are (start_event, end_event, algorithmic_flops, (opA, opB, M, N, K, epilogue)).  None = no instrumentation.
+# launch stream: entries are (start_event, end_event, algorithmic_flops, (opA, opB, M, N, K, epilogue), has_aux).  None = no
+# instrumentation.
 GEMM_PROFILE = None
 
 # Inner-product precision used by sgemm() when the caller passes none (include/msn_hip.h):
@@ -90,7 +91,7 @@ def sgemm(a, b, op_a=OP_N, op_b=OP_T, bias=None, epilogue=EPI_NONE, aux=None, ou
                       ptr(ws), ws_bytes, stream_ptr()), "msn_sgemm")
     if prof is not None:
         ev1.record()
-        prof.append((ev0, ev1, 2.0 * M * N * K, (op_a, op_b, M, N, K, epilogue)))
+        prof.append((ev0, ev1, 2.0 * M * N * K, (op_a, op_b, M, N, K, epilogue), aux is not None))
     return c
 
 
@@ -115,7 +116,7 @@ def wgrad_bias(dy, x, precision=None):
                            GEMM_PRECISION if precision is None else precision, ptr(ws), nb, stream_ptr()), "msn_wgrad_bias")
     if prof is not None:
         ev1.record()
-        prof.append((ev0, ev1, 2.0 * M * N * K, (OP_T, OP_N, M, N, K, EPI_NONE)))
+        prof.append((ev0, ev1, 2.0 * M * N * K, (OP_T, OP_N, M, N, K, EPI_NONE), False))
     return dw, db
 
 
