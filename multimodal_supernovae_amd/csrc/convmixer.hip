@@ -16,7 +16,7 @@
 
 namespace msn {
 
-constexpr int RED_BLOCKS_MAX = 256;
+constexpr int RED_BLOCKS_MAX = 1024;   // 4 workgroups per CU on a narrow (<= 64-channel) matrix
 constexpr int RED_CP = 64;                 // columns per block (threads along c)
 constexpr int RED_RG = 256 / RED_CP;       // row groups per block
 
@@ -53,14 +53,29 @@ __device__ __forceinline__ void col_reduce2(int64_t rows, int C, float* __restri
     __shared__ float red[2][RED_RG][RED_CP];
     const int c = blockIdx.y * RED_CP + (threadIdx.x % RED_CP);
     const int rg = threadIdx.x / RED_CP;
+    // four rows in flight per thread, each with its own pair of partial sums (one load per iteration and a single
+    // dependent chain left a 64-channel BatchNorm at 1.6 TB/s); fixed combination order: deterministic
     float sa = 0.f, sb = 0.f;
-    if (c < C)
-        for (int64_t r = (int64_t)blockIdx.x * RED_RG + rg; r < rows; r += (int64_t)gridDim.x * RED_RG) {
-            float a, b;
-            f(r, c, a, b);
-            sa += a;
-            sb += b;
+    if (c < C) {
+        const int64_t step = (int64_t)gridDim.x * RED_RG;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+        int64_t r = (int64_t)blockIdx.x * RED_RG + rg;
+        for (; r + 3 * step < rows; r += 4 * step) {
+            float x0, y0, x1, y1, x2, y2, x3, y3;
+            f(r, c, x0, y0);
+            f(r + step, c, x1, y1);
+            f(r + 2 * step, c, x2, y2);
+            f(r + 3 * step, c, x3, y3);
+            a0 += x0, b0 += y0, a1 += x1, b1 += y1, a2 += x2, b2 += y2, a3 += x3, b3 += y3;
         }
+        for (; r < rows; r += step) {
+            float x0, y0;
+            f(r, c, x0, y0);
+            a0 += x0, b0 += y0;
+        }
+        sa = (a0 + a1) + (a2 + a3);
+        sb = (b0 + b1) + (b2 + b3);
+    }
     red[0][rg][threadIdx.x % RED_CP] = sa;
     red[1][rg][threadIdx.x % RED_CP] = sb;
     __syncthreads();
