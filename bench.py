@@ -19,6 +19,10 @@ import os
 import sys
 import time
 
+# the pool's host driver only supports dmabuf IPC: without this RCCL's cross-process buffer sharing fails with
+# "hipIpcGetMemHandle: invalid argument" (must be in the environment before the HIP runtime starts)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
