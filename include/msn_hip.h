@@ -313,13 +313,16 @@ int msn_col2im(const float* dcols, int B, int H, int W, int C, int kh, int kw, i
                float* dx, msn_stream_t stream);
 /* The same with TAP-MAJOR columns cols[(b,oh,ow)][(u,v,c)] (channels fastest: both kernels move 16-byte channel groups;
  * C % 4 == 0, 16-byte aligned tensors) and the weight re-laid to match: msn_conv_weight_relayout(to_tap = 1) copies
- * torch's (C_out, C_in, kh*kw) weight to (C_out, kh*kw, C_in); to_tap = 0 is the inverse (for the weight gradient). */
+ * torch's (C_out, C_in, kh*kw) weight to (C_out, kh*kw, C_pad) with zeros in the channels C_in .. C_pad-1; to_tap = 0
+ * is the inverse (for the weight gradient; the padding channels are dropped).  msn_pad_channels widens a channels-last
+ * tensor (rows x C -> rows x Cp, zeros added): a 3-channel image stem runs as a 4-channel convolution. */
 int msn_im2col_tap(const float* x, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
                    float* cols, msn_stream_t stream);
 int msn_col2im_tap(const float* dcols, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
                    float* dx, msn_stream_t stream);
-int msn_conv_weight_relayout(const float* src, int64_t co, int ci, int taps, int to_tap, float* dst,
+int msn_conv_weight_relayout(const float* src, int64_t co, int ci, int ci_pad, int taps, int to_tap, float* dst,
                              msn_stream_t stream);
+int msn_pad_channels(const float* x, int64_t rows, int C, int Cp, float* out, msn_stream_t stream);
 int msn_maxpool2d_fwd(const float* x, int B, int H, int W, int C, int k, int s, int p, float* y, int* argmax,
                       msn_stream_t stream);
 int msn_maxpool2d_bwd(const float* dy, const int* argmax, int B, int H, int W, int C, int k, int s, int p,

@@ -71,7 +71,8 @@ SIGNATURES = {
     "msn_col2im": (c_int, [c_ptr] + [c_int] * 10 + [c_ptr, c_ptr]),
     "msn_im2col_tap": (c_int, [c_ptr] + [c_int] * 10 + [c_ptr, c_ptr]),
     "msn_col2im_tap": (c_int, [c_ptr] + [c_int] * 10 + [c_ptr, c_ptr]),
-    "msn_conv_weight_relayout": (c_int, [c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr]),
+    "msn_conv_weight_relayout": (c_int, [c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
+    "msn_pad_channels": (c_int, [c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr]),
     "msn_maxpool2d_fwd": (c_int, [c_ptr] + [c_int] * 7 + [c_ptr, c_ptr, c_ptr]),
     "msn_maxpool2d_bwd": (c_int, [c_ptr, c_ptr] + [c_int] * 7 + [c_ptr, c_ptr]),
     "msn_batchnorm_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr,

@@ -104,6 +104,62 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const int* __re
 }
 
 
+// 4 channels per thread (C % 4 == 0): 16-byte loads / stores of the pixel's channel group
+__global__ void maxpool_fwd4_kernel(const float* __restrict__ x, ConvGeom g, float* __restrict__ y, int* __restrict__ arg) {
+    const int C4 = g.C / 4;
+    const int64_t total = (int64_t)g.B * g.OH * g.OW * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const int ow = (int)((i / C4) % g.OW), oh = (int)((i / ((int64_t)C4 * g.OW)) % g.OH);
+        const int64_t b = i / ((int64_t)C4 * g.OW * g.OH);
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+        for (int u = 0; u < g.kh; ++u) {
+            const int yy = oh * g.sh + u - g.ph;
+            if (yy < 0 || yy >= g.H) continue;
+            for (int v = 0; v < g.kw; ++v) {
+                const int xx = ow * g.sw + v - g.pw;
+                if (xx < 0 || xx >= g.W) continue;
+                const float4 t = *reinterpret_cast<const float4*>(x + ((b * g.H + yy) * g.W + xx) * g.C + 4 * c4);
+                const float val[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (val[k] > best[k]) { best[k] = val[k]; bi[k] = yy * g.W + xx; }
+            }
+        }
+        reinterpret_cast<float4*>(y)[i] = make_float4(best[0], best[1], best[2], best[3]);
+        reinterpret_cast<int4*>(arg)[i] = make_int4(bi[0], bi[1], bi[2], bi[3]);
+    }
+}
+__global__ void maxpool_bwd4_kernel(const float* __restrict__ dy, const int* __restrict__ arg, ConvGeom g,
+                                    float* __restrict__ dx) {
+    const int C4 = g.C / 4;
+    const int64_t total = (int64_t)g.B * g.H * g.W * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const int xx = (int)((i / C4) % g.W), y = (int)((i / ((int64_t)C4 * g.W)) % g.H);
+        const int64_t b = i / ((int64_t)C4 * g.W * g.H);
+        const int me = y * g.W + xx;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < g.kh; ++u) {
+            const int ty = y + g.ph - u;
+            if (ty < 0 || ty % g.sh != 0 || ty / g.sh >= g.OH) continue;
+            for (int v = 0; v < g.kw; ++v) {
+                const int tx = xx + g.pw - v;
+                if (tx < 0 || tx % g.sw != 0 || tx / g.sw >= g.OW) continue;
+                const int64_t o = ((b * g.OH + ty / g.sh) * g.OW + tx / g.sw) * g.C + 4 * c4;
+                const int4 a = *reinterpret_cast<const int4*>(arg + o);
+                const float4 d = *reinterpret_cast<const float4*>(dy + o);
+                s[0] += a.x == me ? d.x : 0.f;
+                s[1] += a.y == me ? d.y : 0.f;
+                s[2] += a.z == me ? d.z : 0.f;
+                s[3] += a.w == me ? d.w : 0.f;
+            }
+        }
+        reinterpret_cast<float4*>(dx)[i] = make_float4(s[0], s[1], s[2], s[3]);
+    }
+}
+
 // ---- tap-major columns: cols[(b,oh,ow)][(u,v,c)] -- channels fastest -------------------------------------------
 // With the (c,u,v) order above neighbouring threads read neighbouring PIXELS of one channel (C * 4 bytes apart) and
 // col2im reads its columns kh*kw floats apart: 2.7 TB/s on the ResNet stages.  With the channel fastest both kernels
@@ -153,20 +209,31 @@ __global__ void col2im_tap_kernel(const float* __restrict__ dcols, ConvGeom g, f
         reinterpret_cast<float4*>(dx)[i] = s;
     }
 }
-// (C_out, C_in, taps) <-> (C_out, taps, C_in); to_tap != 0: src is torch's layout
-__global__ void conv_weight_relayout_kernel(const float* __restrict__ src, int64_t co, int ci, int taps, int to_tap,
-                                            float* __restrict__ dst) {
-    const int64_t total = co * ci * taps;
+// (C_out, C_in, taps) <-> (C_out, taps, C_pad >= C_in); to_tap != 0: src is torch's layout, the channels C_in .. C_pad-1
+// of the tap-major copy are zeros (a 3-channel stem runs as a 4-channel one); to_tap == 0 drops them again
+__global__ void conv_weight_relayout_kernel(const float* __restrict__ src, int64_t co, int ci, int ci_pad, int taps,
+                                            int to_tap, float* __restrict__ dst) {
+    const int64_t total = co * (to_tap ? ci_pad : ci) * taps;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t o = i / ((int64_t)ci * taps);
-        const int rem = (int)(i % ((int64_t)ci * taps));
-        if (to_tap) {   // i indexes dst (o, tap, c)
-            const int c = rem % ci, t = rem / ci;
-            dst[i] = src[(o * ci + c) * taps + t];
-        } else {        // i indexes dst (o, c, tap)
+        if (to_tap) {   // i indexes dst (o, tap, c) with c < ci_pad
+            const int64_t o = i / ((int64_t)ci_pad * taps);
+            const int rem = (int)(i % ((int64_t)ci_pad * taps));
+            const int c = rem % ci_pad, t = rem / ci_pad;
+            dst[i] = c < ci ? src[(o * ci + c) * taps + t] : 0.f;
+        } else {        // i indexes dst (o, c, tap) with c < ci
+            const int64_t o = i / ((int64_t)ci * taps);
+            const int rem = (int)(i % ((int64_t)ci * taps));
             const int t = rem % taps, c = rem / taps;
-            dst[i] = src[(o * taps + t) * ci + c];
+            dst[i] = src[(o * taps + t) * ci_pad + c];
         }
+    }
+}
+// rows x C -> rows x Cp (Cp >= C), zeros in the added channels
+__global__ void pad_channels_kernel(const float* __restrict__ x, int64_t rows, int C, int Cp, float* __restrict__ out) {
+    const int64_t total = rows * Cp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cp);
+        out[i] = c < C ? x[(i / Cp) * C + c] : 0.f;
     }
 }
 
@@ -229,11 +296,18 @@ extern "C" int msn_col2im_tap(const float* dcols, int B, int H, int W, int C, in
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }
-extern "C" int msn_conv_weight_relayout(const float* src, int64_t co, int ci, int taps, int to_tap, float* dst,
-                                        msn_stream_t stream) {
-    MSN_REQUIRE(src && dst && co > 0 && ci > 0 && taps > 0, "msn_conv_weight_relayout: bad arguments");
-    hipLaunchKernelGGL(conv_weight_relayout_kernel, dim3(grid_for(co * ci * taps)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), src, co, ci, taps, to_tap, dst);
+extern "C" int msn_conv_weight_relayout(const float* src, int64_t co, int ci, int ci_pad, int taps, int to_tap,
+                                        float* dst, msn_stream_t stream) {
+    MSN_REQUIRE(src && dst && co > 0 && ci > 0 && ci_pad >= ci && taps > 0, "msn_conv_weight_relayout: bad arguments");
+    hipLaunchKernelGGL(conv_weight_relayout_kernel, dim3(grid_for(co * ci_pad * taps)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), src, co, ci, ci_pad, taps, to_tap, dst);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+extern "C" int msn_pad_channels(const float* x, int64_t rows, int C, int Cp, float* out, msn_stream_t stream) {
+    MSN_REQUIRE(x && out && rows > 0 && C > 0 && Cp >= C, "msn_pad_channels: bad arguments");
+    hipLaunchKernelGGL(pad_channels_kernel, dim3(grid_for(rows * Cp)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       rows, C, Cp, out);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }
@@ -242,8 +316,14 @@ extern "C" int msn_maxpool2d_fwd(const float* x, int B, int H, int W, int C, int
     ConvGeom g;
     if (int rc = make_geom("msn_maxpool2d_fwd", B, H, W, C, k, k, s, s, p, p, &g)) return rc;
     MSN_REQUIRE(x && y && argmax, "msn_maxpool2d_fwd: null pointer");
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((int64_t)B * g.OH * g.OW * C)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), x, g, y, argmax);
+    const bool vec = C % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
+                                     reinterpret_cast<uintptr_t>(argmax)) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(maxpool_fwd4_kernel, dim3(grid_for((int64_t)B * g.OH * g.OW * (C / 4))), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), x, g, y, argmax);
+    else
+        hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((int64_t)B * g.OH * g.OW * C)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), x, g, y, argmax);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }
@@ -252,8 +332,14 @@ extern "C" int msn_maxpool2d_bwd(const float* dy, const int* argmax, int B, int 
     ConvGeom g;
     if (int rc = make_geom("msn_maxpool2d_bwd", B, H, W, C, k, k, s, s, p, p, &g)) return rc;
     MSN_REQUIRE(dy && dx && argmax, "msn_maxpool2d_bwd: null pointer");
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((int64_t)B * H * W * C)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), dy, argmax, g, dx);
+    const bool vec = C % 4 == 0 && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) |
+                                     reinterpret_cast<uintptr_t>(argmax)) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(maxpool_bwd4_kernel, dim3(grid_for((int64_t)B * H * W * (C / 4))), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), dy, argmax, g, dx);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((int64_t)B * H * W * C)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), dy, argmax, g, dx);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }

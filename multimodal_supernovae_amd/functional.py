@@ -639,9 +639,9 @@ def take_token(x, idx):
 @_remember_precision
 class _ConvCL(torch.autograd.Function):
     """y = conv(x) (+ bias) (+ ReLU) on channels-last tensors via im2col + the MFMA GEMM; weight keeps torch's
-    (C_out, C_in, kh, kw) layout.  With C_in % 4 == 0 the columns are tap-major (channels fastest: the gather kernels
-    move 16-byte channel groups) and the weight / its gradient are re-laid to (C_out, kh, kw, C_in) and back; a
-    3-channel stem keeps the (c, u, v) column order, which is the weight's own flattening."""
+    (C_out, C_in, kh, kw) layout.  The columns are tap-major (channels fastest: the gather kernels move 16-byte channel
+    groups) and the weight / its gradient are re-laid to (C_out, kh, kw, C_in) and back; a channel count that is not a
+    multiple of 4 (the 3-channel image stem) is widened with zero channels first."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, relu):
@@ -651,23 +651,22 @@ class _ConvCL(torch.autograd.Function):
         (sh, sw), (ph, pw) = stride, padding
         x = _c(x)
         plain = kh == 1 and kw == 1 and sh == 1 and sw == 1 and ph == 0 and pw == 0
-        tap = (not plain) and C % 4 == 0
+        Cp = C if plain else (C + 3) // 4 * 4
         if plain:
             cols, wmat = x.view(B * H * W, C), weight.view(co, -1)
-        elif tap:
-            cols = ops.im2col_tap(x, kh, kw, sh, sw, ph, pw)
-            wmat = ops.conv_weight_relayout(_c(weight), co, ci, kh * kw, True)
         else:
-            cols, wmat = ops.im2col(x, kh, kw, sh, sw, ph, pw), weight.view(co, -1)
+            xp = x if Cp == C else ops.pad_channels(x, Cp)
+            cols = ops.im2col_tap(xp, kh, kw, sh, sw, ph, pw)
+            wmat = ops.conv_weight_relayout(_c(weight), co, ci, kh * kw, True, ci_pad=Cp)
         oh, ow = ops.conv_out(H, kh, sh, ph), ops.conv_out(W, kw, sw, pw)
         y = sgemm(cols, wmat, OP_N, OP_T, bias=bias, epilogue=EPI_RELU if relu else EPI_NONE)
-        ctx.geom = (B, H, W, C, kh, kw, sh, sw, ph, pw, plain, tap, relu, bias is not None, tuple(weight.shape))
+        ctx.geom = (B, H, W, C, Cp, kh, kw, sh, sw, ph, pw, plain, relu, bias is not None, tuple(weight.shape))
         ctx.save_for_backward(cols, wmat, y if relu else torch.empty(0))
         return y.view(B, oh, ow, co)
 
     @staticmethod
     def backward(ctx, dy):
-        B, H, W, C, kh, kw, sh, sw, ph, pw, plain, tap, relu, has_bias, wshape = ctx.geom
+        B, H, W, C, Cp, kh, kw, sh, sw, ph, pw, plain, relu, has_bias, wshape = ctx.geom
         cols, wmat, y = ctx.saved_tensors
         co = wshape[0]
         d = _c(dy).view(-1, co)
@@ -677,18 +676,18 @@ class _ConvCL(torch.autograd.Function):
             dw, db = ops.wgrad_bias(d, cols)
         else:
             dw, db = sgemm(d, cols, OP_T, OP_N), None
-        if tap:
-            dw = ops.conv_weight_relayout(dw, co, C, kh * kw, False)
+        if not plain:
+            dw = ops.conv_weight_relayout(dw, co, C, kh * kw, False, ci_pad=Cp)
         dw = dw.view(wshape)
         dx = None
         if ctx.needs_input_grad[0]:
             dcols = sgemm(d, wmat, OP_N, OP_N)
             if plain:
                 dx = dcols.view(B, H, W, C)
-            elif tap:
-                dx = ops.col2im_tap(dcols, (B, H, W, C), kh, kw, sh, sw, ph, pw)
             else:
-                dx = ops.col2im(dcols, (B, H, W, C), kh, kw, sh, sw, ph, pw)
+                dx = ops.col2im_tap(dcols, (B, H, W, Cp), kh, kw, sh, sw, ph, pw)
+                if Cp != C:
+                    dx = dx[..., :C].contiguous()    # gradient of the zero channels is dropped (data movement only)
         return dx, dw, db, None, None, None
 
 

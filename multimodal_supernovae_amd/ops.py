@@ -473,11 +473,21 @@ def col2im_tap(dcols, shape, kh, kw, sh, sw, ph, pw):
     return dx
 
 
-def conv_weight_relayout(w, co, ci, taps, to_tap):
-    """(co, ci, taps) -> (co, taps, ci) when to_tap, the inverse otherwise; returns a flat (co, ci * taps) matrix."""
-    out = torch.empty((co, ci * taps), dtype=torch.float32, device=w.device)
-    check(lib().msn_conv_weight_relayout(ptr(_f32c(w, "w")), co, ci, taps, 1 if to_tap else 0, ptr(out), stream_ptr()),
-          "msn_conv_weight_relayout")
+def conv_weight_relayout(w, co, ci, taps, to_tap, ci_pad=None):
+    """(co, ci, taps) -> (co, taps, ci_pad) when to_tap (zeros in the channels ci .. ci_pad-1), the inverse otherwise;
+    returns a flat 2-D matrix of `co` rows."""
+    ci_pad = ci if ci_pad is None else ci_pad
+    out = torch.empty((co, (ci_pad if to_tap else ci) * taps), dtype=torch.float32, device=w.device)
+    check(lib().msn_conv_weight_relayout(ptr(_f32c(w, "w")), co, ci, ci_pad, taps, 1 if to_tap else 0, ptr(out),
+                                         stream_ptr()), "msn_conv_weight_relayout")
+    return out
+
+
+def pad_channels(x, cp):
+    """Channels-last (..., C) -> (..., cp) with zeros in the added channels."""
+    C = x.shape[-1]
+    out = torch.empty(x.shape[:-1] + (cp,), dtype=torch.float32, device=x.device)
+    check(lib().msn_pad_channels(ptr(_f32c(x, "x")), x.numel() // C, C, cp, ptr(out), stream_ptr()), "msn_pad_channels")
     return out
 
 

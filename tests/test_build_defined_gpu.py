@@ -37,9 +37,10 @@ def test_conv_channels_last_matches_torch(H, W, C, co, k, s, p):
     close(bg.grad.cpu(), br.grad, "db")
 
 
-def test_maxpool_channels_last_matches_torch():
+@pytest.mark.parametrize("C", [5, 8, 64])       # scalar kernel, 4-channels-per-thread kernels
+def test_maxpool_channels_last_matches_torch(C):
     from multimodal_supernovae_amd import functional as F_
-    x = torch.randn(2, 5, 9, 11, generator=torch.Generator().manual_seed(1))
+    x = torch.randn(2, C, 9, 11, generator=torch.Generator().manual_seed(1))
     xr = x.clone().requires_grad_()
     ref = F.max_pool2d(xr, 3, 2, 1)
     cot = torch.randn(ref.shape, generator=torch.Generator().manual_seed(2))
