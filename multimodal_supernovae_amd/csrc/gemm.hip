@@ -649,7 +649,7 @@ __global__ __launch_bounds__(64 * G) void splitk_reduce_kernel(const float* __re
 // Column sums, two deterministic stages.  Stage 1: a 256-thread block = 4 row groups x 64 columns
 // streams its share of the rows (coalesced 256-B row segments, 4 rows in flight per thread) and
 // reduces the row groups through LDS -> part[block][N].  Stage 2: the same shape sums the slabs.
-constexpr int CS_COLS = 64, CS_RG = 4, CS_MAX_BLOCKS = 128;
+constexpr int CS_COLS = 64, CS_RG = 4, CS_MAX_BLOCKS = 1024;   // 128 blocks left half of the CUs without a workgroup
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int64_t ldx, int64_t M,
                                                              int64_t N, float* __restrict__ part) {
     __shared__ float red[CS_RG][CS_COLS];
@@ -676,10 +676,18 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     __shared__ float red[CS_RG][CS_COLS];
     const int cl = threadIdx.x % CS_COLS, rg = threadIdx.x / CS_COLS;
     const int64_t n = (int64_t)blockIdx.x * CS_COLS + cl;
-    float s = 0.f;
-    if (n < N)
-        for (int64_t k = rg; k < slabs; k += CS_RG) s += part[k * N + n];
-    red[rg][cl] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (n < N) {
+        int64_t k = rg;
+        for (; k + 3 * CS_RG < slabs; k += 4 * CS_RG) {   // four slabs in flight per thread
+            s0 += part[k * N + n];
+            s1 += part[(k + CS_RG) * N + n];
+            s2 += part[(k + 2 * CS_RG) * N + n];
+            s3 += part[(k + 3 * CS_RG) * N + n];
+        }
+        for (; k < slabs; k += CS_RG) s0 += part[k * N + n];
+    }
+    red[rg][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rg == 0 && n < N) out[n] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
