@@ -222,17 +222,23 @@ __global__ void nce_fwd_finish_kernel(const NceArgs p, float* __restrict__ lse_r
     __syncthreads();
     // rows of S come from side[0].Q (E2), columns from side[1].Q (E1); local row i <-> global q_offset + i
     const int nb = min(p.side[0].nq, p.side[1].nq);
-    // positives: one wave per row (coalesced reads of the two embeddings, wave-shuffle sum), rows dealt to the waves
+    // positives: 16 lanes per row, four rows per wave and iteration (coalesced reads of the two embeddings, a 4-step
+    // shuffle sum inside the lane group): a whole wave per row walked 64 dependent load + reduce rounds per wave
     float acc = 0.f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    for (int i = wave; i < nb; i += nwaves) {
-        if (p.q_offset + i >= p.n_diag) continue;
-        const float* a = p.side[0].Q + (int64_t)i * p.side[0].ldq;
-        const float* b = p.side[1].Q + (int64_t)i * p.side[1].ldq;
+    const int sub = lane >> 4, l16 = lane & 15;
+    for (int i0 = 4 * wave; i0 < nb; i0 += 4 * nwaves) {
+        const int i = i0 + sub;
+        const bool on = i < nb && p.q_offset + i < p.n_diag;
         float dot = 0.f;
-        for (int d = lane; d < D; d += 64) dot = fmaf(a[d], b[d], dot);
-        dot = wave_sum(dot);
-        if (lane == 0) acc += lse_row[i] + lse_col[i] - 2.f * (dot * scale + bias);
+        if (on) {
+            const float* a = p.side[0].Q + (int64_t)i * p.side[0].ldq;
+            const float* b = p.side[1].Q + (int64_t)i * p.side[1].ldq;
+            for (int d = l16; d < D; d += 16) dot = fmaf(a[d], b[d], dot);
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+        if (on && l16 == 0) acc += lse_row[i] + lse_col[i] - 2.f * (dot * scale + bias);
     }
     const float tot = block_sum(acc, red);
     if (threadIdx.x == 0) *loss = tot / (2.f * (float)p.n_diag);
