@@ -335,30 +335,70 @@ __global__ __launch_bounds__(1024) void time_embed_bwd_finish_kernel(const float
 // ref transformer_utils.py:234-239: x = x * mask; mean: sum_t / sum_t mask (0/0 -> NaN for an empty
 // row, as the reference); max: max over ALL t of the zeroed tokens (padded zeros take part).
 constexpr int POOL_MEAN = 0, POOL_MAX = 1;
-__global__ void pool_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask, int T, int e, int mode,
-                                float* __restrict__ out, int* __restrict__ arg, float* __restrict__ count) {
+// One workgroup per sample: 4 thread groups x 64 channels, group q owns the q-th quarter of the sequence (contiguous,
+// so the first maximum wins ties exactly as in a sequential scan) and keeps 4 loads in flight; the groups are combined
+// through LDS in order.  (One thread per channel walking all T tokens ran at 0.8 TB/s.)
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask, int T,
+                                                       int e, int mode, float* __restrict__ out, int* __restrict__ arg,
+                                                       float* __restrict__ count) {
+    __shared__ float red_v[4][64];
+    __shared__ float red_c[4][64];
+    __shared__ int red_i[4][64];
     const int b = blockIdx.x;
     const float* xb = x + (int64_t)b * T * e;
     const uint8_t* mb = mask + (int64_t)b * T;
-    for (int c = threadIdx.x; c < e; c += blockDim.x) {
-        if (mode == POOL_MEAN) {
-            float s = 0.f, cnt = 0.f;
-            for (int t = 0; t < T; ++t) {
-                const float m = mb[t] ? 1.f : 0.f;
-                s += xb[(int64_t)t * e + c] * m;
-                cnt += m;
+    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int per = (T + 3) / 4, t0 = q * per, t1 = min(T, t0 + per);
+    for (int c0 = 0; c0 < e; c0 += 64) {
+        const int c = c0 + cl;
+        float s = 0.f, cnt = 0.f, best = -INFINITY;
+        int bi = t0;
+        if (c < e) {
+            if (mode == POOL_MEAN) {
+                float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                int t = t0;
+                for (; t + 3 < t1; t += 4) {
+                    const float m0 = mb[t] ? 1.f : 0.f, m1 = mb[t + 1] ? 1.f : 0.f, m2 = mb[t + 2] ? 1.f : 0.f,
+                                m3 = mb[t + 3] ? 1.f : 0.f;
+                    s += xb[(int64_t)t * e + c] * m0;
+                    s1 += xb[(int64_t)(t + 1) * e + c] * m1;
+                    s2 += xb[(int64_t)(t + 2) * e + c] * m2;
+                    s3 += xb[(int64_t)(t + 3) * e + c] * m3;
+                    cnt += (m0 + m1) + (m2 + m3);
+                }
+                for (; t < t1; ++t) {
+                    const float m = mb[t] ? 1.f : 0.f;
+                    s += xb[(int64_t)t * e + c] * m;
+                    cnt += m;
+                }
+                s = (s + s1) + (s2 + s3);
+            } else {
+                for (int t = t0; t < t1; ++t) {
+                    const float v = xb[(int64_t)t * e + c] * (mb[t] ? 1.f : 0.f);
+                    if (v > best) { best = v; bi = t; }
+                }
             }
-            out[(int64_t)b * e + c] = s / cnt;
-            if (c == 0) count[b] = cnt;
-        } else {
-            float best = -INFINITY;
-            int bi = 0;
-            for (int t = 0; t < T; ++t) {
-                const float v = xb[(int64_t)t * e + c] * (mb[t] ? 1.f : 0.f);
-                if (v > best) { best = v; bi = t; }
+        }
+        __syncthreads();
+        red_v[q][cl] = mode == POOL_MEAN ? s : best;
+        red_c[q][cl] = cnt;
+        red_i[q][cl] = bi;
+        __syncthreads();
+        if (q == 0 && c < e) {
+            if (mode == POOL_MEAN) {
+                const float tot = (red_v[0][cl] + red_v[1][cl]) + (red_v[2][cl] + red_v[3][cl]);
+                const float n = (red_c[0][cl] + red_c[1][cl]) + (red_c[2][cl] + red_c[3][cl]);
+                out[(int64_t)b * e + c] = tot / n;
+                if (c == 0) count[b] = n;
+            } else {
+                float bb = red_v[0][cl];
+                int ii = red_i[0][cl];
+#pragma unroll
+                for (int k = 1; k < 4; ++k)
+                    if (red_v[k][cl] > bb) { bb = red_v[k][cl]; ii = red_i[k][cl]; }
+                out[(int64_t)b * e + c] = bb;
+                arg[(int64_t)b * e + c] = ii;
             }
-            out[(int64_t)b * e + c] = best;
-            arg[(int64_t)b * e + c] = bi;
         }
     }
 }
@@ -681,7 +721,7 @@ extern "C" int msn_masked_pool_fwd(const float* x, const uint8_t* mask, int64_t 
     MSN_REQUIRE(B > 0 && T > 0 && e > 0 && B < (1ll << 31), "msn_masked_pool_fwd: bad sizes");
     MSN_REQUIRE(x && mask && out && ((mode == POOL_MEAN && count) || (mode == POOL_MAX && argmax)),
                 "msn_masked_pool_fwd: bad arguments");
-    hipLaunchKernelGGL(pool_fwd_kernel, dim3((unsigned)B), dim3(std::min(256, (e + 63) / 64 * 64)), 0,
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3((unsigned)B), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, mask, T, e, mode, out, argmax, count);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
