@@ -165,6 +165,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     const bool qfast = p.s == S && vec4_ok(p.q, p.ldq, p.q_bstride, p.s);
     const bool ofast = p.s == S && vec4_ok(p.o, p.ldo, p.o_bstride, p.s);
 
+    // scores are kept in log2 units (log2(e) folded into the query scale): v_exp_f32 is 2^x, so the exponentials need
+    // no multiply; the masked-fill value is scaled the same way and the stored maximum converted back (exactly -1e7 when
+    // every key is masked: one fp32 ulp is 1.0 there)
+    constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+    const float qscale = p.scale * kLog2e;
     f2 q[R][S / 2], o[R][S / 2];
     float m[R], l[R];
 #pragma unroll
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         load_row_any<S>(qs, p.q + (int64_t)b * p.q_bstride + (int64_t)(on ? i0 + r : 0) * p.ldq + col0, p.s, on, qfast);
 #pragma unroll
         for (int d = 0; d < S / 2; ++d) {
-            q[r][d] = f2{qs[2 * d] * p.scale, qs[2 * d + 1] * p.scale};
+            q[r][d] = f2{qs[2 * d] * qscale, qs[2 * d + 1] * qscale};
             o[r][d] = f2{0.f, 0.f};
         }
         m[r] = -INFINITY, l[r] = 0.f;
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         stage_rows<S>(Ks, kb, p.ldk, col0, p.s, k0, nt, kvec, ntp);
         stage_rows<S>(Vs, vb, p.ldv, col0, p.s, k0, nt, vvec, ntp);
         for (int j = threadIdx.x; j < ntp; j += blockDim.x)
-            Fs[j] = j >= nt ? -INFINITY : ((p.mask && !p.mask[(int64_t)b * p.Tk + k0 + j]) ? kMaskFill : 0.f);
+            Fs[j] = j >= nt ? -INFINITY : ((p.mask && !p.mask[(int64_t)b * p.Tk + k0 + j]) ? kMaskFill * kLog2e : 0.f);
         __syncthreads();
         // whole chunks of KB keys, no per-key control flow: the compiler interleaves the KB x R independent dot
         // products; a key beyond the sequence scores -inf (probability exactly 0)
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 mn[r] = fmaxf(m[r], mx[r]);
-                const float alpha = __expf(m[r] - mn[r]);
+                const float alpha = __builtin_amdgcn_exp2f(m[r] - mn[r]);
                 l[r] *= alpha;
 #pragma unroll
                 for (int d = 0; d < S / 2; ++d) o[r][d] *= alpha;
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
                 load_row2<S>(vv, Vs + (j0 + jj) * S);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const float pj = __expf(sc[r][jj] - mn[r]);
+                    const float pj = __builtin_amdgcn_exp2f(sc[r][jj] - mn[r]);
                     l[r] += pj;
                     axpy2<S>(o[r], pj, vv);
                 }
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
             store_row_any<S>(op, os, p.s, ofast);
             // (max, log-sum) kept apart: with every key padded the max is -1e7, where one fp32 ulp is 1.0
             float* st = p.lse + 2 * (((int64_t)b * p.H + hh) * p.Tq + i);
-            st[0] = m[r];
+            st[0] = m[r] < -1e6f ? kMaskFill : m[r] * kLn2;
             st[1] = __logf(l[r]);
         }
     }
