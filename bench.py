@@ -203,6 +203,9 @@ def main():
                     help="fp32 GEMM kernel family: 0 register-staged, 1 / 2 / 3 LDS-DMA rings (3 = default)")
     ap.add_argument("--gemm-precision", default="f32", choices=["f32", "bf16x3", "bf16"],
                     help="inner-product precision of the GEMMs (bf16x3 = split-bf16, fp32-grade accuracy)")
+    ap.add_argument("--graphed", action="store_true",
+                    help="N = 1: record the training step as a HIP graph (trainer.GraphedTrainStep) and time its replays -- "
+                         "what the reference's own batch sizes (32 ... 256), which are launch-bound when run eagerly, gain")
     ap.add_argument("--sync-batchnorm", action="store_true",
                     help="N > 1, BatchNorm towers (resnet18_cnn1d, convmixer_lc_sp): batch statistics over all ranks")
     ap.add_argument("--cpu-sample-batch", type=int, default=32)
@@ -245,6 +248,18 @@ def main():
         opt.step()
         return loss
 
+    if args.graphed:
+        if world != 1:
+            raise SystemExit("--graphed is a single-GPU measurement")
+        from multimodal_supernovae_amd.trainer import GraphedTrainStep
+        graphed = GraphedTrainStep(model, opt, warmup=3)
+        args.warmup = max(args.warmup, 5)          # 3 eager steps, the capture, one replay
+        args.no_alt = True
+        eager_step = step
+
+        def step():
+            return graphed(batch)
+
     def fence():
         if world > 1:
             torch.distributed.barrier()
@@ -268,6 +283,8 @@ def main():
     # One extra, identical step with HIP events recorded on the launch stream around every msn_sgemm call.
     # (towers one after the other for this step: with the light-curve tower on its own stream, as in the timed
     # steps, an event pair around a GEMM would also span whatever the other stream ran meanwhile)
+    if args.graphed:
+        step = eager_step                           # the instrumented roofline step below is an eager one
     ops.GEMM_PROFILE = []
     concurrent, model.concurrent_towers = getattr(model, "concurrent_towers", False), False
     try:    # this one step replays the side-stream towers on the caller's stream: autograd's stream-mismatch note is expected
@@ -346,6 +363,7 @@ def main():
                                     "symmetric InfoNCE with all-gathered global negatives, RAdam; full train step")
                        if args.workload == "vit_s8_lc" else WORKLOADS[args.workload] + " (non-headline configuration)",
                        "per_gpu_batch": b, "global_batch": b * world, "parallelism": f"dp{world}",
+                       "launch": "HIP graph replay" if args.graphed else "eager",
                        "loss": loss_value, "algorithmic_gflop_per_pair": flops_per_pair() / 1e9,
                        "model_tflops": pairs * flops_per_pair() / 1e12},
             "roofline": {"bound": "mfma", "kernel": GEMM_KERNEL_NAME[args.gemm_precision],

@@ -302,6 +302,11 @@ int msn_dwconv_bwd(const float* dpre, const float* x, const float* w, int B, int
  */
 int msn_radam_step(const void* table, int n_tensors, int64_t max_numel, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int64_t step, msn_stream_t stream);
+/* The same step for a training step recorded in a HIP graph: hyper[8] (device) = {lr, beta1, beta2, eps, weight_decay,
+ * -, -, -}, step_counter[1] (device int64: steps taken so far).  Every launch increments the counter and derives
+ * 1 / (1 - beta1^t) and the rectification term from it ON the device, so replays need no host write. */
+int msn_radam_step_dev(const void* table, int n_tensors, int64_t max_numel, float* hyper, long long* step_counter,
+                       msn_stream_t stream);
 
 /* Channels-last convolution plumbing for the build-defined ResNet-18 / 1-D CNN encoders (not in the
  * reference): cols[(b,oh,ow)][(c,u,v)] = x[b, oh*sh+u-ph, ow*sw+v-pw, c] (0 outside), column order equal to

@@ -17,8 +17,15 @@ struct RadamTensor {  // 5 x 8 bytes, uploaded by the host as int64 words
     int64_t n;
 };
 
+// hyper != NULL: the seven scalars come from device memory {lr, beta1, beta2, eps, weight_decay, inv_c1, rect_scale}
+// (a launch recorded in a HIP graph is replayed with the step-dependent values of the replay, not of the capture)
 __global__ void radam_kernel(const RadamTensor* __restrict__ table, float lr, float beta1, float beta2, float eps,
-                             float weight_decay, float inv_c1, float rect_scale /* rect * sqrt(c2), 0 = unrectified */) {
+                             float weight_decay, float inv_c1, float rect_scale /* rect * sqrt(c2), 0 = unrectified */,
+                             const float* __restrict__ hyper) {
+    if (hyper) {
+        lr = hyper[0], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], weight_decay = hyper[4], inv_c1 = hyper[5],
+        rect_scale = hyper[6];
+    }
     const RadamTensor t = table[blockIdx.y];
     const bool vec = ((reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(t.g) |
                        reinterpret_cast<uintptr_t>(t.m) | reinterpret_cast<uintptr_t>(t.v)) & 15) == 0;
@@ -63,7 +70,38 @@ extern "C" int msn_radam_step(const void* table, int n_tensors, int64_t max_nume
     const unsigned gx = (unsigned)std::min<int64_t>(cdiv(max_numel, 4 * 256), 1024);
     hipLaunchKernelGGL(radam_kernel, dim3(gx ? gx : 1, n_tensors), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const RadamTensor*>(table), lr, beta1, beta2, eps, weight_decay, (float)(1.0 / c1),
-                       (float)rect_scale);
+                       (float)rect_scale, static_cast<const float*>(nullptr));
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+// Step-dependent scalars computed ON the device from a device-resident step counter: a recorded launch needs no host
+// write between replays (a pinned-buffer refresh would race with the copy node of a replay still in flight).
+__global__ void radam_prepare_kernel(float* __restrict__ hyper, long long* __restrict__ step_counter) {
+    const long long step = ++step_counter[0];
+    const double b1 = hyper[1], b2 = hyper[2];
+    const double c1 = 1.0 - pow(b1, (double)step), c2 = 1.0 - pow(b2, (double)step);
+    const double rho_inf = 2.0 / (1.0 - b2) - 1.0;
+    const double rho_t = rho_inf - 2.0 * (double)step * pow(b2, (double)step) / c2;
+    double rect_scale = 0.0;
+    if (rho_t > 5.0)
+        rect_scale = sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t)) * sqrt(c2);
+    hyper[5] = (float)(1.0 / c1);
+    hyper[6] = (float)rect_scale;
+}
+
+// The same step for a training step recorded in a HIP graph: hyper[8] (device) = {lr, beta1, beta2, eps, weight_decay,
+// -, -, -} and step_counter[1] (device, the number of steps taken so far); every launch increments the counter and
+// derives 1 / (1 - beta1^t) and the rectification term from it on the device (same double-precision formulas).
+extern "C" int msn_radam_step_dev(const void* table, int n_tensors, int64_t max_numel, float* hyper,
+                                  long long* step_counter, msn_stream_t stream) {
+    MSN_REQUIRE(table && hyper && step_counter && n_tensors > 0 && n_tensors <= 65535 && max_numel > 0,
+                "msn_radam_step_dev: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(radam_prepare_kernel, dim3(1), dim3(1), 0, st, hyper, step_counter);
+    const unsigned gx = (unsigned)std::min<int64_t>(cdiv(max_numel, 4 * 256), 1024);
+    hipLaunchKernelGGL(radam_kernel, dim3(gx ? gx : 1, n_tensors), dim3(256), 0, st,
+                       static_cast<const RadamTensor*>(table), 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, hyper);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }

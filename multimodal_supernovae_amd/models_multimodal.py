@@ -149,7 +149,9 @@ class LightCurveImageCLIP(nn.Module):
 
     # -- logging stand-in for LightningModule.log: last value per key, readable by the trainer --
     def log(self, name, value, **kwargs):
-        self.logged[name] = value
+        # detached: a logged loss must not keep its autograd graph (and the AccumulateGrad nodes of every parameter,
+        # bound to the stream of that step) alive into the next step
+        self.logged[name] = value.detach() if torch.is_tensor(value) else value
 
     # -- forward: list of unit-norm embeddings in the FIXED order img, lc, sp, meta (ref :259-273) --
     # Towers are independent until the loss: every tower after the first is enqueued on its own HIP stream, so the

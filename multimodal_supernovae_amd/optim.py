@@ -32,8 +32,82 @@ class RAdam(torch.optim.Optimizer):
             slot[0] = torch.empty(max(n, 1024), dtype=torch.int64).pin_memory()
         return slot
 
+    # ---- HIP-graph capture (trainer.GraphedTrainStep) --------------------------------------------------------------
+    # Under stream capture the launch is recorded through msn_radam_step_dev: the descriptor table is copied by a copy
+    # node of the graph from a pinned buffer that never changes, the hyper-parameters sit in device memory, and the
+    # step-dependent terms are derived on the device from a device-resident step counter that every replay increments
+    # -- no host write between replays (it would race with a replay still in flight).
+    def _step_captured(self):
+        self._graph_launches = []
+        for group in self.param_groups:
+            items = []
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if len(st) == 0:
+                    raise _lib.MsnHipError("capture the training step after at least one eager optimizer step "
+                                           "(the moment buffers must exist)")
+                items.append((p, st))
+            if not items:
+                continue
+            steps = {int(st["step"]) for _, st in items}
+            if len(steps) != 1:
+                raise _lib.MsnHipError("graph capture needs one step count per parameter group")
+            dev = items[0][0].device
+            words, max_n = [], 0
+            for p, st in items:
+                if not p.grad.is_contiguous():
+                    raise _lib.MsnHipError("graph capture needs contiguous gradients")
+                words += [p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()]
+                max_n = max(max_n, p.numel())
+            hyper, counter, table_host = self._graph_buffers()
+            table_host = table_host[:len(words)]                      # pinned before the capture began
+            table_host.copy_(torch.tensor(words, dtype=torch.int64))
+            table = table_host.to(dev, non_blocking=True)             # a copy node of the graph (static content)
+            check(lib().msn_radam_step_dev(ptr(table), len(items), max_n, ptr(hyper), ptr(counter), stream_ptr()),
+                  "msn_radam_step_dev")
+            self._graph_launches.append((group, items, table_host, table, hyper, counter))
+
+    def graph_prepare(self):
+        """Call BEFORE the capture (eager): device copies of the hyper-parameters and of the step count per group."""
+        self._graph_ready = {}
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if len(self.state[p])]
+            if not ps:
+                continue
+            b1, b2 = group["betas"]
+            dev = ps[0].device
+            hyper = torch.tensor([group["lr"], b1, b2, group["eps"], group["weight_decay"], 0.0, 0.0, 0.0],
+                                 dtype=torch.float32, device=dev)
+            counter = torch.tensor([int(self.state[ps[0]]["step"])], dtype=torch.int64, device=dev)
+            table_host = torch.empty(5 * len(group["params"]), dtype=torch.int64).pin_memory()
+            self._graph_ready[gi] = (hyper, counter, table_host)
+        torch.cuda.synchronize()
+
+    def _graph_buffers(self):
+        ready = getattr(self, "_graph_ready", {})
+        if not ready:
+            raise _lib.MsnHipError("RAdam.graph_prepare() must run before the training step is captured")
+        return ready.pop(min(ready))
+
+    def graph_note_eager_step(self):
+        """An eager step() ran between two replays (a batch of another shape): advance the device counters with it."""
+        for _, _, _, _, _, counter in getattr(self, "_graph_launches", []):
+            counter.add_(1)
+
+    def graph_pre_replay(self):
+        """Keep the host-side step counts in line with the device counter a replay increments."""
+        for group, items, *_ in self._graph_launches:
+            step = int(items[0][1]["step"]) + 1
+            for _, st in items:
+                st["step"] = step
+
     @torch.no_grad()
     def step(self, closure=None):
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            self._step_captured()
+            return None
         loss = None
         if closure is not None:
             with torch.enable_grad():

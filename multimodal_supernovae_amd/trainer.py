@@ -27,12 +27,13 @@ def _to_device(batch, device):
 
 
 class Trainer:
-    def __init__(self, max_epochs=1, device=None, group=None, log_fn=None, sync_batchnorm=False):
+    def __init__(self, max_epochs=1, device=None, group=None, log_fn=None, sync_batchnorm=False, graphed_steps=False):
         self.max_epochs = max_epochs
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.group = group
         self.log_fn = log_fn
         self.sync_batchnorm = sync_batchnorm   # pl.Trainer(sync_batchnorm=...): batch statistics over all ranks
+        self.graphed_steps = graphed_steps     # single process: replay the training step as a HIP graph (GraphedTrainStep)
         self.history = {"train_loss": [], "val_loss": []}
         self.step_losses = []
         self.global_step = 0
@@ -44,12 +45,17 @@ class Trainer:
         optimizer = model.configure_optimizers()["optimizer"]
         self.optimizer = optimizer
         reducer = D.GradientReducer(model.parameters(), group=self.group)   # bucket all-reduces run under backward
+        graphed = GraphedTrainStep(model.train(), optimizer) if self.graphed_steps and D.world_size(self.group) == 1 else None
         for epoch in range(self.max_epochs):
             model.train()
             model.on_train_epoch_start()
             losses = []
             for batch_idx, batch in enumerate(train_dataloaders):
                 batch = _to_device(batch, self.device)
+                if graphed is not None:
+                    losses.append(graphed(batch).detach().clone())     # the graph's loss tensor is overwritten by the next replay
+                    self.global_step += 1
+                    continue
                 optimizer.zero_grad(set_to_none=True)
                 loss = model.training_step(batch, batch_idx)
                 loss.backward()
@@ -75,3 +81,81 @@ class Trainer:
                 self.log_fn(epoch, {k: v[-1] for k, v in self.history.items() if v})
         reducer.remove()
         return self
+
+
+class GraphedTrainStep:
+    """One training step (zero_grad -> training_step -> backward -> RAdam) recorded as a HIP graph and replayed.
+
+    The reference's own batch sizes (32 ... 256) leave the GPU waiting for the host: a Maven step issues ~1300 launches
+    and takes ~10 ms of host time whatever the batch, 1.5 ms of GPU time at batch 32.  The first `warmup` calls run
+    eagerly (they are real steps: moment buffers, allocator, code objects); the next call captures the step on the
+    caller's batch shapes and every later call copies its batch into the captured input tensors and replays.
+    Restrictions: fixed batch shapes, a single process (the gradient all-reduce is not captured), no dropout with
+    p > 0 in train mode (its seeds would be frozen into the graph).  The towers' side streams fork from and join the
+    capturing stream, so the graph keeps their concurrency.
+
+        step = GraphedTrainStep(model, model.configure_optimizers()["optimizer"])
+        for batch in loader: loss = step(batch)          # `loss` is a device tensor overwritten by the next call
+    """
+
+    def __init__(self, model, optimizer, warmup=3, concurrent_towers=None):
+        self.concurrent_towers = concurrent_towers      # None: as the model is set (towers fork / join inside the graph)
+        if D.world_size() > 1:
+            raise RuntimeError("GraphedTrainStep is single-process (the gradient all-reduce is not captured)")
+        for m in model.modules():
+            pd = getattr(m, "p", None) if isinstance(m, torch.nn.Dropout) else None
+            if model.training and pd:
+                raise RuntimeError("GraphedTrainStep: dropout p > 0 would replay one frozen mask")
+        self.model, self.optimizer, self.warmup = model, optimizer, int(warmup)
+        self.calls, self.graph, self.static, self.loss = 0, None, None, None
+
+    def _eager(self, batch):
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self.model.training_step(batch, 0)
+        loss.backward()
+        self.optimizer.step()
+        return loss
+
+    def _capture(self, batch):
+        model = self.model
+        self.static = tuple(t.clone() if torch.is_tensor(t) else t for t in batch)
+        concurrent = getattr(model, "concurrent_towers", False)
+        if self.concurrent_towers is not None:
+            model.concurrent_towers = bool(self.concurrent_towers)
+        self.graph = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad(set_to_none=True)
+        self.optimizer.graph_prepare()        # device copies of the hyper-parameters and the step count (eager)
+        import gc
+        gc.collect()                          # no autograd graph of an earlier step (bound to other streams) may survive
+        try:
+            with torch.cuda.graph(self.graph):
+                self.loss = model.training_step(self.static, 0)
+                self.loss.backward()
+                self.optimizer.step()
+        finally:
+            model.concurrent_towers = concurrent
+
+    def __call__(self, batch):
+        self.calls += 1
+        if self.graph is None:
+            if self.calls <= self.warmup:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):             # torch's rule: warm up off the stream that will capture
+                    loss = self._eager(batch)
+                torch.cuda.current_stream().wait_stream(side)
+                return loss
+            self._capture(batch)
+        same = len(batch) == len(self.static) and all(
+            (torch.is_tensor(d) and torch.is_tensor(s_) and d.shape == s_.shape) or (d is None and s_ is None)
+            for d, s_ in zip(self.static, batch))
+        if not same:                 # e.g. the short last batch of an epoch: one eager step, the graph stays valid
+            loss = self._eager(batch)
+            self.optimizer.graph_note_eager_step()
+            return loss
+        for dst, src in zip(self.static, batch):
+            if torch.is_tensor(dst):
+                dst.copy_(src, non_blocking=True)
+        self.optimizer.graph_pre_replay()
+        self.graph.replay()
+        return self.loss
