@@ -185,7 +185,8 @@ def _attn_forward_raw(x2, B, T, wq, wk, wv, wu, bu, mask_u8, heads, scale, resid
     M, e = x2.shape
     # the three bias-free projections read the same tokens: one product against the stacked (3e, e) weight
     # (a 3 x e x e copy per call) instead of three passes over x2
-    qkv = sgemm(x2, torch.cat([wq, wk, wv], 0), OP_N, OP_T)
+    wcat = torch.cat([wq, wk, wv], 0)                   # kept for backward (one copy per step, not two)
+    qkv = sgemm(x2, wcat, OP_N, OP_T)
     q3 = qkv.view(B, T, 3 * e)
     a, lse = ops.attention_fwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], mask_u8, heads, scale)
     a2 = a.view(M, e)
@@ -193,12 +194,12 @@ def _attn_forward_raw(x2, B, T, wq, wk, wv, wu, bu, mask_u8, heads, scale, resid
         z = sgemm(a2, wu, OP_N, OP_T, bias=bu, epilogue=EPI_ADD, aux=residual)
     else:
         z = sgemm(a2, wu, OP_N, OP_T, bias=bu)
-    return z, (qkv, a2, lse)
+    return z, (qkv, a2, lse, wcat)
 
 
 def _attn_backward_raw(dz, x2, B, T, saved, wq, wk, wv, wu, mask_u8, heads, scale, add_to):
     """dz: grad of unify output.  Returns dx (+ add_to fused) and the parameter grads."""
-    qkv, a2, lse = saved
+    qkv, a2, lse, wcat = saved
     M, e = x2.shape
     dwu, dbu = ops.wgrad_bias(dz, a2)
     da = sgemm(dz, wu, OP_N, OP_N)
@@ -207,7 +208,6 @@ def _attn_backward_raw(dz, x2, B, T, saved, wq, wk, wv, wu, mask_u8, heads, scal
     ops.attention_bwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], mask_u8, heads, scale, a2.view(B, T, e), lse,
                       da.view(B, T, e), d3[..., :e], d3[..., e:2 * e], d3[..., 2 * e:])
     dw = sgemm(dqkv, x2, OP_T, OP_N)                       # stacked (3e, e): rows = dWq | dWk | dWv
-    wcat = torch.cat([wq, wk, wv], 0)
     if add_to is not None:
         dx = sgemm(dqkv, wcat, OP_N, OP_N, epilogue=EPI_ADD, aux=add_to)
     else:
@@ -233,9 +233,9 @@ class _SelfAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         B, T, e, heads, scale = ctx.dims
-        x2, wq, wk, wv, wu, qkv, a2, lse = ctx.saved_tensors
+        x2, wq, wk, wv, wu, qkv, a2, lse, wcat = ctx.saved_tensors
         dz = _c(dy).view(B * T, e)
-        dx, dwq, dwk, dwv, dwu, dbu = _attn_backward_raw(dz, x2, B, T, (qkv, a2, lse), wq, wk, wv, wu, ctx.mask,
+        dx, dwq, dwk, dwv, dwu, dbu = _attn_backward_raw(dz, x2, B, T, (qkv, a2, lse, wcat), wq, wk, wv, wu, ctx.mask,
                                                          heads, scale, None)
         return dx.view(B, T, e), None, None, dwk, dwq, dwv, dwu, dbu
 
@@ -256,7 +256,7 @@ class _PostNormBlock(torch.autograd.Function):
         B, T, e = x.shape
         x2 = _c(x).view(B * T, e)
         scale = 1.0 / math.sqrt(e)
-        z1, (qkv, a2, lse) = _attn_forward_raw(x2, B, T, wq, wk, wv, wu, bu, mask_u8, heads, scale, x2)
+        z1, (qkv, a2, lse, wcat) = _attn_forward_raw(x2, B, T, wq, wk, wv, wu, bu, mask_u8, heads, scale, x2)
         y1, m1, r1 = ops.layernorm_fwd(z1, g1, b1)
         seeds = None
         if drop_p > 0.0:                 # x = do(norm1(...)) / x = do(norm2(...)), ref :111-116
@@ -270,13 +270,13 @@ class _PostNormBlock(torch.autograd.Function):
         ctx.drop = (drop_p, seeds)
         ctx.dims = (B, T, e, heads, scale)
         ctx.mask = mask_u8
-        ctx.save_for_backward(x2, wq, wk, wv, wu, g1, w1, w2, g2, qkv, a2, lse, z1, m1, r1, y1, hdn, z2, m2, r2)
+        ctx.save_for_backward(x2, wq, wk, wv, wu, g1, w1, w2, g2, qkv, a2, lse, z1, m1, r1, y1, hdn, z2, m2, r2, wcat)
         return y2.view(B, T, e)
 
     @staticmethod
     def backward(ctx, dy):
         B, T, e, heads, scale = ctx.dims
-        (x2, wq, wk, wv, wu, g1, w1, w2, g2, qkv, a2, lse, z1, m1, r1, y1, hdn, z2, m2, r2) = ctx.saved_tensors
+        (x2, wq, wk, wv, wu, g1, w1, w2, g2, qkv, a2, lse, z1, m1, r1, y1, hdn, z2, m2, r2, wcat) = ctx.saved_tensors
         dy2 = _c(dy).view(B * T, e)
         drop_p, seeds = ctx.drop
         if seeds:
@@ -289,7 +289,7 @@ class _PostNormBlock(torch.autograd.Function):
         if seeds:
             ops.dropout(dy1, drop_p, seeds[0], out=dy1)
         dz1, dg1, db1 = ops.layernorm_bwd(dy1, z1, m1, r1, g1)
-        dx, dwq, dwk, dwv, dwu, dbu = _attn_backward_raw(dz1, x2, B, T, (qkv, a2, lse), wq, wk, wv, wu, ctx.mask,
+        dx, dwq, dwk, dwv, dwu, dbu = _attn_backward_raw(dz1, x2, B, T, (qkv, a2, lse, wcat), wq, wk, wv, wu, ctx.mask,
                                                          heads, scale, dz1)  # + residual branch of LN1's input
         return (dx.view(B, T, e), None, None, None, dwk, dwq, dwv, dwu, dbu, dg1, db1, dw1, dc1, dw2, dc2, dg2, db2)
 
