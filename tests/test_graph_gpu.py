@@ -83,3 +83,21 @@ def test_graphed_step_with_an_odd_batch_in_between():
     torch.cuda.synchronize()
     for (k, p), (_, q) in zip(eager.named_parameters(), graphed.named_parameters()):
         torch.testing.assert_close(q, p, rtol=1e-5, atol=1e-7, msg=lambda m: f"{k}: {m}")
+
+
+def test_trainer_with_graphed_steps_matches_eager_trainer():
+    """Trainer(graphed_steps=True) over two epochs whose last batch is short == the eager Trainer (losses, parameters)."""
+    from multimodal_supernovae_amd.trainer import Trainer
+    combos = ["lightcurve", "spectral"]
+    batches = _batches(8, combos, 6)
+    batches[-1] = tuple(t[:3] if t is not None else None for t in batches[-1])
+    cpu = [tuple(t.cpu() if t is not None else None for t in b) for b in batches]
+    a, b = _model(combos), None
+    b = copy.deepcopy(a)
+    ta = Trainer(max_epochs=2).fit(a, cpu)
+    tb = Trainer(max_epochs=2, graphed_steps=True).fit(b, cpu)
+    torch.cuda.synchronize()
+    for x, y in zip(ta.history["train_loss"], tb.history["train_loss"]):
+        assert abs(x - y) <= 1e-5 * abs(x)
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        torch.testing.assert_close(q, p, rtol=1e-5, atol=1e-7, msg=lambda m: f"{k}: {m}")
