@@ -78,7 +78,7 @@ size_t msn_sgemm_workspace_bytes(int opA, int opB, int64_t M, int64_t N, int64_t
 /* Two fp32 kernel families sit behind msn_sgemm.
  *   mode 0: register-staged global->LDS copies with a distance-1 prefetch; takes every shape.
  *   mode 3 (default): LDS-DMA pipeline (global_load_lds, no staging registers, no ds_write), 4 waves per
- *           workgroup, 2 x 32-deep K ring, two workgroups per CU.  Used where it applies (N > 32, 16-B aligned
+ *           workgroup, 2 x 32-deep K ring, two workgroups per CU.  Used where it applies (16-B aligned
  *           operands, K % 32 == 0); other shapes take mode 0.
  *   mode 1 / 2: LDS-DMA with 8 waves per workgroup and a 3 x 32 / 2 x 64 deep ring (one workgroup per CU).
  * All modes give bit-identical results (same k order per accumulator).  Process-wide. */

@@ -881,7 +881,7 @@ static int sgemm_impl(int opA, int opB, int64_t M, int64_t N, int64_t K, const f
         bf16_ok = (ldb % 4 == 0) && (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
     // LDS-DMA kernels: every operand 16-B aligned with ld % 4 == 0 and extents % 4 == 0, whole K-steps only
     const int64_t a_ext = opA == MSN_OP_T ? M : K, b_ext = opB == MSN_OP_N ? N : K;
-    const bool dma_ok = g_gemm_variant != 0 && bn >= 64 && K % BK == 0 && kps % BK == 0 && (lda % 4 == 0) && (ldb % 4 == 0) &&
+    const bool dma_ok = g_gemm_variant != 0 && bn >= 32 && K % BK == 0 && kps % BK == 0 && (lda % 4 == 0) && (ldb % 4 == 0) &&
                         (a_ext % 4 == 0) && (b_ext % 4 == 0) && a_ext >= 4 && b_ext >= 4 &&
                         ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
     const bool fuse_colsum = colsum_out && !bf16_ok && dma_ok && opA == MSN_OP_T && opB == MSN_OP_N;
@@ -902,6 +902,7 @@ static int sgemm_impl(int opA, int opB, int64_t M, int64_t N, int64_t K, const f
     else if (dma_ok && bn == 128 && g_gemm_variant == 3) rc = launch_dma<128, 128, 64, 64, 32, 2>(a, opA, opB, st);
     else if (dma_ok && bn == 128 && g_gemm_variant < 3) rc = launch_dma<128, 128, 64, 32, 32, 3>(a, opA, opB, st), waves = 8;
     else if (dma_ok && bn == 64) rc = launch_dma<128, 64, 64, 32, 32, 3>(a, opA, opB, st);
+    else if (dma_ok && bn == 32) rc = launch_dma<128, 32, 32, 32, 32, 2>(a, opA, opB, st);
     else if (bn == 128) rc = launch_cfg<128, 128, 64, 64>(a, opA, opB, st);
     else if (bn == 64) rc = launch_cfg<128, 64, 64, 32>(a, opA, opB, st);
     else rc = launch_cfg<128, 32, 32, 32>(a, opA, opB, st);
