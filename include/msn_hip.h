@@ -338,6 +338,12 @@ int msn_maxpool2d_bwd(const float* dy, const int* argmax, int B, int H, int W, i
  * same call applied to the gradient reproduces the mask and nothing is stored.  In place allowed. */
 int msn_dropout(const float* x, int64_t n, float p, uint64_t seed, const float* residual, float* y,
                 msn_stream_t stream);
+/* For a training step recorded in a HIP graph: the seed is seed_base[0] (DEVICE memory) + seed_offset, and
+ * msn_seed_advance (one launch per recorded step) moves the base, so every replay draws new masks while a forward
+ * call and its backward twin (same offset) still agree. */
+int msn_dropout_dev(const float* x, int64_t n, float p, const uint64_t* seed_base, uint64_t seed_offset,
+                    const float* residual, float* y, msn_stream_t stream);
+int msn_seed_advance(uint64_t* seed_base, msn_stream_t stream);
 
 /* On-device form of NoisyDataLoader.__iter__ (src/dataloader.py:88-287), the step right before the path:
  *   images: out = rot90^{rot[b]}( img + (2 u - 1) * noise_level * std(img) )   (B, C, S, S), std = torch.std of the

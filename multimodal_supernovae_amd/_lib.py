@@ -60,6 +60,8 @@ SIGNATURES = {
     "msn_batchnorm_fwd": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_f32, c_int, c_f32, c_ptr, c_ptr, c_ptr, c_int,
                                   c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "msn_dropout": (c_int, [c_ptr, c_i64, c_f32, ctypes.c_uint64, c_ptr, c_ptr, c_ptr]),
+    "msn_dropout_dev": (c_int, [c_ptr, c_i64, c_f32, c_ptr, ctypes.c_uint64, c_ptr, c_ptr, c_ptr]),
+    "msn_seed_advance": (c_int, [c_ptr, c_ptr]),
     "msn_augment_workspace_bytes": (c_size, []),
     "msn_augment_images": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_f32, c_ptr, c_ptr, c_size, c_ptr]),
     "msn_augment_series": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_ptr, c_ptr]),

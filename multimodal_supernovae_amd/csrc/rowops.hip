@@ -568,8 +568,12 @@ __device__ __forceinline__ float keep_scale(uint64_t seed, int64_t i, float p, f
     const float u = (float)(x >> 40) * (1.f / 16777216.f);   // 24 random bits -> [0, 1)
     return u >= p ? inv_keep : 0.f;
 }
+// seed_base != NULL: the seed is seed_base[0] + seed (device-resident base: a launch recorded in a HIP graph draws a new
+// mask at every replay, msn_seed_advance moves the base once per step)
 __global__ void dropout_kernel(const float* __restrict__ x, int64_t n, float p, uint64_t seed,
-                               const float* __restrict__ res, float* __restrict__ y) {
+                               const uint64_t* __restrict__ seed_base, const float* __restrict__ res,
+                               float* __restrict__ y) {
+    if (seed_base) seed += seed_base[0];
     const float inv_keep = 1.f / (1.f - p);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float v = x[i] * keep_scale(seed, i, p, inv_keep);
@@ -827,7 +831,25 @@ extern "C" int msn_dropout(const float* x, int64_t n, float p, uint64_t seed, co
                            msn_stream_t stream) {
     MSN_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, "msn_dropout: bad arguments (p = %f)", (double)p);
     hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 8192)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), x, n, p, seed, residual, y);
+                       static_cast<hipStream_t>(stream), x, n, p, seed, static_cast<const uint64_t*>(nullptr), residual, y);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+// The same with the seed = seed_base[0] (device) + seed_offset: for a training step recorded in a HIP graph.
+extern "C" int msn_dropout_dev(const float* x, int64_t n, float p, const uint64_t* seed_base, uint64_t seed_offset,
+                               const float* residual, float* y, msn_stream_t stream) {
+    MSN_REQUIRE(x && y && seed_base && n > 0 && p >= 0.f && p < 1.f, "msn_dropout_dev: bad arguments (p = %f)", (double)p);
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 8192)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, n, p, seed_offset, seed_base, residual, y);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+__global__ void seed_advance_kernel(uint64_t* seed_base) { seed_base[0] = seed_base[0] * 6364136223846793005ull + 1442695040888963407ull; }
+// seed_base[0] <- next value of a 64-bit LCG: one launch per (recorded) training step
+extern "C" int msn_seed_advance(uint64_t* seed_base, msn_stream_t stream) {
+    MSN_REQUIRE(seed_base, "msn_seed_advance: null pointer");
+    hipLaunchKernelGGL(seed_advance_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), seed_base);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }

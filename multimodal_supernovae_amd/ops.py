@@ -524,14 +524,39 @@ def series_features(x, t, mask_u8, inv_norm):
 
 
 # --------------------------------------------------------------------------------------------- dropout
+# While a training step is being recorded as a HIP graph (trainer.GraphedTrainStep) seeds are TOKENS: a device-resident
+# base that msn_seed_advance moves once per replay + the ordinal of the dropout call inside the step.
+GRAPH_SEED = None           # [int64 device tensor of one element, next ordinal] during a capture
+
+
+class SeedToken:
+    __slots__ = ("base", "offset")
+
+    def __init__(self, base, offset):
+        self.base, self.offset = base, offset
+
+
 def new_seed():
-    """A fresh 63-bit dropout seed from torch's CPU generator (reproducible under torch.manual_seed)."""
+    """A fresh 63-bit dropout seed from torch's CPU generator (reproducible under torch.manual_seed); a SeedToken
+    while a step is being recorded."""
+    if GRAPH_SEED is not None:
+        tok = SeedToken(GRAPH_SEED[0], (GRAPH_SEED[1] * 0xD1B54A32D192ED03 + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
+        GRAPH_SEED[1] += 1
+        return tok
     return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+def graph_seed_advance():
+    check(lib().msn_seed_advance(ptr(GRAPH_SEED[0]), stream_ptr()), "msn_seed_advance")
 
 
 def dropout(x, p, seed, residual=None, out=None):
     """y = dropout(x) (+ residual); the same (p, seed) applied to a gradient reproduces the mask."""
     x = _f32c(x if x.is_contiguous() else x.contiguous(), "x")
     y = out if out is not None else torch.empty_like(x)
+    if isinstance(seed, SeedToken):
+        check(lib().msn_dropout_dev(ptr(x), x.numel(), float(p), ptr(seed.base), seed.offset, ptr(residual), ptr(y),
+                                    stream_ptr()), "msn_dropout_dev")
+        return y
     check(lib().msn_dropout(ptr(x), x.numel(), float(p), seed, ptr(residual), ptr(y), stream_ptr()), "msn_dropout")
     return y

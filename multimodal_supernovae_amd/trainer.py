@@ -90,9 +90,10 @@ class GraphedTrainStep:
     and takes ~10 ms of host time whatever the batch, 1.5 ms of GPU time at batch 32.  The first `warmup` calls run
     eagerly (they are real steps: moment buffers, allocator, code objects); the next call captures the step on the
     caller's batch shapes and every later call copies its batch into the captured input tensors and replays.
-    Restrictions: fixed batch shapes, a single process (the gradient all-reduce is not captured), no dropout with
-    p > 0 in train mode (its seeds would be frozen into the graph).  The towers' side streams fork from and join the
-    capturing stream, so the graph keeps their concurrency.
+    Restrictions: fixed batch shapes (others run eagerly), a single process (the gradient all-reduce is not captured).
+    Dropout seeds are device-resident inside the graph (a base that one launch per replay advances + the ordinal of
+    the call), so every replay draws new masks.  The towers' side streams fork from and join the capturing stream, so
+    the graph keeps their concurrency.
 
         step = GraphedTrainStep(model, model.configure_optimizers()["optimizer"])
         for batch in loader: loss = step(batch)          # `loss` is a device tensor overwritten by the next call
@@ -102,10 +103,6 @@ class GraphedTrainStep:
         self.concurrent_towers = concurrent_towers      # None: as the model is set (towers fork / join inside the graph)
         if D.world_size() > 1:
             raise RuntimeError("GraphedTrainStep is single-process (the gradient all-reduce is not captured)")
-        for m in model.modules():
-            pd = getattr(m, "p", None) if isinstance(m, torch.nn.Dropout) else None
-            if model.training and pd:
-                raise RuntimeError("GraphedTrainStep: dropout p > 0 would replay one frozen mask")
         self.model, self.optimizer, self.warmup = model, optimizer, int(warmup)
         self.calls, self.graph, self.static, self.loss = 0, None, None, None
 
@@ -127,13 +124,22 @@ class GraphedTrainStep:
         self.optimizer.graph_prepare()        # device copies of the hyper-parameters and the step count (eager)
         import gc
         gc.collect()                          # no autograd graph of an earlier step (bound to other streams) may survive
+        from . import ops
+        seed0 = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(self.static_device(), non_blocking=False)
+        ops.GRAPH_SEED = [seed0, 0]
+        self._seed_base = seed0
         try:
             with torch.cuda.graph(self.graph):
+                ops.graph_seed_advance()
                 self.loss = model.training_step(self.static, 0)
                 self.loss.backward()
                 self.optimizer.step()
         finally:
+            ops.GRAPH_SEED = None
             model.concurrent_towers = concurrent
+
+    def static_device(self):
+        return next(t.device for t in self.static if torch.is_tensor(t))
 
     def __call__(self, batch):
         self.calls += 1

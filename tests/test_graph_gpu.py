@@ -101,3 +101,34 @@ def test_trainer_with_graphed_steps_matches_eager_trainer():
         assert abs(x - y) <= 1e-5 * abs(x)
     for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
         torch.testing.assert_close(q, p, rtol=1e-5, atol=1e-7, msg=lambda m: f"{k}: {m}")
+
+
+def test_graphed_step_with_dropout_draws_new_masks_and_is_reproducible():
+    """Dropout inside the recorded step: device-resident seeds (a base advanced once per replay + the call's ordinal).
+    Replays on ONE batch at lr = 0 give different losses (new masks each time), and the whole sequence repeats exactly
+    under the same torch seed."""
+    from multimodal_supernovae_amd.models_multimodal import LightCurveImageCLIP
+    from multimodal_supernovae_amd.trainer import GraphedTrainStep
+    tk = dict(TK, dropout=0.3)
+    sk = dict(SK, dropout=0.3)
+    combos = ["lightcurve", "spectral"]
+    batch = _batches(8, combos, 1)[0]
+
+    def run():
+        torch.manual_seed(11)
+        m = LightCurveImageCLIP(enc_dim=16, nband=2, transformer_kwargs=tk, transformer_spectral_kwargs=sk, conv_kwargs=CK,
+                                combinations=combos, loss="softmax", lr=0.0).cuda().train()
+        step = GraphedTrainStep(m, m.configure_optimizers()["optimizer"], warmup=2)
+        out = [float(step(batch).detach()) for _ in range(7)]
+        assert step.graph is not None
+        g = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+        return out, g
+
+    a, ga = run()
+    b, gb = run()
+    assert a == b                                        # reproducible, replays included
+    replays = a[2:]
+    assert len({round(v, 6) for v in replays}) >= 5, replays      # new masks at every replay
+    assert all(torch.isfinite(torch.tensor(a)))
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]) and torch.isfinite(ga[k]).all(), k
