@@ -6,11 +6,15 @@ global negatives, backward, gradient all-reduce, fused RAdam) on synthetic data 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with no WORLD_SIZE in the environment starts the N ranks itself (N child processes, one
+per GPU, RCCL rendezvous on 127.0.0.1; the parent makes no GPU call and only relays rank 0's JSON line).
+
 Workload (BASELINE.json configs[2] towers; SURVEY.md section 8(d) "headline cfg3"): build-defined ViT-S/8
 image encoder on 64x64x3 cutouts + the reference light-curve TransformerWithTimeEmbeddings (T = 200 =
 2 bands x 100, emb 64, 8 heads, depth 5, mean pooling), n_out 32, enc_dim 128, fp32 (the reference
-precision).  Per-GPU batch 1024: at N = 1 that is the metric's "global batch 1024"; weak scaling keeps
-1024 rows per GPU and all-gathers the embeddings so every rank contrasts against all N * 1024 rows.
+precision).  The metric is quoted at GLOBAL batch 1024, so the headline `value` is strong scaling: every rank
+takes 1024 / N rows and all-gathers the embeddings so each rank contrasts its rows against all 1024.  The second
+field `weak_scaling_256_per_gpu` keeps 256 rows per GPU (global 256 * N: the north star's >= 6x target at 8 GPUs).
 """
 import argparse
 import json
@@ -138,15 +142,25 @@ def usable_cores(cap=32):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(sample_b, steps):
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sample_b, steps, budget_s=12.0):
     """The oracle (CPU restatement, parity-pinned against the reference) timed on this host's cores on a
-    bounded sample of the same workload: full train step incl. RAdam, `sample_b` pairs per step."""
+    bounded sample of the same workload: full train step incl. RAdam, `sample_b` pairs per step -- once on every
+    core this process owns and once on a single thread."""
     from oracle import clip as oclip
     from oracle.build_defined import vision_transformer
     from oracle import encoders as oenc
     from oracle import loss as oloss
     cores = usable_cores()
-    torch.set_num_threads(cores)
     model = build_model("cpu")
     P = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
     batch = synthetic_batch(sample_b, 4321, "cpu")
@@ -165,21 +179,59 @@ def cpu_baseline(sample_b, steps):
         opt.step()
         return float(loss.detach())
 
-    t0 = time.perf_counter()
-    step()                                  # first step also warms the allocator / thread pool
-    first = time.perf_counter() - t0
-    if first > 12.0:                        # keep the whole leg bounded (~10-30 s of CPU work)
-        steps, dt = 1, first
-    else:
-        if steps <= 0:                      # default: as many steps as fit in ~12 s, judged by the first one
-            steps = max(2, min(40, int(12.0 / max(first, 1e-3))))
+    def timed(threads, n_steps, budget):
+        torch.set_num_threads(threads)
         t0 = time.perf_counter()
-        for _ in range(steps):
+        step()                                  # first step also warms the allocator / thread pool
+        first = time.perf_counter() - t0
+        if first > budget:                      # keep the whole leg bounded
+            return 1, first
+        if n_steps <= 0:                        # default: as many steps as fit in the budget, judged by the first one
+            n_steps = max(2, min(40, int(budget / max(first, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
             step()
-        dt = (time.perf_counter() - t0) / steps
-    return {"value": sample_b / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} full train steps (fwd + InfoNCE + bwd + RAdam) of the same two-tower workload at batch "
-                      f"{sample_b} on {cores} host threads (torch {torch.__version__} CPU fp32), {dt:.2f} s/step"}
+        return n_steps, (time.perf_counter() - t0) / n_steps
+
+    n_all, dt_all = timed(cores, steps, budget_s)
+    n_one, dt_one = timed(1, 0, budget_s)
+    torch.set_num_threads(cores)
+    return {"value": sample_b / dt_all, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model_name(), "host_cpus": os.cpu_count(),
+            "single_thread": {"value": sample_b / dt_one, "unit": "pairs/s", "cores": 1, "steps": n_one,
+                              "s_per_step": dt_one},
+            "sample": f"{n_all} full train steps (fwd + InfoNCE + bwd + RAdam) of the same two-tower workload at batch "
+                      f"{sample_b} on {cores} host threads (torch {torch.__version__} CPU fp32), {dt_all:.2f} s/step; "
+                      f"single thread: {n_one} steps, {dt_one:.2f} s/step"}
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks as CHILD processes (fresh interpreters: nothing is
+    exec'ed over a process that has touched the GPU, and this parent never touches it -- torch.cuda.device_count() does
+    not initialise HIP), one per GPU, rendezvous on 127.0.0.1; relay rank 0's JSON line.  With fewer GPUs than ranks
+    (a one-GPU box rehearsing the flow) the ranks share devices round-robin over gloo: RCCL refuses two ranks on one
+    device."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    n_dev = torch.cuda.device_count()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if n_dev < n:
+            env.setdefault("MSN_DIST_BACKEND", "gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit(f"rank exit codes {codes}")
 
 
 def main():
@@ -187,10 +239,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--per-gpu-batch", type=int, default=1024)
-    ap.add_argument("--global-batch", type=int, default=0,
-                    help="strong scaling instead of the default weak scaling: fix the GLOBAL batch (e.g. 1024) and "
-                         "give each rank global / N rows")
+    ap.add_argument("--per-gpu-batch", type=int, default=0,
+                    help="weak scaling instead of the default: fix the rows PER GPU (global = N x this)")
+    ap.add_argument("--global-batch", type=int, default=1024,
+                    help="strong scaling (the default, the metric's definition): fix the GLOBAL batch and give each "
+                         "rank global / N rows")
+    ap.add_argument("--no-weak", action="store_true", help="skip the second measurement at 256 rows per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra split-bf16 measurement")
     ap.add_argument("--workload", default="vit_s8_lc", choices=list(WORKLOADS),
@@ -212,41 +266,52 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=0, help="timed oracle steps (0 = fill about 12 s)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, sys.argv[1:])
+
     from multimodal_supernovae_amd import _lib, distributed as D, ops
     _lib.require_gpu()
     ops.set_gemm_precision(args.gemm_precision)
     ops.set_gemm_variant(args.gemm_variant)
     rank, local, world = D.init_from_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     device = torch.device("cuda", local)
-    b = args.per_gpu_batch
-    if args.global_batch:
+    if args.per_gpu_batch:
+        b, scaling = args.per_gpu_batch, "weak"
+    else:
         if args.global_batch % world:
             raise SystemExit(f"--global-batch {args.global_batch} is not divisible by {world} ranks")
-        b = args.global_batch // world
-    if args.workload == "vit_s8_lc":
-        model = build_model(device)
-        batch = synthetic_batch(b, 1234 + rank, device)
-    else:
-        model, batch = build_workload(args.workload, b, 1234 + rank, device)
-        args.no_alt, args.no_cpu_baseline = True, True
+        b, scaling = args.global_batch // world, "strong"
+    headline = args.workload == "vit_s8_lc"
+    if not headline:
+        args.no_alt, args.no_cpu_baseline, args.no_weak = True, True, True
+
+    def make(rows):
+        if headline:
+            return build_model(device), synthetic_batch(rows, 1234 + rank, device)
+        return build_workload(args.workload, rows, 1234 + rank, device)
+
+    model, batch = make(b)
     if args.serial_towers:
         model.concurrent_towers = False
     D.broadcast_module(model)
     if args.sync_batchnorm and world > 1:
         D.enable_sync_batchnorm()
     opt = model.configure_optimizers()["optimizer"]
-    params = [p for p in model.parameters()]
-    reducer = D.GradientReducer(params)     # N > 1: bucketed SUM all-reduce launched from autograd hooks, under backward
+    reducer = D.GradientReducer(model.parameters())   # N > 1: bucketed SUM all-reduce launched from autograd hooks, under backward
 
-    def step():
-        opt.zero_grad(set_to_none=True)
-        loss = model.training_step(batch, 0)
-        loss.backward()
-        reducer.finish()
-        opt.step()
-        return loss
+    def make_step(model, opt, reducer, batch):
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = model.training_step(batch, 0)
+            loss.backward()
+            reducer.finish()
+            opt.step()
+            return loss
+        return step
+
+    step = make_step(model, opt, reducer, batch)
 
     if args.graphed:
         if world != 1:
@@ -265,19 +330,41 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        loss = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    dt = float(t)
-    loss_value = float(loss.detach())
+    def timed(fn, warmup, steps):
+        """W untimed steps, then EXACTLY `steps` steps between two (barrier + synchronize) fences; max over ranks."""
+        for _ in range(warmup):
+            loss = fn()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = fn()
+        fence()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        if world > 1:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t), float(loss.detach())
+
+    dt, loss_value = timed(step, args.warmup, args.steps)
+
+    # ---- communication of one step: every collective issued through distributed.py, timed on the compute stream ----
+    comm = {"backend": "rccl" if D.backend_name() == "nccl" else D.backend_name(), "ranks": world,
+            "rccl_ranks": torch.distributed.get_world_size() if world > 1 and D.backend_name() == "nccl" else None}
+    if world > 1 and not args.graphed:
+        D.COMM_LOG = []
+        step()
+        torch.cuda.synchronize()
+        log, D.COMM_LOG = D.COMM_LOG, None
+        per_kind = {}
+        for kind, nbytes, ev0, ev1 in log:
+            k = per_kind.setdefault(kind, {"calls": 0, "bytes": 0, "ms": 0.0})
+            k["calls"] += 1
+            k["bytes"] += nbytes
+            k["ms"] += ev0.elapsed_time(ev1) if ev0 is not None else 0.0
+        comm["per_step"] = per_kind
+        comm["all_gather_ms"] = sum(v["ms"] for k, v in per_kind.items() if "all_gather" in k)
+        comm["all_reduce_ms"] = sum(v["ms"] for k, v in per_kind.items() if "all_reduce" in k)
+        comm["note"] = ("ms = time the compute stream was held from issue to completion of the collective (HIP events "
+                        "on the issuing stream); the gradient all-reduce is issued from autograd hooks under backward")
 
     # ---- roofline of the dominant kernel (sgemm_kernel: every dense product of both towers) -----------
     # One extra, identical step with HIP events recorded on the launch stream around every msn_sgemm call.
@@ -296,7 +383,6 @@ def main():
     ops.GEMM_PROFILE = []
     step()
     torch.cuda.synchronize()
-    model.concurrent_towers = concurrent
     prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
     gemm_ms = sum(e[0].elapsed_time(e[1]) for e in prof)
     gemm_flops = sum(e[2] for e in prof)
@@ -307,6 +393,31 @@ def main():
     # dense matrix peak of the instruction the dominant kernel issues (MI355X_MICROARCH.md): fp32 157.3 TFLOP/s;
     # bf16 2500 TFLOP/s, of which the 3-product split can deliver at most a third as algorithmic flops
     peak = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}[args.gemm_precision]
+    if args.workload == "vit_b16_bf16_lc" and args.gemm_precision == "f32":
+        peak = 2500.0           # the image tower of cfg5 issues bf16 MFMAs whatever the process default is
+
+    # ---- per-tower split (serial order, HIP events): what each tower costs alone, and the serial step next to the
+    # concurrent one, so the gain of running the towers on separate streams can be read off the JSON
+    towers = None
+    if headline and not args.graphed:
+        serial_dt, _ = timed(step, 1, max(3, args.steps // 4))
+        towers = {"concurrent_streams_ms_per_step": dt / args.steps * 1e3,
+                  "serial_ms_per_step": serial_dt / max(3, args.steps // 4) * 1e3}
+        cot = torch.full((b, ENC_DIM), 1.0 / b, device=device)
+        for name, fn in (("image_tower_fwd_bwd_ms", lambda: model.image_embeddings_with_projection(batch[0])),
+                         ("lightcurve_tower_fwd_bwd_ms",
+                          lambda: model.lightcurve_embeddings_with_projection(batch[1], batch[2], batch[3]))):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            for it in range(3):
+                model.zero_grad(set_to_none=True)
+                if it == 1:
+                    ev[0].record()
+                fn().backward(cot)
+            ev[1].record()
+            torch.cuda.synchronize()
+            towers[name] = ev[0].elapsed_time(ev[1]) / 2
+        model.zero_grad(set_to_none=True)
+    model.concurrent_towers = concurrent
 
     if rank == 0 and args.gemm_table:
         table = {}
@@ -319,35 +430,46 @@ def main():
             print(f"# gemm opA={key[0]} opB={key[1]} M={key[2]:6d} N={key[3]:5d} K={key[4]:6d} epi={key[5]} calls={n:3d} "
                   f"{ms_:8.3f} ms {fl / ms_ / 1e9:7.1f} TFLOP/s", file=sys.stderr)
     # HBM-side traffic of the same kernel comes from separate rocprofv3 --pmc passes of this command
-    # (FETCH_SIZE, WRITE_SIZE; tools/summarize_pmc.py) -- counters cannot be read from inside the process.
-    traffic = None
+    # (FETCH_SIZE, WRITE_SIZE; tools/run_pmc.sh -> tools/summarize_pmc.py) -- counters cannot be read from inside the
+    # process, so the figure is the committed one and says which commit / date it was collected at.
+    traffic, traffic_source = None, None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_sgemm.json")))
-        if b == 1024 and world == 1:
+        if headline and b == 1024 and world == 1 and args.gemm_precision == "f32":
             traffic = pmc["traffic_bytes_per_launch"]
+            traffic_source = ("profiles/pmc_sgemm.json: rocprofv3 --pmc passes of `python bench.py` (tools/run_pmc.sh), "
+                              f"collected {pmc.get('collected', 'round 1')} at commit {pmc.get('commit', 'c778251')}; "
+                              "not re-measured inside this run")
     except (OSError, ValueError, KeyError):
         pass
 
     # ---- optional second measurement: the same step with the GEMMs on the bf16 matrix cores through the
     # 3-product split (fp32-grade: ~1e-5 relative per product).  Reported beside the headline, never as it.
     alt = None
-    if args.gemm_precision == "f32" and not args.no_alt:
+    if args.gemm_precision == "f32" and not args.no_alt and world == 1:
         ops.set_gemm_precision("bf16x3")
-        for _ in range(2):
-            alt_loss = step()
-        fence()
-        t1 = time.perf_counter()
         n_alt = max(3, args.steps // 2)
-        for _ in range(n_alt):
-            alt_loss = step()
-        fence()
-        dt_alt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
-        if world > 1:
-            torch.distributed.all_reduce(dt_alt, op=torch.distributed.ReduceOp.MAX)
+        dt_alt, _ = timed(step, 2, n_alt)
         ops.set_gemm_precision("f32")
         alt = {"gemm_precision": "bf16x3 (operands split hi+lo into bf16, 3 v_mfma_f32_32x32x16_bf16 products, fp32 accumulate)",
-               "value": b * world * n_alt / float(dt_alt), "unit": "pairs/s", "ms_per_step": float(dt_alt) / n_alt * 1e3,
+               "value": b * world * n_alt / dt_alt, "unit": "pairs/s", "ms_per_step": dt_alt / n_alt * 1e3,
                "steps": n_alt, "note": "opt-in (--gemm-precision bf16x3); the headline value above is exact fp32"}
+
+    # ---- second field: weak scaling at 256 rows per GPU (global 256 * N), same model family, fresh optimiser state
+    weak = None
+    if not args.no_weak and not args.graphed:
+        del step
+        reducer.remove()
+        model_w, batch_w = make(256)
+        D.broadcast_module(model_w)
+        opt_w = model_w.configure_optimizers()["optimizer"]
+        red_w = D.GradientReducer(model_w.parameters())
+        step_w = make_step(model_w, opt_w, red_w, batch_w)
+        dt_w, loss_w = timed(step_w, args.warmup, args.steps)
+        weak = {"value": 256 * world * args.steps / dt_w, "unit": "pairs/s", "per_gpu_batch": 256,
+                "global_batch": 256 * world, "ms_per_step": dt_w / args.steps * 1e3, "steps": args.steps,
+                "scaling": "weak", "loss": loss_w}
+        red_w.remove()
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -355,13 +477,13 @@ def main():
         out = {
             "metric": "contrastive pairs/sec (image+light-curve) at global batch 1024, 1/2/4/8 GPUs",
             "value": pairs, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak",
+            "ms_per_step": ms, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("ViT-S/8 image tower (64x64x3, build-defined) + reference light-curve "
                                     "transformer (T=200, emb 64, 8 heads, depth 5, 2 bands) -> enc_dim 128, "
                                     "symmetric InfoNCE with all-gathered global negatives, RAdam; full train step")
-                       if args.workload == "vit_s8_lc" else WORKLOADS[args.workload] + " (non-headline configuration)",
+                       if headline else WORKLOADS[args.workload] + " (non-headline configuration)",
                        "per_gpu_batch": b, "global_batch": b * world, "parallelism": f"dp{world}",
                        "launch": "HIP graph replay" if args.graphed else "eager",
                        "loss": loss_value, "algorithmic_gflop_per_pair": flops_per_pair() / 1e9,
@@ -369,10 +491,18 @@ def main():
             "roofline": {"bound": "mfma", "kernel": GEMM_KERNEL_NAME[args.gemm_precision],
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_unit": "bytes per launch (mean), 2 x FETCH_SIZE + WRITE_SIZE",
+                         "traffic_source": traffic_source,
                          "launches_per_step": len(prof), "ms_per_step_in_kernel": gemm_ms,
                          "algorithmic_gflop_per_step": gemm_flops / 1e9,
                          "algorithmic_bytes_per_launch": gemm_bytes / max(len(prof), 1)},
+            "comm": comm,
         }
+        if not headline:
+            out["config"].pop("algorithmic_gflop_per_pair"), out["config"].pop("model_tflops")
+        if weak is not None:
+            out["weak_scaling_256_per_gpu"] = weak
+        if towers is not None:
+            out["towers"] = towers
         if alt is not None:
             out["alt_split_bf16"] = alt
         if not args.no_cpu_baseline and world == 1:

@@ -122,7 +122,8 @@ int msn_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, float* out, vo
  *        and the upstream gradient `grad_out` (device scalar).  Writes dE1_loc, dE2_loc (the
  *        complete gradient of the global loss w.r.t. the local rows -- no reduce-scatter) and
  *        dscale_dbias[2] = this rank's share of d/dlog_scale and d/dbias (sum over ranks).
- * log_scale, bias, grad_out are DEVICE scalars (no host synchronisation).  D in {8,16,32,64,128}.
+ * log_scale, bias, grad_out are DEVICE scalars (no host synchronisation).  Any 1 <= D <= 256 (the reference takes
+ * any enc_dim, src/models_multimodal.py:101): tiles are 8/16/32/64/128/256 columns wide, zero beyond column D.
  */
 size_t msn_infonce_workspace_bytes(int b1, int b2, int n1, int n2, int D);
 int msn_infonce_fwd(const float* E1_loc, int64_t ld1, int b1, const float* E2_loc, int64_t ld2, int b2,

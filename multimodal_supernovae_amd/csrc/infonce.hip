@@ -12,16 +12,22 @@
 // per-query log-sum-exp; the backward recomputes S tiles from E and the (all-gathered) LSE vectors,
 // so dE of the local rows is complete on the owning rank and no reduce-scatter is needed.
 //
-// Kernel shape: workgroup = 4 waves, wave w owns the 32-query tile 128*blockIdx.x + 32*w for the
-// whole launch and keeps its Q fragments in registers; the workgroup sweeps its share of the keys
-// (blockIdx.y = key split) in 32-key tiles staged in LDS.  S^T tile = K_tile . Q_tile^T on the
-// f32 matrix cores (v_mfma_f32_32x32x2_f32), oriented so that the lane's column is the QUERY:
-// the softmax statistics of a query are then lane-local (16 registers = 16 keys per half-wave),
-// combined once at the end with one cross-half shuffle.  In the backward the G^T tile sitting in
-// the accumulator registers is directly the A operand of the second product dQ += G . K
-// (key index on the MFMA k axis), whose B operand is read from the same LDS key tile.
-// Partial results of the key splits go to caller scratch and are merged in a fixed order
-// (deterministic; no float atomics).
+// Kernel shape: a workgroup (4 waves) owns ONE 32-query tile (32 * blockIdx.x), keeps the Q fragments in registers, and
+// splits its share of the keys (blockIdx.y = key split) over its waves: wave w sweeps the 32-key tiles w, w + 4, ...
+// through its own LDS buffer (no workgroup barrier inside the sweep).  S^T tile = K_tile . Q_tile^T on the f32 matrix
+// cores (v_mfma_f32_32x32x2_f32), oriented so that the lane's column is the QUERY: the softmax statistics of a query
+// are then lane-local (16 registers = 16 keys per half-wave), combined once at the end with one cross-half shuffle and
+// across the four waves through LDS.  The positive S_ii is taken from the score tile that holds it (the same
+// accumulation the log-sum-exp sees), not recomputed.  In the backward the G^T tile sitting in the accumulator
+// registers is directly the A operand of the second product dQ += G . K (key index on the MFMA k axis), whose B operand
+// is read from the same LDS key tile; the four waves' dQ tiles are summed through LDS in a fixed order, so a key split
+// publishes ONE partial per query tile (a quarter of the slab traffic of a wave-per-query-tile layout) and with a
+// single key split the gradient is final.  Partial results of the key splits go to caller scratch and are merged in
+// a fixed order (deterministic; no float atomics, no zero-initialised scratch).
+//
+// Any embedding width 1 <= D <= 256 (the reference takes any enc_dim, src/models_multimodal.py:101): the tiles are
+// DP = 8 / 16 / 32 / 64 / 128 / 256 columns wide and columns D .. DP-1 are zero in LDS and in the Q fragments -- zero
+// columns change no inner product.
 #include <algorithm>
 #include <math.h>
 
@@ -31,9 +37,9 @@ namespace msn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int QT = 32;        // queries per wave
-constexpr int QB = 128;       // queries per workgroup
+constexpr int QT = 32;        // queries per workgroup
 constexpr int KT = 32;        // keys per tile
+constexpr int NW = 4;         // waves per workgroup, each sweeping its own key tiles
 constexpr int MODE_SOFTMAX = 0, MODE_SIGMOID = 1;
 
 struct Side {
@@ -50,57 +56,73 @@ struct NceArgs {
     Side side[2];
     const float* log_scale;  // device scalar (log of the logit scale)
     const float* bias;       // device scalar
+    const float* grad_out;   // bwd: device scalar
     int q_offset;            // global row id of local row 0
     int n_diag;              // n = min(N1, N2)
+    int D;                   // real embedding width (<= the kernel's DP)
     int ksplit, keys_per_split;
-    float* part_m;           // fwd scratch [2][ksplit][maxq]
+    float* part_m;           // fwd scratch [2][ksplit][maxq]: running max, sum, positive score of a key split
     float* part_l;
-    float* slab;             // bwd scratch [2][ksplit][maxq][D]
-    double* scal;            // bwd scratch [2 * gridDim.x * ksplit][2] : partial dscale, dbias; fwd sigmoid partial loss
+    float* part_d;
+    float* slab;             // bwd scratch [2][ksplit][maxq][D] (ksplit > 1 only)
+    double* scal;            // bwd scratch [qtiles * ksplit][2] : partial dscale, dbias; fwd sigmoid partial loss
     int maxq;
     int mode;
 };
 
 __device__ __forceinline__ int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// Stage one 32-key tile (rows k0..k0+31 of K, zero beyond nk) into LDS, row stride D + 4.
-template <int D>
-__device__ __forceinline__ void stage_keys(float* Ks, const float* __restrict__ K, int64_t ldk, int k0, int nk,
-                                           bool vec_ok) {
-    constexpr int KS = D + 4;
-    constexpr int PER_ROW = D / 4;
-    for (int idx = threadIdx.x; idx < KT * PER_ROW; idx += 256) {
+// A wave re-uses its LDS key buffer: LDS operations of one wave execute in order, this only pins the compiler.
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float4 load4_guarded(const float* p, int c0, int D, bool vec_ok) {
+    if (vec_ok && c0 + 3 < D) return *reinterpret_cast<const float4*>(p);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c0 < D) v.x = p[0];
+    if (c0 + 1 < D) v.y = p[1];
+    if (c0 + 2 < D) v.z = p[2];
+    if (c0 + 3 < D) v.w = p[3];
+    return v;
+}
+
+// One wave stages one 32-key tile (rows k0..k0+31 of K, zero beyond k_end and beyond column D) into ITS LDS buffer,
+// row stride DP + 4.
+template <int DP>
+__device__ __forceinline__ void stage_keys(float* Ks, const float* __restrict__ K, int64_t ldk, int k0, int k_end, int D,
+                                           bool vec_ok, int lane) {
+    constexpr int KS = DP + 4;
+    constexpr int PER_ROW = DP / 4;
+#pragma unroll
+    for (int j = 0; j < KT * PER_ROW / 64; ++j) {
+        const int idx = lane + 64 * j;
         const int r = idx / PER_ROW, q = idx % PER_ROW;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k0 + r < nk) {
-            const float* p = K + (int64_t)(k0 + r) * ldk + 4 * q;
-            if (vec_ok) v = *reinterpret_cast<const float4*>(p);
-            else v = make_float4(p[0], p[1], p[2], p[3]);
-        }
+        if (k0 + r < k_end) v = load4_guarded(K + (int64_t)(k0 + r) * ldk + 4 * q, 4 * q, D, vec_ok);
         *reinterpret_cast<float4*>(Ks + r * KS + 4 * q) = v;
     }
 }
 
-template <int D>
-__device__ __forceinline__ void load_q_frags(float4 (&qf)[D / 8], const float* __restrict__ Q, int64_t ldq,
-                                             int qrow, int h, bool vec_ok) {
+template <int DP>
+__device__ __forceinline__ void load_q_frags(float4 (&qf)[DP / 8], const float* __restrict__ Q, int64_t ldq,
+                                             int qrow, int h, int D, bool vec_ok) {
     const float* p = Q + (int64_t)qrow * ldq + 4 * h;
 #pragma unroll
-    for (int ko = 0; ko < D / 8; ++ko) {
-        if (vec_ok) qf[ko] = *reinterpret_cast<const float4*>(p + 8 * ko);
-        else qf[ko] = make_float4(p[8 * ko], p[8 * ko + 1], p[8 * ko + 2], p[8 * ko + 3]);
-    }
+    for (int ko = 0; ko < DP / 8; ++ko) qf[ko] = load4_guarded(p + 8 * ko, 8 * ko + 4 * h, D, vec_ok);
 }
 
 // acc[key][query] = sum_d K[key][d] * Q[query][d] for the staged tile; lane col = query (lane & 31).
-template <int D>
-__device__ __forceinline__ f32x16 score_tile(const float* Ks, const float4 (&qf)[D / 8], int l32, int h) {
-    constexpr int KS = D + 4;
+template <int DP>
+__device__ __forceinline__ f32x16 score_tile(const float* Ks, const float4 (&qf)[DP / 8], int l32, int h) {
+    constexpr int KS = DP + 4;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-    for (int ko = 0; ko < D / 8; ++ko) {
+    for (int ko = 0; ko < DP / 8; ++ko) {
         const float4 kf = *reinterpret_cast<const float4*>(Ks + l32 * KS + 8 * ko + 4 * h);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[ko].x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[ko].y, acc, 0, 0, 0);
@@ -110,36 +132,44 @@ __device__ __forceinline__ f32x16 score_tile(const float* Ks, const float4 (&qf)
     return acc;
 }
 
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
 // ------------------------------------------------------------------------------------------ forward
-template <int D>
+template <int DP>
 __global__ __launch_bounds__(256) void nce_fwd_kernel(const NceArgs p) {
-    __shared__ __attribute__((aligned(16))) float Ks[KT * (D + 4)];
+    constexpr int KS = DP + 4;
+    __shared__ __attribute__((aligned(16))) float lds[cmax(NW * KT * KS, 3 * NW * QT)];
+    __shared__ double dred[NW];
     const Side& sd = p.side[blockIdx.z];
-    const int qb0 = blockIdx.x * QB;
-    if (qb0 >= sd.nq) return;
+    const int qb0 = blockIdx.x * QT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l32 = lane & 31, h = lane >> 5;
-    const int q_local = qb0 + QT * wave + l32;
+    const bool sig = p.mode == MODE_SIGMOID;
+    if (qb0 >= sd.nq) {          // uniform per workgroup: the other direction has more query tiles
+        if (sig && threadIdx.x == 0) p.scal[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = 0.0;
+        return;
+    }
+    const int q_local = qb0 + l32;
     const bool q_ok = q_local < sd.nq;
+    const int q_glob = p.q_offset + q_local;
     const float scale = __expf(*p.log_scale), bias = *p.bias;
     const bool qvec = (sd.ldq % 4 == 0) && ((reinterpret_cast<uintptr_t>(sd.Q) & 15) == 0);
     const bool kvec = (sd.ldk % 4 == 0) && ((reinterpret_cast<uintptr_t>(sd.K) & 15) == 0);
 
-    float4 qf[D / 8];
-    load_q_frags<D>(qf, sd.Q, sd.ldq, q_ok ? q_local : sd.nq - 1, h, qvec);
+    float4 qf[DP / 8];
+    load_q_frags<DP>(qf, sd.Q, sd.ldq, q_ok ? q_local : sd.nq - 1, h, p.D, qvec);
+    float* Ks = lds + wave * (KT * KS);
 
     const int k_begin = blockIdx.y * p.keys_per_split;
     const int k_end = min(sd.nk, k_begin + p.keys_per_split);
-    if (p.mode == MODE_SIGMOID) {
+    if (sig) {
         // ref src/loss.py:68-83: Z = -(E2 . E1^T) s + b (fp32), then -log sigmoid(-z Z) = softplus(z Z) in fp64,
         // z = +1 on the diagonal and -1 elsewhere.  Only direction 0 accumulates (each (i, j) once).
-        __shared__ double dred[4];
         double part = 0.0;
-        const int q_glob = p.q_offset + q_local;
-        for (int k0 = k_begin; k0 < k_end; k0 += KT) {
-            __syncthreads();
-            stage_keys<D>(Ks, sd.K, sd.ldk, k0, k_end, kvec);
-            __syncthreads();
-            const f32x16 acc = score_tile<D>(Ks, qf, l32, h);
+        for (int k0 = k_begin + KT * wave; k0 < k_end; k0 += KT * NW) {
+            wave_fence();
+            stage_keys<DP>(Ks, sd.K, sd.ldk, k0, k_end, p.D, kvec, lane);
+            wave_fence();
+            const f32x16 acc = score_tile<DP>(Ks, qf, l32, h);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kj = k0 + row_of(r, h);
@@ -157,18 +187,20 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(const NceArgs p) {
         if (threadIdx.x == 0) p.scal[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (dred[0] + dred[1]) + (dred[2] + dred[3]);
         return;
     }
-    float m = -INFINITY, l = 0.f;
-    for (int k0 = k_begin; k0 < k_end; k0 += KT) {
-        __syncthreads();
-        stage_keys<D>(Ks, sd.K, sd.ldk, k0, k_end, kvec);
-        __syncthreads();
-        const f32x16 acc = score_tile<D>(Ks, qf, l32, h);
+    float m = -INFINITY, l = 0.f, dg = -INFINITY;
+    for (int k0 = k_begin + KT * wave; k0 < k_end; k0 += KT * NW) {
+        wave_fence();
+        stage_keys<DP>(Ks, sd.K, sd.ldk, k0, k_end, p.D, kvec, lane);
+        wave_fence();
+        const f32x16 acc = score_tile<DP>(Ks, qf, l32, h);
         float s[16];
         float tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = (k0 + row_of(r, h) < k_end) ? acc[r] * scale + bias : -INFINITY;
+            const int kj = k0 + row_of(r, h);
+            s[r] = (kj < k_end) ? acc[r] * scale + bias : -INFINITY;
             tmax = fmaxf(tmax, s[r]);
+            if (kj == q_glob) dg = s[r];          // the positive: key = the query's own global row
         }
         const float mn = fmaxf(m, tmax);
         if (mn > -INFINITY) {
@@ -179,35 +211,68 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(const NceArgs p) {
             m = mn;
         }
     }
-    // combine the two half-waves (keys were split between them), then publish this split's (m, l)
+    // combine the two half-waves (a tile's keys are split between them), then the four waves through LDS
     const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64);
     const float mm = fmaxf(m, m2);
     float ll = 0.f;
     if (mm > -INFINITY) ll = l * __expf(m - mm) + l2 * __expf(m2 - mm);
-    if (h == 0 && q_ok) {
-        const int64_t o = ((int64_t)blockIdx.z * p.ksplit + blockIdx.y) * p.maxq + q_local;
-        p.part_m[o] = mm;
-        p.part_l[o] = ll;
+    dg = fmaxf(dg, __shfl_xor(dg, 32, 64));
+    __syncthreads();                              // every wave is done with its key buffer
+    float* wm = lds;
+    float* wl = lds + NW * QT;
+    float* wd = lds + 2 * NW * QT;
+    if (h == 0) {
+        wm[wave * QT + l32] = mm;
+        wl[wave * QT + l32] = ll;
+        wd[wave * QT + l32] = dg;
+    }
+    __syncthreads();
+    if (threadIdx.x < QT && qb0 + threadIdx.x < sd.nq) {
+        const int t = threadIdx.x;
+        float M = -INFINITY, Dg = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            M = fmaxf(M, wm[w * QT + t]);
+            Dg = fmaxf(Dg, wd[w * QT + t]);
+        }
+        float L = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const float mw = wm[w * QT + t];
+            if (mw > -INFINITY) L += wl[w * QT + t] * __expf(mw - M);
+        }
+        const int64_t o = ((int64_t)blockIdx.z * p.ksplit + blockIdx.y) * p.maxq + qb0 + t;
+        p.part_m[o] = M;
+        p.part_l[o] = L;
+        p.part_d[o] = Dg;
     }
 }
 
-// Merge key splits -> LSE per local row and direction; diagonal; this rank's share of the loss.
-__global__ void nce_fwd_finish_kernel(const NceArgs p, float* __restrict__ lse_row, float* __restrict__ lse_col,
-                                      float* __restrict__ loss, int D) {
+// Merge key splits -> LSE per local row and direction; this rank's share of the loss.  One workgroup: a thread owns
+// local row i in BOTH directions (2 * ksplit (m, l) pairs and ksplit positives to read), then one block sum.
+__global__ __launch_bounds__(1024) void nce_fwd_finish_kernel(const NceArgs p, float* __restrict__ lse_row,
+                                                              float* __restrict__ lse_col, float* __restrict__ loss,
+                                                              int n_part) {
     __shared__ float red[16];
     if (p.mode == MODE_SIGMOID) {   // loss = sum of the block partials / bs^2 (mean over all bs x bs entries)
         if (threadIdx.x == 0) {
             double tot = 0.0;
-            for (int k = 0; k < D; ++k) tot += p.scal[k];       // D carries the number of partials here
+            for (int k = 0; k < n_part; ++k) tot += p.scal[k];
             *loss = (float)(tot / ((double)p.n_diag * (double)p.n_diag));
         }
         return;
     }
-    const float scale = __expf(*p.log_scale), bias = *p.bias;
     float* lse_out[2] = {lse_row, lse_col};
-    for (int dir = 0; dir < 2; ++dir) {
-        const int nq = p.side[dir].nq;
-        for (int i = threadIdx.x; i < nq; i += blockDim.x) {
+    // rows of S come from side[0].Q (E2), columns from side[1].Q (E1); local row i <-> global q_offset + i
+    const int nb = min(p.side[0].nq, p.side[1].nq);
+    const int nmax = max(p.side[0].nq, p.side[1].nq);
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nmax; i += blockDim.x) {
+        float lse[2] = {0.f, 0.f};
+        float diag = -INFINITY;
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            if (i >= p.side[dir].nq) continue;
             float M = -INFINITY;
             for (int s = 0; s < p.ksplit; ++s) M = fmaxf(M, p.part_m[((int64_t)dir * p.ksplit + s) * p.maxq + i]);
             float L = 0.f;
@@ -215,60 +280,48 @@ __global__ void nce_fwd_finish_kernel(const NceArgs p, float* __restrict__ lse_r
                 const int64_t o = ((int64_t)dir * p.ksplit + s) * p.maxq + i;
                 const float ms = p.part_m[o];
                 if (ms > -INFINITY) L += p.part_l[o] * __expf(ms - M);
+                if (dir == 0) diag = fmaxf(diag, p.part_d[o]);
             }
-            lse_out[dir][i] = M + __logf(L);
+            lse[dir] = M + __logf(L);
+            lse_out[dir][i] = lse[dir];
         }
-    }
-    __syncthreads();
-    // rows of S come from side[0].Q (E2), columns from side[1].Q (E1); local row i <-> global q_offset + i
-    const int nb = min(p.side[0].nq, p.side[1].nq);
-    // positives: 16 lanes per row, four rows per wave and iteration (coalesced reads of the two embeddings, a 4-step
-    // shuffle sum inside the lane group): a whole wave per row walked 64 dependent load + reduce rounds per wave
-    float acc = 0.f;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const int sub = lane >> 4, l16 = lane & 15;
-    for (int i0 = 4 * wave; i0 < nb; i0 += 4 * nwaves) {
-        const int i = i0 + sub;
-        const bool on = i < nb && p.q_offset + i < p.n_diag;
-        float dot = 0.f;
-        if (on) {
-            const float* a = p.side[0].Q + (int64_t)i * p.side[0].ldq;
-            const float* b = p.side[1].Q + (int64_t)i * p.side[1].ldq;
-            for (int d = l16; d < D; d += 16) dot = fmaf(a[d], b[d], dot);
-        }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
-        if (on && l16 == 0) acc += lse_row[i] + lse_col[i] - 2.f * (dot * scale + bias);
+        if (i < nb && p.q_offset + i < p.n_diag) acc += lse[0] + lse[1] - 2.f * diag;
     }
     const float tot = block_sum(acc, red);
     if (threadIdx.x == 0) *loss = tot / (2.f * (float)p.n_diag);
 }
 
 // ----------------------------------------------------------------------------------------- backward
-template <int D>
+template <int DP>
 __global__ __launch_bounds__(256) void nce_bwd_kernel(const NceArgs p) {
-    constexpr int KS = D + 4;
-    constexpr int DT = (D + 31) / 32;
-    __shared__ __attribute__((aligned(16))) float Ks[KT * KS];
-    __shared__ float lseK[KT];
+    constexpr int KS = DP + 4;
+    constexpr int DT = (DP + 31) / 32;
+    constexpr int DW = DT * 32;                 // columns of the dQ reduction image
+    __shared__ __attribute__((aligned(16))) float lds[cmax(NW * KT * KS, NW * QT * DW)];
+    __shared__ float lseK[NW][KT];
     __shared__ float red[8];
     const int dir = blockIdx.z;
     const Side& sd = p.side[dir];
-    const int qb0 = blockIdx.x * QB;
-    if (qb0 >= sd.nq) return;
+    const int qb0 = blockIdx.x * QT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l32 = lane & 31, h = lane >> 5;
-    const int q_local = qb0 + QT * wave + l32;
+    double* scal_out = p.scal + 2 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x);
+    if (qb0 >= sd.nq) {          // uniform per workgroup; direction 0 still owes its (zero) scalar partials
+        if (dir == 0 && threadIdx.x == 0) scal_out[0] = scal_out[1] = 0.0;
+        return;
+    }
+    const int q_local = qb0 + l32;
     const bool q_ok = q_local < sd.nq;
     const int q_glob = p.q_offset + q_local;
     const float scale = __expf(*p.log_scale), bias = *p.bias;
     const bool qvec = (sd.ldq % 4 == 0) && ((reinterpret_cast<uintptr_t>(sd.Q) & 15) == 0);
     const bool kvec = (sd.ldk % 4 == 0) && ((reinterpret_cast<uintptr_t>(sd.K) & 15) == 0);
 
-    float4 qf[D / 8];
-    load_q_frags<D>(qf, sd.Q, sd.ldq, q_ok ? q_local : sd.nq - 1, h, qvec);
+    float4 qf[DP / 8];
+    load_q_frags<DP>(qf, sd.Q, sd.ldq, q_ok ? q_local : sd.nq - 1, h, p.D, qvec);
     const bool sig = p.mode == MODE_SIGMOID;
     const bool q_in = q_ok && q_glob < p.n_diag;
     const float lq = (q_in && !sig) ? sd.lse_q[q_glob] : 0.f;
+    float* Ks = lds + wave * (KT * KS);
 
     f32x16 dq[DT];
 #pragma unroll
@@ -279,15 +332,15 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(const NceArgs p) {
 
     const int k_begin = blockIdx.y * p.keys_per_split;
     const int k_end = min(sd.nk, k_begin + p.keys_per_split);
-    for (int k0 = k_begin; k0 < k_end; k0 += KT) {
-        __syncthreads();
-        stage_keys<D>(Ks, sd.K, sd.ldk, k0, k_end, kvec);
-        if (threadIdx.x < KT) {
-            const int kj = k0 + threadIdx.x;
-            lseK[threadIdx.x] = (!sig && kj < k_end && kj < p.n_diag) ? sd.lse_k[kj] : INFINITY;
+    for (int k0 = k_begin + KT * wave; k0 < k_end; k0 += KT * NW) {
+        wave_fence();
+        stage_keys<DP>(Ks, sd.K, sd.ldk, k0, k_end, p.D, kvec, lane);
+        if (lane < KT) {
+            const int kj = k0 + lane;
+            lseK[wave][lane] = (!sig && kj < k_end && kj < p.n_diag) ? sd.lse_k[kj] : INFINITY;
         }
-        __syncthreads();
-        f32x16 g = score_tile<D>(Ks, qf, l32, h);
+        wave_fence();
+        f32x16 g = score_tile<DP>(Ks, qf, l32, h);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int kr = row_of(r, h);
@@ -304,7 +357,7 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(const NceArgs p) {
                 S = g[r] * scale + bias;
                 if (q_ok && kj < k_end) {
                     if (q_in) G += __expf(S - lq);
-                    G += __expf(S - lseK[kr]);  // lseK = +inf for keys outside the diagonal range -> 0
+                    G += __expf(S - lseK[wave][kr]);  // lseK = +inf for keys outside the diagonal range -> 0
                     if (q_in && kj == q_glob) G -= 2.f;
                 }
             }
@@ -320,50 +373,61 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(const NceArgs p) {
 #pragma unroll
             for (int t = 0; t < DT; ++t) {
                 const int d = 32 * t + l32;
-                const float bv = (D % 32 == 0 || d < D) ? krow[d] : 0.f;
+                const float bv = (DP % 32 == 0 || d < DP) ? krow[d] : 0.f;
                 dq[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[r], bv, dq[t], 0, 0, 0);
             }
         }
     }
-    // partial dQ of this key split -> slab[dir][split][q][D]  (C layout: col = d, rows = queries)
-    float* slab = p.slab + (((int64_t)dir * p.ksplit + blockIdx.y) * p.maxq) * D;
+    // the four waves' partial dQ tiles -> LDS [wave][query][DW] (C layout: col = d on the lane, rows = queries), summed
+    // in wave order; with a single key split the sum is the gradient, otherwise this split's slab
+    __syncthreads();
+    float* R = lds + wave * (QT * DW);
 #pragma unroll
-    for (int t = 0; t < DT; ++t) {
-        const int d = 32 * t + l32;
-        if (D % 32 != 0 && d >= D) continue;
+    for (int t = 0; t < DT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int q = qb0 + QT * wave + row_of(r, h);
-            if (q < sd.nq) slab[(int64_t)q * D + d] = dq[t][r];
-        }
+        for (int r = 0; r < 16; ++r) R[row_of(r, h) * DW + 32 * t + l32] = dq[t][r];
+    __syncthreads();
+    const bool final_pass = p.ksplit == 1;
+    // softmax: G carries 1/(2n) and dS/dx = +s ; sigmoid: G carries 1/bs^2 and dZ/dx = -s
+    const float gsc = sig ? -*p.grad_out / ((float)p.n_diag * (float)p.n_diag) : *p.grad_out / (2.f * (float)p.n_diag);
+    const float f = gsc * scale;
+    float* slab = p.slab + (((int64_t)dir * p.ksplit + blockIdx.y) * p.maxq) * p.D;
+    for (int idx = threadIdx.x; idx < QT * DW; idx += 256) {
+        const int q = idx / DW, d = idx % DW;
+        if (d >= p.D || qb0 + q >= sd.nq) continue;
+        float s = lds[idx];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) s += lds[w * (QT * DW) + idx];
+        if (final_pass) sd.dQ[(int64_t)(qb0 + q) * sd.ldd + d] = f * s;
+        else slab[(int64_t)(qb0 + q) * p.D + d] = s;
     }
     // scalar partials (direction 0 covers every (i, j) exactly once)
     if (dir == 0) {
         const float s1 = block_sum(ds, red);
         const float s2 = block_sum(db, red);
         if (threadIdx.x == 0) {
-            double* o = p.scal + 2 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x);
-            o[0] = (double)s1;
-            o[1] = (double)s2;
+            scal_out[0] = (double)s1;
+            scal_out[1] = (double)s2;
         }
     }
 }
 
-// dQ = grad_out * s / (2n) * sum_split slab ; dscale/dbias = grad_out / (2n) * sum partials
-__global__ void nce_bwd_finish_kernel(const NceArgs p, const float* __restrict__ grad_out, int D, int n_scal,
-                                      float* __restrict__ dscal_out) {
-    // softmax: G carries 1/(2n) and dS/dx = +s ; sigmoid: G carries 1/bs^2 and dZ/dx = -s
-    const float g = p.mode == MODE_SIGMOID ? *grad_out / ((float)p.n_diag * (float)p.n_diag)
-                                           : *grad_out / (2.f * (float)p.n_diag);
+// dQ = grad_out * s / (2n) * sum_split slab (ksplit > 1) ; dscale/dbias = grad_out / (2n) * sum partials
+__global__ void nce_bwd_finish_kernel(const NceArgs p, int n_scal, float* __restrict__ dscal_out) {
+    const float g = p.mode == MODE_SIGMOID ? *p.grad_out / ((float)p.n_diag * (float)p.n_diag)
+                                           : *p.grad_out / (2.f * (float)p.n_diag);
     const float f = (p.mode == MODE_SIGMOID ? -g : g) * __expf(*p.log_scale);
-    for (int dir = 0; dir < 2; ++dir) {
-        const Side& sd = p.side[dir];
-        const int64_t total = (int64_t)sd.nq * D;
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-             i += (int64_t)gridDim.x * blockDim.x) {
-            float s = 0.f;
-            for (int k = 0; k < p.ksplit; ++k) s += p.slab[(((int64_t)dir * p.ksplit + k) * p.maxq) * D + i];
-            sd.dQ[(i / D) * sd.ldd + (i % D)] = f * s;
+    const int D = p.D;
+    if (p.ksplit > 1) {
+        for (int dir = 0; dir < 2; ++dir) {
+            const Side& sd = p.side[dir];
+            const int64_t total = (int64_t)sd.nq * D;
+            for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+                 i += (int64_t)gridDim.x * blockDim.x) {
+                float s = 0.f;
+                for (int k = 0; k < p.ksplit; ++k) s += p.slab[(((int64_t)dir * p.ksplit + k) * p.maxq) * D + i];
+                sd.dQ[(i / D) * sd.ldd + (i % D)] = f * s;
+            }
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < 2 && dscal_out) {
@@ -377,44 +441,44 @@ __global__ void nce_bwd_finish_kernel(const NceArgs p, const float* __restrict__
 // rank[i] = #{ j != i : <E2_i, E1_j> > <E2_i, E1_i> }  -- the position of the true partner in the
 // similarity ranking, ref src/utils.py:380-411 (get_ROC_data sorts every row on the host in a Python
 // loop).  Same tile machinery: the diagonal score is taken from the SAME MFMA accumulation as the scores
-// it is compared with (first pass over the wave's own 32-key tile), then the key split is swept.
-template <int D>
+// it is compared with (a first pass of every wave over the tile of the workgroup's own partners), then the key split
+// is swept.
+template <int DP>
 __global__ __launch_bounds__(256) void nce_rank_kernel(const NceArgs p, int* __restrict__ part_cnt) {
-    __shared__ __attribute__((aligned(16))) float Ks[KT * (D + 4)];
+    constexpr int KS = DP + 4;
+    __shared__ __attribute__((aligned(16))) float lds[NW * KT * KS];
+    __shared__ int wc[NW][QT];
     const Side& sd = p.side[0];
-    const int qb0 = blockIdx.x * QB;
+    const int qb0 = blockIdx.x * QT;
     if (qb0 >= sd.nq) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l32 = lane & 31, h = lane >> 5;
-    const int q_local = qb0 + QT * wave + l32;
+    const int q_local = qb0 + l32;
     const bool q_ok = q_local < sd.nq;
     const bool qvec = (sd.ldq % 4 == 0) && ((reinterpret_cast<uintptr_t>(sd.Q) & 15) == 0);
     const bool kvec = (sd.ldk % 4 == 0) && ((reinterpret_cast<uintptr_t>(sd.K) & 15) == 0);
-    float4 qf[D / 8];
-    load_q_frags<D>(qf, sd.Q, sd.ldq, q_ok ? q_local : sd.nq - 1, h, qvec);
+    float4 qf[DP / 8];
+    load_q_frags<DP>(qf, sd.Q, sd.ldq, q_ok ? q_local : sd.nq - 1, h, p.D, qvec);
+    float* Ks = lds + wave * (KT * KS);
 
     float diag = -INFINITY;
-    for (int w = 0; w < 4; ++w) {          // the key tile holding wave w's own partners
-        const int k0 = qb0 + QT * w;
-        __syncthreads();
-        stage_keys<D>(Ks, sd.K, sd.ldk, k0, sd.nk, kvec);
-        __syncthreads();
-        const f32x16 acc = score_tile<D>(Ks, qf, l32, h);
-        if (w == wave) {
+    {
+        stage_keys<DP>(Ks, sd.K, sd.ldk, qb0, sd.nk, p.D, kvec, lane);
+        wave_fence();
+        const f32x16 acc = score_tile<DP>(Ks, qf, l32, h);
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (row_of(r, h) == l32) diag = acc[r];
-        }
+        for (int r = 0; r < 16; ++r)
+            if (row_of(r, h) == l32) diag = acc[r];
     }
     diag = fmaxf(diag, __shfl_xor(diag, 32, 64));
 
     const int k_begin = blockIdx.y * p.keys_per_split;
     const int k_end = min(sd.nk, k_begin + p.keys_per_split);
     int cnt = 0;
-    for (int k0 = k_begin; k0 < k_end; k0 += KT) {
-        __syncthreads();
-        stage_keys<D>(Ks, sd.K, sd.ldk, k0, k_end, kvec);
-        __syncthreads();
-        const f32x16 acc = score_tile<D>(Ks, qf, l32, h);
+    for (int k0 = k_begin + KT * wave; k0 < k_end; k0 += KT * NW) {
+        wave_fence();
+        stage_keys<DP>(Ks, sd.K, sd.ldk, k0, k_end, p.D, kvec, lane);
+        wave_fence();
+        const f32x16 acc = score_tile<DP>(Ks, qf, l32, h);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int kj = k0 + row_of(r, h);
@@ -422,7 +486,11 @@ __global__ __launch_bounds__(256) void nce_rank_kernel(const NceArgs p, int* __r
         }
     }
     cnt += __shfl_xor(cnt, 32, 64);
-    if (h == 0 && q_ok) part_cnt[(int64_t)blockIdx.y * p.maxq + q_local] = cnt;
+    if (h == 0) wc[wave][l32] = cnt;
+    __syncthreads();
+    if (threadIdx.x < QT && qb0 + threadIdx.x < sd.nq)
+        part_cnt[(int64_t)blockIdx.y * p.maxq + qb0 + threadIdx.x] =
+            (wc[0][threadIdx.x] + wc[1][threadIdx.x]) + (wc[2][threadIdx.x] + wc[3][threadIdx.x]);
 }
 __global__ void nce_rank_finish_kernel(const int* __restrict__ part_cnt, int ksplit, int maxq, int n, int* __restrict__ rank) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -432,53 +500,49 @@ __global__ void nce_rank_finish_kernel(const int* __restrict__ part_cnt, int ksp
     rank[i] = s;
 }
 
-static int pick_ksplit(int maxq, int maxk) {
-    const int qblocks = (int)cdiv(maxq, QB);
-    int ks = std::max(1, 512 / (2 * qblocks));
-    ks = std::min(ks, (int)cdiv(maxk, KT));
-    ks = std::min(ks, 64);
-    return std::max(ks, 1);
-}
-
 struct Plan {
-    int ksplit, keys_per_split, maxq, qblocks;
-    size_t off_m, off_l, off_slab, off_scal, total;
+    int ksplit, keys_per_split, maxq, qtiles;
+    size_t off_m, off_l, off_d, off_slab, off_scal, total;
 };
 
+// Enough workgroups to fill the chip's 512 slots (two directions x query tiles x key splits); a key split is a whole
+// number of 4-tile rounds so that the four waves of a workgroup carry equal shares.
 static Plan make_plan(int b1, int b2, int n1, int n2, int D) {
     Plan pl;
     pl.maxq = std::max(b1, b2);
     const int maxk = std::max(n1, n2);
-    pl.qblocks = (int)cdiv(pl.maxq, QB);
-    pl.ksplit = pick_ksplit(pl.maxq, maxk);
-    pl.keys_per_split = (int)(cdiv(cdiv(maxk, pl.ksplit), KT) * KT);
+    pl.qtiles = (int)cdiv(pl.maxq, QT);
+    int ks = std::max(1, 512 / (2 * pl.qtiles));
+    ks = std::min(ks, (int)cdiv(maxk, KT * NW));
+    ks = std::max(std::min(ks, 64), 1);
+    pl.keys_per_split = (int)(cdiv(cdiv(maxk, ks), KT * NW) * KT * NW);
     pl.ksplit = (int)cdiv(maxk, pl.keys_per_split);
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
     pl.off_m = take(sizeof(float) * 2 * pl.ksplit * (size_t)pl.maxq);
     pl.off_l = take(sizeof(float) * 2 * pl.ksplit * (size_t)pl.maxq);
+    pl.off_d = take(sizeof(float) * 2 * pl.ksplit * (size_t)pl.maxq);
     pl.off_slab = take(sizeof(float) * 2 * pl.ksplit * (size_t)pl.maxq * D);
-    pl.off_scal = take(sizeof(double) * 2 * (size_t)pl.ksplit * pl.qblocks);
+    pl.off_scal = take(sizeof(double) * 2 * (size_t)pl.ksplit * pl.qtiles);
     pl.total = o;
     return pl;
 }
 
 static int check_common(const char* who, int b1, int b2, int n1, int n2, int D, int q_offset) {
-    MSN_REQUIRE(D == 8 || D == 16 || D == 32 || D == 64 || D == 128,
-                "%s: embedding width D=%d unsupported (8, 16, 32, 64 or 128)", who, D);
+    MSN_REQUIRE(D >= 1 && D <= 256, "%s: embedding width D=%d unsupported (1 <= D <= 256)", who, D);
     MSN_REQUIRE(b1 > 0 && b2 > 0 && n1 >= b1 && n2 >= b2 && q_offset >= 0, "%s: bad row counts b1=%d b2=%d N1=%d N2=%d",
                 who, b1, b2, n1, n2);
     return MSN_OK;
 }
 
+// tile width DP = D rounded up to 8 / 16 / 32 / 64 / 128 / 256
 #define MSN_NCE_DISPATCH(KERNEL, ...)                                                        \
-    switch (D) {                                                                             \
-        case 8: hipLaunchKernelGGL((KERNEL<8>), __VA_ARGS__); break;                         \
-        case 16: hipLaunchKernelGGL((KERNEL<16>), __VA_ARGS__); break;                       \
-        case 32: hipLaunchKernelGGL((KERNEL<32>), __VA_ARGS__); break;                       \
-        case 64: hipLaunchKernelGGL((KERNEL<64>), __VA_ARGS__); break;                       \
-        default: hipLaunchKernelGGL((KERNEL<128>), __VA_ARGS__); break;                      \
-    }
+    if (D <= 8) hipLaunchKernelGGL((KERNEL<8>), __VA_ARGS__);                                \
+    else if (D <= 16) hipLaunchKernelGGL((KERNEL<16>), __VA_ARGS__);                         \
+    else if (D <= 32) hipLaunchKernelGGL((KERNEL<32>), __VA_ARGS__);                         \
+    else if (D <= 64) hipLaunchKernelGGL((KERNEL<64>), __VA_ARGS__);                         \
+    else if (D <= 128) hipLaunchKernelGGL((KERNEL<128>), __VA_ARGS__);                       \
+    else hipLaunchKernelGGL((KERNEL<256>), __VA_ARGS__);
 
 }  // namespace msn
 
@@ -523,19 +587,20 @@ static int infonce_fwd_impl(int mode, const float* E1_loc, int64_t ld1, int b1, 
     NceArgs a = {};
     a.side[0] = Side{E2_loc, E1_all, nullptr, nullptr, nullptr, ld2, ld1a, 0, b2, n1};
     a.side[1] = Side{E1_loc, E2_all, nullptr, nullptr, nullptr, ld1, ld2a, 0, b1, n2};
-    a.log_scale = log_scale; a.bias = bias; a.q_offset = q_offset; a.n_diag = std::min(n1, n2);
+    a.log_scale = log_scale; a.bias = bias; a.q_offset = q_offset; a.n_diag = std::min(n1, n2); a.D = D;
     a.ksplit = pl.ksplit; a.keys_per_split = pl.keys_per_split; a.maxq = pl.maxq; a.mode = mode;
     char* w = static_cast<char*>(ws);
     a.part_m = reinterpret_cast<float*>(w + pl.off_m);
     a.part_l = reinterpret_cast<float*>(w + pl.off_l);
+    a.part_d = reinterpret_cast<float*>(w + pl.off_d);
     a.scal = reinterpret_cast<double*>(w + pl.off_scal);
     hipStream_t st = static_cast<hipStream_t>(stream);
     // the sigmoid loss sums each (i, j) once: direction 0 only
-    const dim3 grid(pl.qblocks, pl.ksplit, mode == MODE_SIGMOID ? 1 : 2), block(256);
+    const dim3 grid(pl.qtiles, pl.ksplit, mode == MODE_SIGMOID ? 1 : 2), block(256);
     MSN_NCE_DISPATCH(nce_fwd_kernel, grid, block, 0, st, a)
     MSN_LAUNCH_CHECK();
     hipLaunchKernelGGL(nce_fwd_finish_kernel, dim3(1), dim3(1024), 0, st, a, lse_row, lse_col, loss,
-                       mode == MODE_SIGMOID ? pl.qblocks * pl.ksplit : D);
+                       pl.qtiles * pl.ksplit);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }
@@ -586,24 +651,19 @@ static int infonce_bwd_impl(int mode, const float* E1_loc, int64_t ld1, int b1, 
     // direction 0: queries = rows of S (E2), own LSE = row LSE, keys = E1 with the column LSE
     a.side[0] = Side{E2_loc, E1_all, lse_row_all, lse_col_all, dE2_loc, ld2, ld1a, ldd2, b2, n1};
     a.side[1] = Side{E1_loc, E2_all, lse_col_all, lse_row_all, dE1_loc, ld1, ld2a, ldd1, b1, n2};
-    a.log_scale = log_scale; a.bias = bias; a.q_offset = q_offset; a.n_diag = std::min(n1, n2);
-    a.ksplit = pl.ksplit; a.keys_per_split = pl.keys_per_split; a.maxq = pl.maxq; a.mode = mode;
+    a.log_scale = log_scale; a.bias = bias; a.grad_out = grad_out; a.q_offset = q_offset; a.n_diag = std::min(n1, n2);
+    a.D = D; a.ksplit = pl.ksplit; a.keys_per_split = pl.keys_per_split; a.maxq = pl.maxq; a.mode = mode;
     char* w = static_cast<char*>(ws);
     a.slab = reinterpret_cast<float*>(w + pl.off_slab);
     a.scal = reinterpret_cast<double*>(w + pl.off_scal);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // direction-0 blocks beyond its query count exit before writing their scalar partials: zero them
-    if (hipMemsetAsync(a.scal, 0, sizeof(double) * 2 * (size_t)pl.ksplit * pl.qblocks, st) != hipSuccess) {
-        set_error("msn_infonce_bwd: hipMemsetAsync failed");
-        return MSN_ERR_HIP;
-    }
-    const dim3 grid(pl.qblocks, pl.ksplit, 2), block(256);
+    const dim3 grid(pl.qtiles, pl.ksplit, 2), block(256);
     MSN_NCE_DISPATCH(nce_bwd_kernel, grid, block, 0, st, a)
     MSN_LAUNCH_CHECK();
+    // key splits > 1: fixed-order sum of the slabs; always: the (dscale, dbias) partials of direction 0
     const int64_t total = (int64_t)pl.maxq * D;
-    const int blocks = (int)std::min<int64_t>(cdiv(total, 256), 1024);
-    hipLaunchKernelGGL(nce_bwd_finish_kernel, dim3(blocks), dim3(256), 0, st, a, grad_out, D,
-                       pl.ksplit * pl.qblocks, dscale_dbias);
+    const int blocks = pl.ksplit > 1 ? (int)std::min<int64_t>(cdiv(total, 256), 1024) : 1;
+    hipLaunchKernelGGL(nce_bwd_finish_kernel, dim3(blocks), dim3(256), 0, st, a, pl.ksplit * pl.qtiles, dscale_dbias);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }
@@ -618,10 +678,10 @@ extern "C" int msn_retrieval_rank(const float* E1, int64_t ld1, const float* E2,
     MSN_REQUIRE(ws && ws_bytes >= pl.total, "msn_retrieval_rank: workspace %zu < %zu bytes", ws_bytes, pl.total);
     NceArgs a = {};
     a.side[0] = Side{E2, E1, nullptr, nullptr, nullptr, ld2, ld1, 0, n, n};
-    a.ksplit = pl.ksplit; a.keys_per_split = pl.keys_per_split; a.maxq = pl.maxq;
+    a.D = D; a.ksplit = pl.ksplit; a.keys_per_split = pl.keys_per_split; a.maxq = pl.maxq;
     int* part = reinterpret_cast<int*>(static_cast<char*>(ws) + pl.off_m);   // [ksplit][maxq] ints fit the (m) slab
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid(pl.qblocks, pl.ksplit, 1), block(256);
+    const dim3 grid(pl.qtiles, pl.ksplit, 1), block(256);
     MSN_NCE_DISPATCH(nce_rank_kernel, grid, block, 0, st, a, part)
     MSN_LAUNCH_CHECK();
     hipLaunchKernelGGL(nce_rank_finish_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, part, pl.ksplit, pl.maxq, n, rank);

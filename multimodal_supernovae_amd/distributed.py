@@ -12,13 +12,66 @@ all; what is exchanged and why:
 """
 import os
 
+# The pool's host driver only supports dmabuf IPC: without this RCCL's cross-process buffer sharing fails with
+# "hipIpcGetMemHandle: invalid argument".  It has to be in the environment before the HIP runtime starts, i.e.
+# before the first GPU call of the process -- importing this module early (the package does) is enough.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 import torch.distributed as dist
+
+# Set to a list to record every collective issued through this module (bench.py, tests): entries are
+# (kind, payload bytes, start event | None, end event | None); None = no bookkeeping.  Events are recorded on the
+# CALLER's stream around issue + wait, i.e. they measure how long the compute stream was held by the exchange.
+COMM_LOG = None
+
+
+class _Logged:
+    __slots__ = ("entry",)
+
+    def __init__(self, kind, t):
+        self.entry = None
+        if COMM_LOG is not None:
+            ev0 = ev1 = None
+            if t.is_cuda:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+            self.entry = [kind, t.numel() * t.element_size(), ev0, ev1]
+
+    def done(self):
+        if self.entry is not None:
+            if self.entry[3] is not None:
+                self.entry[3].record()
+            COMM_LOG.append(tuple(self.entry))
+
+
+def all_gather_rows(t, group=None, kind="all_gather"):
+    """All-gather equal-sized row blocks -> (world * b, ...) in rank order (no autograd)."""
+    world = dist.get_world_size(group)
+    t = t.contiguous()
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    log = _Logged(kind, out)
+    dist.all_gather_into_tensor(out, t, group=group)
+    log.done()
+    return out
+
+
+def all_reduce_sum(t, group=None, kind="all_reduce"):
+    """In-place SUM all-reduce (no autograd)."""
+    log = _Logged(kind, t)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    log.done()
+    return t
+
+
+def backend_name(group=None):
+    return dist.get_backend(group) if dist.is_available() and dist.is_initialized() else "none"
 
 
 def init_from_env(backend=None):
     """Initialise from torchrun-style env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Returns
-    (rank, local_rank, world_size).  A no-op for single-process runs."""
+    (rank, local_rank, world_size).  A no-op for single-process runs (unless MSN_DIST_FORCE_INIT=1, which builds a
+    one-rank group -- the RCCL smoke test on a one-GPU box)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -26,7 +79,7 @@ def init_from_env(backend=None):
         # more ranks than GPUs (a 1-GPU test box running the 2-rank flow over gloo) share devices round-robin
         local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("MSN_DIST_FORCE_INIT") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -106,14 +159,14 @@ class GradientReducer:
     Every rank must build it over the same parameter list.
     """
 
-    def __init__(self, params, group=None, bucket_bytes=32 << 20):
+    def __init__(self, params, group=None, bucket_bytes=32 << 20, force=False):
         self.group = group
         self.world = world_size(group)
         self.buckets = []
         self._where = {}
         self._handles = []
-        if self.world == 1:
-            return
+        if self.world == 1 and not (force and dist.is_available() and dist.is_initialized()):
+            return                                   # force: run the machinery on a one-rank group (RCCL smoke test)
         params = [p for p in params if p.requires_grad]
         cur, cur_bytes = [], 0
         groups = []
@@ -162,7 +215,15 @@ class GradientReducer:
             b["flat"].zero_()
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+            if b["flat"].is_cuda:
+                # the old .grad tensors are dropped below; one produced on another tower's side stream must not be
+                # handed back to that stream's allocator pool while THIS stream's copy out of it is still queued
+                cur = torch.cuda.current_stream(b["flat"].device)
+                for _, g in have:
+                    g.record_stream(cur)
+        log = _Logged("grad_all_reduce", b["flat"])
         b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        b["log"] = log
         for v, p in zip(b["views"], b["params"]):
             p.grad = v
 
@@ -172,6 +233,7 @@ class GradientReducer:
                 self._launch(b)
         for b in self.buckets:
             b["work"].wait()
+            b.pop("log").done()
             b["work"], b["ready"], b["events"] = None, 0, []
 
     def remove(self):

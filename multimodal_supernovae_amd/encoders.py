@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as F_
+from .models_multimodal import MLP
 
 
 class _Mlp(nn.Module):
@@ -198,3 +199,22 @@ class _SeriesFeatures(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d):
         return None, None, None, None
+
+
+# ------------------------------------------------------------------- MLP in a series slot (BASELINE cfg1)
+class SeriesMLP(MLP):
+    """BASELINE.json configs[0]: the reference's `MLP` (ref src/models_multimodal.py:834-856; `num_layers` x
+    (Linear, ReLU, Dropout) then Linear, state_dict keys layers.{0,3,6,...}) filling the light-curve slot
+    `(x (B,T,1), t (B,T), mask (B,T)) -> (B, n_out)`: it acts on the flattened magnitudes (SURVEY.md section 8(d):
+    "MLP(50->128->128->32) on flattened mags"); the time stamps and the mask are accepted for the slot signature
+    and unused, as a plain MLP has no notion of either."""
+
+    def __init__(self, seq_len, hidden_dim=128, n_out=32, num_layers=2, dropout=0.0):
+        super().__init__(input_dim=seq_len, hidden_dim=hidden_dim, output_dim=n_out, num_layers=num_layers,
+                         dropout=dropout)
+
+    def forward(self, x, t=None, mask=None):
+        flat = x.reshape(x.shape[0], -1).float()
+        if flat.shape[1] != self.input_dim:
+            raise ValueError(f"SeriesMLP was built for {self.input_dim} time steps, got {flat.shape[1]}")
+        return super().forward(flat)

@@ -19,6 +19,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
+from . import distributed as D
 from ._lib import check, lib, ptr, stream_ptr
 
 
@@ -66,10 +67,104 @@ class HipPairKernels:
 
 def _gather_rows(t, group):
     """All-gather equal-sized row blocks -> (world * b, ...) in rank order (no autograd)."""
-    world = dist.get_world_size(group)
-    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    return D.all_gather_rows(t, group)
+
+
+class _AllReduceSum(torch.autograd.Function):
+    """Loss shares of the ranks summed into the global loss; the gradient of the global loss w.r.t. a rank's share is
+    the incoming gradient itself (every rank differentiates the same global scalar)."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        return D.all_reduce_sum(x.clone(), group, kind="loss_all_reduce")
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def gather_embeddings(embs, group):
+    """ONE all-gather for all modalities: the local (b, D) blocks are packed side by side into a (b, M*D) send buffer,
+    gathered into (world * b, M*D), and handed back as M row-strided column views."""
+    b = embs[0].shape[0]
+    if any(e.shape[0] != b for e in embs):
+        raise ValueError("global-negatives mode needs the same local batch for every modality")
+    widths = [e.shape[1] for e in embs]
+    pack = torch.cat([e.detach() for e in embs], dim=1) if len(embs) > 1 else embs[0].detach()
+    everything = D.all_gather_rows(pack, group, kind="embedding_all_gather")
+    out, off = [], 0
+    for w in widths:
+        out.append(everything[:, off:off + w])
+        off += w
     return out
+
+
+class _MultiPairLoss(torch.autograd.Function):
+    """clip_loss_multimodal as ONE node: every modality pair i < j of one step, single process or row-sharded over
+    `group`.  Sharded, the step costs three collectives whatever the number of pairs -- one all-gather of the packed
+    (b, M*D) embeddings, one of the packed (2P, b) row / column log-sum-exps, one all-reduce of the scalar loss --
+    and each rank evaluates only its own rows and columns of every pair's logit matrix."""
+
+    @staticmethod
+    def forward(ctx, scales, biases, kernels, group, sharded, *embs):
+        m = len(embs)
+        pairs = list(_pairs(range(m), 2))
+        embs = [e.contiguous() for e in embs]
+        scales = scales.detach().to(torch.float32)
+        biases = biases.detach().to(torch.float32)
+        if scales.dim() > 0 and scales.numel() < len(pairs) or biases.dim() > 0 and biases.numel() < len(pairs):
+            raise ValueError(f"{len(pairs)} modality pairs need {len(pairs)} logit scales / biases (or one shared scalar)")
+        s_k = [(scales if scales.dim() == 0 else scales[k]).reshape(()).contiguous() for k in range(len(pairs))]
+        b_k = [(biases if biases.dim() == 0 else biases[k]).reshape(()).contiguous() for k in range(len(pairs))]
+        if sharded:
+            alls = gather_embeddings(embs, group)
+            q_offset = dist.get_rank(group) * embs[0].shape[0]
+        else:
+            alls, q_offset = embs, 0
+        lses, losses = [], []
+        for k, (i, j) in enumerate(pairs):
+            lse_row, lse_col, loss = kernels.forward(embs[i], embs[j], alls[i], alls[j], q_offset, s_k[k], b_k[k])
+            lses += [lse_row, lse_col]
+            losses.append(loss)
+        total = losses[0] if len(losses) == 1 else torch.stack(losses).sum()
+        if sharded:
+            b = embs[0].shape[0]
+            world = dist.get_world_size(group)
+            pack = torch.stack(lses)                                                        # (2P, b)
+            g = D.all_gather_rows(pack.view(1, 2 * len(pairs), b), group, kind="lse_all_gather")   # (world, 2P, b)
+            lse_all = g.permute(1, 0, 2).reshape(2 * len(pairs), world * b)                 # row k: rank-ordered rows
+            lses = [lse_all[r] for r in range(2 * len(pairs))]
+            total = D.all_reduce_sum(total.clone(), group, kind="loss_all_reduce")
+        ctx.kernels, ctx.q_offset, ctx.pairs, ctx.m = kernels, q_offset, pairs, m
+        ctx.shapes = (scales.shape, biases.shape)
+        ctx.save_for_backward(*embs, *alls, *s_k, *b_k, *lses)
+        return total
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        m, pairs = ctx.m, ctx.pairs
+        P = len(pairs)
+        t = ctx.saved_tensors
+        embs, alls = t[:m], t[m:2 * m]
+        s_k, b_k, lses = t[2 * m:2 * m + P], t[2 * m + P:2 * m + 2 * P], t[2 * m + 2 * P:]
+        g = grad_out.to(torch.float32).reshape(()).contiguous()
+        d_emb = [None] * m
+        d_s, d_b = [], []
+        for k, (i, j) in enumerate(pairs):
+            d1, d2, ds, db = ctx.kernels.backward(embs[i], embs[j], alls[i], alls[j], ctx.q_offset, s_k[k], b_k[k],
+                                                  lses[2 * k], lses[2 * k + 1], g)
+            d_emb[i] = d1 if d_emb[i] is None else d_emb[i].add_(d1)
+            d_emb[j] = d2 if d_emb[j] is None else d_emb[j].add_(d2)
+            d_s.append(ds)
+            d_b.append(db)
+        s_shape, b_shape = ctx.shapes
+        if P == 1:
+            gs, gb = d_s[0].reshape(s_shape), d_b[0].reshape(b_shape)
+        else:
+            gs, gb = torch.stack(d_s), torch.stack(d_b)
+            gs = gs.sum() if len(s_shape) == 0 else gs
+            gb = gb.sum() if len(b_shape) == 0 else gb
+        return (gs, gb, None, None, None, *d_emb)
 
 
 class _PairLoss(torch.autograd.Function):
@@ -82,18 +177,17 @@ class _PairLoss(torch.autograd.Function):
         log_scale = log_scale.detach().to(torch.float32).reshape(()).contiguous()
         bias = bias.detach().to(torch.float32).reshape(()).contiguous()
         if sharded:
-            if e1.shape[0] != e2.shape[0]:
-                raise ValueError("global-negatives mode needs the same local batch for both modalities")
             rank = dist.get_rank(group)
-            e1_all, e2_all = _gather_rows(e1, group), _gather_rows(e2, group)
+            e1_all, e2_all = gather_embeddings([e1, e2], group)
             q_offset = rank * e1.shape[0]
         else:
             e1_all, e2_all, q_offset = e1, e2, 0
         lse_row, lse_col, loss = kernels.forward(e1, e2, e1_all, e2_all, q_offset, log_scale, bias)
         if sharded:
-            lse_row, lse_col = _gather_rows(lse_row, group), _gather_rows(lse_col, group)
-            loss = loss.clone()
-            dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=group)
+            both = _gather_rows(torch.stack([lse_row, lse_col]).view(1, 2, -1), group)      # (world, 2, b)
+            both = both.permute(1, 0, 2).reshape(2, -1)
+            lse_row, lse_col = both[0], both[1]
+            loss = D.all_reduce_sum(loss.clone(), group, kind="loss_all_reduce")
         ctx.kernels, ctx.q_offset = kernels, q_offset
         ctx.save_for_backward(e1, e2, e1_all, e2_all, log_scale, bias, lse_row, lse_col)
         return loss
@@ -108,8 +202,9 @@ class _PairLoss(torch.autograd.Function):
 
 
 def _is_sharded(global_negatives, group):
-    return bool(global_negatives and dist.is_available() and dist.is_initialized()
-                and dist.get_world_size(group) > 1)
+    if not (global_negatives and dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or global_negatives == "always"     # "always": also a one-rank group (tests)
 
 
 def clip_loss(embs1, embs2, logit_scale=1.0, logit_bias=0.0, image_encoder=None, lightcurve_encoder=None,
@@ -128,19 +223,12 @@ def clip_loss_multimodal(embeddings, logit_scales=1.0, logit_biases=0.0, *, glob
     """Sum over modality pairs i < j (ref src/loss.py:41-65); a 0-dim scale / bias is shared by
     every pair (:49-52), a vector supplies one value per pair in (0,1),(0,2),(1,2)... order."""
     m = len(embeddings)
-    n_pairs = m * (m - 1) // 2
+    if m < 2:
+        raise ValueError("clip_loss_multimodal needs at least two modalities")
     dev = embeddings[0].device
     scales = torch.as_tensor(logit_scales, dtype=torch.float32, device=dev)
     biases = torch.as_tensor(logit_biases, dtype=torch.float32, device=dev)
-    total = 0
-    for k, (i, j) in enumerate(_pairs(range(m), 2)):
-        s = scales if scales.dim() == 0 else scales[k]
-        b = biases if biases.dim() == 0 else biases[k]
-        total = total + clip_loss(embeddings[i], embeddings[j], s, b, global_negatives=global_negatives,
-                                  group=group, kernels=kernels)
-    if n_pairs == 0:
-        raise ValueError("clip_loss_multimodal needs at least two modalities")
-    return total
+    return _MultiPairLoss.apply(scales, biases, kernels, group, _is_sharded(global_negatives, group), *embeddings)
 
 
 # ------------------------------------------------------------------------------------- sigmoid loss
@@ -148,7 +236,7 @@ class _SigmoidPair(torch.autograd.Function):
     """sigmoid_loss of one modality pair (ref src/loss.py:68-83) on msn_sigmoid_loss_fwd / _bwd."""
 
     @staticmethod
-    def forward(ctx, e1, e2, log_scale, bias, group, sharded):
+    def forward(ctx, e1, e2, log_scale, bias, group, sharded, gathered):
         _lib.require_gpu()
         e1, e2 = e1.contiguous(), e2.contiguous()
         if e1.shape != e2.shape:
@@ -156,7 +244,8 @@ class _SigmoidPair(torch.autograd.Function):
         log_scale = log_scale.detach().to(torch.float32).reshape(()).contiguous()
         bias = bias.detach().to(torch.float32).reshape(()).contiguous()
         if sharded:
-            e1_all, e2_all = _gather_rows(e1, group), _gather_rows(e2, group)
+            # `gathered`: this pair's columns of the step's ONE packed all-gather (sigmoid_loss_multimodal)
+            e1_all, e2_all = gathered if gathered is not None else gather_embeddings([e1, e2], group)
             q_offset = dist.get_rank(group) * e1.shape[0]
         else:
             e1_all, e2_all, q_offset = e1, e2, 0
@@ -169,9 +258,7 @@ class _SigmoidPair(torch.autograd.Function):
         check(L.msn_sigmoid_loss_fwd(ptr(e1), e1.stride(0), ptr(e2), e2.stride(0), b, ptr(e1_all), e1_all.stride(0),
                                      ptr(e2_all), e2_all.stride(0), n, D, q_offset, ptr(log_scale), ptr(bias),
                                      ptr(loss), ptr(ws), nb, stream_ptr()), "msn_sigmoid_loss_fwd")
-        if sharded:
-            dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=group)
-        ctx.q_offset = q_offset
+        ctx.q_offset = q_offset                      # the rank's SHARE of the loss: the caller sums the ranks once
         ctx.save_for_backward(e1, e2, e1_all, e2_all, log_scale, bias)
         return loss
 
@@ -190,7 +277,7 @@ class _SigmoidPair(torch.autograd.Function):
                                      ptr(e2_all), e2_all.stride(0), n, D, ctx.q_offset, ptr(log_scale), ptr(bias),
                                      ptr(g), ptr(d1), D, ptr(d2), D, ptr(dsb), ptr(ws), nb, stream_ptr()),
               "msn_sigmoid_loss_bwd")
-        return d1, d2, dsb[0], dsb[1], None, None
+        return d1, d2, dsb[0], dsb[1], None, None, None
 
 
 def sigmoid_loss(embs1, embs2, logit_scale=1.0, logit_bias=2.73, *, global_negatives=True, group=None):
@@ -199,7 +286,9 @@ def sigmoid_loss(embs1, embs2, logit_scale=1.0, logit_bias=2.73, *, global_negat
     dev = embs1.device
     logit_scale = torch.as_tensor(logit_scale, dtype=torch.float32, device=dev)
     logit_bias = torch.as_tensor(logit_bias, dtype=torch.float32, device=dev)
-    return _SigmoidPair.apply(embs1, embs2, logit_scale, logit_bias, group, _is_sharded(global_negatives, group))
+    sharded = _is_sharded(global_negatives, group)
+    share = _SigmoidPair.apply(embs1, embs2, logit_scale, logit_bias, group, sharded, None)
+    return _AllReduceSum.apply(share, group) if sharded else share
 
 
 def sigmoid_loss_multimodal(embeds, logit_scales=1.0, logit_biases=2.73, *, global_negatives=True, group=None):
@@ -210,9 +299,12 @@ def sigmoid_loss_multimodal(embeds, logit_scales=1.0, logit_biases=2.73, *, glob
     dev = embeds[0].device
     scales = torch.as_tensor(logit_scales, dtype=torch.float32, device=dev)
     biases = torch.as_tensor(logit_biases, dtype=torch.float32, device=dev)
+    sharded = _is_sharded(global_negatives, group)
+    alls = gather_embeddings([e.contiguous() for e in embeds], group) if sharded else None
     total = 0
     for k, (i, j) in enumerate(_pairs(range(m), 2)):
         s = scales if scales.dim() == 0 else scales[k]
         b = biases if biases.dim() == 0 else biases[k]
-        total = total + sigmoid_loss(embeds[i], embeds[j], s, b, global_negatives=global_negatives, group=group)
-    return total
+        total = total + _SigmoidPair.apply(embeds[i], embeds[j], s, b, group, sharded,
+                                           (alls[i], alls[j]) if sharded else None)
+    return _AllReduceSum.apply(total, group) if sharded else total

@@ -70,7 +70,7 @@ def masked_mse(pred, target, select):
 
 
 class MaskedLightCurveEncoder(nn.Module):
-    """ref src/models_pretraining.py:101-259 (Lightning hooks as plain methods; StepLR scheduling is left to the caller)."""
+    """ref src/models_pretraining.py:101-259 (Lightning hooks as plain methods)."""
 
     def __init__(self, f_mask: float = 0.2, nband: int = 1, transformer_kwargs: Dict = None, optimizer_kwargs: Dict = None,
                  lr_scheduler_kwargs: Dict = None, lr: float = 1e-3):
@@ -84,15 +84,23 @@ class MaskedLightCurveEncoder(nn.Module):
         self.logged = {}
 
     def log(self, name, value, **kwargs):
-        self.logged[name] = value
+        # detached: a logged loss must not keep its autograd graph alive into the next step
+        self.logged[name] = value.detach() if torch.is_tensor(value) else value
 
     def forward(self, x, t, mask=None):
         h = self.net(x[..., None], t, mask)                                    # (B, T, emb), padded tokens zeroed
         return F_.linear(h, self.last_layer.weight, self.last_layer.bias).squeeze(2)
 
     def configure_optimizers(self):
+        """RAdam + StepLR stepped once per epoch (ref src/models_pretraining.py:167-189); trainer.Trainer steps the
+        scheduler it finds under "lr_scheduler" after every training epoch, as Lightning does."""
         from .optim import RAdam
-        return {"optimizer": RAdam(self.parameters(), lr=self.lr, **self.optimizer_kwargs)}
+        optimizer = RAdam(self.parameters(), lr=self.lr, **self.optimizer_kwargs)
+        out = {"optimizer": optimizer}
+        if self.lr_scheduler_kwargs:
+            out["lr_scheduler"] = {"scheduler": torch.optim.lr_scheduler.StepLR(optimizer, **self.lr_scheduler_kwargs),
+                                   "monitor": "val_loss", "interval": "epoch", "frequency": 1}
+        return out
 
     def masked_loss(self, x, t, padding_mask, mask_in, mask_pred):
         """MSE on the hidden points given explicit masks (what masked_pred + nn.MSELoss compute, ref :183-231)."""

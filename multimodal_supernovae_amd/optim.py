@@ -83,6 +83,8 @@ class RAdam(torch.optim.Optimizer):
             counter = torch.tensor([int(self.state[ps[0]]["step"])], dtype=torch.int64, device=dev)
             table_host = torch.empty(5 * len(group["params"]), dtype=torch.int64).pin_memory()
             self._graph_ready[gi] = (hyper, counter, table_host)
+            self._graph_hyper_captured = getattr(self, "_graph_hyper_captured", {})
+            self._graph_hyper_captured[id(group)] = self._hyper_of(group)
         torch.cuda.synchronize()
 
     def _graph_buffers(self):
@@ -96,12 +98,27 @@ class RAdam(torch.optim.Optimizer):
         for _, _, _, _, _, counter in getattr(self, "_graph_launches", []):
             counter.add_(1)
 
+    @staticmethod
+    def _hyper_of(group):
+        b1, b2 = group["betas"]
+        return (float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]))
+
     def graph_pre_replay(self):
-        """Keep the host-side step counts in line with the device counter a replay increments."""
-        for group, items, *_ in self._graph_launches:
+        """Keep the host-side step counts in line with the device counter a replay increments, and carry a changed
+        learning rate / betas / eps / weight decay (an lr scheduler, a manual edit of param_groups) into the device
+        copy the recorded launch reads: the copy is enqueued on the replaying stream BEFORE the replay, so it is
+        ordered against the previous replay's read and this replay's."""
+        seen = getattr(self, "_graph_hyper_seen", None)
+        if seen is None:
+            seen = self._graph_hyper_seen = {}
+        for li, (group, items, _, _, hyper, _) in enumerate(self._graph_launches):
             step = int(items[0][1]["step"]) + 1
             for _, st in items:
                 st["step"] = step
+            now = self._hyper_of(group)
+            if seen.setdefault(li, self._graph_hyper_captured.get(id(group), now)) != now:
+                hyper[:5].copy_(torch.tensor(now, dtype=torch.float32), non_blocking=False)
+                seen[li] = now
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -26,6 +26,38 @@ def _to_device(batch, device):
     return tuple(out)
 
 
+def _batch_rows(batch):
+    """Rows of a 9-tuple batch = leading dimension of its first tensor (Lightning's batch-size inference)."""
+    for t in batch:
+        if torch.is_tensor(t) and t.dim() > 0:
+            return int(t.shape[0])
+    return 1
+
+
+def _weighted_mean(values, rows):
+    """Epoch mean the way Lightning's on_epoch=True reduction forms it: every step weighted by its batch size."""
+    w = torch.tensor(rows, dtype=torch.float64, device=values[0].device)
+    return float((torch.stack([v.double() for v in values]) * w).sum() / w.sum())
+
+
+def _check_sharded_loader(loader, group, what):
+    """Data parallel: every rank must see the same number of equally sized batches per epoch -- the embedding
+    all-gather assumes equal local row counts, and a rank with one batch more would wait in a collective the others
+    never enter.  Checked up front (an error instead of a hang) for anything that has a length."""
+    import torch.distributed as dist
+    n = len(loader) if hasattr(loader, "__len__") else -1
+    bs, drop_last, ds = getattr(loader, "batch_size", None), getattr(loader, "drop_last", None), getattr(loader, "dataset", None)
+    if bs and drop_last is False and ds is not None and hasattr(ds, "__len__") and len(ds) % bs != 0:
+        raise ValueError(f"{what}: data-parallel training with global negatives needs equal batches on every rank -- "
+                         f"build the DataLoader with drop_last=True ({len(ds)} samples do not divide into batches of {bs})")
+    world = dist.get_world_size(group)
+    counts = [None] * world
+    dist.all_gather_object(counts, n, group=group)
+    if len(set(counts)) != 1:
+        raise ValueError(f"{what}: ranks disagree on the number of batches per epoch {counts}; shard the dataset "
+                         "into equal parts (e.g. DistributedSampler(drop_last=True))")
+
+
 class Trainer:
     def __init__(self, max_epochs=1, device=None, group=None, log_fn=None, sync_batchnorm=False, graphed_steps=False):
         self.max_epochs = max_epochs
@@ -42,18 +74,24 @@ class Trainer:
         model.to(self.device)
         D.broadcast_module(model, group=self.group)
         D.enable_sync_batchnorm(self.group, enabled=self.sync_batchnorm and D.world_size(self.group) > 1)
-        optimizer = model.configure_optimizers()["optimizer"]
+        optim_config = model.configure_optimizers()
+        optimizer = optim_config["optimizer"]
         self.optimizer = optimizer
         reducer = D.GradientReducer(model.parameters(), group=self.group)   # bucket all-reduces run under backward
+        world = D.world_size(self.group)
+        if world > 1:
+            _check_sharded_loader(train_dataloaders, self.group, "train_dataloaders")
+        scheduler = self._scheduler_of(optim_config)
         graphed = GraphedTrainStep(model.train(), optimizer) if self.graphed_steps and D.world_size(self.group) == 1 else None
         for epoch in range(self.max_epochs):
             model.train()
             model.on_train_epoch_start()
-            losses = []
+            losses, rows = [], []
             for batch_idx, batch in enumerate(train_dataloaders):
                 batch = _to_device(batch, self.device)
+                rows.append(_batch_rows(batch))
                 if graphed is not None:
-                    losses.append(graphed(batch).detach().clone())     # the graph's loss tensor is overwritten by the next replay
+                    losses.append(graphed(batch, batch_idx).detach().clone())   # the graph's loss tensor is overwritten by the next replay
                     self.global_step += 1
                     continue
                 optimizer.zero_grad(set_to_none=True)
@@ -66,21 +104,54 @@ class Trainer:
             model.on_train_epoch_end()
             self.step_losses += losses
             if losses:
-                self.history["train_loss"].append(float(torch.stack(losses).mean()))
+                self.history["train_loss"].append(_weighted_mean(losses, rows))
+            if scheduler is not None:
+                scheduler.step()                  # Lightning steps an epoch-interval scheduler after the training epoch
             if val_dataloaders is not None:
-                model.eval()
-                model.on_validation_start()
-                vlosses = []
-                with torch.no_grad():
-                    for batch_idx, batch in enumerate(val_dataloaders):
-                        vlosses.append(model.validation_step(_to_device(batch, self.device), batch_idx).detach())
-                model.on_validation_epoch_end()
-                if vlosses:
-                    self.history["val_loss"].append(float(torch.stack(vlosses).mean()))
+                self._validate(model, val_dataloaders, world)
             if self.log_fn:
                 self.log_fn(epoch, {k: v[-1] for k, v in self.history.items() if v})
         reducer.remove()
         return self
+
+    @staticmethod
+    def _scheduler_of(cfg):
+        """`configure_optimizers` may return {"optimizer": ..., "lr_scheduler": scheduler | {"scheduler": ...}} as the
+        reference's MaskedLightCurveEncoder does (src/models_pretraining.py:167-189: RAdam + StepLR per epoch)."""
+        sch = cfg.get("lr_scheduler")
+        return sch.get("scheduler") if isinstance(sch, dict) else sch
+
+    def _validate(self, model, val_dataloaders, world):
+        """on_validation_start -> validation_step* -> on_validation_epoch_end (ref src/models_multimodal.py:415-556).
+        With several ranks each one validates ITS shard against local negatives (no collective inside the loop: a
+        short last batch or an uneven shard cannot hang or mix row counts), then the batch-weighted loss sums are
+        all-reduced once; the retrieval AUC a rank logs is that of its own shard."""
+        model.eval()
+        model.on_validation_start()
+        vlosses, vrows = [], []
+        had = getattr(model, "global_negatives", None)
+        if world > 1 and had is not None:
+            model.global_negatives = False
+        try:
+            with torch.no_grad():
+                for batch_idx, batch in enumerate(val_dataloaders):
+                    batch = _to_device(batch, self.device)
+                    vrows.append(_batch_rows(batch))
+                    vlosses.append(model.validation_step(batch, batch_idx).detach())
+        finally:
+            if world > 1 and had is not None:
+                model.global_negatives = had
+        model.on_validation_epoch_end()
+        if not vlosses and world == 1:
+            return
+        w = torch.tensor(vrows, dtype=torch.float64, device=self.device)
+        acc = torch.zeros(2, dtype=torch.float64, device=self.device)
+        if vlosses:
+            acc[0], acc[1] = (torch.stack([v.double() for v in vlosses]) * w).sum(), w.sum()
+        if world > 1:
+            D.all_reduce_sum(acc, self.group, kind="val_loss_all_reduce")
+        if float(acc[1]) > 0:
+            self.history["val_loss"].append(float(acc[0] / acc[1]))
 
 
 class GraphedTrainStep:
@@ -106,9 +177,9 @@ class GraphedTrainStep:
         self.model, self.optimizer, self.warmup = model, optimizer, int(warmup)
         self.calls, self.graph, self.static, self.loss = 0, None, None, None
 
-    def _eager(self, batch):
+    def _eager(self, batch, batch_idx=0):
         self.optimizer.zero_grad(set_to_none=True)
-        loss = self.model.training_step(batch, 0)
+        loss = self.model.training_step(batch, batch_idx)
         loss.backward()
         self.optimizer.step()
         return loss
@@ -141,14 +212,14 @@ class GraphedTrainStep:
     def static_device(self):
         return next(t.device for t in self.static if torch.is_tensor(t))
 
-    def __call__(self, batch):
+    def __call__(self, batch, batch_idx=0):
         self.calls += 1
         if self.graph is None:
             if self.calls <= self.warmup:
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):             # torch's rule: warm up off the stream that will capture
-                    loss = self._eager(batch)
+                    loss = self._eager(batch, batch_idx)
                 torch.cuda.current_stream().wait_stream(side)
                 return loss
             self._capture(batch)
@@ -156,7 +227,7 @@ class GraphedTrainStep:
             (torch.is_tensor(d) and torch.is_tensor(s_) and d.shape == s_.shape) or (d is None and s_ is None)
             for d, s_ in zip(self.static, batch))
         if not same:                 # e.g. the short last batch of an epoch: one eager step, the graph stays valid
-            loss = self._eager(batch)
+            loss = self._eager(batch, batch_idx)
             self.optimizer.graph_note_eager_step()
             return loss
         for dst, src in zip(self.static, batch):

@@ -1,0 +1,280 @@
+"""The five BASELINE.json configurations at their REAL workload shapes, HIP path against the oracle:
+
+  cfg1  ConvMixer(dim 32, depth 2, p 4, k 5) on 32x32 + reference MLP(50 -> 128 -> 128 -> 32) in the light-curve slot, B = 32
+        (reference classes src/models_multimodal.py:38-95, :834-856): loss + every gradient vs oracle.clip / oracle.encoders
+  cfg4  ViT-S/8 + light-curve transformer + 1-D CNN on 1024-bin spectra, 3-way InfoNCE, B = 16; Conv1dEncoder alone at
+        T = 200 and T = 1024
+  cfg5  ViT-B/16 at 224x224 (T = 197, 12 heads x 64): fp32 and split-bf16 to 1e-3, plain bf16 by cosine, and a full-size
+        property check
+(cfg2 = tests/test_build_defined_gpu.py::test_resnet18 + test_cfg2 below at 64x64; cfg3 = tests/test_headline_gpu.py.)
+ViT / ResNet / 1-D CNN are build-defined (not in the reference): their oracle is oracle/build_defined.py.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+LC = dict(n_out=32, emb=64, heads=8, depth=5, dropout=0.0, time_norm=20583.369161312577, agg="mean")
+PLACEHOLDER = dict(dim=8, depth=1, channels=3, kernel_size=5, patch_size=8, n_out=32, dropout_prob=0.0)
+
+
+def _state(model):
+    trainable = {k for k, _ in model.named_parameters()}
+    return {k: v.detach().clone().requires_grad_(k in trainable) for k, v in model.state_dict().items()}
+
+
+def _series(g, b, t, nband, lo, hi, ragged=True):
+    per = t // nband
+    x = torch.randn(b, t, generator=g)
+    tt = torch.cat([torch.sort(torch.rand(b, per, generator=g) * (hi - lo) + lo, dim=1)[0] for _ in range(nband)], 1)
+    mask = torch.ones(b, t, dtype=torch.bool)
+    if ragged:   # valid length per band ~ U{10..per}, True prefix
+        for k in range(nband):
+            n = torch.randint(min(10, per), per + 1, (b, 1), generator=g)
+            mask[:, k * per:(k + 1) * per] = torch.arange(per)[None, :] < n
+    return x, tt, mask
+
+
+def _cuda(batch):
+    return tuple(t.cuda() if torch.is_tensor(t) else t for t in batch)
+
+
+def _compare_grads(model, P, rtol=2e-3, skip=()):
+    worst, worst_k = 0.0, None
+    for k, p in model.named_parameters():
+        if k == "logit_bias" or k in skip:
+            continue
+        want = P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])
+        got = p.grad.cpu() if p.grad is not None else torch.zeros_like(want)
+        err = float((got - want).abs().max()) / (float(want.abs().max()) + 1e-12)
+        if err > worst:
+            worst, worst_k = err, k
+    assert worst < rtol, (worst_k, worst)
+
+
+# ------------------------------------------------------------------------------------------------------- cfg1
+def test_cfg1_convmixer_plus_mlp_batch32():
+    from multimodal_supernovae_amd.encoders import SeriesMLP
+    from multimodal_supernovae_amd.models_multimodal import LightCurveImageCLIP
+    from oracle import clip as oclip
+    from oracle import encoders as oenc
+    from oracle import loss as oloss
+    torch.manual_seed(11)
+    ck = dict(dim=32, depth=2, channels=3, kernel_size=5, patch_size=4, n_out=32, dropout_prob=0.0)
+    model = LightCurveImageCLIP(enc_dim=128, logit_scale=10.0, nband=1, transformer_kwargs=LC, conv_kwargs=ck,
+                                combinations=["host_galaxy", "lightcurve"], loss="softmax")
+    model.lightcurve_encoder = SeriesMLP(seq_len=50, hidden_dim=128, n_out=32, num_layers=2, dropout=0.0)
+    P = _state(model)
+    g = torch.Generator().manual_seed(12)
+    B = 32
+    x_img = torch.rand(B, 3, 32, 32, generator=g)
+    x_lc, t_lc, m_lc = _series(g, B, 50, 1, 0.0, 100.0, ragged=False)
+    stats = {}
+    h = oenc.convmixer(P, "image_encoder.", x_img, depth=2, patch_size=4, training=True, stats_out=stats)
+    e_img = oclip.l2_normalise(oenc.linear(P, "image_projection", h))
+    e_lc = oclip.l2_normalise(oenc.linear(P, "lightcurve_projection", oenc.mlp(P, "lightcurve_encoder.", x_lc, 2)))
+    ref = oloss.clip_loss_multimodal([e_img, e_lc], P["logit_scale"], P["logit_bias"])
+    ref.backward()
+    model.cuda().train()
+    batch = _cuda((x_img, x_lc, t_lc, m_lc, None, None, None, None, None))
+    embs = model(*batch)
+    torch.testing.assert_close(embs[0].detach().cpu(), e_img.detach(), rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(embs[1].detach().cpu(), e_lc.detach(), rtol=1e-3, atol=1e-5)
+    sd = model.state_dict()
+    for k, v in stats.items():                      # BatchNorm running statistics after ONE training-mode forward
+        torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-3, atol=1e-5)
+    loss = model.training_step(batch, 0)
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-3 * abs(float(ref.detach()))
+    loss.backward()
+    _compare_grads(model, P)
+
+
+# ------------------------------------------------------------------------------------------------------- cfg2
+def test_cfg2_resnet18_plus_cnn1d_at_64px():
+    """ResNet-18 @64x64 + 1-D CNN on T = 200 light curves, local-negatives InfoNCE (one process), B = 12."""
+    from multimodal_supernovae_amd.encoders import Conv1dEncoder, ResNet18
+    from multimodal_supernovae_amd.models_multimodal import LightCurveImageCLIP
+    from oracle import clip as oclip
+    from oracle import encoders as oenc
+    from oracle import loss as oloss
+    from oracle.build_defined import conv1d_encoder, resnet18
+    torch.manual_seed(21)
+    model = LightCurveImageCLIP(enc_dim=128, logit_scale=10.0, nband=2, transformer_kwargs=LC, conv_kwargs=PLACEHOLDER,
+                                combinations=["host_galaxy", "lightcurve"], loss="softmax", global_negatives=False)
+    model.image_encoder, model.lightcurve_encoder = ResNet18(n_out=32), Conv1dEncoder(n_out=32, time_norm=100.0)
+    P = _state(model)
+    g = torch.Generator().manual_seed(22)
+    B = 12
+    x_img = torch.rand(B, 3, 64, 64, generator=g)
+    x_lc, t_lc, m_lc = _series(g, B, 200, 2, 0.0, 100.0)
+    e_img = oclip.l2_normalise(oenc.linear(P, "image_projection", resnet18(P, "image_encoder.", x_img, training=True)))
+    h = conv1d_encoder(P, "lightcurve_encoder.", x_lc[..., None], t_lc, m_lc, n_layers=3, time_norm=100.0)
+    e_lc = oclip.l2_normalise(oenc.linear(P, "lightcurve_projection", h))
+    ref = oloss.clip_loss_multimodal([e_img, e_lc], P["logit_scale"], P["logit_bias"])
+    ref.backward()
+    model.cuda().train()
+    loss = model.training_step(_cuda((x_img, x_lc, t_lc, m_lc, None, None, None, None, None)), 0)
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-3 * abs(float(ref.detach()))
+    loss.backward()
+    _compare_grads(model, P, rtol=5e-3)
+
+
+# ------------------------------------------------------------------------------------------------------- cfg4
+@pytest.mark.parametrize("T,lo,hi,tn", [(200, 0.0, 100.0, 100.0), (1024, 3000.0, 9000.0, 9000.0)])
+def test_conv1d_encoder_at_baseline_lengths(T, lo, hi, tn):
+    from multimodal_supernovae_amd.encoders import Conv1dEncoder
+    from oracle.build_defined import conv1d_encoder
+    torch.manual_seed(T)
+    m = Conv1dEncoder(n_out=32, time_norm=tn)                 # default widths (64, 128, 128), k = 5
+    P = {k: v.clone().requires_grad_() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(T + 1)
+    B = 7
+    x, t, mask = _series(g, B, T, 1, lo, hi)
+    cot = torch.randn(B, 32, generator=g)
+    ref = conv1d_encoder(P, "", x[..., None], t, mask, n_layers=3, time_norm=tn)
+    (ref * cot).sum().backward()
+    m.cuda()
+    y = m(x[..., None].cuda(), t.cuda(), mask.cuda())
+    torch.testing.assert_close(y.detach().cpu(), ref.detach(), rtol=1e-3, atol=1e-4 * float(ref.abs().max()))
+    y.backward(cot.cuda())
+    for k, p in m.named_parameters():
+        err = float((p.grad.cpu() - P[k].grad).abs().max()) / (float(P[k].grad.abs().max()) + 1e-12)
+        assert err < 2e-3, (k, err)
+
+
+def test_cfg4_three_towers_vit_s8_lc_cnn1d_spectrum_1024():
+    from multimodal_supernovae_amd.encoders import Conv1dEncoder, vit_s8
+    from multimodal_supernovae_amd.models_multimodal import LightCurveImageCLIP
+    from oracle import clip as oclip
+    from oracle import encoders as oenc
+    from oracle import loss as oloss
+    from oracle.build_defined import conv1d_encoder, vision_transformer
+    torch.manual_seed(41)
+    model = LightCurveImageCLIP(enc_dim=128, logit_scale=19.545966923442453, nband=2, transformer_kwargs=LC,
+                                transformer_spectral_kwargs=LC, conv_kwargs=PLACEHOLDER,
+                                combinations=["host_galaxy", "lightcurve", "spectral"], loss="softmax")
+    model.image_encoder = vit_s8(img_size=64, n_out=32)
+    model.spectral_encoder = Conv1dEncoder(n_out=32, time_norm=9000.0)
+    P = _state(model)
+    g = torch.Generator().manual_seed(42)
+    B = 16
+    x_img = torch.rand(B, 3, 64, 64, generator=g)
+    lc = _series(g, B, 200, 2, 0.0, 100.0)
+    sp = _series(g, B, 1024, 1, 3000.0, 9000.0)
+    e_img = oclip.l2_normalise(oenc.linear(P, "image_projection",
+                                           vision_transformer(P, "image_encoder.", x_img, patch=8, heads=6, depth=12)))
+    h = oenc.transformer_with_time_embeddings(P, "lightcurve_encoder.", lc[0][..., None], lc[1], lc[2], emb=64, heads=8,
+                                              depth=5, time_norm=LC["time_norm"], nband=2, agg="mean")
+    e_lc = oclip.l2_normalise(oenc.linear(P, "lightcurve_projection", h))
+    h = conv1d_encoder(P, "spectral_encoder.", sp[0][..., None], sp[1], sp[2], n_layers=3, time_norm=9000.0)
+    e_sp = oclip.l2_normalise(oenc.linear(P, "spectral_projection", h))
+    ref = oloss.clip_loss_multimodal([e_img, e_lc, e_sp], P["logit_scale"], P["logit_bias"])
+    ref.backward()
+    model.cuda().train()
+    batch = _cuda((x_img, *lc, *sp, None, None))
+    embs = model(*batch)
+    assert len(embs) == 3
+    for got, want in zip(embs, (e_img, e_lc, e_sp)):
+        torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=1e-3, atol=1e-5)
+    loss = model.training_step(batch, 0)
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-3 * abs(float(ref.detach()))
+    loss.backward()
+    _compare_grads(model, P)
+
+
+# ------------------------------------------------------------------------------------------------------- cfg5
+def _cos(a, b):
+    a, b = a.flatten().double(), b.flatten().double()
+    return float(a @ b / (a.norm() * b.norm() + 1e-300))
+
+
+@pytest.fixture(scope="module")
+def vit_b16_case():
+    """ViT-B/16 at 224x224, B = 2: the oracle's outputs and every gradient (computed once for the three precisions)."""
+    from multimodal_supernovae_amd.encoders import vit_b16
+    from oracle.build_defined import vision_transformer
+    torch.manual_seed(51)
+    m = vit_b16(img_size=224, n_out=32, gemm_precision=None)
+    assert m.num_tokens == 197 and m.emb == 768 and m.heads == 12 and m.depth == 12
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.05)
+    P = {k: v.clone().requires_grad_() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(52)
+    x = torch.rand(2, 3, 224, 224, generator=g)
+    cot = torch.randn(2, 32, generator=g)
+    ref = vision_transformer(P, "", x, patch=16, heads=12, depth=12)
+    (ref * cot).sum().backward()
+    return m.state_dict(), P, x, cot, ref.detach()
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16"])
+def test_cfg5_vit_b16_at_224(vit_b16_case, precision):
+    from multimodal_supernovae_amd.encoders import vit_b16
+    sd, P, x, cot, ref = vit_b16_case
+    m = vit_b16(img_size=224, n_out=32, gemm_precision=precision)
+    m.load_state_dict(sd)
+    m.cuda().train()
+    y = m(x.cuda())
+    y.backward(cot.cuda())
+    if precision == "bf16":
+        # operands rounded to bf16 (8 significant bits) through 12 blocks: judged by direction, not element-wise
+        assert _cos(y.detach().cpu(), ref) > 0.999
+        cosines = {k: _cos(p.grad.cpu(), P[k].grad) for k, p in m.named_parameters()}
+        low = {k: c for k, c in cosines.items() if c < 0.98}
+        assert not low, low
+        return
+    torch.testing.assert_close(y.detach().cpu(), ref, rtol=1e-3, atol=1e-3 * float(ref.abs().max()) * 0.1)
+    worst, worst_k = 0.0, None
+    for k, p in m.named_parameters():
+        err = float((p.grad.cpu() - P[k].grad).abs().max()) / (float(P[k].grad.abs().max()) + 1e-12)
+        if err > worst:
+            worst, worst_k = err, k
+    assert worst < (2e-3 if precision == "f32" else 1e-2), (worst_k, worst)
+
+
+def test_cfg5_full_size_properties():
+    """cfg5's towers (ViT-B/16 bf16 @224 + the light-curve transformer) at a per-GPU batch of 256, forward only: unit
+    embeddings, a sample's embedding is independent of its batch (LayerNorm towers), and the symmetric InfoNCE is
+    invariant under a common permutation of the pairs."""
+    import bench
+    model, batch = bench.build_workload("vit_b16_bf16_lc", 256, 77, "cuda")
+    with torch.no_grad():
+        e = model(*batch)
+        loss = model._loss(e)
+        perm = torch.randperm(256, device="cuda")
+        pb = tuple(t[perm] if torch.is_tensor(t) and t.dim() > 0 and t.shape[0] == 256 else t for t in batch)
+        ep = model(*pb)
+        loss_p = model._loss(ep)
+        small = tuple(t[:8] if torch.is_tensor(t) and t.dim() > 0 and t.shape[0] == 256 else t for t in batch)
+        es = model(*small)
+    for t in e:
+        assert t.shape == (256, 128)
+        torch.testing.assert_close(t.norm(dim=-1), torch.ones(256, device="cuda"), rtol=0, atol=2e-6)
+    assert torch.isfinite(loss) and abs(float(loss) - float(loss_p)) <= 1e-5 * abs(float(loss))
+    for a, b in zip(e, ep):
+        torch.testing.assert_close(a[perm], b, rtol=1e-4, atol=1e-5)
+    for a, b in zip(e, es):
+        torch.testing.assert_close(a[:8], b, rtol=1e-4, atol=1e-5)
+
+
+def test_cfg5_training_step_runs_at_size():
+    """One full training step of cfg5's towers at 224x224, B = 16, bf16 MFMA GEMMs: finite loss, a gradient for every
+    parameter, loss within 2 % of the fp32 evaluation of the same step."""
+    import bench
+    from multimodal_supernovae_amd import ops
+    model, batch = bench.build_workload("vit_b16_bf16_lc", 16, 78, "cuda")
+    loss = model.training_step(batch, 0)
+    loss.backward()
+    assert torch.isfinite(loss.detach()) and all(p.grad is not None and torch.isfinite(p.grad).all()
+                                                 for p in model.parameters())
+    model.image_encoder.gemm_precision = "f32"
+    with torch.no_grad():
+        loss32 = model._loss(model(*batch))
+    assert abs(float(loss.detach()) - float(loss32)) <= 2e-2 * abs(float(loss32))

@@ -64,12 +64,21 @@ def _worker(rank, world, port, n_mod, out):
     el = encode([x[sl] for x in x_all], [m.weight for m in lin])
     for e in el:
         e.retain_grad()
+    D.COMM_LOG = []
     loss = clip_loss_multimodal(el, ls, lb, kernels=OraclePairKernels, global_negatives=True)
     loss.backward()
+    # the fused exchange: ONE packed embedding all-gather, ONE packed LSE all-gather, ONE loss all-reduce per step,
+    # whatever the number of modality pairs (1 pair at n_mod = 2, 3 pairs at n_mod = 3); nothing in backward
+    kinds = [e[0] for e in D.COMM_LOG]
+    sizes = [e[1] for e in D.COMM_LOG]
+    D.COMM_LOG = None
+    n_pairs = n_mod * (n_mod - 1) // 2
+    comm_ok = kinds == ["embedding_all_gather", "lse_all_gather", "loss_all_reduce"] and \
+        sizes == [world * b * n_mod * d * 4, world * 2 * n_pairs * b * 4, 4]
     params = [m.weight for m in lin] + [ls, lb]
     D.allreduce_gradients(params)
 
-    ok = torch.allclose(loss.detach(), ref.detach(), rtol=1e-5, atol=1e-6)
+    ok = comm_ok and torch.allclose(loss.detach(), ref.detach(), rtol=1e-5, atol=1e-6)
     for e_loc, e_ref in zip(el, er):
         ok = ok and torch.allclose(e_loc.grad, e_ref.grad[sl], rtol=1e-4, atol=1e-6)
     for m, wref in zip(lin, wr):

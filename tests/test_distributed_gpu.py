@@ -24,3 +24,35 @@ def test_two_rank_synchronised_batchnorm_equals_single_process_global_batch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dist_check.py"), "--batchnorm"], capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "DIST CHECK OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_rccl_carries_the_exchange_on_one_gpu():
+    """RCCL ("nccl" backend) itself, through the product's exchange path: a one-rank group with the sharded loss and
+    the gradient reducer forced on (tools/rccl_smoke.py) -- three exchange collectives for three modality pairs plus
+    the bucketed gradient all-reduces, results equal to the plain single-process step."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_smoke.py")], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "RCCL SMOKE OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: the parent starts two ranks (sharing this box's
+    one GPU over gloo; RCCL on a multi-GPU node), relays rank 0's JSON line, and the line carries the comm fields:
+    one packed embedding all-gather, one LSE all-gather, one loss all-reduce per step."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--global-batch", "64"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["per_gpu_batch"] == 32
+    assert out["config"]["global_batch"] == 64 and out["value"] > 0
+    comm = out["comm"]
+    assert comm["ranks"] == 2 and comm["backend"] in ("gloo", "rccl")
+    per = comm["per_step"]
+    assert per["embedding_all_gather"]["calls"] == 1 and per["embedding_all_gather"]["bytes"] == 64 * 2 * 128 * 4
+    assert per["lse_all_gather"]["calls"] == 1 and per["loss_all_reduce"]["calls"] == 1
+    assert per["grad_all_reduce"]["calls"] >= 1
+    weak = out["weak_scaling_256_per_gpu"]
+    assert weak["global_batch"] == 512 and weak["value"] > 0

@@ -39,9 +39,12 @@ def test_shape_errors_are_reported_without_a_gpu():
     rc = lib.msn_sgemm(0, 1, 4, 4, 0, None, 4, None, 4, None, 4, None, 0, None, 0, 0, None, 0, None)
     assert rc == 1 and b"K must be positive" in lib.msn_last_error()
     fake = ctypes.c_void_p(4096)          # never dereferenced: validation rejects the call before any launch
+    rc = lib.msn_infonce_fwd(fake, 300, 4, fake, 300, 4, fake, 300, 4, fake, 300, 4, 300, 0, fake, fake, fake, fake, fake,
+                             fake, 0, None)
+    assert rc == 1 and b"unsupported" in lib.msn_last_error()          # D = 300 > 256
     rc = lib.msn_infonce_fwd(fake, 12, 4, fake, 12, 4, fake, 12, 4, fake, 12, 4, 12, 0, fake, fake, fake, fake, fake,
                              fake, 0, None)
-    assert rc == 1 and b"unsupported" in lib.msn_last_error()
+    assert rc == 1 and b"workspace" in lib.msn_last_error()            # D = 12 is fine now; the workspace is not
     assert lib.msn_set_attention_path(7) == 1
     assert lib.msn_sgemm_workspace_bytes(1, 0, 384, 1536, 66560) > 0      # wgrad takes the split-K path
     # 6240 tiles = 12 rounds of 512 + 96: those 96 run as 3 K-slabs each (tail split)

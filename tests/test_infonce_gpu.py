@@ -57,7 +57,9 @@ def test_against_reference_golden(name):
 
 
 @pytest.mark.parametrize("n,d", [(1, 8), (5, 16), (32, 128), (33, 32), (129, 64), (256, 128), (1024, 128),
-                                 (1000, 128), (4096, 128)])
+                                 (1000, 128), (4096, 128),
+                                 # any enc_dim the reference accepts (src/models_multimodal.py:101): zero-padded tiles
+                                 (40, 1), (77, 5), (64, 12), (300, 100), (130, 130), (257, 200), (96, 256)])
 @pytest.mark.parametrize("log_scale,bias", [(math.log(10.0), -10.0), (math.log(31.0), 0.5)])
 def test_against_oracle(n, d, log_scale, bias):
     e1, e2 = _unit(n, d, 100 + n), _unit(n, d, 200 + n)
@@ -172,8 +174,23 @@ def test_properties_at_full_size():
 def test_rejects_unsupported_width_and_cpu_tensors():
     from multimodal_supernovae_amd import _lib
     from multimodal_supernovae_amd.loss import clip_loss
-    with pytest.raises(_lib.MsnHipError):
-        clip_loss(_unit(8, 12, 1).cuda(), _unit(8, 12, 2).cuda(), torch.tensor(0.0), torch.tensor(0.0))
+    with pytest.raises(_lib.MsnHipError):        # D > 256 is the one width the tiles do not take
+        clip_loss(_unit(8, 260, 1).cuda(), _unit(8, 260, 2).cuda(), torch.tensor(0.0).cuda(), torch.tensor(0.0).cuda())
+    with pytest.raises(_lib.MsnHipError):        # scalars on the host: no silent copies
+        clip_loss(_unit(8, 16, 1).cuda(), _unit(8, 16, 2).cuda(), torch.tensor(0.0), torch.tensor(0.0))
+
+
+def test_odd_width_strided_and_unaligned():
+    """D = 100 as column slices of the packed all-gather buffer (row stride 300, second / third blocks start at
+    columns 100 / 200: 16-byte aligned, third pair shifted by one float: not aligned)."""
+    from multimodal_supernovae_amd.loss import clip_loss
+    wide = torch.cat([_unit(150, 100, 1), _unit(150, 100, 2), _unit(150, 101, 3)], dim=1).cuda()
+    ls, lb = torch.tensor(2.5).cuda(), torch.tensor(-1.0).cuda()
+    for c1, c2 in ((0, 100), (100, 201)):
+        e1, e2 = wide[:, c1:c1 + 100], wide[:, c2:c2 + 100]
+        a = clip_loss(e1, e2, ls, lb)
+        b = clip_loss(e1.contiguous(), e2.contiguous(), ls, lb)
+        assert float(a) == float(b)
 
 
 # ------------------------------------------------------------------------------------ sigmoid loss
@@ -207,7 +224,7 @@ def test_sigmoid_known_answer_and_multimodal():
     assert abs(float(got) - float(f.out["sigmoid"])) <= RTOL * abs(float(f.out["sigmoid"]))
 
 
-@pytest.mark.parametrize("n,d", [(33, 32), (256, 128), (1024, 128)])
+@pytest.mark.parametrize("n,d", [(33, 32), (256, 128), (1024, 128), (70, 100)])
 def test_sigmoid_loss_against_oracle(n, d):
     from multimodal_supernovae_amd.loss import sigmoid_loss
     from oracle.loss import sigmoid_loss as ref_fn
@@ -237,7 +254,7 @@ def test_retrieval_auc_matches_reference_golden():
         assert abs(get_AUC(e1, e2) - float(f.out[f"auc_{n}"])) < 1e-12
 
 
-@pytest.mark.parametrize("n,d", [(1000, 128), (4096, 128), (33, 8)])
+@pytest.mark.parametrize("n,d", [(1000, 128), (4096, 128), (33, 8), (500, 100)])
 def test_retrieval_ranks_against_oracle(n, d):
     from multimodal_supernovae_amd.utils import retrieval_ranks
     from oracle.clip import roc_data

@@ -237,3 +237,29 @@ def test_masked_pretraining_objective():
     loss.backward()
     for k, g in f.grad.items():
         close(P[k].grad, g, rtol=2e-3, atol=2e-5, what="grad " + k)
+
+
+@pytest.mark.parametrize("name", ["val_loop_lc_sp", "val_loop_3tower"])
+def test_validation_loop_values(name):
+    """Row a15: per-batch val_loss and the retrieval AUC the reference logs from on_validation_epoch_end
+    (src/models_multimodal.py:415-556), three validation batches of 6, 6 and 4 rows, eval mode."""
+    f = Fixture(name)
+    P = f.params(requires_grad=False)
+    batches = [_batch(f.groups["in"], f"b{i}.") for i in range(3)]
+    embs_list = None
+    for i, batch in enumerate(batches):
+        embs = oclip.embeddings(P, f.cfg, batch, training=False)
+        embs_list = [[e] for e in embs] if embs_list is None else [acc + [e] for acc, e in zip(embs_list, embs)]
+        loss = oclip.training_loss(P, f.cfg, batch, training=False)
+        close(loss.double(), f.out["val_losses"][i], rtol=1e-4, atol=1e-5, what=f"val_loss batch {i}")
+    cat = [torch.cat(e, dim=0) for e in embs_list]
+    if len(cat) == 2:
+        assert abs(oclip.auc(cat[0], cat[1]) - float(f.out["AUC_val"])) < 1e-12
+    else:
+        count = 1
+        for i in range(len(cat) - 1):
+            for j in range(i + 1, len(cat)):
+                assert abs(oclip.auc(cat[i], cat[j]) - float(f.out[f"AUC_val{count}"])) < 1e-12, count
+                count += 1
+        assert count == 4
+    assert f.cfg["logged_keys"][:3] == ["val_loss"] * 3

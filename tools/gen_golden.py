@@ -11,7 +11,8 @@ gradients as small .npz fixtures.  Fixture layout:  "P/<state_dict key>" paramet
 and buffers, "in/<name>" inputs, "out/<name>" expected outputs, "grad/<key>"
 expected gradients (of sum(out * cot) or of the loss), "cfg" a JSON string.
 
-    python tools/gen_golden.py            # rewrites every fixture
+    python tools/gen_golden.py                       # rewrites every fixture
+    python tools/gen_golden.py --only val_loop,auc   # only the named generators
 """
 import importlib
 import json
@@ -437,18 +438,64 @@ def gen_pretraining():
             "out": {"pred": pred, "loss": loss}, "grad": grads_of(m)})
 
 
+def gen_val_loop(ref_mm):
+    """Row a15: the reference's validation hooks end to end (src/models_multimodal.py:415-556) --
+    on_validation_start -> validation_step x 3 (the last batch short) -> on_validation_epoch_end -- with every
+    `self.log(name, value)` call captured: per-batch val_loss and AUC_val (two modalities) / AUC_val1..3 (three)."""
+    g = torch.Generator().manual_seed(131)
+    tk = dict(n_out=8, emb=16, heads=4, depth=2, dropout=0.0, time_norm=20583.37, agg="mean")
+    sk = dict(n_out=8, emb=8, heads=2, depth=3, dropout=0.0, time_norm=17945.14, agg="mean")
+    ck = dict(dim=8, depth=2, channels=3, kernel_size=5, patch_size=4, n_out=8, dropout_prob=0.0)
+    mk = dict(input_dim=8, hidden_dim=16, num_layers=2, dropout=0.0)
+    for name, combos in {"val_loop_lc_sp": ["lightcurve", "spectral"],
+                         "val_loop_3tower": ["host_galaxy", "lightcurve", "spectral"]}.items():
+        model = ref_mm.LightCurveImageCLIP(
+            enc_dim=16, logit_scale=10.0, nband=2, transformer_kwargs=tk, transformer_spectral_kwargs=sk,
+            conv_kwargs=ck, meta_kwargs=mk, combinations=combos, optimizer_kwargs={"weight_decay": 1e-3},
+            lr=1e-2, loss="softmax")
+        randomise(model, g)
+        with torch.no_grad():
+            model.logit_scale.fill_(math.log(10.0))
+            model.logit_bias.fill_(-10.0)
+        logged = []
+        model.log = lambda key, value, **kw: logged.append((key, float(value)))
+        model.eval()
+        batches = [_batch(g, b, combos) for b in (6, 6, 4)]
+        with torch.no_grad():
+            model.on_validation_start()
+            for i, batch in enumerate(batches):
+                model.validation_step(batch, i)
+            model.on_validation_epoch_end()
+        assert model.embs_list is None
+        ins = {}
+        for bi, batch in enumerate(batches):
+            for k, v in zip(["x_img", "x_lc", "t_lc", "mask_lc", "x_sp", "t_sp", "mask_sp", "redshift",
+                             "classification"], batch):
+                if v is not None:
+                    ins[f"b{bi}.{k}"] = v
+        out = {"val_losses": torch.tensor([v for k, v in logged if k == "val_loss"], dtype=torch.float64)}
+        for k, v in logged:
+            if k.startswith("AUC_val"):
+                out[k] = np.float64(v)
+        cfg = {"combinations": combos, "nband": 2, "transformer_kwargs": tk, "transformer_spectral_kwargs": sk,
+               "conv_kwargs": ck, "meta_kwargs": mk, "enc_dim": 16, "loss": "softmax", "lr": 1e-2,
+               "weight_decay": 1e-3, "batch_sizes": [6, 6, 4], "logged_keys": [k for k, _ in logged]}
+        save(name, cfg=cfg, P=sd_of(model), **{"in": ins, "out": out})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(4)
     ref_loss, ref_tr, ref_mm = import_reference()
-    gen_loss(ref_loss)
-    gen_transformer(ref_tr)
-    gen_convmixer_mlp(ref_mm)
-    gen_clip(ref_mm)
-    gen_real_checkpoint(ref_mm)
-    gen_auc()
-    gen_pretraining()
+    only = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else None
+    jobs = {"loss": lambda: gen_loss(ref_loss), "transformer": lambda: gen_transformer(ref_tr),
+            "convmixer_mlp": lambda: gen_convmixer_mlp(ref_mm), "clip": lambda: gen_clip(ref_mm),
+            "real_checkpoint": lambda: gen_real_checkpoint(ref_mm), "auc": gen_auc, "pretraining": gen_pretraining,
+            "val_loop": lambda: gen_val_loop(ref_mm)}
+    for name, job in jobs.items():        # each generator seeds its own torch.Generator: independent of the others
+        if only is None or name in only:
+            job()
 
 
 if __name__ == "__main__":
