@@ -248,17 +248,27 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(const NceArgs p) {
     }
 }
 
+// Sum of n doubles at stride `stride` by ONE wave: lane l adds elements l, l + 64, ... in order, then a fixed xor tree
+// (deterministic; 64 loads in flight instead of a chain of n dependent ones).  Every lane gets the result.
+__device__ __forceinline__ double wave_sum_strided(const double* __restrict__ v, int n, int stride, int lane) {
+    double acc = 0.0;
+    for (int k = lane; k < n; k += 64) acc += v[(int64_t)k * stride];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    return acc;
+}
+
 // Merge key splits -> LSE per local row and direction; this rank's share of the loss.  One workgroup: a thread owns
-// local row i in BOTH directions (2 * ksplit (m, l) pairs and ksplit positives to read), then one block sum.
+// local row i in BOTH directions; the splits' (m, l, positive) triples are fetched eight at a time (independent loads,
+// one wait) and folded into a running (M, L) pair, then one block sum.
 __global__ __launch_bounds__(1024) void nce_fwd_finish_kernel(const NceArgs p, float* __restrict__ lse_row,
                                                               float* __restrict__ lse_col, float* __restrict__ loss,
                                                               int n_part) {
     __shared__ float red[16];
     if (p.mode == MODE_SIGMOID) {   // loss = sum of the block partials / bs^2 (mean over all bs x bs entries)
-        if (threadIdx.x == 0) {
-            double tot = 0.0;
-            for (int k = 0; k < n_part; ++k) tot += p.scal[k];
-            *loss = (float)(tot / ((double)p.n_diag * (double)p.n_diag));
+        if (threadIdx.x < 64) {
+            const double tot = wave_sum_strided(p.scal, n_part, 1, threadIdx.x);
+            if (threadIdx.x == 0) *loss = (float)(tot / ((double)p.n_diag * (double)p.n_diag));
         }
         return;
     }
@@ -266,6 +276,7 @@ __global__ __launch_bounds__(1024) void nce_fwd_finish_kernel(const NceArgs p, f
     // rows of S come from side[0].Q (E2), columns from side[1].Q (E1); local row i <-> global q_offset + i
     const int nb = min(p.side[0].nq, p.side[1].nq);
     const int nmax = max(p.side[0].nq, p.side[1].nq);
+    const int ks = p.ksplit;
     float acc = 0.f;
     for (int i = threadIdx.x; i < nmax; i += blockDim.x) {
         float lse[2] = {0.f, 0.f};
@@ -273,14 +284,34 @@ __global__ __launch_bounds__(1024) void nce_fwd_finish_kernel(const NceArgs p, f
 #pragma unroll
         for (int dir = 0; dir < 2; ++dir) {
             if (i >= p.side[dir].nq) continue;
-            float M = -INFINITY;
-            for (int s = 0; s < p.ksplit; ++s) M = fmaxf(M, p.part_m[((int64_t)dir * p.ksplit + s) * p.maxq + i]);
-            float L = 0.f;
-            for (int s = 0; s < p.ksplit; ++s) {
-                const int64_t o = ((int64_t)dir * p.ksplit + s) * p.maxq + i;
-                const float ms = p.part_m[o];
-                if (ms > -INFINITY) L += p.part_l[o] * __expf(ms - M);
-                if (dir == 0) diag = fmaxf(diag, p.part_d[o]);
+            const float* pm = p.part_m + (int64_t)dir * ks * p.maxq + i;
+            const float* pl = p.part_l + (int64_t)dir * ks * p.maxq + i;
+            const float* pd = p.part_d + (int64_t)dir * ks * p.maxq + i;
+            float M = -INFINITY, L = 0.f;
+            for (int s0 = 0; s0 < ks; s0 += 8) {
+                float mv[8], lv[8], dv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {                      // clamped index: unconditional, independent loads
+                    const int64_t o = (int64_t)min(s0 + j, ks - 1) * p.maxq;
+                    mv[j] = pm[o];
+                    lv[j] = pl[o];
+                    dv[j] = dir == 0 ? pd[o] : -INFINITY;
+                }
+                float cm = M;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (s0 + j >= ks) mv[j] = -INFINITY;
+                    cm = fmaxf(cm, mv[j]);
+                    diag = fmaxf(diag, dv[j]);                     // a clamped duplicate repeats the same value: harmless
+                }
+                if (cm > -INFINITY) {
+                    float Ln = (M > -INFINITY) ? L * __expf(M - cm) : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (mv[j] > -INFINITY) Ln += lv[j] * __expf(mv[j] - cm);
+                    L = Ln;
+                    M = cm;
+                }
             }
             lse[dir] = M + __logf(L);
             lse_out[dir][i] = lse[dir];
@@ -403,11 +434,16 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(const NceArgs p) {
     }
     // scalar partials (direction 0 covers every (i, j) exactly once)
     if (dir == 0) {
-        const float s1 = block_sum(ds, red);
-        const float s2 = block_sum(db, red);
+        ds = wave_sum(ds);
+        db = wave_sum(db);
+        if (lane == 0) {
+            red[wave] = ds;
+            red[NW + wave] = db;
+        }
+        __syncthreads();
         if (threadIdx.x == 0) {
-            scal_out[0] = (double)s1;
-            scal_out[1] = (double)s2;
+            scal_out[0] = (double)((red[0] + red[1]) + (red[2] + red[3]));
+            scal_out[1] = (double)((red[NW] + red[NW + 1]) + (red[NW + 2] + red[NW + 3]));
         }
     }
 }
@@ -417,23 +453,32 @@ __global__ void nce_bwd_finish_kernel(const NceArgs p, int n_scal, float* __rest
     const float g = p.mode == MODE_SIGMOID ? *p.grad_out / ((float)p.n_diag * (float)p.n_diag)
                                            : *p.grad_out / (2.f * (float)p.n_diag);
     const float f = (p.mode == MODE_SIGMOID ? -g : g) * __expf(*p.log_scale);
-    const int D = p.D;
-    if (p.ksplit > 1) {
+    const int D = p.D, ks = p.ksplit;
+    if (ks > 1) {
+        const int64_t slab_stride = (int64_t)p.maxq * D;
         for (int dir = 0; dir < 2; ++dir) {
             const Side& sd = p.side[dir];
             const int64_t total = (int64_t)sd.nq * D;
+            const float* base = p.slab + (int64_t)dir * ks * slab_stride;
             for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
                  i += (int64_t)gridDim.x * blockDim.x) {
                 float s = 0.f;
-                for (int k = 0; k < p.ksplit; ++k) s += p.slab[(((int64_t)dir * p.ksplit + k) * p.maxq) * D + i];
+                for (int k0 = 0; k0 < ks; k0 += 8) {              // eight independent loads per wait, summed in split order
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = base[(int64_t)min(k0 + j, ks - 1) * slab_stride + i];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (k0 + j < ks) s += v[j];
+                }
                 sd.dQ[(i / D) * sd.ldd + (i % D)] = f * s;
             }
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x < 2 && dscal_out) {
-        double s = 0.0;
-        for (int k = 0; k < n_scal; ++k) s += p.scal[2 * k + threadIdx.x];
-        dscal_out[threadIdx.x] = g * (float)s;
+    if (blockIdx.x == 0 && threadIdx.x < 128 && dscal_out) {          // wave 0: dscale, wave 1: dbias
+        const int which = threadIdx.x >> 6;
+        const double s = wave_sum_strided(p.scal + which, n_scal, 2, threadIdx.x & 63);
+        if ((threadIdx.x & 63) == 0) dscal_out[which] = g * (float)s;
     }
 }
 

@@ -23,12 +23,28 @@ from . import distributed as D
 from ._lib import check, lib, ptr, stream_ptr
 
 
+def _device_f32(*named):
+    """Every pointer handed to the C-ABI must be float32 device memory with unit column stride: a host pointer would
+    fault on the GPU (there is no CPU path to fall back to), so it is refused here."""
+    for name, t in named:
+        if t.device.type != "cuda":
+            raise _lib.MsnHipError(f"{name} must live on the GPU (got {t.device}); the contrastive loss has no CPU path")
+        if t.dtype != torch.float32:
+            raise _lib.MsnHipError(f"{name} must be float32 (got {t.dtype})")
+        if t.dim() == 2 and t.stride(1) != 1:
+            raise _lib.MsnHipError(f"{name} must have contiguous columns (strides {t.stride()})")
+
+
 class HipPairKernels:
     """The product compute backend: msn_infonce_fwd / msn_infonce_bwd through the C-ABI."""
 
     @staticmethod
     def forward(e1_loc, e2_loc, e1_all, e2_all, q_offset, log_scale, bias):
         _lib.require_gpu()
+        _device_f32(("embs1", e1_loc), ("embs2", e2_loc), ("embs1 (gathered)", e1_all), ("embs2 (gathered)", e2_all),
+                    ("logit_scale", log_scale), ("logit_bias", bias))
+        if e1_loc.shape[1] != e2_loc.shape[1] or e1_all.shape[1] != e1_loc.shape[1] or e2_all.shape[1] != e1_loc.shape[1]:
+            raise _lib.MsnHipError("both modalities must share the embedding width")
         b1, D = e1_loc.shape
         b2 = e2_loc.shape[0]
         n1, n2 = e1_all.shape[0], e2_all.shape[0]
@@ -47,6 +63,12 @@ class HipPairKernels:
 
     @staticmethod
     def backward(e1_loc, e2_loc, e1_all, e2_all, q_offset, log_scale, bias, lse_row_all, lse_col_all, grad_out):
+        _device_f32(("embs1", e1_loc), ("embs2", e2_loc), ("embs1 (gathered)", e1_all), ("embs2 (gathered)", e2_all),
+                    ("logit_scale", log_scale), ("logit_bias", bias), ("lse_row", lse_row_all), ("lse_col", lse_col_all),
+                    ("grad_out", grad_out))
+        if lse_row_all.numel() < e2_all.shape[0] or lse_col_all.numel() < e1_all.shape[0]:
+            raise _lib.MsnHipError("backward needs the log-sum-exp of every gathered row")
+        lse_row_all, lse_col_all = lse_row_all.contiguous(), lse_col_all.contiguous()
         b1, D = e1_loc.shape
         b2 = e2_loc.shape[0]
         n1, n2 = e1_all.shape[0], e2_all.shape[0]
@@ -249,6 +271,8 @@ class _SigmoidPair(torch.autograd.Function):
             q_offset = dist.get_rank(group) * e1.shape[0]
         else:
             e1_all, e2_all, q_offset = e1, e2, 0
+        _device_f32(("embs1", e1), ("embs2", e2), ("embs1 (gathered)", e1_all), ("embs2 (gathered)", e2_all),
+                    ("logit_scale", log_scale), ("logit_bias", bias))
         b, D = e1.shape
         n = e1_all.shape[0]
         L = lib()

@@ -58,6 +58,13 @@ def _check_sharded_loader(loader, group, what):
                          "into equal parts (e.g. DistributedSampler(drop_last=True))")
 
 
+def _hook(model, name):
+    """A Lightning hook is optional on the module (LightningModule supplies no-op defaults)."""
+    fn = getattr(model, name, None)
+    if callable(fn):
+        fn()
+
+
 class Trainer:
     def __init__(self, max_epochs=1, device=None, group=None, log_fn=None, sync_batchnorm=False, graphed_steps=False):
         self.max_epochs = max_epochs
@@ -85,7 +92,7 @@ class Trainer:
         graphed = GraphedTrainStep(model.train(), optimizer) if self.graphed_steps and D.world_size(self.group) == 1 else None
         for epoch in range(self.max_epochs):
             model.train()
-            model.on_train_epoch_start()
+            _hook(model, "on_train_epoch_start")
             losses, rows = [], []
             for batch_idx, batch in enumerate(train_dataloaders):
                 batch = _to_device(batch, self.device)
@@ -101,7 +108,7 @@ class Trainer:
                 optimizer.step()
                 losses.append(loss.detach())
                 self.global_step += 1
-            model.on_train_epoch_end()
+            _hook(model, "on_train_epoch_end")
             self.step_losses += losses
             if losses:
                 self.history["train_loss"].append(_weighted_mean(losses, rows))
@@ -127,7 +134,7 @@ class Trainer:
         short last batch or an uneven shard cannot hang or mix row counts), then the batch-weighted loss sums are
         all-reduced once; the retrieval AUC a rank logs is that of its own shard."""
         model.eval()
-        model.on_validation_start()
+        _hook(model, "on_validation_start")
         vlosses, vrows = [], []
         had = getattr(model, "global_negatives", None)
         if world > 1 and had is not None:
@@ -141,7 +148,7 @@ class Trainer:
         finally:
             if world > 1 and had is not None:
                 model.global_negatives = had
-        model.on_validation_epoch_end()
+        _hook(model, "on_validation_epoch_end")
         if not vlosses and world == 1:
             return
         w = torch.tensor(vrows, dtype=torch.float64, device=self.device)

