@@ -204,6 +204,12 @@ int msn_masked_pool_bwd(const float* dout, const uint8_t* mask, int64_t B, int T
 /* y[r,:] = x[r,:] * mask[r]  (the `x * mask[:, :, None]` of :235; its own backward) */
 int msn_mask_tokens(const float* x, const uint8_t* mask, int64_t rows, int e, float* y, msn_stream_t stream);
 
+/* dst[r][0..cols) += src[r][0..cols) for r < rows, both row-strided (cols, ldd, lds multiples of 4; 16-byte aligned).
+ * The class-token read-out of the build-defined ViT: only token 0 of the last block feeds the head, so that block's
+ * attention output / MLP run on the B class rows alone and their input gradient is added back into row 0 of every
+ * sample of the dense (B, T, e) gradient (no reference counterpart: the ViT is build-defined). */
+int msn_add_rows(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t rows, int cols, msn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused multi-head attention, exact fp32, no T x T tensor in memory -- SelfAttention.forward,
  * src/transformer_utils.py:36-89 (scale = 1/sqrt(emb); key-padding scores REPLACED by -1e7), also

@@ -48,6 +48,7 @@ SIGNATURES = {
     "msn_masked_pool_fwd": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
     "msn_masked_pool_bwd": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
     "msn_mask_tokens": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
+    "msn_add_rows": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_ptr]),
     "msn_attention_fwd": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr,
                                   c_int, c_int, c_int, c_int, c_int, c_f32, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     "msn_attention_bwd": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr,

@@ -752,6 +752,32 @@ extern "C" int msn_mask_tokens(const float* x, const uint8_t* mask, int64_t rows
     return MSN_OK;
 }
 
+// dst[r][c] += src[r][c] over a (rows x cols) window of two row-strided matrices (cols % 4 == 0, 16-byte aligned rows).
+__global__ void add_rows_kernel(float* __restrict__ dst, int64_t ldd, const float* __restrict__ src, int64_t lds,
+                                int64_t rows, int cols4) {
+    const int64_t total = rows * cols4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols4;
+        const int c = (int)(i % cols4) * 4;
+        float4 a = *reinterpret_cast<const float4*>(dst + r * ldd + c);
+        const float4 b = *reinterpret_cast<const float4*>(src + r * lds + c);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        *reinterpret_cast<float4*>(dst + r * ldd + c) = a;
+    }
+}
+
+extern "C" int msn_add_rows(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t rows, int cols,
+                            msn_stream_t stream) {
+    MSN_REQUIRE(dst && src && rows > 0 && cols > 0 && cols % 4 == 0 && ldd % 4 == 0 && lds % 4 == 0 && ldd >= cols &&
+                    lds >= cols && (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0,
+                "msn_add_rows: bad arguments (cols and both leading dimensions must be multiples of 4, 16-byte aligned)");
+    const int64_t total = rows * (cols / 4);
+    hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 4096)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), dst, ldd, src, lds, rows, cols / 4);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
 extern "C" int msn_vit_tokens_fwd(const float* patch, const float* cls, const float* pos, int64_t B, int T, int e,
                                   float* tok, msn_stream_t stream) {
     MSN_REQUIRE(patch && cls && pos && tok && B > 0 && T > 1 && e > 0, "msn_vit_tokens_fwd: bad arguments");

@@ -180,12 +180,14 @@ def l2_normalise(x):
 
 
 # ------------------------------------------------------------------------------ self-attention
-def _attn_forward_raw(x2, B, T, wq, wk, wv, wu, bu, mask_u8, heads, scale, residual):
+def _attn_forward_raw(x2, B, T, wq, wk, wv, wu, bu, mask_u8, heads, scale, residual, wcat=None):
     """x2: (B*T, e).  Returns z = unify(attn) (+ residual) and what backward needs."""
     M, e = x2.shape
-    # the three bias-free projections read the same tokens: one product against the stacked (3e, e) weight
-    # (a 3 x e x e copy per call) instead of three passes over x2
-    wcat = torch.cat([wq, wk, wv], 0)                   # kept for backward (one copy per step, not two)
+    # the three bias-free projections read the same tokens: one product against the stacked (3e, e) weight instead of
+    # three passes over x2; `wcat` is the module's persistent stacked buffer (SelfAttention.stacked_qkv: the three
+    # parameters ARE its row blocks), a copy is made only for callers that hand over loose weights
+    if wcat is None:
+        wcat = torch.cat([wq, wk, wv], 0)
     qkv = sgemm(x2, wcat, OP_N, OP_T)
     q3 = qkv.view(B, T, 3 * e)
     a, lse = ops.attention_fwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], mask_u8, heads, scale)
@@ -220,11 +222,11 @@ class _SelfAttention(torch.autograd.Function):
     """ref transformer_utils.py:36-89 as one node (q/k/v GEMMs, fused attention, unifyheads)."""
 
     @staticmethod
-    def forward(ctx, x, mask_u8, heads, wk, wq, wv, wu, bu):
+    def forward(ctx, x, mask_u8, heads, wk, wq, wv, wu, bu, wcat):
         B, T, e = x.shape
         x2 = _c(x).view(B * T, e)
         scale = 1.0 / math.sqrt(e)
-        z, saved = _attn_forward_raw(x2, B, T, wq, wk, wv, wu, bu, mask_u8, heads, scale, None)
+        z, saved = _attn_forward_raw(x2, B, T, wq, wk, wv, wu, bu, mask_u8, heads, scale, None, wcat)
         ctx.dims = (B, T, e, heads, scale)
         ctx.mask = mask_u8
         ctx.save_for_backward(x2, wq, wk, wv, wu, *saved)
@@ -237,11 +239,11 @@ class _SelfAttention(torch.autograd.Function):
         dz = _c(dy).view(B * T, e)
         dx, dwq, dwk, dwv, dwu, dbu = _attn_backward_raw(dz, x2, B, T, (qkv, a2, lse, wcat), wq, wk, wv, wu, ctx.mask,
                                                          heads, scale, None)
-        return dx.view(B, T, e), None, None, dwk, dwq, dwv, dwu, dbu
+        return dx.view(B, T, e), None, None, dwk, dwq, dwv, dwu, dbu, None
 
 
-def self_attention(x, mask, heads, tokeys, toqueries, tovalues, unify_w, unify_b):
-    return _SelfAttention.apply(x, ops._mask_u8(mask), heads, tokeys, toqueries, tovalues, unify_w, unify_b)
+def self_attention(x, mask, heads, tokeys, toqueries, tovalues, unify_w, unify_b, wcat=None):
+    return _SelfAttention.apply(x, ops._mask_u8(mask), heads, tokeys, toqueries, tovalues, unify_w, unify_b, wcat)
 
 
 # ---------------------------------------------------------------- post-norm transformer block
@@ -252,11 +254,11 @@ class _PostNormBlock(torch.autograd.Function):
     residual-branch gradients ride in the dgrad epilogues."""
 
     @staticmethod
-    def forward(ctx, x, mask_u8, heads, drop_p, wk, wq, wv, wu, bu, g1, b1, w1, c1, w2, c2, g2, b2):
+    def forward(ctx, x, mask_u8, heads, drop_p, wk, wq, wv, wu, bu, g1, b1, w1, c1, w2, c2, g2, b2, wcat):
         B, T, e = x.shape
         x2 = _c(x).view(B * T, e)
         scale = 1.0 / math.sqrt(e)
-        z1, (qkv, a2, lse, wcat) = _attn_forward_raw(x2, B, T, wq, wk, wv, wu, bu, mask_u8, heads, scale, x2)
+        z1, (qkv, a2, lse, wcat) = _attn_forward_raw(x2, B, T, wq, wk, wv, wu, bu, mask_u8, heads, scale, x2, wcat)
         y1, m1, r1 = ops.layernorm_fwd(z1, g1, b1)
         seeds = None
         if drop_p > 0.0:                 # x = do(norm1(...)) / x = do(norm2(...)), ref :111-116
@@ -291,15 +293,16 @@ class _PostNormBlock(torch.autograd.Function):
         dz1, dg1, db1 = ops.layernorm_bwd(dy1, z1, m1, r1, g1)
         dx, dwq, dwk, dwv, dwu, dbu = _attn_backward_raw(dz1, x2, B, T, (qkv, a2, lse, wcat), wq, wk, wv, wu, ctx.mask,
                                                          heads, scale, dz1)  # + residual branch of LN1's input
-        return (dx.view(B, T, e), None, None, None, dwk, dwq, dwv, dwu, dbu, dg1, db1, dw1, dc1, dw2, dc2, dg2, db2)
+        return (dx.view(B, T, e), None, None, None, dwk, dwq, dwv, dwu, dbu, dg1, db1, dw1, dc1, dw2, dc2, dg2, db2, None)
 
 
-def post_norm_block(x, mask_u8, heads, p, drop_p=0.0):
+def post_norm_block(x, mask_u8, heads, p, drop_p=0.0, wcat=None):
     """p: dict with tokeys, toqueries, tovalues, unify_w, unify_b, norm1_w, norm1_b, ff0_w, ff0_b,
-    ff2_w, ff2_b, norm2_w, norm2_b.  drop_p > 0: dropout after both LayerNorms (train mode)."""
+    ff2_w, ff2_b, norm2_w, norm2_b.  drop_p > 0: dropout after both LayerNorms (train mode).
+    wcat: the persistent stacked [toqueries ; tokeys ; tovalues] matrix (SelfAttention.stacked_qkv) or None."""
     return _PostNormBlock.apply(x, mask_u8, heads, float(drop_p), p["tokeys"], p["toqueries"], p["tovalues"], p["unify_w"],
                                 p["unify_b"], p["norm1_w"], p["norm1_b"], p["ff0_w"], p["ff0_b"], p["ff2_w"],
-                                p["ff2_b"], p["norm2_w"], p["norm2_b"])
+                                p["ff2_b"], p["norm2_w"], p["norm2_b"], wcat)
 
 
 # ------------------------------------------------------------------- time / band embedding
@@ -561,6 +564,72 @@ class _PreNormBlock(torch.autograd.Function):
 
 def pre_norm_block(x, heads, p, eps=1e-6):
     return _PreNormBlock.apply(x, heads, eps, *p)
+
+
+@_remember_precision
+class _PreNormLastBlock(torch.autograd.Function):
+    """The LAST block of the build-defined ViT, evaluated for the class token only.  The head reads token 0 of the last
+    block's output and nothing else, so of that block only the class row of x + Attn(LN1(x)) and of the MLP is ever used
+    -- keys and values still come from every token.  Output (B, e) == pre_norm_block(x)[:, 0]; every gradient is identical
+    (the rows left out have exactly zero gradient in the full evaluation).  Saves, per step, the query / output
+    projections, the attention rows and the whole MLP of (T - 1) / T of the last block's tokens."""
+
+    @staticmethod
+    def forward(ctx, x, heads, eps, g1, b1, wqkv, bqkv, wo, bo, g2, b2, w1, c1, w2, c2):
+        B, T, e = x.shape
+        x3 = _c(x)
+        x2 = x3.view(B * T, e)
+        scale = 1.0 / math.sqrt(e // heads)
+        h1, m1, r1 = ops.layernorm_fwd(x2, g1, b1, eps)
+        kv = sgemm(h1, wqkv[e:], OP_N, OP_T, bias=bqkv[e:])                   # keys | values of every token
+        h1c = h1.view(B, T, e)[:, 0, :]                                       # class rows (row stride T * e)
+        q = sgemm(h1c, wqkv[:e], OP_N, OP_T, bias=bqkv[:e])                   # (B, e): the one query per sample
+        kv3 = kv.view(B, T, 2 * e)
+        a, lse = ops.attention_fwd(q.view(B, 1, e), kv3[..., :e], kv3[..., e:], None, heads, scale)
+        a2 = a.view(B, e)
+        x1 = sgemm(a2, wo, OP_N, OP_T, bias=bo, epilogue=EPI_ADD, aux=x3[:, 0, :])
+        h2, m2, r2 = ops.layernorm_fwd(x1, g2, b2, eps)
+        pre = torch.empty((B, w1.shape[0]), dtype=torch.float32, device=x.device)
+        f = sgemm(h2, w1, OP_N, OP_T, bias=c1, epilogue=EPI_GELU, aux=pre)
+        out = sgemm(f, w2, OP_N, OP_T, bias=c2, epilogue=EPI_ADD, aux=x1)
+        ctx.dims = (B, T, e, heads, scale)
+        ctx.save_for_backward(x2, g1, wqkv, wo, g2, w1, w2, m1, r1, h1, kv, q, a2, lse, x1, m2, r2, h2, pre, f)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, e, heads, scale = ctx.dims
+        (x2, g1, wqkv, wo, g2, w1, w2, m1, r1, h1, kv, q, a2, lse, x1, m2, r2, h2, pre, f) = ctx.saved_tensors
+        d = _c(dy)
+        dw2, dc2 = ops.wgrad_bias(d, f)
+        dpre = sgemm(d, w2, OP_N, OP_N, epilogue=EPI_GELU_BWD, aux=pre)
+        dw1, dc1 = ops.wgrad_bias(dpre, h2)
+        dh2 = sgemm(dpre, w1, OP_N, OP_N)
+        dx1, dg2, db2 = ops.layernorm_bwd(dh2, x1, m2, r2, g2, add=d)         # + skip connection
+        dwo, dbo = ops.wgrad_bias(dx1, a2)
+        da = sgemm(dx1, wo, OP_N, OP_N)
+        dq = torch.empty((B, 1, e), dtype=torch.float32, device=d.device)
+        dkv = torch.empty_like(kv)
+        kv3, d3 = kv.view(B, T, 2 * e), dkv.view(B, T, 2 * e)
+        ops.attention_bwd(q.view(B, 1, e), kv3[..., :e], kv3[..., e:], None, heads, scale, a2.view(B, 1, e), lse,
+                          da.view(B, 1, e), dq, d3[..., :e], d3[..., e:])
+        dq2 = dq.view(B, e)
+        h1c = h1.view(B, T, e)[:, 0, :]
+        dwqkv = torch.empty_like(wqkv)
+        dbqkv = torch.empty(3 * e, dtype=torch.float32, device=d.device)
+        ops.wgrad_bias(dq2, h1c, out=(dwqkv[:e], dbqkv[:e]))
+        ops.wgrad_bias(dkv, h1, out=(dwqkv[e:], dbqkv[e:]))
+        dh1 = sgemm(dkv, wqkv[e:], OP_N, OP_N)
+        dh1c = dh1.view(B, T, e)[:, 0, :]
+        sgemm(dq2, wqkv[:e], OP_N, OP_N, epilogue=EPI_ADD, aux=dh1c, out=dh1c)   # the query branch reaches class rows only
+        dx, dg1, db1 = ops.layernorm_bwd(dh1, x2, m1, r1, g1)
+        ops.add_rows(dx.view(B, T, e)[:, 0, :], dx1)                          # skip connection of the class rows
+        return (dx.view(B, T, e), None, None, dg1, db1, dwqkv, dbqkv, dwo, dbo, dg2, db2, dw1, dc1, dw2, dc2)
+
+
+def pre_norm_last_block(x, heads, p, eps=1e-6):
+    """(B, T, e) -> (B, e): the class-token row of pre_norm_block(x, ...)."""
+    return _PreNormLastBlock.apply(x, heads, eps, *p)
 
 
 class _VitTokens(torch.autograd.Function):

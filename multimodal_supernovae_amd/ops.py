@@ -95,16 +95,21 @@ def sgemm(a, b, op_a=OP_N, op_b=OP_T, bias=None, epilogue=EPI_NONE, aux=None, ou
     return c
 
 
-def wgrad_bias(dy, x, precision=None):
-    """Weight and bias gradient of y = x W^T + b in one call: (dy^T x, column sums of dy) (msn_wgrad_bias)."""
+def wgrad_bias(dy, x, precision=None, out=None):
+    """Weight and bias gradient of y = x W^T + b in one call: (dy^T x, column sums of dy) (msn_wgrad_bias).
+    `out` = (dw, db) contiguous destinations, e.g. row blocks of a stacked gradient."""
     _f32c(dy, "dy"), _f32c(x, "x")
     assert dy.dim() == 2 and x.dim() == 2 and dy.stride(1) == 1 and x.stride(1) == 1
     K, M = dy.shape
     if x.shape[0] != K:
         raise _lib.MsnHipError(f"wgrad_bias: row counts differ ({K} vs {x.shape[0]})")
     N = x.shape[1]
-    dw = torch.empty((M, N), dtype=torch.float32, device=dy.device)
-    db = torch.empty(M, dtype=torch.float32, device=dy.device)
+    if out is not None:
+        dw, db = out
+        assert dw.shape == (M, N) and dw.is_contiguous() and db.shape == (M,) and db.is_contiguous()
+    else:
+        dw = torch.empty((M, N), dtype=torch.float32, device=dy.device)
+        db = torch.empty(M, dtype=torch.float32, device=dy.device)
     L = lib()
     nb = L.msn_wgrad_bias_workspace_bytes(M, N, K)
     ws = _workspace(nb, dy.device)
@@ -241,6 +246,14 @@ def masked_pool_bwd(dout, mask_u8, T, mode, arg, cnt):
     check(lib().msn_masked_pool_bwd(ptr(_f32c(dout, "dout")), ptr(mask_u8), B, T, e, mode, ptr(arg), ptr(cnt), ptr(dx),
                                     stream_ptr()), "msn_masked_pool_bwd")
     return dx
+
+
+def add_rows(dst, src):
+    """dst += src for two (rows, cols) row-strided views (in place)."""
+    assert dst.dim() == 2 and src.shape == dst.shape and dst.stride(1) == 1 and src.stride(1) == 1
+    check(lib().msn_add_rows(ptr(_f32c(dst, "dst")), dst.stride(0), ptr(_f32c(src, "src")), src.stride(0), dst.shape[0],
+                             dst.shape[1], stream_ptr()), "msn_add_rows")
+    return dst
 
 
 def mask_tokens(x, mask_u8):

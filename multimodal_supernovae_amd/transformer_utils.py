@@ -30,10 +30,29 @@ class SelfAttention(nn.Module):
         self.tovalues = nn.Linear(emb, emb, bias=False)
         self.unifyheads = nn.Linear(emb, emb)
 
+    def stacked_qkv(self):
+        """The (3 emb, emb) matrix [toqueries ; tokeys ; tovalues] the fused projection multiplies by, WITHOUT a copy per
+        step: the three weights live side by side in one buffer (the parameters are re-pointed at row blocks of it the
+        first time -- and again should a `.to()` / `.cuda()` have moved them apart), so the optimiser's in-place updates
+        land in the stacked matrix directly.  state_dict keys, shapes and values are unchanged."""
+        wq, wk, wv = self.toqueries.weight, self.tokeys.weight, self.tovalues.weight
+        e = self.emb
+        nbytes = e * e * wq.element_size()
+        adjacent = (wq.is_contiguous() and wk.is_contiguous() and wv.is_contiguous() and wq.device == wk.device == wv.device
+                    and wk.data_ptr() == wq.data_ptr() + nbytes and wv.data_ptr() == wk.data_ptr() + nbytes
+                    and wq.untyped_storage().data_ptr() == wv.untyped_storage().data_ptr())
+        if not adjacent:
+            if torch.cuda.is_available() and wq.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("SelfAttention weights must be stacked before a HIP-graph capture: run one eager step first")
+            with torch.no_grad():
+                stacked = torch.cat([wq.detach(), wk.detach(), wv.detach()], dim=0)
+                wq.data, wk.data, wv.data = stacked[:e], stacked[e:2 * e], stacked[2 * e:]
+        return wq.data.as_strided((3 * e, e), (e, 1))
+
     def forward(self, x, mask=None):
         assert x.shape[-1] == self.emb, f"Input embedding dim ({x.shape[-1]}) should match layer embedding dim ({self.emb})"
         return F_.self_attention(x, mask, self.heads, self.tokeys.weight, self.toqueries.weight, self.tovalues.weight,
-                                 self.unifyheads.weight, self.unifyheads.bias)
+                                 self.unifyheads.weight, self.unifyheads.bias, wcat=self.stacked_qkv())
 
 
 class TransformerBlock(nn.Module):
@@ -57,7 +76,8 @@ class TransformerBlock(nn.Module):
 
     def forward(self, x, mask=None):
         return F_.post_norm_block(x, _mask_bytes(mask) if mask is None or mask.dtype != torch.uint8 else mask,
-                                  self.attention.heads, self._params(), drop_p=self.do.p if self.training else 0.0)
+                                  self.attention.heads, self._params(), drop_p=self.do.p if self.training else 0.0,
+                                  wcat=self.attention.stacked_qkv())
 
 
 class Transformer(nn.Module):

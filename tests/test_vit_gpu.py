@@ -86,3 +86,27 @@ def test_vit_b16_geometry():
     assert (b.num_tokens, b.emb, b.heads, b.depth, b.gemm_precision) == (197, 768, 12, 12, "bf16")
     assert (s.num_tokens, s.emb, s.heads, s.depth, s.gemm_precision) == (65, 384, 6, 12, None)
     assert sum(p.numel() for p in b.parameters()) > 85e6
+
+
+@pytest.mark.parametrize("img,patch,emb,depth,heads,B", [(16, 4, 32, 2, 4, 3), (64, 8, 384, 2, 6, 5), (32, 16, 64, 1, 2, 2)])
+def test_class_token_only_last_block_is_exact(img, patch, emb, depth, heads, B):
+    """The last block evaluated for the class row alone == the dense evaluation: same output, same gradient for the
+    image and every parameter (the rows left out carry exactly zero gradient)."""
+    from multimodal_supernovae_amd.encoders import VisionTransformer
+    torch.manual_seed(img)
+    m = VisionTransformer(img_size=img, patch_size=patch, channels=3, emb=emb, depth=depth, heads=heads, n_out=8).cuda()
+    x = torch.rand(B, 3, img, img, device="cuda")
+    cot = torch.randn(B, 8, device="cuda")
+    res = []
+    for flag in (True, False):
+        m.cls_only_last_block = flag
+        m.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_()
+        y = m(xg)
+        y.backward(cot)
+        res.append((y.detach().clone(), xg.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    (ya, dxa, ga), (yb, dxb, gb) = res
+    torch.testing.assert_close(ya, yb, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(dxa, dxb, rtol=1e-4, atol=1e-6 * float(dxb.abs().max()) + 1e-9)
+    for k in ga:
+        torch.testing.assert_close(ga[k], gb[k], rtol=1e-4, atol=2e-5 * float(gb[k].abs().max()) + 1e-9, msg=lambda s: f"{k}: {s}")
