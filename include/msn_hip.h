@@ -211,6 +211,34 @@ int msn_mask_tokens(const float* x, const uint8_t* mask, int64_t rows, int e, fl
 int msn_add_rows(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t rows, int cols, msn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * bf16-RESIDENT products for BASELINE.json configs[4] (ViT-B/16 "bf16 on MFMA"; build-defined encoder, no reference
+ * counterpart -- the reference has no mixed precision): operands are bf16 in HBM (uint16 bit patterns), accumulation fp32.
+ *   msn_bgemm_nt:  C[M][N] = epi(A[M][K] . B[N][K]^T + bias); K % 64 == 0, N % 4 == 0, 16-byte aligned rows.
+ *                  epilogue 0 none (C fp32 or bf16), 1 GELU (aux <- bf16 pre-activation, C <- bf16 gelu), 2 GELU' (C <-
+ *                  acc * gelu'(aux bf16); C fp32 or bf16), 3 ADD (C fp32 <- acc + bias + aux fp32).
+ *   msn_bgemm_tn:  C[N][K] (fp32) = sum_m A[m][N]^T . B[m][K]  (weight gradient dY^T . X), reduction split over m with
+ *                  fixed-order slab sums; ws >= msn_bgemm_tn_workspace_bytes.
+ *   msn_cast_bf16 / msn_cast_bf16_transposed: y = bf16(x) (n % 8 == 0) / y[c][r] = bf16(x[r][c]).
+ *   msn_bcolsum:   out[n] = sum_m X[m][n] for bf16 X (bias gradients).
+ *   msn_layernorm_fwd_bf16 / msn_layernorm_bwd_bf16: nn.LayerNorm as msn_layernorm_fwd / _bwd, writing y as bf16 /
+ *                  writing a bf16 copy of dx next to the fp32 one. */
+int msn_bgemm_nt(int64_t M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                 int c_bf16, const float* bias, int epilogue, void* aux, int64_t ldaux, msn_stream_t stream);
+size_t msn_bgemm_tn_workspace_bytes(int64_t M, int N, int K);
+int msn_bgemm_tn(int64_t M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
+                 void* ws, size_t ws_bytes, msn_stream_t stream);
+int msn_cast_bf16(const float* x, int64_t n, void* y, msn_stream_t stream);
+int msn_cast_bf16_transposed(const float* x, int R, int C, void* y, msn_stream_t stream);
+size_t msn_bcolsum_workspace_bytes(int64_t M, int N);
+int msn_bcolsum(const void* X, int64_t ldx, int64_t M, int N, float* out, void* ws, size_t ws_bytes, msn_stream_t stream);
+int msn_layernorm_fwd_bf16(const float* x, int64_t ldx, int64_t rows, int cols, const float* gamma, const float* beta,
+                           float eps, void* y_bf16, int64_t ldy, float* mean, float* rstd, msn_stream_t stream);
+int msn_layernorm_bwd_bf16(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t rows, int cols,
+                           const float* mean, const float* rstd, const float* gamma, const float* add, int64_t ldadd,
+                           float* dx, int64_t lddx, void* dx_bf16, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                           msn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused multi-head attention, exact fp32, no T x T tensor in memory -- SelfAttention.forward,
  * src/transformer_utils.py:36-89 (scale = 1/sqrt(emb); key-padding scores REPLACED by -1e7), also
  * the 1-query nn.MultiheadAttention pooling (:240-246) and the build-defined ViT blocks.

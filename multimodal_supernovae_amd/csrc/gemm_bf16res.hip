@@ -1,0 +1,589 @@
+// GEMMs with bf16-RESIDENT operands on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16, fp32 accumulate) -- the
+// BASELINE cfg5 image tower (build-defined ViT-B/16; no reference counterpart: the reference has no mixed precision).
+//
+// The older msn::bgemm_kernel keeps every tensor fp32 in HBM and rounds to bf16 between the global load and the LDS
+// write: with 128 x 128 tiles that moves 32 KB L2 -> LDS per MFLOP and is L2-bound at 13 % of the matrix peak.  Here
+// the operands ARE bf16 in HBM (LayerNorm / GELU / attention epilogues write them; weights are rounded once per step),
+// so a K-tile travels global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write) at half
+// the bytes, and the tile is 256 x 256 (16 KB L2 -> LDS per MFLOP).
+//
+//   msn_bgemm_nt :  C[M][N] = epi( A[M][K] . B[N][K]^T + bias )      both operands K-contiguous
+//                   (forward: activations x weight; dgrad: dY x W^T with the pre-transposed bf16 weight copy)
+//   msn_bgemm_tn :  C[N][K] = sum_m A[m][N]^T . B[m][K]               both operands reduction-MAJOR
+//                   (wgrad: dY^T . X; fragments come out of LDS transposed by ds_read_b64_tr_b16; split over m,
+//                    fp32 partial slabs summed in a fixed order)
+//
+// Workgroup = 8 waves (2 x 4), tile 256 x 256, K-step 64, two LDS K-tile buffers of 64 KB.  A wave owns 128 x 64 of
+// the tile = 8 x 4 MFMA tiles of 16 x 16 (128 accumulator registers) and walks a K-tile in four phases of 16 MFMAs
+// (k32 half x 64-row half); the fragments of the next phase are requested before the MFMAs of the current one
+// (ds_read from inline asm with hand-counted lgkmcnt: hipcc would otherwise drain the LDS-DMA queue with vmcnt(0)
+// before every LDS read), the LDS-DMA of K-tile t + 2 is issued in the middle of K-tile t (one full K-tile of lead),
+// ONE raw s_barrier per K-tile.  MFMA operands are swapped (D^T = B . A^T) so that a lane ends up with four CONSECUTIVE
+// output columns of one row: 16-byte stores.  LDS images are written linearly by the DMA and XOR-swizzled on the
+// SOURCE address, with the same XOR on the fragment reads: conflict-free for both read shapes (derivation at `swz`).
+#include <algorithm>
+
+#include "msn_common.h"
+
+namespace msn {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+constexpr int BT = 256;            // tile rows / columns
+constexpr int BKS = 64;            // K-step (elements)
+constexpr int OPER_BYTES = BT * BKS * 2;      // one operand of one K-tile: 32 KB
+constexpr int STAGE_BYTES = 2 * OPER_BYTES;   // 64 KB
+constexpr int EPI_B_NONE = 0, EPI_B_GELU = 1, EPI_B_GELU_BWD = 2, EPI_B_ADD = 3;
+
+__device__ __forceinline__ float bf2f(u16 v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ u16 f2bf(float f) {          // round to nearest even; NaN stays NaN (plain cast)
+    const __bf16 b = (__bf16)f;
+    return *reinterpret_cast<const u16*>(&b);
+}
+
+struct BgemmArgs {
+    const u16* A; const u16* B;
+    void* C; void* aux; const float* bias;
+    int64_t lda, ldb, ldc, ldaux;
+    int64_t M;                 // NT: rows of A / C.  TN: reduction length
+    int N, K;                  // NT: C is M x N, reduction K.  TN: C is N x K
+    int tiles_m, tiles_n;      // NT: tile grid.  TN: tiles over N and K
+    int splits; int64_t rows_per_split;   // TN: reduction split
+    float* slabs;              // TN: [splits][N][K] partials (splits > 1)
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// NT: LDS image of one operand K-tile = [256 rows][128 B] (row = 64 bf16 of k), 16-byte chunk c of row r stored at
+// chunk position c ^ swz(r), swz(r) = (r >> 1) & 7.  A ds_read_b128 of the 16x16x32 operand takes, per 16-lane issue
+// group, rows {0-3, 12-15} at chunk c and rows {4-11} at chunk c ^ 1 (lane l: row l & 15, chunk 4 kk + (l >> 4)):
+// 16-byte slot in the 256-byte bank row = 8 (r & 1) + (c ^ swz(r)); even rows land on 8 distinct slots of the lower
+// half, odd rows on 8 distinct slots of the upper half -> conflict-free.
+__device__ __forceinline__ int swz(int r) { return (r >> 1) & 7; }
+
+__device__ __forceinline__ void ds_read128(bf16x8& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+}
+
+template <int EPI, bool OUT_BF16>
+__global__ __launch_bounds__(512, 2) void bgemm_nt_kernel(const BgemmArgs p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // XCD-aware order: workgroup ids are dealt round-robin to the 8 XCDs; give each XCD a contiguous run of tiles, and
+    // walk the tiles N-fastest so that the workgroups of one XCD share A row panels (and the whole weight) in its L2
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, x = bid % 8, i = bid / 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const int tm = bid / p.tiles_n, tn = bid % p.tiles_n;
+    const int64_t m0 = (int64_t)tm * BT;
+    const int n0 = tn * BT;
+
+    // ---- LDS-DMA sources: wave w moves pieces 4w .. 4w+3 (8 rows x 128 B each) of both operands
+    const u16* srcA[4];
+    const u16* srcB[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int R = 8 * (4 * wave + q) + (lane >> 3);
+        const int c = (lane & 7) ^ swz(R);
+        const int64_t ra = std::min<int64_t>(m0 + R, p.M - 1);        // rows past the edge: clamped, never stored
+        const int64_t rb = std::min<int64_t>((int64_t)n0 + R, p.N - 1);
+        srcA[q] = p.A + ra * p.lda + 8 * c;
+        srcB[q] = p.B + rb * p.ldb + 8 * c;
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t*)lds;   // LDS byte address of the array
+    auto issue = [&](int buf, int kt) {
+        unsigned char* dst = lds + buf * STAGE_BYTES + wave * 4096;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(srcA[q] + (int64_t)kt * BKS), (lptr_t*)(dst + q * 1024), 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(srcB[q] + (int64_t)kt * BKS), (lptr_t*)(dst + OPER_BYTES + q * 1024), 16, 0, 0);
+    };
+
+    // ---- fragment addresses: wave (wm, wn) owns rows 128 wm .. +127 of A, rows (= output columns) 64 wn .. +63 of B
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l15 = lane & 15, g = lane >> 4;
+    // row = base + 16 i + l15: swz(row) = l15 >> 1 for every i;  chunk(kk) = (4 kk + g) ^ swz
+    const unsigned fragA = (unsigned)((wm * 128 + l15) * 128 + 16 * (g ^ (l15 >> 1)));
+    const unsigned fragB = (unsigned)(OPER_BYTES + (wn * 64 + l15) * 128 + 16 * (g ^ (l15 >> 1)));
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa[2][4], fb[2][4];
+
+    // set S of A fragments <- m-tiles 4 mh .. 4 mh + 3 at k32 half kk;  set S of B fragments <- all 4 n-tiles at kk
+#define REQ_A(S, buf, kk, mh)                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                  \
+        ds_read128(fa[S][i], lds0 + (buf) * STAGE_BYTES + (fragA ^ ((kk) << 6)) + (4 * (mh) + i) * 2048);
+#define REQ_B(S, buf, kk)                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                  \
+        ds_read128(fb[S][j], lds0 + (buf) * STAGE_BYTES + (fragB ^ ((kk) << 6)) + j * 2048);
+    // D^T tile = B_frag . A_frag^T: lane gets row m = l15 of the tile and columns n = 4 g .. 4 g + 3
+#define MULT(SA, SB, mh)                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)                    \
+        acc[4 * (mh) + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[SB][j], fa[SA][i], acc[4 * (mh) + i][j], 0, 0, 0);
+#define WAIT_LGKM(n)                                           \
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory"); \
+    __builtin_amdgcn_sched_barrier(0);
+
+    const int nkt = p.K / BKS;
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (nkt > 1) issue(1, 1);
+    REQ_A(0, 0, 0, 0)
+    REQ_B(0, 0, 0)
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        // phase 0: k32 half 0, m-tiles 0-3
+        REQ_A(1, cur, 0, 1)
+        WAIT_LGKM(4)
+        MULT(0, 0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 1: k32 half 0, m-tiles 4-7
+        REQ_A(0, cur, 1, 0)
+        REQ_B(1, cur, 1)
+        WAIT_LGKM(8)
+        MULT(1, 0, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 2: k32 half 1, m-tiles 0-3
+        REQ_A(1, cur, 1, 1)
+        WAIT_LGKM(4)
+        MULT(0, 1, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 3: every fragment of this K-tile is in registers -> the buffer may be refilled; K-tile kt + 1 (issued one
+        // K-tile ago) must have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nkt) issue(cur, kt + 2);
+        if (kt + 1 < nkt) {
+            REQ_A(0, cur ^ 1, 0, 0)
+            REQ_B(0, cur ^ 1, 0)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        MULT(1, 1, 1)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef REQ_A
+#undef REQ_B
+#undef MULT
+
+    // ---- epilogue: lane holds, per (i, j) tile, row m = 16 i + l15 and columns n = 16 j + 4 g .. + 3
+    const int64_t mrow0 = m0 + wm * 128 + l15;
+    const int ncol0 = n0 + wn * 64 + 4 * g;
+    float4 bias4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = ncol0 + 16 * j;
+        bias4[j] = (p.bias && n + 3 < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int64_t m = mrow0 + 16 * i;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = ncol0 + 16 * j;
+            if (n + 3 >= p.N) continue;                        // N % 4 == 0 (checked on the host)
+            float v[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z,
+                          acc[i][j][3] + bias4[j].w};
+            if constexpr (EPI == EPI_B_GELU) {                 // aux <- pre-activation (bf16), C <- gelu(pre)
+                u16* ap = static_cast<u16*>(p.aux) + m * p.ldaux + n;
+                ushort4 pre;
+                pre.x = f2bf(v[0]); pre.y = f2bf(v[1]); pre.z = f2bf(v[2]); pre.w = f2bf(v[3]);
+                *reinterpret_cast<ushort4*>(ap) = pre;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+            } else if constexpr (EPI == EPI_B_GELU_BWD) {      // C <- acc * gelu'(aux), aux = saved bf16 pre-activation
+                const ushort4 pre = *reinterpret_cast<const ushort4*>(static_cast<const u16*>(p.aux) + m * p.ldaux + n);
+                v[0] *= gelu_grad_f(bf2f(pre.x)); v[1] *= gelu_grad_f(bf2f(pre.y));
+                v[2] *= gelu_grad_f(bf2f(pre.z)); v[3] *= gelu_grad_f(bf2f(pre.w));
+            } else if constexpr (EPI == EPI_B_ADD) {           // C <- acc + bias + aux (fp32 residual)
+                const float4 a = *reinterpret_cast<const float4*>(static_cast<const float*>(p.aux) + m * p.ldaux + n);
+                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+            }
+            if constexpr (OUT_BF16) {
+                ushort4 o;
+                o.x = f2bf(v[0]); o.y = f2bf(v[1]); o.z = f2bf(v[2]); o.w = f2bf(v[3]);
+                *reinterpret_cast<ushort4*>(static_cast<u16*>(p.C) + m * p.ldc + n) = o;
+            } else {
+                *reinterpret_cast<float4*>(static_cast<float*>(p.C) + m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// TN: both operands are [m][cols] with the reduction index m on the ROWS.  LDS image of one operand K-step =
+// [64 rows of m][512 B] (256 bf16 of n or k); the MFMA wants, per lane, 8 consecutive m of one column: two
+// ds_read_b64_tr_b16 (each delivers a 4-row x 16-column block column-major to a 16-lane group; lane 4q + p of the group
+// supplies the address of row q, columns 4p .. 4p+3; lane i receives column i).  Banking is per 32-lane half = two
+// groups = rows {8 g2 + 4 h + q : g2 in 0..1, q in 0..3} x 32 bytes: the 32-byte chunk index (low three bits) of row r
+// is XORed with tsw(r) = (r & 3) | ((r >> 3) & 1) << 2, which is distinct over those eight rows -> conflict-free.
+__device__ __forceinline__ int tsw(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+__device__ __align__(16) const unsigned char g_zero_page[16] = {0};
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ds_read_tr(bf16x4& dst, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr));
+}
+
+__global__ __launch_bounds__(512, 2) void bgemm_tn_kernel(const BgemmArgs p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tiles = p.tiles_m * p.tiles_n;               // tiles over (N, K)
+    const int split = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int tn = tile / p.tiles_n, tk = tile % p.tiles_n;
+    const int n0 = tn * BT, k0 = tk * BT;
+    const int64_t m_begin = (int64_t)split * p.rows_per_split;
+    const int64_t m_end = std::min<int64_t>(p.M, m_begin + p.rows_per_split);
+    const int nkt = (int)((m_end - m_begin + BKS - 1) / BKS);
+
+    // ---- LDS-DMA: a piece = 2 rows x 512 B; wave w moves pieces 4w .. 4w+3 (rows 8w .. 8w+7) of both operands.
+    // lane i of a piece: row i / 32, 16-byte slot s = i % 32 <- source chunk c = (s >> 1) with its low 3 bits ^ tsw(row)
+    int64_t offA[4], offB[4];
+    int rloc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int R = 2 * (4 * wave + q) + (lane >> 5);
+        const int s = lane & 31;
+        const int c = (((s >> 1) & 7) ^ tsw(R)) | ((s >> 1) & 8);
+        const int col = 16 * c + 8 * (s & 1);                     // element column inside the 256-wide tile
+        rloc[q] = R;
+        // columns past N / K: clamped (their products are never stored)
+        offA[q] = (int64_t)R * p.lda + std::min(n0 + col, p.N - 8);
+        offB[q] = (int64_t)R * p.ldb + std::min(k0 + col, p.K - 8);
+    }
+    auto issue = [&](int buf, int kt) {
+        unsigned char* dst = lds + buf * STAGE_BYTES + wave * 4096;
+        const int64_t mb = m_begin + (int64_t)kt * BKS;
+        const int left = (int)std::min<int64_t>(m_end - mb, BKS);  // rows of this K-step that exist: the rest read zeros
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u16* sa = rloc[q] < left ? p.A + mb * p.lda + offA[q] : reinterpret_cast<const u16*>(g_zero_page);
+            __builtin_amdgcn_global_load_lds((gptr_t*)sa, (lptr_t*)(dst + q * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u16* sb = rloc[q] < left ? p.B + mb * p.ldb + offB[q] : reinterpret_cast<const u16*>(g_zero_page);
+            __builtin_amdgcn_global_load_lds((gptr_t*)sb, (lptr_t*)(dst + OPER_BYTES + q * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragments.  Output tile rows = n (operand A = dY), columns = k (operand B = X).  Wave (wr, wc): n in
+    // [128 wr, +128) = 8 tiles, k in [64 wc, +64) = 4 tiles.  Swapped MFMA operands again: D[k][n] -> lane holds
+    // n = l15 and k = 4 g .. 4 g + 3 ... see the epilogue.
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l15 = lane & 15, g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+    // a tr read: lane supplies row (32 kk + 8 g + 4 h + tq), byte (2 * col0 + 8 tp) of that row, chunk-swizzled.
+    // tsw(row) depends on (tq, g & 1) only: (tq & 3) | ((8 g + 4 h + tq) >> 3 & 1) << 2 = tq | (g & 1) << 2
+    const int sw = tq | ((g & 1) << 2);
+    auto tr_addr = [&](int oper, int col0, int kk, int h) -> unsigned {
+        const int row = 32 * kk + 8 * g + 4 * h + tq;
+        const int byte = 2 * col0 + 8 * tp;                        // col0 % 16 == 0 -> 32-byte chunk index = byte >> 5
+        const int chunk = byte >> 5;
+        const int sbyte = (((chunk & 7) ^ sw) | (chunk & 8)) * 32 + (byte & 31);
+        return (unsigned)(oper * OPER_BYTES + row * 512 + sbyte);
+    };
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t*)lds;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x4 fa[2][4][2], fb[2][4][2];     // [set][tile][h]: elements m = 8 g + 4 h .. + 3 of the k32 block
+
+#define TREQ_A(S, buf, kk, nh)                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int h = 0; h < 2; ++h)                    \
+        ds_read_tr(fa[S][i][h], lds0 + (buf) * STAGE_BYTES + tr_addr(0, wr * 128 + 16 * (4 * (nh) + i), kk, h));
+#define TREQ_B(S, buf, kk)                                                                                         \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int h = 0; h < 2; ++h)                    \
+        ds_read_tr(fb[S][j][h], lds0 + (buf) * STAGE_BYTES + tr_addr(1, wc * 64 + 16 * j, kk, h));
+    // D = X_frag^T-as-A . dY_frag-as-B: rows of D = k, columns = n: lane holds n = l15, k = 4 g .. 4 g + 3
+#define TMULT(SA, SB, nh)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) {                  \
+        const bf16x8 av = __builtin_shufflevector(fa[SA][i][0], fa[SA][i][1], 0, 1, 2, 3, 4, 5, 6, 7);             \
+        const bf16x8 bv = __builtin_shufflevector(fb[SB][j][0], fb[SB][j][1], 0, 1, 2, 3, 4, 5, 6, 7);             \
+        acc[4 * (nh) + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv, av, acc[4 * (nh) + i][j], 0, 0, 0);     \
+    }
+
+    if (nkt > 0) {
+        issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (nkt > 1) issue(1, 1);
+        TREQ_A(0, 0, 0, 0)
+        TREQ_B(0, 0, 0)
+    }
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        // (lgkmcnt counts at most 15 outstanding: never more than 8 younger reads behind the ones waited for)
+        TREQ_A(1, cur, 0, 1)
+        WAIT_LGKM(8)
+        TMULT(0, 0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        TREQ_A(0, cur, 1, 0)
+        WAIT_LGKM(8)
+        TMULT(1, 0, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        TREQ_B(1, cur, 1)
+        TREQ_A(1, cur, 1, 1)
+        WAIT_LGKM(8)
+        TMULT(0, 1, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nkt) issue(cur, kt + 2);
+        if (kt + 1 < nkt) {
+            TREQ_A(0, cur ^ 1, 0, 0)
+            TREQ_B(0, cur ^ 1, 0)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        TMULT(1, 1, 1)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef TREQ_A
+#undef TREQ_B
+#undef TMULT
+#undef WAIT_LGKM
+
+    // ---- epilogue: C[n][k] (or this split's slab): lane holds n = n0 + wr 128 + 16 i + l15, k = k0 + wc 64 + 16 j + 4 g ..
+    float* out = p.splits > 1 ? p.slabs + (int64_t)split * p.N * p.K : static_cast<float*>(p.C);
+    const int64_t ldo = p.splits > 1 ? p.K : p.ldc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int n = n0 + wr * 128 + 16 * i + l15;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + wc * 64 + 16 * j + 4 * g;
+            if (k + 3 >= p.K) continue;
+            *reinterpret_cast<float4*>(out + (int64_t)n * ldo + k) =
+                make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    }
+}
+
+// C[i] = sum_s slab[s][i] in split order (float4 per thread, eight independent loads per wait)
+__global__ void bgemm_slab_sum_kernel(const float* __restrict__ slabs, int splits, int64_t n4, int K4, int64_t ldc4,
+                                      float* __restrict__ C) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k0 = 0; k0 < splits; k0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = reinterpret_cast<const float4*>(slabs)[(int64_t)std::min(k0 + j, splits - 1) * n4 + i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (k0 + j < splits) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
+        }
+        reinterpret_cast<float4*>(C)[(i / K4) * ldc4 + (i % K4)] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- casts, sums
+// y = bf16(x), 8 elements per thread
+__global__ void cast_bf16_kernel(const float* __restrict__ x, int64_t n8, u16* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+        uint4 o;
+        o.x = f2bf(a.x) | ((unsigned)f2bf(a.y) << 16); o.y = f2bf(a.z) | ((unsigned)f2bf(a.w) << 16);
+        o.z = f2bf(b.x) | ((unsigned)f2bf(b.y) << 16); o.w = f2bf(b.z) | ((unsigned)f2bf(b.w) << 16);
+        reinterpret_cast<uint4*>(y)[i] = o;
+    }
+}
+
+// y[c][r] = bf16(x[r][c]) through a 32 x 33 LDS tile (weights: a few MB per step)
+__global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float* __restrict__ x, int R, int C, u16* __restrict__ y) {
+    __shared__ float t[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        t[i][tx] = (r0 + i < R && c0 + tx < C) ? x[(int64_t)(r0 + i) * C + c0 + tx] : 0.f;
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < C && r0 + tx < R) y[(int64_t)(c0 + i) * R + r0 + tx] = f2bf(t[tx][i]);
+}
+
+// out[n] = sum_m X[m][n] for bf16 X: block partials of 8 columns per thread, then one fixed-order pass
+__global__ __launch_bounds__(256) void bcolsum_part_kernel(const u16* __restrict__ x, int64_t ld, int64_t M, int N8,
+                                                           int rows_per_block, float* __restrict__ part) {
+    const int c8 = blockIdx.x * 32 + (threadIdx.x & 31);          // group of 8 columns
+    const int ry = threadIdx.x >> 5;                               // 8 row lanes
+    __shared__ float red[8][32][8];
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c8 < N8) {
+        const int64_t r_begin = (int64_t)blockIdx.y * rows_per_block;
+        const int64_t r_end = std::min<int64_t>(M, r_begin + rows_per_block);
+        for (int64_t r = r_begin + ry; r < r_end; r += 8) {
+            const uint4 v = *reinterpret_cast<const uint4*>(x + r * ld + 8 * c8);
+            s[0] += bf2f((u16)(v.x & 0xffff)); s[1] += bf2f((u16)(v.x >> 16));
+            s[2] += bf2f((u16)(v.y & 0xffff)); s[3] += bf2f((u16)(v.y >> 16));
+            s[4] += bf2f((u16)(v.z & 0xffff)); s[5] += bf2f((u16)(v.z >> 16));
+            s[6] += bf2f((u16)(v.w & 0xffff)); s[7] += bf2f((u16)(v.w >> 16));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[ry][threadIdx.x & 31][k] = s[k];
+    __syncthreads();
+    if (ry == 0 && c8 < N8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float t = 0.f;
+#pragma unroll
+            for (int y = 0; y < 8; ++y) t += red[y][threadIdx.x & 31][k];
+            part[(int64_t)blockIdx.y * (8 * N8) + 8 * c8 + k] = t;
+        }
+    }
+}
+__global__ void bcolsum_finish_kernel(const float* __restrict__ part, int nparts, int N, float* __restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int k0 = 0; k0 < nparts; k0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = part[(int64_t)std::min(k0 + j, nparts - 1) * N + n];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (k0 + j < nparts) s += v[j];
+    }
+    out[n] = s;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static int tn_splits(int tiles, int64_t M) {
+    // enough workgroups for the 256 CUs (one 128-KB workgroup per CU), each split a whole number of K-steps
+    int s = std::max(1, 256 / tiles);
+    const int64_t steps = cdiv(M, BKS);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(s, steps));
+}
+
+}  // namespace msn
+
+using namespace msn;
+
+extern "C" int msn_bgemm_nt(int64_t M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
+                            int64_t ldc, int c_bf16, const float* bias, int epilogue, void* aux, int64_t ldaux,
+                            msn_stream_t stream) {
+    MSN_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, "msn_bgemm_nt: empty operand");
+    MSN_REQUIRE(K % BKS == 0 && N % 4 == 0, "msn_bgemm_nt: K = %d must be a multiple of 64 and N = %d of 4", K, N);
+    MSN_REQUIRE(lda >= K && ldb >= K && lda % 8 == 0 && ldb % 8 == 0 && aligned16(A) && aligned16(B),
+                "msn_bgemm_nt: operand rows must be 16-byte aligned (lda %lld, ldb %lld)", (long long)lda, (long long)ldb);
+    MSN_REQUIRE(ldc >= N && ldc % 4 == 0 && aligned16(C) && (!bias || aligned16(bias)), "msn_bgemm_nt: bad output / bias");
+    MSN_REQUIRE(epilogue >= EPI_B_NONE && epilogue <= EPI_B_ADD, "msn_bgemm_nt: unknown epilogue %d", epilogue);
+    MSN_REQUIRE(epilogue == EPI_B_NONE || (aux && ldaux >= N && ldaux % 4 == 0 && aligned16(aux)),
+                "msn_bgemm_nt: epilogue %d needs an aux matrix", epilogue);
+    MSN_REQUIRE(!(epilogue == EPI_B_GELU && !c_bf16) && !(epilogue == EPI_B_ADD && c_bf16),
+                "msn_bgemm_nt: GELU writes bf16 (activation + saved pre-activation), ADD writes the fp32 residual stream");
+    BgemmArgs a = {};
+    a.A = static_cast<const u16*>(A); a.B = static_cast<const u16*>(B); a.C = C; a.aux = aux; a.bias = bias;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux; a.M = M; a.N = N; a.K = K;
+    a.tiles_m = (int)cdiv(M, BT); a.tiles_n = (int)cdiv(N, BT);
+    const dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(512);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (epilogue == EPI_B_GELU) hipLaunchKernelGGL((bgemm_nt_kernel<EPI_B_GELU, true>), grid, block, 0, st, a);
+    else if (epilogue == EPI_B_ADD) hipLaunchKernelGGL((bgemm_nt_kernel<EPI_B_ADD, false>), grid, block, 0, st, a);
+    else if (epilogue == EPI_B_GELU_BWD) {
+        if (c_bf16) hipLaunchKernelGGL((bgemm_nt_kernel<EPI_B_GELU_BWD, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((bgemm_nt_kernel<EPI_B_GELU_BWD, false>), grid, block, 0, st, a);
+    } else {
+        if (c_bf16) hipLaunchKernelGGL((bgemm_nt_kernel<EPI_B_NONE, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((bgemm_nt_kernel<EPI_B_NONE, false>), grid, block, 0, st, a);
+    }
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" size_t msn_bgemm_tn_workspace_bytes(int64_t M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int tiles = (int)(cdiv(N, BT) * cdiv(K, BT));
+    const int s = tn_splits(tiles, M);
+    return s > 1 ? sizeof(float) * (size_t)s * N * K : 0;
+}
+
+extern "C" int msn_bgemm_tn(int64_t M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, float* C,
+                            int64_t ldc, void* ws, size_t ws_bytes, msn_stream_t stream) {
+    MSN_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, "msn_bgemm_tn: empty operand");
+    MSN_REQUIRE(N % 8 == 0 && K % 8 == 0 && lda >= N && ldb >= K && lda % 8 == 0 && ldb % 8 == 0 && aligned16(A) && aligned16(B),
+                "msn_bgemm_tn: N, K and both leading dimensions must be multiples of 8, operands 16-byte aligned");
+    MSN_REQUIRE(ldc >= K && ldc % 4 == 0 && aligned16(C), "msn_bgemm_tn: bad output");
+    BgemmArgs a = {};
+    a.A = static_cast<const u16*>(A); a.B = static_cast<const u16*>(B); a.C = C;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+    a.tiles_m = (int)cdiv(N, BT); a.tiles_n = (int)cdiv(K, BT);
+    const int tiles = a.tiles_m * a.tiles_n;
+    a.splits = tn_splits(tiles, M);
+    a.rows_per_split = cdiv(cdiv(M, a.splits), BKS) * BKS;
+    a.splits = (int)cdiv(M, a.rows_per_split);
+    const size_t need = a.splits > 1 ? sizeof(float) * (size_t)a.splits * N * K : 0;
+    MSN_REQUIRE(need == 0 || (ws && ws_bytes >= need && aligned16(ws)), "msn_bgemm_tn: workspace %zu < %zu bytes", ws_bytes, need);
+    a.slabs = static_cast<float*>(ws);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(bgemm_tn_kernel, dim3((unsigned)(tiles * a.splits)), dim3(512), 0, st, a);
+    MSN_LAUNCH_CHECK();
+    if (a.splits > 1) {
+        const int64_t n4 = (int64_t)N * K / 4;
+        hipLaunchKernelGGL(bgemm_slab_sum_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n4, 256), 2048)), dim3(256), 0, st,
+                           a.slabs, a.splits, n4, K / 4, ldc / 4, C);
+        MSN_LAUNCH_CHECK();
+    }
+    return MSN_OK;
+}
+
+extern "C" int msn_cast_bf16(const float* x, int64_t n, void* y, msn_stream_t stream) {
+    MSN_REQUIRE(x && y && n > 0 && n % 8 == 0 && aligned16(x) && aligned16(y), "msn_cast_bf16: n must be a multiple of 8, 16-byte aligned");
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n / 8, 256), 4096)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, n / 8, static_cast<u16*>(y));
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" int msn_cast_bf16_transposed(const float* x, int R, int C, void* y, msn_stream_t stream) {
+    MSN_REQUIRE(x && y && R > 0 && C > 0, "msn_cast_bf16_transposed: bad arguments");
+    hipLaunchKernelGGL(cast_bf16_t_kernel, dim3((unsigned)cdiv(C, 32), (unsigned)cdiv(R, 32)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, R, C, static_cast<u16*>(y));
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" size_t msn_bcolsum_workspace_bytes(int64_t M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    const int parts = (int)std::min<int64_t>(cdiv(M, 64), 256);
+    return sizeof(float) * (size_t)parts * N;
+}
+
+extern "C" int msn_bcolsum(const void* X, int64_t ldx, int64_t M, int N, float* out, void* ws, size_t ws_bytes,
+                           msn_stream_t stream) {
+    MSN_REQUIRE(X && out && M > 0 && N > 0 && N % 8 == 0 && ldx % 8 == 0 && ldx >= N && aligned16(X),
+                "msn_bcolsum: N and ldx must be multiples of 8, rows 16-byte aligned");
+    const int parts = (int)std::min<int64_t>(cdiv(M, 64), 256);
+    const int rows_per_block = (int)cdiv(M, parts);
+    MSN_REQUIRE(ws && ws_bytes >= sizeof(float) * (size_t)parts * N, "msn_bcolsum: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(ws);
+    hipLaunchKernelGGL(bcolsum_part_kernel, dim3((unsigned)cdiv(N / 8, 32), (unsigned)parts), dim3(256), 0, st,
+                       static_cast<const u16*>(X), ldx, M, N / 8, rows_per_block, part);
+    MSN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bcolsum_finish_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, st, part, parts, N, out);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}

@@ -42,6 +42,23 @@ __device__ __forceinline__ void store_row(const float4 (&v)[NCH], float* __restr
         if (c < cols) *reinterpret_cast<float4*>(p + c) = v[k];
     }
 }
+// the same row as bf16 (round to nearest even), 8 bytes per chunk -- operands of the bf16-resident GEMMs (gemm_bf16res.hip)
+__device__ __forceinline__ unsigned short f2bf_bits(float f) {
+    const __bf16 b = (__bf16)f;
+    return *reinterpret_cast<const unsigned short*>(&b);
+}
+template <int LPR>
+__device__ __forceinline__ void store_row_bf16(const float4 (&v)[NCH], unsigned short* __restrict__ p, int cols, int lr) {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c = 4 * (lr + k * LPR);
+        if (c < cols) {
+            ushort4 o;
+            o.x = f2bf_bits(v[k].x); o.y = f2bf_bits(v[k].y); o.z = f2bf_bits(v[k].z); o.w = f2bf_bits(v[k].w);
+            *reinterpret_cast<ushort4*>(p + c) = o;
+        }
+    }
+}
 __device__ __forceinline__ float sum4(float4 a) { return (a.x + a.y) + (a.z + a.w); }
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
@@ -50,7 +67,8 @@ template <int LPR>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t ldx, RowGeom g,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, float* __restrict__ y, int64_t ldy,
-                                                     float* __restrict__ mean, float* __restrict__ rstd) {
+                                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                                     unsigned short* __restrict__ yb) {
     constexpr int RG = 256 / LPR;
     const int lr = threadIdx.x % LPR, rg = threadIdx.x / LPR;
     float4 gm[NCH], bt[NCH];
@@ -80,7 +98,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             v[k].z = (v[k].z - mu) * rs * gm[k].z + bt[k].z;
             v[k].w = (v[k].w - mu) * rs * gm[k].w + bt[k].w;
         }
-        store_row<LPR>(v, y + r * ldy, g.cols, lr);
+        if (y) store_row<LPR>(v, y + r * ldy, g.cols, lr);
+        if (yb) store_row_bf16<LPR>(v, yb + r * ldy, g.cols, lr);
         if (lr == 0) {
             mean[r] = mu;
             rstd[r] = rs;
@@ -95,7 +114,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, float* __restrict__ dx,
                                                      int64_t lddx, float* __restrict__ part,
-                                                     const float* __restrict__ add, int64_t ldadd) {
+                                                     const float* __restrict__ add, int64_t ldadd,
+                                                     unsigned short* __restrict__ dxb) {
     constexpr int RG = 256 / LPR;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [RG][2][cols]
     const int lr = threadIdx.x % LPR, rg = threadIdx.x / LPR;
@@ -138,6 +158,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             for (int k = 0; k < NCH; ++k) { d[k].x += a[k].x; d[k].y += a[k].y; d[k].z += a[k].z; d[k].w += a[k].w; }
         }
         store_row<LPR>(d, dx + r * lddx, g.cols, lr);
+        if (dxb) store_row_bf16<LPR>(d, dxb + r * lddx, g.cols, lr);
     }
     // reduce the RG row-groups of this block, then publish [2][cols] for the final pass
     float* mine = lds + (int64_t)rg * 2 * g.cols;
@@ -624,7 +645,22 @@ extern "C" int msn_layernorm_fwd(const float* x, int64_t ldx, int64_t rows, int 
     const int lpr = pick_lpr(cols);
     const RowGeom g{rows, cols, ldx};
     hipStream_t st = static_cast<hipStream_t>(stream);
-    MSN_LPR_DISPATCH(ln_fwd_kernel, lpr, dim3(ln_grid(rows, lpr)), 0, st, x, ldx, g, gamma, beta, eps, y, ldy, mean, rstd)
+    MSN_LPR_DISPATCH(ln_fwd_kernel, lpr, dim3(ln_grid(rows, lpr)), 0, st, x, ldx, g, gamma, beta, eps, y, ldy, mean, rstd,
+                     (unsigned short*)nullptr)
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" int msn_layernorm_fwd_bf16(const float* x, int64_t ldx, int64_t rows, int cols, const float* gamma,
+                                      const float* beta, float eps, void* y_bf16, int64_t ldy, float* mean, float* rstd,
+                                      msn_stream_t stream) {
+    if (int rc = check_rows("msn_layernorm_fwd_bf16", rows, cols, {ldx, ldy}, {x, gamma, beta})) return rc;
+    MSN_REQUIRE(mean && rstd && y_bf16 && (reinterpret_cast<uintptr_t>(y_bf16) & 7) == 0, "msn_layernorm_fwd_bf16: bad pointer");
+    const int lpr = pick_lpr(cols);
+    const RowGeom g{rows, cols, ldx};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MSN_LPR_DISPATCH(ln_fwd_kernel, lpr, dim3(ln_grid(rows, lpr)), 0, st, x, ldx, g, gamma, beta, eps, (float*)nullptr, ldy,
+                     mean, rstd, static_cast<unsigned short*>(y_bf16))
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }
@@ -649,7 +685,35 @@ extern "C" int msn_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* part = static_cast<float*>(ws);
     const size_t lds = sizeof(float) * 2 * (size_t)cols * (256 / lpr);
-    MSN_LPR_DISPATCH(ln_bwd_kernel, lpr, dim3(grid), lds, st, dy, lddy, x, ldx, g, mean, rstd, gamma, dx, lddx, part, add, ldadd)
+    MSN_LPR_DISPATCH(ln_bwd_kernel, lpr, dim3(grid), lds, st, dy, lddy, x, ldx, g, mean, rstd, gamma, dx, lddx, part, add, ldadd,
+                     (unsigned short*)nullptr)
+    MSN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)cdiv(2 * cols, 64)), dim3(1024), 0, st, part, grid, 2 * cols,
+                       dgamma, dbeta, cols);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+// the same backward that ALSO writes a bf16 copy of dx (row stride lddx): the gradient is consumed twice, as the fp32
+// residual-stream gradient and as the bf16 operand of the next weight / input gradient product
+extern "C" int msn_layernorm_bwd_bf16(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t rows, int cols,
+                                      const float* mean, const float* rstd, const float* gamma, const float* add,
+                                      int64_t ldadd, float* dx, int64_t lddx, void* dx_bf16, float* dgamma, float* dbeta,
+                                      void* ws, size_t ws_bytes, msn_stream_t stream) {
+    if (int rc = check_rows("msn_layernorm_bwd_bf16", rows, cols, {lddy, ldx, lddx}, {dy, x, dx, gamma})) return rc;
+    MSN_REQUIRE(mean && rstd && dgamma && dbeta && dx_bf16 && (reinterpret_cast<uintptr_t>(dx_bf16) & 7) == 0,
+                "msn_layernorm_bwd_bf16: null pointer");
+    MSN_REQUIRE(!add || (ldadd >= cols && ldadd % 4 == 0 && (reinterpret_cast<uintptr_t>(add) & 15) == 0),
+                "msn_layernorm_bwd_bf16: bad residual-gradient operand");
+    const int lpr = pick_lpr(cols);
+    const int grid = ln_bwd_grid(rows, lpr);
+    MSN_REQUIRE(ws && ws_bytes >= sizeof(float) * 2 * (size_t)cols * grid, "msn_layernorm_bwd_bf16: workspace too small");
+    const RowGeom g{rows, cols, ldx};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(ws);
+    const size_t lds = sizeof(float) * 2 * (size_t)cols * (256 / lpr);
+    MSN_LPR_DISPATCH(ln_bwd_kernel, lpr, dim3(grid), lds, st, dy, lddy, x, ldx, g, mean, rstd, gamma, dx, lddx, part, add, ldadd,
+                     static_cast<unsigned short*>(dx_bf16))
     MSN_LAUNCH_CHECK();
     hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)cdiv(2 * cols, 64)), dim3(1024), 0, st, part, grid, 2 * cols,
                        dgamma, dbeta, cols);

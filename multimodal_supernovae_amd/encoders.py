@@ -55,6 +55,7 @@ class VisionTransformer(nn.Module):
         # (BASELINE cfg5); "bf16x3" = split-bf16, fp32-grade.  Attention, norms and the loss stay fp32.
         self.gemm_precision = gemm_precision
         self.cls_only_last_block = True      # False: evaluate every token of the last block (same result, more work)
+        self.bf16_resident = True            # gemm_precision "bf16": bf16 activations in HBM + the 256-wide LDS-DMA GEMM
         self.patch_size, self.emb, self.heads, self.depth = patch_size, emb, heads, depth
         self.grid = img_size // patch_size
         self.num_tokens = 1 + self.grid * self.grid
@@ -84,16 +85,24 @@ class VisionTransformer(nn.Module):
         emb = F_.linear(patches, pe.weight.view(e, -1), pe.bias)
         h = F_.vit_tokens(emb, self.cls_token, self.pos_embed, B, T)
         last = len(self.blocks) - 1
-        for i, blk in enumerate(self.blocks):
-            p = (blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight,
-                 blk.attn.proj.bias, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
-                 blk.mlp.fc2.weight, blk.mlp.fc2.bias)
+        params = [(blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight,
+                   blk.attn.proj.bias, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
+                   blk.mlp.fc2.weight, blk.mlp.fc2.bias) for blk in self.blocks]
+        from . import ops
+        dense = len(params) - 1 if self.cls_only_last_block else len(params)       # blocks evaluated for every token
+        first = 0
+        if (self.gemm_precision == "bf16" and self.bf16_resident and dense > 0 and e % 64 == 0
+                and all(b.norm1.eps == self.blocks[0].norm1.eps for b in self.blocks)):
+            # BASELINE cfg5: bf16-resident operands, 256 x 256 LDS-DMA tiles (functional._Bf16VitTrunk)
+            h = F_.bf16_vit_trunk(h, self.heads, self.blocks[0].norm1.eps, params[:dense])
+            first = dense
+        for i in range(first, len(params)):
             if i == last and self.cls_only_last_block:
                 # the head reads the class token only: the last block is evaluated for that row alone (identical output
                 # and gradients; keys / values still come from every token)
-                h = F_.pre_norm_last_block(h, self.heads, p, eps=blk.norm1.eps)
+                h = F_.pre_norm_last_block(h, self.heads, params[i], eps=self.blocks[i].norm1.eps)
             else:
-                h = F_.pre_norm_block(h, self.heads, p, eps=blk.norm1.eps)
+                h = F_.pre_norm_block(h, self.heads, params[i], eps=self.blocks[i].norm1.eps)
         cls = h if (last >= 0 and self.cls_only_last_block) else F_.take_token(h, 0)
         cls = F_.layer_norm(cls, self.norm.weight, self.norm.bias, self.norm.eps)   # LN is per token: only the read-out needs it
         return F_.linear(cls, self.head.weight, self.head.bias)

@@ -632,6 +632,86 @@ def pre_norm_last_block(x, heads, p, eps=1e-6):
     return _PreNormLastBlock.apply(x, heads, eps, *p)
 
 
+class _Bf16VitTrunk(torch.autograd.Function):
+    """Blocks 0 .. n-1 of the build-defined pre-norm ViT as ONE node with bf16-RESIDENT GEMM operands (BASELINE cfg5:
+    "ViT-B/16 bf16 on MFMA"): LayerNorm writes bf16, the GELU epilogue writes the bf16 activation and pre-activation, the
+    weights are rounded once per call (plus a transposed copy for the input-gradient products), every product runs on
+    msn_bgemm_nt / msn_bgemm_tn (256 x 256 tiles, LDS-DMA) with fp32 accumulation.  The residual stream, LayerNorm
+    statistics, softmax and every parameter gradient stay fp32.  Arithmetic = the "bf16" GEMM precision of
+    pre_norm_block (operands rounded to bf16), plus bf16 storage of the saved GELU pre-activation.
+
+    Per-block parameter order: g1, b1, wqkv, bqkv, wo, bo, g2, b2, w1, c1, w2, c2."""
+
+    NS = 14   # tensors saved per block
+
+    @staticmethod
+    def forward(ctx, x, heads, eps, n_blocks, *P):
+        B, T, e = x.shape
+        M = B * T
+        scale = 1.0 / math.sqrt(e // heads)
+        x2 = _c(x).view(M, e)
+        saved = []
+        for i in range(n_blocks):
+            g1, b1, wqkv, bqkv, wo, bo, g2, b2, w1, c1, w2, c2 = P[12 * i: 12 * i + 12]
+            h1, m1, r1 = ops.layernorm_fwd_bf16(x2, g1, b1, eps)
+            qkv = ops.bgemm_nt(h1, ops.cast_bf16(wqkv), bias=bqkv)                    # fp32: the attention kernels' input
+            q3 = qkv.view(B, T, 3 * e)
+            a, lse = ops.attention_fwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], None, heads, scale)
+            a2 = a.view(M, e)
+            ab = ops.cast_bf16(a2)
+            x1 = ops.bgemm_nt(ab, ops.cast_bf16(wo), bias=bo, epilogue=ops.BEPI_ADD, aux=x2)
+            h2, m2, r2 = ops.layernorm_fwd_bf16(x1, g2, b2, eps)
+            f, pre = ops.bgemm_nt(h2, ops.cast_bf16(w1), bias=c1, epilogue=ops.BEPI_GELU, out_bf16=True)
+            out = ops.bgemm_nt(f, ops.cast_bf16(w2), bias=c2, epilogue=ops.BEPI_ADD, aux=x1)
+            saved += [x2, m1, r1, h1, qkv, a2, ab, lse, x1, m2, r2, h2, pre, f]
+            x2 = out
+        ctx.dims = (B, T, e, heads, scale, n_blocks)
+        ctx.save_for_backward(*saved, *P)
+        return x2.view(B, T, e)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, e, heads, scale, n_blocks = ctx.dims
+        M = B * T
+        t = ctx.saved_tensors
+        NS = _Bf16VitTrunk.NS
+        acts, P = t[:NS * n_blocks], t[NS * n_blocks:]
+        grads = [None] * len(P)
+        d2 = _c(dy).view(M, e)
+        d2b = ops.cast_bf16(d2)
+        for i in range(n_blocks - 1, -1, -1):
+            x2, m1, r1, h1, qkv, a2, ab, lse, x1, m2, r2, h2, pre, f = acts[NS * i: NS * i + NS]
+            g1, b1, wqkv, bqkv, wo, bo, g2, b2, w1, c1, w2, c2 = P[12 * i: 12 * i + 12]
+            # input gradients dX = dY . W are NT products against the transposed bf16 weight copy (K-contiguous operands)
+            dw2 = ops.bgemm_tn(d2b, f)
+            dc2 = colsum(d2)
+            dpre = ops.bgemm_nt(d2b, ops.cast_bf16_t(w2), epilogue=ops.BEPI_GELU_BWD, aux=pre, out_bf16=True)
+            dw1 = ops.bgemm_tn(dpre, h2)
+            dc1 = ops.bcolsum(dpre)
+            dh2 = ops.bgemm_nt(dpre, ops.cast_bf16_t(w1))
+            dx1, dx1b, dg2, db2 = ops.layernorm_bwd_bf16(dh2, x1, m2, r2, g2, add=d2)     # + skip connection
+            dwo = ops.bgemm_tn(dx1b, ab)
+            dbo = colsum(dx1)
+            da = ops.bgemm_nt(dx1b, ops.cast_bf16_t(wo))
+            dqkv = torch.empty_like(qkv)
+            q3, d3 = qkv.view(B, T, 3 * e), dqkv.view(B, T, 3 * e)
+            ops.attention_bwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], None, heads, scale, a2.view(B, T, e), lse,
+                              da.view(B, T, e), d3[..., :e], d3[..., e:2 * e], d3[..., 2 * e:])
+            dqkvb = ops.cast_bf16(dqkv)
+            dwqkv = ops.bgemm_tn(dqkvb, h1)
+            dbqkv = colsum(dqkv)
+            dh1 = ops.bgemm_nt(dqkvb, ops.cast_bf16_t(wqkv))
+            d2, d2b, dg1, db1 = ops.layernorm_bwd_bf16(dh1, x2, m1, r1, g1, add=dx1)      # + skip connection
+            grads[12 * i: 12 * i + 12] = [dg1, db1, dwqkv, dbqkv, dwo, dbo, dg2, db2, dw1, dc1, dw2, dc2]
+        return (d2.view(B, T, e), None, None, None, *grads)
+
+
+def bf16_vit_trunk(x, heads, eps, block_params):
+    """block_params: one 12-tuple (g1, b1, wqkv, bqkv, wo, bo, g2, b2, w1, c1, w2, c2) per block."""
+    flat = [p for blk in block_params for p in blk]
+    return _Bf16VitTrunk.apply(x, heads, eps, len(block_params), *flat)
+
+
 class _VitTokens(torch.autograd.Function):
     """[cls ; patch embeddings] + positional embedding."""
 

@@ -573,3 +573,125 @@ def dropout(x, p, seed, residual=None, out=None):
         return y
     check(lib().msn_dropout(ptr(x), x.numel(), float(p), seed, ptr(residual), ptr(y), stream_ptr()), "msn_dropout")
     return y
+
+
+# ------------------------------------------------------------------- bf16-resident products (BASELINE cfg5 image tower)
+BEPI_NONE, BEPI_GELU, BEPI_GELU_BWD, BEPI_ADD = range(4)
+
+
+def _bf16c(t, name):
+    if t.device.type != "cuda":
+        _lib.require_gpu()
+        raise _lib.MsnHipError(f"{name} must live on the GPU (got {t.device})")
+    if t.dtype != torch.bfloat16:
+        raise _lib.MsnHipError(f"{name} must be bfloat16 (got {t.dtype})")
+    return t
+
+
+def bgemm_supported(M, N, K):
+    """Shapes msn_bgemm_nt / _tn take: reduction a multiple of 64, widths multiples of 8 (ViT-B: 768 / 2304 / 3072)."""
+    return K % 64 == 0 and N % 8 == 0 and M > 0
+
+
+def bgemm_nt(a, w, bias=None, epilogue=BEPI_NONE, aux=None, out_bf16=False, flops_log=True):
+    """C = epi(a @ w.T + bias): a (M, K) bf16, w (N, K) bf16, both with contiguous rows -> (M, N) fp32 or bf16."""
+    _bf16c(a, "a"), _bf16c(w, "w")
+    assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and a.shape[1] == w.shape[1]
+    M, K = a.shape
+    N = w.shape[0]
+    c = torch.empty((M, N), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=a.device)
+    if epilogue == BEPI_GELU and aux is None:
+        aux = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    prof = GEMM_PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().msn_bgemm_nt(M, N, K, ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(c), N, 1 if out_bf16 else 0, ptr(bias),
+                             epilogue, ptr(aux), aux.stride(0) if aux is not None else 0, stream_ptr()), "msn_bgemm_nt")
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, 2.0 * M * N * K, (OP_N, OP_T, M, N, K, 100 + epilogue), aux is not None))
+    return (c, aux) if epilogue == BEPI_GELU else c
+
+
+def bgemm_tn(dy, x):
+    """dW = dy.T @ x: dy (M, N) bf16, x (M, K) bf16 -> (N, K) fp32 (weight gradient; fixed-order split over M)."""
+    _bf16c(dy, "dy"), _bf16c(x, "x")
+    assert dy.dim() == 2 and x.dim() == 2 and dy.stride(1) == 1 and x.stride(1) == 1 and dy.shape[0] == x.shape[0]
+    M, N = dy.shape
+    K = x.shape[1]
+    c = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    L = lib()
+    nb = L.msn_bgemm_tn_workspace_bytes(M, N, K)
+    ws = _workspace(nb, dy.device) if nb else None
+    prof = GEMM_PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(L.msn_bgemm_tn(M, N, K, ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(c), K, ptr(ws), nb, stream_ptr()), "msn_bgemm_tn")
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, 2.0 * M * N * K, (OP_T, OP_N, N, K, M, 100), False))
+    return c
+
+
+def cast_bf16(x):
+    """bf16 copy of a contiguous fp32 tensor (numel % 8 == 0)."""
+    _f32c(x, "x")
+    assert x.is_contiguous()
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(lib().msn_cast_bf16(ptr(x), x.numel(), ptr(y), stream_ptr()), "msn_cast_bf16")
+    return y
+
+
+def cast_bf16_t(w):
+    """(R, C) fp32 -> (C, R) bf16: the transposed weight copy the input-gradient products multiply by."""
+    _f32c(w, "w")
+    assert w.dim() == 2 and w.is_contiguous()
+    R, C = w.shape
+    y = torch.empty((C, R), dtype=torch.bfloat16, device=w.device)
+    check(lib().msn_cast_bf16_transposed(ptr(w), R, C, ptr(y), stream_ptr()), "msn_cast_bf16_transposed")
+    return y
+
+
+def bcolsum(x):
+    """Column sums of a bf16 (M, N) matrix -> (N,) fp32."""
+    _bf16c(x, "x")
+    assert x.dim() == 2 and x.stride(1) == 1
+    M, N = x.shape
+    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    L = lib()
+    nb = L.msn_bcolsum_workspace_bytes(M, N)
+    ws = _workspace(nb, x.device)
+    check(L.msn_bcolsum(ptr(x), x.stride(0), M, N, ptr(out), ptr(ws), nb, stream_ptr()), "msn_bcolsum")
+    return out
+
+
+def layernorm_fwd_bf16(x, gamma, beta, eps=1e-5):
+    """LayerNorm whose output is written as bf16 (the next product's operand); returns (y_bf16, mean, rstd)."""
+    x2 = _rows2d(_f32c(x, "x"))
+    rows, cols = x2.shape
+    y = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib().msn_layernorm_fwd_bf16(ptr(x2), x2.stride(0), rows, cols, ptr(gamma), ptr(beta), eps, ptr(y), cols,
+                                       ptr(mean), ptr(rstd), stream_ptr()), "msn_layernorm_fwd_bf16")
+    return y, mean, rstd
+
+
+def layernorm_bwd_bf16(dy, x, mean, rstd, gamma, add=None):
+    """LayerNorm backward returning (dx fp32, dx bf16 copy, dgamma, dbeta)."""
+    dy2, x2 = _rows2d(_f32c(dy, "dy")), _rows2d(x)
+    add2 = _rows2d(add) if add is not None else None
+    rows, cols = x2.shape
+    dx = torch.empty((rows, cols), dtype=torch.float32, device=x.device)
+    dxb = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device)
+    dg = torch.empty(cols, dtype=torch.float32, device=x.device)
+    db = torch.empty(cols, dtype=torch.float32, device=x.device)
+    L = lib()
+    nb = L.msn_layernorm_bwd_workspace_bytes(rows, cols)
+    ws = _workspace(nb, x.device)
+    check(L.msn_layernorm_bwd_bf16(ptr(dy2), dy2.stride(0), ptr(x2), x2.stride(0), rows, cols, ptr(mean), ptr(rstd),
+                                   ptr(gamma), ptr(add2), add2.stride(0) if add2 is not None else 0, ptr(dx), cols, ptr(dxb),
+                                   ptr(dg), ptr(db), ptr(ws), nb, stream_ptr()), "msn_layernorm_bwd_bf16")
+    return dx, dxb, dg, db

@@ -1,0 +1,112 @@
+"""bf16-resident GEMMs (msn_bgemm_nt / msn_bgemm_tn, gemm_bf16res.hip) and their helpers against torch on the same bf16
+inputs in fp64.  Integer-valued operands make every product and partial sum exact in fp32, so the result must be
+bit-exact whatever the summation order: that pins the operand / fragment / swizzle maps (an asymmetric B catches a
+transposed output); random operands check the epilogues and the accumulation."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ints(shape, g, lo=-4, hi=5):
+    return torch.randint(lo, hi, shape, generator=g).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (16, 8, 64), (300, 264, 192), (1000, 768, 768),
+                                   (513, 2304, 768), (777, 768, 3072), (4096, 3072, 768)])
+def test_nt_exact_on_integers(M, N, K):
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w = _ints((M, K), g), _ints((N, K), g)
+    bias = torch.randint(-3, 4, (N,), generator=g).float()
+    ref = a.double() @ w.double().T + bias.double()
+    c = ops.bgemm_nt(a.cuda(), w.cuda(), bias=bias.cuda())
+    assert c.dtype == torch.float32 and torch.equal(c.cpu().double(), ref)
+    cb = ops.bgemm_nt(a.cuda(), w.cuda(), bias=None, out_bf16=True)
+    assert cb.dtype == torch.bfloat16
+    torch.testing.assert_close(cb.cpu().double(), (a.double() @ w.double().T).to(torch.bfloat16).double(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 264, 192), (2048, 768, 768), (1030, 3072, 768)])
+def test_nt_epilogues(M, N, K):
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(7)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    pre_ref = a.double() @ w.double().T + bias.double()
+    # ADD: fp32 residual stream
+    out = ops.bgemm_nt(a.cuda(), w.cuda(), bias=bias.cuda(), epilogue=ops.BEPI_ADD, aux=res.cuda())
+    torch.testing.assert_close(out.cpu().double(), pre_ref + res.double(), rtol=1e-4, atol=1e-4)
+    # GELU: bf16 activation + bf16 pre-activation
+    f, pre = ops.bgemm_nt(a.cuda(), w.cuda(), bias=bias.cuda(), epilogue=ops.BEPI_GELU, out_bf16=True)
+    torch.testing.assert_close(pre.cpu().double(), pre_ref, rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(f.cpu().double(), torch.nn.functional.gelu(pre_ref), rtol=1e-2, atol=1e-2)
+    # GELU': C = (a . w^T) * gelu'(aux)
+    x = pre.float().cpu().double().requires_grad_()
+    torch.nn.functional.gelu(x).sum().backward()
+    d = ops.bgemm_nt(a.cuda(), w.cuda(), epilogue=ops.BEPI_GELU_BWD, aux=pre, out_bf16=True)
+    torch.testing.assert_close(d.cpu().double(), (a.double() @ w.double().T) * x.grad, rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 256, 256), (100, 264, 520), (5000, 768, 768), (20000, 256, 512), (3152, 2304, 768),
+                                   (1, 8, 8)])
+def test_tn_exact_on_integers(M, N, K):
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    dy, x = _ints((M, N), g, -2, 3), _ints((M, K), g, -2, 3)
+    ref = dy.double().T @ x.double()
+    c = ops.bgemm_tn(dy.cuda(), x.cuda())
+    assert c.shape == (N, K) and torch.equal(c.cpu().double(), ref)
+
+
+def test_tn_random_and_strided():
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(3)
+    wide = torch.randn(4000, 1024 + 768, generator=g).to(torch.bfloat16).cuda()
+    dy, x = wide[:, :1024], wide[:, 1024:]                       # row-strided views (ld = 1792)
+    ref = dy.double().T @ x.double()
+    c = ops.bgemm_tn(dy, x)
+    torch.testing.assert_close(c.double(), ref, rtol=1e-4, atol=1e-3)
+
+
+def test_casts_colsum_and_layernorm_variants():
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1000, 768, generator=g).cuda()
+    assert torch.equal(ops.cast_bf16(x), x.to(torch.bfloat16))
+    w = torch.randn(300, 520, generator=g).cuda()
+    assert torch.equal(ops.cast_bf16_t(w), w.t().contiguous().to(torch.bfloat16))
+    xb = x.to(torch.bfloat16)
+    torch.testing.assert_close(ops.bcolsum(xb).double(), xb.double().sum(0), rtol=1e-5, atol=1e-4)
+    gamma, beta = torch.randn(768, generator=g).cuda(), torch.randn(768, generator=g).cuda()
+    y32, m32, r32 = ops.layernorm_fwd(x, gamma, beta, 1e-6)
+    yb, mb, rb = ops.layernorm_fwd_bf16(x, gamma, beta, 1e-6)
+    assert torch.equal(yb, y32.to(torch.bfloat16)) and torch.equal(mb, m32) and torch.equal(rb, r32)
+    dy, add = torch.randn(1000, 768, generator=g).cuda(), torch.randn(1000, 768, generator=g).cuda()
+    dx32, dg32, db32 = ops.layernorm_bwd(dy, x, m32, r32, gamma, add=add)
+    dx, dxb, dg, db = ops.layernorm_bwd_bf16(dy, x, m32, r32, gamma, add=add)
+    assert torch.equal(dx, dx32) and torch.equal(dxb, dx32.to(torch.bfloat16)) and torch.equal(dg, dg32) and torch.equal(db, db32)
+
+
+def test_resident_trunk_equals_the_fp32_storage_bf16_path():
+    """ViT blocks through functional._Bf16VitTrunk == the same blocks with gemm_precision "bf16" on fp32-stored
+    activations, up to bf16 rounding noise (direction of every gradient, tight bound on the output)."""
+    from multimodal_supernovae_amd.encoders import VisionTransformer
+    torch.manual_seed(9)
+    m = VisionTransformer(img_size=32, patch_size=8, emb=128, depth=3, heads=2, n_out=8, gemm_precision="bf16").cuda()
+    x = torch.rand(6, 3, 32, 32, device="cuda")
+    cot = torch.randn(6, 8, device="cuda")
+    res = []
+    for resident in (True, False):
+        m.bf16_resident = resident
+        m.zero_grad(set_to_none=True)
+        y = m(x)
+        y.backward(cot)
+        res.append((y.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    (ya, ga), (yb, gb) = res
+    cos = lambda a, b: float((a.flatten().double() @ b.flatten().double()) / (a.double().norm() * b.double().norm() + 1e-300))
+    assert cos(ya, yb) > 0.9995
+    low = {k: cos(ga[k], gb[k]) for k in ga if cos(ga[k], gb[k]) < 0.99}
+    assert not low, low
