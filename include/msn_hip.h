@@ -233,6 +233,13 @@ size_t msn_bcolsum_workspace_bytes(int64_t M, int N);
 int msn_bcolsum(const void* X, int64_t ldx, int64_t M, int N, float* out, void* ws, size_t ws_bytes, msn_stream_t stream);
 int msn_layernorm_fwd_bf16(const float* x, int64_t ldx, int64_t rows, int cols, const float* gamma, const float* beta,
                            float eps, void* y_bf16, int64_t ldy, float* mean, float* rstd, msn_stream_t stream);
+/* Self-attention on the bf16 matrix cores, 64-wide heads, T <= 256 tokens, no key mask (the cfg5 ViT-B/16 attention;
+ * build-defined, scale 1/sqrt(head_dim)): qkv is the (B*T, ld >= 3*H*64) bf16 matrix [q | k | v] the packed projection
+ * writes, out / dout (B*T, H*64) bf16, lse (B, H, T) fp32; bwd writes dqkv in qkv's layout (bf16); delta = (B, H, T) scratch. */
+int msn_attention_bf16_fwd(const void* qkv, int64_t ld, int B, int H, int T, float scale, void* out, int64_t ldo, float* lse,
+                           msn_stream_t stream);
+int msn_attention_bf16_bwd(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t ldd,
+                           const float* lse, int B, int H, int T, float scale, void* dqkv, float* delta, msn_stream_t stream);
 int msn_layernorm_bwd_bf16(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t rows, int cols,
                            const float* mean, const float* rstd, const float* gamma, const float* add, int64_t ldadd,
                            float* dx, int64_t lddx, void* dx_bf16, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,

@@ -649,29 +649,36 @@ class _Bf16VitTrunk(torch.autograd.Function):
         B, T, e = x.shape
         M = B * T
         scale = 1.0 / math.sqrt(e // heads)
+        battn = ops.attention_bf16_supported(T, e // heads)     # 64-wide heads, T <= 256: attention on the bf16 matrix cores
         x2 = _c(x).view(M, e)
         saved = []
+        empty = x2.new_empty(0)
         for i in range(n_blocks):
             g1, b1, wqkv, bqkv, wo, bo, g2, b2, w1, c1, w2, c2 = P[12 * i: 12 * i + 12]
             h1, m1, r1 = ops.layernorm_fwd_bf16(x2, g1, b1, eps)
-            qkv = ops.bgemm_nt(h1, ops.cast_bf16(wqkv), bias=bqkv)                    # fp32: the attention kernels' input
-            q3 = qkv.view(B, T, 3 * e)
-            a, lse = ops.attention_fwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], None, heads, scale)
-            a2 = a.view(M, e)
-            ab = ops.cast_bf16(a2)
+            if battn:
+                qkv = ops.bgemm_nt(h1, ops.cast_bf16(wqkv), bias=bqkv, out_bf16=True)
+                ab, lse = ops.attention_bf16_fwd(qkv, B, T, heads, scale)
+                a2 = empty
+            else:
+                qkv = ops.bgemm_nt(h1, ops.cast_bf16(wqkv), bias=bqkv)                # fp32: the fp32 attention kernels' input
+                q3 = qkv.view(B, T, 3 * e)
+                a, lse = ops.attention_fwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], None, heads, scale)
+                a2 = a.view(M, e)
+                ab = ops.cast_bf16(a2)
             x1 = ops.bgemm_nt(ab, ops.cast_bf16(wo), bias=bo, epilogue=ops.BEPI_ADD, aux=x2)
             h2, m2, r2 = ops.layernorm_fwd_bf16(x1, g2, b2, eps)
             f, pre = ops.bgemm_nt(h2, ops.cast_bf16(w1), bias=c1, epilogue=ops.BEPI_GELU, out_bf16=True)
             out = ops.bgemm_nt(f, ops.cast_bf16(w2), bias=c2, epilogue=ops.BEPI_ADD, aux=x1)
             saved += [x2, m1, r1, h1, qkv, a2, ab, lse, x1, m2, r2, h2, pre, f]
             x2 = out
-        ctx.dims = (B, T, e, heads, scale, n_blocks)
+        ctx.dims = (B, T, e, heads, scale, n_blocks, battn)
         ctx.save_for_backward(*saved, *P)
         return x2.view(B, T, e)
 
     @staticmethod
     def backward(ctx, dy):
-        B, T, e, heads, scale, n_blocks = ctx.dims
+        B, T, e, heads, scale, n_blocks, battn = ctx.dims
         M = B * T
         t = ctx.saved_tensors
         NS = _Bf16VitTrunk.NS
@@ -692,14 +699,19 @@ class _Bf16VitTrunk(torch.autograd.Function):
             dx1, dx1b, dg2, db2 = ops.layernorm_bwd_bf16(dh2, x1, m2, r2, g2, add=d2)     # + skip connection
             dwo = ops.bgemm_tn(dx1b, ab)
             dbo = colsum(dx1)
-            da = ops.bgemm_nt(dx1b, ops.cast_bf16_t(wo))
-            dqkv = torch.empty_like(qkv)
-            q3, d3 = qkv.view(B, T, 3 * e), dqkv.view(B, T, 3 * e)
-            ops.attention_bwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], None, heads, scale, a2.view(B, T, e), lse,
-                              da.view(B, T, e), d3[..., :e], d3[..., e:2 * e], d3[..., 2 * e:])
-            dqkvb = ops.cast_bf16(dqkv)
+            if battn:
+                da = ops.bgemm_nt(dx1b, ops.cast_bf16_t(wo), out_bf16=True)
+                dqkvb = ops.attention_bf16_bwd(qkv, ab, da, lse, B, T, heads, scale)
+                dbqkv = ops.bcolsum(dqkvb)
+            else:
+                da = ops.bgemm_nt(dx1b, ops.cast_bf16_t(wo))
+                dqkv = torch.empty_like(qkv)
+                q3, d3 = qkv.view(B, T, 3 * e), dqkv.view(B, T, 3 * e)
+                ops.attention_bwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], None, heads, scale, a2.view(B, T, e), lse,
+                                  da.view(B, T, e), d3[..., :e], d3[..., e:2 * e], d3[..., 2 * e:])
+                dqkvb = ops.cast_bf16(dqkv)
+                dbqkv = colsum(dqkv)
             dwqkv = ops.bgemm_tn(dqkvb, h1)
-            dbqkv = colsum(dqkv)
             dh1 = ops.bgemm_nt(dqkvb, ops.cast_bf16_t(wqkv))
             d2, d2b, dg1, db1 = ops.layernorm_bwd_bf16(dh1, x2, m1, r1, g1, add=dx1)      # + skip connection
             grads[12 * i: 12 * i + 12] = [dg1, db1, dwqkv, dbqkv, dwo, dbo, dg2, db2, dw1, dc1, dw2, dc2]

@@ -695,3 +695,30 @@ def layernorm_bwd_bf16(dy, x, mean, rstd, gamma, add=None):
                                    ptr(gamma), ptr(add2), add2.stride(0) if add2 is not None else 0, ptr(dx), cols, ptr(dxb),
                                    ptr(dg), ptr(db), ptr(ws), nb, stream_ptr()), "msn_layernorm_bwd_bf16")
     return dx, dxb, dg, db
+
+
+def attention_bf16_supported(T, head_dim):
+    return head_dim == 64 and 0 < T <= 256
+
+
+def attention_bf16_fwd(qkv, B, T, heads, scale):
+    """qkv: (B*T, 3*heads*64) bf16 [q | k | v] -> (out (B*T, heads*64) bf16, lse (B, heads, T) fp32)."""
+    _bf16c(qkv, "qkv")
+    e = heads * 64
+    assert qkv.dim() == 2 and qkv.shape == (B * T, 3 * e) and qkv.stride(1) == 1
+    out = torch.empty((B * T, e), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((B, heads, T), dtype=torch.float32, device=qkv.device)
+    check(lib().msn_attention_bf16_fwd(ptr(qkv), qkv.stride(0), B, heads, T, scale, ptr(out), e, ptr(lse), stream_ptr()),
+          "msn_attention_bf16_fwd")
+    return out, lse
+
+
+def attention_bf16_bwd(qkv, out, dout, lse, B, T, heads, scale):
+    """Gradient w.r.t. the packed projection: (B*T, 3*heads*64) bf16 [dq | dk | dv]."""
+    _bf16c(qkv, "qkv"), _bf16c(out, "out"), _bf16c(dout, "dout")
+    assert dout.shape == out.shape and dout.stride(1) == 1 and out.stride(1) == 1
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, heads, T), dtype=torch.float32, device=qkv.device)
+    check(lib().msn_attention_bf16_bwd(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), ptr(dout), dout.stride(0), ptr(lse), B,
+                                       heads, T, scale, ptr(dqkv), ptr(delta), stream_ptr()), "msn_attention_bf16_bwd")
+    return dqkv

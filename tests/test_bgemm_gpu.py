@@ -110,3 +110,30 @@ def test_resident_trunk_equals_the_fp32_storage_bf16_path():
     assert cos(ya, yb) > 0.9995
     low = {k: cos(ga[k], gb[k]) for k in ga if cos(ga[k], gb[k]) < 0.99}
     assert not low, low
+
+
+@pytest.mark.parametrize("B,H,T", [(2, 2, 16), (3, 2, 65), (2, 12, 197), (1, 1, 256), (2, 3, 33), (1, 2, 1)])
+def test_bf16_attention_forward_backward(B, H, T):
+    """msn_attention_bf16_fwd / _bwd against softmax attention evaluated in fp64 on the same bf16 q, k, v, dO (the
+    kernels round P and dS to bf16 before the second products: tolerance = bf16 resolution of values of that size)."""
+    from multimodal_supernovae_amd import ops
+    e = 64 * H
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    qkv = (torch.randn(B * T, 3 * e, generator=g) * 0.8).to(torch.bfloat16)
+    dout = torch.randn(B * T, e, generator=g).to(torch.bfloat16)
+    scale = 0.125
+    x = qkv.double().view(B, T, 3, H, 64).requires_grad_()
+    q, k, v = x[:, :, 0], x[:, :, 1], x[:, :, 2]
+    att = torch.softmax(torch.einsum("bihd,bjhd->bhij", q, k) * scale, dim=-1)
+    ref = torch.einsum("bhij,bjhd->bihd", att, v).reshape(B * T, e)
+    lse_ref = torch.logsumexp(torch.einsum("bihd,bjhd->bhij", q, k) * scale, dim=-1)
+    ref.backward(dout.double())
+    dref = x.grad.reshape(B * T, 3 * e)
+    out, lse = ops.attention_bf16_fwd(qkv.cuda(), B, T, H, scale)
+    torch.testing.assert_close(out.cpu().double(), ref.detach(), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(lse.cpu().double(), lse_ref.detach(), rtol=1e-4, atol=1e-4)
+    dqkv = ops.attention_bf16_bwd(qkv.cuda(), out, dout.cuda(), lse, B, T, H, scale)
+    err = (dqkv.cpu().double() - dref).abs().max() / dref.abs().max()
+    assert err < 2e-2, float(err)
+    cosv = float((dqkv.cpu().double().flatten() @ dref.flatten()) / (dqkv.cpu().double().norm() * dref.norm()))
+    assert cosv > 0.9995, cosv
