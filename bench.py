@@ -399,8 +399,11 @@ def main():
     # dense matrix peak of the instruction the dominant kernel issues (MI355X_MICROARCH.md): fp32 157.3 TFLOP/s;
     # bf16 2500 TFLOP/s, of which the 3-product split can deliver at most a third as algorithmic flops
     peak = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}[args.gemm_precision]
+    kernel_name = GEMM_KERNEL_NAME[args.gemm_precision]
     if args.workload == "vit_b16_bf16_lc" and args.gemm_precision == "f32":
         peak = 2500.0           # the image tower of cfg5 issues bf16 MFMAs whatever the process default is
+        kernel_name = ("msn::bgemm_nt_kernel + msn::bgemm_tn_kernel (bf16-resident operands, 256x256 tiles, LDS-DMA, "
+                       "v_mfma_f32_16x16x32_bf16; all GEMM launches of the step, the light-curve tower's fp32 ones included)")
 
     # ---- per-tower split (serial order, HIP events): what each tower costs alone, and the serial step next to the
     # concurrent one, so the gain of running the towers on separate streams can be read off the JSON
@@ -495,7 +498,7 @@ def main():
                        "loss": loss_value, "algorithmic_gflop_per_pair": flops_per_pair() / 1e9,
                        "executed_gflop_per_pair": flops_per_pair(executed=True) / 1e9,
                        "model_tflops": pairs * flops_per_pair(executed=True) / 1e12},
-            "roofline": {"bound": "mfma", "kernel": GEMM_KERNEL_NAME[args.gemm_precision],
+            "roofline": {"bound": "mfma", "kernel": kernel_name,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_unit": "bytes per launch (mean), 2 x FETCH_SIZE + WRITE_SIZE",
                          "traffic_source": traffic_source,

@@ -6,7 +6,7 @@
 // output and all gradients bf16 in the layouts the neighbouring bf16-resident GEMMs (gemm_bf16res.hip) read.  Scores,
 // softmax statistics and every accumulation are fp32 (v_mfma_f32_16x16x32_bf16).
 //
-// One workgroup (4 waves) per (batch, head); the token matrices the whole workgroup streams over sit in LDS as
+// One workgroup (8 waves) per (batch, head); the token matrices the whole workgroup streams over sit in LDS as
 // [token][64] bf16 images (128-byte rows, written by LDS-DMA with the XOR swizzle of the GEMM images on the SOURCE
 // address), the 16-token tiles a wave owns come straight from global memory into MFMA fragments.  Products that contract
 // over the head dimension read row fragments (ds_read_b128); products that contract over TOKENS read the same images
@@ -34,6 +34,7 @@ constexpr int AHD = 64;                 // head width
 constexpr int AMAXT = 256;              // tokens an LDS image holds
 constexpr int AIMG = AMAXT * AHD * 2;   // 32 KB
 constexpr float ALOG2E = 1.4426950408889634f;
+constexpr int AWAVES = 8;               // waves per workgroup: the 16-token tiles of a (batch, head) are dealt round-robin
 
 __device__ __align__(16) const unsigned char g_attn_zero_page[16] = {0};
 
@@ -69,8 +70,8 @@ __device__ __forceinline__ void a_wait_lds() {
 __device__ __forceinline__ void stage_image(unsigned char* img, const u16* __restrict__ src, int64_t ld, int T, int wave, int lane) {
     const int rows_needed = (T + 31) / 32 * 32;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int piece = 8 * wave + q;                   // 4 waves x 8 pieces x 8 rows = 256 rows
+    for (int q = 0; q < 32 / AWAVES; ++q) {
+        const int piece = (32 / AWAVES) * wave + q;       // 32 pieces x 8 rows = 256 rows, dealt to the waves in runs
         if (piece * 8 >= rows_needed) break;
         const int R = piece * 8 + (lane >> 3);
         const int c = (lane & 7) ^ aswz(R);
@@ -116,7 +117,7 @@ __device__ __forceinline__ bf16x8 pack8(const float (&a)[4], const float (&b)[4]
 }
 
 // ------------------------------------------------------------------------------------------------------- forward
-__global__ __launch_bounds__(256) void battn_fwd_kernel(const BAttn p) {
+__global__ __launch_bounds__(64 * AWAVES) void battn_fwd_kernel(const BAttn p) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * AIMG];      // K image | V image
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void battn_fwd_kernel(const BAttn p) {
     const int ntile = (T + 15) / 16, nblk = (T + 31) / 32;
     const float sl = p.scale * ALOG2E;
 
-    for (int qt = wave; qt < ntile; qt += 4) {
+    for (int qt = wave; qt < ntile; qt += AWAVES) {
         bf16x8 qf[2];
         load_rows(qf, base, p.ld, 16 * qt, T, l15, g);
         f32x4 o[4];
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void battn_fwd_kernel(const BAttn p) {
 }
 
 // ------------------------------------------------------------------------------------------------------- dQ pass
-__global__ __launch_bounds__(256) void battn_bwd_dq_kernel(const BAttn p) {
+__global__ __launch_bounds__(64 * AWAVES) void battn_bwd_dq_kernel(const BAttn p) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * AIMG];      // K image | V image
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void battn_bwd_dq_kernel(const BAttn p) {
     const int ntile = (T + 15) / 16, nblk = (T + 31) / 32;
     const float sl = p.scale * ALOG2E;
 
-    for (int qt = wave; qt < ntile; qt += 4) {
+    for (int qt = wave; qt < ntile; qt += AWAVES) {
         bf16x8 qf[2], df[2], of[2];
         load_rows(qf, base, p.ld, 16 * qt, T, l15, g);
         load_rows(df, p.dout + (int64_t)b * T * p.ldd + h * AHD, p.ldd, 16 * qt, T, l15, g);
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(256) void battn_bwd_dq_kernel(const BAttn p) {
 }
 
 // ------------------------------------------------------------------------------------------------------- dK, dV pass
-__global__ __launch_bounds__(256) void battn_bwd_dkv_kernel(const BAttn p) {
+__global__ __launch_bounds__(64 * AWAVES) void battn_bwd_dkv_kernel(const BAttn p) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * AIMG];      // Q image | dO image
     __shared__ float stat_l[AMAXT], stat_d[AMAXT];                               // lse * log2e, delta per query
     const int lane = threadIdx.x & 63;
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(256) void battn_bwd_dkv_kernel(const BAttn p) {
     const u16* base = p.qkv + (int64_t)b * T * p.ld + h * AHD;
     stage_image(lds, base, p.ld, T, wave, lane);
     stage_image(lds + AIMG, p.dout + (int64_t)b * T * p.ldd + h * AHD, p.ldd, T, wave, lane);
-    for (int i = threadIdx.x; i < AMAXT; i += 256) {
+    for (int i = threadIdx.x; i < AMAXT; i += 64 * AWAVES) {
         const int64_t st = ((int64_t)b * p.H + h) * T + min(i, T - 1);
         stat_l[i] = p.lse[st] * ALOG2E;
         stat_d[i] = p.delta[st];
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256) void battn_bwd_dkv_kernel(const BAttn p) {
     const int ntile = (T + 15) / 16, nblk = (T + 31) / 32;
     const float sl = p.scale * ALOG2E;
 
-    for (int kt = wave; kt < ntile; kt += 4) {
+    for (int kt = wave; kt < ntile; kt += AWAVES) {
         bf16x8 kf[2], vf[2];
         load_rows(kf, base + E, p.ld, 16 * kt, T, l15, g);
         load_rows(vf, base + 2 * E, p.ld, 16 * kt, T, l15, g);
@@ -395,7 +396,7 @@ extern "C" int msn_attention_bf16_fwd(const void* qkv, int64_t ld, int B, int H,
     BAttn a = {};
     a.qkv = static_cast<const u16*>(qkv); a.ld = ld; a.out = static_cast<u16*>(out); a.ldo = ldo; a.lse = lse;
     a.B = B; a.H = H; a.T = T; a.scale = scale;
-    hipLaunchKernelGGL(battn_fwd_kernel, dim3((unsigned)(B * H)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(battn_fwd_kernel, dim3((unsigned)(B * H)), dim3(64 * AWAVES), 0, static_cast<hipStream_t>(stream), a);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }
@@ -413,9 +414,9 @@ extern "C" int msn_attention_bf16_bwd(const void* qkv, int64_t ld, const void* o
     a.dout = static_cast<const u16*>(dout); a.ldd = ldd; a.dqkv = static_cast<u16*>(dqkv); a.lse = const_cast<float*>(lse);
     a.delta = delta; a.B = B; a.H = H; a.T = T; a.scale = scale;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(battn_bwd_dq_kernel, dim3((unsigned)(B * H)), dim3(256), 0, st, a);      // also writes delta
+    hipLaunchKernelGGL(battn_bwd_dq_kernel, dim3((unsigned)(B * H)), dim3(64 * AWAVES), 0, st, a);      // also writes delta
     MSN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(battn_bwd_dkv_kernel, dim3((unsigned)(B * H)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(battn_bwd_dkv_kernel, dim3((unsigned)(B * H)), dim3(64 * AWAVES), 0, st, a);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }
