@@ -408,7 +408,7 @@ def main():
     # ---- per-tower split (serial order, HIP events): what each tower costs alone, and the serial step next to the
     # concurrent one, so the gain of running the towers on separate streams can be read off the JSON
     towers = None
-    if headline and not args.graphed:
+    if headline and not args.graphed and world == 1:      # one process: the reducer's hooks are no-ops
         serial_dt, _ = timed(step, 1, max(3, args.steps // 4))
         towers = {"concurrent_streams_ms_per_step": dt / args.steps * 1e3,
                   "serial_ms_per_step": serial_dt / max(3, args.steps // 4) * 1e3}

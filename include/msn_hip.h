@@ -88,6 +88,8 @@ int msn_set_gemm_variant(int mode);
  * by a finishing pass that applies the epilogue); msn_sgemm_workspace_bytes covers the slabs.  Results of the
  * tail tiles then differ from the unsplit order in the last bits.  Process-wide. */
 int msn_set_gemm_tail_split(int enabled);
+/* Measurement switch: tile width of products with N > 64: 0 = planned (default), 64, 128. */
+int msn_set_gemm_tile_n(int bn);
 int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
               const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int epilogue,
               float* aux, int64_t ldaux, int precision, void* ws, size_t ws_bytes, msn_stream_t stream);

@@ -732,6 +732,7 @@ static int launch_cfg(const GemmArgs& a, int opA, int opB, hipStream_t st) {
 }
 
 static int g_gemm_tail = 1;      // cut the partly filled last round of tiles into K-slabs (msn_set_gemm_tail_split)
+static int g_gemm_bn = 0;        // measurement switch (msn_set_gemm_tile_n): 0 = planned, 64 / 128 = forced tile width for N > 64
 
 // Launch geometry of one product.
 //  * tile shape by N;
@@ -753,6 +754,12 @@ static Plan plan(int64_t M, int64_t N, int64_t K, int opA, bool allow_tail = tru
     Plan p;
     p.bm = 128;
     p.bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
+    // Under-filled launches (strong scaling: 128 - 512 rows per GPU): up to ~1.5 rounds of 128 x 128 tiles, twice as many
+    // 128 x 64 tiles fill the 512 workgroup slots better than K-slabs of the wide tiles + a finishing pass
+    // (tools/bench_gemm_small.py, M = 8320: proj 42.3 -> 33.1 us, qkv 83.2 -> 77.8, ff1 110.4 -> 102.1; M = 33280 proj
+    // 104.2 -> 97.4; from ~1000 tiles on the wide tile wins again)
+    if (N > 64 && N % 64 == 0 && opA == MSN_OP_N && g_gemm_bn == 0 && cdiv(M, 128) * cdiv(N, 128) <= 800) p.bn = 64;
+    if (N > 64 && g_gemm_bn != 0) p.bn = g_gemm_bn;
     p.tail_tiles = 0, p.tail_splits = 1, p.tail_kps = 0;
     const int64_t tiles = cdiv(M, p.bm) * cdiv(N, p.bn);
     const int64_t ksteps = cdiv(K, BK);
@@ -960,6 +967,12 @@ extern "C" int msn_wgrad_bias(int64_t M, int64_t N, int64_t K, const float* dY, 
                               precision, ws, ws_bytes, stream, db, &fused);
     if (rc != MSN_OK || fused || M == 0 || N == 0) return rc;
     return msn_colsum(dY, lddy, K, M, db, ws, ws_bytes, stream);   // shapes / precisions the fused kernel does not take
+}
+
+extern "C" int msn_set_gemm_tile_n(int bn) {
+    MSN_REQUIRE(bn == 0 || bn == 64 || bn == 128, "msn_set_gemm_tile_n: 0 (planned), 64 or 128");
+    g_gemm_bn = bn;
+    return MSN_OK;
 }
 
 extern "C" int msn_set_gemm_tail_split(int enabled) {

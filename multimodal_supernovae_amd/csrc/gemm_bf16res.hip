@@ -75,6 +75,7 @@ struct BgemmArgs {
     int64_t M;                 // NT: rows of A / C.  TN: reduction length
     int N, K;                  // NT: C is M x N, reduction K.  TN: C is N x K
     int tiles_m, tiles_n;      // NT: tile grid.  TN: tiles over N and K
+    int super_rows;            // NT: tile-rows walked together (L2 blocking)
     int splits; int64_t rows_per_split;   // TN: reduction split
     float* slabs;              // TN: [splits][N][K] partials (splits > 1)
 };
@@ -104,7 +105,15 @@ __global__ __launch_bounds__(512, 2) void bgemm_nt_kernel(const BgemmArgs p) {
         const int q = nwg / 8, r = nwg % 8, x = bid % 8, i = bid / 8;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
     }
-    const int tm = bid / p.tiles_n, tn = bid % p.tiles_n;
+    // inside an XCD's run: super-rows of 8 tile-rows, row-fastest within a tile column -- the 32 workgroups an XCD has in
+    // flight then cover 8 A row panels (3 MB at K = 768) x 4 weight column panels, so a weight panel is fetched once per
+    // super-row instead of once per tile-row (rocprofv3 FETCH_SIZE of the N = 3072, K = 768 products: 2.1 GB per launch
+    // against 0.78 GB of operands with the N-fastest order; the weight alone is 4.7 MB against 4 MB of L2)
+    // (only while the super-row's A panels fit an L2 next to the weight stream: SR = 4096 / K tile-rows, 1 for K >= 2304)
+    const int SR = p.super_rows;
+    const int sr = bid / (SR * p.tiles_n), j = bid % (SR * p.tiles_n);
+    const int rows_sr = min(SR, p.tiles_m - sr * SR);
+    const int tm = sr * SR + j % rows_sr, tn = j / rows_sr;
     const int64_t m0 = (int64_t)tm * BT;
     const int n0 = tn * BT;
 
@@ -269,7 +278,14 @@ __global__ __launch_bounds__(512, 2) void bgemm_tn_kernel(const BgemmArgs p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tiles = p.tiles_m * p.tiles_n;               // tiles over (N, K)
-    const int split = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    // workgroup ids go round-robin to the 8 XCDs: give each XCD a contiguous run of (split, tile) pairs, i.e. the tiles of
+    // one reduction range, so that its dY / X panels are shared in ONE L2 instead of being fetched by all eight
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg / 8, r = nwg % 8, x = bid % 8, i = bid / 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const int split = bid / tiles, tile = bid % tiles;
     const int tn = tile / p.tiles_n, tk = tile % p.tiles_n;
     const int n0 = tn * BT, k0 = tk * BT;
     const int64_t m_begin = (int64_t)split * p.rows_per_split;
@@ -521,6 +537,7 @@ extern "C" int msn_bgemm_nt(int64_t M, int N, int K, const void* A, int64_t lda,
     a.A = static_cast<const u16*>(A); a.B = static_cast<const u16*>(B); a.C = C; a.aux = aux; a.bias = bias;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux; a.M = M; a.N = N; a.K = K;
     a.tiles_m = (int)cdiv(M, BT); a.tiles_n = (int)cdiv(N, BT);
+    a.super_rows = std::max(1, std::min(8, 4096 / K));
     const dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(512);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (epilogue == EPI_B_GELU) hipLaunchKernelGGL((bgemm_nt_kernel<EPI_B_GELU, true>), grid, block, 0, st, a);

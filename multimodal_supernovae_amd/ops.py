@@ -43,6 +43,11 @@ def set_gemm_variant(mode):
     check(lib().msn_set_gemm_variant(int(mode)))
 
 
+def set_gemm_tile_n(bn):
+    """Tile width of products with N > 64 (msn_set_gemm_tile_n): 0 = planned (default), 64, 128 -- measurements / tests."""
+    check(lib().msn_set_gemm_tile_n(int(bn)))
+
+
 def set_gemm_tail_split(enabled):
     """Cut the partly filled last round of GEMM tiles into K-slabs (msn_set_gemm_tail_split); default on."""
     check(lib().msn_set_gemm_tail_split(1 if enabled else 0))
@@ -227,6 +232,8 @@ def _mask_u8(mask):
         return None
     if mask.dtype == torch.bool:
         return mask.contiguous().view(torch.uint8)
+    if mask.dtype == torch.uint8:          # already the byte mask the kernels read (0 / 1): no conversion launch
+        return mask.contiguous()
     return (mask != 0).contiguous().view(torch.uint8)
 
 

@@ -96,10 +96,11 @@ def test_sgemm_tail_split(M, N, K, op_a, op_b, epi, variant, precision):
     aux_in = torch.randn(M, N, generator=g).cuda()
     kw = {"none": dict(), "gelu": dict(bias=bias, epilogue=ops.EPI_GELU, aux=torch.empty(M, N, device="cuda")),
           "add": dict(bias=bias, epilogue=ops.EPI_ADD, aux=aux_in), "relu_bwd": dict(epilogue=ops.EPI_RELU_BWD, aux=aux_in)}[epi]
-    if op_a == 0:
-        assert _lib.lib().msn_sgemm_workspace_bytes(op_a, op_b, M, N, K) > 0  # the plan cuts a tail for these shapes
     outs, auxs = [], []
     try:
+        ops.set_gemm_tile_n(128)          # the planner gives small launches 64-wide tiles (no tail): pin the wide tile here
+        if op_a == 0:
+            assert _lib.lib().msn_sgemm_workspace_bytes(op_a, op_b, M, N, K) > 0  # the plan cuts a tail for these shapes
         ops.set_gemm_variant(variant)
         for tail in (True, False):
             ops.set_gemm_tail_split(tail)
@@ -110,12 +111,43 @@ def test_sgemm_tail_split(M, N, K, op_a, op_b, epi, variant, precision):
     finally:
         ops.set_gemm_variant(3)
         ops.set_gemm_tail_split(True)
+        ops.set_gemm_tile_n(0)
     tol = dict(rtol=1e-4, atol=1e-4 * K ** 0.5) if precision < 2 else dict(rtol=2e-2, atol=3e-2 * K ** 0.5)
     torch.testing.assert_close(outs[0], outs[1], **tol)
     if epi == "gelu":
         torch.testing.assert_close(auxs[0], auxs[1], **tol)
     if epi == "none":
         torch.testing.assert_close(outs[0].double(), _ref(a, b, op_a, op_b), **tol)
+
+
+@pytest.mark.parametrize("M,N,K,op_b", [(8320, 384, 384, 1), (8320, 1152, 384, 1), (8320, 384, 1536, 0), (33280, 384, 384, 0),
+                                        (700, 192, 96, 1)])
+@pytest.mark.parametrize("epi", ["none", "gelu", "add"])
+def test_sgemm_narrow_tiles_for_underfilled_launches(M, N, K, op_b, epi):
+    """Launches of at most ~1.5 rounds of 128 x 128 tiles are planned with 128 x 64 tiles (strong scaling: 128 - 512 rows
+    per GPU): bit-identical to the wide-tile launch without the tail split (same k order per accumulator), and no
+    workspace (no finishing pass)."""
+    from multimodal_supernovae_amd import ops, _lib
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g).cuda()
+    b = torch.randn((K, N) if op_b == 0 else (N, K), generator=g).cuda()
+    bias, aux_in = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+    outs = []
+    try:
+        for bn in (0, 64, 128):
+            ops.set_gemm_tile_n(bn)
+            ops.set_gemm_tail_split(bn != 128)
+            if bn == 0:
+                assert _lib.lib().msn_sgemm_workspace_bytes(0, op_b, M, N, K) == 0
+            kw = {"none": dict(), "gelu": dict(bias=bias, epilogue=ops.EPI_GELU, aux=torch.empty(M, N, device="cuda")),
+                  "add": dict(bias=bias, epilogue=ops.EPI_ADD, aux=aux_in)}[epi]
+            outs.append(ops.sgemm(a, b, 0, op_b, **kw))
+    finally:
+        ops.set_gemm_tile_n(0)
+        ops.set_gemm_tail_split(True)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    if epi == "none":
+        torch.testing.assert_close(outs[0].double(), _ref(a, b, 0, op_b), rtol=1e-4, atol=1e-4 * K ** 0.5)
 
 
 @pytest.mark.parametrize("K,M,N", [(66560, 384, 1536), (4096, 1536, 384), (2048, 64, 256), (1000, 130, 70),

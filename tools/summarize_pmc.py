@@ -23,6 +23,8 @@ def load(root, name):
             keys = [k]
             if "sgemm_kernel" in k or "sgemm_dma_kernel" in k:      # per template instance (layout = the two bools) and the aggregate row
                 keys.append("msn::sgemm_*_kernel<*>")
+            if "bgemm_nt_kernel" in k or "bgemm_tn_kernel" in k:    # bf16-resident GEMMs (cfg5)
+                keys.append("msn::bgemm_{nt,tn}_kernel<*>")
             for k in keys:
                 e = d[k][r["Counter_Name"]]
                 e[0] += 1
@@ -53,13 +55,28 @@ def main():
                       "clock_ghz": clock}
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines[:12]))
+    import datetime
+    import subprocess
+    try:
+        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "unknown"
+    except OSError:
+        commit = "unknown"
+    extra = " ".join(sys.argv[3:])
     g = summary.get("msn::sgemm_*_kernel<*>")
-    if g:
+    if g and "--workload" not in extra:
         json.dump({"kernel": "msn::sgemm_dma_kernel + msn::sgemm_kernel", "traffic_bytes_per_launch": g["traffic_bytes_per_launch"],
                    "mfma_busy_fraction": g["mfma_util"], "effective_clock_ghz": g["clock_ghz"], "launches": g["launches"],
                    "workload": "bench.py default (ViT-S/8 + LC transformer, per-GPU batch 1024)",
+                   "collected": datetime.date.today().isoformat(), "commit": commit,
                    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES passes, tools/summarize_pmc.py"},
                   open(os.path.join(os.path.dirname(out), "pmc_sgemm.json"), "w"), indent=1)
+    bg = summary.get("msn::bgemm_{nt,tn}_kernel<*>")
+    if bg:
+        json.dump({"kernel": "msn::bgemm_nt_kernel + msn::bgemm_tn_kernel", "traffic_bytes_per_launch": bg["traffic_bytes_per_launch"],
+                   "mfma_busy_fraction": bg["mfma_util"], "effective_clock_ghz": bg["clock_ghz"], "launches": bg["launches"],
+                   "workload": "bench.py " + extra, "collected": datetime.date.today().isoformat(), "commit": commit,
+                   "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES passes, tools/summarize_pmc.py"},
+                  open(os.path.join(os.path.dirname(out), "pmc_bgemm.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
