@@ -327,14 +327,6 @@ __global__ __launch_bounds__(64 * AWAVES) void battn_bwd_dkv_kernel(const BAttn 
                     a_read128(qf[t2][kk], qimg + row_frag_addr(2 * j + t2, kk, l15, g));
                     a_read128(df[t2][kk], dimg + row_frag_addr(2 * j + t2, kk, l15, g));
                 }
-            bf16x4 qT[4][2], dT[4][2];                          // Q^T and dO^T fragments of the same 32 queries
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int t2 = 0; t2 < 2; ++t2) {
-                    a_read_tr(qT[dt][t2], qimg + tr_frag_addr(2 * j + t2, dt, g, tq, tp));
-                    a_read_tr(dT[dt][t2], dimg + tr_frag_addr(2 * j + t2, dt, g, tq, tp));
-                }
             a_wait_lds();
             float pr[2][4], ds[2][4];
 #pragma unroll
@@ -354,12 +346,27 @@ __global__ __launch_bounds__(64 * AWAVES) void battn_bwd_dkv_kernel(const BAttn 
                 }
             }
             const bf16x8 pf = pack8(pr[0], pr[1]), dsf = pack8(ds[0], ds[1]);
+            // Q^T and dO^T fragments of the same 32 queries (transposed reads), two d tiles at a time: all four at once
+            // cost 16 more registers and the second workgroup of the CU (142 VGPRs -> 3 waves per SIMD)
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8 dov = __builtin_shufflevector(dT[dt][0], dT[dt][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                const bf16x8 qv = __builtin_shufflevector(qT[dt][0], qT[dt][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dov, pf, dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qv, dsf, dk[dt], 0, 0, 0);
+            for (int half = 0; half < 2; ++half) {
+                bf16x4 qT[2][2], dT[2][2];
+#pragma unroll
+                for (int d2 = 0; d2 < 2; ++d2)
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        a_read_tr(qT[d2][t2], qimg + tr_frag_addr(2 * j + t2, 2 * half + d2, g, tq, tp));
+                        a_read_tr(dT[d2][t2], dimg + tr_frag_addr(2 * j + t2, 2 * half + d2, g, tq, tp));
+                    }
+                a_wait_lds();
+#pragma unroll
+                for (int d2 = 0; d2 < 2; ++d2) {
+                    const int dt = 2 * half + d2;
+                    const bf16x8 dov = __builtin_shufflevector(dT[d2][0], dT[d2][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8 qv = __builtin_shufflevector(qT[d2][0], qT[d2][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dov, pf, dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qv, dsf, dk[dt], 0, 0, 0);
+                }
             }
         }
         const int key = 16 * kt + l15;
