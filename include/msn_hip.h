@@ -225,7 +225,10 @@ int msn_add_rows(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t
  *   msn_layernorm_fwd_bf16 / msn_layernorm_bwd_bf16: nn.LayerNorm as msn_layernorm_fwd / _bwd, writing y as bf16 /
  *                  writing a bf16 copy of dx next to the fp32 one. */
 int msn_bgemm_nt(int64_t M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                 int c_bf16, const float* bias, int epilogue, void* aux, int64_t ldaux, msn_stream_t stream);
+                 int c_bf16, const float* bias, int epilogue, void* aux, int64_t ldaux, float* colsum_out, void* ws,
+                 size_t ws_bytes, msn_stream_t stream);   /* colsum_out (nullable): out[n] = sum_m C[m][n] from the epilogue (the
+                 bias gradient of the Linear whose output gradient C is); ws >= msn_bgemm_nt_colsum_workspace_bytes(M, N) */
+size_t msn_bgemm_nt_colsum_workspace_bytes(int64_t M, int N);
 size_t msn_bgemm_tn_workspace_bytes(int64_t M, int N, int K);
 int msn_bgemm_tn(int64_t M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
                  void* ws, size_t ws_bytes, msn_stream_t stream);
@@ -241,11 +244,14 @@ int msn_layernorm_fwd_bf16(const float* x, int64_t ldx, int64_t rows, int cols, 
 int msn_attention_bf16_fwd(const void* qkv, int64_t ld, int B, int H, int T, float scale, void* out, int64_t ldo, float* lse,
                            msn_stream_t stream);
 int msn_attention_bf16_bwd(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t ldd,
-                           const float* lse, int B, int H, int T, float scale, void* dqkv, float* delta, msn_stream_t stream);
+                           const float* lse, int B, int H, int T, float scale, void* dqkv, float* delta, float* colsum_out,
+                           float* colsum_ws, msn_stream_t stream);   /* colsum_out (3*H*64, nullable): column sums of dqkv = the
+                           bias gradient of the packed projection; colsum_ws: B x 3*H*64 floats */
 int msn_layernorm_bwd_bf16(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t rows, int cols,
                            const float* mean, const float* rstd, const float* gamma, const float* add, int64_t ldadd,
-                           float* dx, int64_t lddx, void* dx_bf16, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
-                           msn_stream_t stream);
+                           float* dx, int64_t lddx, void* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum, void* ws,
+                           size_t ws_bytes, msn_stream_t stream);   /* dx_colsum (nullable): column sums of dx = the bias gradient of
+                           the Linear feeding this LayerNorm's residual add; ws >= 1.5 x msn_layernorm_bwd_workspace_bytes then */
 
 /* ------------------------------------------------------------------------------------------
  * Fused multi-head attention, exact fp32, no T x T tensor in memory -- SelfAttention.forward,

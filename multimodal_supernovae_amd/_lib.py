@@ -51,19 +51,20 @@ SIGNATURES = {
     "msn_mask_tokens": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     "msn_add_rows": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_ptr]),
     "msn_bgemm_nt": (c_int, [c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_i64,
-                             c_ptr]),
+                             c_ptr, c_ptr, c_size, c_ptr]),
+    "msn_bgemm_nt_colsum_workspace_bytes": (c_size, [c_i64, c_int]),
     "msn_bgemm_tn_workspace_bytes": (c_size, [c_i64, c_int, c_int]),
     "msn_bgemm_tn": (c_int, [c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_size, c_ptr]),
     "msn_cast_bf16": (c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
     "msn_attention_bf16_fwd": (c_int, [c_ptr, c_i64, c_int, c_int, c_int, c_f32, c_ptr, c_i64, c_ptr, c_ptr]),
     "msn_attention_bf16_bwd": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_f32, c_ptr,
-                                       c_ptr, c_ptr]),
+                                       c_ptr, c_ptr, c_ptr, c_ptr]),
     "msn_cast_bf16_transposed": (c_int, [c_ptr, c_int, c_int, c_ptr, c_ptr]),
     "msn_bcolsum_workspace_bytes": (c_size, [c_i64, c_int]),
     "msn_bcolsum": (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_size, c_ptr]),
     "msn_layernorm_fwd_bf16": (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_f32, c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
     "msn_layernorm_bwd_bf16": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr,
-                                       c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+                                       c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "msn_attention_fwd": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr,
                                   c_int, c_int, c_int, c_int, c_int, c_f32, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     "msn_attention_bwd": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr,

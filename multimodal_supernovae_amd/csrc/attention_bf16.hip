@@ -45,6 +45,7 @@ struct BAttn {
     u16* dqkv;                          // bwd: [B*T][ld], same layout as qkv
     float* lse;                         // [B][H][T] natural-log sum-exp of the scaled scores
     float* delta;                       // bwd scratch [B][H][T]: rowsum(dO o O)
+    float* colpart;                     // bwd (nullable): [B][3 E] column sums of dq | dk | dv over the tokens of a sample
     int B, H, T;
     float scale;
 };
@@ -114,6 +115,37 @@ __device__ __forceinline__ bf16x8 pack8(const float (&a)[4], const float (&b)[4]
         r[4 + i] = (__bf16)b[i];
     }
     return r;
+}
+
+// Column sums (over the tokens of this (batch, head)) of a gradient tile a wave has just stored: v[dt][r] = this lane's
+// value for d = 16 dt + 4 g + r of token l15 (0 for tokens past T).  The 16 lanes sharing g are reduced by an xor tree and
+// added to the WAVE's own row of an LDS table (single writer: deterministic, no atomics, no registers kept across tiles:
+// a second set of accumulators would cost the second workgroup of the CU); the rows are summed in wave order at the end.
+__device__ __forceinline__ void add_tile_colsum(const float (&v)[4][4], float* __restrict__ wrow, int l15, int g) {
+    // reduce-scatter over the 16 lanes: each halving step trades the half of the values the partner keeps (8 + 4 + 2 + 1
+    // shuffles instead of 16 x 4); lane l15 ends up with the 16-lane sum of value index l15 = 4 dt + r
+    float w8[8], w4[4], w2[2];
+    const bool b3 = l15 & 8, b2 = l15 & 4, b1 = l15 & 2, b0 = l15 & 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float lo = v[i >> 2][i & 3], hi = v[2 + (i >> 2)][i & 3];
+        w8[i] = (b3 ? hi : lo) + __shfl_xor(b3 ? lo : hi, 8, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w4[i] = (b2 ? w8[i + 4] : w8[i]) + __shfl_xor(b2 ? w8[i] : w8[i + 4], 4, 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) w2[i] = (b1 ? w4[i + 2] : w4[i]) + __shfl_xor(b1 ? w4[i] : w4[i + 2], 2, 64);
+    const float t = (b0 ? w2[1] : w2[0]) + __shfl_xor(b0 ? w2[0] : w2[1], 1, 64);
+    // no-return LDS add (ds_add_f32): nothing waits for the round trip; one writer per address
+    __hip_atomic_fetch_add(&wrow[16 * (l15 >> 2) + 4 * g + (l15 & 3)], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+__device__ __forceinline__ void publish_colsum(const float* __restrict__ table, float* __restrict__ out) {
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < AWAVES; ++w) t += table[w * 64 + threadIdx.x];
+        out[threadIdx.x] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------- forward
@@ -220,6 +252,8 @@ __global__ __launch_bounds__(64 * AWAVES) void battn_bwd_dq_kernel(const BAttn p
     const int ntile = (T + 15) / 16, nblk = (T + 31) / 32;
     const float sl = p.scale * ALOG2E;
 
+    __shared__ float cst[AWAVES * 64];                   // per-wave column sums of dq (bias gradient), see add_tile_colsum
+    if (lane < 64) cst[wave * 64 + lane] = 0.f;
     for (int qt = wave; qt < ntile; qt += AWAVES) {
         bf16x8 qf[2], df[2], of[2];
         load_rows(qf, base, p.ld, 16 * qt, T, l15, g);
@@ -276,15 +310,21 @@ __global__ __launch_bounds__(64 * AWAVES) void battn_bwd_dq_kernel(const BAttn p
                 dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kv, dsf, dq[dt], 0, 0, 0);
             }
         }
-        if (q < T) {
-            u16* op = p.dqkv + ((int64_t)b * T + q) * p.ld + h * AHD + 4 * g;
+        float stored[4][4];
+        u16* op = p.dqkv + ((int64_t)b * T + min(q, T - 1)) * p.ld + h * AHD + 4 * g;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                ushort4 v;
-                v.x = abf(dq[dt][0]); v.y = abf(dq[dt][1]); v.z = abf(dq[dt][2]); v.w = abf(dq[dt][3]);
-                *reinterpret_cast<ushort4*>(op + 16 * dt) = v;
-            }
+        for (int dt = 0; dt < 4; ++dt) {
+            ushort4 v;
+            v.x = abf(dq[dt][0]); v.y = abf(dq[dt][1]); v.z = abf(dq[dt][2]); v.w = abf(dq[dt][3]);
+            if (q < T) *reinterpret_cast<ushort4*>(op + 16 * dt) = v;
+            stored[dt][0] = q < T ? afl(v.x) : 0.f; stored[dt][1] = q < T ? afl(v.y) : 0.f;
+            stored[dt][2] = q < T ? afl(v.z) : 0.f; stored[dt][3] = q < T ? afl(v.w) : 0.f;
         }
+        if (p.colpart) add_tile_colsum(stored, cst + wave * 64, l15, g);   // sums of the values as stored
+    }
+    if (p.colpart) {   // bias gradient of the packed projection
+        __syncthreads();
+        publish_colsum(cst, p.colpart + (int64_t)b * 3 * E + h * AHD);
     }
 }
 
@@ -311,6 +351,9 @@ __global__ __launch_bounds__(64 * AWAVES) void battn_bwd_dkv_kernel(const BAttn 
     const int ntile = (T + 15) / 16, nblk = (T + 31) / 32;
     const float sl = p.scale * ALOG2E;
 
+    __shared__ float cst[2 * AWAVES * 64];               // per-wave column sums of dk | dv, see add_tile_colsum
+    cst[wave * 64 + lane] = 0.f;
+    cst[AWAVES * 64 + wave * 64 + lane] = 0.f;
     for (int kt = wave; kt < ntile; kt += AWAVES) {
         bf16x8 kf[2], vf[2];
         load_rows(kf, base + E, p.ld, 16 * kt, T, l15, g);
@@ -370,18 +413,49 @@ __global__ __launch_bounds__(64 * AWAVES) void battn_bwd_dkv_kernel(const BAttn 
             }
         }
         const int key = 16 * kt + l15;
-        if (key < T) {
-            u16* op = p.dqkv + ((int64_t)b * T + key) * p.ld + h * AHD + 4 * g;
+        const bool live = key < T;
+        u16* op = p.dqkv + ((int64_t)b * T + min(key, T - 1)) * p.ld + h * AHD + 4 * g;
+        float stored[4][4];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                ushort4 a, c;
-                a.x = abf(dk[dt][0]); a.y = abf(dk[dt][1]); a.z = abf(dk[dt][2]); a.w = abf(dk[dt][3]);
-                c.x = abf(dv[dt][0]); c.y = abf(dv[dt][1]); c.z = abf(dv[dt][2]); c.w = abf(dv[dt][3]);
-                *reinterpret_cast<ushort4*>(op + E + 16 * dt) = a;
-                *reinterpret_cast<ushort4*>(op + 2 * E + 16 * dt) = c;
-            }
+        for (int dt = 0; dt < 4; ++dt) {
+            ushort4 a;
+            a.x = abf(dk[dt][0]); a.y = abf(dk[dt][1]); a.z = abf(dk[dt][2]); a.w = abf(dk[dt][3]);
+            if (live) *reinterpret_cast<ushort4*>(op + E + 16 * dt) = a;
+            stored[dt][0] = live ? afl(a.x) : 0.f; stored[dt][1] = live ? afl(a.y) : 0.f;
+            stored[dt][2] = live ? afl(a.z) : 0.f; stored[dt][3] = live ? afl(a.w) : 0.f;
         }
+        if (p.colpart) add_tile_colsum(stored, cst + wave * 64, l15, g);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            ushort4 c;
+            c.x = abf(dv[dt][0]); c.y = abf(dv[dt][1]); c.z = abf(dv[dt][2]); c.w = abf(dv[dt][3]);
+            if (live) *reinterpret_cast<ushort4*>(op + 2 * E + 16 * dt) = c;
+            stored[dt][0] = live ? afl(c.x) : 0.f; stored[dt][1] = live ? afl(c.y) : 0.f;
+            stored[dt][2] = live ? afl(c.z) : 0.f; stored[dt][3] = live ? afl(c.w) : 0.f;
+        }
+        if (p.colpart) add_tile_colsum(stored, cst + AWAVES * 64 + wave * 64, l15, g);
     }
+    if (p.colpart) {
+        __syncthreads();
+        publish_colsum(cst, p.colpart + (int64_t)b * 3 * E + E + h * AHD);
+        publish_colsum(cst + AWAVES * 64, p.colpart + (int64_t)b * 3 * E + 2 * E + h * AHD);
+    }
+}
+
+// out[n] = sum over the batch of part[b][n], eight independent loads per wait, fixed order
+__global__ void battn_colsum_finish_kernel(const float* __restrict__ part, int nparts, int N, float* __restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int k0 = 0; k0 < nparts; k0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = part[(int64_t)min(k0 + j, nparts - 1) * N + n];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (k0 + j < nparts) s += v[j];
+    }
+    out[n] = s;
 }
 
 static int check_battn(const char* who, int B, int H, int T, int64_t ld, int64_t ldo) {
@@ -408,9 +482,11 @@ extern "C" int msn_attention_bf16_fwd(const void* qkv, int64_t ld, int B, int H,
     return MSN_OK;
 }
 
+// bias gradient of the packed projection from inside the passes: colsum_out (3 E floats, nullable) = column sums of dqkv;
+// colsum_ws = B x 3 E floats of per-sample partials (summed over the batch in a fixed order)
 extern "C" int msn_attention_bf16_bwd(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout, int64_t ldd,
                                       const float* lse, int B, int H, int T, float scale, void* dqkv, float* delta,
-                                      msn_stream_t stream) {
+                                      float* colsum_out, float* colsum_ws, msn_stream_t stream) {
     if (int rc = check_battn("msn_attention_bf16_bwd", B, H, T, ld, ldo)) return rc;
     MSN_REQUIRE(qkv && out && dout && lse && dqkv && delta && ldd >= H * AHD && ldd % 8 == 0 &&
                     (reinterpret_cast<uintptr_t>(qkv) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
@@ -420,10 +496,17 @@ extern "C" int msn_attention_bf16_bwd(const void* qkv, int64_t ld, const void* o
     a.qkv = static_cast<const u16*>(qkv); a.ld = ld; a.out = const_cast<u16*>(static_cast<const u16*>(out)); a.ldo = ldo;
     a.dout = static_cast<const u16*>(dout); a.ldd = ldd; a.dqkv = static_cast<u16*>(dqkv); a.lse = const_cast<float*>(lse);
     a.delta = delta; a.B = B; a.H = H; a.T = T; a.scale = scale;
+    MSN_REQUIRE(!colsum_out || colsum_ws, "msn_attention_bf16_bwd: column sums need the (B, 3 E) workspace");
+    a.colpart = colsum_out ? colsum_ws : nullptr;
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(battn_bwd_dq_kernel, dim3((unsigned)(B * H)), dim3(64 * AWAVES), 0, st, a);      // also writes delta
     MSN_LAUNCH_CHECK();
     hipLaunchKernelGGL(battn_bwd_dkv_kernel, dim3((unsigned)(B * H)), dim3(64 * AWAVES), 0, st, a);
     MSN_LAUNCH_CHECK();
+    if (colsum_out) {
+        hipLaunchKernelGGL(battn_colsum_finish_kernel, dim3((unsigned)cdiv(3 * H * AHD, 256)), dim3(256), 0, st, colsum_ws, B,
+                           3 * H * AHD, colsum_out);
+        MSN_LAUNCH_CHECK();
+    }
     return MSN_OK;
 }

@@ -83,6 +83,7 @@ struct BgemmArgs {
     int N, K;                  // NT: C is M x N, reduction K.  TN: C is N x K
     int tiles_m, tiles_n;      // NT: tile grid.  TN: tiles over N and K
     int super_rows;            // NT: tile-rows walked together (L2 blocking)
+    float* colpart;            // NT (nullable): [2 * tiles_m][N] column sums of the values written to C, per 128-row slab
     int splits; int64_t rows_per_split;   // TN: reduction split
     float* slabs;              // TN: [splits][N][K] partials (splits > 1)
 };
@@ -229,6 +230,11 @@ __global__ __launch_bounds__(512, 2) void bgemm_nt_kernel(const BgemmArgs p) {
         const int n = ncol0 + 16 * j;
         bias4[j] = (p.bias && n + 3 < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    float cs[4][4];                                            // column sums of this wave's 128 rows (bias gradient)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cs[j][r] = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int64_t m = mrow0 + 16 * i;
@@ -258,8 +264,31 @@ __global__ __launch_bounds__(512, 2) void bgemm_nt_kernel(const BgemmArgs p) {
                 ushort4 o;
                 o.x = f2bf(v[0]); o.y = f2bf(v[1]); o.z = f2bf(v[2]); o.w = f2bf(v[3]);
                 *reinterpret_cast<ushort4*>(static_cast<u16*>(p.C) + m * p.ldc + n) = o;
+                if (p.colpart) {                               // sums of the values AS STORED (what the next products read)
+                    cs[j][0] += bf2f(o.x); cs[j][1] += bf2f(o.y); cs[j][2] += bf2f(o.z); cs[j][3] += bf2f(o.w);
+                }
             } else {
                 *reinterpret_cast<float4*>(static_cast<float*>(p.C) + m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                if (p.colpart) { cs[j][0] += v[0]; cs[j][1] += v[1]; cs[j][2] += v[2]; cs[j][3] += v[3]; }
+            }
+        }
+    }
+    if (p.colpart) {   // the 16 lanes sharing g hold the 16 rows of every row tile: xor tree, then lane l15 == 0 writes 4 columns
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = cs[j][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o, 64);
+                cs[j][r] = t;
+            }
+        if (l15 == 0) {
+            float* row = p.colpart + (int64_t)(2 * tm + wm) * p.N;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = ncol0 + 16 * j;
+                if (n + 3 < p.N) *reinterpret_cast<float4*>(row + n) = make_float4(cs[j][0], cs[j][1], cs[j][2], cs[j][3]);
             }
         }
     }
@@ -499,19 +528,28 @@ __global__ __launch_bounds__(256) void bcolsum_part_kernel(const u16* __restrict
         }
     }
 }
-__global__ void bcolsum_finish_kernel(const float* __restrict__ part, int nparts, int N, float* __restrict__ out) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+// out[n] = sum_k part[k][n]: 64 columns x 4 row groups per workgroup (group rg sums the parts k = rg, rg + 4, ... eight
+// independent loads per wait), the four group sums combined through LDS in a fixed order
+__global__ __launch_bounds__(256) void bcolsum_finish_kernel(const float* __restrict__ part, int nparts, int N,
+                                                             float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int k0 = 0; k0 < nparts; k0 += 8) {
-        float v[8];
+    if (n < N) {
+        const int mine = (nparts - rg + 3) / 4;                 // parts this group owns
+        for (int k0 = 0; k0 < mine; k0 += 8) {
+            float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = part[(int64_t)std::min(k0 + j, nparts - 1) * N + n];
+            for (int j = 0; j < 8; ++j) v[j] = part[(int64_t)(rg + 4 * std::min(k0 + j, mine - 1)) * N + n];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (k0 + j < nparts) s += v[j];
+            for (int j = 0; j < 8; ++j)
+                if (k0 + j < mine) s += v[j];
+        }
     }
-    out[n] = s;
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && n < N) out[n] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -527,9 +565,14 @@ static int tn_splits(int tiles, int64_t M) {
 
 using namespace msn;
 
+extern "C" size_t msn_bgemm_nt_colsum_workspace_bytes(int64_t M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    return sizeof(float) * 2 * (size_t)cdiv(M, BT) * (size_t)N;
+}
+
 extern "C" int msn_bgemm_nt(int64_t M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
                             int64_t ldc, int c_bf16, const float* bias, int epilogue, void* aux, int64_t ldaux,
-                            msn_stream_t stream) {
+                            float* colsum_out, void* ws, size_t ws_bytes, msn_stream_t stream) {
     MSN_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, "msn_bgemm_nt: empty operand");
     MSN_REQUIRE(K % BKS == 0 && N % 4 == 0, "msn_bgemm_nt: K = %d must be a multiple of 64 and N = %d of 4", K, N);
     MSN_REQUIRE(lda >= K && ldb >= K && lda % 8 == 0 && ldb % 8 == 0 && aligned16(A) && aligned16(B),
@@ -545,6 +588,12 @@ extern "C" int msn_bgemm_nt(int64_t M, int N, int K, const void* A, int64_t lda,
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux; a.M = M; a.N = N; a.K = K;
     a.tiles_m = (int)cdiv(M, BT); a.tiles_n = (int)cdiv(N, BT);
     a.super_rows = std::max(1, std::min(8, 4096 / K));
+    a.colpart = nullptr;
+    if (colsum_out) {
+        const size_t need = msn_bgemm_nt_colsum_workspace_bytes(M, N);
+        MSN_REQUIRE(ws && ws_bytes >= need && aligned16(ws) && N % 4 == 0, "msn_bgemm_nt: column-sum workspace %zu < %zu bytes", ws_bytes, need);
+        a.colpart = static_cast<float*>(ws);
+    }
     const dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(512);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (epilogue == EPI_B_GELU) hipLaunchKernelGGL((bgemm_nt_kernel<EPI_B_GELU, true>), grid, block, 0, st, a);
@@ -557,6 +606,11 @@ extern "C" int msn_bgemm_nt(int64_t M, int N, int K, const void* A, int64_t lda,
         else hipLaunchKernelGGL((bgemm_nt_kernel<EPI_B_NONE, false>), grid, block, 0, st, a);
     }
     MSN_LAUNCH_CHECK();
+    if (colsum_out) {   // every (row slab, column) partial was written by exactly one wave: fixed-order sum over the slabs
+        hipLaunchKernelGGL(bcolsum_finish_kernel, dim3((unsigned)cdiv(N, 64)), dim3(256), 0, st, a.colpart, 2 * a.tiles_m, N,
+                           colsum_out);
+        MSN_LAUNCH_CHECK();
+    }
     return MSN_OK;
 }
 
@@ -630,7 +684,7 @@ extern "C" int msn_bcolsum(const void* X, int64_t ldx, int64_t M, int N, float* 
     hipLaunchKernelGGL(bcolsum_part_kernel, dim3((unsigned)cdiv(N / 8, 32), (unsigned)parts), dim3(256), 0, st,
                        static_cast<const u16*>(X), ldx, M, N / 8, rows_per_block, part);
     MSN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bcolsum_finish_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, st, part, parts, N, out);
+    hipLaunchKernelGGL(bcolsum_finish_kernel, dim3((unsigned)cdiv(N, 64)), dim3(256), 0, st, part, parts, N, out);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }

@@ -115,14 +115,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ gamma, float* __restrict__ dx,
                                                      int64_t lddx, float* __restrict__ part,
                                                      const float* __restrict__ add, int64_t ldadd,
-                                                     unsigned short* __restrict__ dxb) {
+                                                     unsigned short* __restrict__ dxb, int want_dxsum) {
     constexpr int RG = 256 / LPR;
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // [RG][2][cols]
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [RG][2 or 3][cols]
     const int lr = threadIdx.x % LPR, rg = threadIdx.x / LPR;
-    float4 gm[NCH], dg[NCH], db[NCH];
+    const int nacc = want_dxsum ? 3 : 2;     // third accumulator: column sums of dx (the bias gradient of the Linear
+                                             // that produced this LayerNorm's input through a residual add)
+    float4 gm[NCH], dg[NCH], db[NCH], sx[NCH];
     load_row<LPR>(gm, gamma, g.cols, lr);
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) dg[k] = db[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < NCH; ++k) dg[k] = db[k] = sx[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float inv_n = 1.f / (float)g.cols;
     for (int64_t r = (int64_t)blockIdx.x * RG + rg; r < g.rows; r += (int64_t)gridDim.x * RG) {
         float4 v[NCH], d[NCH];
@@ -159,23 +161,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         }
         store_row<LPR>(d, dx + r * lddx, g.cols, lr);
         if (dxb) store_row_bf16<LPR>(d, dxb + r * lddx, g.cols, lr);
+        if (want_dxsum) {
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) { sx[k].x += d[k].x; sx[k].y += d[k].y; sx[k].z += d[k].z; sx[k].w += d[k].w; }
+        }
     }
-    // reduce the RG row-groups of this block, then publish [2][cols] for the final pass
-    float* mine = lds + (int64_t)rg * 2 * g.cols;
+    // reduce the RG row-groups of this block, then publish [nacc][cols] for the final pass
+    float* mine = lds + (int64_t)rg * nacc * g.cols;
     store_row<LPR>(dg, mine, g.cols, lr);
     store_row<LPR>(db, mine + g.cols, g.cols, lr);
+    if (want_dxsum) store_row<LPR>(sx, mine + 2 * g.cols, g.cols, lr);
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * g.cols; i += 256) {
+    for (int i = threadIdx.x; i < nacc * g.cols; i += 256) {
         float s = 0.f;
-        for (int k = 0; k < RG; ++k) s += lds[(int64_t)k * 2 * g.cols + i];
-        part[(int64_t)blockIdx.x * 2 * g.cols + i] = s;
+        for (int k = 0; k < RG; ++k) s += lds[(int64_t)k * nacc * g.cols + i];
+        part[(int64_t)blockIdx.x * nacc * g.cols + i] = s;
     }
 }
 
 // out[i] = sum_b part[b][i], i < n : 16 slab groups x 64 columns per block (each thread keeps 4 independent loads
 // in flight), LDS-combined in a fixed order
 __global__ __launch_bounds__(1024) void sum_slabs_kernel(const float* __restrict__ part, int nslabs, int n,
-                                                         float* __restrict__ out0, float* __restrict__ out1, int split) {
+                                                         float* __restrict__ out0, float* __restrict__ out1, int split,
+                                                         float* __restrict__ out2 = nullptr) {
     __shared__ float red[16][64];
     const int cl = threadIdx.x % 64, g = threadIdx.x / 64;
     const int i = blockIdx.x * 64 + cl;
@@ -197,7 +205,8 @@ __global__ __launch_bounds__(1024) void sum_slabs_kernel(const float* __restrict
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += red[k][cl];
         if (i < split) out0[i] = t;
-        else out1[i - split] = t;
+        else if (i < 2 * split || !out2) out1[i - split] = t;
+        else out2[i - 2 * split] = t;
     }
 }
 
@@ -686,7 +695,7 @@ extern "C" int msn_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
     float* part = static_cast<float*>(ws);
     const size_t lds = sizeof(float) * 2 * (size_t)cols * (256 / lpr);
     MSN_LPR_DISPATCH(ln_bwd_kernel, lpr, dim3(grid), lds, st, dy, lddy, x, ldx, g, mean, rstd, gamma, dx, lddx, part, add, ldadd,
-                     (unsigned short*)nullptr)
+                     (unsigned short*)nullptr, 0)
     MSN_LAUNCH_CHECK();
     hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)cdiv(2 * cols, 64)), dim3(1024), 0, st, part, grid, 2 * cols,
                        dgamma, dbeta, cols);
@@ -699,7 +708,7 @@ extern "C" int msn_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
 extern "C" int msn_layernorm_bwd_bf16(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t rows, int cols,
                                       const float* mean, const float* rstd, const float* gamma, const float* add,
                                       int64_t ldadd, float* dx, int64_t lddx, void* dx_bf16, float* dgamma, float* dbeta,
-                                      void* ws, size_t ws_bytes, msn_stream_t stream) {
+                                      float* dx_colsum, void* ws, size_t ws_bytes, msn_stream_t stream) {
     if (int rc = check_rows("msn_layernorm_bwd_bf16", rows, cols, {lddy, ldx, lddx}, {dy, x, dx, gamma})) return rc;
     MSN_REQUIRE(mean && rstd && dgamma && dbeta && dx_bf16 && (reinterpret_cast<uintptr_t>(dx_bf16) & 7) == 0,
                 "msn_layernorm_bwd_bf16: null pointer");
@@ -707,16 +716,17 @@ extern "C" int msn_layernorm_bwd_bf16(const float* dy, int64_t lddy, const float
                 "msn_layernorm_bwd_bf16: bad residual-gradient operand");
     const int lpr = pick_lpr(cols);
     const int grid = ln_bwd_grid(rows, lpr);
-    MSN_REQUIRE(ws && ws_bytes >= sizeof(float) * 2 * (size_t)cols * grid, "msn_layernorm_bwd_bf16: workspace too small");
+    const int nacc = dx_colsum ? 3 : 2;
+    MSN_REQUIRE(ws && ws_bytes >= sizeof(float) * nacc * (size_t)cols * grid, "msn_layernorm_bwd_bf16: workspace too small");
     const RowGeom g{rows, cols, ldx};
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* part = static_cast<float*>(ws);
-    const size_t lds = sizeof(float) * 2 * (size_t)cols * (256 / lpr);
+    const size_t lds = sizeof(float) * nacc * (size_t)cols * (256 / lpr);
     MSN_LPR_DISPATCH(ln_bwd_kernel, lpr, dim3(grid), lds, st, dy, lddy, x, ldx, g, mean, rstd, gamma, dx, lddx, part, add, ldadd,
-                     static_cast<unsigned short*>(dx_bf16))
+                     static_cast<unsigned short*>(dx_bf16), dx_colsum ? 1 : 0)
     MSN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)cdiv(2 * cols, 64)), dim3(1024), 0, st, part, grid, 2 * cols,
-                       dgamma, dbeta, cols);
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)cdiv(nacc * cols, 64)), dim3(1024), 0, st, part, grid, nacc * cols,
+                       dgamma, dbeta, cols, dx_colsum);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }

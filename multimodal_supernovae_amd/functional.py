@@ -686,23 +686,22 @@ class _Bf16VitTrunk(torch.autograd.Function):
         grads = [None] * len(P)
         d2 = _c(dy).view(M, e)
         d2b = ops.cast_bf16(d2)
-        for i in range(n_blocks - 1, -1, -1):
+        dc2 = colsum(d2)                      # bias gradient of the last block's second MLP layer; the other blocks get
+        for i in range(n_blocks - 1, -1, -1):  # theirs from the LayerNorm backward that produced their d2
             x2, m1, r1, h1, qkv, a2, ab, lse, x1, m2, r2, h2, pre, f = acts[NS * i: NS * i + NS]
             g1, b1, wqkv, bqkv, wo, bo, g2, b2, w1, c1, w2, c2 = P[12 * i: 12 * i + 12]
-            # input gradients dX = dY . W are NT products against the transposed bf16 weight copy (K-contiguous operands)
+            # input gradients dX = dY . W are NT products against the transposed bf16 weight copy (K-contiguous operands);
+            # every bias gradient (a column sum of a gradient matrix) comes out of the kernel that writes that matrix
             dw2 = ops.bgemm_tn(d2b, f)
-            dc2 = colsum(d2)
-            dpre = ops.bgemm_nt(d2b, ops.cast_bf16_t(w2), epilogue=ops.BEPI_GELU_BWD, aux=pre, out_bf16=True)
+            dpre, dc1 = ops.bgemm_nt(d2b, ops.cast_bf16_t(w2), epilogue=ops.BEPI_GELU_BWD, aux=pre, out_bf16=True,
+                                     want_colsum=True)
             dw1 = ops.bgemm_tn(dpre, h2)
-            dc1 = ops.bcolsum(dpre)
             dh2 = ops.bgemm_nt(dpre, ops.cast_bf16_t(w1))
-            dx1, dx1b, dg2, db2 = ops.layernorm_bwd_bf16(dh2, x1, m2, r2, g2, add=d2)     # + skip connection
+            dx1, dx1b, dg2, db2, dbo = ops.layernorm_bwd_bf16(dh2, x1, m2, r2, g2, add=d2, want_colsum=True)   # + skip
             dwo = ops.bgemm_tn(dx1b, ab)
-            dbo = colsum(dx1)
             if battn:
                 da = ops.bgemm_nt(dx1b, ops.cast_bf16_t(wo), out_bf16=True)
-                dqkvb = ops.attention_bf16_bwd(qkv, ab, da, lse, B, T, heads, scale)
-                dbqkv = ops.bcolsum(dqkvb)
+                dqkvb, dbqkv = ops.attention_bf16_bwd(qkv, ab, da, lse, B, T, heads, scale, want_colsum=True)
             else:
                 da = ops.bgemm_nt(dx1b, ops.cast_bf16_t(wo))
                 dqkv = torch.empty_like(qkv)
@@ -713,8 +712,9 @@ class _Bf16VitTrunk(torch.autograd.Function):
                 dbqkv = colsum(dqkv)
             dwqkv = ops.bgemm_tn(dqkvb, h1)
             dh1 = ops.bgemm_nt(dqkvb, ops.cast_bf16_t(wqkv))
-            d2, d2b, dg1, db1 = ops.layernorm_bwd_bf16(dh1, x2, m1, r1, g1, add=dx1)      # + skip connection
-            grads[12 * i: 12 * i + 12] = [dg1, db1, dwqkv, dbqkv, dwo, dbo, dg2, db2, dw1, dc1, dw2, dc2]
+            grads[12 * i: 12 * i + 12] = [None, None, dwqkv, dbqkv, dwo, dbo, dg2, db2, dw1, dc1, dw2, dc2]
+            d2, d2b, dg1, db1, dc2 = ops.layernorm_bwd_bf16(dh1, x2, m1, r1, g1, add=dx1, want_colsum=True)   # + skip
+            grads[12 * i], grads[12 * i + 1] = dg1, db1
         return (d2.view(B, T, e), None, None, None, *grads)
 
 

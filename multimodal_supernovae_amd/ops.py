@@ -600,8 +600,9 @@ def bgemm_supported(M, N, K):
     return K % 64 == 0 and N % 8 == 0 and M > 0
 
 
-def bgemm_nt(a, w, bias=None, epilogue=BEPI_NONE, aux=None, out_bf16=False, flops_log=True):
-    """C = epi(a @ w.T + bias): a (M, K) bf16, w (N, K) bf16, both with contiguous rows -> (M, N) fp32 or bf16."""
+def bgemm_nt(a, w, bias=None, epilogue=BEPI_NONE, aux=None, out_bf16=False, want_colsum=False):
+    """C = epi(a @ w.T + bias): a (M, K) bf16, w (N, K) bf16, both with contiguous rows -> (M, N) fp32 or bf16.
+    want_colsum: also return the column sums of C (computed in the epilogue) as the last element of the result."""
     _bf16c(a, "a"), _bf16c(w, "w")
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and a.shape[1] == w.shape[1]
     M, K = a.shape
@@ -609,16 +610,25 @@ def bgemm_nt(a, w, bias=None, epilogue=BEPI_NONE, aux=None, out_bf16=False, flop
     c = torch.empty((M, N), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=a.device)
     if epilogue == BEPI_GELU and aux is None:
         aux = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    cs, ws, nb = None, None, 0
+    if want_colsum:
+        cs = torch.empty(N, dtype=torch.float32, device=a.device)
+        nb = lib().msn_bgemm_nt_colsum_workspace_bytes(M, N)
+        ws = _workspace(nb, a.device)
     prof = GEMM_PROFILE
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     check(lib().msn_bgemm_nt(M, N, K, ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(c), N, 1 if out_bf16 else 0, ptr(bias),
-                             epilogue, ptr(aux), aux.stride(0) if aux is not None else 0, stream_ptr()), "msn_bgemm_nt")
+                             epilogue, ptr(aux), aux.stride(0) if aux is not None else 0, ptr(cs), ptr(ws), nb, stream_ptr()),
+          "msn_bgemm_nt")
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1, 2.0 * M * N * K, (OP_N, OP_T, M, N, K, 100 + epilogue), aux is not None))
-    return (c, aux) if epilogue == BEPI_GELU else c
+    out = (c, aux) if epilogue == BEPI_GELU else (c,)
+    if want_colsum:
+        out = out + (cs,)
+    return out if len(out) > 1 else out[0]
 
 
 def bgemm_tn(dy, x):
@@ -686,8 +696,8 @@ def layernorm_fwd_bf16(x, gamma, beta, eps=1e-5):
     return y, mean, rstd
 
 
-def layernorm_bwd_bf16(dy, x, mean, rstd, gamma, add=None):
-    """LayerNorm backward returning (dx fp32, dx bf16 copy, dgamma, dbeta)."""
+def layernorm_bwd_bf16(dy, x, mean, rstd, gamma, add=None, want_colsum=False):
+    """LayerNorm backward returning (dx fp32, dx bf16 copy, dgamma, dbeta[, column sums of dx])."""
     dy2, x2 = _rows2d(_f32c(dy, "dy")), _rows2d(x)
     add2 = _rows2d(add) if add is not None else None
     rows, cols = x2.shape
@@ -695,13 +705,14 @@ def layernorm_bwd_bf16(dy, x, mean, rstd, gamma, add=None):
     dxb = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device)
     dg = torch.empty(cols, dtype=torch.float32, device=x.device)
     db = torch.empty(cols, dtype=torch.float32, device=x.device)
+    cs = torch.empty(cols, dtype=torch.float32, device=x.device) if want_colsum else None
     L = lib()
-    nb = L.msn_layernorm_bwd_workspace_bytes(rows, cols)
+    nb = L.msn_layernorm_bwd_workspace_bytes(rows, cols) * 3 // 2
     ws = _workspace(nb, x.device)
     check(L.msn_layernorm_bwd_bf16(ptr(dy2), dy2.stride(0), ptr(x2), x2.stride(0), rows, cols, ptr(mean), ptr(rstd),
                                    ptr(gamma), ptr(add2), add2.stride(0) if add2 is not None else 0, ptr(dx), cols, ptr(dxb),
-                                   ptr(dg), ptr(db), ptr(ws), nb, stream_ptr()), "msn_layernorm_bwd_bf16")
-    return dx, dxb, dg, db
+                                   ptr(dg), ptr(db), ptr(cs), ptr(ws), nb, stream_ptr()), "msn_layernorm_bwd_bf16")
+    return (dx, dxb, dg, db, cs) if want_colsum else (dx, dxb, dg, db)
 
 
 def attention_bf16_supported(T, head_dim):
@@ -720,12 +731,17 @@ def attention_bf16_fwd(qkv, B, T, heads, scale):
     return out, lse
 
 
-def attention_bf16_bwd(qkv, out, dout, lse, B, T, heads, scale):
-    """Gradient w.r.t. the packed projection: (B*T, 3*heads*64) bf16 [dq | dk | dv]."""
+def attention_bf16_bwd(qkv, out, dout, lse, B, T, heads, scale, want_colsum=False):
+    """Gradient w.r.t. the packed projection: (B*T, 3*heads*64) bf16 [dq | dk | dv] (+ its column sums, fp32)."""
     _bf16c(qkv, "qkv"), _bf16c(out, "out"), _bf16c(dout, "dout")
     assert dout.shape == out.shape and dout.stride(1) == 1 and out.stride(1) == 1
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, heads, T), dtype=torch.float32, device=qkv.device)
+    cs = ws = None
+    if want_colsum:
+        cs = torch.empty(3 * heads * 64, dtype=torch.float32, device=qkv.device)
+        ws = torch.empty((B, 3 * heads * 64), dtype=torch.float32, device=qkv.device)
     check(lib().msn_attention_bf16_bwd(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), ptr(dout), dout.stride(0), ptr(lse), B,
-                                       heads, T, scale, ptr(dqkv), ptr(delta), stream_ptr()), "msn_attention_bf16_bwd")
-    return dqkv
+                                       heads, T, scale, ptr(dqkv), ptr(delta), ptr(cs), ptr(ws), stream_ptr()),
+          "msn_attention_bf16_bwd")
+    return (dqkv, cs) if want_colsum else dqkv

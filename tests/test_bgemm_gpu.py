@@ -88,6 +88,26 @@ def test_casts_colsum_and_layernorm_variants():
     dx32, dg32, db32 = ops.layernorm_bwd(dy, x, m32, r32, gamma, add=add)
     dx, dxb, dg, db = ops.layernorm_bwd_bf16(dy, x, m32, r32, gamma, add=add)
     assert torch.equal(dx, dx32) and torch.equal(dxb, dx32.to(torch.bfloat16)) and torch.equal(dg, dg32) and torch.equal(db, db32)
+    dx2, dxb2, dg2, db2, cs = ops.layernorm_bwd_bf16(dy, x, m32, r32, gamma, add=add, want_colsum=True)
+    assert torch.equal(dx2, dx32) and torch.equal(dg2, dg32) and torch.equal(db2, db32)
+    torch.testing.assert_close(cs.double(), dx32.double().sum(0), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 264, 192), (4000, 3072, 768), (257, 768, 64)])
+def test_nt_epilogue_column_sums(M, N, K):
+    """Bias gradients from the epilogue of the product that writes the gradient matrix: out[n] = sum_m C[m][n] of the
+    values AS STORED (bf16-rounded when C is bf16), for the plain and the GELU' epilogue."""
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(M)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    pre = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+    c, cs = ops.bgemm_nt(a, w, want_colsum=True)
+    assert torch.equal(c, ops.bgemm_nt(a, w))
+    torch.testing.assert_close(cs.double(), c.double().sum(0), rtol=1e-5, atol=1e-3)
+    d, ds = ops.bgemm_nt(a, w, epilogue=ops.BEPI_GELU_BWD, aux=pre, out_bf16=True, want_colsum=True)
+    assert torch.equal(d, ops.bgemm_nt(a, w, epilogue=ops.BEPI_GELU_BWD, aux=pre, out_bf16=True))
+    torch.testing.assert_close(ds.double(), d.double().sum(0), rtol=1e-5, atol=1e-3)
 
 
 def test_resident_trunk_equals_the_fp32_storage_bf16_path():
@@ -133,6 +153,9 @@ def test_bf16_attention_forward_backward(B, H, T):
     torch.testing.assert_close(out.cpu().double(), ref.detach(), rtol=2e-2, atol=2e-2)
     torch.testing.assert_close(lse.cpu().double(), lse_ref.detach(), rtol=1e-4, atol=1e-4)
     dqkv = ops.attention_bf16_bwd(qkv.cuda(), out, dout.cuda(), lse, B, T, H, scale)
+    dqkv2, cs = ops.attention_bf16_bwd(qkv.cuda(), out, dout.cuda(), lse, B, T, H, scale, want_colsum=True)
+    assert torch.equal(dqkv, dqkv2)                          # bias gradient of the packed projection from inside the passes
+    torch.testing.assert_close(cs.double(), dqkv.double().sum(0), rtol=1e-4, atol=1e-3)
     err = (dqkv.cpu().double() - dref).abs().max() / dref.abs().max()
     assert err < 2e-2, float(err)
     cosv = float((dqkv.cpu().double().flatten() @ dref.flatten()) / (dqkv.cpu().double().norm() * dref.norm()))
