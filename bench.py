@@ -228,16 +228,38 @@ def launch_ranks(n, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.setdefault("OMP_NUM_THREADS", "4")             # N ranks share the host: no N x all-cores thread pools
         if n_dev < n:
             env.setdefault("MSN_DIST_BACKEND", "gloo")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    # rank 0's line is read by a thread; the parent watches the children: if one dies the others would wait for it inside
+    # a collective for ever, so they are stopped (by the PIDs started here) and the failure is reported
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = r
+        time.sleep(0.2)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    reader.join(timeout=30)
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
-    if any(codes):
-        raise SystemExit(f"rank exit codes {codes}")
+    codes = [p.returncode for p in procs]
+    if failed is not None or any(codes):
+        raise SystemExit(f"rank {failed} failed; exit codes {codes}")
 
 
 def main():

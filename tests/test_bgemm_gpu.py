@@ -110,12 +110,13 @@ def test_nt_epilogue_column_sums(M, N, K):
     torch.testing.assert_close(ds.double(), d.double().sum(0), rtol=1e-5, atol=1e-3)
 
 
-def test_resident_trunk_equals_the_fp32_storage_bf16_path():
+@pytest.mark.parametrize("heads", [2, 4])          # 64-wide heads: bf16 attention kernels; 32-wide: fp32 attention + casts
+def test_resident_trunk_equals_the_fp32_storage_bf16_path(heads):
     """ViT blocks through functional._Bf16VitTrunk == the same blocks with gemm_precision "bf16" on fp32-stored
     activations, up to bf16 rounding noise (direction of every gradient, tight bound on the output)."""
     from multimodal_supernovae_amd.encoders import VisionTransformer
     torch.manual_seed(9)
-    m = VisionTransformer(img_size=32, patch_size=8, emb=128, depth=3, heads=2, n_out=8, gemm_precision="bf16").cuda()
+    m = VisionTransformer(img_size=32, patch_size=8, emb=128, depth=3, heads=heads, n_out=8, gemm_precision="bf16").cuda()
     x = torch.rand(6, 3, 32, 32, device="cuda")
     cot = torch.randn(6, 8, device="cuda")
     res = []

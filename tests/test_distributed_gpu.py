@@ -56,3 +56,11 @@ def test_bench_launches_its_own_ranks():
     assert per["grad_all_reduce"]["calls"] >= 1
     weak = out["weak_scaling_256_per_gpu"]
     assert weak["global_batch"] == 512 and weak["value"] > 0
+
+
+def test_trainer_validation_with_uneven_shards_two_ranks():
+    """`Trainer.fit(model, train, val)` on two ranks whose VALIDATION shards differ in length and batch sizes: no hang, both
+    ranks report the batch-weighted global val_loss; an uneven TRAINING shard is refused with an error instead of a hang."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dist_check.py"), "--trainer"], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "DIST CHECK OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

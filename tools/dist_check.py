@@ -17,6 +17,7 @@ SK = dict(n_out=8, emb=8, heads=2, depth=2, dropout=0.0, time_norm=17945.14, agg
 
 CK = dict(dim=8, depth=2, channels=3, kernel_size=5, patch_size=4, n_out=8, dropout_prob=0.0)
 BATCHNORM = "--batchnorm" in sys.argv     # ConvMixer image tower + light curves, synchronised BatchNorm
+TRAINER = "--trainer" in sys.argv         # Trainer.fit with a validation loader whose shards are UNEVEN across the ranks
 
 
 def make_model():
@@ -39,6 +40,40 @@ def make_batch(n):
     return (None, torch.randn(n, 12, generator=g), torch.rand(n, 12, generator=g) * 100, mask,
             torch.randn(n, 10, generator=g), torch.rand(n, 10, generator=g) * 6000 + 3000,
             torch.ones(n, 10, dtype=torch.bool), None, None)
+
+
+def trainer_worker(rank, world, port, out):
+    """Two ranks through Trainer.fit: equal training shards (global negatives), validation shards of DIFFERENT length
+    (rank 0: batches of 8 + 8 + 3 rows, rank 1: one batch of 5) -- the validation loop must not issue a collective per
+    batch (it would hang or gather mismatched rows); the epoch's val_loss is the batch-weighted mean over both shards of
+    each rank's local-negatives loss; an unequal TRAINING shard is refused up front."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from multimodal_supernovae_amd import distributed as D
+    from multimodal_supernovae_amd.trainer import Trainer
+    D.init_from_env(backend="gloo")
+    full = make_batch(40)
+    cut = lambda lo, hi: tuple(t[lo:hi] if t is not None else None for t in full)
+    train = [cut(rank * 8, rank * 8 + 8), cut(16 + rank * 8, 16 + rank * 8 + 8)]
+    val = [cut(0, 8), cut(8, 16), cut(16, 19)] if rank == 0 else [cut(32, 37)]
+    model = make_model()
+    tr = Trainer(max_epochs=1).fit(model, train, val)
+    # single-process expectation of the validation number on the trained weights: local negatives per batch
+    model.eval()
+    model.global_negatives = False
+    tot, rows = 0.0, 0
+    with torch.no_grad():
+        for b in [cut(0, 8), cut(8, 16), cut(16, 19), cut(32, 37)]:
+            n = b[1].shape[0]
+            tot += float(model._loss(model(*tuple(t.cuda() if t is not None else None for t in b)))) * n
+            rows += n
+    refused = False
+    try:
+        Trainer(max_epochs=1).fit(make_model(), train if rank == 0 else train[:1], None)
+    except ValueError:
+        refused = True
+    out[f"r{rank}"] = (tr.history["val_loss"][-1], tot / rows, refused, tr.global_step)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def worker(rank, world, port, out):
@@ -86,6 +121,17 @@ def worker(rank, world, port, out):
 if __name__ == "__main__":
     ctx = mp.get_context("spawn")
     out = ctx.Manager().dict()
+    if TRAINER:
+        procs = [ctx.Process(target=trainer_worker, args=(r, 2, 29613, out)) for r in range(2)]
+        [p.start() for p in procs]
+        [p.join(300) for p in procs]
+        print(dict(out), [p.exitcode for p in procs])
+        ok = all(p.exitcode == 0 for p in procs) and len(out) == 2
+        for got, want, refused, steps in out.values():
+            ok = ok and abs(got - want) <= 1e-4 * abs(want) and refused and steps == 2
+        ok = ok and abs(out["r0"][0] - out["r1"][0]) < 1e-9          # both ranks report the same global number
+        print("DIST CHECK", "OK" if ok else "FAILED")
+        sys.exit(0 if ok else 1)
     procs = [ctx.Process(target=worker, args=(r, 2, 29611, out)) for r in range(2)]
     [p.start() for p in procs]
     [p.join(300) for p in procs]
