@@ -283,6 +283,8 @@ def main():
     ap.add_argument("--gemm-table", action="store_true", help="per-shape GEMM timing of one step on stderr")
     ap.add_argument("--gemm-variant", type=int, default=3, choices=[0, 1, 2, 3],
                     help="fp32 GEMM kernel family: 0 register-staged, 1 / 2 / 3 LDS-DMA rings (3 = default)")
+    ap.add_argument("--gemm-tail", type=int, default=1, choices=[0, 1, 2],
+                    help="tail tiles of the fp32 GEMMs: 1 = K-slabs summed by the last workgroup to arrive (default), 2 = by a finishing launch, 0 = unsplit")
     ap.add_argument("--gemm-precision", default="f32", choices=["f32", "bf16x3", "bf16"],
                     help="inner-product precision of the GEMMs (bf16x3 = split-bf16, fp32-grade accuracy)")
     ap.add_argument("--graphed", action="store_true",
@@ -301,6 +303,7 @@ def main():
     _lib.require_gpu()
     ops.set_gemm_precision(args.gemm_precision)
     ops.set_gemm_variant(args.gemm_variant)
+    ops.set_gemm_tail_split(args.gemm_tail)
     rank, local, world = D.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")

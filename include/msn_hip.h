@@ -84,9 +84,11 @@ size_t msn_sgemm_workspace_bytes(int opA, int opB, int64_t M, int64_t N, int64_t
  * All modes give bit-identical results (same k order per accumulator).  Process-wide. */
 int msn_set_gemm_variant(int mode);
 /* Tail split (default on): a product whose 128 x 128 tiles do not fill a whole number of rounds of the chip's
- * 512 resident workgroups has the tiles of the last, partly filled round cut into K-slabs (summed in slab order
- * by a finishing pass that applies the epilogue); msn_sgemm_workspace_bytes covers the slabs.  Results of the
- * tail tiles then differ from the unsplit order in the last bits.  Process-wide. */
+ * 512 resident workgroups has the tiles of the last, partly filled round cut into K-slabs; msn_sgemm_workspace_bytes
+ * covers the slabs.  enabled = 1 (default): the workgroup that stores a tile's last slab (device-scope arrival
+ * counter in module memory, one slice per stream) sums the slabs in slab order and applies the epilogue inside the
+ * same launch; 2: a finishing launch does (bit-identical: same order); 0: no slabs.  Results of the tail tiles
+ * differ from the unsplit order in the last bits.  Process-wide. */
 int msn_set_gemm_tail_split(int enabled);
 /* Measurement switch: tile width of products with N > 64: 0 = planned (default), 64, 128. */
 int msn_set_gemm_tile_n(int bn);

@@ -12,6 +12,7 @@
 // are dealt round-robin over them, so ids are remapped to give each XCD a contiguous run of
 // tiles that walk N fastest (neighbours share the A row-panel in that XCD's L2).
 #include <algorithm>
+#include <mutex>
 #include <type_traits>
 
 #include "gemm_common.h"
@@ -260,7 +261,8 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmArgs p) {
 #endif
     }
 
-    if (tc.tail_slab >= 0) dump_tail<TM, TN>(acc, p, tc.tail_slab, wave, 4, lane);
+    if (BN == 128 && tc.tail_slab >= 0)   // tails are only planned for 128 x 128 tiles
+        finish_tail<TM, TN>(acc, p, tc, wave, 4, lane, m0, n0, wm0, wn0, reinterpret_cast<unsigned*>(smem));
     else gemm_epilogue<TM, TN>(acc, p, m0, n0, wm0, wn0, l32, h, split);
 }
 
@@ -508,7 +510,8 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM / WM) * (BN / WN) =
             }
         }
     }
-    if (tc.tail_slab >= 0) dump_tail<TM, TN>(acc, p, tc.tail_slab, wave, NWAVES, lane);
+    if (BN == 128 && tc.tail_slab >= 0)   // tails are only planned for 128 x 128 tiles
+        finish_tail<TM, TN>(acc, p, tc, wave, NWAVES, lane, m0, n0, wm0, wn0, reinterpret_cast<unsigned*>(smem));
     else gemm_epilogue<TM, TN>(acc, p, m0, n0, wm0, wn0, l32, h, split);
 #ifdef MSN_TIMELINE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -731,7 +734,32 @@ static int launch_cfg(const GemmArgs& a, int opA, int opB, hipStream_t st) {
     return MSN_OK;
 }
 
-static int g_gemm_tail = 1;      // cut the partly filled last round of tiles into K-slabs (msn_set_gemm_tail_split)
+static int g_gemm_tail = 1;      // cut the partly filled last round of tiles into K-slabs (msn_set_gemm_tail_split):
+                                 // 1 = summed by the last workgroup to arrive, 2 = by a finishing launch, 0 = no slabs
+
+// Arrival counters of the in-kernel tail finish.  Launches on ONE stream run one after the other and every launch
+// leaves its counters at zero, so a stream needs one slice of counters; streams that overlap (the towers of a
+// step run on their own streams) get a slice each.  Module memory: nothing is allocated, the first use looks the
+// address up.  More streams than slices: those launches fall back to the finishing launch.
+constexpr int kTailSlices = 32, kTailSliceTiles = 512;     // a tail has fewer than 512 tiles (tiles % 512)
+__device__ unsigned g_tail_counters[kTailSlices * kTailSliceTiles];
+static unsigned* tail_counter_slice(hipStream_t st) {
+    static std::mutex mu;
+    static hipStream_t owner[kTailSlices];
+    static int used = 0;
+    static unsigned* base = nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!base) {
+        void* sym = nullptr;
+        if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_tail_counters)) != hipSuccess) return nullptr;
+        base = static_cast<unsigned*>(sym);
+    }
+    for (int i = 0; i < used; ++i)
+        if (owner[i] == st) return base + (size_t)i * kTailSliceTiles;
+    if (used == kTailSlices) return nullptr;
+    owner[used] = st;
+    return base + (size_t)(used++) * kTailSliceTiles;
+}
 static int g_gemm_bn = 0;        // measurement switch (msn_set_gemm_tile_n): 0 = planned, 64 / 128 = forced tile width for N > 64
 
 // Launch geometry of one product.
@@ -861,6 +889,7 @@ static int sgemm_impl(int opA, int opB, int64_t M, int64_t N, int64_t K, const f
     a.partial = nullptr;
     a.tail_tiles = pl.tail_tiles, a.tail_splits = pl.tail_splits, a.tail_kps = pl.tail_kps;
     a.tail_partial = nullptr;
+    a.tail_counter = nullptr;
 #ifdef MSN_TIMELINE
     a.dbg = g_timeline;
 #endif
@@ -868,6 +897,7 @@ static int sgemm_impl(int opA, int opB, int64_t M, int64_t N, int64_t K, const f
         const size_t need = pl.ws_bytes(M, N);
         MSN_REQUIRE(ws && ws_bytes >= need, "msn_sgemm: workspace %zu < %zu bytes", ws_bytes, need);
         a.tail_partial = static_cast<float*>(ws);
+        if (g_gemm_tail == 1 && a.tail_tiles <= kTailSliceTiles) a.tail_counter = tail_counter_slice(static_cast<hipStream_t>(stream));
     }
     if (splits > 1) {
         MSN_REQUIRE(epilogue == MSN_EPI_NONE && bias == nullptr,
@@ -914,7 +944,7 @@ static int sgemm_impl(int opA, int opB, int64_t M, int64_t N, int64_t K, const f
     else if (bn == 64) rc = launch_cfg<128, 64, 64, 32>(a, opA, opB, st);
     else rc = launch_cfg<128, 32, 32, 32>(a, opA, opB, st);
     if (rc != MSN_OK) return rc;
-    if (a.tail_tiles > 0) {
+    if (a.tail_tiles > 0 && a.tail_counter == nullptr) {
         rc = launch_tail_finish(a, bn, waves, st);
         if (rc != MSN_OK) return rc;
     }
@@ -976,7 +1006,8 @@ extern "C" int msn_set_gemm_tile_n(int bn) {
 }
 
 extern "C" int msn_set_gemm_tail_split(int enabled) {
-    g_gemm_tail = enabled ? 1 : 0;
+    MSN_REQUIRE(enabled >= 0 && enabled <= 2, "msn_set_gemm_tail_split: 0 (off), 1 (in-kernel finish) or 2 (finishing launch)");
+    g_gemm_tail = enabled;
     return MSN_OK;
 }
 

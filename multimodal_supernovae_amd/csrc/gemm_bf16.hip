@@ -208,7 +208,8 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const GemmArgs p) {
         }
         __syncthreads();
     }
-    if (tc.tail_slab >= 0) dump_tail<TM, TN>(acc, p, tc.tail_slab, wave, 4, lane);
+    if (BN == 128 && tc.tail_slab >= 0)   // tails are only planned for 128 x 128 tiles
+        finish_tail<TM, TN>(acc, p, tc, wave, 4, lane, m0, n0, wm0, wn0, reinterpret_cast<unsigned*>(smem));
     else gemm_epilogue<TM, TN>(acc, p, m0, n0, wm0, wn0, l32, h, split);
 }
 

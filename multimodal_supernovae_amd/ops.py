@@ -49,8 +49,9 @@ def set_gemm_tile_n(bn):
 
 
 def set_gemm_tail_split(enabled):
-    """Cut the partly filled last round of GEMM tiles into K-slabs (msn_set_gemm_tail_split); default on."""
-    check(lib().msn_set_gemm_tail_split(1 if enabled else 0))
+    """Cut the partly filled last round of GEMM tiles into K-slabs (msn_set_gemm_tail_split); default on (True / 1:
+    the last workgroup to arrive sums a tile's slabs inside the launch; 2: a finishing launch does; False / 0: off)."""
+    check(lib().msn_set_gemm_tail_split(int(enabled)))
 
 
 OP_N, OP_T = 0, 1

@@ -102,7 +102,7 @@ def test_sgemm_tail_split(M, N, K, op_a, op_b, epi, variant, precision):
         if op_a == 0:
             assert _lib.lib().msn_sgemm_workspace_bytes(op_a, op_b, M, N, K) > 0  # the plan cuts a tail for these shapes
         ops.set_gemm_variant(variant)
-        for tail in (True, False):
+        for tail in (1, 0, 2, 1):         # in-kernel finish, unsplit, finishing launch, in-kernel again (counters back at 0)
             ops.set_gemm_tail_split(tail)
             if epi == "gelu":
                 kw["aux"] = torch.empty(M, N, device="cuda")
@@ -114,10 +114,36 @@ def test_sgemm_tail_split(M, N, K, op_a, op_b, epi, variant, precision):
         ops.set_gemm_tile_n(0)
     tol = dict(rtol=1e-4, atol=1e-4 * K ** 0.5) if precision < 2 else dict(rtol=2e-2, atol=3e-2 * K ** 0.5)
     torch.testing.assert_close(outs[0], outs[1], **tol)
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3])   # slab order, whoever sums them
     if epi == "gelu":
         torch.testing.assert_close(auxs[0], auxs[1], **tol)
+        assert torch.equal(auxs[0], auxs[2]) and torch.equal(auxs[0], auxs[3])
     if epi == "none":
         torch.testing.assert_close(outs[0].double(), _ref(a, b, op_a, op_b), **tol)
+
+
+def test_sgemm_tail_split_overlapping_streams():
+    """Products with tails on two streams at once (the towers of a step): each stream has its own arrival counters;
+    twenty alternating launches leave the same bits as the launches run alone."""
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(5)
+    a1, b1 = torch.randn(66560, 384, generator=g).cuda(), torch.randn(384, 384, generator=g).cuda()
+    a2, b2 = torch.randn(33280, 1536, generator=g).cuda(), torch.randn(1536, 384, generator=g).cuda()
+    try:
+        ops.set_gemm_tile_n(128)
+        ref1, ref2 = ops.sgemm(a1, b1, 0, 1), ops.sgemm(a2, b2, 0, 0)
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = []
+        for _ in range(10):
+            with torch.cuda.stream(s1):
+                outs.append((ops.sgemm(a1, b1, 0, 1), ref1))
+            with torch.cuda.stream(s2):
+                outs.append((ops.sgemm(a2, b2, 0, 0), ref2))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_gemm_tile_n(0)
+    assert all(torch.equal(o, r) for o, r in outs)
 
 
 @pytest.mark.parametrize("M,N,K,op_b", [(8320, 384, 384, 1), (8320, 1152, 384, 1), (8320, 384, 1536, 0), (33280, 384, 384, 0),
