@@ -371,7 +371,8 @@ int msn_col2im(const float* dcols, int B, int H, int W, int C, int kh, int kw, i
 /* The same with TAP-MAJOR columns cols[(b,oh,ow)][(u,v,c)] (channels fastest: both kernels move 16-byte channel groups;
  * C % 4 == 0, 16-byte aligned tensors) and the weight re-laid to match: msn_conv_weight_relayout(to_tap = 1) copies
  * torch's (C_out, C_in, kh*kw) weight to (C_out, kh*kw, C_pad) with zeros in the channels C_in .. C_pad-1; to_tap = 0
- * is the inverse (for the weight gradient; the padding channels are dropped).  msn_pad_channels widens a channels-last
+ * is the inverse (for the weight gradient; the padding channels are dropped); to_tap = 2 gives (kh*kw, C_out, C_in)
+ * (C_pad == C_in), the weight operand of msn_conv2d_dgrad.  msn_pad_channels widens a channels-last
  * tensor (rows x C -> rows x Cp, zeros added): a 3-channel image stem runs as a 4-channel convolution. */
 int msn_im2col_tap(const float* x, int B, int H, int W, int C, int kh, int kw, int sh, int sw, int ph, int pw,
                    float* cols, msn_stream_t stream);
@@ -380,6 +381,27 @@ int msn_col2im_tap(const float* dcols, int B, int H, int W, int C, int kh, int k
 int msn_conv_weight_relayout(const float* src, int64_t co, int ci, int ci_pad, int taps, int to_tap, float* dst,
                              msn_stream_t stream);
 int msn_pad_channels(const float* x, int64_t rows, int C, int Cp, float* out, msn_stream_t stream);
+
+/* Implicit-GEMM convolution on channels-last fp32 tensors (the build-defined ResNet-18 / 1-D CNN encoders; no
+ * reference counterpart): y[(b,oh,ow)][co] = sum_{u,v,c} x[b, oh*sh+u-ph, ow*sw+v-pw, c] * w_tap[co][(u,v,c)] without a
+ * column matrix in memory -- the GEMM kernel's LDS-DMA lanes compute their own source addresses and padding taps read
+ * a page of zeros.  msn_conv2d_implicit_ok says whether a shape is taken (C and C_out multiples of 32 and > 32,
+ * images up to 512 x 512, B*OH*OW a multiple of 32); other shapes go through msn_im2col_tap + msn_sgemm.
+ *   fwd:   w_tap = msn_conv_weight_relayout(to_tap = 1) of the (C_out, C, kh, kw) weight; epilogue NONE or RELU.
+ *   dgrad: stride 1 only; dx[(b,h,w)][c] from dy[(b,oh,ow)][co] and w_tco = relayout(to_tap = 2): [(u,v,co)][c].
+ *   wgrad: dw_tap[co][(u,v,c)] (relayout(to_tap = 0) gives torch's layout back) and, when dbias != NULL, dbias[co] =
+ *          column sums of dy from the same launch; split over the pixels, slabs in `ws`.
+ * `ws` of msn_conv2d_workspace_bytes(...) bytes serves all three. */
+int msn_conv2d_implicit_ok(int B, int H, int W, int C, int Cout, int kh, int kw, int sh, int sw, int ph, int pw);
+size_t msn_conv2d_workspace_bytes(int B, int H, int W, int C, int Cout, int kh, int kw, int sh, int sw, int ph, int pw);
+int msn_conv2d_fwd(const float* x, int B, int H, int W, int C, const float* w_tap, int Cout, int kh, int kw, int sh,
+                   int sw, int ph, int pw, const float* bias, int epilogue, float* y, void* ws, size_t ws_bytes,
+                   msn_stream_t stream);
+int msn_conv2d_dgrad(const float* dy, int B, int H, int W, int C, const float* w_tco, int Cout, int kh, int kw, int ph,
+                     int pw, float* dx, void* ws, size_t ws_bytes, msn_stream_t stream);
+int msn_conv2d_wgrad(const float* dy, const float* x, int B, int H, int W, int C, int Cout, int kh, int kw, int sh,
+                     int sw, int ph, int pw, float* dw_tap, float* dbias, void* ws, size_t ws_bytes,
+                     msn_stream_t stream);
 int msn_maxpool2d_fwd(const float* x, int B, int H, int W, int C, int k, int s, int p, float* y, int* argmax,
                       msn_stream_t stream);
 int msn_maxpool2d_bwd(const float* dy, const int* argmax, int B, int H, int W, int C, int k, int s, int p,

@@ -91,6 +91,11 @@ SIGNATURES = {
     "msn_im2col_tap": (c_int, [c_ptr] + [c_int] * 10 + [c_ptr, c_ptr]),
     "msn_col2im_tap": (c_int, [c_ptr] + [c_int] * 10 + [c_ptr, c_ptr]),
     "msn_conv_weight_relayout": (c_int, [c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
+    "msn_conv2d_implicit_ok": (c_int, [c_int] * 11),
+    "msn_conv2d_workspace_bytes": (c_size, [c_int] * 11),
+    "msn_conv2d_fwd": (c_int, [c_ptr] + [c_int] * 4 + [c_ptr] + [c_int] * 7 + [c_ptr, c_int, c_ptr, c_ptr, c_size, c_ptr]),
+    "msn_conv2d_dgrad": (c_int, [c_ptr] + [c_int] * 4 + [c_ptr] + [c_int] * 5 + [c_ptr, c_ptr, c_size, c_ptr]),
+    "msn_conv2d_wgrad": (c_int, [c_ptr, c_ptr] + [c_int] * 11 + [c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "msn_pad_channels": (c_int, [c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr]),
     "msn_maxpool2d_fwd": (c_int, [c_ptr] + [c_int] * 7 + [c_ptr, c_ptr, c_ptr]),
     "msn_maxpool2d_bwd": (c_int, [c_ptr, c_ptr] + [c_int] * 7 + [c_ptr, c_ptr]),

@@ -213,13 +213,17 @@ __global__ void col2im_tap_kernel(const float* __restrict__ dcols, ConvGeom g, f
 // of the tap-major copy are zeros (a 3-channel stem runs as a 4-channel one); to_tap == 0 drops them again
 __global__ void conv_weight_relayout_kernel(const float* __restrict__ src, int64_t co, int ci, int ci_pad, int taps,
                                             int to_tap, float* __restrict__ dst) {
-    const int64_t total = co * (to_tap ? ci_pad : ci) * taps;
+    const int64_t total = co * (to_tap == 1 ? ci_pad : ci) * taps;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        if (to_tap) {   // i indexes dst (o, tap, c) with c < ci_pad
+        if (to_tap == 1) {   // i indexes dst (o, tap, c) with c < ci_pad
             const int64_t o = i / ((int64_t)ci_pad * taps);
             const int rem = (int)(i % ((int64_t)ci_pad * taps));
             const int c = rem % ci_pad, t = rem / ci_pad;
             dst[i] = c < ci ? src[(o * ci + c) * taps + t] : 0.f;
+        } else if (to_tap == 2) {   // i indexes dst (tap, o, c): the K-major operand of the implicit-GEMM dgrad (ci_pad == ci)
+            const int c = (int)(i % ci);
+            const int64_t o = (i / ci) % co, t = i / ((int64_t)ci * co);
+            dst[i] = src[(o * ci + c) * taps + t];
         } else {        // i indexes dst (o, c, tap) with c < ci
             const int64_t o = i / ((int64_t)ci * taps);
             const int rem = (int)(i % ((int64_t)ci * taps));

@@ -338,9 +338,12 @@ struct DmaTile {
     }
 };
 
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int DBK, int STAGES, bool CSUM = false>
+// CONV = 1: the A operand (K-contiguous rows) is an implicit column matrix (convolution forward / dgrad);
+// CONV = 2: the B operand (K-major) is (convolution wgrad).  See ConvGather.
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int DBK, int STAGES, bool CSUM = false, int CONV = 0>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM / WM) * (BN / WN) == 4 ? 2 : 1) void sgemm_dma_kernel(const GemmArgs p) {
     static_assert(!CSUM || AKM, "the fused column sums are those of a K-major A operand (wgrad: A = dY)");
+    static_assert(CONV == 0 || (CONV == 1 && !AKM) || (CONV == 2 && BKM), "implicit operand: A rows (1) or K-major B (2)");
     using TA = DmaTile<BM, AKM, DBK>;
     using TB = DmaTile<BN, BKM, DBK>;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -372,20 +375,90 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM / WM) * (BN / WN) =
     // this lane's source pointers for K-step 0 (they advance by a constant per K-step)
     const float* sa[PA];
     const float* sb[PB];
+    if constexpr (CONV != 1) {
 #pragma unroll
-    for (int i = 0; i < PA; ++i) sa[i] = TA::src(p.A, p.lda, m0, p.M, k_begin, wave * PA + i, lane);
+        for (int i = 0; i < PA; ++i) sa[i] = TA::src(p.A, p.lda, m0, p.M, k_begin, wave * PA + i, lane);
+    }
+    if constexpr (CONV != 2) {
 #pragma unroll
-    for (int i = 0; i < PB; ++i) sb[i] = TB::src(p.B, p.ldb, n0, p.N, k_begin, wave * PB + i, lane);
+        for (int i = 0; i < PB; ++i) sb[i] = TB::src(p.B, p.ldb, n0, p.N, k_begin, wave * PB + i, lane);
+    }
     const int64_t a_step = AKM ? (int64_t)DBK * p.lda : DBK, b_step = BKM ? (int64_t)DBK * p.ldb : DBK;
+    // ---- implicit operand (ConvGather) -------------------------------------------------------------------------
+    // CONV 1: a lane serves the same PA rows (pixels) in every K-step; a K-step lies inside one tap (SC % DBK == 0), so
+    // the tap and the channel offset of the next K-step to issue are wave-uniform running values.
+    [[maybe_unused]] int gy[PA], gx[PA];           // source row / column of tap (0, 0) for this lane's rows
+    [[maybe_unused]] int64_t gb[PA];               // batch offset + this lane's (swizzled) chunk inside the K-step
+    [[maybe_unused]] int tky = 0, tkx = 0, tc0 = 0;
+    if constexpr (CONV == 1) {
+        const ConvGather& g = p.cg;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int r = (wave * PA + i) * (64 / TA::CPR) + lane / TA::CPR, pos = lane % TA::CPR;
+            const int64_t m = m0 + r;
+            const int mm = m < p.M ? (int)m : 0;
+            const int b = mm / (g.RH * g.RW), rem = mm - b * (g.RH * g.RW), ry = rem / g.RW, rx = rem - ry * g.RW;
+            gy[i] = m < p.M ? ry * g.sy + g.y0 : -(1 << 24);   // rows beyond M: never inside the image
+            gx[i] = rx * g.sx + g.x0;
+            gb[i] = (int64_t)b * g.SH * g.SW * g.SC + 4 * (pos ^ TA::swz(r));
+        }
+        const int tap = (int)(k_begin / g.SC);
+        tc0 = (int)(k_begin - (int64_t)tap * g.SC);
+        tky = tap / g.kw, tkx = tap - tky * g.kw;
+    }
+    // CONV 2: a lane serves the same 4 columns (one tap, 4 channels) in every K-step; the k index walks the pixels.
+    [[maybe_unused]] int wky = 0, wkx = 0, wcc = 0;
+    [[maybe_unused]] bool wn_ok = false;
+    if constexpr (CONV == 2) {
+        const ConvGather& g = p.cg;
+        constexpr int LPR = BN / 4;
+        const int64_t n = n0 + 4 * (lane % LPR);
+        wn_ok = n < p.N;
+        const int nn = wn_ok ? (int)n : 0, tap = nn / g.SC;
+        wcc = nn - tap * g.SC;
+        wky = tap / g.kw, wkx = tap - wky * g.kw;
+    }
     auto issue = [&](int kt) {   // LDS-DMA of K-step kt into ring slot kt % STAGES
         float* base = smem + (kt % STAGES) * STAGE;
+        if constexpr (CONV == 1) {
+            const ConvGather& g = p.cg;
+            const int dy = g.dir * tky, dx = g.dir * tkx;
 #pragma unroll
-        for (int i = 0; i < PA; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t*)(sa[i] + kt * a_step), (lptr_t*)(base + (wave * PA + i) * 256), 16, 0, 0);
+            for (int i = 0; i < PA; ++i) {
+                const int sy = gy[i] + dy, sx = gx[i] + dx;
+                const bool ok = (unsigned)sy < (unsigned)g.SH && (unsigned)sx < (unsigned)g.SW;
+                const float* s = ok ? g.src + gb[i] + ((int64_t)sy * g.SW + sx) * g.SC + tc0 : g.zero;
+                __builtin_amdgcn_global_load_lds((gptr_t*)s, (lptr_t*)(base + (wave * PA + i) * 256), 16, 0, 0);
+            }
+            tc0 += DBK;                                   // K-steps are issued in order
+            if (tc0 == g.SC) {
+                tc0 = 0;
+                if (++tkx == g.kw) tkx = 0, ++tky;
+            }
+        } else {
 #pragma unroll
-        for (int i = 0; i < PB; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t*)(sb[i] + kt * b_step),
-                                             (lptr_t*)(base + TA::kFloats + (wave * PB + i) * 256), 16, 0, 0);
+            for (int i = 0; i < PA; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t*)(sa[i] + kt * a_step), (lptr_t*)(base + (wave * PA + i) * 256), 16, 0, 0);
+        }
+        if constexpr (CONV == 2) {
+            const ConvGather& g = p.cg;
+            constexpr int LPR = BN / 4;
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                const unsigned m = (unsigned)(k_begin + (int64_t)kt * DBK) + (unsigned)((wave * PB + i) * (64 / LPR) + lane / LPR);
+                const unsigned t = (unsigned)(((unsigned long long)m * g.rw_magic) >> 36), rx = m - t * (unsigned)g.RW;
+                const unsigned b = (unsigned)(((unsigned long long)t * g.rh_magic) >> 36), ry = t - b * (unsigned)g.RH;
+                const int sy = (int)ry * g.sy + g.y0 + wky, sx = (int)rx * g.sx + g.x0 + wkx;
+                const bool ok = wn_ok && (unsigned)sy < (unsigned)g.SH && (unsigned)sx < (unsigned)g.SW;
+                const float* s = ok ? g.src + (((int64_t)b * g.SH + sy) * g.SW + sx) * g.SC + wcc : g.zero;
+                __builtin_amdgcn_global_load_lds((gptr_t*)s, (lptr_t*)(base + TA::kFloats + (wave * PB + i) * 256), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t*)(sb[i] + kt * b_step),
+                                                 (lptr_t*)(base + TA::kFloats + (wave * PB + i) * 256), 16, 0, 0);
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -708,6 +781,19 @@ static int launch_dma(const GemmArgs& a, int opA, int opB, hipStream_t st) {
     return MSN_OK;
 }
 
+// conv = 1: A implicit (forward: B = weights [N][K], opB = T; dgrad: B = weights [K][N], opB = N);
+// conv = 2: B implicit, A = dY K-major (wgrad, with or without the fused bias gradient)
+template <int BM, int BN, int WM, int WN, int DBK, int STAGES>
+static int launch_dma_conv(const GemmArgs& a, int conv, int opB, hipStream_t st) {
+    const dim3 grid(gemm_grid(a)), block(64 * (BM / WM) * (BN / WN));
+    if (conv == 1 && opB == MSN_OP_T) hipLaunchKernelGGL((sgemm_dma_kernel<BM, BN, WM, WN, false, false, DBK, STAGES, false, 1>), grid, block, 0, st, a);
+    else if (conv == 1) hipLaunchKernelGGL((sgemm_dma_kernel<BM, BN, WM, WN, false, true, DBK, STAGES, false, 1>), grid, block, 0, st, a);
+    else if (a.colsum) hipLaunchKernelGGL((sgemm_dma_kernel<BM, BN, WM, WN, true, true, DBK, STAGES, true, 2>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((sgemm_dma_kernel<BM, BN, WM, WN, true, true, DBK, STAGES, false, 2>), grid, block, 0, st, a);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
 static int g_gemm_variant = 3;   // 0 = register-staged kernels; LDS-DMA: 1 = 8 waves, ring 3 x BK 32; 2 = 8 waves, ring 2 x BK 64;
                                  // 3 (default) = 4 waves, ring 2 x BK 32, two workgroups per CU
 
@@ -858,7 +944,7 @@ extern "C" size_t msn_sgemm_workspace_bytes(int opA, int opB, int64_t M, int64_t
 static int sgemm_impl(int opA, int opB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                       int64_t ldb, float* C, int64_t ldc, const float* bias, int epilogue, float* aux, int64_t ldaux,
                       int precision, void* ws, size_t ws_bytes, msn_stream_t stream, float* colsum_out,
-                      bool* colsum_done) {
+                      bool* colsum_done, const ConvGather* conv_gather = nullptr, int conv = 0) {
     MSN_REQUIRE(M >= 0 && N >= 0 && K >= 0, "msn_sgemm: negative size M=%lld N=%lld K=%lld", (long long)M,
                 (long long)N, (long long)K);
     if (M == 0 || N == 0) return MSN_OK;
@@ -890,6 +976,7 @@ static int sgemm_impl(int opA, int opB, int64_t M, int64_t N, int64_t K, const f
     a.tail_tiles = pl.tail_tiles, a.tail_splits = pl.tail_splits, a.tail_kps = pl.tail_kps;
     a.tail_partial = nullptr;
     a.tail_counter = nullptr;
+    a.cg = conv_gather ? *conv_gather : ConvGather{};
 #ifdef MSN_TIMELINE
     a.dbg = g_timeline;
 #endif
@@ -918,7 +1005,7 @@ static int sgemm_impl(int opA, int opB, int64_t M, int64_t N, int64_t K, const f
         bf16_ok = (ldb % 4 == 0) && (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
     // LDS-DMA kernels: every operand 16-B aligned with ld % 4 == 0 and extents % 4 == 0, whole K-steps only
     const int64_t a_ext = opA == MSN_OP_T ? M : K, b_ext = opB == MSN_OP_N ? N : K;
-    const bool dma_ok = g_gemm_variant != 0 && bn >= 32 && K % BK == 0 && kps % BK == 0 && (lda % 4 == 0) && (ldb % 4 == 0) &&
+    const bool dma_ok = (g_gemm_variant != 0 || conv != 0) && bn >= 32 && K % BK == 0 && kps % BK == 0 && (lda % 4 == 0) && (ldb % 4 == 0) &&
                         (a_ext % 4 == 0) && (b_ext % 4 == 0) && a_ext >= 4 && b_ext >= 4 &&
                         ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
     const bool fuse_colsum = colsum_out && !bf16_ok && dma_ok && opA == MSN_OP_T && opB == MSN_OP_N;
@@ -933,7 +1020,11 @@ static int sgemm_impl(int opA, int opB, int64_t M, int64_t N, int64_t K, const f
     }
     if (colsum_done) *colsum_done = fuse_colsum;
     int waves = 4;   // per workgroup of the kernel chosen (the tail pass mirrors its register layout)
-    if (bf16_ok) rc = launch_bgemm(a, opA, opB, precision == MSN_PREC_BF16X3 ? 2 : 1, bm, bn, st);
+    if (conv != 0) {   // implicit-GEMM convolution: the 4-wave LDS-DMA kernels only
+        MSN_REQUIRE(dma_ok && !bf16_ok && bn >= 64, "implicit convolution: shape not taken by the LDS-DMA kernels");
+        if (bn == 128) rc = launch_dma_conv<128, 128, 64, 64, 32, 2>(a, conv, opB, st);
+        else rc = launch_dma_conv<128, 64, 64, 32, 32, 3>(a, conv, opB, st);
+    } else if (bf16_ok) rc = launch_bgemm(a, opA, opB, precision == MSN_PREC_BF16X3 ? 2 : 1, bm, bn, st);
     else if (dma_ok && bn == 128 && K % 64 == 0 && kps % 64 == 0 && g_gemm_variant == 2)
         rc = launch_dma<128, 128, 64, 32, 64, 2>(a, opA, opB, st), waves = 8;
     else if (dma_ok && bn == 128 && g_gemm_variant == 3) rc = launch_dma<128, 128, 64, 64, 32, 2>(a, opA, opB, st);
@@ -978,6 +1069,103 @@ extern "C" int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, cons
                          float* aux, int64_t ldaux, int precision, void* ws, size_t ws_bytes, msn_stream_t stream) {
     return sgemm_impl(opA, opB, M, N, K, A, lda, B, ldb, C, ldc, bias, epilogue, aux, ldaux, precision, ws, ws_bytes,
                       stream, nullptr, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution on channels-last tensors (ConvGather): no column matrix in memory.
+__device__ float g_conv_zero_page[64];
+static const float* conv_zero_page() {
+    static const float* page = nullptr;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!page) {
+        void* sym = nullptr;
+        if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_conv_zero_page)) != hipSuccess) return nullptr;
+        page = static_cast<const float*>(sym);
+    }
+    return page;
+}
+static unsigned long long div_magic(int d) { return (1ull << 36) / (unsigned long long)d + 1ull; }
+struct ConvShape { int B, H, W, C, Cout, kh, kw, sh, sw, ph, pw, OH, OW; };
+static int conv_shape(const char* who, int B, int H, int W, int C, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                      ConvShape* cs) {
+    MSN_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && Cout > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0,
+                "%s: bad geometry", who);
+    const int OH = (H + 2 * ph - kh) / sh + 1, OW = (W + 2 * pw - kw) / sw + 1;
+    MSN_REQUIRE(OH > 0 && OW > 0, "%s: kernel larger than the padded input", who);
+    MSN_REQUIRE(H <= 512 && W <= 512 && (int64_t)B * H * W < (1ll << 27),
+                "%s: implicit convolution takes images up to 512 x 512 and fewer than 2^27 pixels per launch", who);
+    *cs = ConvShape{B, H, W, C, Cout, kh, kw, sh, sw, ph, pw, OH, OW};
+    return MSN_OK;
+}
+// which convolutions the implicit kernels take (the caller falls back to im2col + msn_sgemm otherwise)
+extern "C" int msn_conv2d_implicit_ok(int B, int H, int W, int C, int Cout, int kh, int kw, int sh, int sw, int ph, int pw) {
+    if (B <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || ph < 0 || pw < 0) return 0;
+    if (H > 512 || W > 512 || (int64_t)B * H * W >= (1ll << 27)) return 0;
+    const int OH = (H + 2 * ph - kh) / sh + 1, OW = (W + 2 * pw - kw) / sw + 1;
+    if (OH <= 0 || OW <= 0) return 0;
+    // a K-step of 32 lies inside one tap (C % 32 == 0; dgrad: C_out % 32 == 0); tiles at least 64 wide (C_out, C > 32);
+    // wgrad walks whole K-steps of output pixels
+    return C % 32 == 0 && Cout % 32 == 0 && C > 32 && Cout > 32 && ((int64_t)B * OH * OW) % 32 == 0;
+}
+extern "C" size_t msn_conv2d_workspace_bytes(int B, int H, int W, int C, int Cout, int kh, int kw, int sh, int sw, int ph,
+                                             int pw) {
+    if (!msn_conv2d_implicit_ok(B, H, W, C, Cout, kh, kw, sh, sw, ph, pw)) return 0;
+    const int OH = (H + 2 * ph - kh) / sh + 1, OW = (W + 2 * pw - kw) / sw + 1;
+    const int64_t Mo = (int64_t)B * OH * OW, Mi = (int64_t)B * H * W, Kc = (int64_t)kh * kw * C;
+    const Plan f = plan(Mo, Cout, Kc, MSN_OP_N), d = plan(Mi, C, (int64_t)kh * kw * Cout, MSN_OP_N), w = plan(Cout, Kc, Mo, MSN_OP_T, false);
+    const size_t wg = w.ws_bytes(Cout, Kc) + sizeof(float) * (size_t)w.splits * (size_t)Cout;
+    return std::max(std::max(f.ws_bytes(Mo, Cout), d.ws_bytes(Mi, C)), wg);
+}
+extern "C" int msn_conv2d_fwd(const float* x, int B, int H, int W, int C, const float* w_tap, int Cout, int kh, int kw,
+                              int sh, int sw, int ph, int pw, const float* bias, int epilogue, float* y, void* ws,
+                              size_t ws_bytes, msn_stream_t stream) {
+    ConvShape c;
+    if (int rc = conv_shape("msn_conv2d_fwd", B, H, W, C, Cout, kh, kw, sh, sw, ph, pw, &c)) return rc;
+    MSN_REQUIRE(x && w_tap && y, "msn_conv2d_fwd: null pointer");
+    MSN_REQUIRE(msn_conv2d_implicit_ok(B, H, W, C, Cout, kh, kw, sh, sw, ph, pw), "msn_conv2d_fwd: shape not taken (msn_conv2d_implicit_ok)");
+    MSN_REQUIRE(epilogue == MSN_EPI_NONE || epilogue == MSN_EPI_RELU, "msn_conv2d_fwd: epilogue none or ReLU");
+    const float* zero = conv_zero_page();
+    MSN_REQUIRE(zero, "msn_conv2d_fwd: no zero page");
+    ConvGather g{x, zero, H, W, C, c.OH, c.OW, sh, sw, -ph, -pw, 1, kw, div_magic(c.OW), div_magic(c.OH)};
+    const int64_t M = (int64_t)B * c.OH * c.OW, K = (int64_t)kh * kw * C;
+    return sgemm_impl(MSN_OP_N, MSN_OP_T, M, Cout, K, x, K, w_tap, K, y, Cout, bias, epilogue, nullptr, 0, MSN_PREC_F32, ws,
+                      ws_bytes, stream, nullptr, nullptr, &g, 1);
+}
+// dX of a stride-1 convolution: rows = input pixels, taps mirrored, weights as [(tap, c_out)][c_in]
+// (msn_conv_weight_relayout, to_tap = 2)
+extern "C" int msn_conv2d_dgrad(const float* dy, int B, int H, int W, int C, const float* w_tco, int Cout, int kh, int kw,
+                                int ph, int pw, float* dx, void* ws, size_t ws_bytes, msn_stream_t stream) {
+    ConvShape c;
+    if (int rc = conv_shape("msn_conv2d_dgrad", B, H, W, C, Cout, kh, kw, 1, 1, ph, pw, &c)) return rc;
+    MSN_REQUIRE(dy && w_tco && dx, "msn_conv2d_dgrad: null pointer");
+    MSN_REQUIRE(msn_conv2d_implicit_ok(B, H, W, C, Cout, kh, kw, 1, 1, ph, pw), "msn_conv2d_dgrad: shape not taken (msn_conv2d_implicit_ok)");
+    const float* zero = conv_zero_page();
+    MSN_REQUIRE(zero, "msn_conv2d_dgrad: no zero page");
+    ConvGather g{dy, zero, c.OH, c.OW, Cout, H, W, 1, 1, ph, pw, -1, kw, div_magic(W), div_magic(H)};
+    const int64_t M = (int64_t)B * H * W, K = (int64_t)kh * kw * Cout;
+    return sgemm_impl(MSN_OP_N, MSN_OP_N, M, C, K, dy, K, w_tco, C, dx, C, nullptr, MSN_EPI_NONE, nullptr, 0, MSN_PREC_F32, ws,
+                      ws_bytes, stream, nullptr, nullptr, &g, 1);
+}
+// dW[c_out][(tap, c_in)] = sum over output pixels of dY[pixel][c_out] * x[pixel shifted by the tap][c_in]; dbias (or null)
+// = column sums of dY, inside the same launch
+extern "C" int msn_conv2d_wgrad(const float* dy, const float* x, int B, int H, int W, int C, int Cout, int kh, int kw, int sh,
+                                int sw, int ph, int pw, float* dw_tap, float* dbias, void* ws, size_t ws_bytes,
+                                msn_stream_t stream) {
+    ConvShape c;
+    if (int rc = conv_shape("msn_conv2d_wgrad", B, H, W, C, Cout, kh, kw, sh, sw, ph, pw, &c)) return rc;
+    MSN_REQUIRE(dy && x && dw_tap, "msn_conv2d_wgrad: null pointer");
+    MSN_REQUIRE(msn_conv2d_implicit_ok(B, H, W, C, Cout, kh, kw, sh, sw, ph, pw), "msn_conv2d_wgrad: shape not taken (msn_conv2d_implicit_ok)");
+    const float* zero = conv_zero_page();
+    MSN_REQUIRE(zero, "msn_conv2d_wgrad: no zero page");
+    ConvGather g{x, zero, H, W, C, c.OH, c.OW, sh, sw, -ph, -pw, 1, kw, div_magic(c.OW), div_magic(c.OH)};
+    const int64_t K = (int64_t)B * c.OH * c.OW, N = (int64_t)kh * kw * C;
+    bool done = false;
+    const int rc = sgemm_impl(MSN_OP_T, MSN_OP_N, Cout, N, K, dy, Cout, x, N, dw_tap, N, nullptr, MSN_EPI_NONE, nullptr, 0,
+                              MSN_PREC_F32, ws, ws_bytes, stream, dbias, &done, &g, 2);
+    if (rc != MSN_OK) return rc;
+    MSN_REQUIRE(dbias == nullptr || done, "msn_conv2d_wgrad: bias gradient not produced");
+    return MSN_OK;
 }
 
 extern "C" size_t msn_wgrad_bias_workspace_bytes(int64_t M, int64_t N, int64_t K) {

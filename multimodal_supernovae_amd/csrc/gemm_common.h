@@ -9,6 +9,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 32;
 constexpr int KPAD = 4;  // floats; keeps 16-B alignment and makes b128 fragment reads conflict-free
 
+// Implicit-GEMM convolution: one operand of the product is the column matrix of a channels-last image that is never
+// written -- the LDS-DMA lanes compute their own source address per K-step and taps that fall outside the image read a
+// page of zeros.  The matrix index that walks pixels (the row m of the A operand for forward / dgrad, the k index of
+// the B operand for wgrad) enumerates (b, ry, rx) over RH x RW; tap (ky, kx) of that pixel reads the source pixel
+// (ry * sy + y0 + dir * ky, rx * sx + x0 + dir * kx) of src[b][SH][SW][SC]; the other index walks (tap, channel)
+// with the channel fastest.  forward: rows = output pixels, y0 = -pad, dir = +1; dgrad (stride 1): rows = input
+// pixels, src = dY, y0 = +pad, dir = -1; wgrad: k = output pixels, columns = (tap, input channel).
+struct ConvGather {
+    const float* src;
+    const float* zero;             // at least 16 bytes of zeros
+    int SH, SW, SC, RH, RW, sy, sx, y0, x0, dir, kw;
+    unsigned long long rw_magic, rh_magic;   // floor(2^36 / d) + 1: n / d == (n * magic) >> 36 for n < 2^27, d <= 512
+};
+
 struct GemmArgs {
     const float* A;
     const float* B;
@@ -31,6 +45,7 @@ struct GemmArgs {
     // The workgroup that stores a tile's LAST slab sums the slabs and applies the epilogue itself.  Null = the
     // slabs are summed by a tail_finish_kernel launch instead.
     unsigned* tail_counter;
+    ConvGather cg;         // kernels instantiated with CONV != 0 only
     float* colsum;         // wgrad + bias grad: [splits][M] sums over k of A (opA = T) or null
 #ifdef MSN_TIMELINE
     unsigned long long* dbg;   // per workgroup: 4 timestamps + HW_ID + XCC_ID (diagnostic builds only)

@@ -799,10 +799,13 @@ def take_token(x, idx):
 # ------------------------------------------------------ channels-last convolution (build-defined encoders)
 @_remember_precision
 class _ConvCL(torch.autograd.Function):
-    """y = conv(x) (+ bias) (+ ReLU) on channels-last tensors via im2col + the MFMA GEMM; weight keeps torch's
-    (C_out, C_in, kh, kw) layout.  The columns are tap-major (channels fastest: the gather kernels move 16-byte channel
-    groups) and the weight / its gradient are re-laid to (C_out, kh, kw, C_in) and back; a channel count that is not a
-    multiple of 4 (the 3-channel image stem) is widened with zero channels first."""
+    """y = conv(x) (+ bias) (+ ReLU) on channels-last tensors as an MFMA GEMM; weight keeps torch's (C_out, C_in, kh, kw)
+    layout and is re-laid tap-major (C_out, kh, kw, C_in) per call, its gradient back.
+    Channel counts that are multiples of 32 run as an IMPLICIT GEMM (msn_conv2d_fwd / _dgrad / _wgrad): the column matrix is
+    never written, the GEMM's LDS-DMA lanes gather from the image and padding taps read a zero page; the backward
+    keeps x instead of the 9x larger columns.  Other shapes (the 3-channel stem, 4-channel series features) and the
+    dX of strided convolutions go through tap-major im2col / col2im (channels fastest: 16-byte channel groups); a
+    channel count that is not a multiple of 4 is widened with zero channels first."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, relu):
@@ -813,26 +816,42 @@ class _ConvCL(torch.autograd.Function):
         x = _c(x)
         plain = kh == 1 and kw == 1 and sh == 1 and sw == 1 and ph == 0 and pw == 0
         Cp = C if plain else (C + 3) // 4 * 4
-        if plain:
-            cols, wmat = x.view(B * H * W, C), weight.view(co, -1)
-        else:
-            xp = x if Cp == C else ops.pad_channels(x, Cp)
-            cols = ops.im2col_tap(xp, kh, kw, sh, sw, ph, pw)
-            wmat = ops.conv_weight_relayout(_c(weight), co, ci, kh * kw, True, ci_pad=Cp)
+        implicit = (not plain) and ops.GEMM_PRECISION == ops.PREC_F32 and ops.conv2d_implicit_ok(B, H, W, C, co, kh, kw, sh, sw, ph, pw)
         oh, ow = ops.conv_out(H, kh, sh, ph), ops.conv_out(W, kw, sw, pw)
-        y = sgemm(cols, wmat, OP_N, OP_T, bias=bias, epilogue=EPI_RELU if relu else EPI_NONE)
-        ctx.geom = (B, H, W, C, Cp, kh, kw, sh, sw, ph, pw, plain, relu, bias is not None, tuple(weight.shape))
-        ctx.save_for_backward(cols, wmat, y if relu else torch.empty(0))
+        if implicit:
+            wmat = ops.conv_weight_relayout(_c(weight), co, ci, kh * kw, True)
+            y = ops.conv2d_fwd(x, wmat, kh, kw, sh, sw, ph, pw, bias=bias, relu=relu)
+            cols = x                                          # the backward gathers from the image again
+        else:
+            if plain:
+                cols, wmat = x.view(B * H * W, C), weight.view(co, -1)
+            else:
+                xp = x if Cp == C else ops.pad_channels(x, Cp)
+                cols = ops.im2col_tap(xp, kh, kw, sh, sw, ph, pw)
+                wmat = ops.conv_weight_relayout(_c(weight), co, ci, kh * kw, True, ci_pad=Cp)
+            y = sgemm(cols, wmat, OP_N, OP_T, bias=bias, epilogue=EPI_RELU if relu else EPI_NONE)
+        ctx.geom = (B, H, W, C, Cp, kh, kw, sh, sw, ph, pw, plain, relu, bias is not None, tuple(weight.shape), implicit)
+        ctx.save_for_backward(cols, wmat, y if relu else torch.empty(0), weight if implicit else torch.empty(0))
         return y.view(B, oh, ow, co)
 
     @staticmethod
     def backward(ctx, dy):
-        B, H, W, C, Cp, kh, kw, sh, sw, ph, pw, plain, relu, has_bias, wshape = ctx.geom
-        cols, wmat, y = ctx.saved_tensors
+        B, H, W, C, Cp, kh, kw, sh, sw, ph, pw, plain, relu, has_bias, wshape, implicit = ctx.geom
+        cols, wmat, y, weight = ctx.saved_tensors
         co = wshape[0]
         d = _c(dy).view(-1, co)
         if relu:
             d = ops.relu_mask(d, y)
+        if implicit:
+            dw, db = ops.conv2d_wgrad(d, cols, kh, kw, sh, sw, ph, pw, want_bias=has_bias)
+            dw = ops.conv_weight_relayout(dw, co, C, kh * kw, False).view(wshape)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                if sh == 1 and sw == 1:
+                    dx = ops.conv2d_dgrad(d, ops.conv_weight_relayout(_c(weight), co, C, kh * kw, 2), (B, H, W, C), kh, kw, ph, pw)
+                else:   # strided: 3/4 of the (input pixel, tap) pairs of a gather would be empty -- scatter through columns
+                    dx = ops.col2im_tap(sgemm(d, wmat, OP_N, OP_N), (B, H, W, C), kh, kw, sh, sw, ph, pw)
+            return dx, dw, db, None, None, None
         if has_bias:
             dw, db = ops.wgrad_bias(d, cols)
         else:

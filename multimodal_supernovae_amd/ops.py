@@ -498,10 +498,59 @@ def conv_weight_relayout(w, co, ci, taps, to_tap, ci_pad=None):
     """(co, ci, taps) -> (co, taps, ci_pad) when to_tap (zeros in the channels ci .. ci_pad-1), the inverse otherwise;
     returns a flat 2-D matrix of `co` rows."""
     ci_pad = ci if ci_pad is None else ci_pad
-    out = torch.empty((co, (ci_pad if to_tap else ci) * taps), dtype=torch.float32, device=w.device)
-    check(lib().msn_conv_weight_relayout(ptr(_f32c(w, "w")), co, ci, ci_pad, taps, 1 if to_tap else 0, ptr(out),
+    if to_tap == 2:      # (tap, co, ci): the K-major weight operand of the implicit-GEMM dgrad
+        out = torch.empty((taps * co, ci), dtype=torch.float32, device=w.device)
+    else:
+        out = torch.empty((co, (ci_pad if to_tap else ci) * taps), dtype=torch.float32, device=w.device)
+    check(lib().msn_conv_weight_relayout(ptr(_f32c(w, "w")), co, ci, ci_pad, taps, int(to_tap), ptr(out),
                                          stream_ptr()), "msn_conv_weight_relayout")
     return out
+
+
+def conv2d_implicit_ok(B, H, W, C, co, kh, kw, sh, sw, ph, pw):
+    """Does the implicit-GEMM convolution (no column matrix) take this shape?  (msn_conv2d_implicit_ok)"""
+    return bool(lib().msn_conv2d_implicit_ok(B, H, W, C, co, kh, kw, sh, sw, ph, pw))
+
+
+def _conv_ws(geom, device):
+    nb = lib().msn_conv2d_workspace_bytes(*geom)
+    return (_workspace(nb, device), nb) if nb else (None, 0)
+
+
+def conv2d_fwd(x, w_tap, kh, kw, sh, sw, ph, pw, bias=None, relu=False):
+    """x: (B, H, W, C) channels-last, w_tap: (C_out, kh*kw*C) tap-major -> (B*OH*OW, C_out)."""
+    B, H, W, C = x.shape
+    co = w_tap.shape[0]
+    y = torch.empty((B * conv_out(H, kh, sh, ph) * conv_out(W, kw, sw, pw), co), dtype=torch.float32, device=x.device)
+    ws, nb = _conv_ws((B, H, W, C, co, kh, kw, sh, sw, ph, pw), x.device)
+    check(lib().msn_conv2d_fwd(ptr(_f32c(x, "x")), B, H, W, C, ptr(_f32c(w_tap, "w_tap")), co, kh, kw, sh, sw, ph, pw,
+                               ptr(bias) if bias is not None else None, EPI_RELU if relu else EPI_NONE, ptr(y),
+                               ptr(ws) if ws is not None else None, nb, stream_ptr()), "msn_conv2d_fwd")
+    return y
+
+
+def conv2d_dgrad(dy, w_tco, shape, kh, kw, ph, pw):
+    """dX of a stride-1 convolution: dy (B*OH*OW, C_out), w_tco (kh*kw*C_out, C) -> (B, H, W, C)."""
+    B, H, W, C = shape
+    co = dy.shape[1]
+    dx = torch.empty(shape, dtype=torch.float32, device=dy.device)
+    ws, nb = _conv_ws((B, H, W, C, co, kh, kw, 1, 1, ph, pw), dy.device)
+    check(lib().msn_conv2d_dgrad(ptr(_f32c(dy, "dy")), B, H, W, C, ptr(_f32c(w_tco, "w_tco")), co, kh, kw, ph, pw, ptr(dx),
+                                 ptr(ws) if ws is not None else None, nb, stream_ptr()), "msn_conv2d_dgrad")
+    return dx
+
+
+def conv2d_wgrad(dy, x, kh, kw, sh, sw, ph, pw, want_bias=False):
+    """dW (C_out, kh*kw*C) tap-major [, dbias (C_out,)] from dy (B*OH*OW, C_out) and the channels-last input x."""
+    B, H, W, C = x.shape
+    co = dy.shape[1]
+    dw = torch.empty((co, kh * kw * C), dtype=torch.float32, device=x.device)
+    db = torch.empty(co, dtype=torch.float32, device=x.device) if want_bias else None
+    ws, nb = _conv_ws((B, H, W, C, co, kh, kw, sh, sw, ph, pw), x.device)
+    check(lib().msn_conv2d_wgrad(ptr(_f32c(dy, "dy")), ptr(_f32c(x, "x")), B, H, W, C, co, kh, kw, sh, sw, ph, pw, ptr(dw),
+                                 ptr(db) if db is not None else None, ptr(ws) if ws is not None else None, nb, stream_ptr()),
+          "msn_conv2d_wgrad")
+    return dw, db
 
 
 def pad_channels(x, cp):

@@ -37,6 +37,47 @@ def test_conv_channels_last_matches_torch(H, W, C, co, k, s, p):
     close(bg.grad.cpu(), br.grad, "db")
 
 
+@pytest.mark.parametrize("B,H,W,C,co,k,s,p,bias", [
+    (4, 8, 8, 64, 64, 3, 1, 1, False), (8, 16, 16, 64, 128, 3, 2, 1, False), (4, 8, 8, 128, 64, 3, 1, 1, True),
+    (2, 1, 64, 64, 128, 5, 1, 2, True), (32, 4, 4, 256, 256, 3, 1, 1, False), (32, 5, 7, 64, 96, 3, 1, 1, True),
+    (32, 6, 10, 96, 160, 3, 2, 1, True), (64, 3, 5, 64, 64, 3, 1, 1, False), (8, 12, 12, 64, 64, 5, 1, 2, False),
+    (520, 8, 8, 64, 64, 3, 1, 1, False)])
+def test_conv_implicit_gemm_matches_torch(B, H, W, C, co, k, s, p, bias):
+    """Channel counts that are multiples of 32 run without a column matrix (msn_conv2d_fwd / _dgrad / _wgrad: the GEMM lanes
+    gather from the image, padding taps read zeros): y, dx, dw, db against torch in float64, ragged row tiles, odd image
+    widths (the pixel index is split with multiply-shift division), strides, 1-D series, the last case with a tail
+    of K-slabs and more than one split of the weight gradient."""
+    from multimodal_supernovae_amd import functional as F_, ops
+    kh, ph, sh = (1, 0, 1) if H == 1 else (k, p, s)
+    assert ops.conv2d_implicit_ok(B, H, W, C, co, kh, k, sh, s, ph, p)
+    g = torch.Generator().manual_seed(B + H * W + C + k)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(co, C, kh, k, generator=g) * 0.1
+    b = torch.randn(co, generator=g) if bias else None
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    br = b.double().requires_grad_() if bias else None
+    ref = torch.relu(F.conv2d(xr, wr, br, stride=(sh, s), padding=(ph, p)))
+    cot = torch.randn(ref.shape, generator=g)
+    ref.backward(cot.double())
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_()
+    wg = w.cuda().requires_grad_()
+    bg = b.cuda().requires_grad_() if bias else None
+    calls = []
+    real = ops.conv2d_fwd
+    try:
+        ops.conv2d_fwd = lambda *a, **kw: (calls.append(1), real(*a, **kw))[1]
+        y = F_.conv_cl(xg, wg, bg, (sh, s), (ph, p), relu=True)
+    finally:
+        ops.conv2d_fwd = real
+    assert calls, "the implicit path did not run"
+    close(y.detach().cpu().permute(0, 3, 1, 2), ref.detach(), "y")
+    y.backward(cot.permute(0, 2, 3, 1).contiguous().cuda())
+    close(xg.grad.cpu().permute(0, 3, 1, 2), xr.grad, "dx")
+    close(wg.grad.cpu(), wr.grad, "dw")
+    if bias:
+        close(bg.grad.cpu(), br.grad, "db")
+
+
 @pytest.mark.parametrize("C", [5, 8, 64])       # scalar kernel, 4-channels-per-thread kernels
 def test_maxpool_channels_last_matches_torch(C):
     from multimodal_supernovae_amd import functional as F_
