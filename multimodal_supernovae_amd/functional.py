@@ -3,6 +3,7 @@ sequences of libmsn_hip kernels (ops.py).  One node per transformer block / line
 step, so residual adds, bias adds, activations and their derivatives ride in GEMM epilogues and no
 stock ATen arithmetic runs on the hot path.  Reference lines are cited per node."""
 import math
+import os
 
 import torch
 
@@ -797,6 +798,7 @@ def take_token(x, idx):
 
 
 # ------------------------------------------------------ channels-last convolution (build-defined encoders)
+CONV_IMPLICIT = os.environ.get("MSN_CONV_IMPLICIT", "1") != "0"   # measurements: 0 = always im2col + GEMM
 @_remember_precision
 class _ConvCL(torch.autograd.Function):
     """y = conv(x) (+ bias) (+ ReLU) on channels-last tensors as an MFMA GEMM; weight keeps torch's (C_out, C_in, kh, kw)
@@ -816,7 +818,7 @@ class _ConvCL(torch.autograd.Function):
         x = _c(x)
         plain = kh == 1 and kw == 1 and sh == 1 and sw == 1 and ph == 0 and pw == 0
         Cp = C if plain else (C + 3) // 4 * 4
-        implicit = (not plain) and ops.GEMM_PRECISION == ops.PREC_F32 and ops.conv2d_implicit_ok(B, H, W, C, co, kh, kw, sh, sw, ph, pw)
+        implicit = CONV_IMPLICIT and (not plain) and ops.GEMM_PRECISION == ops.PREC_F32 and ops.conv2d_implicit_ok(B, H, W, C, co, kh, kw, sh, sw, ph, pw)
         oh, ow = ops.conv_out(H, kh, sh, ph), ops.conv_out(W, kw, sw, pw)
         if implicit:
             wmat = ops.conv_weight_relayout(_c(weight), co, ci, kh * kw, True)
