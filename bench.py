@@ -281,7 +281,7 @@ def main():
                     help="towers one after the other on one stream (profiling: with a tower per stream rocprofv3's "
                          "per-kernel durations include whatever the other stream ran meanwhile)")
     ap.add_argument("--gemm-table", action="store_true", help="per-shape GEMM timing of one step on stderr")
-    ap.add_argument("--gemm-variant", type=int, default=3, choices=[0, 1, 2, 3],
+    ap.add_argument("--gemm-variant", type=int, default=3, choices=[0, 1, 2, 3, 4],
                     help="fp32 GEMM kernel family: 0 register-staged, 1 / 2 / 3 LDS-DMA rings (3 = default)")
     ap.add_argument("--gemm-tail", type=int, default=1, choices=[0, 1, 2],
                     help="tail tiles of the fp32 GEMMs: 1 = K-slabs summed by the last workgroup to arrive (default), 2 = by a finishing launch, 0 = unsplit")

@@ -81,6 +81,9 @@ size_t msn_sgemm_workspace_bytes(int opA, int opB, int64_t M, int64_t N, int64_t
  *           workgroup, 2 x 32-deep K ring, two workgroups per CU.  Used where it applies (16-B aligned
  *           operands, K % 32 == 0); other shapes take mode 0.
  *   mode 1 / 2: LDS-DMA with 8 waves per workgroup and a 3 x 32 / 2 x 64 deep ring (one workgroup per CU).
+ *   mode 4: persistent workgroups of 4 multiplying + 2 loader waves (the loaders issue the ring's LDS-DMA for the
+ *           whole sequence of tiles, so epilogue stores never sit in front of an operand wait); 128-wide tiles only.
+ *           Measured equal to mode 3 on long K and slower on K <= 384: kept as an alternative.
  * All modes give bit-identical results (same k order per accumulator).  Process-wide. */
 int msn_set_gemm_variant(int mode);
 /* Tail split (default on): a product whose 128 x 128 tiles do not fill a whole number of rounds of the chip's

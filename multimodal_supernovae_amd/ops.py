@@ -39,7 +39,8 @@ def set_gemm_precision(name):
     GEMM_PRECISION = _PREC_NAMES[name]
 
 def set_gemm_variant(mode):
-    """fp32 GEMM kernel family (msn_set_gemm_variant): 0 register-staged, 1 / 2 / 3 LDS-DMA rings (3 = default)."""
+    """fp32 GEMM kernel family (msn_set_gemm_variant): 0 register-staged, 1 / 2 / 3 LDS-DMA rings (3 = default),
+    4 persistent workgroups with loader waves."""
     check(lib().msn_set_gemm_variant(int(mode)))
 
 

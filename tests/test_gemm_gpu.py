@@ -67,7 +67,7 @@ def test_sgemm_variants_bit_identical(M, N, K, op_a, op_b):
     epi = ops.EPI_GELU if op_a == 0 else ops.EPI_NONE
     try:
         outs = []
-        for v in (0, 1, 2, 3):
+        for v in (0, 1, 2, 3, 4):
             ops.set_gemm_variant(v)
             outs.append(ops.sgemm(a, b, op_a, op_b, bias=bias, epilogue=epi))
     finally:
@@ -82,7 +82,7 @@ def test_sgemm_variants_bit_identical(M, N, K, op_a, op_b):
 @pytest.mark.parametrize("M,N,K,op_a,op_b", [(4096, 512, 256, 0, 1), (4100, 500, 300, 0, 0), (66560, 384, 384, 0, 1),
                                               (2048, 1024, 512, 1, 1), (33280, 384, 1536, 0, 0)])
 @pytest.mark.parametrize("epi", ["none", "gelu", "add", "relu_bwd"])
-@pytest.mark.parametrize("variant,precision", [(0, 0), (1, 0), (2, 0), (3, 0), (0, 1), (0, 2)])
+@pytest.mark.parametrize("variant,precision", [(0, 0), (1, 0), (2, 0), (3, 0), (4, 0), (0, 1), (0, 2)])
 def test_sgemm_tail_split(M, N, K, op_a, op_b, epi, variant, precision):
     """Tiles of the partly filled last round run as K-slabs + a finishing pass (msn_set_gemm_tail_split): same
     result as the unsplit launch up to summation order, through every epilogue, layout, kernel family, precision."""
