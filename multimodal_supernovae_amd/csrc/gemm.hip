@@ -1064,6 +1064,10 @@ static Plan plan(int64_t M, int64_t N, int64_t K, int opA, bool allow_tail = tru
     // 104.2 -> 97.4; from ~1000 tiles on the wide tile wins again)
     if (N > 64 && N % 64 == 0 && opA == MSN_OP_N && g_gemm_bn == 0 && cdiv(M, 128) * cdiv(N, 128) <= 800) p.bn = 64;
     if (N > 64 && g_gemm_bn != 0) p.bn = g_gemm_bn;
+    // Weight gradients with few rows (dW of a Linear whose OUTPUT is 32 / 64 wide: the reference towers' ff2): a 128-row
+    // tile would multiply 4x / 2x rows that do not exist -- measured compute-bound on them (M = 32, N = 128, K = 225 280:
+    // 82 us against 18 us of HBM time)
+    if (opA == MSN_OP_T && p.bn == 128 && M <= 64 && g_gemm_bn == 0) p.bm = M <= 32 ? 32 : 64;
     p.tail_tiles = 0, p.tail_splits = 1, p.tail_kps = 0;
     const int64_t tiles = cdiv(M, p.bm) * cdiv(N, p.bn);
     const int64_t ksteps = cdiv(K, BK);
@@ -1156,7 +1160,7 @@ static int sgemm_impl(int opA, int opB, int64_t M, int64_t N, int64_t K, const f
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
     a.epilogue = epilogue;
     const Plan pl = plan(M, N, K, opA, colsum_out == nullptr);
-    const int bm = pl.bm, bn = pl.bn, splits = pl.splits, kps = pl.kps;
+    const int bm = conv != 0 ? 128 : pl.bm, bn = pl.bn, splits = pl.splits, kps = pl.kps;   // (short tiles: M <= bm, one row of tiles either way)
     a.colsum = nullptr;
     a.tiles_m = (int)cdiv(M, bm);
     a.tiles_n = (int)cdiv(N, bn);
@@ -1211,11 +1215,14 @@ static int sgemm_impl(int opA, int opB, int64_t M, int64_t N, int64_t K, const f
     }
     if (colsum_done) *colsum_done = fuse_colsum;
     int waves = 4;   // per workgroup of the kernel chosen (the tail pass mirrors its register layout)
+    if (bm != 128) bf16_ok = false;   // the short tiles exist for the fp32 kernels only (tiny products: exact fp32 costs nothing)
     if (conv != 0) {   // implicit-GEMM convolution: the 4-wave LDS-DMA kernels only
         MSN_REQUIRE(dma_ok && !bf16_ok && bn >= 64, "implicit convolution: shape not taken by the LDS-DMA kernels");
         if (bn == 128) rc = launch_dma_conv<128, 128, 64, 64, 32, 2>(a, conv, opB, st);
         else rc = launch_dma_conv<128, 64, 64, 32, 32, 3>(a, conv, opB, st);
     } else if (bf16_ok) rc = launch_bgemm(a, opA, opB, precision == MSN_PREC_BF16X3 ? 2 : 1, bm, bn, st);
+    else if (bm == 32) rc = dma_ok ? launch_dma<32, 128, 32, 32, 32, 2>(a, opA, opB, st) : launch_cfg<32, 128, 32, 32>(a, opA, opB, st);
+    else if (bm == 64) rc = dma_ok ? launch_dma<64, 128, 32, 64, 32, 2>(a, opA, opB, st) : launch_cfg<64, 128, 32, 64>(a, opA, opB, st);
     else if (dma_ok && bn == 128 && K % 64 == 0 && kps % 64 == 0 && g_gemm_variant == 2)
         rc = launch_dma<128, 128, 64, 32, 64, 2>(a, opA, opB, st), waves = 8;
     else if (dma_ok && bn == 128 && g_gemm_variant == 4) rc = launch_pw<128, 128, 64, 64, 32, 2>(a, opA, opB, st);

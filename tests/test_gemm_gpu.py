@@ -281,3 +281,24 @@ def test_colsum(M, N):
     from multimodal_supernovae_amd import ops
     x = torch.randn(M, N, generator=torch.Generator().manual_seed(M + N)).cuda()
     torch.testing.assert_close(ops.colsum(x).double(), x.double().sum(0), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 128, 8192), (64, 256, 4096), (24, 160, 2048), (48, 128, 4100), (64, 200, 8192), (32, 128, 225280)])
+@pytest.mark.parametrize("variant", [3, 0])
+def test_wgrad_short_row_tiles(M, N, K, variant):
+    """Weight gradients with at most 64 rows (dW of a Linear with a 32- / 64-wide output) run on 32- / 64-row tiles: product
+    and fused bias gradient against float64, LDS-DMA and register-staged kernels (K = 4100 is not a whole K-step)."""
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(M * N + K)
+    dy, x = torch.randn(K, M, generator=g).cuda(), torch.randn(K, N, generator=g).cuda()
+    try:
+        ops.set_gemm_variant(variant)
+        dw, db = ops.wgrad_bias(dy, x)
+        plain = ops.sgemm(dy, x, ops.OP_T, ops.OP_N)
+    finally:
+        ops.set_gemm_variant(3)
+    ref = dy.double().T @ x.double()
+    tol = dict(rtol=1e-4, atol=2e-4 * K ** 0.5)
+    torch.testing.assert_close(dw.double(), ref, **tol)
+    torch.testing.assert_close(plain.double(), ref, **tol)
+    torch.testing.assert_close(db.double(), dy.double().sum(0), **tol)
