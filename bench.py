@@ -285,6 +285,8 @@ def main():
                     help="fp32 GEMM kernel family: 0 register-staged, 1 / 2 / 3 LDS-DMA rings (3 = default)")
     ap.add_argument("--gemm-tail", type=int, default=1, choices=[0, 1, 2],
                     help="tail tiles of the fp32 GEMMs: 1 = K-slabs summed by the last workgroup to arrive (default), 2 = by a finishing launch, 0 = unsplit")
+    ap.add_argument("--bgemm-one-tile", action="store_true",
+                    help="bf16-resident NT products: one workgroup per tile instead of persistent workgroups (A/B measurement)")
     ap.add_argument("--gemm-precision", default="f32", choices=["f32", "bf16x3", "bf16"],
                     help="inner-product precision of the GEMMs (bf16x3 = split-bf16, fp32-grade accuracy)")
     ap.add_argument("--graphed", action="store_true",
@@ -304,6 +306,9 @@ def main():
     ops.set_gemm_precision(args.gemm_precision)
     ops.set_gemm_variant(args.gemm_variant)
     ops.set_gemm_tail_split(args.gemm_tail)
+    if args.bgemm_one_tile:
+        from multimodal_supernovae_amd import _lib
+        _lib.check(_lib.lib().msn_set_bgemm_persistent(0))
     rank, local, world = D.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")

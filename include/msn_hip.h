@@ -231,7 +231,11 @@ int msn_add_rows(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t
  *                  writing a bf16 copy of dx next to the fp32 one. */
 int msn_bgemm_nt(int64_t M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                  int c_bf16, const float* bias, int epilogue, void* aux, int64_t ldaux, float* colsum_out, void* ws,
-                 size_t ws_bytes, msn_stream_t stream);   /* colsum_out (nullable): out[n] = sum_m C[m][n] from the epilogue (the
+                 size_t ws_bytes, msn_stream_t stream);
+/* msn_bgemm_nt launches one persistent workgroup per CU that walks the 256 x 256 tiles and keeps its LDS ring of K-tiles
+ * running across tile boundaries (default); enabled = 0: one workgroup per tile (measurements; same results). */
+int msn_set_bgemm_persistent(int enabled);
+  /* colsum_out (nullable): out[n] = sum_m C[m][n] from the epilogue (the
                  bias gradient of the Linear whose output gradient C is); ws >= msn_bgemm_nt_colsum_workspace_bytes(M, N) */
 size_t msn_bgemm_nt_colsum_workspace_bytes(int64_t M, int N);
 size_t msn_bgemm_tn_workspace_bytes(int64_t M, int N, int K);

@@ -27,6 +27,7 @@ SIGNATURES = {
     "msn_sgemm": (c_int, [c_int, c_int, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr,
                           c_int, c_ptr, c_i64, c_int, c_ptr, c_size, c_ptr]),
     "msn_set_gemm_variant": (c_int, [c_int]),
+    "msn_set_bgemm_persistent": (c_int, [c_int]),
     "msn_set_gemm_tail_split": (c_int, [c_int]),
     "msn_set_gemm_tile_n": (c_int, [c_int]),
     "msn_wgrad_bias_workspace_bytes": (c_size, [c_i64, c_i64, c_i64]),

@@ -105,47 +105,56 @@ __global__ __launch_bounds__(512, 2) void bgemm_nt_kernel(const BgemmArgs p) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // XCD-aware order: workgroup ids are dealt round-robin to the 8 XCDs; give each XCD a contiguous run of tiles, and
-    // walk the tiles N-fastest so that the workgroups of one XCD share A row panels (and the whole weight) in its L2
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg / 8, r = nwg % 8, x = bid % 8, i = bid / 8;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-    }
-    // inside an XCD's run: super-rows of 8 tile-rows, row-fastest within a tile column -- the 32 workgroups an XCD has in
+    // Persistent: workgroup b multiplies the tiles t = b, b + gridDim.x, ... (one workgroup per CU; gridDim.x is a multiple
+    // of 8 or the number of tiles).  The ring of K-tiles runs on ACROSS tile boundaries: the first two K-tiles of the next
+    // tile are requested during the last two K-tiles of this one, so they land under the epilogue instead of in front of
+    // the next tile's first MFMA -- with one workgroup per CU nothing else would cover that prologue.
+    // XCD-aware order: tile ids are dealt round-robin to the 8 XCDs (t % 8 == blockIdx.x % 8); give each XCD a contiguous
+    // run of tiles, and walk the tiles N-fastest so that the workgroups of one XCD share A row panels (and the whole
+    // weight) in its L2.
+    // Inside an XCD's run: super-rows of 8 tile-rows, row-fastest within a tile column -- the 32 workgroups an XCD has in
     // flight then cover 8 A row panels (3 MB at K = 768) x 4 weight column panels, so a weight panel is fetched once per
     // super-row instead of once per tile-row (rocprofv3 FETCH_SIZE of the N = 3072, K = 768 products: 2.1 GB per launch
     // against 0.78 GB of operands with the N-fastest order; the weight alone is 4.7 MB against 4 MB of L2)
     // (only while the super-row's A panels fit an L2 next to the weight stream: SR = 4096 / K tile-rows, 1 for K >= 2304)
-    const int SR = p.super_rows;
-    const int sr = bid / (SR * p.tiles_n), j = bid % (SR * p.tiles_n);
-    const int rows_sr = min(SR, p.tiles_m - sr * SR);
-    const int tm = sr * SR + j % rows_sr, tn = j / rows_sr;
-    const int64_t m0 = (int64_t)tm * BT;
-    const int n0 = tn * BT;
-
+    const int total = p.tiles_m * p.tiles_n;
+    auto locate = [&](int t, int64_t& m0_, int& n0_, int& tm_) {
+        const int q = total / 8, r = total % 8, x = t % 8, i = t / 8;
+        const int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+        const int SR = p.super_rows;
+        const int sr = bid / (SR * p.tiles_n), j = bid % (SR * p.tiles_n);
+        const int rows_sr = min(SR, p.tiles_m - sr * SR);
+        tm_ = sr * SR + j % rows_sr;
+        m0_ = (int64_t)tm_ * BT;
+        n0_ = (j / rows_sr) * BT;
+    };
     // ---- LDS-DMA sources: wave w moves pieces 4w .. 4w+3 (8 rows x 128 B each) of both operands
-    const u16* srcA[4];
-    const u16* srcB[4];
+    auto make_src = [&](const u16* (&sa)[4], const u16* (&sb)[4], int64_t m0_, int n0_) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int R = 8 * (4 * wave + q) + (lane >> 3);
-        const int c = (lane & 7) ^ swz(R);
-        const int64_t ra = std::min<int64_t>(m0 + R, p.M - 1);        // rows past the edge: clamped, never stored
-        const int64_t rb = std::min<int64_t>((int64_t)n0 + R, p.N - 1);
-        srcA[q] = p.A + ra * p.lda + 8 * c;
-        srcB[q] = p.B + rb * p.ldb + 8 * c;
-    }
+        for (int q = 0; q < 4; ++q) {
+            const int R = 8 * (4 * wave + q) + (lane >> 3);
+            const int c = (lane & 7) ^ swz(R);
+            const int64_t ra = std::min<int64_t>(m0_ + R, p.M - 1);        // rows past the edge: clamped, never stored
+            const int64_t rb = std::min<int64_t>((int64_t)n0_ + R, p.N - 1);
+            sa[q] = p.A + ra * p.lda + 8 * c;
+            sb[q] = p.B + rb * p.ldb + 8 * c;
+        }
+    };
+    int t = blockIdx.x, tm, n0, tm_next = 0, n0_next = 0;
+    int64_t m0, m0_next = 0;
+    locate(t, m0, n0, tm);
+    const u16* srcA[4];            // of the tile whose K-tiles are being REQUESTED: the next tile's from its last-but-one K-tile on
+    const u16* srcB[4];
+    make_src(srcA, srcB, m0, n0);
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t*)lds;   // LDS byte address of the array
-    auto issue = [&](int buf, int kt) {
+    auto issue = [&](int buf, const u16* const (&sa)[4], const u16* const (&sb)[4], int kt) {
         unsigned char* dst = lds + buf * STAGE_BYTES + wave * 4096;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            __builtin_amdgcn_global_load_lds((gptr_t*)(srcA[q] + (int64_t)kt * BKS), (lptr_t*)(dst + q * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t*)(sa[q] + (int64_t)kt * BKS), (lptr_t*)(dst + q * 1024), 16, 0, 0);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            __builtin_amdgcn_global_load_lds((gptr_t*)(srcB[q] + (int64_t)kt * BKS), (lptr_t*)(dst + OPER_BYTES + q * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t*)(sb[q] + (int64_t)kt * BKS), (lptr_t*)(dst + OPER_BYTES + q * 1024), 16, 0, 0);
     };
 
     // ---- fragment addresses: wave (wm, wn) owns rows 128 wm .. +127 of A, rows (= output columns) 64 wn .. +63 of B
@@ -156,10 +165,6 @@ __global__ __launch_bounds__(512, 2) void bgemm_nt_kernel(const BgemmArgs p) {
     const unsigned fragB = (unsigned)(OPER_BYTES + (wn * 64 + l15) * 128 + 16 * (g ^ (l15 >> 1)));
 
     f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 fa[2][4], fb[2][4];
 
     // set S of A fragments <- m-tiles 4 mh .. 4 mh + 3 at k32 half kk;  set S of B fragments <- all 4 n-tiles at kk
@@ -177,121 +182,142 @@ __global__ __launch_bounds__(512, 2) void bgemm_nt_kernel(const BgemmArgs p) {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory"); \
     __builtin_amdgcn_sched_barrier(0);
 
-    const int nkt = p.K / BKS;
-    issue(0, 0);
+    auto store_tile = [&](int64_t m0, int n0, int tm) {
+        // ---- epilogue: lane holds, per (i, j) tile, row m = 16 i + l15 and columns n = 16 j + 4 g .. + 3
+        const int64_t mrow0 = m0 + wm * 128 + l15;
+        const int ncol0 = n0 + wn * 64 + 4 * g;
+        float4 bias4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = ncol0 + 16 * j;
+            bias4[j] = (p.bias && n + 3 < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float cs[4][4];                                            // column sums of this wave's 128 rows (bias gradient)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cs[j][r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t m = mrow0 + 16 * i;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = ncol0 + 16 * j;
+                if (n + 3 >= p.N) continue;                        // N % 4 == 0 (checked on the host)
+                float v[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z,
+                              acc[i][j][3] + bias4[j].w};
+                if constexpr (EPI == EPI_B_GELU) {                 // aux <- pre-activation (bf16), C <- gelu(pre)
+                    u16* ap = static_cast<u16*>(p.aux) + m * p.ldaux + n;
+                    ushort4 pre;
+                    pre.x = f2bf(v[0]); pre.y = f2bf(v[1]); pre.z = f2bf(v[2]); pre.w = f2bf(v[3]);
+                    *reinterpret_cast<ushort4*>(ap) = pre;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
+                } else if constexpr (EPI == EPI_B_GELU_BWD) {      // C <- acc * gelu'(aux), aux = saved bf16 pre-activation
+                    const ushort4 pre = *reinterpret_cast<const ushort4*>(static_cast<const u16*>(p.aux) + m * p.ldaux + n);
+                    v[0] *= gelu_grad_fast(bf2f(pre.x)); v[1] *= gelu_grad_fast(bf2f(pre.y));
+                    v[2] *= gelu_grad_fast(bf2f(pre.z)); v[3] *= gelu_grad_fast(bf2f(pre.w));
+                } else if constexpr (EPI == EPI_B_ADD) {           // C <- acc + bias + aux (fp32 residual)
+                    const float4 a = *reinterpret_cast<const float4*>(static_cast<const float*>(p.aux) + m * p.ldaux + n);
+                    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+                }
+                if constexpr (OUT_BF16) {
+                    ushort4 o;
+                    o.x = f2bf(v[0]); o.y = f2bf(v[1]); o.z = f2bf(v[2]); o.w = f2bf(v[3]);
+                    *reinterpret_cast<ushort4*>(static_cast<u16*>(p.C) + m * p.ldc + n) = o;
+                    if (p.colpart) {                               // sums of the values AS STORED (what the next products read)
+                        cs[j][0] += bf2f(o.x); cs[j][1] += bf2f(o.y); cs[j][2] += bf2f(o.z); cs[j][3] += bf2f(o.w);
+                    }
+                } else {
+                    *reinterpret_cast<float4*>(static_cast<float*>(p.C) + m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (p.colpart) { cs[j][0] += v[0]; cs[j][1] += v[1]; cs[j][2] += v[2]; cs[j][3] += v[3]; }
+                }
+            }
+        }
+        if (p.colpart) {   // the 16 lanes sharing g hold the 16 rows of every row tile: xor tree, then lane l15 == 0 writes 4 columns
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = cs[j][r];
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o, 64);
+                    cs[j][r] = t;
+                }
+            if (l15 == 0) {
+                float* row = p.colpart + (int64_t)(2 * tm + wm) * p.N;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = ncol0 + 16 * j;
+                    if (n + 3 < p.N) *reinterpret_cast<float4*>(row + n) = make_float4(cs[j][0], cs[j][1], cs[j][2], cs[j][3]);
+                }
+            }
+        }
+    };
+
+    const int nkt = p.K / BKS;             // >= 2 whenever gridDim.x < total (host)
+    issue(0, srcA, srcB, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (nkt > 1) issue(1, 1);
-    REQ_A(0, 0, 0, 0)
-    REQ_B(0, 0, 0)
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        // phase 0: k32 half 0, m-tiles 0-3
-        REQ_A(1, cur, 0, 1)
-        WAIT_LGKM(4)
-        MULT(0, 0, 0)
-        __builtin_amdgcn_sched_barrier(0);
-        // phase 1: k32 half 0, m-tiles 4-7
-        REQ_A(0, cur, 1, 0)
-        REQ_B(1, cur, 1)
-        WAIT_LGKM(8)
-        MULT(1, 0, 1)
-        __builtin_amdgcn_sched_barrier(0);
-        // phase 2: k32 half 1, m-tiles 0-3
-        REQ_A(1, cur, 1, 1)
-        WAIT_LGKM(4)
-        MULT(0, 1, 0)
-        __builtin_amdgcn_sched_barrier(0);
-        // phase 3: every fragment of this K-tile is in registers -> the buffer may be refilled; K-tile kt + 1 (issued one
-        // K-tile ago) must have landed
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 2 < nkt) issue(cur, kt + 2);
-        if (kt + 1 < nkt) {
-            REQ_A(0, cur ^ 1, 0, 0)
-            REQ_B(0, cur ^ 1, 0)
+    if (nkt > 1) issue(1, srcA, srcB, 1);
+    unsigned gs = 0;                       // K-tiles this workgroup has started, over all its tiles: K-tile gs sits in buffer gs & 1
+    for (;;) {
+        const int t_next = t + (int)gridDim.x;
+        const bool more = t_next < total;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        REQ_A(0, gs & 1, 0, 0)
+        REQ_B(0, gs & 1, 0)
+        for (int kt = 0; kt < nkt; ++kt, ++gs) {
+            const int cur = gs & 1;
+            // phase 0: k32 half 0, m-tiles 0-3
+            REQ_A(1, cur, 0, 1)
+            WAIT_LGKM(4)
+            MULT(0, 0, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            // phase 1: k32 half 0, m-tiles 4-7
+            REQ_A(0, cur, 1, 0)
+            REQ_B(1, cur, 1)
+            WAIT_LGKM(8)
+            MULT(1, 0, 1)
+            __builtin_amdgcn_sched_barrier(0);
+            // phase 2: k32 half 1, m-tiles 0-3
+            REQ_A(1, cur, 1, 1)
+            WAIT_LGKM(4)
+            MULT(0, 1, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            // phase 3: every fragment of this K-tile is in registers -> the buffer may be refilled; the next K-tile of the
+            // stream (issued one K-tile ago; the next tile's first one at the end of a tile) must have landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 2 < nkt) issue(cur, srcA, srcB, kt + 2);
+            else if (more) {                                   // the ring runs on into the next tile
+                if (kt + 2 == nkt) {                           // (this tile's last K-tile was requested one K-tile ago)
+                    locate(t_next, m0_next, n0_next, tm_next);
+                    make_src(srcA, srcB, m0_next, n0_next);
+                }
+                issue(cur, srcA, srcB, kt + 2 - nkt);
+            }
+            if (kt + 1 < nkt) {
+                REQ_A(0, cur ^ 1, 0, 0)
+                REQ_B(0, cur ^ 1, 0)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            MULT(1, 1, 1)
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        MULT(1, 1, 1)
-        __builtin_amdgcn_sched_barrier(0);
+        store_tile(m0, n0, tm);
+        if (!more) break;
+        t = t_next, m0 = m0_next, n0 = n0_next, tm = tm_next;
     }
 #undef REQ_A
 #undef REQ_B
 #undef MULT
-
-    // ---- epilogue: lane holds, per (i, j) tile, row m = 16 i + l15 and columns n = 16 j + 4 g .. + 3
-    const int64_t mrow0 = m0 + wm * 128 + l15;
-    const int ncol0 = n0 + wn * 64 + 4 * g;
-    float4 bias4[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = ncol0 + 16 * j;
-        bias4[j] = (p.bias && n + 3 < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    float cs[4][4];                                            // column sums of this wave's 128 rows (bias gradient)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cs[j][r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int64_t m = mrow0 + 16 * i;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = ncol0 + 16 * j;
-            if (n + 3 >= p.N) continue;                        // N % 4 == 0 (checked on the host)
-            float v[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z,
-                          acc[i][j][3] + bias4[j].w};
-            if constexpr (EPI == EPI_B_GELU) {                 // aux <- pre-activation (bf16), C <- gelu(pre)
-                u16* ap = static_cast<u16*>(p.aux) + m * p.ldaux + n;
-                ushort4 pre;
-                pre.x = f2bf(v[0]); pre.y = f2bf(v[1]); pre.z = f2bf(v[2]); pre.w = f2bf(v[3]);
-                *reinterpret_cast<ushort4*>(ap) = pre;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
-            } else if constexpr (EPI == EPI_B_GELU_BWD) {      // C <- acc * gelu'(aux), aux = saved bf16 pre-activation
-                const ushort4 pre = *reinterpret_cast<const ushort4*>(static_cast<const u16*>(p.aux) + m * p.ldaux + n);
-                v[0] *= gelu_grad_fast(bf2f(pre.x)); v[1] *= gelu_grad_fast(bf2f(pre.y));
-                v[2] *= gelu_grad_fast(bf2f(pre.z)); v[3] *= gelu_grad_fast(bf2f(pre.w));
-            } else if constexpr (EPI == EPI_B_ADD) {           // C <- acc + bias + aux (fp32 residual)
-                const float4 a = *reinterpret_cast<const float4*>(static_cast<const float*>(p.aux) + m * p.ldaux + n);
-                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
-            }
-            if constexpr (OUT_BF16) {
-                ushort4 o;
-                o.x = f2bf(v[0]); o.y = f2bf(v[1]); o.z = f2bf(v[2]); o.w = f2bf(v[3]);
-                *reinterpret_cast<ushort4*>(static_cast<u16*>(p.C) + m * p.ldc + n) = o;
-                if (p.colpart) {                               // sums of the values AS STORED (what the next products read)
-                    cs[j][0] += bf2f(o.x); cs[j][1] += bf2f(o.y); cs[j][2] += bf2f(o.z); cs[j][3] += bf2f(o.w);
-                }
-            } else {
-                *reinterpret_cast<float4*>(static_cast<float*>(p.C) + m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-                if (p.colpart) { cs[j][0] += v[0]; cs[j][1] += v[1]; cs[j][2] += v[2]; cs[j][3] += v[3]; }
-            }
-        }
-    }
-    if (p.colpart) {   // the 16 lanes sharing g hold the 16 rows of every row tile: xor tree, then lane l15 == 0 writes 4 columns
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float t = cs[j][r];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o, 64);
-                cs[j][r] = t;
-            }
-        if (l15 == 0) {
-            float* row = p.colpart + (int64_t)(2 * tm + wm) * p.N;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = ncol0 + 16 * j;
-                if (n + 3 < p.N) *reinterpret_cast<float4*>(row + n) = make_float4(cs[j][0], cs[j][1], cs[j][2], cs[j][3]);
-            }
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -565,6 +591,12 @@ static int tn_splits(int tiles, int64_t M) {
 
 using namespace msn;
 
+static int g_bgemm_persistent = 1;
+extern "C" int msn_set_bgemm_persistent(int enabled) {
+    g_bgemm_persistent = enabled ? 1 : 0;
+    return MSN_OK;
+}
+
 extern "C" size_t msn_bgemm_nt_colsum_workspace_bytes(int64_t M, int N) {
     if (M <= 0 || N <= 0) return 0;
     return sizeof(float) * 2 * (size_t)cdiv(M, BT) * (size_t)N;
@@ -594,7 +626,11 @@ extern "C" int msn_bgemm_nt(int64_t M, int N, int K, const void* A, int64_t lda,
         MSN_REQUIRE(ws && ws_bytes >= need && aligned16(ws) && N % 4 == 0, "msn_bgemm_nt: column-sum workspace %zu < %zu bytes", ws_bytes, need);
         a.colpart = static_cast<float*>(ws);
     }
-    const dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(512);
+    // one persistent workgroup per CU walking the tiles (the ring of K-tiles runs on across tile boundaries) once there is
+    // more than one tile per CU and a tile has at least two K-tiles; otherwise one workgroup per tile
+    const int total_tiles = a.tiles_m * a.tiles_n;
+    const bool persistent = g_bgemm_persistent && total_tiles > 256 && K / BKS >= 2;
+    const dim3 grid((unsigned)(persistent ? 256 : total_tiles)), block(512);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (epilogue == EPI_B_GELU) hipLaunchKernelGGL((bgemm_nt_kernel<EPI_B_GELU, true>), grid, block, 0, st, a);
     else if (epilogue == EPI_B_ADD) hipLaunchKernelGGL((bgemm_nt_kernel<EPI_B_ADD, false>), grid, block, 0, st, a);
