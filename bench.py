@@ -371,6 +371,20 @@ def main():
         for _ in range(warmup):
             loss = fn()
         fence()
+        # Short steps (small towers: 15 ms) are not warm after W of them -- caching allocator still growing, core clock
+        # still ramping after the idle gap (1.9 -> 2.4 GHz): cfg2 timed 21 ms / step after 3 warm-up steps and 15.2 ms
+        # after 10 or 30.  Keep stepping, untimed, until about 0.6 s of steps have run (same count on every rank).
+        t0 = time.perf_counter()
+        loss = fn()
+        fence()
+        one = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        if world > 1:
+            torch.distributed.all_reduce(one, op=torch.distributed.ReduceOp.MAX)
+        extra = int(min(200, max(0, 0.6 / max(float(one), 1e-4) - warmup - 1)))
+        for _ in range(extra):
+            loss = fn()
+        timed.extra_warmup = extra + 1
+        fence()
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = fn()
@@ -525,6 +539,7 @@ def main():
                        if headline else WORKLOADS[args.workload] + " (non-headline configuration)",
                        "per_gpu_batch": b, "global_batch": b * world, "parallelism": f"dp{world}",
                        "launch": "HIP graph replay" if args.graphed else "eager",
+                       "untimed_steps_after_warmup": getattr(timed, "extra_warmup", 0),
                        "loss": loss_value, "algorithmic_gflop_per_pair": flops_per_pair() / 1e9,
                        "executed_gflop_per_pair": flops_per_pair(executed=True) / 1e9,
                        "model_tflops": pairs * flops_per_pair(executed=True) / 1e12},
