@@ -319,6 +319,10 @@ int msn_relu_mask(const float* dy, const float* y, int64_t total, float* dmasked
 int msn_batchnorm_bwd(const float* dy, const float* x, const float* dact, int64_t rows, int C,
                       const float* mean, const float* rstd, const float* gamma, int training, float* dx,
                       float* dgamma, float* dbeta, void* ws, size_t ws_bytes, msn_stream_t stream);
+/* The same for BatchNorm + ReLU (y = relu(bn(x)) saved): dy is masked by y > 0 inside both passes. */
+int msn_batchnorm_relu_bwd(const float* dy, const float* y, const float* x, int64_t rows, int C, const float* mean,
+                           const float* rstd, const float* gamma, int training, float* dx, float* dgamma, float* dbeta,
+                           void* ws, size_t ws_bytes, msn_stream_t stream);
 
 /* Synchronised BatchNorm for data-parallel replicas (per-replica statistics differ from the
  * single-process statistics at the global batch).  The same two-pass statistics as msn_batchnorm_fwd / _bwd, cut at

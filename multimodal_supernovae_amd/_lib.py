@@ -102,6 +102,8 @@ SIGNATURES = {
     "msn_maxpool2d_bwd": (c_int, [c_ptr, c_ptr] + [c_int] * 7 + [c_ptr, c_ptr]),
     "msn_batchnorm_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr,
                                   c_ptr, c_size, c_ptr]),
+    "msn_batchnorm_relu_bwd": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr,
+                                       c_ptr, c_size, c_ptr]),
     "msn_bn_colsum": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "msn_bn_mean_from_sum": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     "msn_bn_rstd_from_sqdev": (c_int, [c_ptr, c_i64, c_int, c_f32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),

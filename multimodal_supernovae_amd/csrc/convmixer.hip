@@ -178,12 +178,15 @@ __global__ void relu_mask_kernel(const float* __restrict__ dy, const float* __re
         dm[i] = y[i] > 0.f ? dy[i] : 0.f;
 }
 // partial (sum dy, sum dy * xhat)
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+// (ymask != null: BatchNorm was followed by ReLU -- the incoming gradient counts where the saved output is positive)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ ymask,
+                                                            const float* __restrict__ x,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, int64_t rows, int C,
                                                             float* __restrict__ part) {
     col_reduce2(rows, C, part, [&](int64_t r, int c, float& a, float& b) {
-        const float d = dy[r * C + c];
+        float d = dy[r * C + c];
+        if (ymask) d = ymask[r * C + c] > 0.f ? d : 0.f;
         a = d;
         b = d * (x[r * C + c] - mean[c]) * rstd[c];
     });
@@ -200,8 +203,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_finish_kernel(const float* __rest
     }
 }
 // dx = gamma * rstd * (dy - [train](dbeta + xhat * dgamma) / rows), then * pre[] (= saved gelu') when non-null
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                    const float* __restrict__ pre, const float* __restrict__ mean,
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ ymask,
+                                    const float* __restrict__ x, const float* __restrict__ pre, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                     const float* __restrict__ dbeta, const float* __restrict__ dgamma, int64_t rows,
                                     int64_t count, int C, int training, float* __restrict__ dx) {
@@ -210,6 +213,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         float d = dy[i];
+        if (ymask) d = ymask[i] > 0.f ? d : 0.f;
         if (training) {
             const float xhat = (x[i] - mean[c]) * rstd[c];
             d -= (dbeta[c] + xhat * dgamma[c]) * inv_n;
@@ -369,22 +373,35 @@ extern "C" int msn_batchnorm_fwd(const float* x, int64_t rows, int C, const floa
 }
 
 // dx = BN backward (then * gelu'(pre) when pre != NULL); dgamma, dbeta always written.
-extern "C" int msn_batchnorm_bwd(const float* dy, const float* x, const float* pre, int64_t rows, int C,
-                                 const float* mean, const float* rstd, const float* gamma, int training, float* dx,
-                                 float* dgamma, float* dbeta, void* ws, size_t ws_bytes, msn_stream_t stream) {
+static int batchnorm_bwd_impl(const float* dy, const float* ymask, const float* x, const float* pre, int64_t rows, int C,
+                              const float* mean, const float* rstd, const float* gamma, int training, float* dx,
+                              float* dgamma, float* dbeta, void* ws, size_t ws_bytes, msn_stream_t stream) {
     MSN_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && rows > 0 && C > 0,
                 "msn_batchnorm_bwd: bad arguments");
     MSN_REQUIRE(ws && ws_bytes >= msn_bn_workspace_bytes(rows, C), "msn_batchnorm_bwd: workspace too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* part = static_cast<float*>(ws);
     const int nb = red_blocks(rows);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, (unsigned)cdiv(C, RED_CP)), dim3(256), 0, st, dy, x, mean, rstd,
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, (unsigned)cdiv(C, RED_CP)), dim3(256), 0, st, dy, ymask, x, mean, rstd,
                        rows, C, part);
     hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((unsigned)cdiv(C, 64)), dim3(1024), 0, st, part, nb, C, dbeta, dgamma);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * C)), dim3(256), 0, st, dy, x, pre, mean, rstd, gamma,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * C)), dim3(256), 0, st, dy, ymask, x, pre, mean, rstd, gamma,
                        dbeta, dgamma, rows, rows, C, training, dx);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
+}
+extern "C" int msn_batchnorm_bwd(const float* dy, const float* x, const float* pre, int64_t rows, int C,
+                                 const float* mean, const float* rstd, const float* gamma, int training, float* dx,
+                                 float* dgamma, float* dbeta, void* ws, size_t ws_bytes, msn_stream_t stream) {
+    return batchnorm_bwd_impl(dy, nullptr, x, pre, rows, C, mean, rstd, gamma, training, dx, dgamma, dbeta, ws, ws_bytes, stream);
+}
+// BatchNorm followed by ReLU: y = relu(bn(x)) was saved; the gradient dy is masked by y > 0 inside both passes (no
+// separate masking pass, no masked copy of dy)
+extern "C" int msn_batchnorm_relu_bwd(const float* dy, const float* y, const float* x, int64_t rows, int C,
+                                      const float* mean, const float* rstd, const float* gamma, int training, float* dx,
+                                      float* dgamma, float* dbeta, void* ws, size_t ws_bytes, msn_stream_t stream) {
+    MSN_REQUIRE(y, "msn_batchnorm_relu_bwd: null output");
+    return batchnorm_bwd_impl(dy, y, x, nullptr, rows, C, mean, rstd, gamma, training, dx, dgamma, dbeta, ws, ws_bytes, stream);
 }
 
 // ---- synchronised (data-parallel) BatchNorm: the same two-pass statistics cut at the points where the caller
@@ -469,7 +486,7 @@ extern "C" int msn_bn_bwd_sums(const float* dy, const float* x, int64_t rows, in
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* part = static_cast<float*>(ws);
     const int nb = red_blocks(rows);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, (unsigned)cdiv(C, RED_CP)), dim3(256), 0, st, dy, x, mean, rstd,
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, (unsigned)cdiv(C, RED_CP)), dim3(256), 0, st, dy, (const float*)nullptr, x, mean, rstd,
                        rows, C, part);
     hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((unsigned)cdiv(C, 64)), dim3(1024), 0, st, part, nb, C, sums, sums + C);
     MSN_LAUNCH_CHECK();
@@ -481,8 +498,8 @@ extern "C" int msn_bn_bwd_apply(const float* dy, const float* x, const float* da
                                 msn_stream_t stream) {
     MSN_REQUIRE(dy && x && mean && rstd && gamma && sums && dx && rows > 0 && count >= rows && C > 0,
                 "msn_bn_bwd_apply: bad arguments");
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * C)), dim3(256), 0, static_cast<hipStream_t>(stream), dy, x,
-                       dact, mean, rstd, gamma, sums, sums + C, rows, count, C, 1, dx);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * C)), dim3(256), 0, static_cast<hipStream_t>(stream), dy,
+                       (const float*)nullptr, x, dact, mean, rstd, gamma, sums, sums + C, rows, count, C, 1, dx);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }

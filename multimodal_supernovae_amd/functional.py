@@ -895,9 +895,10 @@ class _BatchNormAct(torch.autograd.Function):
         training, relu, has_res, shape = ctx.cfg
         x2, gamma, mean, rstd, y = ctx.saved_tensors
         d = _c(dy).view(-1, shape[-1])
-        if relu:
+        fused_mask = relu and not has_res and not (training and ops._bn_sync_world() > 1)
+        if relu and not fused_mask:       # the masked gradient is also the residual branch's gradient / the all-reduced sums' input
             d = ops.relu_mask(d, y)
-        dx, dg, db = ops.batchnorm_bwd(d, x2, None, mean, rstd, gamma, training)
+        dx, dg, db = ops.batchnorm_bwd(d, x2, None, mean, rstd, gamma, training, relu_out=y.view(-1, shape[-1]) if fused_mask else None)
         return dx.view(shape), dg, db, None, None, None, (d.view(shape) if has_res else None), None
 
 

@@ -388,7 +388,9 @@ def batchnorm_fwd(x, gamma, beta, running_mean, running_var, training, residual=
     return y, mean, rstd
 
 
-def batchnorm_bwd(dy, x, pre, mean, rstd, gamma, training):
+def batchnorm_bwd(dy, x, pre, mean, rstd, gamma, training, relu_out=None):
+    """relu_out: the saved output of a BatchNorm + ReLU -- dy is masked by relu_out > 0 inside the backward passes
+    (single-process statistics; under synchronised BatchNorm the caller masks dy first)."""
     rows, C = x.shape
     dev = x.device
     dx = torch.empty_like(x)
@@ -409,6 +411,12 @@ def batchnorm_bwd(dy, x, pre, mean, rstd, gamma, training):
         return dx, sums[C:], sums[:C]
     dg = torch.empty(C, dtype=torch.float32, device=dev)
     db = torch.empty(C, dtype=torch.float32, device=dev)
+    if relu_out is not None:
+        assert pre is None
+        check(L.msn_batchnorm_relu_bwd(ptr(_f32c(dy, "dy")), ptr(_f32c(relu_out, "relu_out")), ptr(x), rows, C, ptr(mean), ptr(rstd),
+                                       ptr(gamma), 1 if training else 0, ptr(dx), ptr(dg), ptr(db), ptr(ws), nb, stream_ptr()),
+              "msn_batchnorm_relu_bwd")
+        return dx, dg, db
     check(L.msn_batchnorm_bwd(ptr(_f32c(dy, "dy")), ptr(x), ptr(pre), rows, C, ptr(mean), ptr(rstd), ptr(gamma),
                               1 if training else 0, ptr(dx), ptr(dg), ptr(db), ptr(ws), nb, stream_ptr()),
           "msn_batchnorm_bwd")
