@@ -107,3 +107,22 @@ def test_trainer_moves_the_nine_tuple_and_drops_empty_placeholders():
              torch.empty(0), torch.empty(0), torch.zeros(2), None)
     out = _to_device(batch, "cpu")
     assert len(out) == 9 and out[0] is None and out[4] is None and out[8] is None and out[3].dtype == torch.bool
+
+
+def test_convolution_plan_queries_without_a_gpu():
+    """Which convolutions the implicit-GEMM kernels take, and their workspace, are host-side decisions (no launch)."""
+    from multimodal_supernovae_amd import _lib
+    L = _lib.lib()
+    ok = lambda *g: bool(L.msn_conv2d_implicit_ok(*g))
+    # (B, H, W, C, C_out, kh, kw, sh, sw, ph, pw)
+    assert ok(1024, 16, 16, 64, 64, 3, 3, 1, 1, 1, 1)          # ResNet-18 layer1
+    assert ok(1024, 16, 16, 64, 128, 3, 3, 2, 2, 1, 1)         # strided entry of layer2
+    assert ok(1024, 1, 200, 64, 128, 1, 5, 1, 1, 0, 2)         # 1-D CNN layer 2
+    assert not ok(1024, 64, 64, 4, 64, 7, 7, 2, 2, 3, 3)       # the stem: 4 channels, several taps per K-step
+    assert not ok(1024, 16, 16, 64, 32, 3, 3, 1, 1, 1, 1)      # 32-wide output: narrower than the kernels' tiles
+    assert not ok(3, 5, 5, 64, 64, 3, 3, 1, 1, 1, 1)           # 75 output pixels: not whole K-steps for the weight gradient
+    assert not ok(1, 1024, 1024, 64, 64, 3, 3, 1, 1, 1, 1)     # images beyond 512 x 512
+    assert L.msn_conv2d_workspace_bytes(1024, 16, 16, 64, 64, 3, 3, 1, 1, 1, 1) > 0      # split-K slabs of the weight gradient
+    assert L.msn_conv2d_workspace_bytes(3, 5, 5, 64, 64, 3, 3, 1, 1, 1, 1) == 0
+    # weight gradients with few rows are planned on short tiles; the workspace query answers for the same plan
+    assert L.msn_wgrad_bias_workspace_bytes(32, 128, 225280) > 0 and L.msn_sgemm_workspace_bytes(1, 0, 32, 128, 225280) > 0
