@@ -337,11 +337,13 @@ def main():
     opt = model.configure_optimizers()["optimizer"]
     reducer = D.GradientReducer(model.parameters())   # N > 1: bucketed SUM all-reduce launched from autograd hooks, under backward
 
+    from multimodal_supernovae_amd.trainer import _backward_seed
+
     def make_step(model, opt, reducer, batch):
         def step():
             opt.zero_grad(set_to_none=True)
             loss = model.training_step(batch, 0)
-            loss.backward()
+            loss.backward(_backward_seed(loss))      # the cached seed the Trainer uses (no fill launch per step)
             reducer.finish()
             opt.step()
             return loss

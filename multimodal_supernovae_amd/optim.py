@@ -17,6 +17,26 @@ class RAdam(torch.optim.Optimizer):
             raise ValueError("invalid RAdam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
+    def _init_state(self):
+        """Moment buffers of every parameter that has a gradient and no state yet, as views of ONE zeroed buffer per
+        device (one fill launch instead of two per parameter; the step's launch reads them through the pointer table)."""
+        fresh = {}
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is not None and len(self.state[p]) == 0 and p.device.type == "cuda" and p.dtype == torch.float32:
+                    fresh.setdefault(p.device, []).append(p)
+        for dev, ps in fresh.items():
+            n = sum((p.numel() + 3) // 4 * 4 for p in ps)            # 16-byte aligned slices
+            flat = torch.zeros(2 * n, dtype=torch.float32, device=dev)
+            off = 0
+            for p in ps:
+                m = p.numel()
+                st = self.state[p]
+                st["step"] = 0
+                st["exp_avg"] = flat[off:off + m].view(p.shape)
+                st["exp_avg_sq"] = flat[n + off:n + off + m].view(p.shape)
+                off += (m + 3) // 4 * 4
+
     def _staging(self, n):
         """Two pinned buffers used alternately; a buffer is rewritten only after the copy that last read it
         has completed (its event), so the host may run a whole step ahead of the GPU."""
@@ -129,6 +149,7 @@ class RAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self._init_state()
         for group in self.param_groups:
             # parameters of one group that share a step count go into one launch
             buckets = {}

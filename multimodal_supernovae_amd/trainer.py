@@ -65,6 +65,17 @@ def _hook(model, name):
         fn()
 
 
+_SEEDS = {}
+
+
+def _backward_seed(loss):
+    """d loss / d loss = 1 as a cached device tensor (autograd would launch a fill for it every step)."""
+    key = (loss.device, loss.dtype, tuple(loss.shape))
+    if key not in _SEEDS:
+        _SEEDS[key] = torch.ones(loss.shape, dtype=loss.dtype, device=loss.device)
+    return _SEEDS[key]
+
+
 class Trainer:
     def __init__(self, max_epochs=1, device=None, group=None, log_fn=None, sync_batchnorm=False, graphed_steps=False):
         self.max_epochs = max_epochs
@@ -103,7 +114,7 @@ class Trainer:
                     continue
                 optimizer.zero_grad(set_to_none=True)
                 loss = model.training_step(batch, batch_idx)
-                loss.backward()
+                loss.backward(_backward_seed(loss))
                 reducer.finish()
                 optimizer.step()
                 losses.append(loss.detach())
