@@ -1221,8 +1221,8 @@ static int sgemm_impl(int opA, int opB, int64_t M, int64_t N, int64_t K, const f
         if (bn == 128) rc = launch_dma_conv<128, 128, 64, 64, 32, 2>(a, conv, opB, st);
         else rc = launch_dma_conv<128, 64, 64, 32, 32, 3>(a, conv, opB, st);
     } else if (bf16_ok) rc = launch_bgemm(a, opA, opB, precision == MSN_PREC_BF16X3 ? 2 : 1, bm, bn, st);
-    else if (bm == 32) rc = dma_ok ? launch_dma<32, 128, 32, 32, 32, 2>(a, opA, opB, st) : launch_cfg<32, 128, 32, 32>(a, opA, opB, st);
-    else if (bm == 64) rc = dma_ok ? launch_dma<64, 128, 32, 64, 32, 2>(a, opA, opB, st) : launch_cfg<64, 128, 32, 64>(a, opA, opB, st);
+    else if (bm == 32 && dma_ok) rc = launch_dma<32, 128, 32, 32, 32, 2>(a, opA, opB, st);
+    else if (bm == 64 && dma_ok) rc = launch_dma<64, 128, 32, 64, 32, 2>(a, opA, opB, st);   // (not dma_ok: the 128-row kernels below; M <= 64 is one row of tiles either way)
     else if (dma_ok && bn == 128 && K % 64 == 0 && kps % 64 == 0 && g_gemm_variant == 2)
         rc = launch_dma<128, 128, 64, 32, 64, 2>(a, opA, opB, st), waves = 8;
     else if (dma_ok && bn == 128 && g_gemm_variant == 4) rc = launch_pw<128, 128, 64, 64, 32, 2>(a, opA, opB, st);
