@@ -19,253 +19,6 @@
 
 namespace msn {
 
-// Load 4 consecutive elements (r, c..c+3) of a stored row-major matrix from an address CLAMPED into
-// the matrix; `ok` bit j says whether element j is really inside [nr, nc).  Branch-free and with the
-// zero-masking deferred to the LDS write (OperandTile::stash), so that a K-step's loads issue back to
-// back, stay in flight across the MFMA block of the previous K-step, and are waited for only when
-// they are written to LDS.  (A guarded `if (in range) load`, or even a wave-uniform runtime
-// `if (aligned)`, makes hipcc wait vmcnt(0) after every load; masking right after the load makes it
-// wait before the MFMAs.)  VEC is chosen on the host: base 16-B aligned, ld % 4 == 0 and the
-// contiguous extent % 4 == 0, so a vector never straddles nc; otherwise the scalar instantiation runs.
-template <bool VEC>
-__device__ __forceinline__ float4 load4_clamped(const float* __restrict__ base, int64_t r, int64_t c, int64_t ld,
-                                                int64_t nr, int64_t nc, unsigned& ok) {
-    const bool in_r = r < nr;
-    const float* row = base + (in_r ? r : nr - 1) * ld;
-    float4 v;
-    if (VEC) {
-        const bool in = in_r && c < nc;
-        v = *reinterpret_cast<const float4*>(row + (c < nc ? c : 0));
-        ok = in ? 0xFu : 0u;
-    } else {
-        const int64_t last = nc - 1;
-        v.x = row[c < nc ? c : last];
-        v.y = row[c + 1 < nc ? c + 1 : last];
-        v.z = row[c + 2 < nc ? c + 2 : last];
-        v.w = row[c + 3 < nc ? c + 3 : last];
-        ok = in_r ? ((c < nc ? 1u : 0u) | (c + 1 < nc ? 2u : 0u) | (c + 2 < nc ? 4u : 0u) | (c + 3 < nc ? 8u : 0u)) : 0u;
-    }
-    return v;
-}
-
-template <int ROWS, bool KMAJOR>
-struct OperandTile {
-    // K-contiguous: [ROWS][BK + KPAD];  K-major: [BK][ROWS + KPAD]
-    static constexpr int kStride = KMAJOR ? (ROWS + KPAD) : (BK + KPAD);
-    static constexpr int kFloats = KMAJOR ? BK * (ROWS + KPAD) : ROWS * (BK + KPAD);
-    static constexpr int kLoads = ROWS / 32;  // float4 per thread per K-step (256 threads)
-
-    // row0: first row (M or N index) of this tile; k0: first k.  `nrows` = M or N, `nk` = K limit.
-    // ok: 4 validity bits per load, consumed by stash().
-    template <bool VEC>
-    __device__ static __forceinline__ void fetch(float4 (&reg)[kLoads], unsigned& ok, const float* __restrict__ g,
-                                                 int64_t ld, int64_t row0, int64_t nrows, int64_t k0, int64_t nk) {
-        const int t = threadIdx.x;
-        ok = 0u;
-#pragma unroll
-        for (int i = 0; i < kLoads; ++i) {
-            const int idx = t + 256 * i;
-            unsigned m;
-            if (KMAJOR) {  // stored [K][rows]: 4 consecutive rows of one k
-                const int k = idx / (ROWS / 4), q = idx % (ROWS / 4);
-                reg[i] = load4_clamped<VEC>(g, k0 + k, row0 + 4 * q, ld, nk, nrows, m);
-            } else {  // stored [rows][K]: 4 consecutive k of one row
-                const int r = idx / (BK / 4), q = idx % (BK / 4);
-                reg[i] = load4_clamped<VEC>(g, row0 + r, k0 + 4 * q, ld, nrows, nk, m);
-            }
-            ok |= m << (4 * i);
-        }
-    }
-    __device__ static __forceinline__ void stash(const float4 (&reg)[kLoads], unsigned ok, float* lds) {
-        const int t = threadIdx.x;
-#pragma unroll
-        for (int i = 0; i < kLoads; ++i) {
-            const int idx = t + 256 * i;
-            const unsigned m = ok >> (4 * i);
-            float4 v = reg[i];
-            v.x = (m & 1u) ? v.x : 0.f;
-            v.y = (m & 2u) ? v.y : 0.f;
-            v.z = (m & 4u) ? v.z : 0.f;
-            v.w = (m & 8u) ? v.w : 0.f;
-            if (KMAJOR) {
-                const int k = idx / (ROWS / 4), q = idx % (ROWS / 4);
-                *reinterpret_cast<float4*>(lds + k * kStride + 4 * q) = v;
-            } else {
-                const int r = idx / (BK / 4), q = idx % (BK / 4);
-                *reinterpret_cast<float4*>(lds + r * kStride + 4 * q) = v;
-            }
-        }
-    }
-    // ---- fast path (VEC kernels, K-steps that lie completely inside [k_begin, k_end)) ----------------
-    // Per-thread source pointers are computed ONCE: rows / columns beyond the matrix are clamped onto
-    // valid ones (whatever they load only feeds output elements that are never stored), so a full
-    // K-step needs no masks and no address arithmetic beyond one add.
-    __device__ static __forceinline__ void init_ptrs(const float* (&ptr)[kLoads], const float* __restrict__ g,
-                                                     int64_t ld, int64_t row0, int64_t nrows, int64_t k_begin) {
-        const int t = threadIdx.x;
-#pragma unroll
-        for (int i = 0; i < kLoads; ++i) {
-            const int idx = t + 256 * i;
-            if (KMAJOR) {
-                const int k = idx / (ROWS / 4), q = idx % (ROWS / 4);
-                int64_t c = row0 + 4 * q;
-                c = c + 3 < nrows ? c : nrows - 4;
-                ptr[i] = g + (k_begin + k) * ld + c;
-            } else {
-                const int r = idx / (BK / 4), q = idx % (BK / 4);
-                int64_t rr = row0 + r;
-                rr = rr < nrows ? rr : nrows - 1;
-                ptr[i] = g + rr * ld + k_begin + 4 * q;
-            }
-        }
-    }
-    __device__ static __forceinline__ void fetch_fast(float4 (&reg)[kLoads], const float* const (&ptr)[kLoads],
-                                                      int64_t step_offset) {
-#pragma unroll
-        for (int i = 0; i < kLoads; ++i) reg[i] = *reinterpret_cast<const float4*>(ptr[i] + step_offset);
-    }
-    __device__ static __forceinline__ void stash_fast(const float4 (&reg)[kLoads], float* lds) {
-        const int t = threadIdx.x;
-#pragma unroll
-        for (int i = 0; i < kLoads; ++i) {
-            const int idx = t + 256 * i;
-            if (KMAJOR) {
-                const int k = idx / (ROWS / 4), q = idx % (ROWS / 4);
-                *reinterpret_cast<float4*>(lds + k * kStride + 4 * q) = reg[i];
-            } else {
-                const int r = idx / (BK / 4), q = idx % (BK / 4);
-                *reinterpret_cast<float4*>(lds + r * kStride + 4 * q) = reg[i];
-            }
-        }
-    }
-    // Fragment for one 32-row MFMA slab and one k-octet `ko`: f.{x,y,z,w} = element k = 8ko+4h+{0..3}.
-    __device__ static __forceinline__ float4 frag(const float* lds, int row_in_tile, int ko, int h) {
-        if (KMAJOR) {
-            const float* p = lds + (8 * ko + 4 * h) * kStride + row_in_tile;
-            return make_float4(p[0], p[kStride], p[2 * kStride], p[3 * kStride]);
-        } else {
-            return *reinterpret_cast<const float4*>(lds + row_in_tile * kStride + 8 * ko + 4 * h);
-        }
-    }
-};
-
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, bool VEC>
-__global__ __launch_bounds__(256) void sgemm_kernel(const GemmArgs p) {
-    using TA = OperandTile<BM, AKM>;
-    using TB = OperandTile<BN, BKM>;
-    constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int WAVES_N = BN / WN;
-    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
-
-    __shared__ __attribute__((aligned(16))) float smem[2 * (TA::kFloats + TB::kFloats)];
-    auto a_buf = [&](int i) { return smem + i * TA::kFloats; };
-    auto b_buf = [&](int i) { return smem + 2 * TA::kFloats + i * TB::kFloats; };
-
-    const TileCoord tc = locate_tile(p);
-    const int logical = tc.logical;
-    const int tile_m = logical / p.tiles_n, tile_n = logical % p.tiles_n;
-    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
-    const int split = tc.split;
-    const int64_t k_begin = tc.k_begin, k_end = tc.k_end;
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int h = lane >> 5, l32 = lane & 31;
-    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    float4 ra[TA::kLoads], rb[TB::kLoads];
-    unsigned oka = 0u, okb = 0u;
-    const int nkt = (int)((k_end - k_begin + BK - 1) / BK);
-    const int nfull = VEC ? (int)((k_end - k_begin) / BK) : 0;   // K-steps that need no bounds handling
-    const float* pa[TA::kLoads];
-    const float* pb[TB::kLoads];
-    if (VEC) {
-        // VEC guarantees M (or K) % 4 == 0 etc., but a K-major operand narrower than one vector cannot be clamped
-        TA::init_ptrs(pa, p.A, p.lda, m0, p.M, k_begin);
-        TB::init_ptrs(pb, p.B, p.ldb, n0, p.N, k_begin);
-    }
-    const int64_t a_step = AKM ? (int64_t)BK * p.lda : BK, b_step = BKM ? (int64_t)BK * p.ldb : BK;
-    auto fetch_step = [&](int kt) {   // global -> registers for K-step kt
-        if (kt < nfull) {
-            TA::fetch_fast(ra, pa, kt * a_step);
-            TB::fetch_fast(rb, pb, kt * b_step);
-        } else {
-            const int64_t k0 = k_begin + (int64_t)kt * BK;
-            TA::template fetch<VEC>(ra, oka, p.A, p.lda, m0, p.M, k0, k_end);
-            TB::template fetch<VEC>(rb, okb, p.B, p.ldb, n0, p.N, k0, k_end);
-        }
-    };
-    auto stash_step = [&](int kt, int buf) {   // registers -> LDS buffer `buf`
-        if (kt < nfull) {
-            TA::stash_fast(ra, a_buf(buf));
-            TB::stash_fast(rb, b_buf(buf));
-        } else {
-            TA::stash(ra, oka, a_buf(buf));
-            TB::stash(rb, okb, b_buf(buf));
-        }
-    };
-    if (nkt > 0) {
-        fetch_step(0);
-        stash_step(0, 0);
-    }
-    __syncthreads();
-
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nkt;
-#ifndef MSN_ABL_NOFETCH
-        if (more) fetch_step(kt + 1);   // prefetch the next K-step into registers while this one is multiplied
-#endif
-        const float* as = a_buf(cur);
-        const float* bs = b_buf(cur);
-#ifdef MSN_ABL_NOFRAG
-        float4 fa[TM], fb[TN];
-        if (kt == 0) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = TA::frag(as, wm0 + 32 * i + l32, 0, h);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = TB::frag(bs, wn0 + 32 * j + l32, 0, h);
-        }
-#endif
-#pragma unroll
-        for (int ko = 0; ko < BK / 8; ++ko) {
-#ifndef MSN_ABL_NOFRAG
-            float4 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = TA::frag(as, wm0 + 32 * i + l32, ko, h);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = TB::frag(bs, wn0 + 32 * j + l32, ko, h);
-#endif
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
-                }
-        }
-#ifndef MSN_ABL_NOSTASH
-        if (more) stash_step(kt + 1, cur ^ 1);
-#endif
-#ifndef MSN_ABL_NOBAR
-        __syncthreads();
-#endif
-    }
-
-    if (BN == 128 && tc.tail_slab >= 0)   // tails are only planned for 128 x 128 tiles
-        finish_tail<TM, TN>(acc, p, tc, wave, 4, lane, m0, n0, wm0, wn0, reinterpret_cast<unsigned*>(smem));
-    else gemm_epilogue<TM, TN>(acc, p, m0, n0, wm0, wn0, l32, h, split);
-}
-
 // ------------------------------------------------------------------------------------------------
 // LDS-DMA variant (the default whenever it applies): operand tiles go HBM -> LDS directly with
 // global_load_lds_dwordx4 (no staging registers, no VALU, no ds_write), through a STAGES-deep ring so the
@@ -279,65 +32,6 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmArgs p) {
 // Waits are counted (each wave leaves the youngest stage in flight) and the barrier is a raw s_barrier: a
 // __syncthreads() would drain the DMA queue.  Needs: 16-B aligned operands, ld % 4 == 0, extents % 4 == 0,
 // and K-ranges that are whole K-steps (K % 32 == 0); anything else takes the register-staged kernel.
-typedef __attribute__((address_space(1))) const void gptr_t;
-typedef __attribute__((address_space(3))) void lptr_t;
-
-template <int ROWS, bool KMAJOR, int DBK>
-struct DmaTile {
-    static constexpr int kFloats = ROWS * DBK;            // unpadded image
-    static constexpr int kPieces = ROWS * DBK / 256;      // 1-KB LDS-DMA pieces per K-step
-    static constexpr int CPR = DBK / 4;                   // 16-byte chunks per row of a K-contiguous image
-    static constexpr int RPB = DBK >= 64 ? 1 : 64 / DBK;  // rows of a K-contiguous image per 256-B bank row
-    // XOR swizzle of a row's chunk positions.  ds_read_b128 serves 16 lanes (16 different rows, same logical chunk)
-    // per LDS cycle; they must land on 16 different 16-B slots of the bank row.  Rows r and r' share a slot range
-    // when r % RPB == r' % RPB, so the swizzle key must differ between them: (r / RPB) % CPR does for every row set
-    // {0-3, 12-15, 20-27} + 4j + 32h the instruction groups (MI355X_MICROARCH.md, LDS).
-    __device__ static __forceinline__ int swz(int r) { return (r / RPB) % CPR; }
-    // source address of this lane for piece q of the K-step starting at k0
-    __device__ static __forceinline__ const float* src(const float* __restrict__ g, int64_t ld, int64_t row0,
-                                                       int64_t nrows, int64_t k0, int q, int lane) {
-        if (KMAJOR) {   // image [k][ROWS]: piece = 256 / ROWS consecutive k-rows
-            constexpr int LPR = ROWS / 4;                                  // lanes per k-row
-            const int kk = q * (64 / LPR) + lane / LPR;
-            int64_t c = row0 + 4 * (lane % LPR);
-            c = c + 3 < nrows ? c : nrows - 4;
-            return g + (k0 + kk) * ld + c;
-        } else {        // image [ROWS][DBK]: piece = 64 / CPR rows; chunk c of row r sits at position c ^ swz(r)
-            const int r = q * (64 / CPR) + lane / CPR, pos = lane % CPR;
-            int64_t rr = row0 + r;
-            rr = rr < nrows ? rr : nrows - 1;
-            return g + rr * ld + k0 + 4 * (pos ^ swz(r));
-        }
-    }
-    // LDS reads are issued from inline asm: hipcc's waitcnt pass cannot prove that a ds_read does not alias an
-    // LDS-DMA write still in flight and would put s_waitcnt vmcnt(0) in front of every k-step's first read
-    // (draining the whole ring); an asm read is invisible to that pass, so its completion is counted by hand
-    // (lgkmcnt) in the kernel.  `tile_addr` = LDS byte address of the image.
-    // A fragment = this lane's 4 consecutive k values of one row.  The asm outputs bind straight to the registers
-    // the MFMAs read (no copy may sit between the asynchronous read and the hand-placed s_waitcnt).
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    struct FragKM { f32x2 lo, hi; };
-    struct FragKC { float4 v; };
-    using Frag = std::conditional_t<KMAJOR, FragKM, FragKC>;
-    template <int C>
-    __device__ static __forceinline__ float get(const Frag& f) {
-        if constexpr (KMAJOR) return C == 0 ? f.lo.x : C == 1 ? f.lo.y : C == 2 ? f.hi.x : f.hi.y;
-        else return C == 0 ? f.v.x : C == 1 ? f.v.y : C == 2 ? f.v.z : f.v.w;
-    }
-    static constexpr int kReads = KMAJOR ? 2 : 1;   // LDS instructions per fragment
-    __device__ static __forceinline__ void frag_issue(Frag& f, unsigned tile_addr, int row, int ko, int h) {
-        if constexpr (KMAJOR) {   // k, k+1 | k+2, k+3 of this lane half: two ds_read2_b32 (dword offsets 0, ROWS)
-            static_assert(ROWS <= 255, "ds_read2_b32 offset1 is 8 bits (dwords)");
-            const unsigned a = tile_addr + 4u * ((8 * ko + 4 * h) * ROWS + row);
-            asm volatile("ds_read2_b32 %0, %1 offset1:%2" : "=v"(f.lo) : "v"(a), "n"(ROWS));
-            asm volatile("ds_read2_b32 %0, %1 offset1:%2" : "=v"(f.hi) : "v"(a + 8u * ROWS), "n"(ROWS));
-        } else {
-            const unsigned a = tile_addr + 4u * (row * DBK + 4 * ((2 * ko + h) ^ swz(row)));
-            asm volatile("ds_read_b128 %0, %1" : "=v"(f.v) : "v"(a));
-        }
-    }
-};
-
 // CONV = 1: the A operand (K-contiguous rows) is an implicit column matrix (convolution forward / dgrad);
 // CONV = 2: the B operand (K-major) is (convolution wgrad).  See ConvGather.
 template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int DBK, int STAGES, bool CSUM = false, int CONV = 0>
@@ -599,183 +293,6 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM / WM) * (BN / WN) =
 #endif
 }
 
-// ------------------------------------------------------------------------------------------------
-// Loader-wave variant: persistent workgroups of SIX waves.  Waves 0-3 multiply exactly as above; waves 4 and 5 do
-// nothing but issue the LDS-DMA loads of the ring (A pieces / B pieces), for the workgroup's whole sequence of
-// (tile, K-step) items, running ahead across tile boundaries.  Why a wave of its own: epilogue stores and LDS-DMA loads of one wave share vmcnt and may
-// complete out of order with respect to each other, so a wave that does both has to drain its stores before it can
-// know that the next tile's first K-step has landed -- the prologue comes back as a store drain (round 1 measured a
-// persistent kernel built that way equal to the one-tile launch).  Here the multiplying waves never wait on vmcnt for
-// operands: their stores of tile j drain under the K-steps of tile j + 1, whose data the loader has already
-// brought in.  One raw s_barrier per K-step (all five waves), placed as above: the multiplying waves arrive when
-// their fragment reads of the step have returned (its slot is free), the loader when the NEXT step has landed.
-// Work items (tiles, split-K slabs, tail slabs) are walked w = blockIdx.x, + gridDim.x, ... (a multiple of 8: the
-// workgroup stays on its XCD's run of tiles).  Tail slabs are summed by the finishing launch.
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int DBK, int STAGES, bool CSUM = false>
-__global__ __launch_bounds__(64 * ((BM / WM) * (BN / WN) + 2), 3) void sgemm_pw_kernel(const GemmArgs p) {
-    static_assert(!CSUM || AKM, "the fused column sums are those of a K-major A operand (wgrad: A = dY)");
-    using TA = DmaTile<BM, AKM, DBK>;
-    using TB = DmaTile<BN, BKM, DBK>;
-    constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int WAVES_N = BN / WN, NWAVES = (BM / WM) * (BN / WN);
-    constexpr int STAGE = TA::kFloats + TB::kFloats;
-    constexpr int PAT = TA::kPieces, PBT = TB::kPieces;   // LDS-DMA pieces per K-step: A by loader wave 0, B by loader wave 1
-    static_assert((STAGES - 1) * PAT <= 63 && (STAGES - 1) * PBT <= 63, "vmcnt is 6 bits");
-    constexpr int NKO = DBK / 8;
-    __shared__ __attribute__((aligned(16))) float smem[STAGES * STAGE];
-    const unsigned smem_addr = (unsigned)(uintptr_t)(lptr_t*)smem;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nwork = work_items(p);
-    if (wave >= NWAVES) {   // ------------------------------------------------------------------ the two loader waves
-        __builtin_amdgcn_s_setprio(3);   // their few instructions go ahead of the multiplying waves on the same SIMD
-        const bool is_b = wave > NWAVES;
-        constexpr int PT = PAT > PBT ? PAT : PBT;
-        const int np = is_b ? PBT : PAT;
-        const int64_t step = is_b ? (BKM ? (int64_t)DBK * p.ldb : DBK) : (AKM ? (int64_t)DBK * p.lda : DBK);
-        int total = 0;      // K-steps of this workgroup's items
-        for (int w = blockIdx.x; w < nwork; w += gridDim.x) {
-            const TileCoord t = locate_tile(p, w);
-            total += (int)((t.k_end - t.k_begin) / DBK);
-        }
-        const float* src[PT];
-        int w_i = blockIdx.x, kt_i = 0, nkt_i = 0, issued = 0;
-        auto setup = [&]() {
-            const TileCoord t = locate_tile(p, w_i);
-            const int64_t m0 = (int64_t)(t.logical / p.tiles_n) * BM, n0 = (int64_t)(t.logical % p.tiles_n) * BN;
-            if (is_b) {
-#pragma unroll
-                for (int q = 0; q < PBT; ++q) src[q] = TB::src(p.B, p.ldb, n0, p.N, t.k_begin, q, lane);
-            } else {
-#pragma unroll
-                for (int q = 0; q < PAT; ++q) src[q] = TA::src(p.A, p.lda, m0, p.M, t.k_begin, q, lane);
-            }
-            nkt_i = (int)((t.k_end - t.k_begin) / DBK);
-            kt_i = 0;
-        };
-        auto issue_next = [&]() {   // the next K-step of the item sequence into ring slot issued % STAGES
-            if (issued >= total) return;
-            while (kt_i == nkt_i) {   // next item (one without K-steps is skipped by both sides)
-                w_i += gridDim.x;
-                setup();
-            }
-            float* base = smem + (issued % STAGES) * STAGE + (is_b ? TA::kFloats : 0);
-#pragma unroll
-            for (int q = 0; q < PT; ++q)
-                if (q < np) {
-                    __builtin_amdgcn_global_load_lds((gptr_t*)src[q], (lptr_t*)(base + q * 256), 16, 0, 0);
-                    src[q] += step;
-                }
-            ++kt_i, ++issued;
-        };
-        if (total > 0) setup();
-#pragma unroll
-        for (int s = 0; s < STAGES; ++s) issue_next();
-        // `n` younger K-steps may stay in flight (n <= STAGES - 1; immediate operands only: PAT == PBT is the common case)
-        auto wait_younger = [&](int n) {
-            if (PAT == PBT && STAGES > 2 && n >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PAT <= 63 ? 2 * PAT : 0) : "memory");
-            else if (PAT == PBT && n >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PAT) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        };
-        wait_younger(issued - 1);                  // K-step 0 has landed
-        __builtin_amdgcn_s_barrier();
-        for (int g = 0; g < total; ++g) {
-            if (g + 1 < total) wait_younger(issued - (g + 2));   // K-step g + 1 has landed
-            __builtin_amdgcn_s_barrier();                          // ... and slot g % STAGES has been read by every wave
-            issue_next();
-        }
-        return;
-    }
-
-    // ------------------------------------------------------------------------------ the multiplying waves
-    const int h = lane >> 5, l32 = lane & 31;
-    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-    constexpr int NREADS = TM * TA::kReads + TN * TB::kReads;
-    static_assert(NKO % 2 == 0, "k-octets are processed in pairs");
-    typename TA::Frag fa[2][TM];
-    typename TB::Frag fb[2][TN];
-    f32x16 acc[TM][TN];
-    float csum[TM];
-    auto request = [&](auto set, int slot, int ko) {
-        constexpr int S = decltype(set)::value;
-        const unsigned as = smem_addr + 4u * (slot * STAGE);
-        const unsigned bs = as + 4u * TA::kFloats;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) TA::frag_issue(fa[S][i], as, wm0 + 32 * i + l32, ko, h);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) TB::frag_issue(fb[S][j], bs, wn0 + 32 * j + l32, ko, h);
-    };
-    auto multiply = [&](auto set, bool younger_in_flight) {
-        constexpr int S = decltype(set)::value;
-        if (younger_in_flight) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NREADS) : "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (CSUM) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                csum[i] += (TA::template get<0>(fa[S][i]) + TA::template get<1>(fa[S][i])) +
-                           (TA::template get<2>(fa[S][i]) + TA::template get<3>(fa[S][i]));
-        }
-#define MSN_MFMA_SWEEP(C)                                                                                        \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)                 \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(TA::template get<C>(fa[S][i]), TB::template get<C>(fb[S][j]), \
-                                                         acc[i][j], 0, 0, 0);
-        MSN_MFMA_SWEEP(0) MSN_MFMA_SWEEP(1) MSN_MFMA_SWEEP(2) MSN_MFMA_SWEEP(3)
-#undef MSN_MFMA_SWEEP
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    int slot = 0;
-    __builtin_amdgcn_s_barrier();                  // K-step 0 of the first item has landed
-    for (int w = blockIdx.x; w < nwork; w += gridDim.x) {
-        const TileCoord tc = locate_tile(p, w);
-        const int logical = tc.logical;
-        const int64_t m0 = (int64_t)(logical / p.tiles_n) * BM, n0 = (int64_t)(logical % p.tiles_n) * BN;
-        const int nkt = (int)((tc.k_end - tc.k_begin) / DBK);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            csum[i] = 0.f;
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        }
-        if (nkt > 0) request(S0{}, slot, 0);
-        for (int kt = 0; kt < nkt; ++kt) {
-            const int next_slot = slot + 1 == STAGES ? 0 : slot + 1;
-#pragma unroll
-            for (int ko = 0; ko < NKO; ko += 2) {
-                request(S1{}, slot, ko + 1);
-                multiply(S0{}, true);
-                if (ko + 2 < NKO) {
-                    request(S0{}, slot, ko + 2);
-                    multiply(S1{}, true);
-                } else {
-                    const bool has_next = kt + 1 < nkt;
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all fragment reads of this K-step are in
-                    __builtin_amdgcn_s_barrier();                         // next K-step landed (loader), this slot is free
-                    if (has_next) request(S0{}, next_slot, 0);
-                    multiply(S1{}, has_next);
-                }
-            }
-            slot = next_slot;
-        }
-        if constexpr (CSUM) {
-            if (wn0 == 0 && logical % p.tiles_n == 0) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const float v = csum[i] + __shfl_xor(csum[i], 32, 64);
-                    const int64_t row = m0 + wm0 + 32 * i + l32;
-                    if (h == 0 && row < p.M) p.colsum[(int64_t)tc.split * p.M + row] = v;
-                }
-            }
-        }
-        if (BN == 128 && tc.tail_slab >= 0) dump_tail<TM, TN>(acc, p, tc.tail_slab, wave, NWAVES, lane);
-        else gemm_epilogue<TM, TN>(acc, p, m0, n0, wm0, wn0, l32, h, tc.split);
-    }
-}
-
 // Sum of the K-slabs of one tail tile (slab order: deterministic) + the epilogue; same wave / register layout as
 // the kernel that wrote the slabs.
 template <int BM, int BN, int WM, int WN>
@@ -958,18 +475,8 @@ static int launch_dma(const GemmArgs& a, int opA, int opB, hipStream_t st) {
     return MSN_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int DBK, int STAGES>
-static int launch_pw(const GemmArgs& a, int opA, int opB, hipStream_t st) {
-    const unsigned items = gemm_grid(a);
-    const dim3 grid(items < 512u ? items : 512u), block(64 * ((BM / WM) * (BN / WN) + 2));   // two workgroups per CU
-    if (opA == MSN_OP_N && opB == MSN_OP_T) hipLaunchKernelGGL((sgemm_pw_kernel<BM, BN, WM, WN, false, false, DBK, STAGES>), grid, block, 0, st, a);
-    else if (opA == MSN_OP_N && opB == MSN_OP_N) hipLaunchKernelGGL((sgemm_pw_kernel<BM, BN, WM, WN, false, true, DBK, STAGES>), grid, block, 0, st, a);
-    else if (opA == MSN_OP_T && opB == MSN_OP_N && a.colsum) hipLaunchKernelGGL((sgemm_pw_kernel<BM, BN, WM, WN, true, true, DBK, STAGES, true>), grid, block, 0, st, a);
-    else if (opA == MSN_OP_T && opB == MSN_OP_N) hipLaunchKernelGGL((sgemm_pw_kernel<BM, BN, WM, WN, true, true, DBK, STAGES>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((sgemm_pw_kernel<BM, BN, WM, WN, true, false, DBK, STAGES>), grid, block, 0, st, a);
-    MSN_LAUNCH_CHECK();
-    return MSN_OK;
-}
+// gemm_pw.hip: the loader-wave kernel (msn_set_gemm_variant(4)), 128 x 128 tiles
+int launch_pw_128(const GemmArgs& a, int opA, int opB, hipStream_t st);
 
 // conv = 1: A implicit (forward: B = weights [N][K], opB = T; dgrad: B = weights [K][N], opB = N);
 // conv = 2: B implicit, A = dY K-major (wgrad, with or without the fused bias gradient)
@@ -987,28 +494,8 @@ static int launch_dma_conv(const GemmArgs& a, int conv, int opB, hipStream_t st)
 static int g_gemm_variant = 3;   // 0 = register-staged kernels; LDS-DMA: 1 = 8 waves, ring 3 x BK 32; 2 = 8 waves, ring 2 x BK 64;
                                  // 3 (default) = 4 waves, ring 2 x BK 32, two workgroups per CU
 
-template <int BM, int BN, int WM, int WN>
-static int launch_cfg(const GemmArgs& a, int opA, int opB, hipStream_t st) {
-    const dim3 grid(gemm_grid(a)), block(256);
-    // 16-byte operand loads need: base aligned, ld % 4 == 0, contiguous extent % 4 == 0 (K for a
-    // K-contiguous operand, M / N for a K-major one)
-    const int64_t a_ext = opA == MSN_OP_T ? a.M : a.K, b_ext = opB == MSN_OP_N ? a.N : a.K;
-    const bool vec = (a.lda % 4 == 0) && (a_ext % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0) &&
-                     (a.ldb % 4 == 0) && (b_ext % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0) &&
-                     a_ext >= 4 && b_ext >= 4;
-#define MSN_GEMM_GO(AKM, BKM)                                                                               \
-    {                                                                                                       \
-        if (vec) hipLaunchKernelGGL((sgemm_kernel<BM, BN, WM, WN, AKM, BKM, true>), grid, block, 0, st, a); \
-        else hipLaunchKernelGGL((sgemm_kernel<BM, BN, WM, WN, AKM, BKM, false>), grid, block, 0, st, a);    \
-    }
-    if (opA == MSN_OP_N && opB == MSN_OP_T) MSN_GEMM_GO(false, false)
-    else if (opA == MSN_OP_N && opB == MSN_OP_N) MSN_GEMM_GO(false, true)
-    else if (opA == MSN_OP_T && opB == MSN_OP_N) MSN_GEMM_GO(true, true)
-    else MSN_GEMM_GO(true, false)
-#undef MSN_GEMM_GO
-    MSN_LAUNCH_CHECK();
-    return MSN_OK;
-}
+// gemm_reg.hip: the register-staged kernels (every shape; msn_set_gemm_variant(0)) for the three tile widths
+int launch_cfg_tile(const GemmArgs& a, int bn, int opA, int opB, hipStream_t st);
 
 static int g_gemm_tail = 1;      // cut the partly filled last round of tiles into K-slabs (msn_set_gemm_tail_split):
                                  // 1 = summed by the last workgroup to arrive, 2 = by a finishing launch, 0 = no slabs
@@ -1225,14 +712,12 @@ static int sgemm_impl(int opA, int opB, int64_t M, int64_t N, int64_t K, const f
     else if (bm == 64 && dma_ok) rc = launch_dma<64, 128, 32, 64, 32, 2>(a, opA, opB, st);   // (not dma_ok: the 128-row kernels below; M <= 64 is one row of tiles either way)
     else if (dma_ok && bn == 128 && K % 64 == 0 && kps % 64 == 0 && g_gemm_variant == 2)
         rc = launch_dma<128, 128, 64, 32, 64, 2>(a, opA, opB, st), waves = 8;
-    else if (dma_ok && bn == 128 && g_gemm_variant == 4) rc = launch_pw<128, 128, 64, 64, 32, 2>(a, opA, opB, st);
+    else if (dma_ok && bn == 128 && g_gemm_variant == 4) rc = launch_pw_128(a, opA, opB, st);
     else if (dma_ok && bn == 128 && g_gemm_variant == 3) rc = launch_dma<128, 128, 64, 64, 32, 2>(a, opA, opB, st);
     else if (dma_ok && bn == 128 && g_gemm_variant < 3) rc = launch_dma<128, 128, 64, 32, 32, 3>(a, opA, opB, st), waves = 8;
     else if (dma_ok && bn == 64) rc = launch_dma<128, 64, 64, 32, 32, 3>(a, opA, opB, st);
     else if (dma_ok && bn == 32) rc = launch_dma<128, 32, 32, 32, 32, 2>(a, opA, opB, st);
-    else if (bn == 128) rc = launch_cfg<128, 128, 64, 64>(a, opA, opB, st);
-    else if (bn == 64) rc = launch_cfg<128, 64, 64, 32>(a, opA, opB, st);
-    else rc = launch_cfg<128, 32, 32, 32>(a, opA, opB, st);
+    else rc = launch_cfg_tile(a, bn, opA, opB, st);
     if (rc != MSN_OK) return rc;
     if (a.tail_tiles > 0 && a.tail_counter == nullptr) {
         rc = launch_tail_finish(a, bn, waves, st);

@@ -1,5 +1,7 @@
 // Pieces shared by the fp32 (gemm.hip) and bf16 (gemm_bf16.hip) MFMA GEMM kernels.
 #pragma once
+#include <type_traits>
+
 #include "msn_common.h"
 
 namespace msn {
@@ -244,6 +246,67 @@ __device__ __forceinline__ void finish_tail(f32x16 (&acc)[TM][TN], const GemmArg
     }
     gemm_epilogue<TM, TN>(acc, p, m0, n0, wm0, wn0, l32_of(lane), lane >> 5, 0);
 }
+
+// ---- LDS-DMA operand tiles (gemm.hip, gemm_pw.hip) ------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+template <int ROWS, bool KMAJOR, int DBK>
+struct DmaTile {
+    static constexpr int kFloats = ROWS * DBK;            // unpadded image
+    static constexpr int kPieces = ROWS * DBK / 256;      // 1-KB LDS-DMA pieces per K-step
+    static constexpr int CPR = DBK / 4;                   // 16-byte chunks per row of a K-contiguous image
+    static constexpr int RPB = DBK >= 64 ? 1 : 64 / DBK;  // rows of a K-contiguous image per 256-B bank row
+    // XOR swizzle of a row's chunk positions.  ds_read_b128 serves 16 lanes (16 different rows, same logical chunk)
+    // per LDS cycle; they must land on 16 different 16-B slots of the bank row.  Rows r and r' share a slot range
+    // when r % RPB == r' % RPB, so the swizzle key must differ between them: (r / RPB) % CPR does for every row set
+    // {0-3, 12-15, 20-27} + 4j + 32h the instruction groups (MI355X_MICROARCH.md, LDS).
+    __device__ static __forceinline__ int swz(int r) { return (r / RPB) % CPR; }
+    // source address of this lane for piece q of the K-step starting at k0
+    __device__ static __forceinline__ const float* src(const float* __restrict__ g, int64_t ld, int64_t row0,
+                                                       int64_t nrows, int64_t k0, int q, int lane) {
+        if (KMAJOR) {   // image [k][ROWS]: piece = 256 / ROWS consecutive k-rows
+            constexpr int LPR = ROWS / 4;                                  // lanes per k-row
+            const int kk = q * (64 / LPR) + lane / LPR;
+            int64_t c = row0 + 4 * (lane % LPR);
+            c = c + 3 < nrows ? c : nrows - 4;
+            return g + (k0 + kk) * ld + c;
+        } else {        // image [ROWS][DBK]: piece = 64 / CPR rows; chunk c of row r sits at position c ^ swz(r)
+            const int r = q * (64 / CPR) + lane / CPR, pos = lane % CPR;
+            int64_t rr = row0 + r;
+            rr = rr < nrows ? rr : nrows - 1;
+            return g + rr * ld + k0 + 4 * (pos ^ swz(r));
+        }
+    }
+    // LDS reads are issued from inline asm: hipcc's waitcnt pass cannot prove that a ds_read does not alias an
+    // LDS-DMA write still in flight and would put s_waitcnt vmcnt(0) in front of every k-step's first read
+    // (draining the whole ring); an asm read is invisible to that pass, so its completion is counted by hand
+    // (lgkmcnt) in the kernel.  `tile_addr` = LDS byte address of the image.
+    // A fragment = this lane's 4 consecutive k values of one row.  The asm outputs bind straight to the registers
+    // the MFMAs read (no copy may sit between the asynchronous read and the hand-placed s_waitcnt).
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    struct FragKM { f32x2 lo, hi; };
+    struct FragKC { float4 v; };
+    using Frag = std::conditional_t<KMAJOR, FragKM, FragKC>;
+    template <int C>
+    __device__ static __forceinline__ float get(const Frag& f) {
+        if constexpr (KMAJOR) return C == 0 ? f.lo.x : C == 1 ? f.lo.y : C == 2 ? f.hi.x : f.hi.y;
+        else return C == 0 ? f.v.x : C == 1 ? f.v.y : C == 2 ? f.v.z : f.v.w;
+    }
+    static constexpr int kReads = KMAJOR ? 2 : 1;   // LDS instructions per fragment
+    __device__ static __forceinline__ void frag_issue(Frag& f, unsigned tile_addr, int row, int ko, int h) {
+        if constexpr (KMAJOR) {   // k, k+1 | k+2, k+3 of this lane half: two ds_read2_b32 (dword offsets 0, ROWS)
+            static_assert(ROWS <= 255, "ds_read2_b32 offset1 is 8 bits (dwords)");
+            const unsigned a = tile_addr + 4u * ((8 * ko + 4 * h) * ROWS + row);
+            asm volatile("ds_read2_b32 %0, %1 offset1:%2" : "=v"(f.lo) : "v"(a), "n"(ROWS));
+            asm volatile("ds_read2_b32 %0, %1 offset1:%2" : "=v"(f.hi) : "v"(a + 8u * ROWS), "n"(ROWS));
+        } else {
+            const unsigned a = tile_addr + 4u * (row * DBK + 4 * ((2 * ko + h) ^ swz(row)));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(f.v) : "v"(a));
+        }
+    }
+};
+
 
 // bf16 matrix-core variant (gemm_bf16.hip): planes = 1 -> operands rounded to bf16, planes = 2 -> each
 // operand split hi + lo and three products accumulated (fp32-grade accuracy).  Needs the vector-load
