@@ -14,33 +14,53 @@ from ._lib import check, lib, ptr, stream_ptr
 from .transformer_utils import TransformerWithTimeEmbeddings
 
 
+def _hidden_counts(observed_counts, f_mask):
+    """floor(n_observed * f_mask) in double precision, as Python's int(n * f) gives it."""
+    return (observed_counts.to(torch.float64) * float(f_mask)).floor().to(torch.int64)
+
+
 def get_random_mask(padding_mask, f_mask=0.15):
-    """Hide a random fraction of the observed points of every sample (ref :17-55).  Returns (mask, mask_pred):
-    `mask` = padding mask minus the hidden points, `mask_pred` = the hidden points."""
-    mask, mask_pred = padding_mask.clone(), padding_mask.clone()
-    for i in range(padding_mask.shape[0]):
-        n_hide = int(padding_mask[i].sum().item() * f_mask)
-        observed = torch.where(padding_mask[i] == True)[0]  # noqa: E712
-        perm = torch.randperm(len(observed))
-        mask_pred[i, observed[perm[n_hide:]]] = False
-        mask[i, observed[perm[:n_hide]]] = False
-    return mask, mask_pred
+    """Hide a random fraction of the observed points of every sample (ref src/models_pretraining.py:17-55).
+    Returns (mask, mask_pred): `mask` = the padding mask without the hidden points, `mask_pred` = the hidden points.
+
+    Set formulation: draw, per sample, one ranking of its observed points (ONE torch.randperm(n_observed) call per sample,
+    in sample order -- the reference's draws, so a seeded run hides the same points), call the points ranked below
+    n_hide = floor(f_mask * n_observed) "hidden", and build both outputs from the hidden set with two mask operations on
+    the device the padding mask lives on."""
+    pad = padding_mask.to(torch.bool)
+    B, T = pad.shape
+    n_obs = pad.sum(dim=1)
+    n_hide = _hidden_counts(n_obs, f_mask)
+    order = torch.full((B, T), T, dtype=torch.int64)              # rank of every observed point in its sample's draw
+    pad_host = pad.cpu()
+    for i, n in enumerate(n_obs.tolist()):
+        ranks = torch.empty(n, dtype=torch.int64)
+        ranks[torch.randperm(n)] = torch.arange(n)                 # the j-th observed point has rank ranks[j]
+        order[i, pad_host[i]] = ranks
+    hidden = order.to(pad.device) < n_hide.to(pad.device)[:, None]
+    return pad & ~hidden, pad & hidden
 
 
 def get_continous_random_mask(padding_mask, nbands, f_mask=0.15):
-    """Hide one random CONTIGUOUS run of observed points per band (ref :58-98)."""
-    mask, mask_pred = padding_mask.clone(), padding_mask.clone()
-    band = padding_mask.shape[1] // nbands
-    for i in range(padding_mask.shape[0]):
-        for k in range(nbands):
-            n_obs = int(padding_mask[i][band * k: band * (k + 1)].sum().item())
-            n_hide = int(n_obs * f_mask)
-            lo = random.randint(band * k, band * k + n_obs - n_hide)
-            hi = lo + n_hide
-            mask_pred[i, band * k: lo] = False
-            mask_pred[i, hi: band * (k + 1)] = False
-            mask[i, lo:hi] = False
-    return mask, mask_pred
+    """Hide one random CONTIGUOUS run of observed points per band (ref src/models_pretraining.py:58-98): in band k of
+    sample i, with n observed points (packed at the start of the band) and h = floor(f_mask * n), the run starts at a
+    uniformly drawn offset in [0, n - h] (ONE random.randint per (sample, band), sample-major: the reference's draws) and
+    is h long.  Both outputs are then interval tests against the drawn starts, on the padding mask's device."""
+    pad = padding_mask.to(torch.bool)
+    B, T = pad.shape
+    band = T // nbands
+    n_obs = pad[:, :band * nbands].reshape(B, nbands, band).sum(dim=2)
+    n_hide = _hidden_counts(n_obs, f_mask)
+    starts = torch.tensor([[random.randint(band * k, band * k + n - h) for k, (n, h) in enumerate(zip(ns, hs))]
+                           for ns, hs in zip(n_obs.tolist(), n_hide.tolist())], dtype=torch.int64).reshape(B, nbands)
+    pos = torch.arange(T, device=pad.device)[None, :].expand(B, T)
+    which = torch.clamp(pos // band, max=nbands - 1)               # band of every position (a ragged tail joins the last band)
+    lo = torch.gather(starts.to(pad.device), 1, which)
+    hi = lo + torch.gather(n_hide.to(pad.device), 1, which)
+    inside = (pos >= lo) & (pos < hi) & (pos < band * nbands)
+    mask_pred = pad & inside
+    mask_pred[:, band * nbands:] = pad[:, band * nbands:]          # positions beyond the last whole band are left as they are
+    return pad & ~inside, mask_pred
 
 
 class _MaskedMSE(torch.autograd.Function):

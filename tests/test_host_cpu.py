@@ -126,3 +126,40 @@ def test_convolution_plan_queries_without_a_gpu():
     assert L.msn_conv2d_workspace_bytes(3, 5, 5, 64, 64, 3, 3, 1, 1, 1, 1) == 0
     # weight gradients with few rows are planned on short tiles; the workspace query answers for the same plan
     assert L.msn_wgrad_bias_workspace_bytes(32, 128, 225280) > 0 and L.msn_sgemm_workspace_bytes(1, 0, 32, 128, 225280) > 0
+
+
+def test_pretraining_masks_reproduce_the_reference_draws():
+    """get_continous_random_mask with the generator's seed gives the masks the REFERENCE drew (tests/golden/pretraining.npz);
+    get_random_mask hides floor(f * n_observed) observed points per sample and consumes exactly one randperm(n_observed)
+    per sample, in order (what keeps a seeded run on the reference's stream)."""
+    import random
+    import numpy as np
+    from multimodal_supernovae_amd.models_pretraining import get_continous_random_mask, get_random_mask
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pretraining.npz"), allow_pickle=True)
+    pad = torch.from_numpy(g["in/padding_mask"])
+    random.seed(5)                                   # tools/gen_golden.py gen_pretraining
+    mask_in, mask_pred = get_continous_random_mask(pad, 2, f_mask=0.3)
+    assert torch.equal(mask_in, torch.from_numpy(g["in/mask_in"])) and torch.equal(mask_pred, torch.from_numpy(g["in/mask_pred"]))
+    # ragged tail: 23 positions in 2 bands of 11 -- the last position is left as it is
+    pad23 = torch.ones(3, 23, dtype=torch.bool)
+    pad23[1, 7:11] = False
+    mi, mp = get_continous_random_mask(pad23, 2, f_mask=0.25)
+    assert mi[:, 22].all() and mp[:, 22].all() and not (mi & mp)[:, :22].any() and not (mp & ~pad23).any()
+    for i in range(3):
+        for k in range(2):
+            run = mp[i, 11 * k: 11 * (k + 1)].nonzero().flatten()
+            n = int(pad23[i, 11 * k: 11 * (k + 1)].sum())
+            assert len(run) == int(n * 0.25) and (len(run) == 0 or int(run[-1] - run[0]) == len(run) - 1)   # one contiguous run
+
+    torch.manual_seed(11)
+    m, mpred = get_random_mask(pad, f_mask=0.3)
+    after = torch.get_rng_state()
+    n_obs = pad.sum(1)
+    assert torch.equal(mpred.sum(1), (n_obs.double() * 0.3).floor().long()) and torch.equal(m | mpred, pad) and not (m & mpred).any()
+    torch.manual_seed(11)
+    first = torch.randperm(int(n_obs[0]))
+    for n in n_obs.tolist()[1:]:
+        torch.randperm(n)
+    assert torch.equal(torch.get_rng_state(), after)                                    # same draws, same order
+    hidden0 = pad[0].nonzero().flatten()[first[: int(int(n_obs[0]) * 0.3)]]             # the first sample hides the first-ranked points
+    assert torch.equal(mpred[0].nonzero().flatten(), hidden0.sort().values)
