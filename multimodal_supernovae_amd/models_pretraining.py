@@ -133,8 +133,10 @@ class MaskedLightCurveEncoder(nn.Module):
             t, x, padding_mask = batch
         else:
             _, x, t, padding_mask, *_ = batch
-        mask_in, mask_pred = get_continous_random_mask(padding_mask.cpu(), self.nband, f_mask=self.f_mask)
-        loss = self.masked_loss(x, t, padding_mask, mask_in.to(x.device), mask_pred.to(x.device))
+        # masks are built on the padding mask's device; only the per-band counts of observed points (B x nband integers)
+        # come to the host, for the bounds of the random run starts
+        mask_in, mask_pred = get_continous_random_mask(padding_mask.to(x.device), self.nband, f_mask=self.f_mask)
+        loss = self.masked_loss(x, t, padding_mask, mask_in, mask_pred)
         self.log(name, loss, on_epoch=True, on_step=False, prog_bar=True)
         return loss
 
