@@ -1,5 +1,6 @@
 """Masked-light-curve pretraining with the reference's surface, src/models_pretraining.py:
-`get_random_mask`, `get_continous_random_mask` (host index plumbing, same RNG calls as the reference) and
+`get_random_mask`, `get_continous_random_mask` (masks as set operations on the device; the random draws are the
+reference's -- one per sample / band, in its order -- so a seeded run hides the same points) and
 `MaskedLightCurveEncoder` = TransformerWithTimeEmbeddings(agg="pretraining") + Linear(emb, 1), trained with an
 MSE on the hidden points.  The transformer, the read-out GEMM and the masked MSE run on libmsn_hip."""
 import random
