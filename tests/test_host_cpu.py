@@ -163,3 +163,21 @@ def test_pretraining_masks_reproduce_the_reference_draws():
     assert torch.equal(torch.get_rng_state(), after)                                    # same draws, same order
     hidden0 = pad[0].nonzero().flatten()[first[: int(int(n_obs[0]) * 0.3)]]             # the first sample hides the first-ranked points
     assert torch.equal(mpred[0].nonzero().flatten(), hidden0.sort().values)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_mask_helpers_match_reference_goldens(tag):
+    """Both mask helpers against masks the reference drew (tools/gen_golden.py gen_random_masks: 2 / 3 / 1 bands, ragged
+    samples, one sample with a single observed point per band), with the generator's seeds."""
+    import random
+    import numpy as np
+    from multimodal_supernovae_amd.models_pretraining import get_continous_random_mask, get_random_mask
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "random_masks.npz"), allow_pickle=True)
+    t = lambda k: torch.from_numpy(g[f"{tag}/{k}"])
+    pad, nband, f = t("padding_mask"), int(t("nband")), float(t("f_mask"))
+    torch.manual_seed(int(t("torch_seed")))
+    m, mp = get_random_mask(pad, f_mask=f)
+    assert torch.equal(m, t("mask")) and torch.equal(mp, t("mask_pred"))
+    random.seed(int(t("python_seed")))
+    cm, cmp_ = get_continous_random_mask(pad, nband, f_mask=f)
+    assert torch.equal(cm, t("cmask")) and torch.equal(cmp_, t("cmask_pred"))

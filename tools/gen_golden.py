@@ -438,6 +438,27 @@ def gen_pretraining():
             "out": {"pred": pred, "loss": loss}, "grad": grads_of(m)})
 
 
+def gen_random_masks():
+    """Row f4, mask helpers: the reference's get_random_mask (torch RNG seeded) and get_continous_random_mask (python RNG
+    seeded) on ragged padding masks, incl. 3 bands and a sample with a single observed point per band."""
+    import random
+    ref_pt = importlib.import_module("src.models_pretraining")
+    g = torch.Generator().manual_seed(171)
+    out = {}
+    for tag, (b, t, nband, f) in {"a": (6, 24, 2, 0.3), "b": (5, 30, 3, 0.15), "c": (4, 20, 1, 0.5)}.items():
+        pad = ragged_mask(b, t, g, nband)
+        pad[0] = False
+        for k in range(nband):
+            pad[0, k * (t // nband)] = True          # a single observed point per band: nothing to hide
+        torch.manual_seed(1000 + b)
+        m, mp = ref_pt.get_random_mask(pad, f_mask=f)
+        random.seed(2000 + b)
+        cm, cmp_ = ref_pt.get_continous_random_mask(pad, nband, f_mask=f)
+        out[tag] = {"padding_mask": pad, "nband": torch.tensor(nband), "f_mask": torch.tensor(f), "torch_seed": torch.tensor(1000 + b),
+                    "python_seed": torch.tensor(2000 + b), "mask": m, "mask_pred": mp, "cmask": cm, "cmask_pred": cmp_}
+    save("random_masks", **out)
+
+
 def gen_val_loop(ref_mm):
     """Row a15: the reference's validation hooks end to end (src/models_multimodal.py:415-556) --
     on_validation_start -> validation_step x 3 (the last batch short) -> on_validation_epoch_end -- with every
@@ -491,7 +512,7 @@ def main():
     only = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else None
     jobs = {"loss": lambda: gen_loss(ref_loss), "transformer": lambda: gen_transformer(ref_tr),
             "convmixer_mlp": lambda: gen_convmixer_mlp(ref_mm), "clip": lambda: gen_clip(ref_mm),
-            "real_checkpoint": lambda: gen_real_checkpoint(ref_mm), "auc": gen_auc, "pretraining": gen_pretraining,
+            "real_checkpoint": lambda: gen_real_checkpoint(ref_mm), "auc": gen_auc, "pretraining": gen_pretraining, "random_masks": gen_random_masks,
             "val_loop": lambda: gen_val_loop(ref_mm)}
     for name, job in jobs.items():        # each generator seeds its own torch.Generator: independent of the others
         if only is None or name in only:
