@@ -78,6 +78,29 @@ def test_conv_implicit_gemm_matches_torch(B, H, W, C, co, k, s, p, bias):
         close(bg.grad.cpu(), br.grad, "db")
 
 
+@pytest.mark.parametrize("H,C,co,s", [(16, 64, 64, 1), (16, 64, 128, 2), (4, 256, 512, 2), (2, 512, 512, 1)])
+def test_conv_implicit_equals_column_matrix_path_at_baseline_size(H, C, co, s):
+    """BASELINE cfg2 sizes (per-GPU batch 1024: ResNet-18 layers 1-4 at 64 x 64 input): the implicit-GEMM convolution and
+    the im2col + GEMM + col2im path of the same library agree in y, dx and dw (same products, different operand plumbing)."""
+    from multimodal_supernovae_amd import functional as F_
+    g = torch.Generator().manual_seed(H * C + co)
+    x = torch.randn(1024, H, H, C, generator=g).cuda()
+    w = (torch.randn(co, C, 3, 3, generator=g) * 0.05).cuda()
+    cot = torch.randn(1024, (H + 2 - 3) // s + 1, (H + 2 - 3) // s + 1, co, generator=g).cuda()
+    res = []
+    try:
+        for implicit in (True, False):
+            F_.CONV_IMPLICIT = implicit
+            xg, wg = x.clone().requires_grad_(), w.clone().requires_grad_()
+            y = F_.conv_cl(xg, wg, None, (s, s), (1, 1))
+            y.backward(cot)
+            res.append((y.detach(), xg.grad, wg.grad))
+    finally:
+        F_.CONV_IMPLICIT = True
+    for a, b, what in zip(res[0], res[1], ("y", "dx", "dw")):
+        close(a, b, what, rtol=2e-4)
+
+
 @pytest.mark.parametrize("C", [5, 8, 64])       # scalar kernel, 4-channels-per-thread kernels
 def test_maxpool_channels_last_matches_torch(C):
     from multimodal_supernovae_amd import functional as F_
