@@ -161,3 +161,35 @@ def test_bf16_attention_forward_backward(B, H, T):
     assert err < 2e-2, float(err)
     cosv = float((dqkv.cpu().double().flatten() @ dref.flatten()) / (dqkv.cpu().double().norm() * dref.norm()))
     assert cosv > 0.9995, cosv
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(100864, 2304, 768, "none"), (100864, 768, 768, "add"), (100864, 3072, 768, "gelu"), (65700, 768, 3072, "none"),
+                                       (70000, 1000, 128, "none")])
+def test_nt_persistent_workgroups_equal_one_tile_launches(M, N, K, epi):
+    """BASELINE cfg5 sizes (batch 512: 100 864 token rows): the persistent launch (one workgroup per CU walking its tiles, the
+    LDS ring running on across tile boundaries) gives the bits of the one-workgroup-per-tile launch -- ragged last row tile,
+    ragged last column tile, epilogues with aux reads / writes, column sums."""
+    from multimodal_supernovae_amd import ops, _lib
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = (torch.randn(M, K, device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g)
+    res = torch.randn(M, N, device="cuda", generator=g) if epi == "add" else None
+    outs = []
+    try:
+        for persistent in (1, 0):
+            _lib.check(_lib.lib().msn_set_bgemm_persistent(persistent))
+            if epi == "gelu":
+                aux = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+                y = ops.bgemm_nt(a, w, bias=bias, epilogue=ops.BEPI_GELU, aux=aux, out_bf16=True)
+                outs.append((y, aux))
+            elif epi == "add":
+                outs.append((ops.bgemm_nt(a, w, bias=bias, epilogue=ops.BEPI_ADD, aux=res),))
+            else:
+                outs.append(ops.bgemm_nt(a, w, bias=bias, out_bf16=True, want_colsum=True))
+    finally:
+        _lib.check(_lib.lib().msn_set_bgemm_persistent(1))
+    def flat(o):
+        return [o] if torch.is_tensor(o) else [t for e in o for t in flat(e)]
+    a0, a1 = flat(outs[0]), flat(outs[1])
+    assert len(a0) == len(a1) and all(torch.equal(x, y) for x, y in zip(a0, a1))
