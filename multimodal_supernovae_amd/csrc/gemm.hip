@@ -113,6 +113,9 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM / WM) * (BN / WN) =
         wky = tap / g.kw, wkx = tap - wky * g.kw;
     }
     auto issue = [&](int kt) {   // LDS-DMA of K-step kt into ring slot kt % STAGES
+#ifdef MSN_ABL_NODMA
+        return;                  // diagnostic build (tools/microbench/build_ablate.sh): no operand traffic at all
+#endif
         float* base = smem + (kt % STAGES) * STAGE;
         if constexpr (CONV == 1) {
             const ConvGather& g = p.cg;
@@ -162,6 +165,9 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM / WM) * (BN / WN) =
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#ifdef MSN_ACC_AGPR
+    { float agpr_hint = 0.f; asm volatile("" : "+a"(agpr_hint)); }
+#endif
 
     // Ring protocol: one barrier per K-step, placed before the MFMAs of the step's LAST k-octet.  At that point
     // every wave has received all its fragment reads of this step (lgkmcnt(0)), so after the barrier
@@ -193,8 +199,17 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM / WM) * (BN / WN) =
     float csum[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) csum[i] = 0.f;
+#ifdef MSN_ABL_NOFRAG
+    for (int s = 0; s < 2; ++s) {
+        for (int i = 0; i < TM; ++i) asm volatile("" : "=v"(fa[s][i]));
+        for (int j = 0; j < TN; ++j) asm volatile("" : "=v"(fb[s][j]));
+    }
+#endif
     auto request = [&](auto set, int slot, int ko) {
         constexpr int S = decltype(set)::value;
+#ifdef MSN_ABL_NOFRAG
+        return;                  // diagnostic build: no fragment reads (the MFMAs multiply whatever the registers hold)
+#endif
         const unsigned as = smem_addr + 4u * (slot * STAGE);
         const unsigned bs = as + 4u * TA::kFloats;
 #pragma unroll
@@ -251,7 +266,9 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM / WM) * (BN / WN) =
 #if MSN_TIMELINE >= 2
                 const unsigned long long tcc = __builtin_readcyclecounter();
 #endif
+#ifndef MSN_ABL_NOBAR
                 __builtin_amdgcn_s_barrier();
+#endif
 #if MSN_TIMELINE >= 2
                 const unsigned long long td = __builtin_readcyclecounter();
                 w_lds += tb - ta, w_vm += tcc - tb, w_bar += td - tcc;

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Diagnostic builds of libmsn_hip.so with pieces of the LDS-DMA GEMM's K loop removed (results are garbage; timing only):
+#   NODMA  no global -> LDS operand traffic     NOFRAG  no LDS fragment reads     NOBAR  no workgroup barrier per K-step
+# usage: bash tools/microbench/build_ablate.sh NODMA [NOFRAG ...]  ->  tools/microbench/ablate/libmsn_<names>.so
+set -e
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
+PKG=$ROOT/multimodal_supernovae_amd
+python3 -m multimodal_supernovae_amd.build > /dev/null
+mkdir -p "$ROOT/tools/microbench/ablate"
+DEFS=""; NAME=""
+for a in "$@"; do case $a in ACC_AGPR) DEFS="$DEFS -DMSN_ACC_AGPR";; *) DEFS="$DEFS -DMSN_ABL_$a";; esac; NAME="${NAME}_$a"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast $DEFS -c "$PKG/csrc/gemm.hip" -o "/tmp/gemm_abl$NAME.o"
+OBJS=$(ls "$PKG"/build/*.o | grep -v "build/gemm.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/tools/microbench/ablate/libmsn$NAME.so" "/tmp/gemm_abl$NAME.o" $OBJS
+echo "built tools/microbench/ablate/libmsn$NAME.so"
