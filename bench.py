@@ -275,6 +275,8 @@ def main():
     ap.add_argument("--no-weak", action="store_true", help="skip the second measurement at 256 rows per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra split-bf16 measurement")
+    ap.add_argument("--no-three-tower", action="store_true",
+                    help="skip the third field (image + light-curve + 1024-bin-spectrum workload at 256 / 1024 rows per GPU)")
     ap.add_argument("--workload", default="vit_s8_lc", choices=list(WORKLOADS),
                     help="vit_s8_lc = the headline (default); the others are the remaining BASELINE.json configurations")
     ap.add_argument("--serial-towers", action="store_true",
@@ -321,7 +323,7 @@ def main():
         b, scaling = args.global_batch // world, "strong"
     headline = args.workload == "vit_s8_lc"
     if not headline:
-        args.no_alt, args.no_cpu_baseline, args.no_weak = True, True, True
+        args.no_alt, args.no_cpu_baseline, args.no_weak, args.no_three_tower = True, True, True, True
 
     def make(rows):
         if headline:
@@ -385,7 +387,6 @@ def main():
         extra = int(min(200, max(0, 0.6 / max(float(one), 1e-4) - warmup - 1)))
         for _ in range(extra):
             loss = fn()
-        timed.extra_warmup = extra + 1
         fence()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -394,9 +395,9 @@ def main():
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
         if world > 1:
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        return float(t), float(loss.detach())
+        return float(t), float(loss.detach()), extra + 1
 
-    dt, loss_value = timed(step, args.warmup, args.steps)
+    dt, loss_value, untimed_extra = timed(step, args.warmup, args.steps)
 
     # ---- communication of one step: every collective issued through distributed.py, timed on the compute stream ----
     comm = {"backend": "rccl" if D.backend_name() == "nccl" else D.backend_name(), "ranks": world,
@@ -440,7 +441,8 @@ def main():
     gemm_flops = sum(e[2] for e in prof)
     # operands + result, plus the M x N aux matrix an epilogue writes (gelu' saved by the forward) or reads (gelu' / ReLU
     # output / residual in the backward and residual-add epilogues)
-    gemm_bytes = sum(4.0 * (e[3][2] * e[3][4] + e[3][4] * e[3][3] + e[3][2] * e[3][3] * (2 if e[4] else 1)) for e in prof)
+    gemm_bytes = sum(e[5] if len(e) > 5 else 4.0 * (e[3][2] * e[3][4] + e[3][4] * e[3][3] + e[3][2] * e[3][3] * (2 if e[4] else 1))
+                     for e in prof)
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     # dense matrix peak of the instruction the dominant kernel issues (MI355X_MICROARCH.md): fp32 157.3 TFLOP/s;
     # bf16 2500 TFLOP/s, of which the 3-product split can deliver at most a third as algorithmic flops
@@ -455,7 +457,7 @@ def main():
     # concurrent one, so the gain of running the towers on separate streams can be read off the JSON
     towers = None
     if headline and not args.graphed and world == 1:      # one process: the reducer's hooks are no-ops
-        serial_dt, _ = timed(step, 1, max(3, args.steps // 4))
+        serial_dt, _, _ = timed(step, 1, max(3, args.steps // 4))
         towers = {"concurrent_streams_ms_per_step": dt / args.steps * 1e3,
                   "serial_ms_per_step": serial_dt / max(3, args.steps // 4) * 1e3}
         cot = torch.full((b, ENC_DIM), 1.0 / b, device=device)
@@ -504,7 +506,7 @@ def main():
     if args.gemm_precision == "f32" and not args.no_alt and world == 1:
         ops.set_gemm_precision("bf16x3")
         n_alt = max(3, args.steps // 2)
-        dt_alt, _ = timed(step, 2, n_alt)
+        dt_alt, _, _ = timed(step, 2, n_alt)
         ops.set_gemm_precision("f32")
         alt = {"gemm_precision": "bf16x3 (operands split hi+lo into bf16, 3 v_mfma_f32_32x32x16_bf16 products, fp32 accumulate)",
                "value": b * world * n_alt / dt_alt, "unit": "pairs/s", "ms_per_step": dt_alt / n_alt * 1e3,
@@ -520,11 +522,42 @@ def main():
         opt_w = model_w.configure_optimizers()["optimizer"]
         red_w = D.GradientReducer(model_w.parameters())
         step_w = make_step(model_w, opt_w, red_w, batch_w)
-        dt_w, loss_w = timed(step_w, args.warmup, args.steps)
+        dt_w, loss_w, _ = timed(step_w, args.warmup, args.steps)
         weak = {"value": 256 * world * args.steps / dt_w, "unit": "pairs/s", "per_gpu_batch": 256,
                 "global_batch": 256 * world, "ms_per_step": dt_w / args.steps * 1e3, "steps": args.steps,
                 "scaling": "weak", "loss": loss_w}
         red_w.remove()
+
+    # ---- third field (row N1 of the north star: image + light-curve + 1024-bin spectra): the three-tower workload of
+    # BASELINE cfg4 (ViT-S/8 + LC transformer + 1-D CNN spectrum tower, symmetric 3-way InfoNCE) at 256 and 1024 rows per GPU
+    three = None
+    if headline and not args.no_three_tower and not args.graphed and args.gemm_precision == "f32":
+        three = {"workload": WORKLOADS["vit_s8_lc_cnn1d_sp"], "unit": "pairs/s", "scaling": "weak", "per_gpu": []}
+        for rows in (256, 1024):
+            model_t, batch_t = build_workload("vit_s8_lc_cnn1d_sp", rows, 1234 + rank, device)
+            D.broadcast_module(model_t)
+            opt_t = model_t.configure_optimizers()["optimizer"]
+            red_t = D.GradientReducer(model_t.parameters())
+            step_t = make_step(model_t, opt_t, red_t, batch_t)
+            n_t = max(3, args.steps // 2)
+            dt_t, loss_t, _ = timed(step_t, 2, n_t)
+            conc_t, model_t.concurrent_towers = getattr(model_t, "concurrent_towers", False), False
+            step_t()                                   # rehearsal of the serial order, then the instrumented step
+            torch.cuda.synchronize()
+            ops.GEMM_PROFILE = []
+            step_t()
+            torch.cuda.synchronize()
+            prof_t, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+            model_t.concurrent_towers = conc_t
+            ms_t = sum(e[0].elapsed_time(e[1]) for e in prof_t)
+            fl_t = sum(e[2] for e in prof_t)
+            tf_t = fl_t / (ms_t * 1e-3) / 1e12 if ms_t > 0 else 0.0
+            three["per_gpu"].append({"per_gpu_batch": rows, "global_batch": rows * world, "ms_per_step": dt_t / n_t * 1e3,
+                                     "value": rows * world * n_t / dt_t, "steps": n_t, "loss": loss_t,
+                                     "gemm_tflops": tf_t, "gemm_frac_of_fp32_matrix_peak": tf_t / 157.3,
+                                     "gemm_launches_per_step": len(prof_t), "gemm_ms_per_step": ms_t})
+            red_t.remove()
+            del step_t, model_t, batch_t, opt_t, red_t
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -541,7 +574,7 @@ def main():
                        if headline else WORKLOADS[args.workload] + " (non-headline configuration)",
                        "per_gpu_batch": b, "global_batch": b * world, "parallelism": f"dp{world}",
                        "launch": "HIP graph replay" if args.graphed else "eager",
-                       "untimed_steps_after_warmup": getattr(timed, "extra_warmup", 0),
+                       "untimed_steps_after_warmup": untimed_extra,
                        "loss": loss_value, "algorithmic_gflop_per_pair": flops_per_pair() / 1e9,
                        "executed_gflop_per_pair": flops_per_pair(executed=True) / 1e9,
                        "model_tflops": pairs * flops_per_pair(executed=True) / 1e12},
@@ -559,6 +592,8 @@ def main():
                 out["config"].pop(k)
         if weak is not None:
             out["weak_scaling_256_per_gpu"] = weak
+        if three is not None:
+            out["three_tower"] = three
         if towers is not None:
             out["towers"] = towers
         if alt is not None:

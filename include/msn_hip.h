@@ -99,6 +99,42 @@ int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, const float* A,
               const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int epilogue,
               float* aux, int64_t ldaux, int precision, void* ws, size_t ws_bytes, msn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Work-list launch: up to 3 independent products in ONE persistent launch (gemm_list.hip).  The (tile, K-step) pairs
+ * of all products form one sequence that is cut into equal ranges, one per resident workgroup; a tile cut by a range
+ * boundary is finished by the last of its contributors to arrive (slabs of raw accumulators summed in k order:
+ * deterministic).  Built for the 128 - 512 rows per GPU that strong scaling of the global batch leaves a rank, where a
+ * single product cannot fill the chip's 512 workgroup slots, and for the two backward products of a Linear
+ * (src/transformer_utils.py:45-47,89,102-106: dX = dY . W and dW = dY^T . X share dY and are independent) -- the weight
+ * gradient needs no split count and no reduction launch.  `colsum` (opA = T only, may be NULL): also out[M] = column
+ * sums of A, i.e. the bias gradient of the same Linear.  Products the kernel does not take (N or M <= 64, K % 32 != 0,
+ * unaligned operands, precision != fp32) are issued one by one through msn_sgemm / msn_wgrad_bias -- same results as
+ * calling those.  Against the one-by-one path the list kernel's results differ in the last bits (another k order).
+ * msn_set_gemm_list(0) forces the one-by-one path (measurements).  msn_set_gemm_streamk(t): msn_sgemm itself takes the
+ * list kernel for an opA = N product of at most t 128 x 128 tiles (0 = never). */
+typedef struct msn_gemm_desc {
+    int opA, opB;
+    int64_t M, N, K;
+    const float* A;
+    int64_t lda;
+    const float* B;
+    int64_t ldb;
+    float* C;
+    int64_t ldc;
+    const float* bias;
+    int epilogue;
+    float* aux;
+    int64_t ldaux;
+    float* colsum;
+} msn_gemm_desc;
+size_t msn_sgemm_list_workspace_bytes(int n, const msn_gemm_desc* products);
+int msn_sgemm_list(int n, const msn_gemm_desc* products, int precision, void* ws, size_t ws_bytes, msn_stream_t stream);
+int msn_set_gemm_list(int enabled);
+int msn_set_gemm_streamk(int max_tiles);
+/* Zero the arrival counters of the in-kernel tile finishes (tail split, work-list launch) of the current device: they
+ * are zero between launches by construction, but a launch that faulted or was aborted half-way leaves them dirty. */
+int msn_reset_gemm_counters(msn_stream_t stream);
+
 /* Weight + bias gradient of a Linear in one launch (the backward of torch.nn.functional.linear as used at
  * ref src/transformer_utils.py:33-36, :103-107 and every nn.Linear of src/models_multimodal.py):
  *   dW[M x N] = dY^T X,   db[M] = column sums of dY,   dY: K x M (row stride lddy), X: K x N (row stride ldx).

@@ -26,6 +26,11 @@ SIGNATURES = {
     "msn_sgemm_workspace_bytes": (c_size, [c_int, c_int, c_i64, c_i64, c_i64]),
     "msn_sgemm": (c_int, [c_int, c_int, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr,
                           c_int, c_ptr, c_i64, c_int, c_ptr, c_size, c_ptr]),
+    "msn_sgemm_list_workspace_bytes": (c_size, [c_int, c_ptr]),
+    "msn_sgemm_list": (c_int, [c_int, c_ptr, c_int, c_ptr, c_size, c_ptr]),
+    "msn_set_gemm_list": (c_int, [c_int]),
+    "msn_set_gemm_streamk": (c_int, [c_int]),
+    "msn_reset_gemm_counters": (c_int, [c_ptr]),
     "msn_set_gemm_variant": (c_int, [c_int]),
     "msn_set_bgemm_persistent": (c_int, [c_int]),
     "msn_set_gemm_tail_split": (c_int, [c_int]),
@@ -129,6 +134,15 @@ SIGNATURES = {
                                 c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr,
                                 c_ptr, c_size, c_ptr]),
 }
+
+
+
+class GemmDesc(ctypes.Structure):
+    """msn_gemm_desc of include/msn_hip.h (one product of a work-list launch)."""
+    _fields_ = [("opA", c_int), ("opB", c_int), ("M", c_i64), ("N", c_i64), ("K", c_i64), ("A", c_ptr), ("lda", c_i64),
+                ("B", c_ptr), ("ldb", c_i64), ("C", c_ptr), ("ldc", c_i64), ("bias", c_ptr), ("epilogue", c_int),
+                ("aux", c_ptr), ("ldaux", c_i64), ("colsum", c_ptr)]
+
 
 _lib = None
 

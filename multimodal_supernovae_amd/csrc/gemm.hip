@@ -521,25 +521,42 @@ static int g_gemm_tail = 1;      // cut the partly filled last round of tiles in
 // leaves its counters at zero, so a stream needs one slice of counters; streams that overlap (the towers of a
 // step run on their own streams) get a slice each.  Module memory: nothing is allocated, the first use looks the
 // address up.  More streams than slices: those launches fall back to the finishing launch.
+// A __device__ symbol has one address PER GPU and stream handles are per GPU too: the tables below are kept per device
+// (hipGetDevice() of the calling thread, the device the launch goes to), so a process that drives several GPUs never
+// hands a kernel another GPU's counters or zero page.
 constexpr int kTailSlices = 32, kTailSliceTiles = 512;     // a tail has fewer than 512 tiles (tiles % 512)
+constexpr int kMaxDevices = 64;
 __device__ unsigned g_tail_counters[kTailSlices * kTailSliceTiles];
+static int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return -1;
+    return dev;
+}
 static unsigned* tail_counter_slice(hipStream_t st) {
+    struct PerDevice {
+        hipStream_t owner[kTailSlices];
+        int used = 0;
+        unsigned* base = nullptr;
+    };
     static std::mutex mu;
-    static hipStream_t owner[kTailSlices];
-    static int used = 0;
-    static unsigned* base = nullptr;
+    static PerDevice table[kMaxDevices];
+    const int dev = current_device();
+    if (dev < 0) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
-    if (!base) {
+    PerDevice& d = table[dev];
+    if (!d.base) {
         void* sym = nullptr;
         if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_tail_counters)) != hipSuccess) return nullptr;
-        base = static_cast<unsigned*>(sym);
+        d.base = static_cast<unsigned*>(sym);
     }
-    for (int i = 0; i < used; ++i)
-        if (owner[i] == st) return base + (size_t)i * kTailSliceTiles;
-    if (used == kTailSlices) return nullptr;
-    owner[used] = st;
-    return base + (size_t)(used++) * kTailSliceTiles;
+    for (int i = 0; i < d.used; ++i)
+        if (d.owner[i] == st) return d.base + (size_t)i * kTailSliceTiles;
+    if (d.used == kTailSlices) return nullptr;
+    d.owner[d.used] = st;
+    return d.base + (size_t)(d.used++) * kTailSliceTiles;
 }
+unsigned* gemm_counter_slice(hipStream_t st) { return tail_counter_slice(st); }
+static int g_gemm_streamk = 0;   // msn_sgemm: opA = N products of at most this many 128 x 128 tiles take the work-list kernel (0 = never)
 static int g_gemm_bn = 0;        // measurement switch (msn_set_gemm_tile_n): 0 = planned, 64 / 128 = forced tile width for N > 64
 
 // Launch geometry of one product.
@@ -631,10 +648,18 @@ extern "C" int msn_debug_timeline(unsigned long long* buf) {
 }
 #endif
 
+// msn_sgemm's own use of the work-list kernel: an under-filled forward / dgrad product (shape test only; operand
+// alignment is checked at the call)
+static bool streamk_shape(int opA, int64_t M, int64_t N, int64_t K) {
+    return g_gemm_streamk > 0 && opA == MSN_OP_N && M > 64 && N > 64 && K % BK == 0 && g_gemm_bn == 0 &&
+           cdiv(M, 128) * cdiv(N, 128) <= g_gemm_streamk && cdiv(M, 128) * cdiv(N, 128) * (K / BK) >= 64;
+}
+
 extern "C" size_t msn_sgemm_workspace_bytes(int opA, int opB, int64_t M, int64_t N, int64_t K) {
     (void)opB;
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    return plan(M, N, K, opA).ws_bytes(M, N);
+    const size_t own = plan(M, N, K, opA).ws_bytes(M, N);
+    return streamk_shape(opA, M, N, K) ? std::max(own, gemm_list_ws_bytes()) : own;
 }
 
 // The launch behind msn_sgemm and msn_wgrad_bias.  `colsum_out` (opA = T only): also produce out[m] = sum_k A[k][m]
@@ -659,6 +684,11 @@ static int sgemm_impl(int opA, int opB, int64_t M, int64_t N, int64_t K, const f
     MSN_REQUIRE(!needs_aux || (aux && ldaux >= N), "msn_sgemm: epilogue %d needs aux with ldaux >= N", epilogue);
     MSN_REQUIRE(!(epilogue == MSN_EPI_GELU && aux) || ldaux >= N, "msn_sgemm: ldaux < N");
 
+    if (conv == 0 && colsum_out == nullptr && precision == MSN_PREC_F32 && g_gemm_variant == 3 && streamk_shape(opA, M, N, K)) {
+        const msn_gemm_desc d{opA, opB, M, N, K, A, lda, B, ldb, C, ldc, bias, epilogue, aux, ldaux, nullptr};
+        if (gemm_list_takes(1, &d) && ws && ws_bytes >= gemm_list_ws_bytes())
+            return gemm_list_launch(1, &d, ws, ws_bytes, static_cast<hipStream_t>(stream));
+    }
     GemmArgs a;
     a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
@@ -775,16 +805,18 @@ extern "C" int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, cons
 // ---------------------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution on channels-last tensors (ConvGather): no column matrix in memory.
 __device__ float g_conv_zero_page[64];
-static const float* conv_zero_page() {
-    static const float* page = nullptr;
+static const float* conv_zero_page() {      // per device, like the tail counters
+    static const float* page[kMaxDevices] = {};
     static std::mutex mu;
+    const int dev = current_device();
+    if (dev < 0) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
-    if (!page) {
+    if (!page[dev]) {
         void* sym = nullptr;
         if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_conv_zero_page)) != hipSuccess) return nullptr;
-        page = static_cast<const float*>(sym);
+        page[dev] = static_cast<const float*>(sym);
     }
-    return page;
+    return page[dev];
 }
 static unsigned long long div_magic(int d) { return (1ull << 36) / (unsigned long long)d + 1ull; }
 struct ConvShape { int B, H, W, C, Cout, kh, kw, sh, sw, ph, pw, OH, OW; };
@@ -886,6 +918,22 @@ extern "C" int msn_wgrad_bias(int64_t M, int64_t N, int64_t K, const float* dY, 
                               precision, ws, ws_bytes, stream, db, &fused);
     if (rc != MSN_OK || fused || M == 0 || N == 0) return rc;
     return msn_colsum(dY, lddy, K, M, db, ws, ws_bytes, stream);   // shapes / precisions the fused kernel does not take
+}
+
+extern "C" int msn_set_gemm_streamk(int max_tiles) {
+    MSN_REQUIRE(max_tiles >= 0, "msn_set_gemm_streamk: a tile count >= 0");
+    g_gemm_streamk = max_tiles;
+    return MSN_OK;
+}
+
+extern "C" int msn_reset_gemm_counters(msn_stream_t stream) {
+    void* sym = nullptr;
+    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_tail_counters)) != hipSuccess ||
+        hipMemsetAsync(sym, 0, sizeof(unsigned) * kTailSlices * kTailSliceTiles, static_cast<hipStream_t>(stream)) != hipSuccess) {
+        set_error("msn_reset_gemm_counters: %s", hipGetErrorString(hipGetLastError()));
+        return MSN_ERR_HIP;
+    }
+    return MSN_OK;
 }
 
 extern "C" int msn_set_gemm_tile_n(int bn) {

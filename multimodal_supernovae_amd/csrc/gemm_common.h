@@ -313,6 +313,13 @@ struct DmaTile {
 // conditions of the VEC fp32 kernels; the caller falls back to the fp32 kernels otherwise.
 int launch_bgemm(const GemmArgs& a, int opA, int opB, int planes, int bm, int bn, hipStream_t st);
 
+// gemm_list.hip: the work-list (stream-K) launch
+bool gemm_list_takes(int n, const msn_gemm_desc* d);
+size_t gemm_list_ws_bytes();
+int gemm_list_launch(int n, const msn_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st);
+// gemm.hip: one zeroed slice of 512 arrival counters per (device, stream); null when all slices are taken
+unsigned* gemm_counter_slice(hipStream_t st);
+
 inline unsigned gemm_grid(const GemmArgs& a) {
     return (unsigned)((a.tiles_m * a.tiles_n - a.tail_tiles) * a.splits + a.tail_tiles * a.tail_splits);
 }

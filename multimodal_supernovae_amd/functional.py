@@ -546,21 +546,43 @@ class _PreNormBlock(torch.autograd.Function):
         B, T, e, heads, scale = ctx.dims
         (x2, g1, wqkv, wo, g2, w1, w2, m1, r1, h1, qkv, a2, lse, x1, m2, r2, h2, pre, f) = ctx.saved_tensors
         d2 = _c(dy).view(B * T, e)
-        dw2, dc2 = ops.wgrad_bias(d2, f)
-        dpre = sgemm(d2, w2, OP_N, OP_N, epilogue=EPI_GELU_BWD, aux=pre)
-        dw1, dc1 = ops.wgrad_bias(dpre, h2)
-        dh2 = sgemm(dpre, w1, OP_N, OP_N)
+        pair = _pair_backward(B * T)
+        if pair:        # both backward products of a Linear in one work-list launch (ops.dgrad_wgrad)
+            dpre, dw2, dc2 = ops.dgrad_wgrad(d2, w2, f, epilogue=EPI_GELU_BWD, aux=pre)
+            dh2, dw1, dc1 = ops.dgrad_wgrad(dpre, w1, h2)
+        else:
+            dw2, dc2 = ops.wgrad_bias(d2, f)
+            dpre = sgemm(d2, w2, OP_N, OP_N, epilogue=EPI_GELU_BWD, aux=pre)
+            dw1, dc1 = ops.wgrad_bias(dpre, h2)
+            dh2 = sgemm(dpre, w1, OP_N, OP_N)
         dx1, dg2, db2 = ops.layernorm_bwd(dh2, x1, m2, r2, g2, add=d2)        # + skip connection
-        dwo, dbo = ops.wgrad_bias(dx1, a2)
-        da = sgemm(dx1, wo, OP_N, OP_N)
+        if pair & 2:
+            da, dwo, dbo = ops.dgrad_wgrad(dx1, wo, a2)
+        else:
+            dwo, dbo = ops.wgrad_bias(dx1, a2)
+            da = sgemm(dx1, wo, OP_N, OP_N)
         dqkv = torch.empty_like(qkv)
         q3, d3 = qkv.view(B, T, 3 * e), dqkv.view(B, T, 3 * e)
         ops.attention_bwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], None, heads, scale, a2.view(B, T, e), lse,
                           da.view(B, T, e), d3[..., :e], d3[..., e:2 * e], d3[..., 2 * e:])
-        dwqkv, dbqkv = ops.wgrad_bias(dqkv, h1)
-        dh1 = sgemm(dqkv, wqkv, OP_N, OP_N)
+        if pair:
+            dh1, dwqkv, dbqkv = ops.dgrad_wgrad(dqkv, wqkv, h1)
+        else:
+            dwqkv, dbqkv = ops.wgrad_bias(dqkv, h1)
+            dh1 = sgemm(dqkv, wqkv, OP_N, OP_N)
         dx, dg1, db1 = ops.layernorm_bwd(dh1, x2, m1, r1, g1, add=dx1)          # + skip connection
         return (dx.view(B, T, e), None, None, dg1, db1, dwqkv, dbqkv, dwo, dbo, dg2, db2, dw1, dc1, dw2, dc2)
+
+
+# Backward pairs (dX and dW of one Linear) as ONE work-list launch: MSN_PAIR_BACKWARD = 0 never, 1 the wide products of a
+# block (qkv, ff1, ff2), 3 also the e x e output projection; unset: by row count (see _pair_backward).
+PAIR_BACKWARD = os.environ.get("MSN_PAIR_BACKWARD")
+
+
+def _pair_backward(rows):
+    if PAIR_BACKWARD is not None:
+        return int(PAIR_BACKWARD)
+    return 0
 
 
 def pre_norm_block(x, heads, p, eps=1e-6):

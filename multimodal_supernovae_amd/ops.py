@@ -132,6 +132,74 @@ def wgrad_bias(dy, x, precision=None, out=None):
     return dw, db
 
 
+def set_gemm_list(enabled):
+    """msn_sgemm_list: True (default) = one work-list launch, False = its products one by one (measurements, comparisons)."""
+    check(lib().msn_set_gemm_list(int(bool(enabled))))
+
+
+def set_gemm_streamk(max_tiles):
+    """msn_sgemm itself takes the work-list kernel for opA = N products of at most `max_tiles` 128 x 128 tiles (0 = never)."""
+    check(lib().msn_set_gemm_streamk(int(max_tiles)))
+
+
+def _gemm_desc(a, b, op_a, op_b, c, bias=None, epilogue=EPI_NONE, aux=None, colsum_out=None):
+    M, K = (a.shape if op_a == OP_N else (a.shape[1], a.shape[0]))
+    Kb, N = (b.shape if op_b == OP_N else (b.shape[1], b.shape[0]))
+    if K != Kb:
+        raise _lib.MsnHipError(f"sgemm_list: inner dimensions differ ({K} vs {Kb})")
+    assert a.stride(1) == 1 and b.stride(1) == 1 and c.stride(1) == 1 and tuple(c.shape) == (M, N)
+    d = _lib.GemmDesc()
+    d.opA, d.opB, d.M, d.N, d.K = op_a, op_b, M, N, K
+    d.A, d.lda, d.B, d.ldb, d.C, d.ldc = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), c.stride(0)
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.epilogue = epilogue
+    d.aux, d.ldaux = (aux.data_ptr(), aux.stride(0)) if aux is not None else (None, 0)
+    d.colsum = colsum_out.data_ptr() if colsum_out is not None else None
+    return d
+
+
+def sgemm_list(descs, precision=None, profile_key=None):
+    """Up to three independent products (built by _gemm_desc) in one work-list launch (msn_sgemm_list)."""
+    import ctypes
+    n = len(descs)
+    arr = (_lib.GemmDesc * n)(*descs)
+    L = lib()
+    nb = L.msn_sgemm_list_workspace_bytes(n, ctypes.cast(arr, ctypes.c_void_p))
+    ws = _workspace(nb, torch.device("cuda", torch.cuda.current_device()))
+    prof = GEMM_PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(L.msn_sgemm_list(n, ctypes.cast(arr, ctypes.c_void_p), GEMM_PRECISION if precision is None else precision,
+                           ptr(ws), nb, stream_ptr()), "msn_sgemm_list")
+    if prof is not None:
+        ev1.record()
+        flops = sum(2.0 * d.M * d.N * d.K for d in descs)
+        nbytes = sum(4.0 * (d.M * d.K + d.K * d.N + d.M * d.N * (2 if d.aux else 1)) for d in descs)
+        d0 = descs[0]
+        prof.append((ev0, ev1, flops, profile_key or (8, n, d0.M, d0.N, d0.K, d0.epilogue), False, nbytes))
+
+
+def dgrad_wgrad(dy, w, x, epilogue=EPI_NONE, aux=None, want_bias=True, precision=None, want_dx=True):
+    """Both backward products of y = x W^T (+ b) in ONE launch: dx = epilogue(dy . W), dW = dy^T . x and (want_bias)
+    db = column sums of dy (ref src/transformer_utils.py:45-47, 89, 102-106 backward).  dy (rows, n_out), w (n_out, n_in),
+    x (rows, n_in), all with contiguous columns.  Returns (dx, dW, db | None)."""
+    _f32c(dy, "dy"), _f32c(w, "w"), _f32c(x, "x")
+    rows, n_out = dy.shape
+    n_in = w.shape[1]
+    dev = dy.device
+    dw = torch.empty((n_out, n_in), dtype=torch.float32, device=dev)
+    db = torch.empty(n_out, dtype=torch.float32, device=dev) if want_bias else None
+    descs = []
+    dx = None
+    if want_dx:
+        dx = torch.empty((rows, n_in), dtype=torch.float32, device=dev)
+        descs.append(_gemm_desc(dy, w, OP_N, OP_N, dx, epilogue=epilogue, aux=aux))
+    descs.append(_gemm_desc(dy, x, OP_T, OP_N, dw, colsum_out=db))
+    sgemm_list(descs, precision, profile_key=(9, len(descs), rows, n_in, n_out, epilogue))
+    return dx, dw, db
+
+
 def colsum(x):
     """Sum over rows of a 2-D tensor -> (N,)."""
     _f32c(x, "x")

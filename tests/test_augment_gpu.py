@@ -1,9 +1,38 @@
-"""Row f3: the on-device augmentation against the reference's formulas (src/dataloader.py:88-287) evaluated with
-plain torch on the same random fields (the fields are inputs, so the comparison is exact up to fp32 rounding)."""
+"""Row f3: the on-device augmentation.  Series noise (ref src/dataloader.py:119-137, :215-238) is pinned by fixtures the
+REAL NoisyDataLoader.__iter__ produced under a fixed seed (tools/gen_golden.py --only augment: inputs, errors, the Gaussian
+field the loader drew, its output).  The image branch (:96-114: uniform noise + torchvision RandomRotation) cannot be run
+in the build image (torchvision is absent) and is compared with the reference's formula evaluated in plain torch on the
+same random fields; its rotation sense stays unpinned."""
 import pytest
 import torch
 
+from conftest import Fixture, golden_names
+
 pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", golden_names("augment_"))
+def test_series_noise_against_reference_loader(name):
+    """augment_series on the field the reference loader drew == the batch the reference loader yielded."""
+    from multimodal_supernovae_amd.augment import augment_batch, augment_series
+    fx = Fixture(name)
+    level, nb = fx.cfg["noise_level_mag"], fx.cfg["batches"]
+    seen = 0
+    for bi in range(nb):
+        for kind in ("lc", "sp"):
+            if f"b{bi}.x_{kind}" not in fx.groups["in"]:
+                continue
+            x, err, field = (fx.groups["in"][f"b{bi}.{k}_{kind}"].cuda() for k in ("x", "err", "field"))
+            out = augment_series(x, err, level, g=field)
+            torch.testing.assert_close(out.cpu(), fx.out[f"b{bi}.x_{kind}"], rtol=1e-6, atol=1e-6)
+            seen += 1
+    assert seen >= nb
+    if fx.cfg["combinations"] == ["spectral", "lightcurve"]:      # the 9-tuple wrapper leaves everything else untouched
+        x_lc, x_sp = fx.groups["in"]["b0.x_lc"].cuda(), fx.groups["in"]["b0.x_sp"].cuda()
+        batch = (None, x_lc, x_lc * 0, x_lc > 0, x_sp, x_sp * 0, x_sp > 0, None, None)
+        aug = augment_batch(batch, 0.25, level, magerr=fx.groups["in"]["b0.err_lc"].cuda(), specerr=fx.groups["in"]["b0.err_sp"].cuda())
+        assert aug[0] is None and aug[2] is batch[2] and aug[3] is batch[3] and aug[5] is batch[5] and aug[6] is batch[6]
+        assert aug[1].shape == x_lc.shape and aug[4].shape == x_sp.shape and not torch.equal(aug[1], x_lc)
 
 
 @pytest.mark.parametrize("B,C,S", [(5, 3, 8), (16, 3, 60), (3, 1, 7)])

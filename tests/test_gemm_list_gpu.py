@@ -1,0 +1,171 @@
+"""Work-list (stream-K) GEMM launch, csrc/gemm_list.hip: one persistent launch for up to three products, tiles cut by range
+boundaries finished by the last contributor.  Against fp64 references, against the one-by-one path, determinism, ragged
+shapes, every epilogue, the backward pair of a Linear with its bias gradient, two streams at once."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = dict(rtol=2e-5, atol=2e-5)
+
+
+def _ref(a, b, oa, ob):
+    A = a.double() if oa == 0 else a.double().t()
+    B = b.double() if ob == 0 else b.double().t()
+    return A @ B
+
+
+def _rel(x, ref):
+    return float((x.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture
+def streamk():
+    from multimodal_supernovae_amd import ops
+    ops.set_gemm_streamk(1 << 20)
+    yield ops
+    ops.set_gemm_streamk(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(8320, 384, 384), (8320, 1152, 384), (8320, 384, 1536), (1000, 384, 384), (200, 130, 64),
+                                   (4160, 1536, 384), (129, 129, 32), (16640, 384, 1152)])
+@pytest.mark.parametrize("ob", [0, 1])
+def test_single_product_through_msn_sgemm(streamk, M, N, K, ob):
+    ops = streamk
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + ob)
+    a = torch.randn(M, K, device="cuda", generator=g)
+    b = torch.randn((K, N) if ob == 0 else (N, K), device="cuda", generator=g)
+    if N % 4 != 0 and ob == 0:
+        pytest.skip("K-major B needs N % 4 == 0 for the LDS-DMA kernels")
+    ref = _ref(a, b, 0, ob)
+    out = ops.sgemm(a, b, 0, ob)
+    assert _rel(out, ref) < 2e-6
+    again = ops.sgemm(a, b, 0, ob)
+    assert torch.equal(out, again)                      # no dependence on arrival order
+    ops.set_gemm_streamk(0)
+    flat = ops.sgemm(a, b, 0, ob)
+    torch.testing.assert_close(out, flat, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("epi", ["none", "relu", "gelu", "relu_bwd", "gelu_bwd", "add"])
+def test_epilogues_on_cut_tiles(streamk, epi):
+    ops = streamk
+    M, N, K = 8320, 384, 384                            # 195 tiles x 12 steps over 512 ranges: every tile is cut
+    g = torch.Generator(device="cuda").manual_seed(7)
+    a, w = torch.randn(M, K, device="cuda", generator=g), torch.randn(N, K, device="cuda", generator=g) * 0.1
+    bias = torch.randn(N, device="cuda", generator=g)
+    aux = torch.randn(M, N, device="cuda", generator=g)
+    z = (a.double() @ w.double().t())
+    if epi == "none":
+        out, ref = ops.sgemm(a, w, 0, 1, bias=bias), z + bias.double()
+    elif epi == "relu":
+        out, ref = ops.sgemm(a, w, 0, 1, bias=bias, epilogue=ops.EPI_RELU), (z + bias.double()).clamp_min(0)
+    elif epi == "gelu":
+        saved = torch.empty(M, N, device="cuda")
+        out = ops.sgemm(a, w, 0, 1, bias=bias, epilogue=ops.EPI_GELU, aux=saved)
+        x = (z + bias.double()).requires_grad_()
+        ref = torch.nn.functional.gelu(x)
+        (dref,) = torch.autograd.grad(ref.sum(), x)
+        torch.testing.assert_close(saved.double(), dref, rtol=1e-5, atol=2e-6)
+        ref = ref.detach()
+    elif epi == "relu_bwd":
+        out, ref = ops.sgemm(a, w, 0, 1, epilogue=ops.EPI_RELU_BWD, aux=aux), z * (aux.double() > 0)
+    elif epi == "gelu_bwd":
+        out, ref = ops.sgemm(a, w, 0, 1, epilogue=ops.EPI_GELU_BWD, aux=aux), z * aux.double()
+    else:
+        out, ref = ops.sgemm(a, w, 0, 1, bias=bias, epilogue=ops.EPI_ADD, aux=aux), z + bias.double() + aux.double()
+    assert _rel(out, ref) < 3e-6
+
+
+@pytest.mark.parametrize("rows,n_in,n_out,epi", [(8320, 384, 1536, "gelu_bwd"), (8320, 1536, 384, "none"), (8320, 384, 384, "none"),
+                                                 (8320, 384, 1152, "add"), (16640, 1536, 384, "none"), (33280, 384, 1536, "gelu_bwd"),
+                                                 (8320, 384, 768, "none"), (2080, 384, 384, "none"), (8192, 192, 384, "none")])
+def test_backward_pair_of_a_linear(rows, n_in, n_out, epi):
+    """dx = epilogue(dy W), dW = dy^T x, db = sum(dy) in one launch == fp64, and == the three separate launches closely."""
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(rows + n_in)
+    dy = torch.randn(rows, n_out, device="cuda", generator=g)
+    w = torch.randn(n_out, n_in, device="cuda", generator=g) * 0.1
+    x = torch.randn(rows, n_in, device="cuda", generator=g)
+    aux = torch.randn(rows, n_in, device="cuda", generator=g) if epi != "none" else None
+    e = {"none": ops.EPI_NONE, "gelu_bwd": ops.EPI_GELU_BWD, "add": ops.EPI_ADD}[epi]
+    dx, dw, db = ops.dgrad_wgrad(dy, w, x, epilogue=e, aux=aux)
+    dx_ref = dy.double() @ w.double()
+    if epi == "gelu_bwd":
+        dx_ref = dx_ref * aux.double()
+    elif epi == "add":
+        dx_ref = dx_ref + aux.double()
+    assert _rel(dx, dx_ref) < 3e-6
+    assert _rel(dw, dy.double().t() @ x.double()) < 3e-6
+    assert _rel(db, dy.double().sum(0)) < 3e-6
+    dx2, dw2, db2 = ops.dgrad_wgrad(dy, w, x, epilogue=e, aux=aux)
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2)
+    ops.set_gemm_list(False)                            # one by one: msn_sgemm + msn_wgrad_bias
+    try:
+        dx3, dw3, db3 = ops.dgrad_wgrad(dy, w, x, epilogue=e, aux=aux)
+        dw4, db4 = ops.wgrad_bias(dy, x)
+        assert torch.equal(dw3, dw4) and torch.equal(db3, db4)
+    finally:
+        ops.set_gemm_list(True)
+    for got, other in ((dx, dx3), (dw, dw3), (db, db3)):         # another k order: last bits only
+        assert float((got - other).abs().max()) <= 2e-5 * float(other.abs().max())
+
+
+def test_products_the_list_kernel_does_not_take_fall_back():
+    """Narrow outputs (the reference towers' emb-64 Linear) and K % 32 != 0 run one by one with the same results."""
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for rows, n_in, n_out in [(25600, 64, 256), (25600, 256, 64), (1000, 48, 200), (520, 384, 384)]:
+        dy, w, x = (torch.randn(rows, n_out, device="cuda", generator=g), torch.randn(n_out, n_in, device="cuda", generator=g),
+                    torch.randn(rows, n_in, device="cuda", generator=g))
+        dx, dw, db = ops.dgrad_wgrad(dy, w, x)
+        assert torch.equal(dx, ops.sgemm(dy, w, 0, 0))
+        dw2, db2 = ops.wgrad_bias(dy, x)
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)
+        dx3, dw3, db3 = ops.dgrad_wgrad(dy, w, x, want_bias=False)
+        assert db3 is None and _rel(dw3, dy.double().t() @ x.double()) < 3e-6
+
+
+def test_two_streams_use_their_own_counters():
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(11)
+    dy, w, x = (torch.randn(8320, 1536, device="cuda", generator=g), torch.randn(1536, 384, device="cuda", generator=g) * 0.1,
+                torch.randn(8320, 384, device="cuda", generator=g))
+    want = ops.dgrad_wgrad(dy, w, x)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for _ in range(4):
+        for s in (s1, s2):
+            with torch.cuda.stream(s):
+                outs.append(ops.dgrad_wgrad(dy, w, x))
+    torch.cuda.synchronize()
+    for o in outs:
+        assert all(torch.equal(a, b) for a, b in zip(o, want))
+
+
+@pytest.mark.parametrize("mode", [1, 3])
+def test_vit_block_backward_with_paired_launches(mode):
+    """Every gradient of a pre-norm ViT block (B = 128 cutouts, 65 tokens, e = 384) with the Linear backward pairs as
+    work-list launches == the one-product-per-launch backward, to fp32 rounding; and twice the same bits."""
+    from multimodal_supernovae_amd import functional as F
+    torch.manual_seed(3)
+    B, T, e, heads = 128, 65, 384, 6
+    x = torch.randn(B, T, e, device="cuda", requires_grad=True)
+    mk = lambda *s: (torch.randn(*s, device="cuda") * 0.05).requires_grad_()
+    P = [torch.ones(e, device="cuda", requires_grad=True), mk(e), mk(3 * e, e), mk(3 * e), mk(e, e), mk(e),
+         torch.ones(e, device="cuda", requires_grad=True), mk(e), mk(4 * e, e), mk(4 * e), mk(e, 4 * e), mk(e)]
+    cot = torch.randn(B, T, e, device="cuda")
+
+    def grads(pair):
+        old, F.PAIR_BACKWARD = F.PAIR_BACKWARD, str(pair)
+        try:
+            out = F.pre_norm_block(x, heads, P)
+            return torch.autograd.grad(out, [x] + P, cot)
+        finally:
+            F.PAIR_BACKWARD = old
+
+    base, paired, again = grads(0), grads(mode), grads(mode)
+    for a, b, c in zip(base, paired, again):
+        assert torch.equal(b, c)
+        assert float((a - b).abs().max()) <= 3e-5 * float(a.abs().max())

@@ -263,3 +263,19 @@ def test_validation_loop_values(name):
                 count += 1
         assert count == 4
     assert f.cfg["logged_keys"][:3] == ["val_loss"] * 3
+
+
+@pytest.mark.parametrize("name", golden_names("augment_"))
+def test_series_augmentation_matches_reference_loader(name):
+    """oracle.augment.series_noise on the field the REAL NoisyDataLoader drew == the batch it yielded (bit for bit)."""
+    from oracle import augment as oaug
+    fx = Fixture(name)
+    checked = 0
+    for key, want in fx.out.items():
+        b, what = key.split(".")
+        kind = what.split("_")[1]
+        got = oaug.series_noise(fx.groups["in"][f"{b}.x_{kind}"], fx.groups["in"][f"{b}.err_{kind}"],
+                                fx.groups["in"][f"{b}.field_{kind}"], fx.cfg["noise_level_mag"])
+        assert torch.equal(got, want), key
+        checked += 1
+    assert checked == fx.cfg["batches"] * len(fx.cfg["combinations"])

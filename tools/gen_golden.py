@@ -504,6 +504,62 @@ def gen_val_loop(ref_mm):
         save(name, cfg=cfg, P=sd_of(model), **{"in": ins, "out": out})
 
 
+def gen_augment():
+    """Row f3: NoisyDataLoader.__iter__ (ref src/dataloader.py:88-240) run for the combinations whose branches need no
+    torchvision -- {lightcurve} (:119-126), {spectral} (:128-137), {spectral, lightcurve} (:215-238) -- under
+    torch.manual_seed.  The loader is given its own torch.Generator for the sampler / worker seed, so the GLOBAL stream the
+    branch draws its Gaussian fields from starts right at the seed: the fields are replayed here, asserted to reproduce the
+    loader's output bit for bit, and stored with it.  The image branches (:96-114: uniform noise + torchvision's
+    RandomRotation) cannot be run in this image (torchvision is absent) and stay unpinned."""
+    import importlib
+    for name in ["astropy.cosmology", "PIL", "PIL.Image"]:       # inert stand-ins: none of them is touched by __iter__
+        try:
+            importlib.import_module(name)
+        except Exception:
+            _stub(name)
+    dl = importlib.import_module("src.dataloader")
+    from torch.utils.data import TensorDataset
+    g = torch.Generator().manual_seed(77)
+    n, t_lc, t_sp = 10, 24, 40
+
+    def series(t):
+        x = torch.randn(n, t, generator=g)
+        tt = torch.sort(torch.rand(n, t, generator=g) * 100.0, dim=1)[0]
+        mask = torch.rand(n, t, generator=g) > 0.2
+        err = torch.rand(n, t, generator=g) * 0.5 + 0.01
+        return x, tt, mask, err
+
+    mag, time, mask, magerr = series(t_lc)
+    spec, freq, maskspec, specerr = series(t_sp)
+    red, cls = torch.rand(n, generator=g), torch.randint(0, 5, (n,), generator=g)
+    cases = {"lightcurve": ((mag, time, mask, magerr, red, cls), ["lightcurve"], 0.7, 4),
+             "spectral": ((spec, freq, maskspec, specerr, red, cls), ["spectral"], 1.3, 5),
+             "lc_sp": ((mag, time, mask, magerr, spec, freq, maskspec, specerr, red, cls), ["spectral", "lightcurve"], 0.9, 4)}
+    for name, (tensors, combos, level, bs) in cases.items():
+        loader = dl.NoisyDataLoader(TensorDataset(*tensors), batch_size=bs, noise_level_img=0.25, noise_level_mag=level,
+                                    combinations=list(combos), shuffle=False, generator=torch.Generator().manual_seed(5))
+        seed = 1000 + len(name)
+        torch.manual_seed(seed)
+        outs = list(loader)
+        # replay of the global stream: per batch, one field per noisy series in the order the branch draws them
+        torch.manual_seed(seed)
+        ins, out = {}, {}
+        for bi, o in enumerate(outs):
+            lo, hi = bi * bs, min(n, (bi + 1) * bs)
+            if "lightcurve" in combos:
+                f = torch.randn_like(mag[lo:hi])
+                assert torch.equal(o[1], mag[lo:hi] + f * magerr[lo:hi] * level), name
+                assert torch.equal(o[2], time[lo:hi]) and torch.equal(o[3], mask[lo:hi])
+                ins[f"b{bi}.x_lc"], ins[f"b{bi}.err_lc"], ins[f"b{bi}.field_lc"], out[f"b{bi}.x_lc"] = mag[lo:hi], magerr[lo:hi], f, o[1]
+            if "spectral" in combos:
+                f = torch.randn_like(spec[lo:hi])
+                assert torch.equal(o[4], spec[lo:hi] + f * specerr[lo:hi] * level), name
+                ins[f"b{bi}.x_sp"], ins[f"b{bi}.err_sp"], ins[f"b{bi}.field_sp"], out[f"b{bi}.x_sp"] = spec[lo:hi], specerr[lo:hi], f, o[4]
+            assert o[0] is None and len(o) == 9
+        save(f"augment_{name}", cfg={"combinations": combos, "noise_level_mag": level, "batch_size": bs, "batches": len(outs),
+                                     "seed": seed}, **{"in": ins, "out": out})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -513,7 +569,7 @@ def main():
     jobs = {"loss": lambda: gen_loss(ref_loss), "transformer": lambda: gen_transformer(ref_tr),
             "convmixer_mlp": lambda: gen_convmixer_mlp(ref_mm), "clip": lambda: gen_clip(ref_mm),
             "real_checkpoint": lambda: gen_real_checkpoint(ref_mm), "auc": gen_auc, "pretraining": gen_pretraining, "random_masks": gen_random_masks,
-            "val_loop": lambda: gen_val_loop(ref_mm)}
+            "val_loop": lambda: gen_val_loop(ref_mm), "augment": gen_augment}
     for name, job in jobs.items():        # each generator seeds its own torch.Generator: independent of the others
         if only is None or name in only:
             job()
