@@ -110,8 +110,9 @@ int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, const float* A,
  * sums of A, i.e. the bias gradient of the same Linear.  Products the kernel does not take (N or M <= 64, K % 32 != 0,
  * unaligned operands, precision != fp32) are issued one by one through msn_sgemm / msn_wgrad_bias -- same results as
  * calling those.  Against the one-by-one path the list kernel's results differ in the last bits (another k order).
- * msn_set_gemm_list(0) forces the one-by-one path (measurements).  msn_set_gemm_streamk(t): msn_sgemm itself takes the
- * list kernel for an opA = N product of at most t 128 x 128 tiles (0 = never). */
+ * msn_set_gemm_list(0) forces the one-by-one path (measurements).  msn_set_gemm_streamk(t, k): msn_sgemm itself takes the
+ * list kernel for an opA = N product of at most t 128 x 128 tiles and K >= k (t = 0: never; default t = 1024, k = 1024:
+ * the long-K products of an under-filled launch, where the balance gained outweighs the slabs of the cut tiles). */
 typedef struct msn_gemm_desc {
     int opA, opB;
     int64_t M, N, K;
@@ -130,7 +131,7 @@ typedef struct msn_gemm_desc {
 size_t msn_sgemm_list_workspace_bytes(int n, const msn_gemm_desc* products);
 int msn_sgemm_list(int n, const msn_gemm_desc* products, int precision, void* ws, size_t ws_bytes, msn_stream_t stream);
 int msn_set_gemm_list(int enabled);
-int msn_set_gemm_streamk(int max_tiles);
+int msn_set_gemm_streamk(int max_tiles, int min_k);
 /* Zero the arrival counters of the in-kernel tile finishes (tail split, work-list launch) of the current device: they
  * are zero between launches by construction, but a launch that faulted or was aborted half-way leaves them dirty. */
 int msn_reset_gemm_counters(msn_stream_t stream);

@@ -29,7 +29,7 @@ SIGNATURES = {
     "msn_sgemm_list_workspace_bytes": (c_size, [c_int, c_ptr]),
     "msn_sgemm_list": (c_int, [c_int, c_ptr, c_int, c_ptr, c_size, c_ptr]),
     "msn_set_gemm_list": (c_int, [c_int]),
-    "msn_set_gemm_streamk": (c_int, [c_int]),
+    "msn_set_gemm_streamk": (c_int, [c_int, c_int]),
     "msn_reset_gemm_counters": (c_int, [c_ptr]),
     "msn_set_gemm_variant": (c_int, [c_int]),
     "msn_set_bgemm_persistent": (c_int, [c_int]),

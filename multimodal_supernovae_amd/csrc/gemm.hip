@@ -556,7 +556,8 @@ static unsigned* tail_counter_slice(hipStream_t st) {
     return d.base + (size_t)(d.used++) * kTailSliceTiles;
 }
 unsigned* gemm_counter_slice(hipStream_t st) { return tail_counter_slice(st); }
-static int g_gemm_streamk = 0;   // msn_sgemm: opA = N products of at most this many 128 x 128 tiles take the work-list kernel (0 = never)
+static int g_gemm_streamk = 1024, g_gemm_streamk_min_k = 1024;   // msn_sgemm: opA = N products of at most this many 128 x 128 tiles and at
+                                                                 // least this K take the work-list kernel (0 tiles = never)
 static int g_gemm_bn = 0;        // measurement switch (msn_set_gemm_tile_n): 0 = planned, 64 / 128 = forced tile width for N > 64
 
 // Launch geometry of one product.
@@ -651,7 +652,7 @@ extern "C" int msn_debug_timeline(unsigned long long* buf) {
 // msn_sgemm's own use of the work-list kernel: an under-filled forward / dgrad product (shape test only; operand
 // alignment is checked at the call)
 static bool streamk_shape(int opA, int64_t M, int64_t N, int64_t K) {
-    return g_gemm_streamk > 0 && opA == MSN_OP_N && M > 64 && N > 64 && K % BK == 0 && g_gemm_bn == 0 &&
+    return g_gemm_streamk > 0 && opA == MSN_OP_N && M > 64 && N > 64 && K % BK == 0 && K >= g_gemm_streamk_min_k && g_gemm_bn == 0 &&
            cdiv(M, 128) * cdiv(N, 128) <= g_gemm_streamk && cdiv(M, 128) * cdiv(N, 128) * (K / BK) >= 64;
 }
 
@@ -920,9 +921,10 @@ extern "C" int msn_wgrad_bias(int64_t M, int64_t N, int64_t K, const float* dY, 
     return msn_colsum(dY, lddy, K, M, db, ws, ws_bytes, stream);   // shapes / precisions the fused kernel does not take
 }
 
-extern "C" int msn_set_gemm_streamk(int max_tiles) {
-    MSN_REQUIRE(max_tiles >= 0, "msn_set_gemm_streamk: a tile count >= 0");
+extern "C" int msn_set_gemm_streamk(int max_tiles, int min_k) {
+    MSN_REQUIRE(max_tiles >= 0 && min_k >= 0, "msn_set_gemm_streamk: a tile count and a K, both >= 0");
     g_gemm_streamk = max_tiles;
+    g_gemm_streamk_min_k = min_k;
     return MSN_OK;
 }
 

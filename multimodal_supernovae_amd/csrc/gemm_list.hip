@@ -258,7 +258,7 @@ typedef __attribute__((address_space(4))) const void kernarg_ptr_t;
 __global__ __launch_bounds__(64 * LNW, 2) void sgemm_list_kernel(const ListArgs list_by_value) {
     __shared__ __attribute__((aligned(16))) float smem[LSTAGES * 2 * LT * BK];
     (void)list_by_value;
-    const ListArgs& L = *reinterpret_cast<const ListArgs*>((kernarg_ptr_t*)__builtin_amdgcn_kernarg_segment_ptr());
+    const ListArgs& L = *(const ListArgs*)(kernarg_ptr_t*)__builtin_amdgcn_kernarg_segment_ptr();
     const int r = xcd_remap((int)blockIdx.x, L.G);
     const long long lo = range_lo(L, r), end = range_lo(L, r + 1);
     long long pos = lo;

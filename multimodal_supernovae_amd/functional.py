@@ -580,9 +580,14 @@ PAIR_BACKWARD = os.environ.get("MSN_PAIR_BACKWARD")
 
 
 def _pair_backward(rows):
+    """Which Linear backward pairs of a ViT block run as one work-list launch.  Measured on the headline step
+    (profiles/r03_gemm_worklist_vs_flat.txt): with up to ~40 000 token rows (512 cutouts x 65 tokens) the launch of the
+    wide products (qkv, ff1, ff2) is under-filled and the pair wins 7-16 % over dgrad + wgrad + split-K sum; at 66 560 rows
+    the flat launches are full and win; the e x e projection loses at every size (its two products are too short for
+    the slabs of the cut tiles)."""
     if PAIR_BACKWARD is not None:
         return int(PAIR_BACKWARD)
-    return 0
+    return 1 if rows <= 40000 else 0
 
 
 def pre_norm_block(x, heads, p, eps=1e-6):

@@ -137,9 +137,10 @@ def set_gemm_list(enabled):
     check(lib().msn_set_gemm_list(int(bool(enabled))))
 
 
-def set_gemm_streamk(max_tiles):
-    """msn_sgemm itself takes the work-list kernel for opA = N products of at most `max_tiles` 128 x 128 tiles (0 = never)."""
-    check(lib().msn_set_gemm_streamk(int(max_tiles)))
+def set_gemm_streamk(max_tiles=1024, min_k=1024):
+    """msn_sgemm itself takes the work-list kernel for opA = N products of at most `max_tiles` 128 x 128 tiles with
+    K >= min_k (max_tiles = 0: never; the defaults are the library's)."""
+    check(lib().msn_set_gemm_streamk(int(max_tiles), int(min_k)))
 
 
 def _gemm_desc(a, b, op_a, op_b, c, bias=None, epilogue=EPI_NONE, aux=None, colsum_out=None):
