@@ -292,8 +292,9 @@ def main():
     ap.add_argument("--gemm-precision", default="f32", choices=["f32", "bf16x3", "bf16"],
                     help="inner-product precision of the GEMMs (bf16x3 = split-bf16, fp32-grade accuracy)")
     ap.add_argument("--graphed", action="store_true",
-                    help="N = 1: record the training step as a HIP graph (trainer.GraphedTrainStep) and time its replays -- "
-                         "what the reference's own batch sizes (32 ... 256), which are launch-bound when run eagerly, gain")
+                    help="record the training step as HIP graphs (trainer.GraphedTrainStep; N > 1: segments between the host-driven "
+                         "exchanges) and time its replays -- what launch-bound batches (the reference's 32 ... 256, or the "
+                         "128 rows per GPU of the global batch on 8 GPUs) gain")
     ap.add_argument("--sync-batchnorm", action="store_true",
                     help="N > 1, BatchNorm towers (resnet18_cnn1d, convmixer_lc_sp): batch statistics over all ranks")
     ap.add_argument("--cpu-sample-batch", type=int, default=32)
@@ -337,7 +338,8 @@ def main():
     if args.sync_batchnorm and world > 1:
         D.enable_sync_batchnorm()
     opt = model.configure_optimizers()["optimizer"]
-    reducer = D.GradientReducer(model.parameters())   # N > 1: bucketed SUM all-reduce launched from autograd hooks, under backward
+    # N > 1: bucketed SUM all-reduce launched from autograd hooks, under backward (graph replay: every bucket after backward)
+    reducer = D.GradientReducer(model.parameters(), overlap=not args.graphed)
 
     from multimodal_supernovae_amd.trainer import _backward_seed
 
@@ -354,10 +356,8 @@ def main():
     step = make_step(model, opt, reducer, batch)
 
     if args.graphed:
-        if world != 1:
-            raise SystemExit("--graphed is a single-GPU measurement")
         from multimodal_supernovae_amd.trainer import GraphedTrainStep
-        graphed = GraphedTrainStep(model, opt, warmup=3)
+        graphed = GraphedTrainStep(model, opt, warmup=3, reducer=reducer)
         args.warmup = max(args.warmup, 5)          # 3 eager steps, the capture, one replay
         args.no_alt = True
         eager_step = step

@@ -45,22 +45,44 @@ class _Logged:
             COMM_LOG.append(tuple(self.entry))
 
 
+# Segmented HIP-graph capture of a data-parallel step (trainer.GraphedTrainStep): while a step is being recorded, every
+# collective issued through this module ENDS the graph segment under capture, runs for real between two segments (the
+# exchange is host-driven: gloo cannot be captured at all, and RCCL then needs no capture support either) and a new segment
+# begins behind it.  The object installed here implements exchange(fn): "close the segment, remember fn, open the next".
+SEGMENTED_CAPTURE = None
+
+
+def _exchange(fn):
+    """Run the collective(s) of `fn` -- now, or as the break between two graph segments of a step being recorded."""
+    if SEGMENTED_CAPTURE is not None:
+        SEGMENTED_CAPTURE.exchange(fn)
+    else:
+        fn()
+
+
 def all_gather_rows(t, group=None, kind="all_gather"):
     """All-gather equal-sized row blocks -> (world * b, ...) in rank order (no autograd)."""
     world = dist.get_world_size(group)
     t = t.contiguous()
     out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    log = _Logged(kind, out)
-    dist.all_gather_into_tensor(out, t, group=group)
-    log.done()
+
+    def run():
+        log = _Logged(kind, out)
+        dist.all_gather_into_tensor(out, t, group=group)
+        log.done()
+
+    _exchange(run)
     return out
 
 
 def all_reduce_sum(t, group=None, kind="all_reduce"):
     """In-place SUM all-reduce (no autograd)."""
-    log = _Logged(kind, t)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    log.done()
+    def run():
+        log = _Logged(kind, t)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        log.done()
+
+    _exchange(run)
     return t
 
 
@@ -159,8 +181,9 @@ class GradientReducer:
     Every rank must build it over the same parameter list.
     """
 
-    def __init__(self, params, group=None, bucket_bytes=32 << 20, force=False):
+    def __init__(self, params, group=None, bucket_bytes=32 << 20, force=False, overlap=True):
         self.group = group
+        self.overlap = overlap            # False: no autograd hooks, every bucket is reduced in finish() (graph-replayed steps)
         self.world = world_size(group)
         self.buckets = []
         self._where = {}
@@ -189,7 +212,8 @@ class GradientReducer:
             self.buckets.append({"params": plist, "flat": flat, "views": views, "ready": 0, "work": None, "events": []})
             for p in plist:
                 self._where[p] = bi
-                self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+                if overlap:
+                    self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     def _on_grad(self, p):
         b = self.buckets[self._where[p]]
@@ -202,6 +226,25 @@ class GradientReducer:
         b["ready"] += 1
         if b["ready"] == len(b["params"]) and b["work"] is None:
             self._launch(b)
+
+    @torch.no_grad()
+    def _gather(self, b):
+        """Copy a bucket's gradients into its flat buffer and re-point .grad at the slices (no collective)."""
+        if b["events"]:
+            cur = torch.cuda.current_stream(b["flat"].device)
+            for ev in b["events"]:
+                cur.wait_event(ev)
+            b["events"] = []
+        have = [(v, p.grad) for v, p in zip(b["views"], b["params"]) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        missing = any(p.grad is None for p in b["params"])
+        if missing:
+            for v, p in zip(b["views"], b["params"]):
+                if p.grad is None:
+                    v.zero_()
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for v, p in zip(b["views"], b["params"]):
+            p.grad = v
 
     @torch.no_grad()
     def _launch(self, b):
@@ -228,6 +271,21 @@ class GradientReducer:
             p.grad = v
 
     def finish(self):
+        if not self.buckets:
+            return
+        if not self.overlap:
+            # deferred form: gather every bucket, then all the all-reduces as ONE exchange (one break of a recorded step)
+            for b in self.buckets:
+                self._gather(b)
+
+            def run():
+                for b in self.buckets:
+                    log = _Logged("grad_all_reduce", b["flat"])
+                    dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group)
+                    log.done()
+
+            _exchange(run)
+            return
         for b in self.buckets:
             if b["work"] is None:
                 self._launch(b)

@@ -83,7 +83,7 @@ class Trainer:
         self.group = group
         self.log_fn = log_fn
         self.sync_batchnorm = sync_batchnorm   # pl.Trainer(sync_batchnorm=...): batch statistics over all ranks
-        self.graphed_steps = graphed_steps     # single process: replay the training step as a HIP graph (GraphedTrainStep)
+        self.graphed_steps = graphed_steps     # replay the training step as HIP graphs (GraphedTrainStep; any world size)
         self.history = {"train_loss": [], "val_loss": []}
         self.step_losses = []
         self.global_step = 0
@@ -95,12 +95,13 @@ class Trainer:
         optim_config = model.configure_optimizers()
         optimizer = optim_config["optimizer"]
         self.optimizer = optimizer
-        reducer = D.GradientReducer(model.parameters(), group=self.group)   # bucket all-reduces run under backward
+        # bucket all-reduces run under backward; a graph-replayed step reduces every bucket after backward (deferred form)
+        reducer = D.GradientReducer(model.parameters(), group=self.group, overlap=not self.graphed_steps)
         world = D.world_size(self.group)
         if world > 1:
             _check_sharded_loader(train_dataloaders, self.group, "train_dataloaders")
         scheduler = self._scheduler_of(optim_config)
-        graphed = GraphedTrainStep(model.train(), optimizer) if self.graphed_steps and D.world_size(self.group) == 1 else None
+        graphed = GraphedTrainStep(model.train(), optimizer, reducer=reducer, group=self.group) if self.graphed_steps else None
         for epoch in range(self.max_epochs):
             model.train()
             _hook(model, "on_train_epoch_start")
@@ -172,26 +173,86 @@ class Trainer:
             self.history["val_loss"].append(float(acc[0] / acc[1]))
 
 
-class GraphedTrainStep:
-    """One training step (zero_grad -> training_step -> backward -> RAdam) recorded as a HIP graph and replayed.
+class _RecordedStep:
+    """A training step recorded as HIP-graph SEGMENTS separated by host-driven exchanges.  While it records it is installed
+    as distributed.SEGMENTED_CAPTURE: every collective issued through distributed.py closes the segment under capture,
+    runs for real (so that all ranks stay in step; the data it moves during the recording pass is meaningless) and opens
+    the next segment.  All segments allocate from ONE private pool, so a tensor produced in one segment and consumed in a
+    later one keeps its address.  replay() = segment, exchange, segment, ... in the recorded order."""
 
-    The reference's own batch sizes (32 ... 256) leave the GPU waiting for the host: a Maven step issues ~1300 launches
-    and takes ~10 ms of host time whatever the batch, 1.5 ms of GPU time at batch 32.  The first `warmup` calls run
-    eagerly (they are real steps: moment buffers, allocator, code objects); the next call captures the step on the
-    caller's batch shapes and every later call copies its batch into the captured input tensors and replays.
-    Restrictions: fixed batch shapes (others run eagerly), a single process (the gradient all-reduce is not captured).
+    def __init__(self, device):
+        self.device = device
+        self.items = []                 # ("graph", CUDAGraph) | ("call", fn)
+        self.pool = torch.cuda.graph_pool_handle()
+        self.cur = None
+
+    def begin(self):
+        self.cur = torch.cuda.CUDAGraph()
+        self.cur.capture_begin(pool=self.pool)
+
+    def exchange(self, fn):
+        self.cur.capture_end()
+        self.items.append(("graph", self.cur))
+        fn()
+        self.items.append(("call", fn))
+        self.begin()
+
+    def end(self):
+        self.cur.capture_end()
+        self.items.append(("graph", self.cur))
+        self.cur = None
+
+    def replay(self):
+        for kind, x in self.items:
+            if kind == "graph":
+                x.replay()
+            else:
+                x()
+
+    @property
+    def segments(self):
+        return sum(1 for k, _ in self.items if k == "graph")
+
+    @property
+    def exchanges(self):
+        return sum(1 for k, _ in self.items if k == "call")
+
+
+class GraphedTrainStep:
+    """One training step (zero_grad -> training_step -> backward -> gradient all-reduce -> RAdam) recorded as HIP graphs
+    and replayed.
+
+    The reference's own batch sizes (32 ... 256) -- and the 128 ... 256 rows a rank keeps when the global batch of 1024 is
+    spread over 4 or 8 GPUs -- leave the GPU waiting for the host: a Maven step issues ~1300 launches and takes ~10 ms of
+    host time whatever the batch, 1.5 ms of GPU time at batch 32.  The first `warmup` calls run eagerly (they are real
+    steps: moment buffers, allocator, code objects); the next call records the step on the caller's batch shapes and every
+    later call copies its batch into the recorded input tensors and replays.
+
+    Data parallel (world size > 1): the step is recorded in SEGMENTS around its exchanges (_RecordedStep): embedding
+    all-gather | InfoNCE forward | LSE all-gather | loss all-reduce | backward of the loss and the towers + gather of the
+    gradient buckets | SUM all-reduce of the buckets | RAdam.  The collectives stay host-driven between two graph replays
+    (gloo cannot be captured at all; RCCL needs no capture support this way), so the gradient reduction is the deferred
+    form of GradientReducer (overlap=False: every bucket after backward) -- pass such a reducer or none.
+    Restrictions: fixed batch shapes (others run eagerly, with the same reducer); synchronised BatchNorm issues
+    collectives from inside autograd's backward threads and is refused.
     Dropout seeds are device-resident inside the graph (a base that one launch per replay advances + the ordinal of
-    the call), so every replay draws new masks.  The towers' side streams fork from and join the capturing stream, so
-    the graph keeps their concurrency.
+    the call), so every replay draws new masks.  The towers' side streams fork from and join the capturing stream, so the
+    graph keeps their concurrency.
 
         step = GraphedTrainStep(model, model.configure_optimizers()["optimizer"])
         for batch in loader: loss = step(batch)          # `loss` is a device tensor overwritten by the next call
     """
 
-    def __init__(self, model, optimizer, warmup=3, concurrent_towers=None):
+    def __init__(self, model, optimizer, warmup=3, concurrent_towers=None, reducer=None, group=None):
         self.concurrent_towers = concurrent_towers      # None: as the model is set (towers fork / join inside the graph)
-        if D.world_size() > 1:
-            raise RuntimeError("GraphedTrainStep is single-process (the gradient all-reduce is not captured)")
+        self.group = group
+        self.world = D.world_size(group)
+        if self.world > 1 and reducer is None:
+            reducer = D.GradientReducer(model.parameters(), group=group, overlap=False)
+        if reducer is not None and reducer.buckets and reducer.overlap:
+            raise RuntimeError("GraphedTrainStep needs the deferred GradientReducer (overlap=False): hook-driven all-reduces "
+                               "would be issued from autograd's threads in the middle of a graph segment")
+        self.reducer = reducer
         self.model, self.optimizer, self.warmup = model, optimizer, int(warmup)
         self.calls, self.graph, self.static, self.loss = 0, None, None, None
 
@@ -199,33 +260,51 @@ class GraphedTrainStep:
         self.optimizer.zero_grad(set_to_none=True)
         loss = self.model.training_step(batch, batch_idx)
         loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
         self.optimizer.step()
         return loss
 
     def _capture(self, batch):
         model = self.model
+        from . import ops
+        if self.world > 1 and ops.BN_SYNC_GROUP is not None:
+            raise RuntimeError("GraphedTrainStep: synchronised BatchNorm exchanges statistics from inside backward and "
+                               "cannot be recorded; use per-replica statistics or the eager step")
         self.static = tuple(t.clone() if torch.is_tensor(t) else t for t in batch)
         concurrent = getattr(model, "concurrent_towers", False)
         if self.concurrent_towers is not None:
             model.concurrent_towers = bool(self.concurrent_towers)
-        self.graph = torch.cuda.CUDAGraph()
         self.optimizer.zero_grad(set_to_none=True)
         self.optimizer.graph_prepare()        # device copies of the hyper-parameters and the step count (eager)
         import gc
         gc.collect()                          # no autograd graph of an earlier step (bound to other streams) may survive
-        from . import ops
-        seed0 = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(self.static_device(), non_blocking=False)
+        device = self.static_device()
+        seed0 = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(device, non_blocking=False)
         ops.GRAPH_SEED = [seed0, 0]
         self._seed_base = seed0
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        rec = _RecordedStep(device)
+        stream = torch.cuda.Stream(device=device)
+        stream.wait_stream(torch.cuda.current_stream(device))
+        D.SEGMENTED_CAPTURE = rec
         try:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.stream(stream):
+                rec.begin()
                 ops.graph_seed_advance()
                 self.loss = model.training_step(self.static, 0)
                 self.loss.backward()
+                if self.reducer is not None:
+                    self.reducer.finish()
                 self.optimizer.step()
+                rec.end()
         finally:
+            D.SEGMENTED_CAPTURE = None
             ops.GRAPH_SEED = None
             model.concurrent_towers = concurrent
+        torch.cuda.current_stream(device).wait_stream(stream)
+        self.graph = rec
 
     def static_device(self):
         return next(t.device for t in self.static if torch.is_tensor(t))

@@ -64,3 +64,11 @@ def test_trainer_validation_with_uneven_shards_two_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dist_check.py"), "--trainer"], capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "DIST CHECK OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_graph_replayed_data_parallel_step_equals_eager_steps_bit_for_bit():
+    """trainer.GraphedTrainStep with two ranks (segmented capture: graph segments between the host-driven exchanges): seven
+    steps incl. two eager warm-up steps, the recording, replays and one short batch == the same steps issued eagerly."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dist_check.py"), "--graphed"], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "DIST CHECK OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

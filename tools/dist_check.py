@@ -18,6 +18,7 @@ SK = dict(n_out=8, emb=8, heads=2, depth=2, dropout=0.0, time_norm=17945.14, agg
 CK = dict(dim=8, depth=2, channels=3, kernel_size=5, patch_size=4, n_out=8, dropout_prob=0.0)
 BATCHNORM = "--batchnorm" in sys.argv     # ConvMixer image tower + light curves, synchronised BatchNorm
 TRAINER = "--trainer" in sys.argv         # Trainer.fit with a validation loader whose shards are UNEVEN across the ranks
+GRAPHED = "--graphed" in sys.argv         # GraphedTrainStep under data parallel (segmented capture) == the eager steps, bit for bit
 
 
 def make_model():
@@ -76,6 +77,55 @@ def trainer_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def graphed_worker(rank, world, port, out):
+    """Seven data-parallel steps (two eager warm-up steps, the recording, replays, ONE SHORT BATCH in between that runs
+    eagerly) through trainer.GraphedTrainStep against the same seven steps issued eagerly with the hook-driven reducer:
+    every loss and every parameter must be bit-identical on both ranks."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from multimodal_supernovae_amd import distributed as D
+    from multimodal_supernovae_amd.trainer import GraphedTrainStep
+    D.init_from_env(backend="gloo")
+    b, steps, short_at = 8, 7, 4
+    full = make_batch(steps * world * b)
+    batches = []
+    for i in range(steps):
+        lo = (i * world + rank) * b
+        rows = 5 if i == short_at else b
+        batches.append(tuple(t[lo:lo + rows].cuda() if t is not None else None for t in full))
+
+    def run(graphed):
+        model = make_model()
+        D.broadcast_module(model)
+        opt = model.configure_optimizers()["optimizer"]
+        losses = []
+        if graphed:
+            step = GraphedTrainStep(model, opt, warmup=2)
+            for i, batch in enumerate(batches):
+                losses.append(float(step(batch, i).detach()))
+            info = (step.graph.segments, step.graph.exchanges)
+        else:
+            reducer = D.GradientReducer(model.parameters(), bucket_bytes=64 << 10)
+            for i, batch in enumerate(batches):
+                opt.zero_grad(set_to_none=True)
+                loss = model.training_step(batch, i)
+                loss.backward()
+                reducer.finish()
+                opt.step()
+                losses.append(float(loss.detach()))
+            reducer.remove()
+            info = None
+        torch.cuda.synchronize()
+        return [p.detach().clone() for p in model.parameters()], losses, info
+
+    pe, le, _ = run(False)
+    pg, lg, info = run(True)
+    same_params = all(torch.equal(a, c) for a, c in zip(pe, pg))
+    worst = max(float((a - c).abs().max()) for a, c in zip(pe, pg))
+    out[f"r{rank}"] = (same_params, le == lg, worst, le, lg, info)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     from multimodal_supernovae_amd import distributed as D
@@ -121,6 +171,16 @@ def worker(rank, world, port, out):
 if __name__ == "__main__":
     ctx = mp.get_context("spawn")
     out = ctx.Manager().dict()
+    if GRAPHED:
+        procs = [ctx.Process(target=graphed_worker, args=(r, 2, 29615, out)) for r in range(2)]
+        [p.start() for p in procs]
+        [p.join(300) for p in procs]
+        print(dict(out), [p.exitcode for p in procs])
+        ok = all(p.exitcode == 0 for p in procs) and len(out) == 2
+        for same_params, same_losses, worst, le, lg, info in out.values():
+            ok = ok and same_params and same_losses and len(le) == 7 and info[0] >= 4 and info[1] >= 4
+        print("DIST CHECK", "OK" if ok else "FAILED")
+        sys.exit(0 if ok else 1)
     if TRAINER:
         procs = [ctx.Process(target=trainer_worker, args=(r, 2, 29613, out)) for r in range(2)]
         [p.start() for p in procs]
