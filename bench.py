@@ -309,6 +309,8 @@ def main():
     ops.set_gemm_precision(args.gemm_precision)
     ops.set_gemm_variant(args.gemm_variant)
     ops.set_gemm_tail_split(args.gemm_tail)
+    if os.environ.get("MSN_GEMM_LDS_PAD"):
+        _lib.check(_lib.lib().msn_set_gemm_lds_pad(int(os.environ["MSN_GEMM_LDS_PAD"])))
     if args.bgemm_one_tile:
         from multimodal_supernovae_amd import _lib
         _lib.check(_lib.lib().msn_set_bgemm_persistent(0))
@@ -343,13 +345,18 @@ def main():
 
     from multimodal_supernovae_amd.trainer import _backward_seed
 
+    from multimodal_supernovae_amd import markers     # roctx ranges (MSN_ROCTX=1): readable rocprofv3 timelines
+
     def make_step(model, opt, reducer, batch):
         def step():
             opt.zero_grad(set_to_none=True)
-            loss = model.training_step(batch, 0)
-            loss.backward(_backward_seed(loss))      # the cached seed the Trainer uses (no fill launch per step)
+            with markers.range("forward + loss"):
+                loss = model.training_step(batch, 0)
+            with markers.range("backward"):
+                loss.backward(_backward_seed(loss))      # the cached seed the Trainer uses (no fill launch per step)
             reducer.finish()
-            opt.step()
+            with markers.range("optimiser (RAdam)"):
+                opt.step()
             return loss
         return step
 
@@ -490,12 +497,18 @@ def main():
     # (FETCH_SIZE, WRITE_SIZE; tools/run_pmc.sh -> tools/summarize_pmc.py) -- counters cannot be read from inside the
     # process, so the figure is the committed one and says which commit / date it was collected at.
     traffic, traffic_source = None, None
+    if args.workload == "vit_b16_bf16_lc":
+        pmc_name = "pmc_bgemm.json"
+    elif headline and b == 1024:
+        pmc_name = "pmc_sgemm.json"
+    else:
+        pmc_name = f"pmc_sgemm_{args.workload}_b{b}.json"      # tools/run_pmc.sh --workload W --per-gpu-batch B
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_sgemm.json")))
-        if headline and b == 1024 and world == 1 and args.gemm_precision == "f32":
+        pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
+        if args.gemm_precision == "f32":       # per launch on ONE GPU: the same whatever the number of ranks (rows per GPU match)
             traffic = pmc["traffic_bytes_per_launch"]
-            traffic_source = ("profiles/pmc_sgemm.json: rocprofv3 --pmc passes of `python bench.py` (tools/run_pmc.sh), "
-                              f"collected {pmc.get('collected', 'round 1')} at commit {pmc.get('commit', 'c778251')}; "
+            traffic_source = (f"profiles/{pmc_name}: rocprofv3 --pmc passes of `{pmc.get('workload', 'python bench.py')}` "
+                              f"(tools/run_pmc.sh), collected {pmc.get('collected', '?')} at commit {pmc.get('commit', '?')}; "
                               "not re-measured inside this run")
     except (OSError, ValueError, KeyError):
         pass

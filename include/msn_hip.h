@@ -93,6 +93,9 @@ int msn_set_gemm_variant(int mode);
  * same launch; 2: a finishing launch does (bit-identical: same order); 0: no slabs.  Results of the tail tiles
  * differ from the unsplit order in the last bits.  Process-wide. */
 int msn_set_gemm_tail_split(int enabled);
+/* Unused dynamic LDS (bytes) added to every launch of the 128 x 128 fp32 kernel: >= 17 KB keeps a second workgroup of
+ * the kernel off the CU and leaves half the register file + the rest of the LDS to kernels of another stream. 0 = off. */
+int msn_set_gemm_lds_pad(int bytes);
 /* Measurement switch: tile width of products with N > 64: 0 = planned (default), 64, 128. */
 int msn_set_gemm_tile_n(int bn);
 int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,

@@ -31,6 +31,7 @@ SIGNATURES = {
     "msn_set_gemm_list": (c_int, [c_int]),
     "msn_set_gemm_streamk": (c_int, [c_int, c_int]),
     "msn_reset_gemm_counters": (c_int, [c_ptr]),
+    "msn_set_gemm_lds_pad": (c_int, [c_int]),
     "msn_set_gemm_variant": (c_int, [c_int]),
     "msn_set_bgemm_persistent": (c_int, [c_int]),
     "msn_set_gemm_tail_split": (c_int, [c_int]),

@@ -810,12 +810,11 @@ static int launch_big_lds(K kernel, dim3 grid, dim3 block, size_t lds, hipStream
     return MSN_OK;
 }
 
-// Is the matrix-core path applicable?  (16-B aligned operands, head width 4/8/12/16/32/48/64, <= 256 tokens.)
-static int padded_hd(int hd) { return hd < 16 ? 16 : hd; }
+// Is the matrix-core path applicable?  (16-B aligned operands, head width a multiple of 4 up to 64: a width that is not a
+// multiple of 16 runs as the next one, its missing columns zeros in LDS / registers only.)
+static int padded_hd(int hd) { return (hd + 15) / 16 * 16; }
 bool mattn_applicable(const MAttn& a) {
-    if (!(a.hd % 16 == 0 || (a.hd < 16 && a.hd % 4 == 0)) || a.hd > 64 || a.hd < 4 || a.Tq > 65535 || a.Tk > 65535 ||
-        a.q_bs == 0)
-        return false;
+    if (a.hd % 4 != 0 || a.hd > 64 || a.hd < 4 || a.Tq > 65535 || a.Tk > 65535 || a.q_bs == 0) return false;
     if ((int64_t)a.B * a.H * ((std::max(a.Tq, a.Tk) + 127) / 128) > 0x7fffffffLL) return false;
     const int64_t lds[] = {a.ldq, a.ldk, a.ldv, a.q_bs, a.k_bs, a.v_bs};
     for (int64_t v : lds)

@@ -480,14 +480,24 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 }
 static int colsum_blocks(int64_t M) { return (int)std::min<int64_t>(cdiv(M, 16 * CS_RG), CS_MAX_BLOCKS); }
 
+// Unused dynamic LDS added to the launches of the 128 x 128 kernel (msn_set_gemm_lds_pad): with 64 KB of its own, a pad
+// of 17 KB and more keeps a SECOND workgroup of the kernel off the CU, which leaves half the register file and the rest of
+// the LDS to kernels of another stream (the light-curve / spectrum towers beside the image tower's products).
+static int g_gemm_lds_pad = 0;
+template <typename K>
+static void launch_padded(K kernel, dim3 grid, dim3 block, size_t pad, hipStream_t st, const GemmArgs& a) {
+    if (pad > 0) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+    hipLaunchKernelGGL(kernel, grid, block, pad, st, a);
+}
 template <int BM, int BN, int WM, int WN, int DBK, int STAGES>
 static int launch_dma(const GemmArgs& a, int opA, int opB, hipStream_t st) {
     const dim3 grid(gemm_grid(a)), block(64 * (BM / WM) * (BN / WN));
-    if (opA == MSN_OP_N && opB == MSN_OP_T) hipLaunchKernelGGL((sgemm_dma_kernel<BM, BN, WM, WN, false, false, DBK, STAGES>), grid, block, 0, st, a);
-    else if (opA == MSN_OP_N && opB == MSN_OP_N) hipLaunchKernelGGL((sgemm_dma_kernel<BM, BN, WM, WN, false, true, DBK, STAGES>), grid, block, 0, st, a);
-    else if (opA == MSN_OP_T && opB == MSN_OP_N && a.colsum) hipLaunchKernelGGL((sgemm_dma_kernel<BM, BN, WM, WN, true, true, DBK, STAGES, true>), grid, block, 0, st, a);
-    else if (opA == MSN_OP_T && opB == MSN_OP_N) hipLaunchKernelGGL((sgemm_dma_kernel<BM, BN, WM, WN, true, true, DBK, STAGES>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((sgemm_dma_kernel<BM, BN, WM, WN, true, false, DBK, STAGES>), grid, block, 0, st, a);
+    const size_t pad = (BM == 128 && BN == 128) ? (size_t)g_gemm_lds_pad : 0;
+    if (opA == MSN_OP_N && opB == MSN_OP_T) launch_padded(sgemm_dma_kernel<BM, BN, WM, WN, false, false, DBK, STAGES>, grid, block, pad, st, a);
+    else if (opA == MSN_OP_N && opB == MSN_OP_N) launch_padded(sgemm_dma_kernel<BM, BN, WM, WN, false, true, DBK, STAGES>, grid, block, pad, st, a);
+    else if (opA == MSN_OP_T && opB == MSN_OP_N && a.colsum) launch_padded(sgemm_dma_kernel<BM, BN, WM, WN, true, true, DBK, STAGES, true>, grid, block, pad, st, a);
+    else if (opA == MSN_OP_T && opB == MSN_OP_N) launch_padded(sgemm_dma_kernel<BM, BN, WM, WN, true, true, DBK, STAGES>, grid, block, pad, st, a);
+    else launch_padded(sgemm_dma_kernel<BM, BN, WM, WN, true, false, DBK, STAGES>, grid, block, pad, st, a);
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }
@@ -935,6 +945,12 @@ extern "C" int msn_reset_gemm_counters(msn_stream_t stream) {
         set_error("msn_reset_gemm_counters: %s", hipGetErrorString(hipGetLastError()));
         return MSN_ERR_HIP;
     }
+    return MSN_OK;
+}
+
+extern "C" int msn_set_gemm_lds_pad(int bytes) {
+    MSN_REQUIRE(bytes >= 0 && bytes <= 96 * 1024, "msn_set_gemm_lds_pad: 0 .. 98304 bytes");
+    g_gemm_lds_pad = bytes;
     return MSN_OK;
 }
 

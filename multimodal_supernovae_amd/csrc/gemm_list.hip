@@ -11,6 +11,10 @@
 // covered by as many ranges as its length needs: split-K without a split count and without a reduction launch.
 // Ranges are dealt to the XCDs in contiguous runs (xcd_remap), so neighbours in the sequence -- tiles of one row panel,
 // or K-chunks of one tile -- share that XCD's L2.
+// Hybrid: cutting costs (a 64-KB slab store per contributor + a serial re-read by the finisher), so only what must be cut
+// is: of a product with T tiles, floor(T / G) G tiles are dealt WHOLE, floor(T / G) per workgroup (tile j G + r to range r);
+// the remaining T mod G tiles of every product -- all tiles of a weight gradient -- form the sequence that is cut into equal
+// ranges.  The cut part runs first, so its slabs are on their way while everybody still has whole tiles to multiply.
 //
 // Same tile machinery as sgemm_dma_kernel<128, 128, 64, 64, .., 32, 2> (gemm.hip): LDS-DMA ring of 2 x 32-deep K-steps,
 // swizzled unpadded images, inline-asm fragment reads with counted lgkmcnt, one raw s_barrier per K-step, epilogues of
@@ -34,19 +38,23 @@ struct ListItem {
     GemmArgs g;          // A, B, C, bias, aux, sizes, epilogue; splits = 1, tiles_m / tiles_n of 128 x 128 tiles
     int kind;            // 0: A [M][K], B [N][K]   1: A [M][K], B [K][N]   2: A [K][M], B [K][N]   3: kind 2 + column sums of A
     int ksteps;          // K / 32
-    long long first;     // position of this product's first unit step in the launch's sequence
+    int whole;           // tiles dealt whole to every workgroup: tile j G + r, j < whole
+    int tile0;           // = whole * G: first tile of the part that is cut into ranges
+    long long first;     // position of tile0's first unit step in the launch's cut sequence
 };
 struct ListArgs {
     ListItem it[kListMax];
-    int n, G;
-    long long total;
-    float* slabs;        // [G][2][kSlabFloats]: a range's first and last segment, when they are parts of tiles
-    unsigned* counters;  // [G] arrival counters, indexed by a cut tile's first contributing range; zero between launches
+    int n, G;            // G workgroups
+    int Gt, stride;      // the cut sequence is shared by Gt = G / stride of them (those with r % stride == 0): short sequences
+                         // are not cut into pieces of less than ~3 K-steps
+    long long total;     // unit steps of the cut sequence
+    float* slabs;        // [Gt][2][kSlabFloats]: a range's first and last segment, when they are parts of tiles
+    unsigned* counters;  // [Gt] arrival counters, indexed by a cut tile's first contributing range; zero between launches
 };
 
-__device__ __forceinline__ long long range_lo(const ListArgs& L, int r) { return L.total * r / L.G; }
-// the range that owns unit step x: max r with total r / G <= x
-__device__ __forceinline__ int range_of(const ListArgs& L, long long x) { return (int)(((x + 1) * L.G - 1) / L.total); }
+__device__ __forceinline__ long long range_lo(const ListArgs& L, int r) { return L.total * r / L.Gt; }
+// the range that owns unit step x: max r with total r / Gt <= x
+__device__ __forceinline__ int range_of(const ListArgs& L, long long x) { return (int)(((x + 1) * L.Gt - 1) / L.total); }
 
 // K loop of one segment: acc += A[m0.., k_begin ..] . B[.., n0..] over nkt K-steps (the loop of sgemm_dma_kernel, CONV = 0).
 template <bool AKM, bool BKM, bool CSUM>
@@ -201,7 +209,7 @@ __device__ __forceinline__ void list_segment(const ListArgs& L, const ListItem& 
                 __hip_atomic_store(slab + kAccFloats + wm0 + 32 * i + l32, cs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    const long long a = I.first + (long long)tile * I.ksteps;          // the tile's unit steps are [a, a + ksteps)
+    const long long a = I.first + (long long)(tile - I.tile0) * I.ksteps;   // the tile's unit steps are [a, a + ksteps)
     const int r_first = range_of(L, a), r_last = range_of(L, a + I.ksteps - 1);
     unsigned* flag = reinterpret_cast<unsigned*>(smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -260,25 +268,37 @@ __global__ __launch_bounds__(64 * LNW, 2) void sgemm_list_kernel(const ListArgs 
     (void)list_by_value;
     const ListArgs& L = *(const ListArgs*)(kernarg_ptr_t*)__builtin_amdgcn_kernarg_segment_ptr();
     const int r = xcd_remap((int)blockIdx.x, L.G);
-    const long long lo = range_lo(L, r), end = range_lo(L, r + 1);
-    long long pos = lo;
-    while (pos < end) {
-        int pi = 0;
-        if (L.n > 1 && pos >= L.it[1].first) pi = 1;
-        if (L.n > 2 && pos >= L.it[2].first) pi = 2;
-        const ListItem& I = L.it[pi];
-        const long long local = pos - I.first;
-        const int tile = (int)(local / I.ksteps);
-        const int ks = (int)(local - (long long)tile * I.ksteps);
-        const int ke = (int)std::min<long long>(I.ksteps, ks + (end - pos));
-        switch (I.kind) {
-            case 0: list_segment<false, false, false>(L, I, tile, ks, ke, r, lo, pos, smem); break;
-            case 1: list_segment<false, true, false>(L, I, tile, ks, ke, r, lo, pos, smem); break;
-            case 2: list_segment<true, true, false>(L, I, tile, ks, ke, r, lo, pos, smem); break;
-            default: list_segment<true, true, true>(L, I, tile, ks, ke, r, lo, pos, smem); break;
-        }
-        pos += ke - ks;
+#define MSN_LIST_SEGMENT(I, tile, ks, ke, rt, lo, pos)                                                              \
+    switch ((I).kind) {                                                                                             \
+        case 0: list_segment<false, false, false>(L, I, tile, ks, ke, rt, lo, pos, smem); break;                     \
+        case 1: list_segment<false, true, false>(L, I, tile, ks, ke, rt, lo, pos, smem); break;                      \
+        case 2: list_segment<true, true, false>(L, I, tile, ks, ke, rt, lo, pos, smem); break;                       \
+        default: list_segment<true, true, true>(L, I, tile, ks, ke, rt, lo, pos, smem); break;                       \
     }
+    // ---- the cut sequence (ranges of equal length over the tiles that are not dealt whole)
+    if (L.total > 0 && r % L.stride == 0) {
+        const int rt = r / L.stride;
+        const long long lo = range_lo(L, rt), end = range_lo(L, rt + 1);
+        long long pos = lo;
+        while (pos < end) {
+            int pi = 0;
+            if (L.n > 1 && pos >= L.it[1].first) pi = 1;
+            if (L.n > 2 && pos >= L.it[2].first) pi = 2;
+            const ListItem& I = L.it[pi];
+            const long long local = pos - I.first;
+            const int t = (int)(local / I.ksteps);
+            const int ks = (int)(local - (long long)t * I.ksteps);
+            const int ke = (int)std::min<long long>(I.ksteps, ks + (end - pos));
+            MSN_LIST_SEGMENT(I, I.tile0 + t, ks, ke, rt, lo, pos)
+            pos += ke - ks;
+        }
+    }
+    // ---- whole tiles: the same number for every workgroup
+    for (int pi = 0; pi < L.n; ++pi) {
+        const ListItem& I = L.it[pi];
+        for (int j = 0; j < I.whole; ++j) MSN_LIST_SEGMENT(I, j * L.G + r, 0, I.ksteps, 0, 0ll, 0ll)
+    }
+#undef MSN_LIST_SEGMENT
 }
 
 // which single products / lists the kernel takes: plain fp32, 128-wide tiles, the LDS-DMA conditions of sgemm_impl
@@ -305,10 +325,10 @@ static bool list_takes(const msn_gemm_desc& d) {
     return true;
 }
 
-static int list_groups(long long total) {
-    // 512 resident workgroups (256 CUs x 2); short lists: at least ~4 unit steps per range so that the slab traffic of
-    // the cut tiles stays below the multiplication time
-    long long g = std::min<long long>(512, std::max<long long>(8, total / 4));
+// Workgroups of a launch: the 512 resident ones (256 CUs x 2) once there is work for them; tiny lists get fewer, so that a
+// range is not shorter than ~4 unit steps.
+static int list_groups(long long all_steps) {
+    long long g = std::min<long long>(512, std::max<long long>(8, all_steps / 4));
     g = g / 8 * 8;
     return (int)std::max<long long>(8, g);
 }
@@ -325,6 +345,9 @@ size_t gemm_list_ws_bytes() { return sizeof(float) * (size_t)512 * 2 * (size_t)k
 
 int gemm_list_launch(int n, const msn_gemm_desc* d, void* ws, size_t ws_bytes, hipStream_t st) {
     ListArgs L;
+    long long all_steps = 0;
+    for (int i = 0; i < n; ++i) all_steps += cdiv(d[i].M, LT) * cdiv(d[i].N, LT) * (d[i].K / BK);
+    L.n = n, L.G = list_groups(all_steps);
     long long total = 0;
     for (int i = 0; i < n; ++i) {
         ListItem& I = L.it[i];
@@ -339,12 +362,19 @@ int gemm_list_launch(int n, const msn_gemm_desc* d, void* ws, size_t ws_bytes, h
         a.colsum = d[i].colsum;
         I.kind = d[i].opA == MSN_OP_T ? (d[i].colsum ? 3 : 2) : (d[i].opB == MSN_OP_T ? 0 : 1);
         I.ksteps = (int)(a.K / BK);
+        const long long tiles = (long long)a.tiles_m * a.tiles_n;
+        I.whole = (int)(tiles / L.G);
+        I.tile0 = I.whole * L.G;
         I.first = total;
-        total += (long long)a.tiles_m * a.tiles_n * I.ksteps;
+        total += (tiles - I.tile0) * I.ksteps;
     }
-    for (int i = n; i < kListMax; ++i) L.it[i] = L.it[0], L.it[i].first = total;
-    L.n = n, L.total = total, L.G = list_groups(total);
-    MSN_REQUIRE(ws && ws_bytes >= sizeof(float) * (size_t)L.G * 2 * (size_t)kSlabFloats, "msn_sgemm_list: workspace %zu too small", ws_bytes);
+    for (int i = n; i < kListMax; ++i) L.it[i] = L.it[0], L.it[i].first = total, L.it[i].whole = 0;
+    L.total = total;
+    // the cut sequence is shared by Gt = G / stride workgroups: pieces of at least ~3 unit steps (G is a multiple of 8)
+    L.stride = 1;
+    while (L.G / L.stride > 8 && (L.G / L.stride) % 2 == 0 && total < 3ll * (L.G / L.stride)) L.stride *= 2;
+    L.Gt = L.G / L.stride;
+    MSN_REQUIRE(ws && ws_bytes >= sizeof(float) * (size_t)L.Gt * 2 * (size_t)kSlabFloats, "msn_sgemm_list: workspace %zu too small", ws_bytes);
     L.slabs = static_cast<float*>(ws);
     L.counters = gemm_counter_slice(st);
     MSN_REQUIRE(L.counters, "msn_sgemm_list: no arrival-counter slice left for this stream (more than 32 streams in use)");

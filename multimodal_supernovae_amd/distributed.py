@@ -20,6 +20,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import torch
 import torch.distributed as dist
 
+from . import markers
+
 # Set to a list to record every collective issued through this module (bench.py, tests): entries are
 # (kind, payload bytes, start event | None, end event | None); None = no bookkeeping.  Events are recorded on the
 # CALLER's stream around issue + wait, i.e. they measure how long the compute stream was held by the exchange.
@@ -68,7 +70,8 @@ def all_gather_rows(t, group=None, kind="all_gather"):
 
     def run():
         log = _Logged(kind, out)
-        dist.all_gather_into_tensor(out, t, group=group)
+        with markers.range("exchange: " + kind):
+            dist.all_gather_into_tensor(out, t, group=group)
         log.done()
 
     _exchange(run)
@@ -79,7 +82,8 @@ def all_reduce_sum(t, group=None, kind="all_reduce"):
     """In-place SUM all-reduce (no autograd)."""
     def run():
         log = _Logged(kind, t)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        with markers.range("exchange: " + kind):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         log.done()
 
     _exchange(run)
@@ -265,7 +269,8 @@ class GradientReducer:
                 for _, g in have:
                     g.record_stream(cur)
         log = _Logged("grad_all_reduce", b["flat"])
-        b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        with markers.range("gradient all-reduce (bucket, issued under backward)"):
+            b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         b["log"] = log
         for v, p in zip(b["views"], b["params"]):
             p.grad = v
@@ -279,20 +284,22 @@ class GradientReducer:
                 self._gather(b)
 
             def run():
-                for b in self.buckets:
-                    log = _Logged("grad_all_reduce", b["flat"])
-                    dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group)
-                    log.done()
+                with markers.range("gradient all-reduce (all buckets)"):
+                    for b in self.buckets:
+                        log = _Logged("grad_all_reduce", b["flat"])
+                        dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group)
+                        log.done()
 
             _exchange(run)
             return
         for b in self.buckets:
             if b["work"] is None:
                 self._launch(b)
-        for b in self.buckets:
-            b["work"].wait()
-            b.pop("log").done()
-            b["work"], b["ready"], b["events"] = None, 0, []
+        with markers.range("gradient all-reduce (wait)"):
+            for b in self.buckets:
+                b["work"].wait()
+                b.pop("log").done()
+                b["work"], b["ready"], b["events"] = None, 0, []
 
     def remove(self):
         for h in self._handles:

@@ -14,6 +14,7 @@ import torch.nn as nn
 
 from . import functional as F_
 from . import ops
+from . import markers
 from .loss import clip_loss_multimodal
 from .transformer_utils import TransformerWithTimeEmbeddings
 
@@ -193,16 +194,19 @@ class LightCurveImageCLIP(nn.Module):
         return out
 
     def image_embeddings_with_projection(self, x_img):
-        h = self.image_encoder(x_img)
-        return F_.project_normalise(h, self.image_projection.weight, self.image_projection.bias)
+        with markers.range("image tower forward"):
+            h = self.image_encoder(x_img)
+            return F_.project_normalise(h, self.image_projection.weight, self.image_projection.bias)
 
     def lightcurve_embeddings_with_projection(self, x_lc, t_lc, mask_lc=None):
-        h = self.lightcurve_encoder(x_lc[..., None], t_lc, mask_lc)
-        return F_.project_normalise(h, self.lightcurve_projection.weight, self.lightcurve_projection.bias)
+        with markers.range("light-curve tower forward"):
+            h = self.lightcurve_encoder(x_lc[..., None], t_lc, mask_lc)
+            return F_.project_normalise(h, self.lightcurve_projection.weight, self.lightcurve_projection.bias)
 
     def spectral_embeddings_with_projection(self, x_lc, t_lc, mask_lc=None):
-        h = self.spectral_encoder(x_lc[..., None], t_lc, mask_lc)
-        return F_.project_normalise(h, self.spectral_projection.weight, self.spectral_projection.bias)
+        with markers.range("spectrum tower forward"):
+            h = self.spectral_encoder(x_lc[..., None], t_lc, mask_lc)
+            return F_.project_normalise(h, self.spectral_projection.weight, self.spectral_projection.bias)
 
     def meta_embeddings_with_projection(self, classification, redshift):
         half = self.len_meta_input // 2
@@ -217,8 +221,9 @@ class LightCurveImageCLIP(nn.Module):
 
     def _loss(self, embs):
         if self.loss == "softmax":
-            return clip_loss_multimodal(embs, self.logit_scale, self.logit_bias,
-                                        global_negatives=self.global_negatives)
+            with markers.range("InfoNCE forward (+ exchange)"):
+                return clip_loss_multimodal(embs, self.logit_scale, self.logit_bias,
+                                            global_negatives=self.global_negatives)
         if self.loss == "sigmoid":
             from .loss import sigmoid_loss_multimodal
             return sigmoid_loss_multimodal(embs, self.logit_scale, self.logit_bias,

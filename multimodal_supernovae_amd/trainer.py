@@ -12,6 +12,7 @@ Checkpointing, early stopping and W&B logging of the reference harness are out o
 import torch
 
 from . import distributed as D
+from . import markers
 
 
 def _to_device(batch, device):
@@ -114,10 +115,13 @@ class Trainer:
                     self.global_step += 1
                     continue
                 optimizer.zero_grad(set_to_none=True)
-                loss = model.training_step(batch, batch_idx)
-                loss.backward(_backward_seed(loss))
+                with markers.range("forward + loss"):
+                    loss = model.training_step(batch, batch_idx)
+                with markers.range("backward"):
+                    loss.backward(_backward_seed(loss))
                 reducer.finish()
-                optimizer.step()
+                with markers.range("optimiser (RAdam)"):
+                    optimizer.step()
                 losses.append(loss.detach())
                 self.global_step += 1
             _hook(model, "on_train_epoch_end")

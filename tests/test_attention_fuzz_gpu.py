@@ -63,7 +63,7 @@ def test_attention_fuzz(seed, path):
 
 
 @pytest.mark.parametrize("T", [17, 33, 49, 65, 81, 97, 113])
-@pytest.mark.parametrize("hd,heads", [(64, 6), (32, 2), (16, 2), (8, 4), (48, 1)])
+@pytest.mark.parametrize("hd,heads", [(64, 6), (32, 2), (16, 2), (8, 4), (48, 1), (24, 3), (40, 2)])
 @pytest.mark.parametrize("masked", [False, True])
 def test_ragged_last_token_path(T, hd, heads, masked):
     """Self-attention over 16n + 1 tokens (class token + patch grid): the matrix-core kernels run the n x n full tiles and

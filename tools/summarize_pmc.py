@@ -21,7 +21,7 @@ def load(root, name):
             k = r["Kernel_Name"].split("(")[0]
             k = k.replace("void ", "")
             keys = [k]
-            if "sgemm_kernel" in k or "sgemm_dma_kernel" in k:      # per template instance (layout = the two bools) and the aggregate row
+            if "sgemm_kernel" in k or "sgemm_dma_kernel" in k or "sgemm_list_kernel" in k:      # per template instance (layout = the two bools) and the aggregate row
                 keys.append("msn::sgemm_*_kernel<*>")
             if "bgemm_nt_kernel" in k or "bgemm_tn_kernel" in k:    # bf16-resident GEMMs (cfg5)
                 keys.append("msn::bgemm_{nt,tn}_kernel<*>")
@@ -62,14 +62,20 @@ def main():
     except OSError:
         commit = "unknown"
     extra = " ".join(sys.argv[3:])
+    args = sys.argv[3:]
+    rows = int(args[args.index("--per-gpu-batch") + 1]) if "--per-gpu-batch" in args else 1024
+    workload = args[args.index("--workload") + 1] if "--workload" in args else "vit_s8_lc"
     g = summary.get("msn::sgemm_*_kernel<*>")
-    if g and "--workload" not in extra:
-        json.dump({"kernel": "msn::sgemm_dma_kernel + msn::sgemm_kernel", "traffic_bytes_per_launch": g["traffic_bytes_per_launch"],
+    if g:
+        # one file per (workload, rows per GPU); the headline at 1024 rows keeps the historical name
+        name = "pmc_sgemm.json" if (workload == "vit_s8_lc" and rows == 1024) else f"pmc_sgemm_{workload}_b{rows}.json"
+        json.dump({"kernel": "msn::sgemm_dma_kernel + msn::sgemm_list_kernel + msn::sgemm_kernel (all fp32 GEMM launches)",
+                   "traffic_bytes_per_launch": g["traffic_bytes_per_launch"],
                    "mfma_busy_fraction": g["mfma_util"], "effective_clock_ghz": g["clock_ghz"], "launches": g["launches"],
-                   "workload": "bench.py default (ViT-S/8 + LC transformer, per-GPU batch 1024)",
+                   "workload": f"bench.py --workload {workload} --per-gpu-batch {rows}",
                    "collected": datetime.date.today().isoformat(), "commit": commit,
                    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES passes, tools/summarize_pmc.py"},
-                  open(os.path.join(os.path.dirname(out), "pmc_sgemm.json"), "w"), indent=1)
+                  open(os.path.join(os.path.dirname(out), name), "w"), indent=1)
     bg = summary.get("msn::bgemm_{nt,tn}_kernel<*>")
     if bg:
         json.dump({"kernel": "msn::bgemm_nt_kernel + msn::bgemm_tn_kernel", "traffic_bytes_per_launch": bg["traffic_bytes_per_launch"],
