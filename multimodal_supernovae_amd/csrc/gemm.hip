@@ -662,8 +662,11 @@ extern "C" int msn_debug_timeline(unsigned long long* buf) {
 // msn_sgemm's own use of the work-list kernel: an under-filled forward / dgrad product (shape test only; operand
 // alignment is checked at the call)
 static bool streamk_shape(int opA, int64_t M, int64_t N, int64_t K) {
+    const int64_t tiles = cdiv(M, 128) * cdiv(N, 128);
+    // under-filled = the last round of 512 workgroup slots is at most ~90 % full (a whole number of rounds is what the flat
+    // launch does best: 4096^3 = 1024 tiles runs at 134 TFLOP/s flat)
     return g_gemm_streamk > 0 && opA == MSN_OP_N && M > 64 && N > 64 && K % BK == 0 && K >= g_gemm_streamk_min_k && g_gemm_bn == 0 &&
-           cdiv(M, 128) * cdiv(N, 128) <= g_gemm_streamk && cdiv(M, 128) * cdiv(N, 128) * (K / BK) >= 64;
+           tiles <= g_gemm_streamk && tiles % 512 != 0 && tiles % 512 <= 460 && tiles * (K / BK) >= 64;
 }
 
 extern "C" size_t msn_sgemm_workspace_bytes(int opA, int opB, int64_t M, int64_t N, int64_t K) {

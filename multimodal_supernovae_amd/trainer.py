@@ -47,16 +47,22 @@ def _check_sharded_loader(loader, group, what):
     never enter.  Checked up front (an error instead of a hang) for anything that has a length."""
     import torch.distributed as dist
     n = len(loader) if hasattr(loader, "__len__") else -1
-    bs, drop_last, ds = getattr(loader, "batch_size", None), getattr(loader, "drop_last", None), getattr(loader, "dataset", None)
-    if bs and drop_last is False and ds is not None and hasattr(ds, "__len__") and len(ds) % bs != 0:
-        raise ValueError(f"{what}: data-parallel training with global negatives needs equal batches on every rank -- "
-                         f"build the DataLoader with drop_last=True ({len(ds)} samples do not divide into batches of {bs})")
+    bs, drop_last = getattr(loader, "batch_size", None), getattr(loader, "drop_last", None)
+    # rows THIS rank iterates over: its sampler's length (a DistributedSampler holds the shard), else the whole dataset
+    shard = getattr(loader, "sampler", None)
+    if shard is None or not hasattr(shard, "__len__"):
+        shard = getattr(loader, "dataset", None)
+    rows = len(shard) if shard is not None and hasattr(shard, "__len__") else -1
+    last = (rows % bs or bs) if (bs and rows > 0 and not drop_last) else (bs or -1)      # rows of this rank's last batch
     world = dist.get_world_size(group)
-    counts = [None] * world
-    dist.all_gather_object(counts, n, group=group)
-    if len(set(counts)) != 1:
-        raise ValueError(f"{what}: ranks disagree on the number of batches per epoch {counts}; shard the dataset "
-                         "into equal parts (e.g. DistributedSampler(drop_last=True))")
+    seen = [None] * world
+    dist.all_gather_object(seen, (n, last), group=group)
+    if len({c for c, _ in seen}) != 1:
+        raise ValueError(f"{what}: ranks disagree on the number of batches per epoch {[c for c, _ in seen]}; shard the "
+                         "dataset into equal parts (e.g. DistributedSampler(drop_last=True))")
+    if len({l for _, l in seen}) != 1:
+        raise ValueError(f"{what}: data-parallel training with global negatives needs equal batches on every rank -- the "
+                         f"last batches of the ranks have {[l for _, l in seen]} rows; build the DataLoader with drop_last=True")
 
 
 def _hook(model, name):

@@ -29,6 +29,19 @@ class SelfAttention(nn.Module):
         self.toqueries = nn.Linear(emb, emb, bias=False)
         self.tovalues = nn.Linear(emb, emb, bias=False)
         self.unifyheads = nn.Linear(emb, emb)
+        # the three projection weights share one buffer once stacked_qkv() has run: a state_dict handed to
+        # safetensors.save_file / torch.save must not expose three views of one storage (safetensors refuses them,
+        # torch.save would write the 3e x e storage per key) -- every entry of this module is saved as its own copy
+        self._register_state_dict_hook(SelfAttention._unshare_saved_weights)
+
+    @staticmethod
+    def _unshare_saved_weights(module, state_dict, prefix, local_metadata):
+        for name in ("toqueries", "tokeys", "tovalues"):
+            key = f"{prefix}{name}.weight"
+            t = state_dict.get(key)
+            if t is not None and t.untyped_storage().nbytes() != t.numel() * t.element_size():
+                state_dict[key] = t.clone()
+        return state_dict
 
     def stacked_qkv(self):
         """The (3 emb, emb) matrix [toqueries ; tokeys ; tovalues] the fused projection multiplies by, WITHOUT a copy per

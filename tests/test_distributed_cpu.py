@@ -167,3 +167,73 @@ def test_overlapped_gradient_reducer_two_ranks_gloo():
         p.join(180)
         assert p.exitcode == 0, f"rank exited with {p.exitcode}"
     assert dict(out) == {0: True, 1: True}
+
+
+def _shard_worker(rank, world, port, out):
+    """Deferred GradientReducer (the form a graph-replayed step uses) == the hook-driven one, and the sharded-loader check:
+    a DistributedSampler shard whose last batch is short but EQUAL on every rank is accepted (1000 samples, 2 ranks,
+    batches of 300: 300 + 200 rows each), unequal last batches and unequal batch counts are refused up front."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from multimodal_supernovae_amd import distributed as D
+    from multimodal_supernovae_amd.trainer import _check_sharded_loader
+    from torch.utils.data import DataLoader, TensorDataset
+    from torch.utils.data.distributed import DistributedSampler
+    torch.set_num_threads(1)
+    D.init_from_env(backend="gloo")
+    ok = True
+    ds = TensorDataset(torch.arange(1000.0))
+    loader = DataLoader(ds, batch_size=300, sampler=DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=False))
+    _check_sharded_loader(loader, None, "even shards")                       # must not raise
+    uneven = TensorDataset(torch.arange(10.0 if rank == 0 else 12.0))       # same batch count (3), last batches 2 / 4 rows
+    try:
+        _check_sharded_loader(DataLoader(uneven, batch_size=4), None, "uneven last batch")
+        ok = False
+    except ValueError:
+        pass
+    counts = TensorDataset(torch.arange(8.0 if rank == 0 else 16.0))
+    try:
+        _check_sharded_loader(DataLoader(counts, batch_size=4), None, "uneven counts")
+        ok = False
+    except ValueError:
+        pass
+    # deferred reducer: same sums as the hook-driven one, .grad re-pointed at the flat buffer, one exchange for all buckets
+    torch.manual_seed(5)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 9), torch.nn.Tanh(), torch.nn.Linear(9, 3))
+    D.broadcast_module(net)
+    import copy
+    twin = copy.deepcopy(net)
+    x = torch.randn(world * 4, 6, generator=torch.Generator().manual_seed(2))
+    hooked = D.GradientReducer(net.parameters(), bucket_bytes=100)
+    deferred = D.GradientReducer(twin.parameters(), bucket_bytes=100, overlap=False)
+    calls = []
+    D.SEGMENTED_CAPTURE = type("Spy", (), {"exchange": staticmethod(lambda fn: (calls.append(1), fn()))})()
+    try:
+        for step in range(2):
+            for m, red in ((net, hooked), (twin, deferred)):
+                m.zero_grad(set_to_none=True)
+                m(x[rank * 4:(rank + 1) * 4] * (step + 1)).square().sum().backward()
+                red.finish()
+            for p, q in zip(net.parameters(), twin.parameters()):
+                ok = ok and torch.equal(p.grad, q.grad)
+    finally:
+        D.SEGMENTED_CAPTURE = None
+    ok = ok and len(deferred.buckets) >= 2 and len(calls) == 2               # ONE exchange per deferred finish()
+    out[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_loader_check_and_deferred_reducer_two_ranks_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    assert dict(out) == {0: True, 1: True}
