@@ -169,3 +169,25 @@ def test_vit_block_backward_with_paired_launches(mode):
     for a, b, c in zip(base, paired, again):
         assert torch.equal(b, c)
         assert float((a - b).abs().max()) <= 3e-5 * float(a.abs().max())
+
+
+def test_counter_reset_entry_point_and_second_device():
+    """msn_reset_gemm_counters is harmless between launches (the counters are zero by construction); in a process that
+    drives two GPUs every device gets its own counter slices and zero page (the symbol caches of gemm.hip are per device)."""
+    from multimodal_supernovae_amd import _lib, ops
+    g = torch.Generator(device="cuda").manual_seed(2)
+    dy, w, x = (torch.randn(8320, 1152, device="cuda", generator=g), torch.randn(1152, 384, device="cuda", generator=g) * 0.1,
+                torch.randn(8320, 384, device="cuda", generator=g))
+    want = ops.dgrad_wgrad(dy, w, x)
+    _lib.check(_lib.lib().msn_reset_gemm_counters(_lib.stream_ptr()))
+    again = ops.dgrad_wgrad(dy, w, x)
+    assert all(torch.equal(a, b) for a, b in zip(want, again))
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box: the two-device half needs a second one")
+    with torch.cuda.device(1):
+        other = ops.dgrad_wgrad(dy.to("cuda:1"), w.to("cuda:1"), x.to("cuda:1"))
+        a = torch.randn(66560, 384, device="cuda:1")
+        flat = ops.sgemm(a, w.to("cuda:1")[:384, :384].contiguous(), 0, 1)      # a flat launch with an in-kernel tail finish
+        torch.cuda.synchronize()
+    assert all(torch.equal(a_, b_.to("cuda:0")) for a_, b_ in zip(want, other))
+    assert torch.isfinite(flat).all()
