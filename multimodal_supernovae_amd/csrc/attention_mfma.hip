@@ -216,6 +216,12 @@ __global__ __launch_bounds__(1024) void mattn_fwd_kernel(const MAttn p) {
         if (4 * lane < p.hd) v = *reinterpret_cast<const float4*>(p.q + (int64_t)b * p.q_bs + (int64_t)z * p.ldq + col0 + 4 * lane);
         *reinterpret_cast<float4*>(Zs + 4 * lane) = make_float4(v.x * p.scale, v.y * p.scale, v.z * p.scale, v.w * p.scale);
     }
+    // this wave's query fragments are requested BEFORE the barrier, beside the K / V rows: behind it they would be a second,
+    // dependent memory round trip of every workgroup (the kernel moves 16 bytes per element at ~5 TB/s: it lives on how
+    // many requests are in flight, profiles/r03_attention_memory_bound.txt)
+    const int q0 = wave * 16, qrow = q0 + c;
+    float4 qf[DT];
+    if (!tail_wave) load_frags<HD>(qf, p.q + (int64_t)b * p.q_bs, p.ldq, col0, qrow, p.Tq, g, p.scale, p.hd);
     __syncthreads();
 
     if (tail_wave) {
@@ -253,9 +259,6 @@ __global__ __launch_bounds__(1024) void mattn_fwd_kernel(const MAttn p) {
         return;
     }
 
-    const int q0 = wave * 16, qrow = q0 + c;
-    float4 qf[DT];
-    load_frags<HD>(qf, p.q + (int64_t)b * p.q_bs, p.ldq, col0, qrow, p.Tq, g, p.scale, p.hd);
     const int nkt = TPk / 16 - (p.tail ? 1 : 0);          // full key tiles on the matrix cores
 
     float m = -INFINITY;
@@ -386,6 +389,18 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dq_kernel(const MAttn p) {
             dz = p.dout[(int64_t)b * p.d_bs + (int64_t)z * p.ldd + col0 + lane] *
                  p.o[(int64_t)b * p.o_bs + (int64_t)z * p.ldo + col0 + lane];
     }
+    // fragments and row statistics of this wave's query tile: requested before the barrier (see the forward kernel)
+    const int q0 = wave * 16, qrow = q0 + c;
+    const bool q_ok = qrow < p.Tq;
+    float4 qf[DT], df[DT], of[DT];
+    float lm = 0.f, ll = 0.f;
+    const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + (q_ok ? qrow : 0);
+    if (!tail_wave) {
+        load_frags<HD>(qf, p.q + (int64_t)b * p.q_bs, p.ldq, col0, qrow, p.Tq, g, p.scale, p.hd);
+        load_frags<HD>(df, p.dout + (int64_t)b * p.d_bs, p.ldd, col0, qrow, p.Tq, g, 1.f, p.hd);
+        load_frags<HD>(of, p.o + (int64_t)b * p.o_bs, p.ldo, col0, qrow, p.Tq, g, 1.f, p.hd);
+        if (q_ok) lm = p.lse[2 * stat], ll = p.lse[2 * stat + 1];
+    }
     __syncthreads();
 
     if (tail_wave) {
@@ -414,19 +429,11 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dq_kernel(const MAttn p) {
         return;
     }
 
-    const int q0 = wave * 16, qrow = q0 + c;
-    const bool q_ok = qrow < p.Tq;
-    float4 qf[DT], df[DT], of[DT];
-    load_frags<HD>(qf, p.q + (int64_t)b * p.q_bs, p.ldq, col0, qrow, p.Tq, g, p.scale, p.hd);
-    load_frags<HD>(df, p.dout + (int64_t)b * p.d_bs, p.ldd, col0, qrow, p.Tq, g, 1.f, p.hd);
-    load_frags<HD>(of, p.o + (int64_t)b * p.o_bs, p.ldo, col0, qrow, p.Tq, g, 1.f, p.hd);
     float delta = 0.f;
 #pragma unroll
     for (int x = 0; x < DT; ++x)
         delta += df[x].x * of[x].x + df[x].y * of[x].y + df[x].z * of[x].z + df[x].w * of[x].w;
     delta = group_sum4(delta);
-    const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + (q_ok ? qrow : 0);
-    const float lm = q_ok ? p.lse[2 * stat] : 0.f, ll = q_ok ? p.lse[2 * stat + 1] : 0.f;
     if (g == 0 && q_ok) p.delta[stat] = delta;
 
     f32x4 dq[DT];
@@ -499,9 +506,18 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dkv_kernel(const MAttn p) {
         Ll[t] = t < p.Tq ? p.lse[2 * stat + 1] : 0.f;
         Dl[t] = t < p.Tq ? p.delta[stat] : 0.f;
     }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    // fragments of this wave's key tile: requested before the barrier (see the forward kernel)
+    const int k0 = wave * 16, krow = k0 + c;
+    float4 kf[DT], vf[DT];
+    bool keep = false;
+    if (!tail_wave) {
+        load_frags<HD>(kf, p.k + (int64_t)b * p.k_bs, p.ldk, col0, krow, p.Tk, g, p.scale, p.hd);
+        load_frags<HD>(vf, p.v + (int64_t)b * p.v_bs, p.ldv, col0, krow, p.Tk, g, 1.f, p.hd);
+        keep = krow < p.Tk && (p.mask ? p.mask[(int64_t)b * p.Tk + krow] != 0 : true);
+    }
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
     if (tail_wave) {
         float* Pp = Zs + 128;
         float* Pd = Zs + 256;
@@ -532,12 +548,6 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dkv_kernel(const MAttn p) {
         }
         return;
     }
-    const int k0 = wave * 16, krow = k0 + c;
-    float4 kf[DT], vf[DT];
-    load_frags<HD>(kf, p.k + (int64_t)b * p.k_bs, p.ldk, col0, krow, p.Tk, g, p.scale, p.hd);
-    load_frags<HD>(vf, p.v + (int64_t)b * p.v_bs, p.ldv, col0, krow, p.Tk, g, 1.f, p.hd);
-    const bool keep = krow < p.Tk && (p.mask ? p.mask[(int64_t)b * p.Tk + krow] != 0 : true);
-
     f32x4 dk[DT], dv[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) dk[t] = dv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
