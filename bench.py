@@ -444,6 +444,15 @@ def main():
     step()
     torch.cuda.synchronize()
     prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+    fp32_side = None
+    if args.workload == "vit_b16_bf16_lc":
+        # cfg5: the roofline object is that of the bf16-resident launches (epilogue key >= 100) against the bf16 matrix peak; the
+        # fp32 products of the light-curve tower (0.5 % of the flops) are reported beside it, not folded into the fraction
+        rest = [e for e in prof if e[3][5] < 100]
+        prof = [e for e in prof if e[3][5] >= 100]
+        r_ms, r_fl = sum(e[0].elapsed_time(e[1]) for e in rest), sum(e[2] for e in rest)
+        fp32_side = {"launches_per_step": len(rest), "ms_per_step_in_kernel": r_ms, "algorithmic_gflop_per_step": r_fl / 1e9,
+                     "achieved_tflops": r_fl / (r_ms * 1e-3) / 1e12 if r_ms > 0 else 0.0, "peak_tflops": 157.3}
     gemm_ms = sum(e[0].elapsed_time(e[1]) for e in prof)
     gemm_flops = sum(e[2] for e in prof)
     # operands + result, plus the M x N aux matrix an epilogue writes (gelu' saved by the forward) or reads (gelu' / ReLU
@@ -458,7 +467,7 @@ def main():
     if args.workload == "vit_b16_bf16_lc" and args.gemm_precision == "f32":
         peak = 2500.0           # the image tower of cfg5 issues bf16 MFMAs whatever the process default is
         kernel_name = ("msn::bgemm_nt_kernel + msn::bgemm_tn_kernel (bf16-resident operands, 256x256 tiles, LDS-DMA, "
-                       "v_mfma_f32_16x16x32_bf16; all GEMM launches of the step, the light-curve tower's fp32 ones included)")
+                       "v_mfma_f32_16x16x32_bf16; the image tower's launches -- the light-curve tower's fp32 products: fp32_launches)")
 
     # ---- per-tower split (serial order, HIP events): what each tower costs alone, and the serial step next to the
     # concurrent one, so the gain of running the towers on separate streams can be read off the JSON
@@ -597,7 +606,8 @@ def main():
                          "traffic_source": traffic_source,
                          "launches_per_step": len(prof), "ms_per_step_in_kernel": gemm_ms,
                          "algorithmic_gflop_per_step": gemm_flops / 1e9,
-                         "algorithmic_bytes_per_launch": gemm_bytes / max(len(prof), 1)},
+                         "algorithmic_bytes_per_launch": gemm_bytes / max(len(prof), 1),
+                         **({"fp32_launches": fp32_side} if fp32_side is not None else {})},
             "comm": comm,
         }
         if not headline:

@@ -8,7 +8,7 @@ for set in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     name=${set%% *}
     rm -rf "$ROOT/gpurun_out/pmc_$name"
     rocprofv3 --kernel-trace --pmc $set -d "$ROOT/gpurun_out/pmc_$name" --output-format csv -- \
-        python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-alt --no-cpu-baseline --no-weak --serial-towers "$@" > "$ROOT/gpurun_out/pmc_$name.log" 2>&1
+        python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-alt --no-cpu-baseline --no-weak --no-three-tower --serial-towers "$@" > "$ROOT/gpurun_out/pmc_$name.log" 2>&1
     tail -1 "$ROOT/gpurun_out/pmc_$name.log" | cut -c1-200
 done
 cd "$ROOT" && python3 tools/summarize_pmc.py gpurun_out gpurun_out/pmc_summary.txt "$@"
