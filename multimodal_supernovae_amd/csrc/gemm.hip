@@ -12,6 +12,7 @@
 // are dealt round-robin over them, so ids are remapped to give each XCD a contiguous run of
 // tiles that walk N fastest (neighbours share the A row-panel in that XCD's L2).
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <type_traits>
 
@@ -595,11 +596,20 @@ static Plan plan(int64_t M, int64_t N, int64_t K, int opA, bool allow_tail = tru
     // (tools/bench_gemm_small.py, M = 8320: proj 42.3 -> 33.1 us, qkv 83.2 -> 77.8, ff1 110.4 -> 102.1; M = 33280 proj
     // 104.2 -> 97.4; from ~1000 tiles on the wide tile wins again)
     if (N > 64 && N % 64 == 0 && opA == MSN_OP_N && g_gemm_bn == 0 && cdiv(M, 128) * cdiv(N, 128) <= 800) p.bn = 64;
+    // A width whose last 128-wide tile would be at most half full (N = 96, 192: the stacked q|k|v projections of the emb-32 /
+    // emb-64 towers) wastes a quarter and more of the MFMAs on columns that do not exist: 64-wide tiles (measured on
+    // 200k-row products: N = 192 80.5 -> 69.8 us, N = 96 46.2 -> 38.8 us)
+    if (N > 64 && N % 128 != 0 && N % 128 <= 64 && opA == MSN_OP_N && g_gemm_bn == 0) p.bn = 64;
     if (N > 64 && g_gemm_bn != 0) p.bn = g_gemm_bn;
     // Weight gradients with few rows (dW of a Linear whose OUTPUT is 32 / 64 wide: the reference towers' ff2): a 128-row
     // tile would multiply 4x / 2x rows that do not exist -- measured compute-bound on them (M = 32, N = 128, K = 225 280:
     // 82 us against 18 us of HBM time)
     if (opA == MSN_OP_T && p.bn == 128 && M <= 64 && g_gemm_bn == 0) p.bm = M <= 32 ? 32 : 64;
+    // Forward / dgrad products with one or two K-steps (K <= 64: ff1 forward and ff2 dgrad of the emb-32 / emb-64 towers): a
+    // workgroup's life is prologue + epilogue more than K loop (per-launch accounting: 25-30 % of the CU time with nobody in
+    // a K loop), so 64-row tiles -- 48 KB of LDS, three workgroups per CU -- overlap more of it (N = 256, K = 64 over 204 800
+    // rows: forward 83.7 -> 78.2 us, dgrad + ReLU' 122.2 -> 109.8; 32-row tiles lose again)
+    if (opA == MSN_OP_N && K <= 64 && p.bn == 128 && g_gemm_bn == 0) p.bm = 64;
     p.tail_tiles = 0, p.tail_splits = 1, p.tail_kps = 0;
     const int64_t tiles = cdiv(M, p.bm) * cdiv(N, p.bn);
     const int64_t ksteps = cdiv(K, BK);
@@ -620,7 +630,7 @@ static Plan plan(int64_t M, int64_t N, int64_t K, int opA, bool allow_tail = tru
     p.splits = s;
     p.kps = (int)per;
     const int64_t r = tiles % 512;
-    if (g_gemm_tail && allow_tail && s == 1 && p.bn == 128 && r > 0 && tiles >= 128 && tiles < (1ll << 30)) {
+    if (g_gemm_tail && allow_tail && s == 1 && p.bn == 128 && p.bm == 128 && r > 0 && tiles >= 128 && tiles < (1ll << 30)) {
         // time of the last round in units of one whole tile: ceil(r c / 512) rounds of 1 / c tile each (+ a small
         // charge per slab for its prologue, the slab store and the finishing pass)
         const int64_t cmax = std::min<int64_t>(std::min<int64_t>(ksteps / 4, 16), 1024 / r);
