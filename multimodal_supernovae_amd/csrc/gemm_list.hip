@@ -45,8 +45,8 @@ struct ListItem {
 struct ListArgs {
     ListItem it[kListMax];
     int n, G;            // G workgroups
-    int Gt, stride;      // the cut sequence is shared by Gt = G / stride of them (those with r % stride == 0): short sequences
-                         // are not cut into pieces of less than ~3 K-steps
+    int Gt, stride;      // the cut sequence is shared by Gt <= G / stride of them (r % stride == 0, r / stride < Gt): short sequences
+                         // are not cut into pieces of less than ~3 K-steps, and no range is empty
     long long total;     // unit steps of the cut sequence
     float* slabs;        // [Gt][2][kSlabFloats]: a range's first and last segment, when they are parts of tiles
     unsigned* counters;  // [Gt] arrival counters, indexed by a cut tile's first contributing range; zero between launches
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(64 * LNW, 2) void sgemm_list_kernel(const ListArgs 
         default: list_segment<true, true, true>(L, I, tile, ks, ke, rt, lo, pos, smem); break;                       \
     }
     // ---- the cut sequence (ranges of equal length over the tiles that are not dealt whole)
-    if (L.total > 0 && r % L.stride == 0) {
+    if (L.total > 0 && r % L.stride == 0 && r / L.stride < L.Gt) {
         const int rt = r / L.stride;
         const long long lo = range_lo(L, rt), end = range_lo(L, rt + 1);
         long long pos = lo;
@@ -371,9 +371,10 @@ int gemm_list_launch(int n, const msn_gemm_desc* d, void* ws, size_t ws_bytes, h
     for (int i = n; i < kListMax; ++i) L.it[i] = L.it[0], L.it[i].first = total, L.it[i].whole = 0;
     L.total = total;
     // the cut sequence is shared by Gt = G / stride workgroups: pieces of at least ~3 unit steps (G is a multiple of 8)
+    // (every range must own at least one unit step: a tile's contributors are counted as r_last - r_first + 1)
     L.stride = 1;
     while (L.G / L.stride > 8 && (L.G / L.stride) % 2 == 0 && total < 3ll * (L.G / L.stride)) L.stride *= 2;
-    L.Gt = L.G / L.stride;
+    L.Gt = (int)std::max<long long>(1, std::min<long long>(L.G / L.stride, total / 3));
     MSN_REQUIRE(ws && ws_bytes >= sizeof(float) * (size_t)L.Gt * 2 * (size_t)kSlabFloats, "msn_sgemm_list: workspace %zu too small", ws_bytes);
     L.slabs = static_cast<float*>(ws);
     L.counters = gemm_counter_slice(st);

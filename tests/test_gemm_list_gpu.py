@@ -191,3 +191,57 @@ def test_counter_reset_entry_point_and_second_device():
         torch.cuda.synchronize()
     assert all(torch.equal(a_, b_.to("cuda:0")) for a_, b_ in zip(want, other))
     assert torch.isfinite(flat).all()
+
+
+def test_fuzz_lists_against_fp64():
+    """Random lists (1 - 3 products: forward, dgrad with every epilogue, wgrad with / without column sums) over random sizes:
+    the range arithmetic of the work-list kernel (whole tiles per workgroup, cut sequence shared by G / stride workgroups,
+    first / last slab of a range, finisher by arrival) against fp64, and twice the same bits."""
+    import random
+    from multimodal_supernovae_amd import ops
+    rng = random.Random(1234)
+    g = torch.Generator(device="cuda").manual_seed(99)
+    widths = [128, 192, 256, 320, 384, 512, 640, 1152, 1536]
+    for case in range(64):
+        n = rng.choice([1, 2, 2, 3])
+        rows = 32 * rng.randint(3, 700)
+        descs, checks, keep = [], [], []
+        for i in range(n):
+            kind = rng.choice(["fwd", "dgrad", "wgrad", "wgrad_cs"])
+            n_in, n_out = rng.choice(widths), rng.choice(widths)
+            if kind == "fwd":
+                a = torch.randn(rows, n_in, device="cuda", generator=g)
+                w = torch.randn(n_out, n_in, device="cuda", generator=g) * 0.1
+                bias = torch.randn(n_out, device="cuda", generator=g)
+                c = torch.empty(rows, n_out, device="cuda")
+                descs.append(ops._gemm_desc(a, w, ops.OP_N, ops.OP_T, c, bias=bias, epilogue=ops.EPI_RELU))
+                checks.append((c, (a.double() @ w.double().t() + bias.double()).clamp_min(0)))
+                keep += [a, w, bias]
+            elif kind == "dgrad":
+                dy = torch.randn(rows, n_out, device="cuda", generator=g)
+                w = torch.randn(n_out, n_in, device="cuda", generator=g) * 0.1
+                aux = torch.randn(rows, n_in, device="cuda", generator=g)
+                c = torch.empty(rows, n_in, device="cuda")
+                epi = rng.choice([ops.EPI_NONE, ops.EPI_ADD, ops.EPI_GELU_BWD, ops.EPI_RELU_BWD])
+                descs.append(ops._gemm_desc(dy, w, ops.OP_N, ops.OP_N, c, epilogue=epi, aux=aux if epi != ops.EPI_NONE else None))
+                z = dy.double() @ w.double()
+                ref = {ops.EPI_NONE: z, ops.EPI_ADD: z + aux.double(), ops.EPI_GELU_BWD: z * aux.double(),
+                       ops.EPI_RELU_BWD: z * (aux.double() > 0)}[epi]
+                checks.append((c, ref))
+                keep += [dy, w, aux]
+            else:
+                dy = torch.randn(rows, n_out, device="cuda", generator=g)
+                x = torch.randn(rows, n_in, device="cuda", generator=g)
+                c = torch.empty(n_out, n_in, device="cuda")
+                cs = torch.empty(n_out, device="cuda") if kind == "wgrad_cs" else None
+                descs.append(ops._gemm_desc(dy, x, ops.OP_T, ops.OP_N, c, colsum_out=cs))
+                checks.append((c, dy.double().t() @ x.double()))
+                if cs is not None:
+                    checks.append((cs, dy.double().sum(0)))
+                keep += [dy, x]
+        ops.sgemm_list(descs)
+        first = [c.clone() for c, _ in checks]
+        for (c, ref), what in zip(checks, range(len(checks))):
+            assert _rel(c, ref) < 4e-6, (case, what, rows, [(d.M, d.N, d.K, d.opA, d.opB, d.epilogue) for d in descs])
+        ops.sgemm_list(descs)
+        assert all(torch.equal(c, f) for (c, _), f in zip(checks, first)), case
