@@ -534,26 +534,31 @@ def main():
                "value": b * world * n_alt / dt_alt, "unit": "pairs/s", "ms_per_step": dt_alt / n_alt * 1e3,
                "steps": n_alt, "note": "opt-in (--gemm-precision bf16x3); the headline value above is exact fp32"}
 
-    # ---- second field: weak scaling at 256 rows per GPU (global 256 * N), same model family, fresh optimiser state
+    # ---- second field: weak scaling at 256 rows per GPU (global 256 * N): the SAME model, optimiser and gradient buckets on
+    # a batch of 256 rows per rank (throughput does not depend on the optimiser's age; building a second model + a second
+    # hook-driven reducer in the same process is what the 2-rank rehearsal on one shared GPU could not do at speed)
     weak = None
+    import gc
     if not args.no_weak and not args.graphed:
-        del step
-        reducer.remove()
-        model_w, batch_w = make(256)
-        D.broadcast_module(model_w)
-        opt_w = model_w.configure_optimizers()["optimizer"]
-        red_w = D.GradientReducer(model_w.parameters())
-        step_w = make_step(model_w, opt_w, red_w, batch_w)
+        batch_w = synthetic_batch(256, 1234 + rank, device)
+        step_w = make_step(model, opt, reducer, batch_w)
         dt_w, loss_w, _ = timed(step_w, args.warmup, args.steps)
         weak = {"value": 256 * world * args.steps / dt_w, "unit": "pairs/s", "per_gpu_batch": 256,
                 "global_batch": 256 * world, "ms_per_step": dt_w / args.steps * 1e3, "steps": args.steps,
                 "scaling": "weak", "loss": loss_w}
-        red_w.remove()
+        del step_w, batch_w
+    want_three = headline and not args.no_three_tower and not args.graphed and args.gemm_precision == "f32"
+    if want_three:
+        # the headline's model, optimiser state and gradient buckets are released before the three-tower model is built
+        reducer.remove()
+        del step, reducer, opt, model, batch
+        gc.collect()
+        torch.cuda.empty_cache()
 
     # ---- third field (row N1 of the north star: image + light-curve + 1024-bin spectra): the three-tower workload of
     # BASELINE cfg4 (ViT-S/8 + LC transformer + 1-D CNN spectrum tower, symmetric 3-way InfoNCE) at 256 and 1024 rows per GPU
     three = None
-    if headline and not args.no_three_tower and not args.graphed and args.gemm_precision == "f32":
+    if want_three:
         three = {"workload": WORKLOADS["vit_s8_lc_cnn1d_sp"], "unit": "pairs/s", "scaling": "weak", "per_gpu": []}
         for rows in (256, 1024):
             model_t, batch_t = build_workload("vit_s8_lc_cnn1d_sp", rows, 1234 + rank, device)
@@ -580,6 +585,8 @@ def main():
                                      "gemm_launches_per_step": len(prof_t), "gemm_ms_per_step": ms_t})
             red_t.remove()
             del step_t, model_t, batch_t, opt_t, red_t
+            gc.collect()
+            torch.cuda.empty_cache()
 
     if rank == 0:
         ms = dt / args.steps * 1e3
