@@ -31,9 +31,9 @@ for B in (128, 256, 512):
         b = torch.randn((K, N) if ob == 0 else (N, K), device="cuda")
         out = torch.empty(M, N, device="cuda")
         res = []
-        for bn in (0, 64):
+        for bn in (0, 64, 128):
             check(lib().msn_set_gemm_tile_n(bn))
             res.append(timeit(lambda: ops.sgemm(a, b, 0, ob, out=out)))
         check(lib().msn_set_gemm_tile_n(0))
-        print(f"B={B:4d} {tag:11s} M={M:6d} N={N:5d} K={K:5d}  planned {res[0]:7.1f} us  bn=64 {res[1]:7.1f} us  "
+        print(f"B={B:4d} {tag:11s} M={M:6d} N={N:5d} K={K:5d}  planned {res[0]:7.1f} us  bn=64 {res[1]:7.1f} us  bn=128 {res[2]:7.1f} us  "
               f"({2.0 * M * N * K / res[0] / 1e6:6.1f} / {2.0 * M * N * K / res[1] / 1e6:6.1f} TFLOP/s)", flush=True)

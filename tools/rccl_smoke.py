@@ -3,7 +3,8 @@
 the sharded InfoNCE forced on (`global_negatives="always"`) and the gradient reducer forced on, so the packed embedding
 all-gather, the LSE all-gather, the loss all-reduce and the bucketed gradient all-reduce all run as RCCL collectives
 on device buffers.  With one rank every collective is the identity, so loss and gradients must equal the plain
-single-process step.  (Two ranks cannot share a device under RCCL; the 2-rank algebra is tested over gloo.)"""
+single-process step.  The same one-rank RCCL group then carries the exchanges BETWEEN the graph segments of a replayed
+step (trainer.GraphedTrainStep): five steps equal the eager ones bit for bit.  (Two ranks cannot share a device under RCCL; the 2-rank algebra is tested over gloo.)"""
 import os
 import sys
 
@@ -62,6 +63,37 @@ def main():
           and abs(float(loss.detach()) - ref_loss) <= 1e-6 * abs(ref_loss) and worst < 1e-5)
     print({"backend": dist.get_backend(), "collectives": kinds, "comm_ms": ms, "loss": float(loss.detach()), "ref_loss": ref_loss,
            "worst_rel_grad_err": worst})
+    # ---- graph replay with RCCL carrying the exchanges between the graph segments (trainer.GraphedTrainStep): five steps
+    # (two eager warm-up steps, the recording, replays) against the same five steps issued eagerly, bit for bit
+    from multimodal_supernovae_amd.trainer import GraphedTrainStep
+
+    def five_steps(graphed):
+        m = make("always")
+        opt = m.configure_optimizers()["optimizer"]
+        red = D.GradientReducer(m.parameters(), bucket_bytes=16 << 10, force=True, overlap=not graphed)
+        losses, info = [], None
+        if graphed:
+            step = GraphedTrainStep(m, opt, warmup=2, reducer=red)
+            for i in range(5):
+                losses.append(float(step(batch, i).detach()))
+            info = (step.graph.segments, step.graph.exchanges)
+        else:
+            for i in range(5):
+                opt.zero_grad(set_to_none=True)
+                l = m.training_step(batch, i)
+                l.backward()
+                red.finish()
+                opt.step()
+                losses.append(float(l.detach()))
+        red.remove()
+        torch.cuda.synchronize()
+        return [p.detach().clone() for p in m.parameters()], losses, info
+
+    pe, le, _ = five_steps(False)
+    pg, lg, info = five_steps(True)
+    graphed_ok = le == lg and all(torch.equal(a, c) for a, c in zip(pe, pg)) and info[0] >= 4 and info[1] >= 4
+    print({"graphed == eager": graphed_ok, "segments / exchanges": info, "losses": lg})
+    ok = ok and graphed_ok
     dist.destroy_process_group()
     print("RCCL SMOKE", "OK" if ok else "FAILED")
     sys.exit(0 if ok else 1)
