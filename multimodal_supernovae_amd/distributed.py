@@ -213,7 +213,8 @@ class GradientReducer:
                 views.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
             bi = len(self.buckets)
-            self.buckets.append({"params": plist, "flat": flat, "views": views, "ready": 0, "work": None, "events": []})
+            self.buckets.append({"params": plist, "flat": flat, "views": views, "ready": 0, "work": None, "events": [],
+                                 "stream_events": {}})
             for p in plist:
                 self._where[p] = bi
                 if overlap:
@@ -223,10 +224,15 @@ class GradientReducer:
         b = self.buckets[self._where[p]]
         if p.grad is not None and p.grad.is_cuda:
             # towers run on their own streams (models_multimodal.forward): the gradient exists on the stream this hook
-            # runs under, which need not be the stream the bucket is finally gathered on
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(p.grad.device))
-            b["events"].append(ev)
+            # runs under, which need not be the stream the bucket is finally gathered on.  One event per (bucket, stream)
+            # -- re-recorded at every gradient of that stream, so it covers the last one -- instead of one per parameter
+            # (150 event creations per step are ~0.7 ms of host time, which a 13-ms step at 128 rows per GPU does not have)
+            s = torch.cuda.current_stream(p.grad.device)
+            ev = b["stream_events"].get(s.cuda_stream)
+            if ev is None:
+                ev = b["stream_events"][s.cuda_stream] = torch.cuda.Event()
+            ev.record(s)
+            b["events"] = list(b["stream_events"].values())
         b["ready"] += 1
         if b["ready"] == len(b["params"]) and b["work"] is None:
             self._launch(b)
