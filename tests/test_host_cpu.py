@@ -203,3 +203,21 @@ def test_saved_attention_weights_do_not_share_storage():
     assert len(ptrs) == len(sd)
     fresh = SelfAttention(16, heads=2)
     fresh.load_state_dict(sd, strict=True)
+
+
+def test_host_shim_under_address_and_ub_sanitizers():
+    """The C-ABI's host side (validation, launch planning, workspace sizing, work-list descriptors) under ASan + UBSan:
+    runs when tools/build_host_sanitized.sh has produced the sanitized library (a 90-second build, not part of the default
+    CPU suite); the probe exercises every entry point that returns before a launch."""
+    import glob
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "multimodal_supernovae_amd", "build_asan", "libmsn_hip_asan.so")
+    rt = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    if not os.path.exists(lib) or not rt:
+        pytest.skip("sanitized library not built (bash tools/build_host_sanitized.sh)")
+    env = dict(os.environ, LD_PRELOAD=rt[-1], ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_sanitizer_probe.py")], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode == 0 and "HOST SANITIZER PROBE OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
