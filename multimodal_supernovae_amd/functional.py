@@ -547,12 +547,14 @@ class _PreNormBlock(torch.autograd.Function):
         (x2, g1, wqkv, wo, g2, w1, w2, m1, r1, h1, qkv, a2, lse, x1, m2, r2, h2, pre, f) = ctx.saved_tensors
         d2 = _c(dy).view(B * T, e)
         pair = _pair_backward(B * T)
-        if pair:        # both backward products of a Linear in one work-list launch (ops.dgrad_wgrad)
+        if pair & 4:    # both backward products of a Linear in one work-list launch (ops.dgrad_wgrad)
             dpre, dw2, dc2 = ops.dgrad_wgrad(d2, w2, f, epilogue=EPI_GELU_BWD, aux=pre)
-            dh2, dw1, dc1 = ops.dgrad_wgrad(dpre, w1, h2)
         else:
             dw2, dc2 = ops.wgrad_bias(d2, f)
             dpre = sgemm(d2, w2, OP_N, OP_N, epilogue=EPI_GELU_BWD, aux=pre)
+        if pair & 1:
+            dh2, dw1, dc1 = ops.dgrad_wgrad(dpre, w1, h2)
+        else:
             dw1, dc1 = ops.wgrad_bias(dpre, h2)
             dh2 = sgemm(dpre, w1, OP_N, OP_N)
         dx1, dg2, db2 = ops.layernorm_bwd(dh2, x1, m2, r2, g2, add=d2)        # + skip connection
@@ -565,7 +567,7 @@ class _PreNormBlock(torch.autograd.Function):
         q3, d3 = qkv.view(B, T, 3 * e), dqkv.view(B, T, 3 * e)
         ops.attention_bwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], None, heads, scale, a2.view(B, T, e), lse,
                           da.view(B, T, e), d3[..., :e], d3[..., e:2 * e], d3[..., 2 * e:])
-        if pair:
+        if pair & 1:
             dh1, dwqkv, dbqkv = ops.dgrad_wgrad(dqkv, wqkv, h1)
         else:
             dwqkv, dbqkv = ops.wgrad_bias(dqkv, h1)
@@ -574,20 +576,21 @@ class _PreNormBlock(torch.autograd.Function):
         return (dx.view(B, T, e), None, None, dg1, db1, dwqkv, dbqkv, dwo, dbo, dg2, db2, dw1, dc1, dw2, dc2)
 
 
-# Backward pairs (dX and dW of one Linear) as ONE work-list launch: MSN_PAIR_BACKWARD = 0 never, 1 the wide products of a
-# block (qkv, ff1, ff2), 3 also the e x e output projection; unset: by row count (see _pair_backward).
+# Backward pairs (dX and dW of one Linear) as ONE work-list launch: bit 1 = the qkv and ff1 pairs (e-wide dX), bit 4 = the ff2
+# pair (4e-wide dX), bit 2 = the e x e output projection.  MSN_PAIR_BACKWARD overrides; unset: by row count (_pair_backward).
 PAIR_BACKWARD = os.environ.get("MSN_PAIR_BACKWARD")
 
 
 def _pair_backward(rows):
-    """Which Linear backward pairs of a ViT block run as one work-list launch.  Measured on the headline step
-    (profiles/r03_gemm_worklist_vs_flat.txt): with up to ~40 000 token rows (512 cutouts x 65 tokens) the launch of the
-    wide products (qkv, ff1, ff2) is under-filled and the pair wins 7-16 % over dgrad + wgrad + split-K sum; at 66 560 rows
-    the flat launches are full and win; the e x e projection loses at every size (its two products are too short for
-    the slabs of the cut tiles)."""
+    """Which Linear backward pairs of a ViT block run as one work-list launch.  Measured on the headline step and
+    tools/bench_gemm_list.py (profiles/r03_gemm_worklist_vs_flat.txt): with up to ~40 000 token rows (512 cutouts x 65 tokens)
+    the launches of the qkv and ff1 pairs are under-filled and the pair wins 4-16 % over dgrad + wgrad + split-K sum; the
+    ff2 pair (its dX has four times the tiles) wins up to ~12 000 rows (128 cutouts: 194 -> 182 us) and loses from 16 640 on
+    (353 -> 372 us); at 66 560 rows the flat launches are full and every pair only ties; the e x e projection loses at every
+    size (its two products are too short for the slabs of the cut tiles)."""
     if PAIR_BACKWARD is not None:
         return int(PAIR_BACKWARD)
-    return 1 if rows <= 40000 else 0
+    return (1 if rows <= 40000 else 0) | (4 if rows <= 12000 else 0)
 
 
 def pre_norm_block(x, heads, p, eps=1e-6):

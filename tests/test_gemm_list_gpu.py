@@ -144,7 +144,7 @@ def test_two_streams_use_their_own_counters():
         assert all(torch.equal(a, b) for a, b in zip(o, want))
 
 
-@pytest.mark.parametrize("mode", [1, 3])
+@pytest.mark.parametrize("mode", [1, 5, 7])
 def test_vit_block_backward_with_paired_launches(mode):
     """Every gradient of a pre-norm ViT block (B = 128 cutouts, 65 tokens, e = 384) with the Linear backward pairs as
     work-list launches == the one-product-per-launch backward, to fp32 rounding; and twice the same bits."""
