@@ -605,6 +605,8 @@ static Plan plan(int64_t M, int64_t N, int64_t K, int opA, bool allow_tail = tru
     // tile would multiply 4x / 2x rows that do not exist -- measured compute-bound on them (M = 32, N = 128, K = 225 280:
     // 82 us against 18 us of HBM time)
     if (opA == MSN_OP_T && p.bn == 128 && M <= 64 && g_gemm_bn == 0) p.bm = M <= 32 ? 32 : 64;
+    // ... and with a narrow OUTPUT as well (dW of the emb-32 / emb-64 unifyheads: 32 x 32, 64 x 64): 64-row tiles of 64 / 32 columns
+    if (opA == MSN_OP_T && p.bn <= 64 && M <= 64 && g_gemm_bn == 0) p.bm = 64;
     // Forward / dgrad products with one or two K-steps (K <= 64: ff1 forward and ff2 dgrad of the emb-32 / emb-64 towers): a
     // workgroup's life is prologue + epilogue more than K loop (per-launch accounting: 25-30 % of the CU time with nobody in
     // a K loop), so 64-row tiles -- 48 KB of LDS, three workgroups per CU -- overlap more of it (N = 256, K = 64 over 204 800
@@ -779,6 +781,8 @@ static int sgemm_impl(int opA, int opB, int64_t M, int64_t N, int64_t K, const f
         if (bn == 128) rc = launch_dma_conv<128, 128, 64, 64, 32, 2>(a, conv, opB, st);
         else rc = launch_dma_conv<128, 64, 64, 32, 32, 3>(a, conv, opB, st);
     } else if (bf16_ok) rc = launch_bgemm(a, opA, opB, precision == MSN_PREC_BF16X3 ? 2 : 1, bm, bn, st);
+    else if (bm == 64 && bn == 64 && dma_ok) rc = launch_dma<64, 64, 32, 32, 32, 3>(a, opA, opB, st);
+    else if (bm == 64 && bn == 32 && dma_ok) rc = launch_dma<64, 32, 32, 32, 32, 3>(a, opA, opB, st);
     else if (bm == 32 && dma_ok) rc = launch_dma<32, 128, 32, 32, 32, 2>(a, opA, opB, st);
     else if (bm == 64 && dma_ok) rc = launch_dma<64, 128, 32, 64, 32, 2>(a, opA, opB, st);   // (not dma_ok: the 128-row kernels below; M <= 64 is one row of tiles either way)
     else if (dma_ok && bn == 128 && K % 64 == 0 && kps % 64 == 0 && g_gemm_variant == 2)
