@@ -607,6 +607,8 @@ static Plan plan(int64_t M, int64_t N, int64_t K, int opA, bool allow_tail = tru
     if (opA == MSN_OP_T && p.bn == 128 && M <= 64 && g_gemm_bn == 0) p.bm = M <= 32 ? 32 : 64;
     // ... and with a narrow OUTPUT as well (dW of the emb-32 / emb-64 unifyheads: 32 x 32, 64 x 64): 64-row tiles of 64 / 32 columns
     if (opA == MSN_OP_T && p.bn <= 64 && M <= 64 && g_gemm_bn == 0) p.bm = 64;
+    // ... or whose last 128-row tile would be at most half full (dW of the emb-64 q|k|v projection: 192 x 64 = three 64 x 64 tiles)
+    if (opA == MSN_OP_T && p.bn <= 64 && M > 64 && M % 128 != 0 && M % 128 <= 64 && g_gemm_bn == 0) p.bm = 64;
     // Forward / dgrad products with one or two K-steps (K <= 64: ff1 forward and ff2 dgrad of the emb-32 / emb-64 towers): a
     // workgroup's life is prologue + epilogue more than K loop (per-launch accounting: 25-30 % of the CU time with nobody in
     // a K loop), so 64-row tiles -- 48 KB of LDS, three workgroups per CU -- overlap more of it (N = 256, K = 64 over 204 800
