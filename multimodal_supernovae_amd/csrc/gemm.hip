@@ -613,7 +613,7 @@ static Plan plan(int64_t M, int64_t N, int64_t K, int opA, bool allow_tail = tru
     // workgroup's life is prologue + epilogue more than K loop (per-launch accounting: 25-30 % of the CU time with nobody in
     // a K loop), so 64-row tiles -- 48 KB of LDS, three workgroups per CU -- overlap more of it (N = 256, K = 64 over 204 800
     // rows: forward 83.7 -> 78.2 us, dgrad + ReLU' 122.2 -> 109.8; 32-row tiles lose again)
-    if (opA == MSN_OP_N && K <= 64 && p.bn == 128 && g_gemm_bn == 0) p.bm = 64;
+    if (opA == MSN_OP_N && K <= 64 && p.bn >= 64 && g_gemm_bn == 0) p.bm = 64;
     p.tail_tiles = 0, p.tail_splits = 1, p.tail_kps = 0;
     const int64_t tiles = cdiv(M, p.bm) * cdiv(N, p.bn);
     const int64_t ksteps = cdiv(K, BK);
