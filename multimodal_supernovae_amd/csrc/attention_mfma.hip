@@ -53,37 +53,96 @@ __device__ __forceinline__ void locate_head(const MAttn& p, int& b, int& hh) {
     }
 }
 
-// rows [0, T) of src (row stride ld, columns col0..col0+HD-1) -> LDS [TP][HD + 4], zero rows beyond T
-template <int HD>
-__device__ __forceinline__ void stage(float* dst, const float* __restrict__ src, int64_t ld, int col0, int T, int TP,
-                                      int hd) {
-    constexpr int LS = HD + 4, Q4 = HD / 4, U = 4;   // U independent 16-byte loads in flight per thread
-    const int total = TP * Q4;
-    for (int base = threadIdx.x; base < total; base += U * blockDim.x) {
-        float4 v[U];
+// Long kernels: workgroup id -> (sample, head, row block).  The H * NB workgroups of a sample read the same 128-byte
+// lines of its q|k|v rows (every head a slice of the line, every row block the whole K / V): with B % 8 == 0 they are
+// made consecutive workgroups of ONE XCD (ids go to the XCDs round-robin), so the lines come from HBM once, not H * NB times.
+__device__ __forceinline__ void locate_block(const MAttn& p, int NB, int& b, int& hh, int& blk) {
+    const unsigned per = (unsigned)(p.H * NB);
+    unsigned id = blockIdx.x;
+    if ((p.B & 7) == 0) {
+        const unsigned xcd = id & 7, j = id >> 3;
+        id = ((j / per) * 8 + xcd) * per + j % per;
+    }
+    blk = (int)(id % NB);
+    const unsigned bh = id / NB;
+    b = (int)(bh / p.H), hh = (int)(bh % p.H);
+}
+
+// ---- prologue reads in two halves: REQUEST everything, then COMMIT ----------------------------------------------------
+// Written the obvious way (image 1: load, store to LDS; image 2: load, store; mask; fragments, each scaled on arrival) hipcc
+// keeps the program order and a workgroup makes 5-7 DEPENDENT memory round trips before its barrier.  So every read of the
+// prologue is first REQUESTED into registers -- branch-free, an out-of-range element re-reads element (0, 0) of its matrix --
+// and only then COMMITTED (zeroed, scaled, written to LDS): one round trip (two with SPLIT).
+// Two images of rows [0, T) (row stride ld, columns col0..col0+hd-1) -> LDS [TP][HD + 4], zeros beyond T / hd.  Thread t owns
+// the 16-byte pieces t + u * blockDim.x, u < U, of both images (U = pieces per thread of the kernel's own shapes; what lies
+// beyond goes through rest()).  SPLIT (wide heads: 2 U float4 in flight beside the fragments cost a wave of occupancy): the second
+// image is requested when the first is committed -- two round trips instead of one.
+template <int HD, int U, bool SPLIT>
+struct Stager {
+    static constexpr int LS = HD + 4, Q4 = HD / 4;
+    float4 a[U], b[U];
+    const float* s0; const float* s1;
+    int64_t ld0, ld1;
+    int col0, T, TP, hd;
+
+    __device__ __forceinline__ void load(float4 (&v)[U], const float* __restrict__ src, int64_t ld, int base) const {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int idx = base + u * blockDim.x;
+            const int idx = base + u * (int)blockDim.x;
             const int r = idx / Q4, c = 4 * (idx % Q4);
-            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < total && r < T && c < hd) v[u] = *reinterpret_cast<const float4*>(src + (int64_t)r * ld + col0 + c);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int idx = base + u * blockDim.x;
-            if (idx < total) *reinterpret_cast<float4*>(dst + (idx / Q4) * LS + 4 * (idx % Q4)) = v[u];
+            const bool ok = idx < TP * Q4 && r < T && c < hd;
+            v[u] = *reinterpret_cast<const float4*>(src + (int64_t)(ok ? r : 0) * ld + col0 + (ok ? c : 0));
         }
     }
-}
+    __device__ __forceinline__ void store(float* dst, const float4 (&v)[U], int base) const {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * (int)blockDim.x;
+            const int r = idx / Q4, c = 4 * (idx % Q4);
+            if (idx < TP * Q4) {
+                float4 w = v[u];                          // (a value, not `ok ? v[u] : zero`: that selects between ADDRESSES
+                if (r >= T || c >= hd) w = make_float4(0.f, 0.f, 0.f, 0.f);   //  and pins the pieces in scratch memory)
+                *reinterpret_cast<float4*>(dst + r * LS + c) = w;
+            }
+        }
+    }
+    __device__ __forceinline__ void request(const float* src0, const float* src1, int64_t l0, int64_t l1, int col, int rows,
+                                            int padded, int width) {
+        s0 = src0, s1 = src1, ld0 = l0, ld1 = l1, col0 = col, T = rows, TP = padded, hd = width;
+        load(a, s0, ld0, threadIdx.x);
+        if (!SPLIT) load(b, s1, ld1, threadIdx.x);
+    }
+    __device__ __forceinline__ void commit_first(float* d0) {
+        store(d0, a, threadIdx.x);
+        if (SPLIT) load(b, s1, ld1, threadIdx.x);
+    }
+    __device__ __forceinline__ void commit_second(float* d0, float* d1) {
+        store(d1, b, threadIdx.x);
+        for (int base = threadIdx.x + U * blockDim.x; base < TP * Q4; base += U * blockDim.x) {   // not the towers' shapes
+            load(a, s0, ld0, base);
+            load(b, s1, ld1, base);
+            store(d0, a, base);
+            store(d1, b, base);
+        }
+    }
+};
 // fragments of one 16-row tile held by this wave as the B operand: row = lane & 15, d = 16x + 4g + j
 template <int HD>
-__device__ __forceinline__ void load_frags(float4 (&f)[HD / 16], const float* __restrict__ src, int64_t ld, int col0,
-                                           int row, int T, int g, float mul, int hd) {
+__device__ __forceinline__ void frags_request(float4 (&f)[HD / 16], const float* __restrict__ src, int64_t ld, int col0,
+                                              int row, int T, int g, int hd) {
     const float* p = src + (int64_t)(row < T ? row : T - 1) * ld + col0;
 #pragma unroll
     for (int x = 0; x < HD / 16; ++x) {
         const int d0 = 16 * x + 4 * g;
-        float4 v = *reinterpret_cast<const float4*>(p + (d0 < hd ? d0 : 0));
+        f[x] = *reinterpret_cast<const float4*>(p + (d0 < hd ? d0 : 0));
+    }
+}
+template <int HD>
+__device__ __forceinline__ void frags_commit(float4 (&f)[HD / 16], int row, int T, int g, float mul, int hd) {
+#pragma unroll
+    for (int x = 0; x < HD / 16; ++x) {
+        const int d0 = 16 * x + 4 * g;
+        float4 v = f[x];
         if (row >= T || d0 >= hd) v = make_float4(0.f, 0.f, 0.f, 0.f);
         f[x] = make_float4(v.x * mul, v.y * mul, v.z * mul, v.w * mul);
     }
@@ -208,20 +267,34 @@ __global__ __launch_bounds__(1024) void mattn_fwd_kernel(const MAttn p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
     const int z = p.Tk - 1;                               // the ragged token (tail only)
     const bool tail_wave = p.tail && wave == TPk / 16 - 1;
-    stage<HD>(Ks, p.k + (int64_t)b * p.k_bs, p.ldk, col0, p.Tk, rows, p.hd);
-    stage<HD>(Vs, p.v + (int64_t)b * p.v_bs, p.ldv, col0, p.Tk, rows, p.hd);
-    for (int j = threadIdx.x; j < TPk; j += blockDim.x) Ms[j] = (j < p.Tk && p.mask) ? p.mask[(int64_t)b * p.Tk + j] : 1;
-    if (tail_wave && lane < HD / 4) {                     // query z, scaled, as a broadcast row
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (4 * lane < p.hd) v = *reinterpret_cast<const float4*>(p.q + (int64_t)b * p.q_bs + (int64_t)z * p.ldq + col0 + 4 * lane);
-        *reinterpret_cast<float4*>(Zs + 4 * lane) = make_float4(v.x * p.scale, v.y * p.scale, v.z * p.scale, v.w * p.scale);
-    }
-    // this wave's query fragments are requested BEFORE the barrier, beside the K / V rows: behind it they would be a second,
-    // dependent memory round trip of every workgroup (the kernel moves 16 bytes per element at ~5 TB/s: it lives on how
-    // many requests are in flight, profiles/r03_attention_memory_bound.txt)
+    // ---- request: K / V rows, key mask, this wave's query fragments (the tail wave: query z), all in flight together
+    const float* ksrc = p.k + (int64_t)b * p.k_bs;
+    const float* vsrc = p.v + (int64_t)b * p.v_bs;
+    Stager<HD, DT, (HD > 32)> sv;
+    sv.request(ksrc, vsrc, p.ldk, p.ldv, col0, p.Tk, rows, p.hd);
+    const int mj = threadIdx.x;
+    uint8_t mk = 1;
+    if (p.mask) mk = p.mask[(int64_t)b * p.Tk + (mj < p.Tk ? mj : 0)];
     const int q0 = wave * 16, qrow = q0 + c;
     float4 qf[DT];
-    if (!tail_wave) load_frags<HD>(qf, p.q + (int64_t)b * p.q_bs, p.ldq, col0, qrow, p.Tq, g, p.scale, p.hd);
+    float4 zq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tail_wave) {
+        if (lane < HD / 4 && 4 * lane < p.hd)
+            zq = *reinterpret_cast<const float4*>(p.q + (int64_t)b * p.q_bs + (int64_t)z * p.ldq + col0 + 4 * lane);
+    } else {
+        frags_request<HD>(qf, p.q + (int64_t)b * p.q_bs, p.ldq, col0, qrow, p.Tq, g, p.hd);
+    }
+    // ---- commit
+    sv.commit_first(Ks);
+    if (mj < TPk) Ms[mj] = mj < p.Tk ? mk : 1;
+    for (int j = mj + blockDim.x; j < TPk; j += blockDim.x) Ms[j] = (j < p.Tk && p.mask) ? p.mask[(int64_t)b * p.Tk + j] : 1;
+    if (tail_wave) {
+        if (lane < HD / 4)                                // query z, scaled, as a broadcast row
+            *reinterpret_cast<float4*>(Zs + 4 * lane) = make_float4(zq.x * p.scale, zq.y * p.scale, zq.z * p.scale, zq.w * p.scale);
+    } else {
+        frags_commit<HD>(qf, qrow, p.Tq, g, p.scale, p.hd);
+    }
+    sv.commit_second(Ks, Vs);
     __syncthreads();
 
     if (tail_wave) {
@@ -356,6 +429,7 @@ __global__ __launch_bounds__(1024) void mattn_fwd_kernel(const MAttn p) {
 template <int HD>
 __global__ __launch_bounds__(1024) void mattn_bwd_dq_kernel(const MAttn p) {
     constexpr int LS = HD + 4, DT = HD / 16;
+    constexpr bool LATE = HD > 32;   // fragments requested behind the staged rows (as many registers as before), not beside them
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int TPk = (p.Tk + 15) / 16 * 16;
     float* Ks = smem;
@@ -371,36 +445,59 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dq_kernel(const MAttn p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
     const int z = p.Tk - 1;
     const bool tail_wave = p.tail && wave == TPk / 16 - 1;
-    stage<HD>(Ks, p.k + (int64_t)b * p.k_bs, p.ldk, col0, p.Tk, rows, p.hd);
-    stage<HD>(Vs, p.v + (int64_t)b * p.v_bs, p.ldv, col0, p.Tk, rows, p.hd);
-    for (int j = threadIdx.x; j < TPk; j += blockDim.x) Ms[j] = (j < p.Tk && p.mask) ? p.mask[(int64_t)b * p.Tk + j] : 1;
-    float dz = 0.f;                                       // tail wave: lane d's term of delta_z = dO_z . O_z
-    if (tail_wave) {
-        if (lane < HD / 4) {                              // query z (scaled) and its dO row as broadcast rows
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f), w = v;
-            if (4 * lane < p.hd) {
-                v = *reinterpret_cast<const float4*>(p.q + (int64_t)b * p.q_bs + (int64_t)z * p.ldq + col0 + 4 * lane);
-                w = *reinterpret_cast<const float4*>(p.dout + (int64_t)b * p.d_bs + (int64_t)z * p.ldd + col0 + 4 * lane);
-            }
-            *reinterpret_cast<float4*>(Zs + 4 * lane) = make_float4(v.x * p.scale, v.y * p.scale, v.z * p.scale, v.w * p.scale);
-            *reinterpret_cast<float4*>(Zs + 64 + 4 * lane) = w;
-        }
-        if (lane < p.hd)
-            dz = p.dout[(int64_t)b * p.d_bs + (int64_t)z * p.ldd + col0 + lane] *
-                 p.o[(int64_t)b * p.o_bs + (int64_t)z * p.ldo + col0 + lane];
-    }
-    // fragments and row statistics of this wave's query tile: requested before the barrier (see the forward kernel)
+    // ---- request (see the forward kernel): K / V rows, key mask, this wave's q / dO / O fragments and row statistics
+    const float* ksrc = p.k + (int64_t)b * p.k_bs;
+    const float* vsrc = p.v + (int64_t)b * p.v_bs;
+    Stager<HD, DT, (HD > 32)> sv;
+    sv.request(ksrc, vsrc, p.ldk, p.ldv, col0, p.Tk, rows, p.hd);
+    const int mj = threadIdx.x;
+    uint8_t mk = 1;
+    if (p.mask) mk = p.mask[(int64_t)b * p.Tk + (mj < p.Tk ? mj : 0)];
     const int q0 = wave * 16, qrow = q0 + c;
     const bool q_ok = qrow < p.Tq;
     float4 qf[DT], df[DT], of[DT];
     float lm = 0.f, ll = 0.f;
     const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + (q_ok ? qrow : 0);
-    if (!tail_wave) {
-        load_frags<HD>(qf, p.q + (int64_t)b * p.q_bs, p.ldq, col0, qrow, p.Tq, g, p.scale, p.hd);
-        load_frags<HD>(df, p.dout + (int64_t)b * p.d_bs, p.ldd, col0, qrow, p.Tq, g, 1.f, p.hd);
-        load_frags<HD>(of, p.o + (int64_t)b * p.o_bs, p.ldo, col0, qrow, p.Tq, g, 1.f, p.hd);
-        if (q_ok) lm = p.lse[2 * stat], ll = p.lse[2 * stat + 1];
+    float4 zq = make_float4(0.f, 0.f, 0.f, 0.f), zd = zq;
+    float dz = 0.f;                                       // tail wave: lane d's term of delta_z = dO_z . O_z
+    if (tail_wave) {
+        if (lane < HD / 4 && 4 * lane < p.hd) {           // query z and its dO row
+            zq = *reinterpret_cast<const float4*>(p.q + (int64_t)b * p.q_bs + (int64_t)z * p.ldq + col0 + 4 * lane);
+            zd = *reinterpret_cast<const float4*>(p.dout + (int64_t)b * p.d_bs + (int64_t)z * p.ldd + col0 + 4 * lane);
+        }
+        if (lane < p.hd)
+            dz = p.dout[(int64_t)b * p.d_bs + (int64_t)z * p.ldd + col0 + lane] *
+                 p.o[(int64_t)b * p.o_bs + (int64_t)z * p.ldo + col0 + lane];
+    } else {
+        if (!LATE) {
+            frags_request<HD>(qf, p.q + (int64_t)b * p.q_bs, p.ldq, col0, qrow, p.Tq, g, p.hd);
+            frags_request<HD>(df, p.dout + (int64_t)b * p.d_bs, p.ldd, col0, qrow, p.Tq, g, p.hd);
+            frags_request<HD>(of, p.o + (int64_t)b * p.o_bs, p.ldo, col0, qrow, p.Tq, g, p.hd);
+        }
+        lm = p.lse[2 * stat], ll = p.lse[2 * stat + 1];   // row 0's for a padded query: never used (q_ok)
     }
+    // ---- commit
+    sv.commit_first(Ks);
+    if (mj < TPk) Ms[mj] = mj < p.Tk ? mk : 1;
+    for (int j = mj + blockDim.x; j < TPk; j += blockDim.x) Ms[j] = (j < p.Tk && p.mask) ? p.mask[(int64_t)b * p.Tk + j] : 1;
+    if (tail_wave) {
+        if (lane < HD / 4) {                              // query z (scaled) and its dO row as broadcast rows
+            *reinterpret_cast<float4*>(Zs + 4 * lane) = make_float4(zq.x * p.scale, zq.y * p.scale, zq.z * p.scale, zq.w * p.scale);
+            *reinterpret_cast<float4*>(Zs + 64 + 4 * lane) = zd;
+        }
+    }
+    if (LATE) sv.commit_second(Ks, Vs);
+    if (!tail_wave) {
+        if (LATE) {                                       // wide heads: the fragments take their own round trip, behind K and V
+            frags_request<HD>(qf, p.q + (int64_t)b * p.q_bs, p.ldq, col0, qrow, p.Tq, g, p.hd);
+            frags_request<HD>(df, p.dout + (int64_t)b * p.d_bs, p.ldd, col0, qrow, p.Tq, g, p.hd);
+            frags_request<HD>(of, p.o + (int64_t)b * p.o_bs, p.ldo, col0, qrow, p.Tq, g, p.hd);
+        }
+        frags_commit<HD>(qf, qrow, p.Tq, g, p.scale, p.hd);
+        frags_commit<HD>(df, qrow, p.Tq, g, 1.f, p.hd);
+        frags_commit<HD>(of, qrow, p.Tq, g, 1.f, p.hd);
+    }
+    if (!LATE) sv.commit_second(Ks, Vs);
     __syncthreads();
 
     if (tail_wave) {
@@ -474,6 +571,7 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dq_kernel(const MAttn p) {
 template <int HD>
 __global__ __launch_bounds__(1024) void mattn_bwd_dkv_kernel(const MAttn p) {
     constexpr int LS = HD + 4, DT = HD / 16;
+    constexpr bool LATE = HD > 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int TPq = (p.Tq + 15) / 16 * 16;
     float* Qs = smem;
@@ -488,34 +586,60 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dkv_kernel(const MAttn p) {
     const int col0 = hh * p.hd;
     const int z = p.Tq - 1;
     const bool tail_wave = p.tail && (int)(threadIdx.x >> 6) == TPq / 16 - 1;
-    stage<HD>(Qs, p.q + (int64_t)b * p.q_bs, p.ldq, col0, p.Tq, rows, p.hd);
-    stage<HD>(Ds, p.dout + (int64_t)b * p.d_bs, p.ldd, col0, p.Tq, rows, p.hd);
-    if (tail_wave && (threadIdx.x & 63) < HD / 4) {       // key z (scaled) and value z as broadcast rows
-        const int l4 = 4 * (threadIdx.x & 63);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f), w = v;
-        if (l4 < p.hd) {
-            v = *reinterpret_cast<const float4*>(p.k + (int64_t)b * p.k_bs + (int64_t)z * p.ldk + col0 + l4);
-            w = *reinterpret_cast<const float4*>(p.v + (int64_t)b * p.v_bs + (int64_t)z * p.ldv + col0 + l4);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    // ---- request (see the forward kernel): Q / dO rows, the queries' statistics, this wave's key / value fragments + mask
+    const float* qsrc = p.q + (int64_t)b * p.q_bs;
+    const float* dsrc = p.dout + (int64_t)b * p.d_bs;
+    Stager<HD, DT, (HD > 32)> sv;
+    sv.request(qsrc, dsrc, p.ldq, p.ldd, col0, p.Tq, rows, p.hd);
+    const int tj = threadIdx.x;
+    const int64_t sj = ((int64_t)b * p.H + hh) * p.Tq + (tj < p.Tq ? tj : 0);
+    const float s_m = p.lse[2 * sj], s_l = p.lse[2 * sj + 1], s_d = p.delta[sj];
+    const int k0 = wave * 16, krow = k0 + c;
+    float4 kf[DT], vf[DT];
+    float4 zk = make_float4(0.f, 0.f, 0.f, 0.f), zv = zk;
+    uint8_t mk = 1;
+    if (tail_wave) {
+        if (lane < HD / 4 && 4 * lane < p.hd) {           // key z and value z
+            zk = *reinterpret_cast<const float4*>(p.k + (int64_t)b * p.k_bs + (int64_t)z * p.ldk + col0 + 4 * lane);
+            zv = *reinterpret_cast<const float4*>(p.v + (int64_t)b * p.v_bs + (int64_t)z * p.ldv + col0 + 4 * lane);
         }
-        *reinterpret_cast<float4*>(Zs + l4) = make_float4(v.x * p.scale, v.y * p.scale, v.z * p.scale, v.w * p.scale);
-        *reinterpret_cast<float4*>(Zs + 64 + l4) = w;
+    } else {
+        if (!LATE) {
+            frags_request<HD>(kf, p.k + (int64_t)b * p.k_bs, p.ldk, col0, krow, p.Tk, g, p.hd);
+            frags_request<HD>(vf, p.v + (int64_t)b * p.v_bs, p.ldv, col0, krow, p.Tk, g, p.hd);
+        }
+        if (p.mask) mk = p.mask[(int64_t)b * p.Tk + (krow < p.Tk ? krow : 0)];
     }
-    for (int t = threadIdx.x; t < TPq; t += blockDim.x) {
+    // ---- commit
+    sv.commit_first(Qs);
+    if (tj < TPq) {
+        Lm[tj] = tj < p.Tq ? s_m : INFINITY;              // +inf: a padded query row gets p = exp(-inf) = 0
+        Ll[tj] = tj < p.Tq ? s_l : 0.f;
+        Dl[tj] = tj < p.Tq ? s_d : 0.f;
+    }
+    for (int t = tj + blockDim.x; t < TPq; t += blockDim.x) {
         const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + (t < p.Tq ? t : 0);
-        Lm[t] = t < p.Tq ? p.lse[2 * stat] : INFINITY;     // +inf: a padded query row gets p = exp(-inf) = 0
+        Lm[t] = t < p.Tq ? p.lse[2 * stat] : INFINITY;
         Ll[t] = t < p.Tq ? p.lse[2 * stat + 1] : 0.f;
         Dl[t] = t < p.Tq ? p.delta[stat] : 0.f;
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-    // fragments of this wave's key tile: requested before the barrier (see the forward kernel)
-    const int k0 = wave * 16, krow = k0 + c;
-    float4 kf[DT], vf[DT];
     bool keep = false;
-    if (!tail_wave) {
-        load_frags<HD>(kf, p.k + (int64_t)b * p.k_bs, p.ldk, col0, krow, p.Tk, g, p.scale, p.hd);
-        load_frags<HD>(vf, p.v + (int64_t)b * p.v_bs, p.ldv, col0, krow, p.Tk, g, 1.f, p.hd);
-        keep = krow < p.Tk && (p.mask ? p.mask[(int64_t)b * p.Tk + krow] != 0 : true);
+    if (tail_wave) {
+        if (lane < HD / 4) {                              // key z (scaled) and value z as broadcast rows
+            *reinterpret_cast<float4*>(Zs + 4 * lane) = make_float4(zk.x * p.scale, zk.y * p.scale, zk.z * p.scale, zk.w * p.scale);
+            *reinterpret_cast<float4*>(Zs + 64 + 4 * lane) = zv;
+        }
+    } else {
+        if (LATE) {
+            frags_request<HD>(kf, p.k + (int64_t)b * p.k_bs, p.ldk, col0, krow, p.Tk, g, p.hd);
+            frags_request<HD>(vf, p.v + (int64_t)b * p.v_bs, p.ldv, col0, krow, p.Tk, g, p.hd);
+        }
+        frags_commit<HD>(kf, krow, p.Tk, g, p.scale, p.hd);
+        frags_commit<HD>(vf, krow, p.Tk, g, 1.f, p.hd);
+        keep = krow < p.Tk && mk != 0;
     }
+    sv.commit_second(Qs, Ds);
     __syncthreads();
 
     if (tail_wave) {
@@ -597,7 +721,7 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dkv_kernel(const MAttn p) {
 // fit in registers.  Forward: online softmax ACROSS chunks (running maximum; the output accumulators -- rows are
 // queries 4g + r -- take the rescale factor of their query from its column-owner lane), one pass WITHIN a chunk.
 // The backward kernels only accumulate over the chunks (probabilities come from the saved row statistics).
-// blockIdx.x = (b * H + h) * NB + block: the row blocks of a (b, h) are neighbours and share its K / V lines in L2.
+// Workgroup -> (sample, head, row block) by locate_block: the workgroups of a sample run on one XCD and share its lines in L2.
 template <int HD>
 __global__ __launch_bounds__(512, 4) void mattn_fwd_long_kernel(const MAttn p) {
     constexpr int LS = HD + 4, DT = HD / 16, KEEP = HD <= 16 ? 16 : 8, CH = 16 * KEEP;
@@ -606,11 +730,26 @@ __global__ __launch_bounds__(512, 4) void mattn_fwd_long_kernel(const MAttn p) {
     float* Vs = smem + (size_t)CH * LS;
     uint8_t* Ms = reinterpret_cast<uint8_t*>(Vs + (size_t)CH * LS);
     const int NB = (p.Tq + 127) / 128;
-    const int blk = blockIdx.x % NB, bh = blockIdx.x / NB, b = bh / p.H, hh = bh % p.H, col0 = hh * p.hd;
+    int b, hh, blk;
+    locate_block(p, NB, b, hh, blk);
+    const int col0 = hh * p.hd;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
     const int q0 = blk * 128 + wave * 16, qrow = q0 + c;
+    const float* ksrc = p.k + (int64_t)b * p.k_bs;
+    const float* vsrc = p.v + (int64_t)b * p.v_bs;
     float4 qf[DT];
-    load_frags<HD>(qf, p.q + (int64_t)b * p.q_bs, p.ldq, col0, qrow, p.Tq, g, p.scale, p.hd);
+    Stager<HD, (HD > 32 ? 2 : CH * (HD / 4) / 512), (HD > 32)> sv;   // wide heads: the rest in a second pass (registers)
+    uint8_t mk = 1;
+    const int tj = threadIdx.x;
+    // a chunk's K / V rows and key mask, requested together (see Stager); the first chunk beside the query fragments
+    auto request = [&](int k0) {
+        const int nt = min(CH, p.Tk - k0), TPc = (nt + 15) / 16 * 16;
+        sv.request(ksrc + (int64_t)k0 * p.ldk, vsrc + (int64_t)k0 * p.ldv, p.ldk, p.ldv, col0, nt, TPc, p.hd);
+        if (p.mask) mk = p.mask[(int64_t)b * p.Tk + k0 + (tj < nt ? tj : 0)];
+    };
+    frags_request<HD>(qf, p.q + (int64_t)b * p.q_bs, p.ldq, col0, qrow, p.Tq, g, p.hd);
+    if (HD <= 32) request(0);
+    frags_commit<HD>(qf, qrow, p.Tq, g, p.scale, p.hd);
     float m = -INFINITY, l = 0.f;
     f32x4 o[DT];
 #pragma unroll
@@ -618,9 +757,11 @@ __global__ __launch_bounds__(512, 4) void mattn_fwd_long_kernel(const MAttn p) {
     for (int k0 = 0; k0 < p.Tk; k0 += CH) {
         const int nt = min(CH, p.Tk - k0), TPc = (nt + 15) / 16 * 16, nkt = TPc / 16;
         __syncthreads();                                  // every wave is done with the previous chunk
-        stage<HD>(Ks, p.k + (int64_t)b * p.k_bs + (int64_t)k0 * p.ldk, p.ldk, col0, nt, TPc, p.hd);
-        stage<HD>(Vs, p.v + (int64_t)b * p.v_bs + (int64_t)k0 * p.ldv, p.ldv, col0, nt, TPc, p.hd);
-        for (int j = threadIdx.x; j < TPc; j += blockDim.x)   // key codes: 1 live, 0 masked out, 2 beyond the sequence
+        if (k0 > 0 || HD > 32) request(k0);               // (narrow heads: chunk 0 was requested beside the fragments)
+        sv.commit_first(Ks);
+        sv.commit_second(Ks, Vs);
+        if (tj < TPc) Ms[tj] = tj < nt ? (mk ? 1 : 0) : 2;    // key codes: 1 live, 0 masked out, 2 beyond the sequence
+        for (int j = tj + blockDim.x; j < TPc; j += blockDim.x)
             Ms[j] = j < nt ? (p.mask ? (p.mask[(int64_t)b * p.Tk + k0 + j] ? 1 : 0) : 1) : 2;
         __syncthreads();
         f32x4 sc[KEEP];
@@ -690,21 +831,37 @@ __global__ __launch_bounds__(512, 4) void mattn_bwd_dq_long_kernel(const MAttn p
     float* Vs = smem + (size_t)CH * LS;
     uint8_t* Ms = reinterpret_cast<uint8_t*>(Vs + (size_t)CH * LS);
     const int NB = (p.Tq + 127) / 128;
-    const int blk = blockIdx.x % NB, bh = blockIdx.x / NB, b = bh / p.H, hh = bh % p.H, col0 = hh * p.hd;
+    int b, hh, blk;
+    locate_block(p, NB, b, hh, blk);
+    const int col0 = hh * p.hd;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
     const int q0 = blk * 128 + wave * 16, qrow = q0 + c;
     const bool q_ok = qrow < p.Tq;
+    const float* ksrc = p.k + (int64_t)b * p.k_bs;
+    const float* vsrc = p.v + (int64_t)b * p.v_bs;
     float4 qf[DT], df[DT], of[DT];
-    load_frags<HD>(qf, p.q + (int64_t)b * p.q_bs, p.ldq, col0, qrow, p.Tq, g, p.scale, p.hd);
-    load_frags<HD>(df, p.dout + (int64_t)b * p.d_bs, p.ldd, col0, qrow, p.Tq, g, 1.f, p.hd);
-    load_frags<HD>(of, p.o + (int64_t)b * p.o_bs, p.ldo, col0, qrow, p.Tq, g, 1.f, p.hd);
+    Stager<HD, (HD > 32 ? 2 : CH * (HD / 4) / 512), (HD > 32)> sv;   // wide heads: the rest in a second pass (registers)
+    uint8_t mk = 1;
+    const int tj = threadIdx.x;
+    auto request = [&](int k0) {                          // see the forward kernel
+        const int nt = min(CH, p.Tk - k0), TPc = (nt + 15) / 16 * 16;
+        sv.request(ksrc + (int64_t)k0 * p.ldk, vsrc + (int64_t)k0 * p.ldv, p.ldk, p.ldv, col0, nt, TPc, p.hd);
+        if (p.mask) mk = p.mask[(int64_t)b * p.Tk + k0 + (tj < nt ? tj : 0)];
+    };
+    frags_request<HD>(qf, p.q + (int64_t)b * p.q_bs, p.ldq, col0, qrow, p.Tq, g, p.hd);
+    frags_request<HD>(df, p.dout + (int64_t)b * p.d_bs, p.ldd, col0, qrow, p.Tq, g, p.hd);
+    frags_request<HD>(of, p.o + (int64_t)b * p.o_bs, p.ldo, col0, qrow, p.Tq, g, p.hd);
+    const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + (q_ok ? qrow : 0);
+    const float lm = p.lse[2 * stat], ll = p.lse[2 * stat + 1];   // row 0's for a padded query: never used (q_ok)
+    if (HD <= 32) request(0);
+    frags_commit<HD>(qf, qrow, p.Tq, g, p.scale, p.hd);
+    frags_commit<HD>(df, qrow, p.Tq, g, 1.f, p.hd);
+    frags_commit<HD>(of, qrow, p.Tq, g, 1.f, p.hd);
     float delta = 0.f;
 #pragma unroll
     for (int x = 0; x < DT; ++x)
         delta += df[x].x * of[x].x + df[x].y * of[x].y + df[x].z * of[x].z + df[x].w * of[x].w;
     delta = group_sum4(delta);
-    const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + (q_ok ? qrow : 0);
-    const float lm = q_ok ? p.lse[2 * stat] : 0.f, ll = q_ok ? p.lse[2 * stat + 1] : 0.f;
     if (g == 0 && q_ok) p.delta[stat] = delta;
     f32x4 dq[DT];
 #pragma unroll
@@ -712,9 +869,11 @@ __global__ __launch_bounds__(512, 4) void mattn_bwd_dq_long_kernel(const MAttn p
     for (int k0 = 0; k0 < p.Tk; k0 += CH) {
         const int nt = min(CH, p.Tk - k0), TPc = (nt + 15) / 16 * 16, nkt = TPc / 16;
         __syncthreads();
-        stage<HD>(Ks, p.k + (int64_t)b * p.k_bs + (int64_t)k0 * p.ldk, p.ldk, col0, nt, TPc, p.hd);
-        stage<HD>(Vs, p.v + (int64_t)b * p.v_bs + (int64_t)k0 * p.ldv, p.ldv, col0, nt, TPc, p.hd);
-        for (int j = threadIdx.x; j < TPc; j += blockDim.x)   // key codes: 1 live, 0 masked out, 2 beyond the sequence
+        if (k0 > 0 || HD > 32) request(k0);               // (narrow heads: chunk 0 was requested beside the fragments)
+        sv.commit_first(Ks);
+        sv.commit_second(Ks, Vs);
+        if (tj < TPc) Ms[tj] = tj < nt ? (mk ? 1 : 0) : 2;    // key codes: 1 live, 0 masked out, 2 beyond the sequence
+        for (int j = tj + blockDim.x; j < TPc; j += blockDim.x)
             Ms[j] = j < nt ? (p.mask ? (p.mask[(int64_t)b * p.Tk + k0 + j] ? 1 : 0) : 1) : 2;
         __syncthreads();
         for (int kt = 0; kt < nkt; ++kt) {
@@ -752,23 +911,47 @@ __global__ __launch_bounds__(512, 4) void mattn_bwd_dkv_long_kernel(const MAttn 
     float* Ll = Lm + CH;
     float* Dl = Ll + CH;
     const int NB = (p.Tk + 127) / 128;
-    const int blk = blockIdx.x % NB, bh = blockIdx.x / NB, b = bh / p.H, hh = bh % p.H, col0 = hh * p.hd;
+    int b, hh, blk;
+    locate_block(p, NB, b, hh, blk);
+    const int col0 = hh * p.hd;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
     const int k0 = blk * 128 + wave * 16, krow = k0 + c;
+    const float* qsrc = p.q + (int64_t)b * p.q_bs;
+    const float* dsrc = p.dout + (int64_t)b * p.d_bs;
     float4 kf[DT], vf[DT];
-    load_frags<HD>(kf, p.k + (int64_t)b * p.k_bs, p.ldk, col0, krow, p.Tk, g, p.scale, p.hd);
-    load_frags<HD>(vf, p.v + (int64_t)b * p.v_bs, p.ldv, col0, krow, p.Tk, g, 1.f, p.hd);
+    Stager<HD, (HD > 32 ? 2 : CH * (HD / 4) / 512), (HD > 32)> sv;   // wide heads: the rest in a second pass (registers)
+    float s_m = 0.f, s_l = 0.f, s_d = 0.f;
+    const int tj = threadIdx.x;
+    auto request = [&](int i0) {                          // a chunk's Q / dO rows and row statistics, requested together
+        const int nt = min(CH, p.Tq - i0), TPc = (nt + 15) / 16 * 16;
+        sv.request(qsrc + (int64_t)i0 * p.ldq, dsrc + (int64_t)i0 * p.ldd, p.ldq, p.ldd, col0, nt, TPc, p.hd);
+        const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + i0 + (tj < nt ? tj : 0);
+        s_m = p.lse[2 * stat], s_l = p.lse[2 * stat + 1], s_d = p.delta[stat];
+    };
+    frags_request<HD>(kf, p.k + (int64_t)b * p.k_bs, p.ldk, col0, krow, p.Tk, g, p.hd);
+    frags_request<HD>(vf, p.v + (int64_t)b * p.v_bs, p.ldv, col0, krow, p.Tk, g, p.hd);
     const bool in_seq = krow < p.Tk;
-    const bool keep = in_seq && (p.mask ? p.mask[(int64_t)b * p.Tk + krow] != 0 : true);
+    uint8_t mk = 1;
+    if (p.mask) mk = p.mask[(int64_t)b * p.Tk + (in_seq ? krow : 0)];
+    if (HD <= 32) request(0);
+    frags_commit<HD>(kf, krow, p.Tk, g, p.scale, p.hd);
+    frags_commit<HD>(vf, krow, p.Tk, g, 1.f, p.hd);
+    const bool keep = in_seq && mk != 0;
     f32x4 dk[DT], dv[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) dk[t] = dv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int i0 = 0; i0 < p.Tq; i0 += CH) {
         const int nt = min(CH, p.Tq - i0), TPc = (nt + 15) / 16 * 16, nqt = TPc / 16;
         __syncthreads();
-        stage<HD>(Qs, p.q + (int64_t)b * p.q_bs + (int64_t)i0 * p.ldq, p.ldq, col0, nt, TPc, p.hd);
-        stage<HD>(Ds, p.dout + (int64_t)b * p.d_bs + (int64_t)i0 * p.ldd, p.ldd, col0, nt, TPc, p.hd);
-        for (int t = threadIdx.x; t < TPc; t += blockDim.x) {
+        if (i0 > 0 || HD > 32) request(i0);               // (narrow heads: chunk 0 was requested beside the fragments)
+        sv.commit_first(Qs);
+        sv.commit_second(Qs, Ds);
+        if (tj < TPc) {
+            Lm[tj] = tj < nt ? s_m : INFINITY;            // +inf: a padded query row gets p = exp(-inf) = 0
+            Ll[tj] = tj < nt ? s_l : 0.f;
+            Dl[tj] = tj < nt ? s_d : 0.f;
+        }
+        for (int t = tj + blockDim.x; t < TPc; t += blockDim.x) {
             const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + i0 + (t < nt ? t : 0);
             Lm[t] = t < nt ? p.lse[2 * stat] : INFINITY;     // +inf: a padded query row gets p = exp(-inf) = 0
             Ll[t] = t < nt ? p.lse[2 * stat + 1] : 0.f;
