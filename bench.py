@@ -311,6 +311,8 @@ def main():
     ops.set_gemm_tail_split(args.gemm_tail)
     if os.environ.get("MSN_GEMM_LDS_PAD"):
         _lib.check(_lib.lib().msn_set_gemm_lds_pad(int(os.environ["MSN_GEMM_LDS_PAD"])))
+    if os.environ.get("MSN_GEMM_STREAMK"):          # "max_tiles,min_k": experiment switch for the work-list rule of single products
+        ops.set_gemm_streamk(*(int(v) for v in os.environ["MSN_GEMM_STREAMK"].split(",")))
     if args.bgemm_one_tile:
         from multimodal_supernovae_amd import _lib
         _lib.check(_lib.lib().msn_set_bgemm_persistent(0))

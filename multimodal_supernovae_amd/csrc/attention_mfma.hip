@@ -1,4 +1,4 @@
-// Matrix-core attention (sequences up to 256 tokens; head_dim 16..64 in multiples of 16: the ViT image
+// Matrix-core attention (head_dim up to 128 in multiples of 16 -- 80..128: eight waves with 256 registers each; the ViT image
 // tower; head_dim 4 / 8 / 12: the light-curve transformer, run as 16-wide heads whose missing columns
 // are zeros in LDS / registers only).  Exact fp32 on v_mfma_f32_16x16x4_f32.
 //
@@ -250,7 +250,7 @@ constexpr int kTailScratch = 384;   // floats of LDS behind the images: 2 broadc
 
 // ------------------------------------------------------------------------------------------ forward
 template <int HD>
-__global__ __launch_bounds__(1024) void mattn_fwd_kernel(const MAttn p) {
+__global__ __launch_bounds__(HD > 64 ? 512 : 1024) void mattn_fwd_kernel(const MAttn p) {
     constexpr int LS = HD + 4, DT = HD / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int TPk = (p.Tk + 15) / 16 * 16;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(1024) void mattn_fwd_kernel(const MAttn p) {
 
 // ------------------------------------------------------------------------------- backward: dQ, delta
 template <int HD>
-__global__ __launch_bounds__(1024) void mattn_bwd_dq_kernel(const MAttn p) {
+__global__ __launch_bounds__(HD > 64 ? 512 : 1024) void mattn_bwd_dq_kernel(const MAttn p) {
     constexpr int LS = HD + 4, DT = HD / 16;
     constexpr bool LATE = HD > 32;   // fragments requested behind the staged rows (as many registers as before), not beside them
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dq_kernel(const MAttn p) {
 
 // ------------------------------------------------------------------------------- backward: dK, dV
 template <int HD>
-__global__ __launch_bounds__(1024) void mattn_bwd_dkv_kernel(const MAttn p) {
+__global__ __launch_bounds__(HD > 64 ? 512 : 1024) void mattn_bwd_dkv_kernel(const MAttn p) {
     constexpr int LS = HD + 4, DT = HD / 16;
     constexpr bool LATE = HD > 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(1024) void mattn_bwd_dkv_kernel(const MAttn p) {
 // The backward kernels only accumulate over the chunks (probabilities come from the saved row statistics).
 // Workgroup -> (sample, head, row block) by locate_block: the workgroups of a sample run on one XCD and share its lines in L2.
 template <int HD>
-__global__ __launch_bounds__(512, 4) void mattn_fwd_long_kernel(const MAttn p) {
+__global__ __launch_bounds__(512, HD > 64 ? 2 : 4) void mattn_fwd_long_kernel(const MAttn p) {
     constexpr int LS = HD + 4, DT = HD / 16, KEEP = HD <= 16 ? 16 : 8, CH = 16 * KEEP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;
@@ -824,7 +824,7 @@ __global__ __launch_bounds__(512, 4) void mattn_fwd_long_kernel(const MAttn p) {
 }
 
 template <int HD>
-__global__ __launch_bounds__(512, 4) void mattn_bwd_dq_long_kernel(const MAttn p) {
+__global__ __launch_bounds__(512, HD > 64 ? 2 : 4) void mattn_bwd_dq_long_kernel(const MAttn p) {
     constexpr int LS = HD + 4, DT = HD / 16, KEEP = HD <= 16 ? 16 : 8, CH = 16 * KEEP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;
@@ -902,7 +902,7 @@ __global__ __launch_bounds__(512, 4) void mattn_bwd_dq_long_kernel(const MAttn p
 }
 
 template <int HD>
-__global__ __launch_bounds__(512, 4) void mattn_bwd_dkv_long_kernel(const MAttn p) {
+__global__ __launch_bounds__(512, HD > 64 ? 2 : 4) void mattn_bwd_dkv_long_kernel(const MAttn p) {
     constexpr int LS = HD + 4, DT = HD / 16, KEEP = HD <= 16 ? 16 : 8, CH = 16 * KEEP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Qs = smem;
@@ -1003,11 +1003,11 @@ static int launch_big_lds(K kernel, dim3 grid, dim3 block, size_t lds, hipStream
     return MSN_OK;
 }
 
-// Is the matrix-core path applicable?  (16-B aligned operands, head width a multiple of 4 up to 64: a width that is not a
+// Is the matrix-core path applicable?  (16-B aligned operands, head width a multiple of 4 up to 128: a width that is not a
 // multiple of 16 runs as the next one, its missing columns zeros in LDS / registers only.)
 static int padded_hd(int hd) { return (hd + 15) / 16 * 16; }
 bool mattn_applicable(const MAttn& a) {
-    if (a.hd % 4 != 0 || a.hd > 64 || a.hd < 4 || a.Tq > 65535 || a.Tk > 65535 || a.q_bs == 0) return false;
+    if (a.hd % 4 != 0 || a.hd > 128 || a.hd < 4 || a.Tq > 65535 || a.Tk > 65535 || a.q_bs == 0) return false;
     if ((int64_t)a.B * a.H * ((std::max(a.Tq, a.Tk) + 127) / 128) > 0x7fffffffLL) return false;
     const int64_t lds[] = {a.ldq, a.ldk, a.ldv, a.q_bs, a.k_bs, a.v_bs};
     for (int64_t v : lds)
@@ -1023,12 +1023,16 @@ bool mattn_applicable(const MAttn& a) {
         case 16: rc = launch_big_lds(KERNEL<16>, __VA_ARGS__); break;                      \
         case 32: rc = launch_big_lds(KERNEL<32>, __VA_ARGS__); break;                      \
         case 48: rc = launch_big_lds(KERNEL<48>, __VA_ARGS__); break;                      \
-        default: rc = launch_big_lds(KERNEL<64>, __VA_ARGS__); break;                      \
+        case 64: rc = launch_big_lds(KERNEL<64>, __VA_ARGS__); break;                      \
+        case 80: rc = launch_big_lds(KERNEL<80>, __VA_ARGS__); break;                      \
+        case 96: rc = launch_big_lds(KERNEL<96>, __VA_ARGS__); break;                      \
+        case 112: rc = launch_big_lds(KERNEL<112>, __VA_ARGS__); break;                    \
+        default: rc = launch_big_lds(KERNEL<128>, __VA_ARGS__); break;                     \
     }
 
 // ragged-token path: self-attention over 16n + 1 tokens, one-pass forward (n + 1 <= 8 tiles), both weight passes of
 // the tail wave inside 128 rows
-static bool use_tail(const MAttn& a) { return a.Tq == a.Tk && a.Tk % 16 == 1 && a.Tk > 16 && a.Tk <= 113; }
+static bool use_tail(const MAttn& a) { return a.Tq == a.Tk && a.Tk % 16 == 1 && a.Tk > 16 && a.Tk <= 113 && a.hd <= 64; }
 
 static bool is_long(const MAttn& a) { return a.Tq > 128 || a.Tk > 128; }
 static int chunk_rows(int hd) { return padded_hd(hd) <= 16 ? 256 : 128; }

@@ -98,6 +98,44 @@ def test_ragged_last_token_path(T, hd, heads, masked):
         _lib.lib().msn_set_attention_path(0)
 
 
+@pytest.mark.parametrize("T", [(9, 9), (65, 65), (128, 128), (40, 128), (129, 129), (200, 200), (77, 300)])
+@pytest.mark.parametrize("hd,heads", [(128, 2), (96, 1), (80, 2), (112, 1), (72, 1), (100, 1)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_wide_heads_on_the_matrix_cores(T, hd, heads, masked):
+    """Head widths 65 .. 128 (the reference's default transformer_kwargs: emb 256 / 2 heads = 128-wide heads) take the matrix-core
+    kernels too (eight waves of up to 256 registers; a width that is not a multiple of 16 runs as the next one with zero columns),
+    short (<= 128 tokens) and chunked (longer) forms, Tq != Tk included; the result must also equal the vector-ALU kernels'."""
+    from multimodal_supernovae_amd import _lib, ops
+    Tq, Tk = T
+    g = torch.Generator().manual_seed(7000 + 10 * Tk + hd)
+    B, E = 3, heads * hd
+    q = torch.randn(B, Tq, E, generator=g)
+    k, v = torch.randn(B, Tk, E, generator=g), torch.randn(B, Tk, E, generator=g)
+    dout = torch.randn(B, Tq, E, generator=g)
+    mask = None
+    if masked:
+        mask = torch.rand(B, Tk, generator=g) > 0.3
+        mask[:, 0] = True
+        mask[2] = False                # a fully padded sample
+    scale = 1.0 / math.sqrt(E)
+    qr, kr, vr = (t.double().requires_grad_() for t in (q, k, v))
+    ref = _ref(qr, kr, vr, mask, heads, scale)
+    ref.backward(dout.double())
+    qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+    mu8 = ops._mask_u8(mask.cuda()) if mask is not None else None
+    try:
+        for path in (0, 1):            # automatic (= matrix cores for these widths) and the vector-ALU kernels
+            _lib.check(_lib.lib().msn_set_attention_path(path))
+            out, lse = ops.attention_fwd(qc, kc, vc, mu8, heads, scale)
+            torch.testing.assert_close(out.cpu().double(), ref.detach(), rtol=1e-4, atol=3e-5, msg=lambda m: f"path {path}: {m}")
+            dq, dk, dv = torch.empty_like(qc), torch.empty_like(kc), torch.empty_like(vc)
+            ops.attention_bwd(qc, kc, vc, mu8, heads, scale, out, lse, dout.cuda(), dq, dk, dv)
+            for got, want, name in ((dq, qr.grad, "dq"), (dk, kr.grad, "dk"), (dv, vr.grad, "dv")):
+                torch.testing.assert_close(got.cpu().double(), want, rtol=3e-4, atol=3e-5, msg=lambda m: f"{name} path {path}: {m}")
+    finally:
+        _lib.lib().msn_set_attention_path(0)
+
+
 @pytest.mark.parametrize("B,heads,hd,T", [(8, 8, 8, 50), (16, 3, 8, 200), (24, 2, 16, 220), (8, 5, 4, 33), (16, 6, 64, 65), (8, 2, 16, 220), (32, 8, 8, 12)])
 def test_xcd_grouped_head_order(B, heads, hd, T):
     """Batches that are multiples of 8 take the XCD-grouped (batch, head) order of the vector-ALU kernels (the heads of a

@@ -20,7 +20,8 @@ def timeit(fn, iters=20, warm=5):
 
 L = _lib.lib()
 for name, B, T, E, H in [("spectrum", 1024, 220, 32, 2), ("lightcurve", 1024, 200, 64, 8), ("spectrum 1024 bins", 64, 1024, 32, 2),
-                         ("vit-s", 1024, 65, 384, 6)]:
+                         ("vit-s", 1024, 65, 384, 6), ("reference default e256 / 2 heads", 1024, 200, 256, 2),
+                         ("128-wide heads, 100 tokens", 1024, 100, 256, 2)]:
     torch.manual_seed(0)
     qkv = torch.randn(B, T, 3 * E, device="cuda")
     q, k, v = qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:]
