@@ -100,6 +100,11 @@ __device__ __forceinline__ void ds_read128(bf16x8& dst, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
 }
 
+#ifndef MSN_BGEMM_STAGGER
+#define MSN_BGEMM_STAGGER 0
+#endif
+constexpr bool g_stagger = MSN_BGEMM_STAGGER != 0;
+
 template <int EPI, bool OUT_BF16>
 __global__ __launch_bounds__(512, 2) void bgemm_nt_kernel(const BgemmArgs p) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE_BYTES];
@@ -134,8 +139,12 @@ __global__ __launch_bounds__(512, 2) void bgemm_nt_kernel(const BgemmArgs p) {
         for (int q = 0; q < 4; ++q) {
             const int R = 8 * (4 * wave + q) + (lane >> 3);
             const int c = (lane & 7) ^ swz(R);
+#ifdef MSN_ABL_BF_SAMEPANEL               // diagnostic build: every tile reads the panels of tile (0, 0) -- L2 hits only
+            const int64_t ra = R, rb = R;
+#else
             const int64_t ra = std::min<int64_t>(m0_ + R, p.M - 1);        // rows past the edge: clamped, never stored
             const int64_t rb = std::min<int64_t>((int64_t)n0_ + R, p.N - 1);
+#endif
             sa[q] = p.A + ra * p.lda + 8 * c;
             sb[q] = p.B + rb * p.ldb + 8 * c;
         }
@@ -148,6 +157,9 @@ __global__ __launch_bounds__(512, 2) void bgemm_nt_kernel(const BgemmArgs p) {
     make_src(srcA, srcB, m0, n0);
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t*)lds;   // LDS byte address of the array
     auto issue = [&](int buf, const u16* const (&sa)[4], const u16* const (&sb)[4], int kt) {
+#ifdef MSN_ABL_BF_NODMA
+        return;                            // diagnostic build (tools/microbench/build_ablate.sh): no operand traffic at all
+#endif
         unsigned char* dst = lds + buf * STAGE_BYTES + wave * 4096;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -168,12 +180,19 @@ __global__ __launch_bounds__(512, 2) void bgemm_nt_kernel(const BgemmArgs p) {
     bf16x8 fa[2][4], fb[2][4];
 
     // set S of A fragments <- m-tiles 4 mh .. 4 mh + 3 at k32 half kk;  set S of B fragments <- all 4 n-tiles at kk
+#ifdef MSN_ABL_BF_NOFRAG                   // diagnostic build: no fragment reads (the MFMAs multiply whatever the registers hold)
+    for (int s_ = 0; s_ < 2; ++s_)
+        for (int i = 0; i < 4; ++i) { asm volatile("" : "=v"(fa[s_][i])); asm volatile("" : "=v"(fb[s_][i])); }
+#define REQ_A(S, buf, kk, mh)
+#define REQ_B(S, buf, kk)
+#else
 #define REQ_A(S, buf, kk, mh)                                                                                      \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                  \
         ds_read128(fa[S][i], lds0 + (buf) * STAGE_BYTES + (fragA ^ ((kk) << 6)) + (4 * (mh) + i) * 2048);
 #define REQ_B(S, buf, kk)                                                                                          \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                  \
         ds_read128(fb[S][j], lds0 + (buf) * STAGE_BYTES + (fragB ^ ((kk) << 6)) + j * 2048);
+#endif
     // D^T tile = B_frag . A_frag^T: lane gets row m = l15 of the tile and columns n = 4 g .. 4 g + 3
 #define MULT(SA, SB, mh)                                                                                           \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)                    \
@@ -295,20 +314,29 @@ __global__ __launch_bounds__(512, 2) void bgemm_nt_kernel(const BgemmArgs p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (kt + 2 < nkt) issue(cur, srcA, srcB, kt + 2);
-            else if (more) {                                   // the ring runs on into the next tile
-                if (kt + 2 == nkt) {                           // (this tile's last K-tile was requested one K-tile ago)
-                    locate(t_next, m0_next, n0_next, tm_next);
-                    make_src(srcA, srcB, m0_next, n0_next);
+            // (The 8 LDS-DMA instructions of a wave are what the loop pays most for -- profiles/r03_bgemm_kloop_ablation.txt: without
+            // them it runs 40 % faster, with every panel an L2 hit 15 %.  Letting the two waves of a SIMD take turns -- one issues
+            // here, the other behind its MULT -- gains 5 % on long K in isolation and nothing in the training step; issuing later
+            // still loses: the pieces land too late for the next barrier.  Build with -DMSN_BGEMM_STAGGER=1 to try.)
+            auto refill = [&]() {
+                if (kt + 2 < nkt) issue(cur, srcA, srcB, kt + 2);
+                else if (more) {                               // the ring runs on into the next tile
+                    if (kt + 2 == nkt) {                       // (this tile's last K-tile was requested one K-tile ago)
+                        locate(t_next, m0_next, n0_next, tm_next);
+                        make_src(srcA, srcB, m0_next, n0_next);
+                    }
+                    issue(cur, srcA, srcB, kt + 2 - nkt);
                 }
-                issue(cur, srcA, srcB, kt + 2 - nkt);
-            }
+            };
+            if (wave < 4 || !g_stagger) refill();
             if (kt + 1 < nkt) {
                 REQ_A(0, cur ^ 1, 0, 0)
                 REQ_B(0, cur ^ 1, 0)
             }
             __builtin_amdgcn_sched_barrier(0);
             MULT(1, 1, 1)
+            __builtin_amdgcn_sched_barrier(0);
+            if (wave >= 4 && g_stagger) refill();
             __builtin_amdgcn_sched_barrier(0);
         }
         store_tile(m0, n0, tm);

@@ -8,8 +8,10 @@ PKG=$ROOT/multimodal_supernovae_amd
 python3 -m multimodal_supernovae_amd.build > /dev/null
 mkdir -p "$ROOT/tools/microbench/ablate"
 DEFS=""; NAME=""
-for a in "$@"; do case $a in ACC_AGPR) DEFS="$DEFS -DMSN_ACC_AGPR";; *) DEFS="$DEFS -DMSN_ABL_$a";; esac; NAME="${NAME}_$a"; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast $DEFS -c "$PKG/csrc/gemm.hip" -o "/tmp/gemm_abl$NAME.o"
-OBJS=$(ls "$PKG"/build/*.o | grep -v "build/gemm.o")
+#   BF_NODMA / BF_NOFRAG: the same for the bf16-resident NT kernel (gemm_bf16res.hip)
+SRC=gemm
+for a in "$@"; do case $a in ACC_AGPR) DEFS="$DEFS -DMSN_ACC_AGPR";; BF_*) DEFS="$DEFS -DMSN_ABL_$a"; SRC=gemm_bf16res;; *) DEFS="$DEFS -DMSN_ABL_$a";; esac; NAME="${NAME}_$a"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -I"$ROOT/include" $DEFS -c "$PKG/csrc/$SRC.hip" -o "/tmp/gemm_abl$NAME.o"
+OBJS=$(ls "$PKG"/build/*.o | grep -v "build/$SRC.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/tools/microbench/ablate/libmsn$NAME.so" "/tmp/gemm_abl$NAME.o" $OBJS
 echo "built tools/microbench/ablate/libmsn$NAME.so"
