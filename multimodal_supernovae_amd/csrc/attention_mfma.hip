@@ -722,6 +722,20 @@ __global__ __launch_bounds__(HD > 64 ? 512 : 1024) void mattn_bwd_dkv_kernel(con
 // queries 4g + r -- take the rescale factor of their query from its column-owner lane), one pass WITHIN a chunk.
 // The backward kernels only accumulate over the chunks (probabilities come from the saved row statistics).
 // Workgroup -> (sample, head, row block) by locate_block: the workgroups of a sample run on one XCD and share its lines in L2.
+#ifdef MSN_ATTN_TIMELINE   // diagnostic build (tools/microbench/attn_timeline.py): shader-clock stamps of wave 0 of every workgroup
+constexpr int kDbgRows = 32768;
+__device__ unsigned long long g_mattn_dbg[kDbgRows * 8];
+extern "C" int msn_mattn_debug_read(unsigned long long* out, int rows) {   // out[rows][8]; clears the buffer
+    if (rows > kDbgRows) return 1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mattn_dbg), sizeof(unsigned long long) * 8 * rows) != hipSuccess) return 1;
+    void* sym = nullptr;
+    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_mattn_dbg)) != hipSuccess) return 1;
+    return hipMemset(sym, 0, sizeof(unsigned long long) * 8 * kDbgRows) == hipSuccess ? 0 : 1;
+}
+#define MSN_TL(var) const unsigned long long var = __builtin_readcyclecounter();
+#else
+#define MSN_TL(var)
+#endif
 template <int HD>
 __global__ __launch_bounds__(512, HD > 64 ? 2 : 4) void mattn_fwd_long_kernel(const MAttn p) {
     constexpr int LS = HD + 4, DT = HD / 16, KEEP = HD <= 16 ? 16 : 8, CH = 16 * KEEP;
@@ -729,6 +743,7 @@ __global__ __launch_bounds__(512, HD > 64 ? 2 : 4) void mattn_fwd_long_kernel(co
     float* Ks = smem;
     float* Vs = smem + (size_t)CH * LS;
     uint8_t* Ms = reinterpret_cast<uint8_t*>(Vs + (size_t)CH * LS);
+    MSN_TL(tl0)
     const int NB = (p.Tq + 127) / 128;
     int b, hh, blk;
     locate_block(p, NB, b, hh, blk);
@@ -749,6 +764,7 @@ __global__ __launch_bounds__(512, HD > 64 ? 2 : 4) void mattn_fwd_long_kernel(co
     };
     frags_request<HD>(qf, p.q + (int64_t)b * p.q_bs, p.ldq, col0, qrow, p.Tq, g, p.hd);
     if (HD <= 32) request(0);
+    MSN_TL(tla)
     frags_commit<HD>(qf, qrow, p.Tq, g, p.scale, p.hd);
     float m = -INFINITY, l = 0.f;
     f32x4 o[DT];
@@ -760,10 +776,12 @@ __global__ __launch_bounds__(512, HD > 64 ? 2 : 4) void mattn_fwd_long_kernel(co
         if (k0 > 0 || HD > 32) request(k0);               // (narrow heads: chunk 0 was requested beside the fragments)
         sv.commit_first(Ks);
         sv.commit_second(Ks, Vs);
+        MSN_TL(tlc)
         if (tj < TPc) Ms[tj] = tj < nt ? (mk ? 1 : 0) : 2;    // key codes: 1 live, 0 masked out, 2 beyond the sequence
         for (int j = tj + blockDim.x; j < TPc; j += blockDim.x)
             Ms[j] = j < nt ? (p.mask ? (p.mask[(int64_t)b * p.Tk + k0 + j] ? 1 : 0) : 1) : 2;
         __syncthreads();
+        MSN_TL(tl1)
         f32x4 sc[KEEP];
         float mc = -INFINITY;
 #pragma unroll
@@ -802,6 +820,12 @@ __global__ __launch_bounds__(512, HD > 64 ? 2 : 4) void mattn_fwd_long_kernel(co
                 accum16<HD>(sc[kt], Vs + kt * 16 * LS, o, c, g);
             }
         }
+#ifdef MSN_ATTN_TIMELINE
+        if (threadIdx.x == 0 && blockIdx.x < kDbgRows && k0 == 0) {
+            unsigned long long* d = g_mattn_dbg + 8 * blockIdx.x;
+            d[0] = tl0, d[1] = tla, d[2] = tlc, d[3] = tl1, d[4] = __builtin_readcyclecounter();
+        }
+#endif
     }
     l = group_sum4(l);
 #pragma unroll
@@ -821,6 +845,10 @@ __global__ __launch_bounds__(512, HD > 64 ? 2 : 4) void mattn_fwd_long_kernel(co
         st[0] = m;
         st[1] = __logf(l);
     }
+#ifdef MSN_ATTN_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0 && blockIdx.x < kDbgRows) g_mattn_dbg[8 * blockIdx.x + 5] = __builtin_readcyclecounter();
+#endif
 }
 
 template <int HD>
