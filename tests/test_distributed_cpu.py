@@ -93,9 +93,9 @@ def _worker(rank, world, port, n_mod, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_mod", [2, 3])
-def test_global_negatives_two_ranks_gloo(n_mod):
-    world = 2
+@pytest.mark.parametrize("n_mod,world", [(2, 2), (3, 2), (3, 4), (2, 8)])
+def test_global_negatives_two_ranks_gloo(n_mod, world):
+    """world 2, and -- the row offsets of ranks beyond the second, the layouts of the 4- and 8-GPU points of the metric -- 4 and 8."""
     ctx = mp.get_context("spawn")
     out = ctx.Manager().dict()
     port = _free_port()
@@ -105,7 +105,7 @@ def test_global_negatives_two_ranks_gloo(n_mod):
     for p in procs:
         p.join(180)
         assert p.exitcode == 0, f"rank exited with {p.exitcode}"
-    assert dict(out) == {0: True, 1: True}
+    assert dict(out) == {r: True for r in range(world)}
 
 
 def _reducer_worker(rank, world, port, out):

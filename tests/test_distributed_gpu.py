@@ -18,6 +18,14 @@ def test_two_rank_step_equals_single_process_global_batch():
     assert r.returncode == 0 and "DIST CHECK OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_four_rank_step_equals_single_process_global_batch():
+    """The same with FOUR ranks sharing the GPU: the row offsets of ranks 2 and 3 in the sharded InfoNCE kernels and in the packed
+    all-gather (the 4- and 8-GPU points of the metric use them; two ranks only ever exercise offsets 0 and b)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dist_check.py"), "--world", "4"], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "DIST CHECK OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_two_rank_synchronised_batchnorm_equals_single_process_global_batch():
     """ConvMixer tower (three BatchNorms per layer) under data parallel with `enable_sync_batchnorm`: loss, gradients
     and running statistics of two ranks equal the single-process step at the doubled batch."""

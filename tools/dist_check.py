@@ -19,6 +19,7 @@ CK = dict(dim=8, depth=2, channels=3, kernel_size=5, patch_size=4, n_out=8, drop
 BATCHNORM = "--batchnorm" in sys.argv     # ConvMixer image tower + light curves, synchronised BatchNorm
 TRAINER = "--trainer" in sys.argv         # Trainer.fit with a validation loader whose shards are UNEVEN across the ranks
 GRAPHED = "--graphed" in sys.argv         # GraphedTrainStep under data parallel (segmented capture) == the eager steps, bit for bit
+WORLD = int(sys.argv[sys.argv.index("--world") + 1]) if "--world" in sys.argv else 2   # default check only: ranks sharing the GPU (<= 4)
 
 
 def make_model():
@@ -192,7 +193,7 @@ if __name__ == "__main__":
         ok = ok and abs(out["r0"][0] - out["r1"][0]) < 1e-9          # both ranks report the same global number
         print("DIST CHECK", "OK" if ok else "FAILED")
         sys.exit(0 if ok else 1)
-    procs = [ctx.Process(target=worker, args=(r, 2, 29611, out)) for r in range(2)]
+    procs = [ctx.Process(target=worker, args=(r, WORLD, 29611, out)) for r in range(WORLD)]
     [p.start() for p in procs]
     [p.join(300) for p in procs]
     print(dict(out), [p.exitcode for p in procs])
