@@ -600,6 +600,14 @@ static Plan plan(int64_t M, int64_t N, int64_t K, int opA, bool allow_tail = tru
     // emb-64 towers) wastes a quarter and more of the MFMAs on columns that do not exist: 64-wide tiles (measured on
     // 200k-row products: N = 192 80.5 -> 69.8 us, N = 96 46.2 -> 38.8 us)
     if (N > 64 && N % 128 != 0 && N % 128 <= 64 && opA == MSN_OP_N && g_gemm_bn == 0) p.bn = 64;
+    // Weight gradients with a small output (dW of the e x e projection: 384 x 384 = 9 tiles of 128 x 128) are all split-K: twice as
+    // many 128 x 64 tiles need half the K-slabs for the same 512 workgroups -- half the slab bytes, K loops twice as long per prologue
+    // (tools/microbench/wgrad_tiles.py: 384 x 384 over 16 640 rows 66.1 -> 53.1 us, 8320: 38.7 -> 35.8, 66 560: 182 -> 175;
+    // 1152 x 384 gains up to 16 640 rows (94 -> 80, 146 -> 138 us) and loses from 66 560 on; 36 tiles and more: no gain)
+    if (opA == MSN_OP_T && M > 64 && N > 64 && N % 64 == 0 && g_gemm_bn == 0) {          // (few rows: the 32- / 64-row tiles below)
+        const int64_t t128 = cdiv(M, 128) * cdiv(N, 128);
+        if (t128 <= 9 || (t128 <= 27 && K <= 20000)) p.bn = 64;
+    }
     if (N > 64 && g_gemm_bn != 0) p.bn = g_gemm_bn;
     // Weight gradients with few rows (dW of a Linear whose OUTPUT is 32 / 64 wide: the reference towers' ff2): a 128-row
     // tile would multiply 4x / 2x rows that do not exist -- measured compute-bound on them (M = 32, N = 128, K = 225 280:
