@@ -325,9 +325,10 @@ int msn_attention_bwd(const float* q, int64_t ldq, int64_t q_bstride, const floa
                       int64_t lddq, int64_t dq_bstride, float* dk, int64_t lddk, int64_t dk_bstride,
                       float* dv, int64_t lddv, int64_t dv_bstride, msn_stream_t stream);
 /* Two implementations sit behind msn_attention_*: vector-ALU kernels (any head width <= 128, any
- * length; the reference-native 8-wide heads and every sequence longer than 256 tokens) and matrix-core
- * kernels (v_mfma_f32_16x16x4_f32; <= 256 tokens; head width 16/32/48/64: the ViT towers and the
- * reference's 16-wide spectrum heads at 220 tokens; widths 4/8/12 run zero-padded to 16).
+ * length; the reference-native 8-wide heads, widths that are not a multiple of 4, unaligned operands)
+ * and matrix-core kernels (v_mfma_f32_16x16x4_f32; any length -- chunked beyond 128 tokens; every head
+ * width that is a multiple of 4 up to 128, run as the next multiple of 16 with zero columns: the ViT
+ * towers, the reference's 16-wide spectrum heads, its default 128-wide heads (emb 256 / 2 heads)).
  * mode 0 = automatic (default: matrix cores for widths >= 16 where they apply), 1 = always vector-ALU,
  * 2 = matrix cores whenever applicable, narrow heads included (measured no faster there).
  * Process-wide; meant for tests. */
