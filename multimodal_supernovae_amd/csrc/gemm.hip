@@ -856,7 +856,15 @@ static const float* conv_zero_page() {      // per device, like the tail counter
     }
     return page[dev];
 }
+// n / d == (n * div_magic(d)) >> 36 for every n with n * d < 2^36 (the kernels split pixel indices this way)
 static unsigned long long div_magic(int d) { return (1ull << 36) / (unsigned long long)d + 1ull; }
+// image sizes the gather arithmetic covers: fewer than 2^27 pixels on either side of the convolution and every index x divisor pair
+// inside the multiply-shift division's exact range (512 x 512 images at any batch up to 512; a 1 x 1024 series at batch 1024 ...)
+static bool conv_size_ok(int B, int H, int W, int OH, int OW) {
+    const int64_t n = std::max((int64_t)B * H * W, (int64_t)B * OH * OW);
+    const int64_t d = std::max(std::max(H, W), std::max(OH, OW));
+    return H <= 8192 && W <= 8192 && n < (1ll << 27) && n * d < (1ll << 36);
+}
 struct ConvShape { int B, H, W, C, Cout, kh, kw, sh, sw, ph, pw, OH, OW; };
 static int conv_shape(const char* who, int B, int H, int W, int C, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
                       ConvShape* cs) {
@@ -864,17 +872,16 @@ static int conv_shape(const char* who, int B, int H, int W, int C, int Cout, int
                 "%s: bad geometry", who);
     const int OH = (H + 2 * ph - kh) / sh + 1, OW = (W + 2 * pw - kw) / sw + 1;
     MSN_REQUIRE(OH > 0 && OW > 0, "%s: kernel larger than the padded input", who);
-    MSN_REQUIRE(H <= 512 && W <= 512 && (int64_t)B * H * W < (1ll << 27),
-                "%s: implicit convolution takes images up to 512 x 512 and fewer than 2^27 pixels per launch", who);
+    MSN_REQUIRE(conv_size_ok(B, H, W, OH, OW),
+                "%s: implicit convolution takes fewer than 2^27 pixels per launch with pixels x longest side < 2^36", who);
     *cs = ConvShape{B, H, W, C, Cout, kh, kw, sh, sw, ph, pw, OH, OW};
     return MSN_OK;
 }
 // which convolutions the implicit kernels take (the caller falls back to im2col + msn_sgemm otherwise)
 extern "C" int msn_conv2d_implicit_ok(int B, int H, int W, int C, int Cout, int kh, int kw, int sh, int sw, int ph, int pw) {
     if (B <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || ph < 0 || pw < 0) return 0;
-    if (H > 512 || W > 512 || (int64_t)B * H * W >= (1ll << 27)) return 0;
     const int OH = (H + 2 * ph - kh) / sh + 1, OW = (W + 2 * pw - kw) / sw + 1;
-    if (OH <= 0 || OW <= 0) return 0;
+    if (OH <= 0 || OW <= 0 || !conv_size_ok(B, H, W, OH, OW)) return 0;
     // a K-step of 32 lies inside one tap (C % 32 == 0; dgrad: C_out % 32 == 0); tiles at least 64 wide (C_out, C > 32);
     // wgrad walks whole K-steps of output pixels
     return C % 32 == 0 && Cout % 32 == 0 && C > 32 && Cout > 32 && ((int64_t)B * OH * OW) % 32 == 0;

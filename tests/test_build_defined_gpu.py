@@ -41,7 +41,7 @@ def test_conv_channels_last_matches_torch(H, W, C, co, k, s, p):
     (4, 8, 8, 64, 64, 3, 1, 1, False), (8, 16, 16, 64, 128, 3, 2, 1, False), (4, 8, 8, 128, 64, 3, 1, 1, True),
     (2, 1, 64, 64, 128, 5, 1, 2, True), (32, 4, 4, 256, 256, 3, 1, 1, False), (32, 5, 7, 64, 96, 3, 1, 1, True),
     (32, 6, 10, 96, 160, 3, 2, 1, True), (64, 3, 5, 64, 64, 3, 1, 1, False), (8, 12, 12, 64, 64, 5, 1, 2, False),
-    (520, 8, 8, 64, 64, 3, 1, 1, False)])
+    (520, 8, 8, 64, 64, 3, 1, 1, False), (4, 1, 1024, 64, 128, 5, 1, 2, True), (2, 600, 8, 64, 64, 3, 1, 1, False)])
 def test_conv_implicit_gemm_matches_torch(B, H, W, C, co, k, s, p, bias):
     """Channel counts that are multiples of 32 run without a column matrix (msn_conv2d_fwd / _dgrad / _wgrad: the GEMM lanes
     gather from the image, padding taps read zeros): y, dx, dw, db against torch in float64, ragged row tiles, odd image

@@ -121,7 +121,10 @@ def test_convolution_plan_queries_without_a_gpu():
     assert not ok(1024, 64, 64, 4, 64, 7, 7, 2, 2, 3, 3)       # the stem: 4 channels, several taps per K-step
     assert not ok(1024, 16, 16, 64, 32, 3, 3, 1, 1, 1, 1)      # 32-wide output: narrower than the kernels' tiles
     assert not ok(3, 5, 5, 64, 64, 3, 3, 1, 1, 1, 1)           # 75 output pixels: not whole K-steps for the weight gradient
-    assert not ok(1, 1024, 1024, 64, 64, 3, 3, 1, 1, 1, 1)     # images beyond 512 x 512
+    assert ok(1024, 1, 1024, 64, 128, 1, 5, 1, 1, 0, 2)        # the 1-D CNN on 1024-bin spectra (cfg4's third tower)
+    assert ok(1, 1024, 1024, 64, 64, 3, 3, 1, 1, 1, 1)         # one 1024 x 1024 image: 2^20 pixels x 2^10 < 2^36
+    assert not ok(64, 2048, 2048, 64, 64, 3, 3, 1, 1, 1, 1)    # 2^28 pixels: beyond the gather arithmetic
+    assert not ok(100, 1024, 1024, 64, 64, 3, 3, 1, 1, 1, 1)   # < 2^27 pixels, but pixels x side >= 2^36 (multiply-shift division)
     assert L.msn_conv2d_workspace_bytes(1024, 16, 16, 64, 64, 3, 3, 1, 1, 1, 1) > 0      # split-K slabs of the weight gradient
     assert L.msn_conv2d_workspace_bytes(3, 5, 5, 64, 64, 3, 3, 1, 1, 1, 1) == 0
     # weight gradients with few rows are planned on short tiles; the workspace query answers for the same plan
