@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 LC = dict(n_out=32, emb=64, heads=8, depth=5, dropout=0.0, time_norm=20583.369161312577, agg="mean")
 CONV_PLACEHOLDER = dict(dim=8, depth=1, channels=3, kernel_size=5, patch_size=8, n_out=32, dropout_prob=0.0)
 IMG, T_LC, NBAND, ENC_DIM, N_OUT = 64, 200, 2, 128, 32
-GEMM_KERNEL_NAME = {"f32": "msn::sgemm_dma_kernel + msn::sgemm_kernel (fp32 v_mfma_f32_32x32x2_f32; all msn_sgemm launches)",
+GEMM_KERNEL_NAME = {"f32": "msn::sgemm_dma_kernel + msn::sgemm_kernel (fp32 v_mfma_f32_32x32x2_f32; all msn_sgemm launches and, where a tower has convolutions, the implicit-GEMM msn_conv2d_* launches of the same kernel)",
                     "bf16x3": "msn::bgemm_kernel<planes=2> (3 x v_mfma_f32_32x32x16_bf16 per algorithmic MAC tile)",
                     "bf16": "msn::bgemm_kernel<planes=1> (v_mfma_f32_32x32x16_bf16)"}
 LR, WD, LOGIT_SCALE = 3.716367614864064e-05, 0.000555522900788888, 19.545966923442453  # maven_pretrain_config.yaml

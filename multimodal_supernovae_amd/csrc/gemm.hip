@@ -587,7 +587,7 @@ struct Plan {
     }
 };
 
-static Plan plan(int64_t M, int64_t N, int64_t K, int opA, bool allow_tail = true) {
+static Plan plan(int64_t M, int64_t N, int64_t K, int opA, bool allow_tail = true, bool small_tail = false) {
     Plan p;
     p.bm = 128;
     p.bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
@@ -595,7 +595,12 @@ static Plan plan(int64_t M, int64_t N, int64_t K, int opA, bool allow_tail = tru
     // 128 x 64 tiles fill the 512 workgroup slots better than K-slabs of the wide tiles + a finishing pass
     // (tools/bench_gemm_small.py, M = 8320: proj 42.3 -> 33.1 us, qkv 83.2 -> 77.8, ff1 110.4 -> 102.1; M = 33280 proj
     // 104.2 -> 97.4; from ~1000 tiles on the wide tile wins again)
-    if (N > 64 && N % 64 == 0 && opA == MSN_OP_N && g_gemm_bn == 0 && cdiv(M, 128) * cdiv(N, 128) <= 800) p.bn = 64;
+    // (small_tail: the implicit convolutions, which the work-list kernel does not take -- a launch of fewer than 128 wide tiles with a long
+    // K keeps them and cuts EVERY tile into K-slabs instead, see the tail split below: ResNet-18's last stages at 256 rows per GPU are
+    // 32 / 64 tiles of 144 / 72 K-steps)
+    const bool cut_all = small_tail && opA == MSN_OP_N && g_gemm_bn == 0 && g_gemm_tail && allow_tail && N >= 128 &&
+                         cdiv(M, 128) * cdiv(N, 128) < 128 && cdiv(K, BK) >= 32;
+    if (N > 64 && N % 64 == 0 && opA == MSN_OP_N && g_gemm_bn == 0 && cdiv(M, 128) * cdiv(N, 128) <= 800 && !cut_all) p.bn = 64;
     // A width whose last 128-wide tile would be at most half full (N = 96, 192: the stacked q|k|v projections of the emb-32 /
     // emb-64 towers) wastes a quarter and more of the MFMAs on columns that do not exist: 64-wide tiles (measured on
     // 200k-row products: N = 192 80.5 -> 69.8 us, N = 96 46.2 -> 38.8 us)
@@ -642,7 +647,7 @@ static Plan plan(int64_t M, int64_t N, int64_t K, int opA, bool allow_tail = tru
     p.splits = s;
     p.kps = (int)per;
     const int64_t r = tiles % 512;
-    if (g_gemm_tail && allow_tail && s == 1 && p.bn == 128 && p.bm == 128 && r > 0 && tiles >= 128 && tiles < (1ll << 30)) {
+    if (g_gemm_tail && allow_tail && s == 1 && p.bn == 128 && p.bm == 128 && r > 0 && (tiles >= 128 || cut_all) && tiles < (1ll << 30)) {
         // time of the last round in units of one whole tile: ceil(r c / 512) rounds of 1 / c tile each (+ a small
         // charge per slab for its prologue, the slab store and the finishing pass)
         const int64_t cmax = std::min<int64_t>(std::min<int64_t>(ksteps / 4, 16), 1024 / r);
@@ -729,8 +734,10 @@ static int sgemm_impl(int opA, int opB, int64_t M, int64_t N, int64_t K, const f
     a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux;
     a.epilogue = epilogue;
-    const Plan pl = plan(M, N, K, opA, colsum_out == nullptr);
-    const int bm = conv != 0 ? 128 : pl.bm, bn = pl.bn, splits = pl.splits, kps = pl.kps;   // (short tiles: M <= bm, one row of tiles either way)
+    const Plan pl = plan(M, N, K, opA, colsum_out == nullptr, conv != 0);
+    // (short tiles: M <= bm, one row of tiles either way; of the implicit convolutions only the weight gradient of a 64-channel layer
+    // -- 64 x (taps x C) over all output pixels: ResNet-18's first stage -- has a 64-row kernel, the others keep 128 rows)
+    const int bm = conv != 0 ? ((conv == 2 && pl.bm == 64 && pl.bn == 128) ? 64 : 128) : pl.bm, bn = pl.bn, splits = pl.splits, kps = pl.kps;
     a.colsum = nullptr;
     a.tiles_m = (int)cdiv(M, bm);
     a.tiles_n = (int)cdiv(N, bn);
@@ -788,7 +795,8 @@ static int sgemm_impl(int opA, int opB, int64_t M, int64_t N, int64_t K, const f
     if (bm != 128) bf16_ok = false;   // the short tiles exist for the fp32 kernels only (tiny products: exact fp32 costs nothing)
     if (conv != 0) {   // implicit-GEMM convolution: the 4-wave LDS-DMA kernels only
         MSN_REQUIRE(dma_ok && !bf16_ok && bn >= 64, "implicit convolution: shape not taken by the LDS-DMA kernels");
-        if (bn == 128) rc = launch_dma_conv<128, 128, 64, 64, 32, 2>(a, conv, opB, st);
+        if (bm == 64) rc = launch_dma_conv<64, 128, 32, 64, 32, 2>(a, conv, opB, st);
+        else if (bn == 128) rc = launch_dma_conv<128, 128, 64, 64, 32, 2>(a, conv, opB, st);
         else rc = launch_dma_conv<128, 64, 64, 32, 32, 3>(a, conv, opB, st);
     } else if (bf16_ok) rc = launch_bgemm(a, opA, opB, precision == MSN_PREC_BF16X3 ? 2 : 1, bm, bn, st);
     else if (bm == 64 && bn == 64 && dma_ok) rc = launch_dma<64, 64, 32, 32, 32, 3>(a, opA, opB, st);
@@ -891,7 +899,7 @@ extern "C" size_t msn_conv2d_workspace_bytes(int B, int H, int W, int C, int Cou
     if (!msn_conv2d_implicit_ok(B, H, W, C, Cout, kh, kw, sh, sw, ph, pw)) return 0;
     const int OH = (H + 2 * ph - kh) / sh + 1, OW = (W + 2 * pw - kw) / sw + 1;
     const int64_t Mo = (int64_t)B * OH * OW, Mi = (int64_t)B * H * W, Kc = (int64_t)kh * kw * C;
-    const Plan f = plan(Mo, Cout, Kc, MSN_OP_N), d = plan(Mi, C, (int64_t)kh * kw * Cout, MSN_OP_N), w = plan(Cout, Kc, Mo, MSN_OP_T, false);
+    const Plan f = plan(Mo, Cout, Kc, MSN_OP_N, true, true), d = plan(Mi, C, (int64_t)kh * kw * Cout, MSN_OP_N, true, true), w = plan(Cout, Kc, Mo, MSN_OP_T, false);
     const size_t wg = w.ws_bytes(Cout, Kc) + sizeof(float) * (size_t)w.splits * (size_t)Cout;
     return std::max(std::max(f.ws_bytes(Mo, Cout), d.ws_bytes(Mi, C)), wg);
 }

@@ -590,6 +590,27 @@ def conv2d_implicit_ok(B, H, W, C, co, kh, kw, sh, sw, ph, pw):
     return bool(lib().msn_conv2d_implicit_ok(B, H, W, C, co, kh, kw, sh, sw, ph, pw))
 
 
+class _conv_profile:
+    """GEMM_PROFILE entry for an implicit-GEMM convolution launch (bench.py's roofline step): M x N x K of the product the kernel
+    multiplies, and the bytes it must move -- image, weights, result; NOT the column matrix, which is never written."""
+
+    def __init__(self, code, M, N, K, nbytes, epilogue=0):
+        self.key, self.flops, self.nbytes = (code, 0, int(M), int(N), int(K), int(epilogue)), 2.0 * M * N * K, float(nbytes)
+        self.prof = GEMM_PROFILE
+
+    def __enter__(self):
+        if self.prof is not None:
+            self.ev0, self.ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.ev0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.prof is not None and exc[0] is None:
+            self.ev1.record()
+            self.prof.append((self.ev0, self.ev1, self.flops, self.key, False, self.nbytes))
+        return False
+
+
 def _conv_ws(geom, device):
     nb = lib().msn_conv2d_workspace_bytes(*geom)
     return (_workspace(nb, device), nb) if nb else (None, 0)
@@ -601,9 +622,11 @@ def conv2d_fwd(x, w_tap, kh, kw, sh, sw, ph, pw, bias=None, relu=False):
     co = w_tap.shape[0]
     y = torch.empty((B * conv_out(H, kh, sh, ph) * conv_out(W, kw, sw, pw), co), dtype=torch.float32, device=x.device)
     ws, nb = _conv_ws((B, H, W, C, co, kh, kw, sh, sw, ph, pw), x.device)
-    check(lib().msn_conv2d_fwd(ptr(_f32c(x, "x")), B, H, W, C, ptr(_f32c(w_tap, "w_tap")), co, kh, kw, sh, sw, ph, pw,
-                               ptr(bias) if bias is not None else None, EPI_RELU if relu else EPI_NONE, ptr(y),
-                               ptr(ws) if ws is not None else None, nb, stream_ptr()), "msn_conv2d_fwd")
+    Mo, K = y.shape[0], kh * kw * C
+    with _conv_profile(20, Mo, co, K, 4.0 * (x.numel() + co * K + Mo * co), EPI_RELU if relu else EPI_NONE):
+        check(lib().msn_conv2d_fwd(ptr(_f32c(x, "x")), B, H, W, C, ptr(_f32c(w_tap, "w_tap")), co, kh, kw, sh, sw, ph, pw,
+                                   ptr(bias) if bias is not None else None, EPI_RELU if relu else EPI_NONE, ptr(y),
+                                   ptr(ws) if ws is not None else None, nb, stream_ptr()), "msn_conv2d_fwd")
     return y
 
 
@@ -613,8 +636,10 @@ def conv2d_dgrad(dy, w_tco, shape, kh, kw, ph, pw):
     co = dy.shape[1]
     dx = torch.empty(shape, dtype=torch.float32, device=dy.device)
     ws, nb = _conv_ws((B, H, W, C, co, kh, kw, 1, 1, ph, pw), dy.device)
-    check(lib().msn_conv2d_dgrad(ptr(_f32c(dy, "dy")), B, H, W, C, ptr(_f32c(w_tco, "w_tco")), co, kh, kw, ph, pw, ptr(dx),
-                                 ptr(ws) if ws is not None else None, nb, stream_ptr()), "msn_conv2d_dgrad")
+    Mi, K = B * H * W, kh * kw * co
+    with _conv_profile(21, Mi, C, K, 4.0 * (dy.numel() + K * C + Mi * C)):
+        check(lib().msn_conv2d_dgrad(ptr(_f32c(dy, "dy")), B, H, W, C, ptr(_f32c(w_tco, "w_tco")), co, kh, kw, ph, pw, ptr(dx),
+                                     ptr(ws) if ws is not None else None, nb, stream_ptr()), "msn_conv2d_dgrad")
     return dx
 
 
@@ -625,9 +650,11 @@ def conv2d_wgrad(dy, x, kh, kw, sh, sw, ph, pw, want_bias=False):
     dw = torch.empty((co, kh * kw * C), dtype=torch.float32, device=x.device)
     db = torch.empty(co, dtype=torch.float32, device=x.device) if want_bias else None
     ws, nb = _conv_ws((B, H, W, C, co, kh, kw, sh, sw, ph, pw), x.device)
-    check(lib().msn_conv2d_wgrad(ptr(_f32c(dy, "dy")), ptr(_f32c(x, "x")), B, H, W, C, co, kh, kw, sh, sw, ph, pw, ptr(dw),
-                                 ptr(db) if db is not None else None, ptr(ws) if ws is not None else None, nb, stream_ptr()),
-          "msn_conv2d_wgrad")
+    Mo, K = dy.shape[0], kh * kw * C
+    with _conv_profile(22, co, K, Mo, 4.0 * (dy.numel() + x.numel() + co * K)):
+        check(lib().msn_conv2d_wgrad(ptr(_f32c(dy, "dy")), ptr(_f32c(x, "x")), B, H, W, C, co, kh, kw, sh, sw, ph, pw, ptr(dw),
+                                     ptr(db) if db is not None else None, ptr(ws) if ws is not None else None, nb, stream_ptr()),
+              "msn_conv2d_wgrad")
     return dw, db
 
 
