@@ -160,13 +160,14 @@ class ResNet18(nn.Module):
         self.fc = nn.Linear(512, n_out)
 
     def forward(self, x):
-        h = F_.to_channels_last(x)
-        h = F_.conv_cl(h, self.conv1.weight, None, (2, 2), (3, 3))
-        h = F_.batchnorm_act(h, self.bn1, self.training, relu=True)
-        h = F_.maxpool_cl(h, 3, 2, 1)
-        for i in range(1, 5):
-            for blk in getattr(self, f"layer{i}"):
-                h = blk(h)
+        with F_.collect_batchnorm_counters():
+            h = F_.to_channels_last(x)
+            h = F_.conv_cl(h, self.conv1.weight, None, (2, 2), (3, 3))
+            h = F_.batchnorm_act(h, self.bn1, self.training, relu=True)
+            h = F_.maxpool_cl(h, 3, 2, 1)
+            for i in range(1, 5):
+                for blk in getattr(self, f"layer{i}"):
+                    h = blk(h)
         B, H, W, C = h.shape
         ones = torch.ones((B, H * W), dtype=torch.uint8, device=h.device)
         pooled = F_.masked_pool(h.reshape(B, H * W, C), ones, "mean")

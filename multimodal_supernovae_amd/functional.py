@@ -932,13 +932,37 @@ class _BatchNormAct(torch.autograd.Function):
         return dx.view(shape), dg, db, None, None, None, (d.view(shape) if has_res else None), None
 
 
+BN_COUNTERS = None   # a list while an encoder collects the step counters of its BatchNorms (bump_batchnorm_counters)
+
+
 def batchnorm_act(x, bn, training, residual=None, relu=False):
     """`bn` is an nn.BatchNorm2d parameter holder."""
     out = _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, residual, relu)
     if training:
-        with torch.no_grad():
-            bn.num_batches_tracked += 1
+        if BN_COUNTERS is not None:
+            BN_COUNTERS.append(bn.num_batches_tracked)
+        else:
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
     return out
+
+
+class collect_batchnorm_counters:
+    """`with collect_batchnorm_counters():` around a forward pass: the `num_batches_tracked += 1` of every BatchNorm inside becomes ONE
+    fused add at the end (ResNet-18: 20 one-element launches per step otherwise)."""
+
+    def __enter__(self):
+        global BN_COUNTERS
+        self.prev, BN_COUNTERS = BN_COUNTERS, []
+        return self
+
+    def __exit__(self, *exc):
+        global BN_COUNTERS
+        counters, BN_COUNTERS = BN_COUNTERS, self.prev
+        if counters and exc[0] is None:
+            with torch.no_grad():
+                torch._foreach_add_(counters, 1)
+        return False
 
 
 class _MaxPoolCL(torch.autograd.Function):
