@@ -10,6 +10,7 @@ of train_loss / val_loss, and (multi-process) SUM all-reduce of the gradients be
 Checkpointing, early stopping and W&B logging of the reference harness are out of scope.
 """
 import torch
+import torch.distributed as dist
 
 from . import distributed as D
 from . import markers
@@ -186,8 +187,7 @@ class Trainer:
 class _RecordedStep:
     """A training step recorded as HIP-graph SEGMENTS separated by host-driven exchanges.  While it records it is installed
     as distributed.SEGMENTED_CAPTURE: every collective issued through distributed.py closes the segment under capture,
-    runs for real (so that all ranks stay in step; the data it moves during the recording pass is meaningless) and opens
-    the next segment.  All segments allocate from ONE private pool, so a tensor produced in one segment and consumed in a
+    is remembered (not run: see exchange) and opens the next segment.  All segments allocate from ONE private pool, so a tensor produced in one segment and consumed in a
     later one keeps its address.  replay() = segment, exchange, segment, ... in the recorded order."""
 
     def __init__(self, device):
@@ -198,12 +198,20 @@ class _RecordedStep:
 
     def begin(self):
         self.cur = torch.cuda.CUDAGraph()
-        self.cur.capture_begin(pool=self.pool)
+        # thread-local capture mode: the process group's watchdog THREAD polls the events of the exchanges that ran between the
+        # segments (hipEventQuery); under the default global mode such a call from any thread while a segment is being captured
+        # is an error, the watchdog throws and the process aborts -- about one recording in three with a one-rank RCCL group
+        self.cur.capture_begin(pool=self.pool, capture_error_mode="thread_local")
 
     def exchange(self, fn):
+        # The exchange is only REMEMBERED while recording -- nothing of a segment under capture executes, so there is no data to
+        # exchange yet, and every rank skips the same collectives in the same order (the step is carried out by the first
+        # replay).  Running it for real here put RCCL work between two captures: the process group's watchdog thread polls
+        # such work with hipEventQuery while the next segment is being captured, which HIP refuses ("event last recorded in a
+        # capturing stream" / "not permitted when stream is capturing") -- the watchdog throws and the process aborts, about
+        # one recording in five.
         self.cur.capture_end()
         self.items.append(("graph", self.cur))
-        fn()
         self.items.append(("call", fn))
         self.begin()
 
@@ -294,7 +302,10 @@ class GraphedTrainStep:
         ops.GRAPH_SEED = [seed0, 0]
         self._seed_base = seed0
         torch.cuda.synchronize()
-        torch.cuda.empty_cache()
+        if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+            import time
+            time.sleep(0.35)                  # > 3 sweeps of the process group's watchdog: the warm-up steps' finished work is retired
+        torch.cuda.empty_cache()              # (it must not be polled while a segment is under capture, see _RecordedStep.exchange)
         rec = _RecordedStep(device)
         stream = torch.cuda.Stream(device=device)
         stream.wait_stream(torch.cuda.current_stream(device))
