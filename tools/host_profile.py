@@ -1,10 +1,15 @@
 #!/usr/bin/env python3
 """Host-side (Python) time of one training step of a bench workload: cProfile over 10 steps, top functions.
 
-    python tools/host_profile.py [workload] [batch]
+    python tools/host_profile.py [workload] [batch] [--dp]
+--dp: a one-rank RCCL group with the sharded loss and the hook-driven gradient reducer forced on (the host work of a data-parallel rank).
 """
 import cProfile, os, pstats, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+DP = "--dp" in sys.argv
+if DP:
+    sys.argv.remove("--dp")
+    os.environ.update(MSN_DIST_FORCE_INIT="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29655")
 import torch
 import bench
 
@@ -16,12 +21,20 @@ if name == "vit_s8_lc":
 else:
     model, batch = bench.build_workload(name, b, 0, dev)
 opt = model.configure_optimizers()["optimizer"]
+reducer = None
+if DP:
+    from multimodal_supernovae_amd import distributed as D
+    D.init_from_env(backend="nccl")
+    model.global_negatives = "always"
+    reducer = D.GradientReducer(model.parameters(), force=True)
 
 
 def step():
     opt.zero_grad(set_to_none=True)
     loss = model.training_step(batch, 0)
     loss.backward()
+    if reducer is not None:
+        reducer.finish()
     opt.step()
 
 
