@@ -48,9 +48,10 @@ class _Logged:
 
 
 # Segmented HIP-graph capture of a data-parallel step (trainer.GraphedTrainStep): while a step is being recorded, every
-# collective issued through this module ENDS the graph segment under capture, runs for real between two segments (the
-# exchange is host-driven: gloo cannot be captured at all, and RCCL then needs no capture support either) and a new segment
-# begins behind it.  The object installed here implements exchange(fn): "close the segment, remember fn, open the next".
+# collective issued through this module ENDS the graph segment under capture and a new segment begins behind it; at replay the
+# collective runs between the two graphs (the exchange is host-driven: gloo cannot be captured at all, and RCCL then needs no
+# capture support either).  The object installed here implements exchange(fn): "close the segment, remember fn, open the next"
+# -- fn is NOT run while recording (trainer._RecordedStep.exchange says why).
 SEGMENTED_CAPTURE = None
 
 
