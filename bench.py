@@ -37,7 +37,9 @@ CONV_PLACEHOLDER = dict(dim=8, depth=1, channels=3, kernel_size=5, patch_size=8,
 IMG, T_LC, NBAND, ENC_DIM, N_OUT = 64, 200, 2, 128, 32
 GEMM_KERNEL_NAME = {"f32": "msn::sgemm_dma_kernel + msn::sgemm_kernel (fp32 v_mfma_f32_32x32x2_f32; all msn_sgemm launches and, where a tower has convolutions, the implicit-GEMM msn_conv2d_* launches of the same kernel)",
                     "bf16x3": "msn::bgemm_kernel<planes=2> (3 x v_mfma_f32_32x32x16_bf16 per algorithmic MAC tile)",
-                    "bf16": "msn::bgemm_kernel<planes=1> (v_mfma_f32_32x32x16_bf16)"}
+                    "bf16": "msn::bgemm_kernel<planes=1> (v_mfma_f32_32x32x16_bf16)",
+                    "bf16x6": "msn::pgemm_nt_kernel<3> + msn::pgemm_tn_kernel<3> (operands resident as 3 bf16 planes, 6 x v_mfma_f32_32x32x16_bf16 per algorithmic MAC tile, two accumulator sets; narrow products: msn::sgemm_dma_kernel)",
+                    "bf16x3p": "msn::pgemm_nt_kernel<2> + msn::pgemm_tn_kernel<2> (operands resident as 2 bf16 planes, 3 x v_mfma_f32_32x32x16_bf16 per algorithmic MAC tile)"}
 LR, WD, LOGIT_SCALE = 3.716367614864064e-05, 0.000555522900788888, 19.545966923442453  # maven_pretrain_config.yaml
 
 
@@ -289,8 +291,9 @@ def main():
                     help="tail tiles of the fp32 GEMMs: 1 = K-slabs summed by the last workgroup to arrive (default), 2 = by a finishing launch, 0 = unsplit")
     ap.add_argument("--bgemm-one-tile", action="store_true",
                     help="bf16-resident NT products: one workgroup per tile instead of persistent workgroups (A/B measurement)")
-    ap.add_argument("--gemm-precision", default="f32", choices=["f32", "bf16x3", "bf16"],
-                    help="inner-product precision of the GEMMs (bf16x3 = split-bf16, fp32-grade accuracy)")
+    ap.add_argument("--gemm-precision", default="f32", choices=["f32", "bf16x6", "bf16x3p", "bf16x3", "bf16"],
+                    help="inner-product precision of the GEMMs (bf16x6 = fp32-grade from three resident bf16 planes, 6 products; "
+                         "bf16x3p = two resident planes, 3 products; bf16x3 = split in registers, 3 products)")
     ap.add_argument("--graphed", action="store_true",
                     help="record the training step as HIP graphs (trainer.GraphedTrainStep; N > 1: segments between the host-driven "
                          "exchanges) and time its replays -- what launch-bound batches (the reference's 32 ... 256, or the "
@@ -464,7 +467,7 @@ def main():
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     # dense matrix peak of the instruction the dominant kernel issues (MI355X_MICROARCH.md): fp32 157.3 TFLOP/s;
     # bf16 2500 TFLOP/s, of which the 3-product split can deliver at most a third as algorithmic flops
-    peak = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}[args.gemm_precision]
+    peak = {"f32": 157.3, "bf16x6": 2500.0, "bf16x3p": 2500.0, "bf16x3": 2500.0, "bf16": 2500.0}[args.gemm_precision]
     kernel_name = GEMM_KERNEL_NAME[args.gemm_precision]
     if args.workload == "vit_b16_bf16_lc" and args.gemm_precision == "f32":
         peak = 2500.0           # the image tower of cfg5 issues bf16 MFMAs whatever the process default is

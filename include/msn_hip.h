@@ -258,6 +258,43 @@ int msn_mask_tokens(const float* x, const uint8_t* mask, int64_t rows, int e, fl
 int msn_add_rows(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t rows, int cols, msn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * fp32-GRADE products on the bf16 matrix cores from resident bf16 PLANES (pgemm.hip) -- the same nn.Linear products
+ * msn_sgemm multiplies (ref src/transformer_utils.py:45-47, 89, 102-106, 251; src/models_multimodal.py:277), for the wide
+ * layers of the build-defined ViT towers.  An fp32 matrix is kept in HBM as `planes` bf16 planes, x = p0 + p1 (+ p2) with
+ * p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1): three planes hold an fp32 value EXACTLY (3 x 8 significand
+ * bits, fp32 exponent range).  A product sums the plane products with pa + pb < planes on v_mfma_f32_32x32x16_bf16 with
+ * fp32 accumulation: planes = 3 -> 6 MFMA products, terms dropped <= 2^-26 |a||b| (fp32 grade); planes = 2 -> 3 products,
+ * dropped <= 2^-17 |a||b|.
+ * Plane matrix of a logical R x C matrix ("blocked planes"): 32-row x 16-column blocks, block (rb, cb) = `planes`
+ * consecutive 1-KB images [32][16] bf16; byte offset of (r, c, plane) = (((r / 32) * CB + c / 16) * planes + plane) * 1024
+ * + (r % 32) * 32 + (c % 16) * 2, CB = 2 * ceil(C / 32); rows / columns past R / C are zero.  msn_plane_bytes gives its size.
+ *   msn_plane_split:  fp32 (R x C, row stride ldx) -> plane matrix; transposed = 1 writes the planes of the C x R
+ *                     transpose (weights for the input-gradient products).  colsum (nullable, untransposed only):
+ *                     out[c] = sum_r x[r][c] (bias gradients); ws >= msn_plane_split_colsum_workspace_bytes.
+ *   msn_plane_merge:  plane matrix -> fp32 (tests).
+ *   msn_pgemm_nt:     C[M][N] = epilogue(A[M][K] . B[N][K]^T + bias); A, B plane matrices (M x K, N x K).  C is fp32
+ *                     (row stride ldc) or, with c_planes = 1, the plane matrix of the M x N result (N % 16 == 0) -- the
+ *                     operand of the next product, split in the epilogue.  Epilogues as msn_sgemm (MSN_EPI_*; aux fp32).
+ *                     colsum_out (nullable): column sums of the values written to C; ws >= msn_pgemm_nt_colsum_workspace_bytes.
+ *   msn_pgemm_tn:     C[N][K] (fp32) = sum_m A[m][N]^T . B[m][K] (weight gradient dY^T . X); A, B plane matrices with the
+ *                     reduction on the rows (M x N, M x K); reduction split over workgroups, fixed-order slab sums;
+ *                     ws >= msn_pgemm_tn_workspace_bytes.
+ * Results are deterministic.  msn_set_pgemm_tile_n (0 = planned, 128, 256): tile width of msn_pgemm_nt (measurements). */
+size_t msn_plane_bytes(int64_t R, int64_t C, int planes);
+size_t msn_plane_split_colsum_workspace_bytes(int64_t R, int64_t C);
+int msn_plane_split(const float* x, int64_t ldx, int64_t R, int64_t C, int planes, int transposed, void* out, float* colsum,
+                    void* ws, size_t ws_bytes, msn_stream_t stream);
+int msn_plane_merge(const void* planes_in, int planes, int64_t R, int64_t C, float* y, int64_t ldy, msn_stream_t stream);
+size_t msn_pgemm_nt_colsum_workspace_bytes(int64_t M, int N);
+int msn_pgemm_nt(int64_t M, int N, int K, int planes, const void* A, const void* B, void* C, int64_t ldc, int c_planes,
+                 const float* bias, int epilogue, float* aux, int64_t ldaux, float* colsum_out, void* ws, size_t ws_bytes,
+                 msn_stream_t stream);
+size_t msn_pgemm_tn_workspace_bytes(int64_t M, int N, int K, int planes);
+int msn_pgemm_tn(int64_t M, int N, int K, int planes, const void* A, const void* B, float* C, int64_t ldc, void* ws,
+                 size_t ws_bytes, msn_stream_t stream);
+int msn_set_pgemm_tile_n(int bn);
+
+/* ------------------------------------------------------------------------------------------
  * bf16-RESIDENT products for BASELINE.json configs[4] (ViT-B/16 "bf16 on MFMA"; build-defined encoder, no reference
  * counterpart -- the reference has no mixed precision): operands are bf16 in HBM (uint16 bit patterns), accumulation fp32.
  *   msn_bgemm_nt:  C[M][N] = epi(A[M][K] . B[N][K]^T + bias); K % 64 == 0, N % 4 == 0, 16-byte aligned rows.

@@ -57,6 +57,16 @@ SIGNATURES = {
     "msn_masked_pool_bwd": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
     "msn_mask_tokens": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     "msn_add_rows": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_ptr]),
+    "msn_plane_bytes": (c_size, [c_i64, c_i64, c_int]),
+    "msn_plane_split_colsum_workspace_bytes": (c_size, [c_i64, c_i64]),
+    "msn_plane_split": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "msn_plane_merge": (c_int, [c_ptr, c_int, c_i64, c_i64, c_ptr, c_i64, c_ptr]),
+    "msn_pgemm_nt_colsum_workspace_bytes": (c_size, [c_i64, c_int]),
+    "msn_pgemm_nt": (c_int, [c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_i64, c_ptr,
+                             c_ptr, c_size, c_ptr]),
+    "msn_pgemm_tn_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int]),
+    "msn_pgemm_tn": (c_int, [c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_size, c_ptr]),
+    "msn_set_pgemm_tile_n": (c_int, [c_int]),
     "msn_bgemm_nt": (c_int, [c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_i64,
                              c_ptr, c_ptr, c_size, c_ptr]),
     "msn_bgemm_nt_colsum_workspace_bytes": (c_size, [c_i64, c_int]),

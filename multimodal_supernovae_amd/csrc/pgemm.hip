@@ -1,0 +1,1079 @@
+// fp32-grade GEMMs on the bf16 matrix cores from RESIDENT bf16 planes (v_mfma_f32_32x32x16_bf16, fp32 accumulate).
+//
+// Replaces, for the wide products of the build-defined ViT towers, every nn.Linear product the fp32 kernels of gemm.hip
+// multiply (ref src/transformer_utils.py:45-47, 89, 102-106, 251 are the same Linear pattern).  The native fp32 matrix
+// instruction runs at 1/16 of the bf16 rate and its kernel family tops out at 0.85 of that peak on long K
+// (profiles/r03_gemm_kloop_ablation.txt); here an fp32 operand is held in HBM as NP bf16 PLANES
+//
+//      x = p0 + p1 + p2,   p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1)      (round to nearest even)
+//
+// -- an fp32 significand (24 bits) splits EXACTLY into three bf16 significands (8 bits + sign each), and bf16 has the
+// fp32 exponent range, so no scaling is needed -- and a product is the sum of the plane products with pa + pb < NP:
+//
+//      NP = 3:  p0.q0 + p0.q1 + p1.q0 + p0.q2 + p2.q0 + p1.q1     6 bf16 MFMA products, dropped terms <= 2^-26 |a||b|
+//      NP = 2:  p0.q0 + p0.q1 + p1.q0                             3 products, dropped terms <= 2^-17 |a||b|  ("bf16x3")
+//
+// every bf16 x bf16 product is exact in fp32 and the sums accumulate in fp32 inside the MFMA.  The split is done ONCE by
+// the producer of a matrix (msn_plane_split, or the epilogue of the product that writes it), not inside the K loop.
+//
+// Plane matrix format ("blocked planes") of a logical R x C matrix: 32-row x 16-column blocks, block (rb, cb) holds NP
+// consecutive 1-KB plane images [32 rows][16 bf16]:
+//      byte offset of (r, c, plane) = (((r / 32) * CB + c / 16) * NP + plane) * 1024 + (r % 32) * 32 + (c % 16) * 2,
+// CB = 2 ceil(C / 32) (an even number of column blocks: a product then has an even number of K-steps and a K-step's
+// register roles alternate without a tail case), rows / columns past R / C are ZERO.  One plane image of one block is
+// exactly one LDS-DMA piece (one wave instruction of global_load_lds_dwordx4): a contiguous 1-KB read, whatever K is.
+//
+//   msn_pgemm_nt :  C[M][N] = epi( A[M][K] . B[N][K]^T + bias )    both operands plane matrices with K on the columns
+//                   (forward: activations x weight; dgrad: dY x W^T against the planes of the transposed weight)
+//   msn_pgemm_tn :  C[N][K] = sum_m A[m][N]^T . B[m][K]             both operands plane matrices with the reduction on the
+//                   ROWS (wgrad dY^T . X), fragments transposed out of LDS by ds_read_b64_tr_b16, reduction split over
+//                   workgroups with fixed-order slab sums
+//
+// NT workgroup = 8 waves (2 x 4), tile 256 x BN (BN = 256 or 128), K-step 16 = one MFMA deep, ring of 3-4 LDS slots of
+// (8 + BN / 32) * NP pieces; persistent (one workgroup per CU walks its tiles, the ring runs on across tile boundaries).
+#include <algorithm>
+#include <type_traits>
+
+#include "msn_common.h"
+
+namespace msn {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned short u16;
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+constexpr int PBLK = 1024;          // bytes of one plane image of one 32 x 16 block
+constexpr int BM = 256;             // tile rows
+
+struct PgemmArgs {
+    const unsigned char* A;         // NT: planes of the M x K operand.   TN: planes of dY (rows = reduction, N columns)
+    const unsigned char* B;         // NT: planes of the N x K operand.   TN: planes of X  (rows = reduction, K columns)
+    void* C;                        // fp32 matrix (ldc) or plane matrix (cbC column blocks)
+    float* aux;
+    const float* bias;
+    int64_t ldc, ldaux;
+    int64_t M;                      // NT: rows of A / C.  TN: reduction length
+    int N, K;
+    int rbA, rbB;                   // NT: row blocks of A / B.  TN: row blocks (both operands share the rows)
+    int cbA, cbB;                   // column blocks of A / B (NT: both = K-steps)
+    int cbC;                        // column blocks of a plane output
+    int tiles_m, tiles_n, super_rows, epi;
+    int chunk_steps;                // NT: K-steps per chunk (0 = the whole reduction in one accumulation)
+    float* colpart;                 // NT (nullable): [2 * tiles_m][N] column sums of the values written to C
+    int splits;                     // TN: reduction split
+    int rb_per_split;               // TN: row blocks per split
+    float* slabs;                   // TN: [splits][N][K] partials (splits > 1)
+};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int OFF>
+__device__ __forceinline__ void ds_read128(bf16x8& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void wait_vm(int n) {        // n is wave-uniform
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    }
+}
+
+__device__ __forceinline__ u16 f2bf(float f) {          // round to nearest even; NaN stays NaN (plain cast)
+    const __bf16 b = (__bf16)f;
+    return *reinterpret_cast<const u16*>(&b);
+}
+__device__ __forceinline__ float bf2f(u16 v) { return __uint_as_float((unsigned)v << 16); }
+
+// x -> NP planes (u16 each).  Each residual x - p0 (- p1) is exact in fp32.
+template <int NP>
+__device__ __forceinline__ void split_planes(float x, u16 (&pl)[NP]) {
+    float r = x;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        pl[k] = f2bf(r);
+        r -= bf2f(pl[k]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// NT kernel.  LDS slot = [A: 8 row blocks][NP planes][1 KB] then [B: BN / 32 row blocks][NP][1 KB].  Inside a plane image
+// the 16-byte half h of row r sits at chunk 2 r + (h ^ swz(r)), swz(r) = (r >> 3) & 1 (applied on the DMA source address):
+// a ds_read_b128 of the 32x32x16 operand (lane l: row l & 31, half l >> 5) is served in 16-lane groups {0-3, 12-15,
+// 20-27} / {4-11, 16-19, 28-31}; row r covers banks 8 r + 4 (h ^ swz) .. + 3 (mod 64): with the swizzle every group touches
+// 16 distinct 4-bank quads -> conflict-free.
+//
+// DUAL (the fp32-grade form, NP = 3, BN = 128): TWO accumulator sets.  The bf16 MFMA adds its 16-term dot product into the
+// accumulator with a truncating (biased) rounding -- unlike the fp32-input MFMA's round-to-nearest -- so every MFMA into a
+// LARGE accumulator costs a systematic ~1/18 ulp and the error of one accumulator grows like K^1.5 (measured: 5.4 x the
+// native kernel's at K = 1536 with all six products in one accumulator).  The p0.q0 products alone go to `acc`; the five
+// small products (<= 2^-8 of it) go to `acc2`, whose roundings are 2^-8 smaller; the epilogue adds the two in fp32.
+template <int NP, int BN, bool OUTP, bool DUAL>
+__global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(const PgemmArgs p) {
+    constexpr int ARB = BM / 32, BRB = BN / 32, AP = ARB * NP, BP = BRB * NP, PIECES = AP + BP;
+    constexpr int SLOT = PIECES * PBLK;
+    constexpr int NSLOT = (4 * SLOT <= 160 * 1024) ? 4 : 3;
+    constexpr int MAXQ = (PIECES + 7) / 8;           // pieces per wave and K-step (the last one only for the low waves)
+    constexpr int MT = 4, NT = BN / 128;             // 32 x 32 MFMA tiles per wave: rows x columns
+    constexpr int NG = NP * (NP + 1) / 2;            // plane products per K-step
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSLOT * SLOT];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int G = gridDim.x;
+    const int total = p.tiles_m * p.tiles_n;
+    const int nk = p.cbA;                            // K-steps per tile
+
+    // tile order: ids are dealt round-robin to the 8 XCDs; each XCD gets a contiguous run of tiles walked in super-rows
+    // (SR tile-rows x all tile columns, row-fastest) so that its workgroups share A row panels and the weight in one L2
+    auto locate = [&](int t, int& tm_, int& tn_) {
+        const int q = total / 8, r = total % 8, x = t % 8, i = t / 8;
+        const int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+        const int SR = p.super_rows;
+        const int sr = bid / (SR * p.tiles_n), j = bid % (SR * p.tiles_n);
+        const int rows_sr = min(SR, p.tiles_m - sr * SR);
+        tm_ = sr * SR + j % rows_sr;
+        tn_ = j / rows_sr;
+    };
+    auto tile_of = [&](int idx, int& tm_, int& tn_) -> bool {      // idx-th tile of this workgroup
+        const int t = blockIdx.x + idx * G;
+        if (t >= total) return false;
+        locate(t, tm_, tn_);
+        return true;
+    };
+
+    // ---- producer: the LDS-DMA stream.  Global K-step g (over all tiles of this workgroup) lives in slot g % NSLOT.
+    const int lane_src = (((lane >> 1) * 2) + ((lane & 1) ^ ((lane >> 4) & 1))) * 16;
+    const unsigned char* pbase[MAXQ];                // source of piece q of the producer's tile at K-step 0 (wave-uniform)
+    int p_idx = 0, p_k = 0, p_slot = 0, p_tm = 0, p_tn = 0;
+    bool p_live = tile_of(0, p_tm, p_tn);
+    auto set_bases = [&]() {
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int id = wave + 8 * q;
+            if (id < AP) {
+                const int rb = min(p_tm * ARB + id / NP, p.rbA - 1);            // rows past the edge: clamped, never stored
+                pbase[q] = p.A + ((int64_t)rb * nk * NP + id % NP) * PBLK;
+            } else {
+                const int id2 = min(id, PIECES - 1) - AP;
+                const int rb = min(p_tn * BRB + id2 / NP, p.rbB - 1);
+                pbase[q] = p.B + ((int64_t)rb * nk * NP + id2 % NP) * PBLK;
+            }
+        }
+    };
+    if (p_live) set_bases();
+    auto issue_q = [&](int q) {                      // piece q of the producer's current K-step
+#ifdef MSN_ABL_PG_NODMA                      // diagnostic build (tools/microbench/build_ablate.sh): no operand traffic at all
+        return;
+#endif
+        const int id = wave + 8 * q;
+        if (id < PIECES)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(pbase[q] + (int64_t)p_k * (NP * PBLK) + lane_src),
+                                             (lptr_t*)(lds + p_slot * SLOT + id * PBLK), 16, 0, 0);
+    };
+    auto issue_chunk = [&](auto c_) {                // chunk c of NG: pieces [c MAXQ / NG, (c + 1) MAXQ / NG)
+        constexpr int c = decltype(c_)::value;
+        if (p_live) {
+#pragma unroll
+            for (int q = c * MAXQ / NG; q < (c + 1) * MAXQ / NG; ++q) issue_q(q);
+        }
+    };
+    auto advance = [&]() {                           // producer -> next global K-step
+        if (!p_live) return;
+        p_slot = (p_slot + 1 == NSLOT) ? 0 : p_slot + 1;
+        if (++p_k == nk) {
+            p_k = 0;
+            p_live = tile_of(++p_idx, p_tm, p_tn);
+            if (p_live) set_bases();
+        }
+    };
+    // pieces of this wave issued by the chunks 0 .. NG - 2 of one K-step (all waves own every piece q < MAXQ - 1)
+    constexpr int Q_BEFORE = (NG - 1) * MAXQ / NG;
+    const int ppw = (wave + 8 * (MAXQ - 1) < PIECES) ? MAXQ : MAXQ - 1;      // pieces of this wave per K-step
+
+    // ---- fragments
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const unsigned frag_lane = (unsigned)(frow * 32 + 16 * (fhalf ^ ((frow >> 3) & 1)));
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t*)lds;
+    const unsigned fragA = lds0 + frag_lane + (unsigned)(wm * 4 * NP * PBLK);                   // + (i * NP + plane) KB
+    const unsigned fragB = lds0 + frag_lane + (unsigned)((AP + wn * NT * NP) * PBLK);           // + (j * NP + plane) KB
+
+    f32x16 acc[MT][NT], acc2[DUAL ? MT : 1][DUAL ? NT : 1];
+    bf16x8 fa[2][MT], fb0[2][NT], fbh[NP > 1 ? NP - 1 : 1][NT];
+
+    auto req_a = [&](bf16x8 (&dst)[MT], unsigned slot_off, auto pl_) {
+        constexpr int pl = decltype(pl_)::value;
+#ifdef MSN_ABL_PG_NOFRAG                     // diagnostic build: no fragment reads (the MFMAs multiply whatever the registers hold)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) asm volatile("" : "=v"(dst[i]));
+        return;
+#endif
+        static_for<0, MT>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            ds_read128<(i * NP + pl) * PBLK>(dst[i], fragA + slot_off);
+        });
+    };
+    auto req_b = [&](bf16x8 (&dst)[NT], unsigned slot_off, auto pl_) {
+        constexpr int pl = decltype(pl_)::value;
+#ifdef MSN_ABL_PG_NOFRAG
+#pragma unroll
+        for (int j = 0; j < NT; ++j) asm volatile("" : "=v"(dst[j]));
+        return;
+#endif
+        static_for<0, NT>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            ds_read128<(j * NP + pl) * PBLK>(dst[j], fragB + slot_off);
+        });
+    };
+    // D^T tile = B_frag . A_frag^T: lane gets row m = lane & 31 of the tile and columns n = 8 b + 4 (lane >> 5) + r
+    auto mult = [&](const bf16x8 (&a)[MT], const bf16x8 (&b)[NT], auto small_) {
+        constexpr bool SMALL = decltype(small_)::value && DUAL;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if constexpr (SMALL) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc2[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using BIG = std::integral_constant<bool, false>;
+    using SML = std::integral_constant<bool, true>;
+    // request the first fragments of a K-step (A plane 0 and every B plane) -- order matters for the counted waits
+    auto req_first = [&](bf16x8 (&a0)[MT], bf16x8 (&b0)[NT], unsigned slot_off) {
+        req_a(a0, slot_off, std::integral_constant<int, 0>{});
+        req_b(b0, slot_off, std::integral_constant<int, 0>{});
+        static_for<1, NP>([&](auto pb_) {
+            constexpr int pb = decltype(pb_)::value;
+            req_b(fbh[pb - 1], slot_off, pb_);
+        });
+    };
+
+    int c_slot = 0;                                  // slot of the consumer's current K-step
+    // One K-step; PAR = parity of the step inside its tile (a tile has an EVEN number of K-steps: the plane format pads K).
+    // On entry outstanding LDS reads, oldest first: A0 (MT), B0 (NT), B1 .. B_{NP-1} (NT each).  The first fragments of the
+    // next K-step -- the next tile's first one at the end of a tile: the ring runs on -- are requested before this step's
+    // last product (past the workgroup's last step they read whatever the slot holds, into registers nobody uses).
+    auto step = [&](auto par_) {
+        constexpr int PAR = decltype(par_)::value;
+        constexpr int QA = (NP & 1) ? PAR : 0;       // fa buffer of plane 0; plane pa sits in fa[(QA + pa) & 1]
+        const unsigned cur = (unsigned)(c_slot * SLOT);
+        const int n_slot = (c_slot + 1 == NSLOT) ? 0 : c_slot + 1;
+        const unsigned nxt = (unsigned)(n_slot * SLOT);
+        const bool p_was_live = p_live;
+        req_a(fa[QA ^ 1], cur, std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        // plane 0 of A against every plane of B
+        static_for<0, NP>([&](auto pb_) {
+            constexpr int pb = decltype(pb_)::value;
+            wait_lgkm<NT*(NP - 1 - pb) + MT>();
+            if constexpr (pb == 0) mult(fa[QA], fb0[PAR], BIG{});
+            else mult(fa[QA], fbh[pb - 1], SML{});
+            issue_chunk(std::integral_constant<int, pb>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // planes 1 .. NP - 2 of A
+        static_for<1, NP - 1>([&](auto pa_) {
+            constexpr int pa = decltype(pa_)::value;
+            constexpr int g0 = pa * NP - pa * (pa - 1) / 2;         // products before plane pa
+            req_a(fa[(QA + pa + 1) & 1], cur, std::integral_constant<int, pa + 1>{});
+            wait_lgkm<MT>();
+            static_for<0, NP - pa>([&](auto pb_) {
+                constexpr int pb = decltype(pb_)::value;
+                if constexpr (pb == 0) mult(fa[(QA + pa) & 1], fb0[PAR], SML{});
+                else mult(fa[(QA + pa) & 1], fbh[pb - 1], SML{});
+                issue_chunk(std::integral_constant<int, g0 + pb>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        // every fragment of this K-step is in registers -> its slot may be refilled; the next K-step must have landed
+        wait_lgkm<0>();
+        wait_vm(p_was_live ? (NSLOT - 3) * ppw + Q_BEFORE : 0);
+#ifndef MSN_ABL_PG_NOBAR
+        __builtin_amdgcn_s_barrier();
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        req_first(fa[(QA + NP) & 1], fb0[PAR ^ 1], nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        mult(fa[(QA + NP - 1) & 1], fb0[PAR], SML{});
+        issue_chunk(std::integral_constant<int, NG - 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        advance();
+        c_slot = n_slot;
+    };
+
+    // ---- epilogue: lane holds, per (i, j) tile, row m = 32 i + (lane & 31) and columns n = 32 j + 8 b + 4 (lane >> 5) + r
+    // MODE 0: the tile's result.  MODE 1: the tile's result when earlier K chunks left a partial sum in C (added first).
+    // MODE 2 / 3: a K chunk's partial sum -> C (first chunk) / C += (later chunks); no bias, no epilogue (fp32 outputs only).
+    auto store_tile_epi = [&](int tm, int tn, auto epi_, auto mode_) {
+        constexpr int epi = decltype(epi_)::value;
+        constexpr int MODE = decltype(mode_)::value;
+        constexpr bool PARTIAL = MODE >= 2, ADDC = MODE == 1 || MODE == 3;
+        const int64_t mrow0 = (int64_t)tm * BM + wm * 128 + frow;
+        const int ncol0 = tn * BN + wn * (BN / 4) + 4 * fhalf;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int n = ncol0 + 32 * j + 8 * b;
+                if (n >= p.N) continue;                           // N % 4 == 0 (host): n < N <=> n + 3 < N
+                const float4 bias4 = (!PARTIAL && p.bias) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float cs[4] = {0.f, 0.f, 0.f, 0.f};               // column sums over this wave's 128 rows
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int64_t m = mrow0 + 32 * i;
+                    const bool row_ok = m < p.M;
+                    if (!OUTP && !row_ok) continue;
+                    const int rbk = tm * ARB + wm * 4 + i;        // row block of a plane output (it has the rows of A)
+                    if (OUTP && rbk >= p.rbA) continue;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = acc[i][j][4 * b + r];
+                        if constexpr (DUAL) v[r] += acc2[i][j][4 * b + r];
+                    }
+                    if constexpr (ADDC && !OUTP) {
+                        if (row_ok) {
+                            const float4 c0 = *reinterpret_cast<const float4*>(static_cast<const float*>(p.C) + m * p.ldc + n);
+                            v[0] += c0.x; v[1] += c0.y; v[2] += c0.z; v[3] += c0.w;
+                        }
+                    }
+                    v[0] += bias4.x; v[1] += bias4.y; v[2] += bias4.z; v[3] += bias4.w;
+                    if (row_ok) {
+                        if constexpr (PARTIAL) {
+                        } else if constexpr (epi == MSN_EPI_GELU) {
+                            if (p.aux) {
+                                *reinterpret_cast<float4*>(p.aux + m * p.ldaux + n) =
+                                    make_float4(gelu_grad_f(v[0]), gelu_grad_f(v[1]), gelu_grad_f(v[2]), gelu_grad_f(v[3]));
+                            }
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+                        } else if constexpr (epi == MSN_EPI_RELU) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                        } else if constexpr (epi != MSN_EPI_NONE) {
+                            const float4 a = *reinterpret_cast<const float4*>(p.aux + m * p.ldaux + n);
+                            if constexpr (epi == MSN_EPI_GELU_BWD) { v[0] *= a.x; v[1] *= a.y; v[2] *= a.z; v[3] *= a.w; }
+                            else if constexpr (epi == MSN_EPI_RELU_BWD) {
+                                v[0] = a.x > 0.f ? v[0] : 0.f; v[1] = a.y > 0.f ? v[1] : 0.f;
+                                v[2] = a.z > 0.f ? v[2] : 0.f; v[3] = a.w > 0.f ? v[3] : 0.f;
+                            } else { v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; }     // MSN_EPI_ADD
+                        }
+                    } else {
+                        v[0] = v[1] = v[2] = v[3] = 0.f;          // padding rows of a plane output are zero
+                    }
+                    if constexpr (OUTP) {
+                        u16 pl[4][NP];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) split_planes<NP>(v[r], pl[r]);
+                        unsigned char* dst = static_cast<unsigned char*>(p.C) + ((int64_t)rbk * p.cbC + (n >> 4)) * (NP * PBLK) +
+                                             frow * 32 + (n & 15) * 2;
+#pragma unroll
+                        for (int k = 0; k < NP; ++k) {
+                            uint2 o;
+                            o.x = pl[0][k] | ((unsigned)pl[1][k] << 16);
+                            o.y = pl[2][k] | ((unsigned)pl[3][k] << 16);
+                            *reinterpret_cast<uint2*>(dst + k * PBLK) = o;
+                        }
+                    } else {
+                        *reinterpret_cast<float4*>(static_cast<float*>(p.C) + m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                    cs[0] += v[0]; cs[1] += v[1]; cs[2] += v[2]; cs[3] += v[3];
+                }
+                if (!PARTIAL && p.colpart) {   // the 32 lanes sharing lane >> 5 hold the 32 rows of every row tile: xor tree, one lane writes
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float t = cs[r];
+#pragma unroll
+                        for (int o = 1; o < 32; o <<= 1) t += __shfl_xor(t, o, 64);
+                        cs[r] = t;
+                    }
+                    if (frow == 0)
+                        *reinterpret_cast<float4*>(p.colpart + (int64_t)(2 * tm + wm) * p.N + n) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+                }
+            }
+    };
+    auto store_tile = [&](int tm, int tn, auto mode_) {
+        switch (p.epi) {
+            case MSN_EPI_RELU: store_tile_epi(tm, tn, std::integral_constant<int, MSN_EPI_RELU>{}, mode_); break;
+            case MSN_EPI_GELU: store_tile_epi(tm, tn, std::integral_constant<int, MSN_EPI_GELU>{}, mode_); break;
+            case MSN_EPI_RELU_BWD: store_tile_epi(tm, tn, std::integral_constant<int, MSN_EPI_RELU_BWD>{}, mode_); break;
+            case MSN_EPI_GELU_BWD: store_tile_epi(tm, tn, std::integral_constant<int, MSN_EPI_GELU_BWD>{}, mode_); break;
+            case MSN_EPI_ADD: store_tile_epi(tm, tn, std::integral_constant<int, MSN_EPI_ADD>{}, mode_); break;
+            default: store_tile_epi(tm, tn, std::integral_constant<int, MSN_EPI_NONE>{}, mode_); break;
+        }
+    };
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    acc[i][j][e] = 0.f;
+                    if constexpr (DUAL) acc2[i][j][e] = 0.f;
+                }
+    };
+
+    // ---- prologue: K-steps 0 .. NSLOT - 2 of the stream
+#pragma unroll
+    for (int s = 0; s < NSLOT - 1; ++s) {
+        if (p_live) {
+#pragma unroll
+            for (int q = 0; q < MAXQ; ++q) issue_q(q);
+        }
+        advance();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    req_first(fa[0], fb0[0], 0u);
+
+    using T0 = std::integral_constant<int, 0>;
+    using T1 = std::integral_constant<int, 1>;
+    int tm, tn;
+    // K chunks (fp32 outputs of the DUAL form): the bf16 MFMA's biased accumulate costs ~K^1.5, so a long reduction is cut into
+    // chunks of p.chunk_steps K-steps whose partial sums meet in C by round-to-nearest fp32 adds (the lane that wrote a partial
+    // is the lane that reads it back: same wave, same address, program order)
+    const int csteps = (!OUTP && p.chunk_steps > 0) ? p.chunk_steps : nk;
+    for (int idx = 0; tile_of(idx, tm, tn); ++idx) {
+        zero_acc();
+        int k0 = 0;
+        for (; k0 + csteps < nk; k0 += csteps) {
+            for (int k = 0; k < csteps; k += 2) {
+                step(T0{});
+                step(T1{});
+            }
+            wait_lgkm<0>();
+            if (k0 == 0) store_tile_epi(tm, tn, std::integral_constant<int, MSN_EPI_NONE>{}, std::integral_constant<int, 2>{});
+            else store_tile_epi(tm, tn, std::integral_constant<int, MSN_EPI_NONE>{}, std::integral_constant<int, 3>{});
+            zero_acc();
+        }
+        for (int k = k0; k < nk; k += 2) {           // nk is even (plane format)
+            step(T0{});
+            step(T1{});
+        }
+        // the epilogue is compiler-scheduled code under register pressure: the fragments requested for the next tile must
+        // be IN their registers before it may move them
+        wait_lgkm<0>();
+        if (k0 == 0) store_tile(tm, tn, std::integral_constant<int, 0>{});
+        else store_tile(tm, tn, std::integral_constant<int, 1>{});
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// TN kernel (weight gradients): T[p][q] = sum_m P[m][p] . Q[m][q], both operands plane matrices with the reduction index m
+// on the ROWS.  SWAP = false: P = dY (p = n), Q = X (q = k);  SWAP = true: P = X (p = k), Q = dY (q = n) -- the 256-wide side
+// of the tile goes to whichever of N, K it divides better; the MFMA operand order is chosen so that a lane always ends up
+// with four consecutive k of one n (16-byte stores into C[n][k]).
+// K-step = 16 reduction rows = half a row block.  LDS slot = [P: 16 column blocks][NP][512 B] then [Q: BQ / 16][NP][512 B];
+// a 512-byte half-block image is [16 rows of m][32 B], its four row quads (4 rows = 128 B) stored at quad position
+// Q ^ (column block & 1).  The MFMA wants, per lane, 8 consecutive m of one column: two ds_read_b64_tr_b16 (each hands a
+// 4-row x 16-column block, column-major, to a 16-lane group: lane 4 q + p of the group supplies the address of row q,
+// bytes 8 p .. 8 p + 7; lane i receives column i).  Banking is per 32 lanes = the two column blocks of a 32-wide MFMA tile:
+// they read the same row quad, which the swizzle puts into opposite 128-byte halves of the bank row -> conflict-free.
+template <int OFF>
+__device__ __forceinline__ void ds_read_tr_o(bf16x4& dst, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+
+template <int NP, int BQ, bool SWAP, bool DUAL>
+__global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(const PgemmArgs p) {
+    constexpr int PHB = 16 * NP, QHB = (BQ / 16) * NP;       // half-block images per K-step: P side, Q side
+    constexpr int PIECES = (PHB + QHB) / 2;                  // 1-KB pieces (two half-block images each)
+    constexpr int PP = PHB / 2;
+    constexpr int SLOT = PIECES * PBLK;
+    constexpr int NSLOT = (4 * SLOT <= 160 * 1024) ? 4 : 3;
+    constexpr int MAXQ = (PIECES + 7) / 8;
+    constexpr int MT = 4, NT = BQ / 128;
+    constexpr int NG = NP * (NP + 1) / 2;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSLOT * SLOT];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int tiles = p.tiles_m * p.tiles_n;                 // tiles over (P side, Q side)
+    // workgroup ids go round-robin to the 8 XCDs: give each XCD a contiguous run of (split, tile) pairs, i.e. the tiles of
+    // one reduction range, so that its panels are shared in ONE L2
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg / 8, r = nwg % 8, x = bid % 8, i = bid / 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const int split = bid / tiles, tile = bid % tiles;
+    const int tp = tile / p.tiles_n, tq = tile % p.tiles_n;
+    const unsigned char* Pm = SWAP ? p.B : p.A;
+    const unsigned char* Qm = SWAP ? p.A : p.B;
+    const int cbP = SWAP ? p.cbB : p.cbA, cbQ = SWAP ? p.cbA : p.cbB;    // column blocks of the plane matrices
+    const int rb0 = split * p.rb_per_split;
+    const int rb1 = min(p.rbA, rb0 + p.rb_per_split);
+    const int nk = 2 * (rb1 - rb0);                          // K-steps (>= 2)
+
+    // ---- LDS-DMA: piece id = two consecutive half-block images hb = 2 id + (lane >> 5); image hb of the P side is column
+    // block hb / NP, plane hb % NP: in the plane matrix its 1-KB block is block (cb0 * NP + hb) of the row block.
+    const int sub = lane >> 5, j = lane & 31;
+    const unsigned char* pbase[MAXQ];
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+        const int id = min(wave + 8 * q, PIECES - 1);
+        const bool isP = id < PP;
+        const int hb = 2 * (isP ? id : id - PP) + sub;
+        const int cbp = hb / NP;                                            // column block inside the tile
+        const int cb0 = isP ? tp * 16 : tq * (BQ / 16);
+        const int cbs = isP ? cbP : cbQ;
+        const int hbc = min(hb, (cbs - cb0) * NP - 1);                      // past the matrix: clamped, never stored
+        const int rpos = j >> 1;                                            // row position in the image
+        const int rsrc = (rpos & 3) + 4 * ((rpos >> 2) ^ (cbp & 1));        // source row of that position
+        pbase[q] = (isP ? Pm : Qm) + ((int64_t)rb0 * cbs + cb0) * (NP * PBLK) + (int64_t)hbc * PBLK + rsrc * 32 + (j & 1) * 16;
+    }
+    const int64_t rbstepP = (int64_t)cbP * (NP * PBLK), rbstepQ = (int64_t)cbQ * (NP * PBLK);
+    int p_k = 0, p_slot = 0;
+    auto issue_q = [&](int q) {
+        const int id = wave + 8 * q;
+        if (id < PIECES) {
+            const int64_t off = (int64_t)(p_k >> 1) * (id < PP ? rbstepP : rbstepQ) + (p_k & 1) * 512;
+            __builtin_amdgcn_global_load_lds((gptr_t*)(pbase[q] + off), (lptr_t*)(lds + p_slot * SLOT + id * PBLK), 16, 0, 0);
+        }
+    };
+    auto issue_chunk = [&](auto c_) {
+        constexpr int c = decltype(c_)::value;
+        if (p_k < nk) {
+#pragma unroll
+            for (int q = c * MAXQ / NG; q < (c + 1) * MAXQ / NG; ++q) issue_q(q);
+        }
+    };
+    auto advance = [&]() {
+        if (p_k < nk) {
+            ++p_k;
+            p_slot = (p_slot + 1 == NSLOT) ? 0 : p_slot + 1;
+        }
+    };
+    constexpr int Q_BEFORE = (NG - 1) * MAXQ / NG;
+    const int ppw = (wave + 8 * (MAXQ - 1) < PIECES) ? MAXQ : MAXQ - 1;
+
+    // ---- fragments: lane -> 16-lane group g16 = (lane >> 4) & 1 (column block of the 32-wide tile), m-octet lane >> 5;
+    // inside the group lane 4 q + pp supplies row q, bytes 8 pp.  Read t = 0, 1 of a fragment takes row quad 2 (lane >> 5) + t.
+    const int g16 = (lane >> 4) & 1, moct = lane >> 5, rq = (lane >> 2) & 3, pp = lane & 3;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t*)lds;
+    // address of read t: image(cb pair * 2 + g16, plane) * 512 + ((2 moct + t) ^ g16) * 128 + rq * 32 + pp * 8
+    const unsigned tr0 = lds0 + (unsigned)(g16 * NP * 512 + ((2 * moct) ^ g16) * 128 + rq * 32 + pp * 8);
+    const unsigned tr1 = lds0 + (unsigned)(g16 * NP * 512 + ((2 * moct + 1) ^ g16) * 128 + rq * 32 + pp * 8);
+    const unsigned fragP0 = tr0 + (unsigned)(wm * 8 * NP * 512), fragP1 = tr1 + (unsigned)(wm * 8 * NP * 512);      // + (2 i NP + plane) * 512
+    const unsigned fragQ0 = tr0 + (unsigned)(PHB * 512 + wn * 2 * NT * NP * 512), fragQ1 = tr1 + (unsigned)(PHB * 512 + wn * 2 * NT * NP * 512);
+
+    f32x16 acc[MT][NT], acc2[DUAL ? MT : 1][DUAL ? NT : 1];        // DUAL: see pgemm_nt_kernel
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NT; ++jj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc[i][jj][e] = 0.f;
+                if constexpr (DUAL) acc2[i][jj][e] = 0.f;
+            }
+    bf16x4 fa[2][MT][2], fb0[2][NT][2], fbh[NP > 1 ? NP - 1 : 1][NT][2];
+
+    auto req_a = [&](bf16x4 (&dst)[MT][2], unsigned slot_off, auto pl_) {
+        constexpr int pl = decltype(pl_)::value;
+        static_for<0, MT>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            ds_read_tr_o<(2 * i * NP + pl) * 512>(dst[i][0], fragP0 + slot_off);
+            ds_read_tr_o<(2 * i * NP + pl) * 512>(dst[i][1], fragP1 + slot_off);
+        });
+    };
+    auto req_b = [&](bf16x4 (&dst)[NT][2], unsigned slot_off, auto pl_) {
+        constexpr int pl = decltype(pl_)::value;
+        static_for<0, NT>([&](auto j_) {
+            constexpr int jj = decltype(j_)::value;
+            ds_read_tr_o<(2 * jj * NP + pl) * 512>(dst[jj][0], fragQ0 + slot_off);
+            ds_read_tr_o<(2 * jj * NP + pl) * 512>(dst[jj][1], fragQ1 + slot_off);
+        });
+    };
+    auto mult = [&](const bf16x4 (&a)[MT][2], const bf16x4 (&b)[NT][2], auto small_) {
+        constexpr bool SMALL = decltype(small_)::value && DUAL;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NT; ++jj) {
+                const bf16x8 av = __builtin_shufflevector(a[i][0], a[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8 bv = __builtin_shufflevector(b[jj][0], b[jj][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                if constexpr (SMALL) {
+                    if constexpr (SWAP) acc2[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc2[i][jj], 0, 0, 0);
+                    else acc2[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, acc2[i][jj], 0, 0, 0);
+                } else {
+                    if constexpr (SWAP) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][jj], 0, 0, 0);
+                    else acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, acc[i][jj], 0, 0, 0);
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using BIG = std::integral_constant<bool, false>;
+    using SML = std::integral_constant<bool, true>;
+
+    int c_slot = 0;
+    // One K-step.  On entry outstanding LDS reads, oldest first: P plane 0 (2 MT), Q plane 0 (2 NT); the other Q planes and
+    // the later P planes are requested one product ahead (lgkmcnt counts at most 15 reads).
+    auto step = [&](auto par_) {
+        constexpr int PAR = decltype(par_)::value;
+        constexpr int QA = (NP & 1) ? PAR : 0;
+        const unsigned cur = (unsigned)(c_slot * SLOT);
+        const int n_slot = (c_slot + 1 == NSLOT) ? 0 : c_slot + 1;
+        const unsigned nxt = (unsigned)(n_slot * SLOT);
+        const bool p_was_live = p_k < nk;
+        static_for<0, NP>([&](auto pb_) {
+            constexpr int pb = decltype(pb_)::value;
+            if constexpr (pb + 1 < NP) {
+                if constexpr (pb == 0 && 2 * MT + 4 * NT > 15) wait_lgkm<15 - 2 * NT>();    // never more than 15 reads in flight
+                req_b(fbh[pb], cur, std::integral_constant<int, pb + 1>{});
+                wait_lgkm<2 * NT>();
+            } else {
+                req_a(fa[QA ^ 1], cur, std::integral_constant<int, 1>{});
+                wait_lgkm<2 * MT>();
+            }
+            if constexpr (pb == 0) mult(fa[QA], fb0[PAR], BIG{});
+            else mult(fa[QA], fbh[pb - 1], SML{});
+            issue_chunk(std::integral_constant<int, pb>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        static_for<1, NP - 1>([&](auto pa_) {
+            constexpr int pa = decltype(pa_)::value;
+            constexpr int g0 = pa * NP - pa * (pa - 1) / 2;
+            req_a(fa[(QA + pa + 1) & 1], cur, std::integral_constant<int, pa + 1>{});
+            wait_lgkm<2 * MT>();
+            static_for<0, NP - pa>([&](auto pb_) {
+                constexpr int pb = decltype(pb_)::value;
+                if constexpr (pb == 0) mult(fa[(QA + pa) & 1], fb0[PAR], SML{});
+                else mult(fa[(QA + pa) & 1], fbh[pb - 1], SML{});
+                issue_chunk(std::integral_constant<int, g0 + pb>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        wait_lgkm<0>();
+        wait_vm(p_was_live ? (NSLOT - 3) * ppw + Q_BEFORE : 0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        req_a(fa[(QA + NP) & 1], nxt, std::integral_constant<int, 0>{});
+        req_b(fb0[PAR ^ 1], nxt, std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mult(fa[(QA + NP - 1) & 1], fb0[PAR], SML{});
+        issue_chunk(std::integral_constant<int, NG - 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        advance();
+        c_slot = n_slot;
+    };
+
+    // ---- prologue
+#pragma unroll
+    for (int s_ = 0; s_ < NSLOT - 1; ++s_) {
+        if (p_k < nk) {
+#pragma unroll
+            for (int q = 0; q < MAXQ; ++q) issue_q(q);
+        }
+        advance();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    req_a(fa[0], 0u, std::integral_constant<int, 0>{});
+    req_b(fb0[0], 0u, std::integral_constant<int, 0>{});
+    for (int k = 0; k < nk; k += 2) {
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+    }
+    wait_lgkm<0>();
+
+    // ---- epilogue: C[n][k] (or this split's slab)
+    float* out = p.splits > 1 ? p.slabs + (int64_t)split * p.N * p.K : static_cast<float*>(p.C);
+    const int64_t ldo = p.splits > 1 ? p.K : p.ldc;
+    const int l31 = lane & 31, h4 = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NT; ++jj)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                int n, k;
+                if constexpr (SWAP) {     // D[p][q]: lane holds q = l31 (n), p = 8 b + h4 + r (k)
+                    k = tp * 256 + wm * 128 + 32 * i + 8 * b + h4;
+                    n = tq * BQ + wn * (BQ / 4) + 32 * jj + l31;
+                } else {                  // D'[q][p]: lane holds p = l31 (n), q = 8 b + h4 + r (k)
+                    n = tp * 256 + wm * 128 + 32 * i + l31;
+                    k = tq * BQ + wn * (BQ / 4) + 32 * jj + 8 * b + h4;
+                }
+                if (n >= p.N || k >= p.K) continue;                  // K % 4 == 0 (host)
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[i][jj][4 * b + r];
+                    if constexpr (DUAL) v[r] += acc2[i][jj][4 * b + r];
+                }
+                *reinterpret_cast<float4*>(out + (int64_t)n * ldo + k) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+}
+
+// C[i] = sum_s slab[s][i] in split order (float4 per thread, eight independent loads per wait)
+__global__ void pgemm_slab_sum_kernel(const float* __restrict__ slabs, int splits, int64_t n4, int K4, int64_t ldc4,
+                                      float* __restrict__ C) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k0 = 0; k0 < splits; k0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = reinterpret_cast<const float4*>(slabs)[(int64_t)std::min(k0 + j, splits - 1) * n4 + i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (k0 + j < splits) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
+        }
+        reinterpret_cast<float4*>(C)[(i / K4) * ldc4 + (i % K4)] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fp32 [R][ld] -> blocked planes.  A wave converts two neighbouring blocks of one row block: lane = row (lane >> 1) x
+// 16 columns (lane & 1): 64 contiguous bytes in, two 16-byte stores per plane out (each plane image is written whole by
+// its 32 lanes: 1-KB bursts).  Column sums of x (bias gradients) ride along when `colpart` is given: [row blocks][C].
+template <int NP>
+__global__ __launch_bounds__(256) void plane_split_kernel(const float* __restrict__ x, int64_t ld, int64_t R, int C, int RB, int CB,
+                                                          unsigned char* __restrict__ out, float* __restrict__ colpart) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int CB2 = (CB + 1) / 2;
+    const int64_t nw = (int64_t)RB * CB2;
+    if (wid >= nw) return;
+    const int rb = (int)(wid / CB2), cb = 2 * (int)(wid % CB2) + (lane & 1);
+    const int64_t r = (int64_t)rb * 32 + (lane >> 1);
+    const int c0 = cb * 16;
+    float v[16];
+    if (r < R && c0 + 15 < C && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const float4* s = reinterpret_cast<const float4*>(x + r * ld + c0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float4 t = s[q]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = (r < R && c0 + q < C) ? x[r * ld + c0 + q] : 0.f;
+    }
+    if (cb < CB) {
+        u16 pl[16][NP];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) split_planes<NP>(v[q], pl[q]);
+        unsigned char* dst = out + ((int64_t)rb * CB + cb) * (NP * PBLK) + (lane >> 1) * 32;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            uint4 a, b;
+            a.x = pl[0][k] | ((unsigned)pl[1][k] << 16); a.y = pl[2][k] | ((unsigned)pl[3][k] << 16);
+            a.z = pl[4][k] | ((unsigned)pl[5][k] << 16); a.w = pl[6][k] | ((unsigned)pl[7][k] << 16);
+            b.x = pl[8][k] | ((unsigned)pl[9][k] << 16); b.y = pl[10][k] | ((unsigned)pl[11][k] << 16);
+            b.z = pl[12][k] | ((unsigned)pl[13][k] << 16); b.w = pl[14][k] | ((unsigned)pl[15][k] << 16);
+            *reinterpret_cast<uint4*>(dst + k * PBLK) = a;
+            *reinterpret_cast<uint4*>(dst + k * PBLK + 16) = b;
+        }
+    }
+    if (colpart) {      // sum over the 32 rows of the block: lanes of equal parity (xor 2, 4, .., 32)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            float t = v[q];
+#pragma unroll
+            for (int o = 2; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
+            v[q] = t;
+        }
+        if (lane < 2 && cb < CB) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (c0 + q < C) colpart[(int64_t)rb * C + c0 + q] = v[q];
+        }
+    }
+}
+
+// planes of x^T: out is the plane matrix of the C x R transpose (weights: a few MB per step).  One workgroup per 32 x 32
+// tile of x through LDS.
+template <int NP>
+__global__ __launch_bounds__(256) void plane_split_t_kernel(const float* __restrict__ x, int64_t ld, int R, int C, int CBT,
+                                                            unsigned char* __restrict__ out) {
+    __shared__ float t[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;        // tile of x; the transpose has rows c0.., columns r0..
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) t[i][tx] = (r0 + i < R && c0 + tx < C) ? x[(int64_t)(r0 + i) * ld + c0 + tx] : 0.f;
+    __syncthreads();
+    // transposed element (row c0 + i, column r0 + j) = t[j][i]; thread -> row i = threadIdx.x / 8, 4 columns j0 = 4 (threadIdx.x % 8)
+    const int i = threadIdx.x >> 3, j0 = 4 * (threadIdx.x & 7);
+    u16 pl[4][NP];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split_planes<NP>(t[j0 + q][i], pl[q]);
+    const int rbT = blockIdx.x;                                    // row block of the transpose (32 rows = c0 .. c0 + 31)
+    const int cbT = (r0 + j0) >> 4;                                // column block of the transpose
+    if (cbT < CBT) {
+        unsigned char* dst = out + ((int64_t)rbT * CBT + cbT) * (NP * PBLK) + i * 32 + ((r0 + j0) & 15) * 2;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            uint2 o;
+            o.x = pl[0][k] | ((unsigned)pl[1][k] << 16);
+            o.y = pl[2][k] | ((unsigned)pl[3][k] << 16);
+            *reinterpret_cast<uint2*>(dst + k * PBLK) = o;
+        }
+    }
+}
+
+// blocked planes -> fp32 (sum of the planes, smallest first): tests and debugging
+__global__ void plane_merge_kernel(const unsigned char* __restrict__ in, int NP, int64_t R, int C, int CB, float* __restrict__ y,
+                                   int64_t ld) {
+    const int64_t n = R * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / C;
+        const int c = (int)(i % C);
+        const unsigned char* s = in + ((r >> 5) * CB + (c >> 4)) * ((int64_t)NP * PBLK) + (r & 31) * 32 + (c & 15) * 2;
+        float acc = 0.f;
+        for (int k = NP - 1; k >= 0; --k) acc += bf2f(*reinterpret_cast<const u16*>(s + k * PBLK));
+        y[r * ld + c] = acc;
+    }
+}
+
+// out[n] = sum_k part[k][n]: 64 columns x 4 row groups per workgroup, fixed order
+__global__ __launch_bounds__(256) void pcolsum_finish_kernel(const float* __restrict__ part, int nparts, int N,
+                                                             float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + cl;
+    float s = 0.f;
+    if (n < N) {
+        const int mine = (nparts - rg + 3) / 4;
+        for (int k0 = 0; k0 < mine; k0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = part[(int64_t)(rg + 4 * std::min(k0 + j, mine - 1)) * N + n];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (k0 + j < mine) s += v[j];
+        }
+    }
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && n < N) out[n] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
+static bool aligned16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace msn
+
+using namespace msn;
+
+static int g_pgemm_bn = 0;          // 0 = planned, 128 / 256 forced (measurements)
+extern "C" int msn_set_pgemm_tile_n(int bn) {
+    MSN_REQUIRE(bn == 0 || bn == 128 || bn == 256, "msn_set_pgemm_tile_n: 0, 128 or 256");
+    g_pgemm_bn = bn;
+    return MSN_OK;
+}
+
+extern "C" size_t msn_plane_bytes(int64_t R, int64_t C, int planes) {
+    if (R <= 0 || C <= 0 || planes < 1 || planes > 3) return 0;
+    return (size_t)cdiv(R, 32) * (size_t)(2 * cdiv(C, 32)) * (size_t)planes * PBLK;
+}
+
+extern "C" size_t msn_plane_split_colsum_workspace_bytes(int64_t R, int64_t C) {
+    if (R <= 0 || C <= 0) return 0;
+    return sizeof(float) * (size_t)cdiv(R, 32) * (size_t)C;
+}
+
+extern "C" int msn_plane_split(const float* x, int64_t ldx, int64_t R, int64_t C, int planes, int transposed, void* out,
+                               float* colsum, void* ws, size_t ws_bytes, msn_stream_t stream) {
+    MSN_REQUIRE(x && out && R > 0 && C > 0 && ldx >= C, "msn_plane_split: bad operand");
+    MSN_REQUIRE(planes == 2 || planes == 3, "msn_plane_split: planes must be 2 or 3 (got %d)", planes);
+    MSN_REQUIRE(aligned16p(out), "msn_plane_split: the plane matrix must be 16-byte aligned");
+    MSN_REQUIRE(R < (1ll << 31) && C < (1ll << 31), "msn_plane_split: matrix too large");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (transposed) {
+        MSN_REQUIRE(!colsum, "msn_plane_split: column sums only for the untransposed form");
+        const int CBT = 2 * (int)cdiv(R, 32);                       // the transpose is C x R
+        const dim3 grid((unsigned)cdiv(C, 32), (unsigned)cdiv(R, 32));
+        if (planes == 3) hipLaunchKernelGGL(plane_split_t_kernel<3>, grid, dim3(256), 0, st, x, ldx, (int)R, (int)C, CBT, static_cast<unsigned char*>(out));
+        else hipLaunchKernelGGL(plane_split_t_kernel<2>, grid, dim3(256), 0, st, x, ldx, (int)R, (int)C, CBT, static_cast<unsigned char*>(out));
+        MSN_LAUNCH_CHECK();
+        return MSN_OK;
+    }
+    const int RB = (int)cdiv(R, 32), CB = 2 * (int)cdiv(C, 32);
+    float* part = nullptr;
+    if (colsum) {
+        const size_t need = msn_plane_split_colsum_workspace_bytes(R, C);
+        MSN_REQUIRE(ws && ws_bytes >= need, "msn_plane_split: column-sum workspace %zu < %zu bytes", ws_bytes, need);
+        part = static_cast<float*>(ws);
+    }
+    const int64_t nw = (int64_t)RB * ((CB + 1) / 2);
+    const dim3 grid((unsigned)cdiv(nw, 4));
+    if (planes == 3) hipLaunchKernelGGL(plane_split_kernel<3>, grid, dim3(256), 0, st, x, ldx, R, (int)C, RB, CB, static_cast<unsigned char*>(out), part);
+    else hipLaunchKernelGGL(plane_split_kernel<2>, grid, dim3(256), 0, st, x, ldx, R, (int)C, RB, CB, static_cast<unsigned char*>(out), part);
+    MSN_LAUNCH_CHECK();
+    if (colsum) {
+        hipLaunchKernelGGL(pcolsum_finish_kernel, dim3((unsigned)cdiv(C, 64)), dim3(256), 0, st, part, RB, (int)C, colsum);
+        MSN_LAUNCH_CHECK();
+    }
+    return MSN_OK;
+}
+
+extern "C" int msn_plane_merge(const void* planes_in, int planes, int64_t R, int64_t C, float* y, int64_t ldy, msn_stream_t stream) {
+    MSN_REQUIRE(planes_in && y && R > 0 && C > 0 && ldy >= C && planes >= 1 && planes <= 3, "msn_plane_merge: bad operand");
+    const int64_t n = R * C;
+    hipLaunchKernelGGL(plane_merge_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 8192)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const unsigned char*>(planes_in), planes, R, (int)C,
+                       2 * (int)cdiv(C, 32), y, ldy);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" size_t msn_pgemm_nt_colsum_workspace_bytes(int64_t M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    return sizeof(float) * 2 * (size_t)cdiv(M, BM) * (size_t)N;
+}
+
+template <int NP, int BN, bool DUAL>
+static void launch_nt(const PgemmArgs& a, bool outp, int grid, hipStream_t st) {
+    if (outp) hipLaunchKernelGGL((pgemm_nt_kernel<NP, BN, true, DUAL>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((pgemm_nt_kernel<NP, BN, false, DUAL>), dim3((unsigned)grid), dim3(512), 0, st, a);
+}
+
+extern "C" int msn_pgemm_nt(int64_t M, int N, int K, int planes, const void* A, const void* B, void* C, int64_t ldc,
+                            int c_planes, const float* bias, int epilogue, float* aux, int64_t ldaux, float* colsum_out,
+                            void* ws, size_t ws_bytes, msn_stream_t stream) {
+    MSN_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, "msn_pgemm_nt: empty operand");
+    MSN_REQUIRE(planes == 2 || planes == 3, "msn_pgemm_nt: planes must be 2 or 3 (got %d)", planes);
+    MSN_REQUIRE(N % 4 == 0 && (!c_planes || N % 16 == 0), "msn_pgemm_nt: N = %d must be a multiple of 4 (16 for a plane output)", N);
+    MSN_REQUIRE(aligned16p(A) && aligned16p(B) && aligned16p(C) && (!bias || aligned16p(bias)), "msn_pgemm_nt: operands must be 16-byte aligned");
+    MSN_REQUIRE(c_planes || (ldc >= N && ldc % 4 == 0), "msn_pgemm_nt: bad output row stride %lld", (long long)ldc);
+    MSN_REQUIRE(epilogue >= MSN_EPI_NONE && epilogue <= MSN_EPI_ADD, "msn_pgemm_nt: unknown epilogue %d", epilogue);
+    const bool needs_aux = epilogue == MSN_EPI_RELU_BWD || epilogue == MSN_EPI_GELU_BWD || epilogue == MSN_EPI_ADD;
+    MSN_REQUIRE(!needs_aux || aux, "msn_pgemm_nt: epilogue %d needs an aux matrix", epilogue);
+    MSN_REQUIRE(!aux || (ldaux >= N && ldaux % 4 == 0 && aligned16p(aux)), "msn_pgemm_nt: bad aux matrix");
+    MSN_REQUIRE(M < (1ll << 31) * 32, "msn_pgemm_nt: too many rows");
+    PgemmArgs a = {};
+    a.A = static_cast<const unsigned char*>(A); a.B = static_cast<const unsigned char*>(B); a.C = C;
+    a.aux = aux; a.bias = bias; a.ldc = ldc; a.ldaux = ldaux; a.M = M; a.N = N; a.K = K;
+    a.rbA = (int)cdiv(M, 32); a.rbB = (int)cdiv(N, 32);
+    a.cbA = a.cbB = 2 * (int)cdiv(K, 32);
+    a.cbC = 2 * (int)cdiv(N, 32);
+    a.epi = epilogue;
+    // tile width: 128 when that wastes fewer columns than 256 (N = 384 -> 3 x 128, N = 1152 -> 9 x 128); the 3-plane
+    // (fp32-grade) form always takes 128: it carries two accumulator sets (see the kernel), which fill the register file
+    int bn = g_pgemm_bn;
+    if (!bn) bn = (cdiv(N, 256) * 256 - N >= 128 || N <= 128) ? 128 : 256;
+    if (planes == 3) bn = 128;
+    a.tiles_m = (int)cdiv(M, BM); a.tiles_n = (int)cdiv(N, bn);
+    // super-rows: tile-rows walked together while their A panels (256 rows x K x 2 NP bytes) fit half an L2
+    a.super_rows = (int)std::max<int64_t>(1, std::min<int64_t>(8, (2 << 20) / ((int64_t)BM * K * 2 * planes)));
+    // fp32 grade: reductions longer than 768 columns are cut into chunks of at most 512 (the partial sums meet in C by fp32 adds)
+    a.chunk_steps = 0;
+    if (planes == 3 && !c_planes && a.cbA > 48) {
+        const int nch = (int)cdiv(a.cbA, 32);
+        a.chunk_steps = 2 * (int)cdiv(a.cbA, 2 * nch);
+    }
+    a.colpart = nullptr;
+    if (colsum_out) {
+        const size_t need = msn_pgemm_nt_colsum_workspace_bytes(M, N);
+        MSN_REQUIRE(ws && ws_bytes >= need && aligned16p(ws), "msn_pgemm_nt: column-sum workspace %zu < %zu bytes", ws_bytes, need);
+        a.colpart = static_cast<float*>(ws);
+    }
+    const int total = a.tiles_m * a.tiles_n;
+    const int grid = std::min(total, 256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (planes == 3) launch_nt<3, 128, true>(a, c_planes != 0, grid, st);
+    else if (bn == 256) launch_nt<2, 256, false>(a, c_planes != 0, grid, st);
+    else launch_nt<2, 128, false>(a, c_planes != 0, grid, st);
+    MSN_LAUNCH_CHECK();
+    if (colsum_out) {
+        hipLaunchKernelGGL(pcolsum_finish_kernel, dim3((unsigned)cdiv(N, 64)), dim3(256), 0, st, a.colpart, 2 * a.tiles_m, N, colsum_out);
+        MSN_LAUNCH_CHECK();
+    }
+    return MSN_OK;
+}
+
+// ---- TN host side: orientation, tile width and reduction split
+namespace {
+struct TnPlan { bool swap; int bq, tiles_p, tiles_q, splits, rb_per_split; };
+TnPlan tn_plan(int64_t M, int N, int K, int planes) {
+    TnPlan t;
+    // the 256-wide side goes to the dimension with fewer wasted columns (ties: N, the non-swapped form)
+    auto waste = [](int n, int w) { return (int)(cdiv(n, w) * w - n); };
+    const int wn = waste(N, 256), wk = waste(K, 256);
+    t.swap = wk < wn;
+    const int Pd = t.swap ? K : N, Qd = t.swap ? N : K;
+    t.bq = (planes == 3 || waste(Qd, 256) >= 128 || Qd <= 128) ? 128 : 256;     // 3 planes: two accumulator sets
+    t.tiles_p = (int)cdiv(Pd, 256);
+    t.tiles_q = (int)cdiv(Qd, t.bq);
+    const int tiles = t.tiles_p * t.tiles_q;
+    const int rbs = (int)cdiv(M, 32);
+    int s = std::max(1, 256 / tiles);                 // enough workgroups for the 256 CUs (one 144-KB workgroup per CU)
+    s = std::min(s, rbs);
+    // fp32 grade: at most 2048 reduction rows per accumulator (the bf16 MFMA's biased rounding grows like K^1.5; the slab
+    // sums are round-to-nearest fp32 adds)
+    if (planes == 3) s = std::max<int>(s, (int)cdiv(rbs, 64));
+    t.rb_per_split = (int)cdiv(rbs, s);
+    t.splits = (int)cdiv(rbs, t.rb_per_split);
+    return t;
+}
+}  // namespace
+
+extern "C" size_t msn_pgemm_tn_workspace_bytes(int64_t M, int N, int K, int planes) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const TnPlan t = tn_plan(M, N, K, planes);
+    return t.splits > 1 ? sizeof(float) * (size_t)t.splits * N * K : 0;
+}
+
+template <int NP, int BQ, bool DUAL>
+static void launch_tn(const PgemmArgs& a, bool swap, int grid, hipStream_t st) {
+    if (swap) hipLaunchKernelGGL((pgemm_tn_kernel<NP, BQ, true, DUAL>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((pgemm_tn_kernel<NP, BQ, false, DUAL>), dim3((unsigned)grid), dim3(512), 0, st, a);
+}
+
+extern "C" int msn_pgemm_tn(int64_t M, int N, int K, int planes, const void* A, const void* B, float* C, int64_t ldc, void* ws,
+                            size_t ws_bytes, msn_stream_t stream) {
+    MSN_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, "msn_pgemm_tn: empty operand");
+    MSN_REQUIRE(planes == 2 || planes == 3, "msn_pgemm_tn: planes must be 2 or 3 (got %d)", planes);
+    MSN_REQUIRE(K % 4 == 0 && ldc >= K && ldc % 4 == 0 && aligned16p(C) && aligned16p(A) && aligned16p(B),
+                "msn_pgemm_tn: K and ldc must be multiples of 4, operands 16-byte aligned");
+    const TnPlan t = tn_plan(M, N, K, planes);
+    PgemmArgs a = {};
+    a.A = static_cast<const unsigned char*>(A); a.B = static_cast<const unsigned char*>(B); a.C = C;
+    a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+    a.rbA = a.rbB = (int)cdiv(M, 32);
+    a.cbA = 2 * (int)cdiv(N, 32); a.cbB = 2 * (int)cdiv(K, 32);
+    a.tiles_m = t.tiles_p; a.tiles_n = t.tiles_q;
+    a.splits = t.splits; a.rb_per_split = t.rb_per_split;
+    const size_t need = t.splits > 1 ? sizeof(float) * (size_t)t.splits * N * K : 0;
+    MSN_REQUIRE(need == 0 || (ws && ws_bytes >= need && aligned16p(ws)), "msn_pgemm_tn: workspace %zu < %zu bytes", ws_bytes, need);
+    a.slabs = static_cast<float*>(ws);
+    const int grid = t.tiles_p * t.tiles_q * t.splits;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (planes == 3) launch_tn<3, 128, true>(a, t.swap, grid, st);
+    else if (t.bq == 256) launch_tn<2, 256, false>(a, t.swap, grid, st);
+    else launch_tn<2, 128, false>(a, t.swap, grid, st);
+    MSN_LAUNCH_CHECK();
+    if (t.splits > 1) {
+        const int64_t n4 = (int64_t)N * K / 4;
+        hipLaunchKernelGGL(pgemm_slab_sum_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n4, 256), 2048)), dim3(256), 0, st,
+                           a.slabs, t.splits, n4, K / 4, ldc / 4, C);
+        MSN_LAUNCH_CHECK();
+    }
+    return MSN_OK;
+}

@@ -576,6 +576,67 @@ class _PreNormBlock(torch.autograd.Function):
         return (dx.view(B, T, e), None, None, dg1, db1, dwqkv, dbqkv, dwo, dbo, dg2, db2, dw1, dc1, dw2, dc2)
 
 
+@_remember_precision
+class _PreNormBlockPlanes(torch.autograd.Function):
+    """_PreNormBlock with every Linear product on the plane kernels (csrc/pgemm.hip: fp32-grade products on the bf16 matrix
+    cores from operands RESIDENT as bf16 planes; ops.plane_count() = 3 planes / 6 products, or 2 / 3).  Same arithmetic
+    plan as the fp32 block -- residual adds, bias adds, GELU and GELU' in GEMM epilogues -- with each operand split into
+    planes ONCE by its producer: LayerNorm outputs, the attention output, the GELU epilogue (writes the planes of f
+    directly), gradients as they leave LayerNorm backward / the GELU' epilogue / attention backward; the weights (and
+    their transposes, for the input-gradient products) once per call.  The residual stream, LayerNorm statistics,
+    attention and every parameter gradient stay fp32."""
+
+    @staticmethod
+    def forward(ctx, x, heads, eps, g1, b1, wqkv, bqkv, wo, bo, g2, b2, w1, c1, w2, c2):
+        B, T, e = x.shape
+        NPL = ops.plane_count()
+        x2 = _c(x).view(B * T, e)
+        scale = 1.0 / math.sqrt(e // heads)
+        h1p, m1, r1 = ops.layernorm_fwd_planes(x2, g1, b1, eps, NPL)
+        qkv = ops.pgemm_nt(h1p, ops.plane_split(wqkv, NPL), bias=bqkv)
+        q3 = qkv.view(B, T, 3 * e)
+        a, lse = ops.attention_fwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], None, heads, scale)
+        a2 = a.view(B * T, e)
+        ap = ops.plane_split(a2, NPL)
+        x1 = ops.pgemm_nt(ap, ops.plane_split(wo, NPL), bias=bo, epilogue=EPI_ADD, aux=x2)
+        h2p, m2, r2 = ops.layernorm_fwd_planes(x1, g2, b2, eps, NPL)
+        fp, dact = ops.pgemm_nt(h2p, ops.plane_split(w1, NPL), bias=c1, epilogue=EPI_GELU, aux=True, out_planes=True)
+        out = ops.pgemm_nt(fp, ops.plane_split(w2, NPL), bias=c2, epilogue=EPI_ADD, aux=x1)
+        ctx.dims = (B, T, e, heads, scale, NPL)
+        ctx.planes = (h1p, ap, h2p, fp)                       # plane matrices are not tensors: kept on the node
+        ctx.save_for_backward(x2, g1, wqkv, wo, g2, w1, w2, m1, r1, qkv, a2, lse, x1, m2, r2, dact,
+                              h1p.buf, ap.buf, h2p.buf, fp.buf)
+        return out.view(B, T, e)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, e, heads, scale, NPL = ctx.dims
+        (x2, g1, wqkv, wo, g2, w1, w2, m1, r1, qkv, a2, lse, x1, m2, r2, dact, *_bufs) = ctx.saved_tensors
+        h1p, ap, h2p, fp = ctx.planes
+        d2 = _c(dy).view(B * T, e)
+        # input gradients dX = dY . W are NT products against the planes of the transposed weight; every bias gradient (a
+        # column sum of a gradient matrix) comes out of the pass that writes that matrix's planes
+        d2p, dc2 = ops.plane_split(d2, NPL, want_colsum=True)
+        dw2 = ops.pgemm_tn(d2p, fp)
+        dprep, dc1 = ops.pgemm_nt(d2p, ops.plane_split(w2, NPL, transposed=True), epilogue=EPI_GELU_BWD, aux=dact,
+                                  out_planes=True, want_colsum=True)
+        dw1 = ops.pgemm_tn(dprep, h2p)
+        dh2 = ops.pgemm_nt(dprep, ops.plane_split(w1, NPL, transposed=True))
+        dx1, dg2, db2 = ops.layernorm_bwd(dh2, x1, m2, r2, g2, add=d2)        # + skip connection
+        dx1p, dbo = ops.plane_split(dx1, NPL, want_colsum=True)
+        dwo = ops.pgemm_tn(dx1p, ap)
+        da = ops.pgemm_nt(dx1p, ops.plane_split(wo, NPL, transposed=True))
+        dqkv = torch.empty_like(qkv)
+        q3, d3 = qkv.view(B, T, 3 * e), dqkv.view(B, T, 3 * e)
+        ops.attention_bwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], None, heads, scale, a2.view(B, T, e), lse,
+                          da.view(B, T, e), d3[..., :e], d3[..., e:2 * e], d3[..., 2 * e:])
+        dqkvp, dbqkv = ops.plane_split(dqkv, NPL, want_colsum=True)
+        dwqkv = ops.pgemm_tn(dqkvp, h1p)
+        dh1 = ops.pgemm_nt(dqkvp, ops.plane_split(wqkv, NPL, transposed=True))
+        dx, dg1, db1 = ops.layernorm_bwd(dh1, x2, m1, r1, g1, add=dx1)          # + skip connection
+        return (dx.view(B, T, e), None, None, dg1, db1, dwqkv, dbqkv, dwo, dbo, dg2, db2, dw1, dc1, dw2, dc2)
+
+
 # Backward pairs (dX and dW of one Linear) as ONE work-list launch: bit 1 = the qkv and ff1 pairs (e-wide dX), bit 4 = the ff2
 # pair (4e-wide dX), bit 2 = the e x e output projection.  MSN_PAIR_BACKWARD overrides; unset: by row count (_pair_backward).
 PAIR_BACKWARD = os.environ.get("MSN_PAIR_BACKWARD")
@@ -594,6 +655,9 @@ def _pair_backward(rows):
 
 
 def pre_norm_block(x, heads, p, eps=1e-6):
+    B, T, e = x.shape
+    if ops.plane_count() and ops.pgemm_supported(B * T, e, e) and x.is_cuda:
+        return _PreNormBlockPlanes.apply(x, heads, eps, *p)
     return _PreNormBlock.apply(x, heads, eps, *p)
 
 

@@ -13,7 +13,19 @@ GEMM_PROFILE = None
 # Inner-product precision used by sgemm() when the caller passes none (include/msn_hip.h):
 # PREC_F32 exact fp32 MFMA (default), PREC_BF16X3 split-bf16 (fp32-grade, ~1e-5), PREC_BF16 plain bf16.
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
-_PREC_NAMES = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
+# Python-level precisions of the plane path (csrc/pgemm.hip; the wide ViT products run on pgemm_nt / pgemm_tn with
+# operands resident as bf16 planes): "bf16x6" = 3 planes, 6 MFMA products, fp32 grade; "bf16x3p" = 2 planes, 3 products.
+# Products the plane kernels do not take (narrow towers, small batches) fall back to msn_sgemm in f32 / bf16x3.
+PREC_PLANES3, PREC_PLANES2 = 3, 4
+_PREC_NAMES = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "bf16x6": PREC_PLANES3, "bf16x3p": PREC_PLANES2}
+_C_PRECISION = {PREC_F32: PREC_F32, PREC_BF16X3: PREC_BF16X3, PREC_BF16: PREC_BF16, PREC_PLANES3: PREC_F32,
+                PREC_PLANES2: PREC_BF16X3}      # what msn_sgemm is asked for
+
+
+def plane_count(precision=None):
+    """Planes per operand of the plane path under `precision` (default: the one in force), or 0 outside it."""
+    p = GEMM_PRECISION if precision is None else precision
+    return 3 if p == PREC_PLANES3 else 2 if p == PREC_PLANES2 else 0
 GEMM_PRECISION = _PREC_NAMES[__import__("os").environ.get("MSN_GEMM_PRECISION", "f32").lower()]
 
 
@@ -94,7 +106,7 @@ def sgemm(a, b, op_a=OP_N, op_b=OP_T, bias=None, epilogue=EPI_NONE, aux=None, ou
         ev0.record()
     check(L.msn_sgemm(op_a, op_b, M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(c),
                       c.stride(0) if c.numel() else max(N, 1), ptr(bias), epilogue, ptr(aux),
-                      aux.stride(0) if aux is not None else 0, GEMM_PRECISION if precision is None else precision,
+                      aux.stride(0) if aux is not None else 0, _C_PRECISION[GEMM_PRECISION if precision is None else precision],
                       ptr(ws), ws_bytes, stream_ptr()), "msn_sgemm")
     if prof is not None:
         ev1.record()
@@ -125,7 +137,7 @@ def wgrad_bias(dy, x, precision=None, out=None):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     check(L.msn_wgrad_bias(M, N, K, ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(dw), max(N, 1), ptr(db),
-                           GEMM_PRECISION if precision is None else precision, ptr(ws), nb, stream_ptr()), "msn_wgrad_bias")
+                           _C_PRECISION[GEMM_PRECISION if precision is None else precision], ptr(ws), nb, stream_ptr()), "msn_wgrad_bias")
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1, 2.0 * M * N * K, (OP_T, OP_N, M, N, K, EPI_NONE), False))
@@ -171,7 +183,7 @@ def sgemm_list(descs, precision=None, profile_key=None):
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(L.msn_sgemm_list(n, ctypes.cast(arr, ctypes.c_void_p), GEMM_PRECISION if precision is None else precision,
+    check(L.msn_sgemm_list(n, ctypes.cast(arr, ctypes.c_void_p), _C_PRECISION[GEMM_PRECISION if precision is None else precision],
                            ptr(ws), nb, stream_ptr()), "msn_sgemm_list")
     if prof is not None:
         ev1.record()
@@ -900,3 +912,113 @@ def attention_bf16_bwd(qkv, out, dout, lse, B, T, heads, scale, want_colsum=Fals
                                        heads, T, scale, ptr(dqkv), ptr(delta), ptr(cs), ptr(ws), stream_ptr()),
           "msn_attention_bf16_bwd")
     return (dqkv, cs) if want_colsum else dqkv
+
+
+# ------------------------------------------------ fp32-grade products from resident bf16 planes (csrc/pgemm.hip)
+PLANES = int(__import__("os").environ.get("MSN_PLANES", "3"))     # planes per operand: 3 = fp32 grade (6 products), 2 = 3 products
+
+
+class Planes:
+    """An fp32 (R, C) matrix held as `planes` bf16 planes in the blocked layout of include/msn_hip.h (msn_plane_split):
+    the operand format of pgemm_nt / pgemm_tn.  `buf` is a flat uint8 device tensor."""
+    __slots__ = ("buf", "R", "C", "planes")
+
+    def __init__(self, buf, R, C, planes):
+        self.buf, self.R, self.C, self.planes = buf, int(R), int(C), int(planes)
+
+    @staticmethod
+    def empty(R, C, planes, device):
+        nb = lib().msn_plane_bytes(R, C, planes)
+        return Planes(torch.empty(nb, dtype=torch.uint8, device=device), R, C, planes)
+
+    def to_float(self):
+        y = torch.empty((self.R, self.C), dtype=torch.float32, device=self.buf.device)
+        check(lib().msn_plane_merge(ptr(self.buf), self.planes, self.R, self.C, ptr(y), self.C, stream_ptr()), "msn_plane_merge")
+        return y
+
+
+def plane_split(x, planes=None, transposed=False, want_colsum=False):
+    """Planes of a 2-D fp32 matrix (row stride free) or, transposed=True, of its transpose.  want_colsum: also the column
+    sums of x (a bias gradient) from the same pass."""
+    _f32c(x, "x")
+    assert x.dim() == 2 and x.stride(1) == 1
+    planes = PLANES if planes is None else planes
+    R, C = x.shape
+    out = Planes.empty(C, R, planes, x.device) if transposed else Planes.empty(R, C, planes, x.device)
+    cs = ws = None
+    nb = 0
+    if want_colsum:
+        cs = torch.empty(C, dtype=torch.float32, device=x.device)
+        nb = lib().msn_plane_split_colsum_workspace_bytes(R, C)
+        ws = _workspace(nb, x.device)
+    check(lib().msn_plane_split(ptr(x), x.stride(0), R, C, planes, 1 if transposed else 0, ptr(out.buf), ptr(cs), ptr(ws), nb,
+                                stream_ptr()), "msn_plane_split")
+    return (out, cs) if want_colsum else out
+
+
+def pgemm_supported(M, N, K):
+    """Shapes worth the plane kernels (256-row tiles, 16-deep K-steps): wide layers of the ViT towers."""
+    return M >= 256 and N >= 128 and N % 16 == 0 and K >= 128 and K % 4 == 0
+
+
+def pgemm_nt(a, w, bias=None, epilogue=EPI_NONE, aux=None, out_planes=False, want_colsum=False):
+    """C = epilogue(a @ w.T + bias): a = Planes (M, K), w = Planes (N, K) -> fp32 (M, N) or, out_planes, Planes (M, N).
+    GELU with aux=True allocates and returns the fp32 gelu' matrix as second result.  want_colsum: column sums of C last."""
+    assert isinstance(a, Planes) and isinstance(w, Planes) and a.C == w.C and a.planes == w.planes
+    M, K, N = a.R, a.C, w.R
+    dev = a.buf.device
+    c = Planes.empty(M, N, a.planes, dev) if out_planes else torch.empty((M, N), dtype=torch.float32, device=dev)
+    ret_aux = False
+    if epilogue == EPI_GELU and aux is True:
+        aux = torch.empty((M, N), dtype=torch.float32, device=dev)
+        ret_aux = True
+    cs, ws, nb = None, None, 0
+    if want_colsum:
+        cs = torch.empty(N, dtype=torch.float32, device=dev)
+        nb = lib().msn_pgemm_nt_colsum_workspace_bytes(M, N)
+        ws = _workspace(nb, dev)
+    prof = GEMM_PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().msn_pgemm_nt(M, N, K, a.planes, ptr(a.buf), ptr(w.buf), ptr(c.buf if out_planes else c), N, 1 if out_planes else 0,
+                             ptr(bias), epilogue, ptr(aux), aux.stride(0) if aux is not None else 0, ptr(cs), ptr(ws), nb,
+                             stream_ptr()), "msn_pgemm_nt")
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, 2.0 * M * N * K, (OP_N, OP_T, M, N, K, 200 + epilogue), aux is not None))
+    out = (c, aux) if ret_aux else (c,)
+    if want_colsum:
+        out = out + (cs,)
+    return out if len(out) > 1 else out[0]
+
+
+def pgemm_tn(dy, x):
+    """dW = dy.T @ x: dy = Planes (M, N), x = Planes (M, K) -> fp32 (N, K) (weight gradient; fixed-order split over M)."""
+    assert isinstance(dy, Planes) and isinstance(x, Planes) and dy.R == x.R and dy.planes == x.planes
+    M, N, K = dy.R, dy.C, x.C
+    dev = dy.buf.device
+    c = torch.empty((N, K), dtype=torch.float32, device=dev)
+    L = lib()
+    nb = L.msn_pgemm_tn_workspace_bytes(M, N, K, dy.planes)
+    ws = _workspace(nb, dev) if nb else None
+    prof = GEMM_PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(L.msn_pgemm_tn(M, N, K, dy.planes, ptr(dy.buf), ptr(x.buf), ptr(c), K, ptr(ws), nb, stream_ptr()), "msn_pgemm_tn")
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, 2.0 * M * N * K, (OP_T, OP_N, N, K, M, 200), False))
+    return c
+
+
+def set_pgemm_tile_n(bn):
+    """Tile width of pgemm_nt: 0 = planned (default), 128, 256 -- measurements / tests."""
+    check(lib().msn_set_pgemm_tile_n(int(bn)))
+
+
+def layernorm_fwd_planes(x, gamma, beta, eps, planes):
+    """LayerNorm whose output goes straight to bf16 planes (the next product's operand); returns (Planes, mean, rstd)."""
+    y, mean, rstd = layernorm_fwd(x, gamma, beta, eps)
+    return plane_split(y, planes), mean, rstd

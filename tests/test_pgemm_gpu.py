@@ -1,0 +1,161 @@
+"""fp32-grade GEMMs from resident bf16 planes (msn_pgemm_nt / msn_pgemm_tn / msn_plane_split, csrc/pgemm.hip) against
+torch in fp64.
+
+* three planes hold an fp32 value exactly: split -> merge is the identity, bit for bit;
+* integer-valued operands make every product and partial sum exact in fp32, so the result must be bit-exact whatever the
+  summation order: that pins the block layout, the LDS-DMA / fragment / swizzle maps and the tile edges (an asymmetric B
+  catches a transposed output);
+* THE GATE for using the 3-plane form where the product promises fp32: on every GEMM shape of the
+  headline step, on N(0,1), cancellation-heavy and wide-dynamic-range operands, maximum and RMS error against fp64 at
+  most 1.5 x those of the native fp32 MFMA kernel (msn_sgemm)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ints(shape, g, lo=-4, hi=5):
+    return torch.randint(lo, hi, shape, generator=g).float()
+
+
+@pytest.mark.parametrize("R,C", [(32, 32), (100, 70), (257, 384), (1000, 1152), (31, 17)])
+@pytest.mark.parametrize("planes", [3, 2])
+def test_split_merge(R, C, planes):
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(R * 7 + C)
+    x = torch.randn(R, C, generator=g) * torch.exp(torch.randn(R, C, generator=g) * 4)      # wide dynamic range
+    xp, cs = ops.plane_split(x.cuda(), planes=planes, want_colsum=True)
+    y = xp.to_float().cpu()
+    if planes == 3:
+        assert torch.equal(y, x), "three bf16 planes must hold an fp32 value exactly"
+    else:
+        assert float(((y - x).abs() / x.abs().clamp_min(1e-30)).max()) < 2.0 ** -15
+    torch.testing.assert_close(cs.cpu().double(), x.double().sum(0), rtol=1e-5, atol=1e-5 * float(x.abs().sum(0).max()))
+    xt = ops.plane_split(x.cuda(), planes=planes, transposed=True)
+    assert (xt.R, xt.C) == (C, R)
+    yt = xt.to_float().cpu()
+    if planes == 3:
+        assert torch.equal(yt, x.T.contiguous())
+    # strided rows (a column slice of a wider matrix)
+    wide = torch.randn(R, C + 8, generator=g).cuda()
+    assert torch.equal(ops.plane_split(wide[:, 4:4 + C], planes=3).to_float(), wide[:, 4:4 + C])
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (256, 128, 64), (300, 272, 200), (1000, 384, 384), (513, 1152, 384),
+                                   (777, 384, 1536), (4096, 1536, 384), (260, 144, 132), (65 * 40, 384, 192)])
+@pytest.mark.parametrize("planes", [3, 2])
+def test_nt_exact_on_integers(M, N, K, planes):
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w = _ints((M, K), g), _ints((N, K), g)
+    bias = torch.randint(-3, 4, (N,), generator=g).float()
+    ref = a.double() @ w.double().T + bias.double()
+    ap, wp = ops.plane_split(a.cuda(), planes), ops.plane_split(w.cuda(), planes)
+    for bn in (0, 128, 256):
+        ops.set_pgemm_tile_n(bn)
+        try:
+            c = ops.pgemm_nt(ap, wp, bias=bias.cuda())
+        finally:
+            ops.set_pgemm_tile_n(0)
+        assert c.dtype == torch.float32 and torch.equal(c.cpu().double(), ref), f"tile width {bn}"
+    # the operand of the dgrad products: planes of the transposed weight
+    wt = ops.plane_split(w.T.contiguous().cuda(), planes, transposed=True)
+    assert torch.equal(ops.pgemm_nt(ap, wt).cpu().double(), a.double() @ w.double().T)
+    if N % 16 == 0:
+        cp, cs = ops.pgemm_nt(ap, wp, bias=bias.cuda(), out_planes=True, want_colsum=True)
+        assert torch.equal(cp.to_float().cpu().double(), ref)
+        assert torch.equal(cs.cpu().double(), ref.sum(0))
+        # a plane output is an operand: rows / columns of its padding must be zero (they enter the TN reduction)
+        z = ops.pgemm_tn(cp, ap)
+        assert torch.equal(z.cpu().double(), ref.T @ a.double())
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 272, 200), (2048, 384, 384), (1030, 1536, 384)])
+def test_nt_epilogues(M, N, K):
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(7)
+    a = torch.randn(M, K, generator=g) * 0.5
+    w = torch.randn(N, K, generator=g) * 0.05
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    pre_ref = a.double() @ w.double().T + bias.double()
+    ap, wp = ops.plane_split(a.cuda(), 3), ops.plane_split(w.cuda(), 3)
+    out = ops.pgemm_nt(ap, wp, bias=bias.cuda(), epilogue=ops.EPI_ADD, aux=res.cuda())
+    torch.testing.assert_close(out.cpu().double(), pre_ref + res.double(), rtol=1e-5, atol=1e-5)
+    f, dact = ops.pgemm_nt(ap, wp, bias=bias.cuda(), epilogue=ops.EPI_GELU, aux=True, out_planes=True)
+    torch.testing.assert_close(f.to_float().cpu().double(), torch.nn.functional.gelu(pre_ref), rtol=1e-5, atol=1e-5)
+    x = pre_ref.clone().requires_grad_()
+    torch.nn.functional.gelu(x).sum().backward()
+    torch.testing.assert_close(dact.cpu().double(), x.grad, rtol=1e-5, atol=1e-5)
+    d, cs = ops.pgemm_nt(ap, wp, epilogue=ops.EPI_GELU_BWD, aux=dact, out_planes=True, want_colsum=True)
+    dref = (a.double() @ w.double().T) * dact.cpu().double()
+    torch.testing.assert_close(d.to_float().cpu().double(), dref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(cs.cpu().double(), dref.sum(0), rtol=1e-4, atol=1e-4)
+    r = ops.pgemm_nt(ap, wp, bias=bias.cuda(), epilogue=ops.EPI_RELU)
+    torch.testing.assert_close(r.cpu().double(), pre_ref.clamp_min(0), rtol=1e-5, atol=1e-5)
+    rb = ops.pgemm_nt(ap, wp, epilogue=ops.EPI_RELU_BWD, aux=r)
+    torch.testing.assert_close(rb.cpu().double(), (a.double() @ w.double().T) * (r.cpu() > 0), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 256, 256), (100, 264, 520), (5000, 384, 384), (20000, 1152, 384), (3152, 384, 1536),
+                                   (6656, 1536, 384), (33, 16, 8), (1, 128, 128)])
+@pytest.mark.parametrize("planes", [3, 2])
+def test_tn_exact_on_integers(M, N, K, planes):
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    dy, x = _ints((M, N), g, -2, 3), _ints((M, K), g, -2, 3)
+    ref = dy.double().T @ x.double()
+    c = ops.pgemm_tn(ops.plane_split(dy.cuda(), planes), ops.plane_split(x.cuda(), planes))
+    assert torch.equal(c.cpu().double(), ref)
+
+
+def _operands(kind, M, N, K, g):
+    if kind == "normal":
+        return torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    if kind == "cancel":       # every inner product is a sum of large terms that cancel to O(1)
+        a = torch.randn(M, K, generator=g) * 100
+        a[:, 1::2] = -a[:, 0::2] + torch.randn(M, K // 2, generator=g) * 0.01
+        w = torch.randn(N, K, generator=g)
+        w[:, 1::2] = w[:, 0::2]
+        return a, w
+    # wide dynamic range: exponents spread over 2^+-20, per element
+    a = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-20, 21, (M, K), generator=g).float())
+    w = torch.randn(N, K, generator=g) * torch.exp2(torch.randint(-20, 21, (N, K), generator=g).float())
+    return a, w
+
+
+HEADLINE_SHAPES = [   # (N, K) of the ViT-S/8 block products, forward and input-gradient (rows M = tokens)
+    (1152, 384), (384, 384), (1536, 384), (384, 1536), (384, 1152), (384, 192)]
+
+
+@pytest.mark.parametrize("N,K", HEADLINE_SHAPES)
+@pytest.mark.parametrize("kind", ["normal", "cancel", "wide"])
+def test_fp32_grade_gate_nt(N, K, kind):
+    """max and RMS error of the 6-product plane GEMM against fp64 <= 1.5 x the native fp32 MFMA kernel's."""
+    from multimodal_supernovae_amd import ops
+    M = 2080                                             # 32 cutouts x 65 tokens: the error statistics do not depend on M
+    g = torch.Generator().manual_seed(N + K)
+    a, w = _operands(kind, M, N, K, g)
+    ref = a.double() @ w.double().T
+    c_nat = ops.sgemm(a.cuda(), w.cuda(), ops.OP_N, ops.OP_T, precision=ops.PREC_F32).cpu().double()
+    c_pl = ops.pgemm_nt(ops.plane_split(a.cuda(), 3), ops.plane_split(w.cuda(), 3)).cpu().double()
+    e_nat, e_pl = (c_nat - ref).abs(), (c_pl - ref).abs()
+    assert float(e_pl.max()) <= 1.5 * float(e_nat.max()) + 1e-30, (float(e_pl.max()), float(e_nat.max()))
+    assert float(e_pl.pow(2).mean().sqrt()) <= 1.5 * float(e_nat.pow(2).mean().sqrt()) + 1e-30
+
+
+@pytest.mark.parametrize("N,K", [(1152, 384), (384, 384), (1536, 384), (384, 1536)])
+@pytest.mark.parametrize("kind", ["normal", "cancel", "wide"])
+def test_fp32_grade_gate_tn(N, K, kind):
+    from multimodal_supernovae_amd import ops
+    M = 66560 // 8
+    g = torch.Generator().manual_seed(N * 3 + K)
+    # the reduction runs over the rows here: build the operands reduction-major
+    at, wt = _operands(kind, N, K, M, g)                 # (N, M), (K, M)
+    dy, x = at.T.contiguous(), wt.T.contiguous()
+    ref = dy.double().T @ x.double()
+    c_nat = ops.sgemm(dy.cuda(), x.cuda(), ops.OP_T, ops.OP_N, precision=ops.PREC_F32).cpu().double()
+    c_pl = ops.pgemm_tn(ops.plane_split(dy.cuda(), 3), ops.plane_split(x.cuda(), 3)).cpu().double()
+    e_nat, e_pl = (c_nat - ref).abs(), (c_pl - ref).abs()
+    assert float(e_pl.max()) <= 1.5 * float(e_nat.max()) + 1e-30, (float(e_pl.max()), float(e_nat.max()))
+    assert float(e_pl.pow(2).mean().sqrt()) <= 1.5 * float(e_nat.pow(2).mean().sqrt()) + 1e-30
