@@ -292,7 +292,23 @@ int msn_pgemm_nt(int64_t M, int N, int K, int planes, const void* A, const void*
 size_t msn_pgemm_tn_workspace_bytes(int64_t M, int N, int K, int planes);
 int msn_pgemm_tn(int64_t M, int N, int K, int planes, const void* A, const void* B, float* C, int64_t ldc, void* ws,
                  size_t ws_bytes, msn_stream_t stream);
+/* nn.LayerNorm as msn_layernorm_fwd / _bwd, writing the result as a plane matrix (the next product's operand): forward y
+ * (y_planes; y fp32 optional, may be NULL), backward dx (fp32 AND planes; dx_colsum nullable = column sums of dx, the bias
+ * gradient of the Linear below a residual add).  Workspace of the backward: msn_layernorm_bwd_workspace_bytes * 3 / 2. */
+int msn_layernorm_fwd_planes(const float* x, int64_t ldx, int64_t rows, int cols, const float* gamma, const float* beta,
+                             float eps, int planes, void* y_planes, float* y, int64_t ldy, float* mean, float* rstd,
+                             msn_stream_t stream);
+int msn_layernorm_bwd_planes(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t rows, int cols,
+                             const float* mean, const float* rstd, const float* gamma, const float* add, int64_t ldadd,
+                             float* dx, int64_t lddx, int planes, void* dx_planes, float* dgamma, float* dbeta,
+                             float* dx_colsum, void* ws, size_t ws_bytes, msn_stream_t stream);
 int msn_set_pgemm_tile_n(int bn);
+/* Wave layout of the 3-plane msn_pgemm_nt kernel (measurements; same results up to the summation order of the column
+ * sums): 0 = 2 x 4 waves, 1 = 4 x 2 (default), 3 / 4 = 0 / 1 with the LDS-DMA issue staggered between the two waves of a
+ * SIMD; + 1000 * c: K chunks of c K-steps (default 32).  Process-wide, not thread-safe (as every msn_set_* switch). */
+int msn_set_pgemm_variant(int v);
+/* Start skew of msn_pgemm_nt's persistent workgroups (shader cycles per phase, 0 = off; measurements). */
+int msn_set_pgemm_skew(int cycles);
 
 /* ------------------------------------------------------------------------------------------
  * bf16-RESIDENT products for BASELINE.json configs[4] (ViT-B/16 "bf16 on MFMA"; build-defined encoder, no reference

@@ -67,6 +67,12 @@ SIGNATURES = {
     "msn_pgemm_tn_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int]),
     "msn_pgemm_tn": (c_int, [c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_size, c_ptr]),
     "msn_set_pgemm_tile_n": (c_int, [c_int]),
+    "msn_layernorm_fwd_planes": (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_f32, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr,
+                                         c_ptr]),
+    "msn_layernorm_bwd_planes": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr,
+                                         c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "msn_set_pgemm_variant": (c_int, [c_int]),
+    "msn_set_pgemm_skew": (c_int, [c_int]),
     "msn_bgemm_nt": (c_int, [c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_i64,
                              c_ptr, c_ptr, c_size, c_ptr]),
     "msn_bgemm_nt_colsum_workspace_bytes": (c_size, [c_i64, c_int]),

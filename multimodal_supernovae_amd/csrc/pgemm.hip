@@ -41,6 +41,7 @@ namespace msn {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
@@ -61,7 +62,9 @@ struct PgemmArgs {
     int cbA, cbB;                   // column blocks of A / B (NT: both = K-steps)
     int cbC;                        // column blocks of a plane output
     int tiles_m, tiles_n, super_rows, epi;
+    int colsum_rows;                // NT: column-sum partial rows per tile row (= WM of the kernel's wave layout)
     int chunk_steps;                // NT: K-steps per chunk (0 = the whole reduction in one accumulation)
+    int skew;                       // NT: start delay unit in shader cycles (0 = none): workgroup b waits ((b >> 3) & 3) * skew
     float* colpart;                 // NT (nullable): [2 * tiles_m][N] column sums of the values written to C
     int splits;                     // TN: reduction split
     int rb_per_split;               // TN: row blocks per split
@@ -131,20 +134,31 @@ __device__ __forceinline__ void split_planes(float x, u16 (&pl)[NP]) {
 // accumulator with a truncating (biased) rounding -- unlike the fp32-input MFMA's round-to-nearest -- so every MFMA into a
 // LARGE accumulator costs a systematic ~1/18 ulp and the error of one accumulator grows like K^1.5 (measured: 5.4 x the
 // native kernel's at K = 1536 with all six products in one accumulator).  The p0.q0 products alone go to `acc`; the five
-// small products (<= 2^-8 of it) go to `acc2`, whose roundings are 2^-8 smaller; the epilogue adds the two in fp32.
-template <int NP, int BN, bool OUTP, bool DUAL>
-__global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(const PgemmArgs p) {
+// small products (<= 2^-8 of it) go to `acc2`, whose roundings are 2^-8 smaller; the epilogue adds the two in fp32.  With
+// that the error is 0.3 x the native kernel's up to K = 768; longer reductions are cut into K chunks of <= 512 columns whose
+// partial sums meet in C by fp32 adds (host: chunk_steps).  (The TN kernel instead folds the p0.q0 product in by VALU adds:
+// there the reduction is thousands of rows long.  The same fold on the NT kernel costs 11 % at K = 384 and leaves the
+// maximum error at K >= 1152 where chunks put it -- profiles/r04_pgemm_accuracy.txt.)
+// Wave layout WM x WN (rows x columns of the tile): 2 x 4 = eight waves of 128 x (BN / 4); 4 x 2 = eight waves of 64 x (BN / 2)
+// (12 instead of 15 fragment reads per 24 MFMAs on BN = 128: +7-12 %, the 3-plane default; four waves of 128 x 64 with the
+// whole register file each were 15-25 % slower).  STAG: the two waves of a SIMD issue their LDS-DMA pieces in different halves of a K-step
+// (waves 0-3 behind the first products, waves 4-7 behind the last ones) instead of both stalling in the same gaps.
+template <int NP, int BN, bool OUTP, bool DUAL, int WM = 2, int WN = 4, bool STAG = false>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(const PgemmArgs p) {
+    constexpr int NW = WM * WN;
     constexpr int ARB = BM / 32, BRB = BN / 32, AP = ARB * NP, BP = BRB * NP, PIECES = AP + BP;
     constexpr int SLOT = PIECES * PBLK;
-    constexpr int NSLOT = (4 * SLOT <= 160 * 1024) ? 4 : 3;
-    constexpr int MAXQ = (PIECES + 7) / 8;           // pieces per wave and K-step (the last one only for the low waves)
-    constexpr int MT = 4, NT = BN / 128;             // 32 x 32 MFMA tiles per wave: rows x columns
+    constexpr int STG = 6 * 1024;                    // epilogue staging per wave (one 32 x 32 tile: 4 KB fp32 / 6 plane images)
+    constexpr int NSLOT = (4 * SLOT + NW * STG <= 160 * 1024) ? 4 : 3;
+    static_assert(NSLOT * SLOT + NW * STG <= 160 * 1024, "LDS: ring + staging");
+    constexpr int MAXQ = (PIECES + NW - 1) / NW;     // pieces per wave and K-step (the last one only for the low waves)
+    constexpr int MT = 8 / WM, NT = BN / (32 * WN);  // 32 x 32 MFMA tiles per wave: rows x columns
     constexpr int NG = NP * (NP + 1) / 2;            // plane products per K-step
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSLOT * SLOT];
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSLOT * SLOT + NW * STG];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
     const int G = gridDim.x;
     const int total = p.tiles_m * p.tiles_n;
     const int nk = p.cbA;                            // K-steps per tile
@@ -175,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(const PgemmArgs p) {
     auto set_bases = [&]() {
 #pragma unroll
         for (int q = 0; q < MAXQ; ++q) {
-            const int id = wave + 8 * q;
+            const int id = wave + NW * q;
             if (id < AP) {
                 const int rb = min(p_tm * ARB + id / NP, p.rbA - 1);            // rows past the edge: clamped, never stored
                 pbase[q] = p.A + ((int64_t)rb * nk * NP + id % NP) * PBLK;
@@ -191,16 +205,31 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(const PgemmArgs p) {
 #ifdef MSN_ABL_PG_NODMA                      // diagnostic build (tools/microbench/build_ablate.sh): no operand traffic at all
         return;
 #endif
-        const int id = wave + 8 * q;
+        const int id = wave + NW * q;
         if (id < PIECES)
             __builtin_amdgcn_global_load_lds((gptr_t*)(pbase[q] + (int64_t)p_k * (NP * PBLK) + lane_src),
                                              (lptr_t*)(lds + p_slot * SLOT + id * PBLK), 16, 0, 0);
     };
-    auto issue_chunk = [&](auto c_) {                // chunk c of NG: pieces [c MAXQ / NG, (c + 1) MAXQ / NG)
+    // gap c of NG (behind the c-th plane product of a K-step): pieces [c MAXQ / NG, (c + 1) MAXQ / NG); STAG: the low waves
+    // issue theirs in the gaps 0 .. HG - 1, the high waves in HG .. NG - 2 (none behind the barrier: the counted wait stays
+    // the same for both halves)
+    constexpr int HG = (NG - 1) / 2;
+    const bool hi_half = wave >= NW / 2;
+    auto issue_chunk = [&](auto c_) {
         constexpr int c = decltype(c_)::value;
         if (p_live) {
+            if constexpr (STAG) {
+                if (c < HG && !hi_half) {
 #pragma unroll
-            for (int q = c * MAXQ / NG; q < (c + 1) * MAXQ / NG; ++q) issue_q(q);
+                    for (int q = c * MAXQ / HG; q < (c + 1) * MAXQ / HG; ++q) issue_q(q);
+                } else if (c >= HG && c < NG - 1 && hi_half) {
+#pragma unroll
+                    for (int q = (c - HG) * MAXQ / (NG - 1 - HG); q < (c - HG + 1) * MAXQ / (NG - 1 - HG); ++q) issue_q(q);
+                }
+            } else {
+#pragma unroll
+                for (int q = c * MAXQ / NG; q < (c + 1) * MAXQ / NG; ++q) issue_q(q);
+            }
         }
     };
     auto advance = [&]() {                           // producer -> next global K-step
@@ -213,14 +242,14 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(const PgemmArgs p) {
         }
     };
     // pieces of this wave issued by the chunks 0 .. NG - 2 of one K-step (all waves own every piece q < MAXQ - 1)
-    constexpr int Q_BEFORE = (NG - 1) * MAXQ / NG;
-    const int ppw = (wave + 8 * (MAXQ - 1) < PIECES) ? MAXQ : MAXQ - 1;      // pieces of this wave per K-step
+    constexpr int Q_BEFORE = STAG ? MAXQ : (NG - 1) * MAXQ / NG;
+    const int ppw = (wave + NW * (MAXQ - 1) < PIECES) ? MAXQ : MAXQ - 1;      // pieces of this wave per K-step
 
     // ---- fragments
     const int frow = lane & 31, fhalf = lane >> 5;
     const unsigned frag_lane = (unsigned)(frow * 32 + 16 * (fhalf ^ ((frow >> 3) & 1)));
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t*)lds;
-    const unsigned fragA = lds0 + frag_lane + (unsigned)(wm * 4 * NP * PBLK);                   // + (i * NP + plane) KB
+    const unsigned fragA = lds0 + frag_lane + (unsigned)(wm * MT * NP * PBLK);                   // + (i * NP + plane) KB
     const unsigned fragB = lds0 + frag_lane + (unsigned)((AP + wn * NT * NP) * PBLK);           // + (j * NP + plane) KB
 
     f32x16 acc[MT][NT], acc2[DUAL ? MT : 1][DUAL ? NT : 1];
@@ -277,9 +306,9 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(const PgemmArgs p) {
     int c_slot = 0;                                  // slot of the consumer's current K-step
     // One K-step; PAR = parity of the step inside its tile (a tile has an EVEN number of K-steps: the plane format pads K).
     // On entry outstanding LDS reads, oldest first: A0 (MT), B0 (NT), B1 .. B_{NP-1} (NT each).  The first fragments of the
-    // next K-step -- the next tile's first one at the end of a tile: the ring runs on -- are requested before this step's
-    // last product (past the workgroup's last step they read whatever the slot holds, into registers nobody uses).
-    auto step = [&](auto par_) {
+    // next K-step are requested before this step's last product; behind the last step of a tile (or of a K chunk) the
+    // epilogue requests them once it is done -- the ring of K-steps itself runs on across tiles.
+    auto step = [&](auto par_, bool last = false) {
         constexpr int PAR = decltype(par_)::value;
         constexpr int QA = (NP & 1) ? PAR : 0;       // fa buffer of plane 0; plane pa sits in fa[(QA + pa) & 1]
         const unsigned cur = (unsigned)(c_slot * SLOT);
@@ -313,12 +342,13 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(const PgemmArgs p) {
         });
         // every fragment of this K-step is in registers -> its slot may be refilled; the next K-step must have landed
         wait_lgkm<0>();
-        wait_vm(p_was_live ? (NSLOT - 3) * ppw + Q_BEFORE : 0);
+        wait_vm(p_was_live ? (NSLOT - 3) * ppw + (STAG ? ppw : Q_BEFORE) : 0);
 #ifndef MSN_ABL_PG_NOBAR
         __builtin_amdgcn_s_barrier();
 #endif
         __builtin_amdgcn_sched_barrier(0);
-        req_first(fa[(QA + NP) & 1], fb0[PAR ^ 1], nxt);
+        // (not behind a tile's or a K chunk's last step: the epilogue wants the registers -- it requests them when it is done)
+        if (!last) req_first(fa[(QA + NP) & 1], fb0[PAR ^ 1], nxt);
         __builtin_amdgcn_sched_barrier(0);
         mult(fa[(QA + NP - 1) & 1], fb0[PAR], SML{});
         issue_chunk(std::integral_constant<int, NG - 1>{});
@@ -328,95 +358,219 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(const PgemmArgs p) {
     };
 
     // ---- epilogue: lane holds, per (i, j) tile, row m = 32 i + (lane & 31) and columns n = 32 j + 8 b + 4 (lane >> 5) + r
+    // ---- epilogue.  The accumulator layout (lane = one row, 4 consecutive columns) is the wrong shape for memory: a 16-byte
+    // store per lane touches 32 different 128-byte lines per wave instruction and the address coalescer, not HBM, bounds the
+    // epilogue (64 such instructions per wave for a GELU tile: +320 us on a 470-us product).  Every 32 x 32 MFMA tile therefore
+    // goes through a per-wave LDS staging area (6 KB behind the ring) and leaves -- or enters, for the matrices an epilogue
+    // reads -- in memory order: fp32 as 8 rows x 128 bytes per instruction, planes as whole 1-KB block images.
     // MODE 0: the tile's result.  MODE 1: the tile's result when earlier K chunks left a partial sum in C (added first).
     // MODE 2 / 3: a K chunk's partial sum -> C (first chunk) / C += (later chunks); no bias, no epilogue (fp32 outputs only).
+    const unsigned stg = lds0 + (unsigned)(NSLOT * SLOT + wave * STG);
+    // fp32 image of a tile: [32 rows][128 B], 16-byte chunk c of row r at position c ^ (r & 7) (conflict-free both ways)
+    const unsigned st_acc = stg + (unsigned)(frow * 128);                       // + ((2 b + fhalf) ^ (frow & 7)) * 16
+    const int srow = lane >> 3, schunk = lane & 7;                              // memory order: pass q -> row 8 q + srow
+    const unsigned st_mem = stg + (unsigned)(srow * 128 + ((schunk ^ srow) * 16));   // + q * 1024   ((8 q + srow) & 7 == srow)
+    auto lds_w128 = [&](unsigned addr, const float (&v)[4]) {
+        asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(*reinterpret_cast<const f32x4*>(v)) : "memory");
+    };
+    auto lds_r128 = [&](f32x4& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory"); };
+    // a 32 x 32 fp32 tile of a matrix the epilogue READS (residual / saved activation derivative / K-chunk partial):
+    // tile_fetch issues its four 16-byte loads per lane in memory order (for EVERY tile of the wave before the first is used:
+    // one exposed memory latency per output tile instead of one per MFMA tile), tile_take turns one through the staging
+    // area into the accumulator layout a[4 b + r]
+    auto tile_fetch = [&](const float* src, int64_t ld, int64_t m0, int n0, f32x4 (&t)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t m = m0 + 8 * q + srow;
+            const int n = n0 + 4 * schunk;
+            t[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (m < p.M && n < p.N) t[q] = *reinterpret_cast<const f32x4*>(src + m * ld + n);
+        }
+    };
+    auto tile_take = [&](const f32x4 (&t)[4], float (&a)[16]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("ds_write_b128 %0, %1" ::"v"(st_mem + q * 1024), "v"(t[q]) : "memory");
+        f32x4 r[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) lds_r128(r[b], st_acc + (unsigned)(((2 * b + fhalf) ^ (frow & 7)) * 16));
+        // the wait names the registers it guards: the compiler may otherwise move a copy of them above it (it believes the
+        // asm that issued the read has already defined them)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3])::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[4 * b + e] = r[b][e];
+    };
+    // accumulator layout -> rows m0.., columns n0.. of `dst` in memory order: stage_chunk(b, 4 values) four times, then flush
+    auto stage_chunk = [&](int b, const float (&w)[4]) { lds_w128(st_acc + (unsigned)(((2 * b + fhalf) ^ (frow & 7)) * 16), w); };
+    auto tile_flush = [&](float* dst, int64_t ld, int64_t m0, int n0) {
+        f32x4 r[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lds_r128(r[q], st_mem + q * 1024);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3])::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t m = m0 + 8 * q + srow;
+            const int n = n0 + 4 * schunk;
+            if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(dst + m * ld + n) = r[q];
+        }
+    };
     auto store_tile_epi = [&](int tm, int tn, auto epi_, auto mode_) {
         constexpr int epi = decltype(epi_)::value;
-        constexpr int MODE = decltype(mode_)::value;
-        constexpr bool PARTIAL = MODE >= 2, ADDC = MODE == 1 || MODE == 3;
-        const int64_t mrow0 = (int64_t)tm * BM + wm * 128 + frow;
-        const int ncol0 = tn * BN + wn * (BN / 4) + 4 * fhalf;
+        constexpr int MODE = decltype(mode_)::value & 3;
+        constexpr bool CS = (decltype(mode_)::value & 4) != 0;    // column sums of the stored values -> p.colpart
+        constexpr bool PARTIAL = MODE >= 2, ADDC = (MODE == 1 || MODE == 3) && !OUTP;
+        constexpr bool AUXIN = !PARTIAL && (epi == MSN_EPI_RELU_BWD || epi == MSN_EPI_GELU_BWD || epi == MSN_EPI_ADD);
+        // everything the epilogue reads, requested up front: the K-chunk partial if there is one, else the aux matrix
+        if constexpr (DUAL) {      // the two accumulator sets meet here (one round-to-nearest add); acc2's registers are free from now on
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int n = ncol0 + 32 * j + 8 * b;
-                if (n >= p.N) continue;                           // N % 4 == 0 (host): n < N <=> n + 3 < N
-                const float4 bias4 = (!PARTIAL && p.bias) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-                float cs[4] = {0.f, 0.f, 0.f, 0.f};               // column sums over this wave's 128 rows
+                for (int j = 0; j < NT; ++j) acc[i][j] += acc2[i][j];
+        }
+        constexpr bool PRE = ADDC || AUXIN;
+        constexpr int PW = (DUAL || MT * NT < 2) ? MT * NT : 2;          // tiles requested ahead (16 registers each)
+        f32x4 pre[PRE ? PW : 1][4];
+        const float* pre_src = ADDC ? static_cast<const float*>(p.C) : p.aux;
+        const int64_t pre_ld = ADDC ? p.ldc : p.ldaux;
+        auto pre_fetch = [&](auto t_) {                            // tile t = j * MT + i of this wave -> pre[t % PW]
+            constexpr int t = decltype(t_)::value;
+            if constexpr (PRE && t < MT * NT)
+                tile_fetch(pre_src, pre_ld, (int64_t)tm * BM + wm * (32 * MT) + 32 * (t % MT), tn * BN + wn * (32 * NT) + 32 * (t / MT),
+                           pre[t % PW]);
+        };
+        static_for<0, PW>([&](auto t_) { pre_fetch(t_); });
+        static_for<0, NT>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            const int n0 = tn * BN + wn * (32 * NT) + 32 * j;
+            float cs[CS ? 16 : 1];                                 // column sums over this wave's rows, accumulator layout
 #pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const int64_t m = mrow0 + 32 * i;
-                    const bool row_ok = m < p.M;
-                    if (!OUTP && !row_ok) continue;
-                    const int rbk = tm * ARB + wm * 4 + i;        // row block of a plane output (it has the rows of A)
-                    if (OUTP && rbk >= p.rbA) continue;
-                    float v[4];
+            for (int e = 0; e < (CS ? 16 : 1); ++e) cs[e] = 0.f;
+            static_for<0, MT>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                constexpr int t = j * MT + i;
+                const int64_t m0 = (int64_t)tm * BM + wm * (32 * MT) + 32 * i;
+                const int rbk = tm * ARB + wm * MT + i;           // row block of a plane output (it has the rows of A)
+                const bool live = n0 < p.N && (OUTP ? rbk < p.rbA : m0 < p.M);      // (wave-uniform)
+                if (!live) {
+                    pre_fetch(std::integral_constant<int, t + PW>{});
+                    return;
+                }
+                const bool row_ok = m0 + frow < p.M;
+                float v[16];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        v[r] = acc[i][j][4 * b + r];
-                        if constexpr (DUAL) v[r] += acc2[i][j][4 * b + r];
-                    }
-                    if constexpr (ADDC && !OUTP) {
-                        if (row_ok) {
-                            const float4 c0 = *reinterpret_cast<const float4*>(static_cast<const float*>(p.C) + m * p.ldc + n);
-                            v[0] += c0.x; v[1] += c0.y; v[2] += c0.z; v[3] += c0.w;
+                for (int e = 0; e < 16; ++e) v[e] = acc[i][j][e];
+                if constexpr (ADDC) {
+                    float c0[16];
+                    tile_take(pre[t % PW], c0);
+                    pre_fetch(std::integral_constant<int, t + PW>{});
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] += c0[e];
+                }
+                if (!PARTIAL && p.bias) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int n = n0 + 8 * b + 4 * fhalf;
+                        if (n < p.N) {
+                            const float4 t = *reinterpret_cast<const float4*>(p.bias + n);
+                            v[4 * b] += t.x; v[4 * b + 1] += t.y; v[4 * b + 2] += t.z; v[4 * b + 3] += t.w;
                         }
                     }
-                    v[0] += bias4.x; v[1] += bias4.y; v[2] += bias4.z; v[3] += bias4.w;
-                    if (row_ok) {
-                        if constexpr (PARTIAL) {
-                        } else if constexpr (epi == MSN_EPI_GELU) {
-                            if (p.aux) {
-                                *reinterpret_cast<float4*>(p.aux + m * p.ldaux + n) =
-                                    make_float4(gelu_grad_f(v[0]), gelu_grad_f(v[1]), gelu_grad_f(v[2]), gelu_grad_f(v[3]));
-                            }
+                }
+                if constexpr (!PARTIAL && epi == MSN_EPI_GELU) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
-                        } else if constexpr (epi == MSN_EPI_RELU) {
+                    for (int b = 0; b < 4; ++b) {
+                        float dg[4];
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                        } else if constexpr (epi != MSN_EPI_NONE) {
-                            const float4 a = *reinterpret_cast<const float4*>(p.aux + m * p.ldaux + n);
-                            if constexpr (epi == MSN_EPI_GELU_BWD) { v[0] *= a.x; v[1] *= a.y; v[2] *= a.z; v[3] *= a.w; }
-                            else if constexpr (epi == MSN_EPI_RELU_BWD) {
-                                v[0] = a.x > 0.f ? v[0] : 0.f; v[1] = a.y > 0.f ? v[1] : 0.f;
-                                v[2] = a.z > 0.f ? v[2] : 0.f; v[3] = a.w > 0.f ? v[3] : 0.f;
-                            } else { v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; }     // MSN_EPI_ADD
-                        }
+                        for (int r = 0; r < 4; ++r) gelu_both(v[4 * b + r], v[4 * b + r], dg[r]);
+                        if (p.aux) stage_chunk(b, dg);
+                    }
+                    if (p.aux) tile_flush(p.aux, p.ldaux, m0, n0);
+                } else if constexpr (!PARTIAL && epi == MSN_EPI_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if constexpr (!PARTIAL && epi != MSN_EPI_NONE) {
+                    float a[16];
+                    if constexpr (ADDC) {                              // (both a partial and an aux matrix: the aux tile comes now)
+                        f32x4 t[4];
+                        tile_fetch(p.aux, p.ldaux, m0, n0, t);
+                        tile_take(t, a);
                     } else {
-                        v[0] = v[1] = v[2] = v[3] = 0.f;          // padding rows of a plane output are zero
+                        tile_take(pre[t % PW], a);
+                        pre_fetch(std::integral_constant<int, t + PW>{});
                     }
-                    if constexpr (OUTP) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        if constexpr (epi == MSN_EPI_GELU_BWD) v[e] *= a[e];
+                        else if constexpr (epi == MSN_EPI_RELU_BWD) v[e] = a[e] > 0.f ? v[e] : 0.f;
+                        else v[e] += a[e];                         // MSN_EPI_ADD
+                    }
+                }
+                if (!row_ok) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = 0.f;       // padding rows of a plane output are zero
+                }
+                if constexpr (OUTP) {
+                    // planes -> the 2 * NP block images of this tile ([32 rows][16 bf16] each, as they lie in HBM) -> 1-KB stores
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
                         u16 pl[4][NP];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) split_planes<NP>(v[r], pl[r]);
-                        unsigned char* dst = static_cast<unsigned char*>(p.C) + ((int64_t)rbk * p.cbC + (n >> 4)) * (NP * PBLK) +
-                                             frow * 32 + (n & 15) * 2;
+                        for (int r = 0; r < 4; ++r) split_planes<NP>(v[4 * b + r], pl[r]);
 #pragma unroll
                         for (int k = 0; k < NP; ++k) {
                             uint2 o;
                             o.x = pl[0][k] | ((unsigned)pl[1][k] << 16);
                             o.y = pl[2][k] | ((unsigned)pl[3][k] << 16);
-                            *reinterpret_cast<uint2*>(dst + k * PBLK) = o;
+                            asm volatile("ds_write_b64 %0, %1" ::"v"(stg + (unsigned)((((b >> 1) * NP + k) * PBLK) + frow * 32 + (8 * (b & 1) + 4 * fhalf) * 2)), "v"(o) : "memory");
                         }
-                    } else {
-                        *reinterpret_cast<float4*>(static_cast<float*>(p.C) + m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
                     }
-                    cs[0] += v[0]; cs[1] += v[1]; cs[2] += v[2]; cs[3] += v[3];
+                    f32x4 img[2 * NP];
+#pragma unroll
+                    for (int q = 0; q < 2 * NP; ++q) lds_r128(img[q], stg + (unsigned)(q * PBLK + lane * 16));
+                    if constexpr (NP == 3)
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(img[0]), "+v"(img[1]), "+v"(img[2]), "+v"(img[3]), "+v"(img[4]), "+v"(img[5])::"memory");
+                    else
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(img[0]), "+v"(img[1]), "+v"(img[2]), "+v"(img[3])::"memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    unsigned char* blk = static_cast<unsigned char*>(p.C) + ((int64_t)rbk * p.cbC + (n0 >> 4)) * (NP * PBLK) + lane * 16;
+#pragma unroll
+                    for (int q = 0; q < 2 * NP; ++q)
+                        if (n0 + 16 * (q / NP) < p.N) *reinterpret_cast<f32x4*>(blk + q * PBLK) = img[q];
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const float w[4] = {v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]};
+                        stage_chunk(b, w);
+                    }
+                    tile_flush(static_cast<float*>(p.C), p.ldc, m0, n0);
                 }
-                if (!PARTIAL && p.colpart) {   // the 32 lanes sharing lane >> 5 hold the 32 rows of every row tile: xor tree, one lane writes
+                if constexpr (CS) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float t = cs[r];
+                    for (int e = 0; e < 16; ++e) cs[e] += v[e];
+                }
+            });
+            if constexpr (CS) {   // the 32 lanes sharing lane >> 5 hold the 32 rows of every row tile: xor tree, one lane writes
 #pragma unroll
-                        for (int o = 1; o < 32; o <<= 1) t += __shfl_xor(t, o, 64);
-                        cs[r] = t;
+                for (int e = 0; e < 16; ++e) {
+                    float t = cs[e];
+#pragma unroll
+                    for (int o = 1; o < 32; o <<= 1) t += __shfl_xor(t, o, 64);
+                    cs[e] = t;
+                }
+                if (frow == 0) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int n = n0 + 8 * b + 4 * fhalf;
+                        if (n < p.N)
+                            *reinterpret_cast<float4*>(p.colpart + (int64_t)(WM * tm + wm) * p.N + n) =
+                                make_float4(cs[4 * b], cs[4 * b + 1], cs[4 * b + 2], cs[4 * b + 3]);
                     }
-                    if (frow == 0)
-                        *reinterpret_cast<float4*>(p.colpart + (int64_t)(2 * tm + wm) * p.N + n) = make_float4(cs[0], cs[1], cs[2], cs[3]);
                 }
             }
+        });
     };
     auto store_tile = [&](int tm, int tn, auto mode_) {
         switch (p.epi) {
@@ -440,6 +594,17 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(const PgemmArgs p) {
                 }
     };
 
+    // ---- start skew: equal tiles keep the workgroups of a launch in lockstep -- all in their K loops (HBM idle), then all in
+    // their epilogues (matrix cores idle, HBM write-bound).  Four start phases a quarter tile apart spread the epilogues'
+    // stores over the others' K loops; workgroups with one tile fewer than the rest have the slack for it.
+    if (p.skew > 0) {
+        const int phase = (blockIdx.x >> 3) & 3;
+        const int mine = (total - (int)blockIdx.x + G - 1) / G, most = (total + G - 1) / G;
+        if (phase && (mine < most || p.skew < 0x40000000)) {
+            const long long until = (long long)__builtin_readcyclecounter() + (long long)phase * (p.skew & 0x3fffffff);
+            while ((long long)__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(32);
+        }
+    }
     // ---- prologue: K-steps 0 .. NSLOT - 2 of the stream
 #pragma unroll
     for (int s = 0; s < NSLOT - 1; ++s) {
@@ -467,22 +632,24 @@ __global__ __launch_bounds__(512, 2) void pgemm_nt_kernel(const PgemmArgs p) {
         for (; k0 + csteps < nk; k0 += csteps) {
             for (int k = 0; k < csteps; k += 2) {
                 step(T0{});
-                step(T1{});
+                step(T1{}, k + 2 >= csteps);
             }
             wait_lgkm<0>();
             if (k0 == 0) store_tile_epi(tm, tn, std::integral_constant<int, MSN_EPI_NONE>{}, std::integral_constant<int, 2>{});
             else store_tile_epi(tm, tn, std::integral_constant<int, MSN_EPI_NONE>{}, std::integral_constant<int, 3>{});
             zero_acc();
+            req_first(fa[0], fb0[0], (unsigned)(c_slot * SLOT));
         }
         for (int k = k0; k < nk; k += 2) {           // nk is even (plane format)
             step(T0{});
-            step(T1{});
+            step(T1{}, k + 2 >= nk);
         }
-        // the epilogue is compiler-scheduled code under register pressure: the fragments requested for the next tile must
-        // be IN their registers before it may move them
         wait_lgkm<0>();
-        if (k0 == 0) store_tile(tm, tn, std::integral_constant<int, 0>{});
-        else store_tile(tm, tn, std::integral_constant<int, 1>{});
+        if (k0 != 0) store_tile(tm, tn, std::integral_constant<int, 1>{});
+        else if (p.colpart) store_tile(tm, tn, std::integral_constant<int, 4>{});
+        else store_tile(tm, tn, std::integral_constant<int, 0>{});
+        // the next tile's first fragments (past the workgroup's last tile: whatever the slot holds, into registers nobody uses)
+        req_first(fa[0], fb0[0], (unsigned)(c_slot * SLOT));
     }
 }
 
@@ -614,6 +781,36 @@ __global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(const PgemmArgs p) {
             ds_read_tr_o<(2 * jj * NP + pl) * 512>(dst[jj][1], fragQ1 + slot_off);
         });
     };
+    auto mfma1 = [&](const bf16x8& av, const bf16x8& bv, const f32x16& c) -> f32x16 {
+        if constexpr (SWAP) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, c, 0, 0, 0);
+    };
+    // DUAL: zero-accumulator MFMA + round-to-nearest fold of the p0.q0 product (see pgemm_nt_kernel)
+    f32x16 tbig[2];
+    auto fold = [&](auto v_) {
+        constexpr int v = decltype(v_)::value;
+        acc[v / NT][v % NT] += tbig[v & 1];
+        asm volatile("" : "+v"(acc[v / NT][v % NT]));
+    };
+    auto mult_big = [&](const bf16x4 (&a)[MT][2], const bf16x4 (&b)[NT][2]) {
+        static_for<0, MT * NT>([&](auto u_) {
+            constexpr int u = decltype(u_)::value;
+            if constexpr (u >= 2) fold(std::integral_constant<int, u - 2>{});
+            f32x16 z;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) z[e] = 0.f;
+            const bf16x8 av = __builtin_shufflevector(a[u / NT][0], a[u / NT][1], 0, 1, 2, 3, 4, 5, 6, 7);
+            const bf16x8 bv = __builtin_shufflevector(b[u % NT][0], b[u % NT][1], 0, 1, 2, 3, 4, 5, 6, 7);
+            tbig[u & 1] = mfma1(av, bv, z);
+            asm volatile("" : "+v"(tbig[u & 1]));
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto fold_pending = [&]() {
+        fold(std::integral_constant<int, MT * NT - 2>{});
+        fold(std::integral_constant<int, MT * NT - 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+    };
     auto mult = [&](const bf16x4 (&a)[MT][2], const bf16x4 (&b)[NT][2], auto small_) {
         constexpr bool SMALL = decltype(small_)::value && DUAL;
 #pragma unroll
@@ -622,13 +819,8 @@ __global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(const PgemmArgs p) {
             for (int jj = 0; jj < NT; ++jj) {
                 const bf16x8 av = __builtin_shufflevector(a[i][0], a[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
                 const bf16x8 bv = __builtin_shufflevector(b[jj][0], b[jj][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                if constexpr (SMALL) {
-                    if constexpr (SWAP) acc2[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc2[i][jj], 0, 0, 0);
-                    else acc2[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, acc2[i][jj], 0, 0, 0);
-                } else {
-                    if constexpr (SWAP) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][jj], 0, 0, 0);
-                    else acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, acc[i][jj], 0, 0, 0);
-                }
+                if constexpr (SMALL) acc2[i][jj] = mfma1(av, bv, acc2[i][jj]);
+                else acc[i][jj] = mfma1(av, bv, acc[i][jj]);
             }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -655,8 +847,13 @@ __global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(const PgemmArgs p) {
                 req_a(fa[QA ^ 1], cur, std::integral_constant<int, 1>{});
                 wait_lgkm<2 * MT>();
             }
-            if constexpr (pb == 0) mult(fa[QA], fb0[PAR], BIG{});
-            else mult(fa[QA], fbh[pb - 1], SML{});
+            if constexpr (pb == 0) {
+                if constexpr (DUAL) mult_big(fa[QA], fb0[PAR]);
+                else mult(fa[QA], fb0[PAR], BIG{});
+            } else {
+                mult(fa[QA], fbh[pb - 1], SML{});
+                if constexpr (DUAL && pb == 1) fold_pending();
+            }
             issue_chunk(std::integral_constant<int, pb>{});
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -882,6 +1079,20 @@ static bool aligned16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) &
 using namespace msn;
 
 static int g_pgemm_bn = 0;          // 0 = planned, 128 / 256 forced (measurements)
+static int g_pgemm_skew = 0;        // NT start skew (shader cycles per phase; experiments)
+extern "C" int msn_set_pgemm_skew(int cycles) {
+    g_pgemm_skew = cycles;
+    return MSN_OK;
+}
+static int g_pgemm_chunk = 0;       // K-steps per chunk of the 3-plane NT kernel (0 = whole reduction; experiments)
+static int g_pgemm_variant = 1;     // 3-plane NT kernel: 0 = 2 x 4 waves, 1 = 4 x 2 (default), 3 / 4 = 0 / 1 with staggered DMA issue
+extern "C" int msn_set_pgemm_variant(int v) {
+    MSN_REQUIRE(v >= 0 && v <= 4 + 1000 * 1000, "msn_set_pgemm_variant: 0 .. 4 (+ 1000 * K-steps per chunk)");
+    g_pgemm_chunk = v / 1000;
+    v %= 1000;
+    g_pgemm_variant = v;
+    return MSN_OK;
+}
 extern "C" int msn_set_pgemm_tile_n(int bn) {
     MSN_REQUIRE(bn == 0 || bn == 128 || bn == 256, "msn_set_pgemm_tile_n: 0, 128 or 256");
     g_pgemm_bn = bn;
@@ -945,13 +1156,13 @@ extern "C" int msn_plane_merge(const void* planes_in, int planes, int64_t R, int
 
 extern "C" size_t msn_pgemm_nt_colsum_workspace_bytes(int64_t M, int N) {
     if (M <= 0 || N <= 0) return 0;
-    return sizeof(float) * 2 * (size_t)cdiv(M, BM) * (size_t)N;
+    return sizeof(float) * 4 * (size_t)cdiv(M, BM) * (size_t)N;          // up to 4 wave rows per tile row
 }
 
-template <int NP, int BN, bool DUAL>
+template <int NP, int BN, bool DUAL, int WM = 2, int WN = 4, bool STAG = false>
 static void launch_nt(const PgemmArgs& a, bool outp, int grid, hipStream_t st) {
-    if (outp) hipLaunchKernelGGL((pgemm_nt_kernel<NP, BN, true, DUAL>), dim3((unsigned)grid), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((pgemm_nt_kernel<NP, BN, false, DUAL>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    if (outp) hipLaunchKernelGGL((pgemm_nt_kernel<NP, BN, true, DUAL, WM, WN, STAG>), dim3((unsigned)grid), dim3(64 * WM * WN), 0, st, a);
+    else hipLaunchKernelGGL((pgemm_nt_kernel<NP, BN, false, DUAL, WM, WN, STAG>), dim3((unsigned)grid), dim3(64 * WM * WN), 0, st, a);
 }
 
 extern "C" int msn_pgemm_nt(int64_t M, int N, int K, int planes, const void* A, const void* B, void* C, int64_t ldc,
@@ -974,20 +1185,23 @@ extern "C" int msn_pgemm_nt(int64_t M, int N, int K, int planes, const void* A, 
     a.cbA = a.cbB = 2 * (int)cdiv(K, 32);
     a.cbC = 2 * (int)cdiv(N, 32);
     a.epi = epilogue;
-    // tile width: 128 when that wastes fewer columns than 256 (N = 384 -> 3 x 128, N = 1152 -> 9 x 128); the 3-plane
-    // (fp32-grade) form always takes 128: it carries two accumulator sets (see the kernel), which fill the register file
-    int bn = g_pgemm_bn;
-    if (!bn) bn = (cdiv(N, 256) * 256 - N >= 128 || N <= 128) ? 128 : 256;
-    if (planes == 3) bn = 128;
+    // tile width 128: the 3-plane form carries two accumulator sets (see the kernel), which fill the register file at 256 x 128;
+    // the 2-plane form measured faster at 128 than at 256 on every headline shape (profiles/r04_pgemm_variants.txt), so the
+    // 256-wide instantiation is only built on request (msn_set_pgemm_tile_n(256), measurements)
+    int bn = (g_pgemm_bn == 256 && planes == 2) ? 256 : 128;
     a.tiles_m = (int)cdiv(M, BM); a.tiles_n = (int)cdiv(N, bn);
     // super-rows: tile-rows walked together while their A panels (256 rows x K x 2 NP bytes) fit half an L2
     a.super_rows = (int)std::max<int64_t>(1, std::min<int64_t>(8, (2 << 20) / ((int64_t)BM * K * 2 * planes)));
     // fp32 grade: reductions longer than 768 columns are cut into chunks of at most 512 (the partial sums meet in C by fp32 adds)
     a.chunk_steps = 0;
-    if (planes == 3 && !c_planes && a.cbA > 48) {
-        const int nch = (int)cdiv(a.cbA, 32);
-        a.chunk_steps = 2 * (int)cdiv(a.cbA, 2 * nch);
+    {
+        const int cs = g_pgemm_chunk > 0 ? g_pgemm_chunk : 32;         // K-steps per chunk (msn_set_pgemm_variant: experiments)
+        if (planes == 3 && !c_planes && a.cbA > std::max(cs, 48)) {
+            const int nch = (int)cdiv(a.cbA, cs);
+            a.chunk_steps = 2 * (int)cdiv(a.cbA, 2 * nch);
+        }
     }
+    a.skew = g_pgemm_skew;
     a.colpart = nullptr;
     if (colsum_out) {
         const size_t need = msn_pgemm_nt_colsum_workspace_bytes(M, N);
@@ -997,12 +1211,19 @@ extern "C" int msn_pgemm_nt(int64_t M, int N, int K, int planes, const void* A, 
     const int total = a.tiles_m * a.tiles_n;
     const int grid = std::min(total, 256);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (planes == 3) launch_nt<3, 128, true>(a, c_planes != 0, grid, st);
-    else if (bn == 256) launch_nt<2, 256, false>(a, c_planes != 0, grid, st);
+    if (planes == 3) {
+        a.colsum_rows = g_pgemm_variant == 1 || g_pgemm_variant == 4 ? 4 : 2;
+        switch (g_pgemm_variant) {
+            case 0: launch_nt<3, 128, true>(a, c_planes != 0, grid, st); break;
+            case 3: launch_nt<3, 128, true, 2, 4, true>(a, c_planes != 0, grid, st); break;
+            case 4: launch_nt<3, 128, true, 4, 2, true>(a, c_planes != 0, grid, st); break;
+            default: launch_nt<3, 128, true, 4, 2>(a, c_planes != 0, grid, st); break;
+        }
+    } else if (bn == 256) launch_nt<2, 256, false>(a, c_planes != 0, grid, st);
     else launch_nt<2, 128, false>(a, c_planes != 0, grid, st);
     MSN_LAUNCH_CHECK();
     if (colsum_out) {
-        hipLaunchKernelGGL(pcolsum_finish_kernel, dim3((unsigned)cdiv(N, 64)), dim3(256), 0, st, a.colpart, 2 * a.tiles_m, N, colsum_out);
+        hipLaunchKernelGGL(pcolsum_finish_kernel, dim3((unsigned)cdiv(N, 64)), dim3(256), 0, st, a.colpart, (a.colsum_rows ? a.colsum_rows : 2) * a.tiles_m, N, colsum_out);
         MSN_LAUNCH_CHECK();
     }
     return MSN_OK;
@@ -1025,9 +1246,6 @@ TnPlan tn_plan(int64_t M, int N, int K, int planes) {
     const int rbs = (int)cdiv(M, 32);
     int s = std::max(1, 256 / tiles);                 // enough workgroups for the 256 CUs (one 144-KB workgroup per CU)
     s = std::min(s, rbs);
-    // fp32 grade: at most 2048 reduction rows per accumulator (the bf16 MFMA's biased rounding grows like K^1.5; the slab
-    // sums are round-to-nearest fp32 adds)
-    if (planes == 3) s = std::max<int>(s, (int)cdiv(rbs, 64));
     t.rb_per_split = (int)cdiv(rbs, s);
     t.splits = (int)cdiv(rbs, t.rb_per_split);
     return t;

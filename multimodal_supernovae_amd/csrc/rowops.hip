@@ -59,6 +59,49 @@ __device__ __forceinline__ void store_row_bf16(const float4 (&v)[NCH], unsigned 
         }
     }
 }
+// the same row as bf16 PLANES in the blocked layout of msn_plane_split (include/msn_hip.h; csrc/pgemm.hip): the operand of
+// the fp32-grade plane GEMMs, written by the kernel that produces the row instead of a separate split pass.  A lane's chunk
+// of 4 columns is 8 bytes of one block row per plane; the four rows a workgroup normalises together complete a 128-byte line.
+struct PlaneOut {
+    unsigned char* base;   // nullptr: no plane output
+    int np, cb;            // planes (2 | 3), column blocks = 2 ceil(cols / 32)
+    int cols;              // columns of the matrix: the padding behind them is written as +0
+};
+template <int NP>
+__device__ __forceinline__ void split4(const float4& v, uint2 (&o)[NP]) {
+    float r[4] = {v.x, v.y, v.z, v.w};
+    unsigned short b[4];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            b[e] = f2bf_bits(r[e]);
+            r[e] -= __uint_as_float((unsigned)b[e] << 16);       // exact
+        }
+        o[k].x = b[0] | ((unsigned)b[1] << 16);
+        o[k].y = b[2] | ((unsigned)b[3] << 16);
+    }
+}
+template <int LPR, int NP>
+__device__ __forceinline__ void store_row_planes(const float4 (&v)[NCH], const PlaneOut& po, int64_t r, int lr) {
+    unsigned char* rowp = po.base + (r >> 5) * (int64_t)po.cb * (NP * 1024) + (int)(r & 31) * 32;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c = 4 * (lr + k * LPR);
+        if (c < po.cb * 16) {                                     // columns past `cols` hold zeros (load_row): the padding
+            uint2 o[NP];
+            split4<NP>(c < po.cols ? v[k] : make_float4(0.f, 0.f, 0.f, 0.f), o);
+            unsigned char* dst = rowp + (c >> 4) * (NP * 1024) + (c & 15) * 2;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(dst + q * 1024) = o[q];
+        }
+    }
+}
+template <int LPR>
+__device__ __forceinline__ void store_row_planes_any(const float4 (&v)[NCH], const PlaneOut& po, int64_t r, int lr) {
+    if (po.np == 3) store_row_planes<LPR, 3>(v, po, r, lr);
+    else store_row_planes<LPR, 2>(v, po, r, lr);
+}
 __device__ __forceinline__ float sum4(float4 a) { return (a.x + a.y) + (a.z + a.w); }
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
@@ -68,7 +111,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, float* __restrict__ y, int64_t ldy,
                                                      float* __restrict__ mean, float* __restrict__ rstd,
-                                                     unsigned short* __restrict__ yb) {
+                                                     unsigned short* __restrict__ yb, PlaneOut po) {
     constexpr int RG = 256 / LPR;
     const int lr = threadIdx.x % LPR, rg = threadIdx.x / LPR;
     float4 gm[NCH], bt[NCH];
@@ -100,6 +143,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         }
         if (y) store_row<LPR>(v, y + r * ldy, g.cols, lr);
         if (yb) store_row_bf16<LPR>(v, yb + r * ldy, g.cols, lr);
+        if (po.base) store_row_planes_any<LPR>(v, po, r, lr);
         if (lr == 0) {
             mean[r] = mu;
             rstd[r] = rs;
@@ -115,7 +159,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ gamma, float* __restrict__ dx,
                                                      int64_t lddx, float* __restrict__ part,
                                                      const float* __restrict__ add, int64_t ldadd,
-                                                     unsigned short* __restrict__ dxb, int want_dxsum) {
+                                                     unsigned short* __restrict__ dxb, int want_dxsum, PlaneOut po) {
     constexpr int RG = 256 / LPR;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [RG][2 or 3][cols]
     const int lr = threadIdx.x % LPR, rg = threadIdx.x / LPR;
@@ -161,6 +205,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         }
         store_row<LPR>(d, dx + r * lddx, g.cols, lr);
         if (dxb) store_row_bf16<LPR>(d, dxb + r * lddx, g.cols, lr);
+        if (po.base) store_row_planes_any<LPR>(d, po, r, lr);
         if (want_dxsum) {
 #pragma unroll
             for (int k = 0; k < NCH; ++k) { sx[k].x += d[k].x; sx[k].y += d[k].y; sx[k].z += d[k].z; sx[k].w += d[k].w; }
@@ -655,7 +700,7 @@ extern "C" int msn_layernorm_fwd(const float* x, int64_t ldx, int64_t rows, int 
     const RowGeom g{rows, cols, ldx};
     hipStream_t st = static_cast<hipStream_t>(stream);
     MSN_LPR_DISPATCH(ln_fwd_kernel, lpr, dim3(ln_grid(rows, lpr)), 0, st, x, ldx, g, gamma, beta, eps, y, ldy, mean, rstd,
-                     (unsigned short*)nullptr)
+                     (unsigned short*)nullptr, PlaneOut{nullptr, 0, 0, 0})
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }
@@ -669,7 +714,7 @@ extern "C" int msn_layernorm_fwd_bf16(const float* x, int64_t ldx, int64_t rows,
     const RowGeom g{rows, cols, ldx};
     hipStream_t st = static_cast<hipStream_t>(stream);
     MSN_LPR_DISPATCH(ln_fwd_kernel, lpr, dim3(ln_grid(rows, lpr)), 0, st, x, ldx, g, gamma, beta, eps, (float*)nullptr, ldy,
-                     mean, rstd, static_cast<unsigned short*>(y_bf16))
+                     mean, rstd, static_cast<unsigned short*>(y_bf16), PlaneOut{nullptr, 0, 0, 0})
     MSN_LAUNCH_CHECK();
     return MSN_OK;
 }
@@ -695,7 +740,7 @@ extern "C" int msn_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
     float* part = static_cast<float*>(ws);
     const size_t lds = sizeof(float) * 2 * (size_t)cols * (256 / lpr);
     MSN_LPR_DISPATCH(ln_bwd_kernel, lpr, dim3(grid), lds, st, dy, lddy, x, ldx, g, mean, rstd, gamma, dx, lddx, part, add, ldadd,
-                     (unsigned short*)nullptr, 0)
+                     (unsigned short*)nullptr, 0, PlaneOut{nullptr, 0, 0, 0})
     MSN_LAUNCH_CHECK();
     hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)cdiv(2 * cols, 64)), dim3(1024), 0, st, part, grid, 2 * cols,
                        dgamma, dbeta, cols);
@@ -723,7 +768,66 @@ extern "C" int msn_layernorm_bwd_bf16(const float* dy, int64_t lddy, const float
     float* part = static_cast<float*>(ws);
     const size_t lds = sizeof(float) * nacc * (size_t)cols * (256 / lpr);
     MSN_LPR_DISPATCH(ln_bwd_kernel, lpr, dim3(grid), lds, st, dy, lddy, x, ldx, g, mean, rstd, gamma, dx, lddx, part, add, ldadd,
-                     static_cast<unsigned short*>(dx_bf16), dx_colsum ? 1 : 0)
+                     static_cast<unsigned short*>(dx_bf16), dx_colsum ? 1 : 0, PlaneOut{nullptr, 0, 0, 0})
+    MSN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)cdiv(nacc * cols, 64)), dim3(1024), 0, st, part, grid, nacc * cols,
+                       dgamma, dbeta, cols, dx_colsum);
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+// ---- LayerNorm writing bf16 PLANES (blocked layout of msn_plane_split): the operand of the plane GEMMs (pgemm.hip)
+static int plane_tail_zero(void* planes_out, int64_t rows, int cols, int np, hipStream_t st) {
+    // rows past `rows` in the last 32-row block are part of the plane matrix and must be zero
+    if (rows % 32 == 0) return MSN_OK;
+    const int64_t cb = 2 * cdiv(cols, 32);
+    const size_t block_row = (size_t)cb * np * 1024;
+    if (hipMemsetAsync(static_cast<unsigned char*>(planes_out) + (rows / 32) * block_row, 0, block_row, st) != hipSuccess) {
+        set_error("plane output: hipMemsetAsync failed");
+        return MSN_ERR_HIP;
+    }
+    return MSN_OK;
+}
+
+extern "C" int msn_layernorm_fwd_planes(const float* x, int64_t ldx, int64_t rows, int cols, const float* gamma,
+                                        const float* beta, float eps, int planes, void* y_planes, float* y, int64_t ldy,
+                                        float* mean, float* rstd, msn_stream_t stream) {
+    if (int rc = check_rows("msn_layernorm_fwd_planes", rows, cols, {ldx}, {x, gamma, beta, y_planes})) return rc;
+    MSN_REQUIRE(mean && rstd && (planes == 2 || planes == 3), "msn_layernorm_fwd_planes: bad argument");
+    MSN_REQUIRE(!y || (ldy >= cols && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0), "msn_layernorm_fwd_planes: bad fp32 output");
+    const int lpr = pick_lpr(cols);
+    const RowGeom g{rows, cols, ldx};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (int rc = plane_tail_zero(y_planes, rows, cols, planes, st)) return rc;
+    const PlaneOut po{static_cast<unsigned char*>(y_planes), planes, 2 * (int)cdiv(cols, 32), cols};
+    MSN_LPR_DISPATCH(ln_fwd_kernel, lpr, dim3(ln_grid(rows, lpr)), 0, st, x, ldx, g, gamma, beta, eps, y, ldy, mean, rstd,
+                     (unsigned short*)nullptr, po)
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+// backward that ALSO writes the planes of dx: the gradient is consumed as the fp32 residual-stream gradient and as the plane
+// operand of the next weight / input gradient products; dx_colsum (nullable): column sums of dx (a bias gradient)
+extern "C" int msn_layernorm_bwd_planes(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t rows, int cols,
+                                        const float* mean, const float* rstd, const float* gamma, const float* add,
+                                        int64_t ldadd, float* dx, int64_t lddx, int planes, void* dx_planes, float* dgamma,
+                                        float* dbeta, float* dx_colsum, void* ws, size_t ws_bytes, msn_stream_t stream) {
+    if (int rc = check_rows("msn_layernorm_bwd_planes", rows, cols, {lddy, ldx, lddx}, {dy, x, dx, gamma, dx_planes})) return rc;
+    MSN_REQUIRE(mean && rstd && dgamma && dbeta && (planes == 2 || planes == 3), "msn_layernorm_bwd_planes: bad argument");
+    MSN_REQUIRE(!add || (ldadd >= cols && ldadd % 4 == 0 && (reinterpret_cast<uintptr_t>(add) & 15) == 0),
+                "msn_layernorm_bwd_planes: bad residual-gradient operand");
+    const int lpr = pick_lpr(cols);
+    const int grid = ln_bwd_grid(rows, lpr);
+    const int nacc = dx_colsum ? 3 : 2;
+    MSN_REQUIRE(ws && ws_bytes >= sizeof(float) * nacc * (size_t)cols * grid, "msn_layernorm_bwd_planes: workspace too small");
+    const RowGeom g{rows, cols, ldx};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (int rc = plane_tail_zero(dx_planes, rows, cols, planes, st)) return rc;
+    const PlaneOut po{static_cast<unsigned char*>(dx_planes), planes, 2 * (int)cdiv(cols, 32), cols};
+    float* part = static_cast<float*>(ws);
+    const size_t lds = sizeof(float) * nacc * (size_t)cols * (256 / lpr);
+    MSN_LPR_DISPATCH(ln_bwd_kernel, lpr, dim3(grid), lds, st, dy, lddy, x, ldx, g, mean, rstd, gamma, dx, lddx, part, add, ldadd,
+                     (unsigned short*)nullptr, dx_colsum ? 1 : 0, po)
     MSN_LAUNCH_CHECK();
     hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)cdiv(nacc * cols, 64)), dim3(1024), 0, st, part, grid, nacc * cols,
                        dgamma, dbeta, cols, dx_colsum);

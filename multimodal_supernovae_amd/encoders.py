@@ -51,8 +51,9 @@ class VisionTransformer(nn.Module):
                  gemm_precision=None):
         super().__init__()
         assert emb % heads == 0
-        # None = the process default (exact fp32); "bf16" = operands rounded to bf16 on the bf16 matrix cores
-        # (BASELINE cfg5); "bf16x3" = split-bf16, fp32-grade.  Attention, norms and the loss stay fp32.
+        # None = the process default; "f32" = native fp32 MFMA; "bf16x6" = fp32-grade from three resident bf16 planes (six
+        # bf16 MFMA products); "bf16x3p" / "bf16x3" = two planes / split in registers (three products, ~1e-5); "bf16" =
+        # operands rounded to bf16 (BASELINE cfg5).  Attention, norms and the loss stay fp32.
         self.gemm_precision = gemm_precision
         self.cls_only_last_block = True      # False: evaluate every token of the last block (same result, more work)
         self.bf16_resident = True            # gemm_precision "bf16": bf16 activations in HBM + the 256-wide LDS-DMA GEMM
@@ -95,6 +96,10 @@ class VisionTransformer(nn.Module):
                 and all(b.norm1.eps == self.blocks[0].norm1.eps for b in self.blocks)):
             # BASELINE cfg5: bf16-resident operands, 256 x 256 LDS-DMA tiles (functional._Bf16VitTrunk)
             h = F_.bf16_vit_trunk(h, self.heads, self.blocks[0].norm1.eps, params[:dense])
+            first = dense
+        elif (dense > 0 and F_.plane_path_ok(h) and all(b.norm1.eps == self.blocks[0].norm1.eps for b in self.blocks)):
+            # "bf16x6" / "bf16x3p": fp32-grade products from resident bf16 planes (functional._PlaneVitTrunk)
+            h = F_.plane_vit_trunk(h, self.heads, self.blocks[0].norm1.eps, params[:dense])
             first = dense
         for i in range(first, len(params)):
             if i == last and self.cls_only_last_block:

@@ -577,64 +577,99 @@ class _PreNormBlock(torch.autograd.Function):
 
 
 @_remember_precision
-class _PreNormBlockPlanes(torch.autograd.Function):
-    """_PreNormBlock with every Linear product on the plane kernels (csrc/pgemm.hip: fp32-grade products on the bf16 matrix
-    cores from operands RESIDENT as bf16 planes; ops.plane_count() = 3 planes / 6 products, or 2 / 3).  Same arithmetic
-    plan as the fp32 block -- residual adds, bias adds, GELU and GELU' in GEMM epilogues -- with each operand split into
-    planes ONCE by its producer: LayerNorm outputs, the attention output, the GELU epilogue (writes the planes of f
-    directly), gradients as they leave LayerNorm backward / the GELU' epilogue / attention backward; the weights (and
-    their transposes, for the input-gradient products) once per call.  The residual stream, LayerNorm statistics,
-    attention and every parameter gradient stay fp32."""
+class _PlaneVitTrunk(torch.autograd.Function):
+    """Blocks 0 .. n-1 of the build-defined pre-norm ViT as ONE node with every Linear product on the plane kernels
+    (csrc/pgemm.hip: fp32-grade products on the bf16 matrix cores from operands RESIDENT as bf16 planes; ops.plane_count()
+    = 3 planes / 6 products, or 2 / 3).  Same arithmetic plan as pre_norm_block -- residual adds, bias adds, GELU and GELU'
+    in GEMM epilogues -- with each operand split into planes ONCE, by the kernel that produces it: LayerNorm forward writes
+    planes only, the GELU epilogue writes the planes of its activation, LayerNorm backward and the GELU' epilogue write the
+    planes of the gradients they produce (and the column sums that are the bias gradients); the attention output and the
+    attention gradient are split by msn_plane_split (the one pass that is not fused yet); the weights and their transposes
+    (for the input-gradient products) once per call.  The residual stream, LayerNorm statistics, attention and every
+    parameter gradient stay fp32.
+
+    Per-block parameter order: g1, b1, wqkv, bqkv, wo, bo, g2, b2, w1, c1, w2, c2."""
+
+    NS = 10   # tensors saved per block
 
     @staticmethod
-    def forward(ctx, x, heads, eps, g1, b1, wqkv, bqkv, wo, bo, g2, b2, w1, c1, w2, c2):
+    def forward(ctx, x, heads, eps, n_blocks, *P):
         B, T, e = x.shape
+        M = B * T
         NPL = ops.plane_count()
-        x2 = _c(x).view(B * T, e)
         scale = 1.0 / math.sqrt(e // heads)
-        h1p, m1, r1 = ops.layernorm_fwd_planes(x2, g1, b1, eps, NPL)
-        qkv = ops.pgemm_nt(h1p, ops.plane_split(wqkv, NPL), bias=bqkv)
-        q3 = qkv.view(B, T, 3 * e)
-        a, lse = ops.attention_fwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], None, heads, scale)
-        a2 = a.view(B * T, e)
-        ap = ops.plane_split(a2, NPL)
-        x1 = ops.pgemm_nt(ap, ops.plane_split(wo, NPL), bias=bo, epilogue=EPI_ADD, aux=x2)
-        h2p, m2, r2 = ops.layernorm_fwd_planes(x1, g2, b2, eps, NPL)
-        fp, dact = ops.pgemm_nt(h2p, ops.plane_split(w1, NPL), bias=c1, epilogue=EPI_GELU, aux=True, out_planes=True)
-        out = ops.pgemm_nt(fp, ops.plane_split(w2, NPL), bias=c2, epilogue=EPI_ADD, aux=x1)
-        ctx.dims = (B, T, e, heads, scale, NPL)
-        ctx.planes = (h1p, ap, h2p, fp)                       # plane matrices are not tensors: kept on the node
-        ctx.save_for_backward(x2, g1, wqkv, wo, g2, w1, w2, m1, r1, qkv, a2, lse, x1, m2, r2, dact,
-                              h1p.buf, ap.buf, h2p.buf, fp.buf)
-        return out.view(B, T, e)
+        x2 = _c(x).view(M, e)
+        saved, planes = [], []
+        for i in range(n_blocks):
+            g1, b1, wqkv, bqkv, wo, bo, g2, b2, w1, c1, w2, c2 = P[12 * i: 12 * i + 12]
+            h1p, m1, r1 = ops.layernorm_fwd_planes(x2, g1, b1, eps, NPL)
+            qkv = ops.pgemm_nt(h1p, ops.plane_split(wqkv, NPL), bias=bqkv)
+            q3 = qkv.view(B, T, 3 * e)
+            a, lse = ops.attention_fwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], None, heads, scale)
+            a2 = a.view(M, e)
+            ap = ops.plane_split(a2, NPL)
+            x1 = ops.pgemm_nt(ap, ops.plane_split(wo, NPL), bias=bo, epilogue=EPI_ADD, aux=x2)
+            h2p, m2, r2 = ops.layernorm_fwd_planes(x1, g2, b2, eps, NPL)
+            fp, dact = ops.pgemm_nt(h2p, ops.plane_split(w1, NPL), bias=c1, epilogue=EPI_GELU, aux=True, out_planes=True)
+            out = ops.pgemm_nt(fp, ops.plane_split(w2, NPL), bias=c2, epilogue=EPI_ADD, aux=x1)
+            saved += [x2, m1, r1, qkv, a2, lse, x1, m2, r2, dact]
+            planes.append((h1p, ap, h2p, fp))
+            x2 = out
+        ctx.dims = (B, T, e, heads, scale, n_blocks, NPL)
+        ctx.planes = planes                                   # plane matrices are not tensors: kept on the node
+        ctx.save_for_backward(*saved, *P)
+        return x2.view(B, T, e)
 
     @staticmethod
     def backward(ctx, dy):
-        B, T, e, heads, scale, NPL = ctx.dims
-        (x2, g1, wqkv, wo, g2, w1, w2, m1, r1, qkv, a2, lse, x1, m2, r2, dact, *_bufs) = ctx.saved_tensors
-        h1p, ap, h2p, fp = ctx.planes
-        d2 = _c(dy).view(B * T, e)
-        # input gradients dX = dY . W are NT products against the planes of the transposed weight; every bias gradient (a
-        # column sum of a gradient matrix) comes out of the pass that writes that matrix's planes
+        B, T, e, heads, scale, n_blocks, NPL = ctx.dims
+        M = B * T
+        t = ctx.saved_tensors
+        NS = _PlaneVitTrunk.NS
+        acts, P = t[:NS * n_blocks], t[NS * n_blocks:]
+        grads = [None] * len(P)
+        d2 = _c(dy).view(M, e)
+        # the gradient entering the trunk is the one operand nobody produced in plane form; its column sums are the bias
+        # gradient of the last block's second MLP layer (the other blocks get theirs from the LayerNorm backward above them)
         d2p, dc2 = ops.plane_split(d2, NPL, want_colsum=True)
-        dw2 = ops.pgemm_tn(d2p, fp)
-        dprep, dc1 = ops.pgemm_nt(d2p, ops.plane_split(w2, NPL, transposed=True), epilogue=EPI_GELU_BWD, aux=dact,
-                                  out_planes=True, want_colsum=True)
-        dw1 = ops.pgemm_tn(dprep, h2p)
-        dh2 = ops.pgemm_nt(dprep, ops.plane_split(w1, NPL, transposed=True))
-        dx1, dg2, db2 = ops.layernorm_bwd(dh2, x1, m2, r2, g2, add=d2)        # + skip connection
-        dx1p, dbo = ops.plane_split(dx1, NPL, want_colsum=True)
-        dwo = ops.pgemm_tn(dx1p, ap)
-        da = ops.pgemm_nt(dx1p, ops.plane_split(wo, NPL, transposed=True))
-        dqkv = torch.empty_like(qkv)
-        q3, d3 = qkv.view(B, T, 3 * e), dqkv.view(B, T, 3 * e)
-        ops.attention_bwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], None, heads, scale, a2.view(B, T, e), lse,
-                          da.view(B, T, e), d3[..., :e], d3[..., e:2 * e], d3[..., 2 * e:])
-        dqkvp, dbqkv = ops.plane_split(dqkv, NPL, want_colsum=True)
-        dwqkv = ops.pgemm_tn(dqkvp, h1p)
-        dh1 = ops.pgemm_nt(dqkvp, ops.plane_split(wqkv, NPL, transposed=True))
-        dx, dg1, db1 = ops.layernorm_bwd(dh1, x2, m1, r1, g1, add=dx1)          # + skip connection
-        return (dx.view(B, T, e), None, None, dg1, db1, dwqkv, dbqkv, dwo, dbo, dg2, db2, dw1, dc1, dw2, dc2)
+        for i in range(n_blocks - 1, -1, -1):
+            x2, m1, r1, qkv, a2, lse, x1, m2, r2, dact = acts[NS * i: NS * i + NS]
+            h1p, ap, h2p, fp = ctx.planes[i]
+            g1, b1, wqkv, bqkv, wo, bo, g2, b2, w1, c1, w2, c2 = P[12 * i: 12 * i + 12]
+            # input gradients dX = dY . W are NT products against the planes of the transposed weight; every bias gradient (a
+            # column sum of a gradient matrix) comes out of the kernel that writes that matrix's planes
+            dw2 = ops.pgemm_tn(d2p, fp)
+            dprep, dc1 = ops.pgemm_nt(d2p, ops.plane_split(w2, NPL, transposed=True), epilogue=EPI_GELU_BWD, aux=dact,
+                                      out_planes=True, want_colsum=True)
+            dw1 = ops.pgemm_tn(dprep, h2p)
+            dh2 = ops.pgemm_nt(dprep, ops.plane_split(w1, NPL, transposed=True))
+            dx1, dx1p, dg2, db2, dbo = ops.layernorm_bwd_planes(dh2, x1, m2, r2, g2, NPL, add=d2, want_colsum=True)   # + skip
+            dwo = ops.pgemm_tn(dx1p, ap)
+            da = ops.pgemm_nt(dx1p, ops.plane_split(wo, NPL, transposed=True))
+            dqkv = torch.empty_like(qkv)
+            q3, d3 = qkv.view(B, T, 3 * e), dqkv.view(B, T, 3 * e)
+            ops.attention_bwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], None, heads, scale, a2.view(B, T, e), lse,
+                              da.view(B, T, e), d3[..., :e], d3[..., e:2 * e], d3[..., 2 * e:])
+            dqkvp, dbqkv = ops.plane_split(dqkv, NPL, want_colsum=True)
+            dwqkv = ops.pgemm_tn(dqkvp, h1p)
+            dh1 = ops.pgemm_nt(dqkvp, ops.plane_split(wqkv, NPL, transposed=True))
+            grads[12 * i: 12 * i + 12] = [None, None, dwqkv, dbqkv, dwo, dbo, dg2, db2, dw1, dc1, dw2, dc2]
+            d2, d2p, dg1, db1, dc2 = ops.layernorm_bwd_planes(dh1, x2, m1, r1, g1, NPL, add=dx1, want_colsum=True)    # + skip
+            grads[12 * i], grads[12 * i + 1] = dg1, db1
+            ctx.planes[i] = None                              # this block's planes are done with
+        return (d2.view(B, T, e), None, None, None, *grads)
+
+
+def plane_vit_trunk(x, heads, eps, block_params):
+    """block_params: one 12-tuple (g1, b1, wqkv, bqkv, wo, bo, g2, b2, w1, c1, w2, c2) per block."""
+    flat = [p for blk in block_params for p in blk]
+    return _PlaneVitTrunk.apply(x, heads, eps, len(block_params), *flat)
+
+
+def plane_path_ok(x):
+    """The plane kernels take the wide token matrices of the ViT towers (256-row tiles, 128-wide tiles)."""
+    B, T, e = x.shape
+    return bool(ops.plane_count()) and x.is_cuda and ops.pgemm_supported(B * T, e, e)
 
 
 # Backward pairs (dX and dW of one Linear) as ONE work-list launch: bit 1 = the qkv and ff1 pairs (e-wide dX), bit 4 = the ff2
@@ -655,9 +690,8 @@ def _pair_backward(rows):
 
 
 def pre_norm_block(x, heads, p, eps=1e-6):
-    B, T, e = x.shape
-    if ops.plane_count() and ops.pgemm_supported(B * T, e, e) and x.is_cuda:
-        return _PreNormBlockPlanes.apply(x, heads, eps, *p)
+    if plane_path_ok(x):
+        return plane_vit_trunk(x, heads, eps, [p])
     return _PreNormBlock.apply(x, heads, eps, *p)
 
 

@@ -1020,5 +1020,35 @@ def set_pgemm_tile_n(bn):
 
 def layernorm_fwd_planes(x, gamma, beta, eps, planes):
     """LayerNorm whose output goes straight to bf16 planes (the next product's operand); returns (Planes, mean, rstd)."""
-    y, mean, rstd = layernorm_fwd(x, gamma, beta, eps)
-    return plane_split(y, planes), mean, rstd
+    x2 = _rows2d(_f32c(x, "x"))
+    rows, cols = x2.shape
+    y = Planes.empty(rows, cols, planes, x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib().msn_layernorm_fwd_planes(ptr(x2), x2.stride(0), rows, cols, ptr(gamma), ptr(beta), eps, planes, ptr(y.buf), None, 0,
+                                         ptr(mean), ptr(rstd), stream_ptr()), "msn_layernorm_fwd_planes")
+    return y, mean, rstd
+
+
+def layernorm_bwd_planes(dy, x, mean, rstd, gamma, planes, add=None, want_colsum=False):
+    """LayerNorm backward returning (dx fp32, dx Planes, dgamma, dbeta[, column sums of dx])."""
+    dy2, x2 = _rows2d(_f32c(dy, "dy")), _rows2d(x)
+    add2 = _rows2d(add) if add is not None else None
+    rows, cols = x2.shape
+    dx = torch.empty((rows, cols), dtype=torch.float32, device=x.device)
+    dxp = Planes.empty(rows, cols, planes, x.device)
+    dg = torch.empty(cols, dtype=torch.float32, device=x.device)
+    db = torch.empty(cols, dtype=torch.float32, device=x.device)
+    cs = torch.empty(cols, dtype=torch.float32, device=x.device) if want_colsum else None
+    L = lib()
+    nb = L.msn_layernorm_bwd_workspace_bytes(rows, cols) * 3 // 2
+    ws = _workspace(nb, x.device)
+    check(L.msn_layernorm_bwd_planes(ptr(dy2), dy2.stride(0), ptr(x2), x2.stride(0), rows, cols, ptr(mean), ptr(rstd), ptr(gamma),
+                                     ptr(add2), add2.stride(0) if add2 is not None else 0, ptr(dx), cols, planes, ptr(dxp.buf),
+                                     ptr(dg), ptr(db), ptr(cs), ptr(ws), nb, stream_ptr()), "msn_layernorm_bwd_planes")
+    return (dx, dxp, dg, db, cs) if want_colsum else (dx, dxp, dg, db)
+
+
+def set_pgemm_variant(v):
+    """Wave layout of the 3-plane pgemm_nt kernel (msn_set_pgemm_variant) -- measurements."""
+    check(lib().msn_set_pgemm_variant(int(v)))

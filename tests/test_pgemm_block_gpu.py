@@ -31,3 +31,53 @@ def test_block_matches_fp32_block(precision, tol):
     for i, (a, b) in enumerate(zip(got, ref)):
         err = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
         assert err < tol, (i, err)
+
+
+@pytest.mark.parametrize("rows,cols,planes", [(260, 384, 3), (77, 64, 3), (1000, 1024, 2), (33, 200, 3)])
+def test_layernorm_plane_outputs(rows, cols, planes):
+    """LayerNorm forward / backward writing planes == the fp32 kernels' results split by msn_plane_split, bit for bit."""
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(rows + cols)
+    x = torch.randn(rows, cols, generator=g).cuda()
+    gm, bt = (torch.randn(cols, generator=g) + 1).cuda(), torch.randn(cols, generator=g).cuda()
+    dy, add = torch.randn(rows, cols, generator=g).cuda(), torch.randn(rows, cols, generator=g).cuda()
+    y, mean, rstd = ops.layernorm_fwd(x, gm, bt, 1e-6)
+    yp, mean2, rstd2 = ops.layernorm_fwd_planes(x, gm, bt, 1e-6, planes)
+    assert torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
+    assert torch.equal(yp.buf, ops.plane_split(y, planes).buf)
+    dx, dg, db = ops.layernorm_bwd(dy, x, mean, rstd, gm, add=add)
+    dx2, dxp, dg2, db2, cs = ops.layernorm_bwd_planes(dy, x, mean, rstd, gm, planes, add=add, want_colsum=True)
+    assert torch.equal(dx, dx2) and torch.equal(dg, dg2) and torch.equal(db, db2)
+    assert torch.equal(dxp.buf, ops.plane_split(dx, planes).buf)
+    torch.testing.assert_close(cs.cpu().double(), dx.cpu().double().sum(0), rtol=1e-5, atol=1e-4)
+
+
+def test_trunk_of_three_blocks():
+    """functional.plane_vit_trunk over several blocks (planes handed from block to block) == the fp32 blocks."""
+    from multimodal_supernovae_amd import functional as F_, ops
+    B, T, e, heads, nb = 8, 65, 384, 6, 3
+    g = torch.Generator().manual_seed(5)
+    def rnd(*s, scale=1.0, shift=0.0):
+        return (torch.randn(*s, generator=g) * scale + shift).cuda().requires_grad_()
+    blocks = [[rnd(e, shift=1.0), rnd(e, scale=0.1), rnd(3 * e, e, scale=0.05), rnd(3 * e, scale=0.1), rnd(e, e, scale=0.05),
+               rnd(e, scale=0.1), rnd(e, shift=1.0), rnd(e, scale=0.1), rnd(4 * e, e, scale=0.05), rnd(4 * e, scale=0.1),
+               rnd(e, 4 * e, scale=0.05), rnd(e, scale=0.1)] for _ in range(nb)]
+    x = rnd(B, T, e)
+    dy = torch.randn(B, T, e, generator=g).cuda()
+    leaves = [x] + [p for blk in blocks for p in blk]
+    def run(prec):
+        for t in leaves:
+            t.grad = None
+        with ops.gemm_precision(prec):
+            if prec == "f32":
+                h = x
+                for blk in blocks:
+                    h = F_.pre_norm_block(h, heads, blk, eps=1e-6)
+            else:
+                h = F_.plane_vit_trunk(x, heads, 1e-6, blocks)
+            h.backward(dy)
+        return [h.detach().clone()] + [t.grad.clone() for t in leaves]
+    ref, got = run("f32"), run("bf16x6")
+    for i, (a, b) in enumerate(zip(got, ref)):
+        err = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+        assert err < 5e-5, (i, err)

@@ -159,3 +159,23 @@ def test_fp32_grade_gate_tn(N, K, kind):
     e_nat, e_pl = (c_nat - ref).abs(), (c_pl - ref).abs()
     assert float(e_pl.max()) <= 1.5 * float(e_nat.max()) + 1e-30, (float(e_pl.max()), float(e_nat.max()))
     assert float(e_pl.pow(2).mean().sqrt()) <= 1.5 * float(e_nat.pow(2).mean().sqrt()) + 1e-30
+
+
+@pytest.mark.parametrize("variant", [0, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(300, 272, 200), (4096, 1536, 384), (777, 384, 1536)])
+def test_nt_wave_layouts_exact_on_integers(M, N, K, variant):
+    """The alternative wave layouts / staggered DMA issue of the 3-plane kernel (msn_set_pgemm_variant)."""
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w = _ints((M, K), g), _ints((N, K), g)
+    bias = torch.randint(-3, 4, (N,), generator=g).float()
+    ref = a.double() @ w.double().T + bias.double()
+    ap, wp = ops.plane_split(a.cuda(), 3), ops.plane_split(w.cuda(), 3)
+    ops.set_pgemm_variant(variant)
+    try:
+        c = ops.pgemm_nt(ap, wp, bias=bias.cuda())
+        cp, cs = ops.pgemm_nt(ap, wp, bias=bias.cuda(), out_planes=True, want_colsum=True)
+    finally:
+        ops.set_pgemm_variant(1)
+    assert torch.equal(c.cpu().double(), ref)
+    assert torch.equal(cp.to_float().cpu().double(), ref) and torch.equal(cs.cpu().double(), ref.sum(0))

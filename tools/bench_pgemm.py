@@ -25,6 +25,9 @@ def timed(fn, reps=10):
 def main():
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 1024 * 65
     planes_list = [int(v) for v in os.environ.get("PLANES", "3,2").split(",")]
+    if os.environ.get("SKEW"):
+        from multimodal_supernovae_amd import _lib
+        _lib.check(_lib.lib().msn_set_pgemm_skew(int(os.environ["SKEW"])))
     g = torch.Generator(device="cuda").manual_seed(0)
     rnd = lambda *s: torch.randn(*s, device="cuda", generator=g) * 0.3
     shapes = [("qkv   fwd", 1152, 384), ("proj  fwd", 384, 384), ("fc1   fwd", 1536, 384), ("fc2   fwd", 384, 1536),
@@ -37,13 +40,27 @@ def main():
         for pl in planes_list:
             ap, wp = ops.plane_split(a, pl), ops.plane_split(w, pl)
             ts = timed(lambda: ops.plane_split(a, pl))
-            for bn in (128, 256):
-                ops.set_pgemm_tile_n(bn)
-                t = timed(lambda: ops.pgemm_nt(ap, wp))
-                line += f" | {pl}pl bn{bn} {fl / t / 1e12:6.1f} ({t * 1e6:6.0f} us)"
-            ops.set_pgemm_tile_n(0)
+            if pl == 3:
+                for v in [int(x) for x in os.environ.get("PG_VARIANTS", "1").split(",")]:
+                    ops.set_pgemm_variant(v)
+                    t = timed(lambda: ops.pgemm_nt(ap, wp))
+                    line += f" | 3pl v{v} {fl / t / 1e12:6.1f} ({t * 1e6:6.0f} us)"
+                ops.set_pgemm_variant(1)
+            else:
+                for bn in (128, 256):
+                    ops.set_pgemm_tile_n(bn)
+                    t = timed(lambda: ops.pgemm_nt(ap, wp))
+                    line += f" | {pl}pl bn{bn} {fl / t / 1e12:6.1f} ({t * 1e6:6.0f} us)"
+                ops.set_pgemm_tile_n(0)
             tp = timed(lambda: ops.pgemm_nt(ap, wp, out_planes=True))
-            line += f" planes-out {fl / tp / 1e12:6.1f}; split {ts * 1e6:5.0f} us"
+            line += f" planes-out {fl / tp / 1e12:6.1f} ({tp * 1e6:5.0f} us)"
+            if N % 16 == 0 and os.environ.get("GELU"):
+                bias = rnd(N)
+                tg = timed(lambda: ops.pgemm_nt(ap, wp, bias=bias, epilogue=ops.EPI_GELU, aux=True, out_planes=True))
+                dact = rnd(M, N)
+                tb = timed(lambda: ops.pgemm_nt(ap, wp, epilogue=ops.EPI_GELU_BWD, aux=dact, out_planes=True, want_colsum=True))
+                line += f" gelu {tg * 1e6:5.0f} us gelu' {tb * 1e6:5.0f} us"
+            line += f"; split {ts * 1e6:5.0f} us"
         print(line, flush=True)
     if os.environ.get("NT_ONLY"):
         return
