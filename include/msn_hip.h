@@ -279,13 +279,19 @@ int msn_add_rows(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t
  *   msn_pgemm_tn:     C[N][K] (fp32) = sum_m A[m][N]^T . B[m][K] (weight gradient dY^T . X); A, B plane matrices with the
  *                     reduction on the rows (M x N, M x K); reduction split over workgroups, fixed-order slab sums;
  *                     ws >= msn_pgemm_tn_workspace_bytes.
- * Results are deterministic.  msn_set_pgemm_tile_n (0 = planned, 128, 256): tile width of msn_pgemm_nt (measurements). */
+ * Results are deterministic.  msn_set_pgemm_tile_n (0 | 128): tile width of msn_pgemm_nt (256-wide tiles were slower on every shape). */
 size_t msn_plane_bytes(int64_t R, int64_t C, int planes);
 size_t msn_plane_split_colsum_workspace_bytes(int64_t R, int64_t C);
 int msn_plane_split(const float* x, int64_t ldx, int64_t R, int64_t C, int planes, int transposed, void* out, float* colsum,
                     void* ws, size_t ws_bytes, msn_stream_t stream);
 int msn_plane_merge(const void* planes_in, int planes, int64_t R, int64_t C, float* y, int64_t ldy, msn_stream_t stream);
 size_t msn_pgemm_nt_colsum_workspace_bytes(int64_t M, int N);
+/* Workspace of msn_pgemm_nt: the column sums' partials (want_colsum) or the slabs of the TAIL split -- the tiles that do not
+ * fill a round of the 256 persistent workgroups are cut into K-segments, one per workgroup, and a finishing launch sums
+ * the segments in K order and applies the epilogue (fp32 outputs, epilogues NONE / RELU / ADD; deterministic).  Without a
+ * workspace (NULL / too small) the tail tiles are multiplied whole.  msn_set_pgemm_tail_split(0) turns the split off. */
+size_t msn_pgemm_nt_workspace_bytes(int64_t M, int N, int K, int planes, int c_planes, int epilogue, int want_colsum);
+int msn_set_pgemm_tail_split(int enabled);
 int msn_pgemm_nt(int64_t M, int N, int K, int planes, const void* A, const void* B, void* C, int64_t ldc, int c_planes,
                  const float* bias, int epilogue, float* aux, int64_t ldaux, float* colsum_out, void* ws, size_t ws_bytes,
                  msn_stream_t stream);

@@ -64,6 +64,9 @@ struct PgemmArgs {
     int tiles_m, tiles_n, super_rows, epi;
     int colsum_rows;                // NT: column-sum partial rows per tile row (= WM of the kernel's wave layout)
     int chunk_steps;                // NT: K-steps per chunk (0 = the whole reduction in one accumulation)
+    int tail_full;                  // NT: tiles [0, tail_full) are dealt whole; [tail_full, total) are the TAIL tiles, each cut into
+    int tail_segs, tail_steps;      //     tail_segs K-segments of tail_steps K-steps (units): unit u -> workgroup u, raw sums -> tail_slabs[u]
+    float* tail_slabs;              //     (0 segments: no tail split)
     int skew;                       // NT: start delay unit in shader cycles (0 = none): workgroup b waits ((b >> 3) & 3) * skew
     float* colpart;                 // NT (nullable): [2 * tiles_m][N] column sums of the values written to C
     int splits;                     // TN: reduction split
@@ -174,18 +177,33 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
         tm_ = sr * SR + j % rows_sr;
         tn_ = j / rows_sr;
     };
-    auto tile_of = [&](int idx, int& tm_, int& tn_) -> bool {      // idx-th tile of this workgroup
+    // idx-th SEGMENT of this workgroup: its whole tiles first (every K-step), then -- tail split -- at most one unit: a K range
+    // of one of the tiles that do not fill a round of the G workgroups (the host cuts each of them into tail_segs ranges so that
+    // the units spread over the chip instead of a few workgroups multiplying a whole extra tile while the others wait)
+    const int n_whole = p.tail_segs ? p.tail_full : total;
+    auto seg_of = [&](int idx, int& tm_, int& tn_, int& kb_, int& ke_) -> bool {
         const int t = blockIdx.x + idx * G;
-        if (t >= total) return false;
-        locate(t, tm_, tn_);
-        return true;
+        if (t < n_whole) {
+            locate(t, tm_, tn_);
+            kb_ = 0, ke_ = nk;
+            return true;
+        }
+        const int first_tail_idx = n_whole / G;                       // n_whole is a multiple of G when the tail is split
+        if (p.tail_segs && idx == first_tail_idx && (int)blockIdx.x < (total - n_whole) * p.tail_segs) {
+            const int u = blockIdx.x;
+            locate(n_whole + u / p.tail_segs, tm_, tn_);
+            kb_ = (u % p.tail_segs) * p.tail_steps;
+            ke_ = min(nk, kb_ + p.tail_steps);
+            return kb_ < ke_;
+        }
+        return false;
     };
 
     // ---- producer: the LDS-DMA stream.  Global K-step g (over all tiles of this workgroup) lives in slot g % NSLOT.
     const int lane_src = (((lane >> 1) * 2) + ((lane & 1) ^ ((lane >> 4) & 1))) * 16;
     const unsigned char* pbase[MAXQ];                // source of piece q of the producer's tile at K-step 0 (wave-uniform)
-    int p_idx = 0, p_k = 0, p_slot = 0, p_tm = 0, p_tn = 0;
-    bool p_live = tile_of(0, p_tm, p_tn);
+    int p_idx = 0, p_k = 0, p_ke = 0, p_slot = 0, p_tm = 0, p_tn = 0;
+    bool p_live = seg_of(0, p_tm, p_tn, p_k, p_ke);
     auto set_bases = [&]() {
 #pragma unroll
         for (int q = 0; q < MAXQ; ++q) {
@@ -235,9 +253,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
     auto advance = [&]() {                           // producer -> next global K-step
         if (!p_live) return;
         p_slot = (p_slot + 1 == NSLOT) ? 0 : p_slot + 1;
-        if (++p_k == nk) {
-            p_k = 0;
-            p_live = tile_of(++p_idx, p_tm, p_tn);
+        if (++p_k == p_ke) {
+            p_live = seg_of(++p_idx, p_tm, p_tn, p_k, p_ke);
             if (p_live) set_bases();
         }
     };
@@ -301,6 +318,25 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
             constexpr int pb = decltype(pb_)::value;
             req_b(fbh[pb - 1], slot_off, pb_);
         });
+    };
+
+    // req_first at a tile boundary (behind an epilogue, before the first tile): the registers have three defining sites that
+    // meet at the K loop's head, and where the register allocator does not coalesce them it copies them -- a copy of a
+    // fragment that has not ARRIVED yet (the compiler believes the asm that requested it defined it) is a stale fragment: one
+    // K-step of two MFMA tiles came out wrong in a few tiles per launch of the plane-output kernel.  So here the reads are
+    // waited for, and every register is re-defined behind the wait (an empty asm) so that any copy sits behind it too.
+    auto req_first_settled = [&](unsigned slot_off) {
+        req_first(fa[0], fb0[0], slot_off);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(fa[0][i]));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(fb0[0][j]));
+#pragma unroll
+        for (int k = 0; k < NP - 1; ++k)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(fbh[k][j]));
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     int c_slot = 0;                                  // slot of the consumer's current K-step
@@ -370,8 +406,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
     const unsigned st_acc = stg + (unsigned)(frow * 128);                       // + ((2 b + fhalf) ^ (frow & 7)) * 16
     const int srow = lane >> 3, schunk = lane & 7;                              // memory order: pass q -> row 8 q + srow
     const unsigned st_mem = stg + (unsigned)(srow * 128 + ((schunk ^ srow) * 16));   // + q * 1024   ((8 q + srow) & 7 == srow)
+    // (s_nop behind every ds_write_b128: a VALU write to the data registers of a DS store of more than 8 bytes needs a wait
+    // state the compiler's hazard recognizer would insert -- it cannot see the store inside the asm; without it a few lanes
+    // of a tile came out wrong once in a few launches)
     auto lds_w128 = [&](unsigned addr, const float (&v)[4]) {
-        asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(*reinterpret_cast<const f32x4*>(v)) : "memory");
+        asm volatile("ds_write_b128 %0, %1\n\ts_nop 1" ::"v"(addr), "v"(*reinterpret_cast<const f32x4*>(v)) : "memory");
     };
     auto lds_r128 = [&](f32x4& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory"); };
     // a 32 x 32 fp32 tile of a matrix the epilogue READS (residual / saved activation derivative / K-chunk partial):
@@ -389,7 +428,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
     };
     auto tile_take = [&](const f32x4 (&t)[4], float (&a)[16]) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) asm volatile("ds_write_b128 %0, %1" ::"v"(st_mem + q * 1024), "v"(t[q]) : "memory");
+        for (int q = 0; q < 4; ++q) asm volatile("ds_write_b128 %0, %1\n\ts_nop 1" ::"v"(st_mem + q * 1024), "v"(t[q]) : "memory");
         f32x4 r[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) lds_r128(r[b], st_acc + (unsigned)(((2 * b + fhalf) ^ (frow & 7)) * 16));
@@ -417,10 +456,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
             if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(dst + m * ld + n) = r[q];
         }
     };
+    auto slab_flush = [&](float* slab, int r0, int c0) {            // the staged tile -> rows r0.., columns c0.. of a 256 x BN slab
+        f32x4 r[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lds_r128(r[q], st_mem + q * 1024);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3])::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(slab + (r0 + 8 * q + srow) * BN + c0 + 4 * schunk) = r[q];
+    };
     auto store_tile_epi = [&](int tm, int tn, auto epi_, auto mode_) {
         constexpr int epi = decltype(epi_)::value;
         constexpr int MODE = decltype(mode_)::value & 3;
         constexpr bool CS = (decltype(mode_)::value & 4) != 0;    // column sums of the stored values -> p.colpart
+        constexpr bool SLAB = (decltype(mode_)::value & 8) != 0;  // a tail unit's raw sums -> its slab (256 x BN, row-major)
         constexpr bool PARTIAL = MODE >= 2, ADDC = (MODE == 1 || MODE == 3) && !OUTP;
         constexpr bool AUXIN = !PARTIAL && (epi == MSN_EPI_RELU_BWD || epi == MSN_EPI_GELU_BWD || epi == MSN_EPI_ADD);
         // everything the epilogue reads, requested up front: the K-chunk partial if there is one, else the aux matrix
@@ -453,7 +502,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
                 constexpr int t = j * MT + i;
                 const int64_t m0 = (int64_t)tm * BM + wm * (32 * MT) + 32 * i;
                 const int rbk = tm * ARB + wm * MT + i;           // row block of a plane output (it has the rows of A)
-                const bool live = n0 < p.N && (OUTP ? rbk < p.rbA : m0 < p.M);      // (wave-uniform)
+                const bool live = SLAB || (n0 < p.N && (OUTP ? rbk < p.rbA : m0 < p.M));      // (wave-uniform)
                 if (!live) {
                     pre_fetch(std::integral_constant<int, t + PW>{});
                     return;
@@ -545,7 +594,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
                         const float w[4] = {v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]};
                         stage_chunk(b, w);
                     }
-                    tile_flush(static_cast<float*>(p.C), p.ldc, m0, n0);
+                    if constexpr (SLAB)
+                        slab_flush(p.tail_slabs + (int64_t)blockIdx.x * (BM * BN), wm * (32 * MT) + 32 * i, wn * (32 * NT) + 32 * j);
+                    else
+                        tile_flush(static_cast<float*>(p.C), p.ldc, m0, n0);
                 }
                 if constexpr (CS) {
 #pragma unroll
@@ -617,7 +669,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    req_first(fa[0], fb0[0], 0u);
+    req_first_settled(0u);
 
     using T0 = std::integral_constant<int, 0>;
     using T1 = std::integral_constant<int, 1>;
@@ -626,8 +678,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
     // chunks of p.chunk_steps K-steps whose partial sums meet in C by round-to-nearest fp32 adds (the lane that wrote a partial
     // is the lane that reads it back: same wave, same address, program order)
     const int csteps = (!OUTP && p.chunk_steps > 0) ? p.chunk_steps : nk;
-    for (int idx = 0; tile_of(idx, tm, tn); ++idx) {
+    int kb, ke;
+    for (int idx = 0; seg_of(idx, tm, tn, kb, ke); ++idx) {
         zero_acc();
+        if (ke - kb < nk) {                          // a tail unit: raw sums of its K range -> its slab (finishing launch: host)
+            for (int k = kb; k < ke; k += 2) {
+                step(T0{});
+                step(T1{}, k + 2 >= ke);
+            }
+            wait_lgkm<0>();
+            store_tile_epi(tm, tn, std::integral_constant<int, MSN_EPI_NONE>{}, std::integral_constant<int, 2 + 8>{});
+            req_first_settled((unsigned)(c_slot * SLOT));
+            continue;
+        }
         int k0 = 0;
         for (; k0 + csteps < nk; k0 += csteps) {
             for (int k = 0; k < csteps; k += 2) {
@@ -638,7 +701,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
             if (k0 == 0) store_tile_epi(tm, tn, std::integral_constant<int, MSN_EPI_NONE>{}, std::integral_constant<int, 2>{});
             else store_tile_epi(tm, tn, std::integral_constant<int, MSN_EPI_NONE>{}, std::integral_constant<int, 3>{});
             zero_acc();
-            req_first(fa[0], fb0[0], (unsigned)(c_slot * SLOT));
+            req_first_settled((unsigned)(c_slot * SLOT));
         }
         for (int k = k0; k < nk; k += 2) {           // nk is even (plane format)
             step(T0{});
@@ -649,8 +712,46 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
         else if (p.colpart) store_tile(tm, tn, std::integral_constant<int, 4>{});
         else store_tile(tm, tn, std::integral_constant<int, 0>{});
         // the next tile's first fragments (past the workgroup's last tile: whatever the slot holds, into registers nobody uses)
-        req_first(fa[0], fb0[0], (unsigned)(c_slot * SLOT));
+        req_first_settled((unsigned)(c_slot * SLOT));
     }
+}
+
+// Tail tiles of an NT product (PgemmArgs::tail_*): C tile = epilogue(sum over its K-segments' slabs, in K order).  One thread
+// per float4 of a 256 x 128 tile; epilogues NONE / RELU / ADD (the products whose tails are split).
+__global__ __launch_bounds__(256) void pgemm_tail_finish_kernel(const PgemmArgs p, int bn) {
+    const int tiles_tail = p.tiles_m * p.tiles_n - p.tail_full;
+    const int per_tile = BM * bn / 4;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)tiles_tail * per_tile) return;
+    const int tt = (int)(i / per_tile), e = (int)(i % per_tile);
+    // the tile's position: the same XCD-aware map as the kernel's
+    const int total = p.tiles_m * p.tiles_n, t = p.tail_full + tt;
+    const int q = total / 8, r = total % 8, x = t % 8, ii = t / 8;
+    const int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + ii;
+    const int SR = p.super_rows;
+    const int sr = bid / (SR * p.tiles_n), j = bid % (SR * p.tiles_n);
+    const int rows_sr = min(SR, p.tiles_m - sr * SR);
+    const int tm = sr * SR + j % rows_sr, tn = j / rows_sr;
+    const int row = e / (bn / 4), c4 = e % (bn / 4);
+    const int64_t m = (int64_t)tm * BM + row;
+    const int n = tn * bn + 4 * c4;
+    if (m >= p.M || n >= p.N) return;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = 0; g < p.tail_segs; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(p.tail_slabs + ((int64_t)(tt * p.tail_segs + g) * BM + row) * bn + 4 * c4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+    }
+    if (p.epi == MSN_EPI_ADD) {
+        const float4 a = *reinterpret_cast<const float4*>(p.aux + m * p.ldaux + n);
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    } else if (p.epi == MSN_EPI_RELU) {
+        s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f);
+    }
+    *reinterpret_cast<float4*>(static_cast<float*>(p.C) + m * p.ldc + n) = s;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -669,21 +770,22 @@ __device__ __forceinline__ void ds_read_tr_o(bf16x4& dst, unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
 }
 
-template <int NP, int BQ, bool SWAP, bool DUAL>
+template <int NP, int BQ, bool SWAP, bool DUAL, int WM = 2, int WN = 4>
 __global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(const PgemmArgs p) {
+    static_assert(WM * WN == 8, "eight waves");
     constexpr int PHB = 16 * NP, QHB = (BQ / 16) * NP;       // half-block images per K-step: P side, Q side
     constexpr int PIECES = (PHB + QHB) / 2;                  // 1-KB pieces (two half-block images each)
     constexpr int PP = PHB / 2;
     constexpr int SLOT = PIECES * PBLK;
     constexpr int NSLOT = (4 * SLOT <= 160 * 1024) ? 4 : 3;
     constexpr int MAXQ = (PIECES + 7) / 8;
-    constexpr int MT = 4, NT = BQ / 128;
+    constexpr int MT = 8 / WM, NT = BQ / (32 * WN);       // 32 x 32 MFMA tiles per wave: P side x Q side
     constexpr int NG = NP * (NP + 1) / 2;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[NSLOT * SLOT];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
     const int tiles = p.tiles_m * p.tiles_n;                 // tiles over (P side, Q side)
     // workgroup ids go round-robin to the 8 XCDs: give each XCD a contiguous run of (split, tile) pairs, i.e. the tiles of
     // one reduction range, so that its panels are shared in ONE L2
@@ -750,7 +852,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(const PgemmArgs p) {
     // address of read t: image(cb pair * 2 + g16, plane) * 512 + ((2 moct + t) ^ g16) * 128 + rq * 32 + pp * 8
     const unsigned tr0 = lds0 + (unsigned)(g16 * NP * 512 + ((2 * moct) ^ g16) * 128 + rq * 32 + pp * 8);
     const unsigned tr1 = lds0 + (unsigned)(g16 * NP * 512 + ((2 * moct + 1) ^ g16) * 128 + rq * 32 + pp * 8);
-    const unsigned fragP0 = tr0 + (unsigned)(wm * 8 * NP * 512), fragP1 = tr1 + (unsigned)(wm * 8 * NP * 512);      // + (2 i NP + plane) * 512
+    const unsigned fragP0 = tr0 + (unsigned)(wm * 2 * MT * NP * 512), fragP1 = tr1 + (unsigned)(wm * 2 * MT * NP * 512);      // + (2 i NP + plane) * 512
     const unsigned fragQ0 = tr0 + (unsigned)(PHB * 512 + wn * 2 * NT * NP * 512), fragQ1 = tr1 + (unsigned)(PHB * 512 + wn * 2 * NT * NP * 512);
 
     f32x16 acc[MT][NT], acc2[DUAL ? MT : 1][DUAL ? NT : 1];        // DUAL: see pgemm_nt_kernel
@@ -916,11 +1018,11 @@ __global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(const PgemmArgs p) {
             for (int b = 0; b < 4; ++b) {
                 int n, k;
                 if constexpr (SWAP) {     // D[p][q]: lane holds q = l31 (n), p = 8 b + h4 + r (k)
-                    k = tp * 256 + wm * 128 + 32 * i + 8 * b + h4;
-                    n = tq * BQ + wn * (BQ / 4) + 32 * jj + l31;
+                    k = tp * 256 + wm * (32 * MT) + 32 * i + 8 * b + h4;
+                    n = tq * BQ + wn * (32 * NT) + 32 * jj + l31;
                 } else {                  // D'[q][p]: lane holds p = l31 (n), q = 8 b + h4 + r (k)
-                    n = tp * 256 + wm * 128 + 32 * i + l31;
-                    k = tq * BQ + wn * (BQ / 4) + 32 * jj + 8 * b + h4;
+                    n = tp * 256 + wm * (32 * MT) + 32 * i + l31;
+                    k = tq * BQ + wn * (32 * NT) + 32 * jj + 8 * b + h4;
                 }
                 if (n >= p.N || k >= p.K) continue;                  // K % 4 == 0 (host)
                 float v[4];
@@ -1049,19 +1151,23 @@ __global__ void plane_merge_kernel(const unsigned char* __restrict__ in, int NP,
     }
 }
 
-// out[n] = sum_k part[k][n]: 64 columns x 4 row groups per workgroup, fixed order
-__global__ __launch_bounds__(256) void pcolsum_finish_kernel(const float* __restrict__ part, int nparts, int N,
+// out[y][n] = sum over the parts k of slice y (parts_per_slice each) of part[k][n]: 64 columns x 4 row groups per workgroup,
+// fixed order.  Thousands of parts (one per 32-row block of a split, one per wave row of a GEMM) are summed in two passes:
+// 32 slices, then the 32 slice sums (colsum_finish) -- one pass over 2080 parts with 6 workgroups took 32 us.
+__global__ __launch_bounds__(256) void pcolsum_finish_kernel(const float* __restrict__ part, int nparts, int parts_per_slice, int N,
                                                              float* __restrict__ out) {
     __shared__ float red[4][64];
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + cl;
+    const int k_begin = blockIdx.y * parts_per_slice, k_end = min(nparts, k_begin + parts_per_slice);
     float s = 0.f;
-    if (n < N) {
-        const int mine = (nparts - rg + 3) / 4;
+    if (n < N && k_begin < k_end) {
+        const int cnt = k_end - k_begin;
+        const int mine = (cnt - rg + 3) / 4;
         for (int k0 = 0; k0 < mine; k0 += 8) {
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = part[(int64_t)(rg + 4 * std::min(k0 + j, mine - 1)) * N + n];
+            for (int j = 0; j < 8; ++j) v[j] = part[(int64_t)(k_begin + rg + 4 * std::min(k0 + j, mine - 1)) * N + n];
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 if (k0 + j < mine) s += v[j];
@@ -1069,7 +1175,22 @@ __global__ __launch_bounds__(256) void pcolsum_finish_kernel(const float* __rest
     }
     red[rg][cl] = s;
     __syncthreads();
-    if (rg == 0 && n < N) out[n] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    if (rg == 0 && n < N) out[(int64_t)blockIdx.y * N + n] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
+constexpr int COLSUM_SLICES = 32;
+// part: [nparts][N] followed by COLSUM_SLICES x N floats of scratch
+static int colsum_finish(float* part, int nparts, int N, float* out, hipStream_t st) {
+    const dim3 block(256);
+    if (nparts <= 2 * COLSUM_SLICES) {
+        hipLaunchKernelGGL(pcolsum_finish_kernel, dim3((unsigned)cdiv(N, 64), 1), block, 0, st, part, nparts, nparts, N, out);
+    } else {
+        float* tmp = part + (size_t)nparts * N;
+        const int per = (int)cdiv(nparts, COLSUM_SLICES);
+        hipLaunchKernelGGL(pcolsum_finish_kernel, dim3((unsigned)cdiv(N, 64), COLSUM_SLICES), block, 0, st, part, nparts, per, N, tmp);
+        hipLaunchKernelGGL(pcolsum_finish_kernel, dim3((unsigned)cdiv(N, 64), 1), block, 0, st, tmp, COLSUM_SLICES, COLSUM_SLICES, N, out);
+    }
+    return hipGetLastError() == hipSuccess ? MSN_OK : MSN_ERR_HIP;
 }
 
 static bool aligned16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1094,7 +1215,7 @@ extern "C" int msn_set_pgemm_variant(int v) {
     return MSN_OK;
 }
 extern "C" int msn_set_pgemm_tile_n(int bn) {
-    MSN_REQUIRE(bn == 0 || bn == 128 || bn == 256, "msn_set_pgemm_tile_n: 0, 128 or 256");
+    MSN_REQUIRE(bn == 0 || bn == 128, "msn_set_pgemm_tile_n: 0 or 128 (the 256-wide tiles were slower on every shape and are no longer built)");
     g_pgemm_bn = bn;
     return MSN_OK;
 }
@@ -1106,7 +1227,7 @@ extern "C" size_t msn_plane_bytes(int64_t R, int64_t C, int planes) {
 
 extern "C" size_t msn_plane_split_colsum_workspace_bytes(int64_t R, int64_t C) {
     if (R <= 0 || C <= 0) return 0;
-    return sizeof(float) * (size_t)cdiv(R, 32) * (size_t)C;
+    return sizeof(float) * ((size_t)cdiv(R, 32) + COLSUM_SLICES) * (size_t)C;
 }
 
 extern "C" int msn_plane_split(const float* x, int64_t ldx, int64_t R, int64_t C, int planes, int transposed, void* out,
@@ -1138,8 +1259,10 @@ extern "C" int msn_plane_split(const float* x, int64_t ldx, int64_t R, int64_t C
     else hipLaunchKernelGGL(plane_split_kernel<2>, grid, dim3(256), 0, st, x, ldx, R, (int)C, RB, CB, static_cast<unsigned char*>(out), part);
     MSN_LAUNCH_CHECK();
     if (colsum) {
-        hipLaunchKernelGGL(pcolsum_finish_kernel, dim3((unsigned)cdiv(C, 64)), dim3(256), 0, st, part, RB, (int)C, colsum);
-        MSN_LAUNCH_CHECK();
+        if (colsum_finish(part, RB, (int)C, colsum, st) != MSN_OK) {
+            set_error("msn_plane_split: column-sum launch failed");
+            return MSN_ERR_HIP;
+        }
     }
     return MSN_OK;
 }
@@ -1156,7 +1279,41 @@ extern "C" int msn_plane_merge(const void* planes_in, int planes, int64_t R, int
 
 extern "C" size_t msn_pgemm_nt_colsum_workspace_bytes(int64_t M, int N) {
     if (M <= 0 || N <= 0) return 0;
-    return sizeof(float) * 4 * (size_t)cdiv(M, BM) * (size_t)N;          // up to 4 wave rows per tile row
+    return sizeof(float) * (4 * (size_t)cdiv(M, BM) + COLSUM_SLICES) * (size_t)N;          // up to 4 wave rows per tile row
+}
+
+// ---- tail split of msn_pgemm_nt: the tiles that do not fill a round of the 256 persistent workgroups
+namespace {
+struct NtTail { int full, segs, steps; };
+static int g_pgemm_tail = 1;
+NtTail nt_tail_plan(int64_t M, int N, int K, int c_planes, int epilogue, bool want_colsum) {
+    NtTail t = {0, 0, 0};
+    if (!g_pgemm_tail || c_planes || want_colsum) return t;
+    if (epilogue != MSN_EPI_NONE && epilogue != MSN_EPI_RELU && epilogue != MSN_EPI_ADD) return t;
+    const int total = (int)(cdiv(M, BM) * cdiv(N, 128)), G = 256;
+    if (total <= G) return t;
+    const int left = total % G, nk = 2 * (int)cdiv(K, 32);
+    if (left == 0 || left > G / 2) return t;
+    int segs = std::min(std::min(G / left, nk / 2), 16);
+    if (segs < 2) return t;
+    t.steps = 2 * (int)cdiv(nk, 2 * segs);
+    t.segs = (int)cdiv(nk, t.steps);
+    t.full = total - left;
+    if (t.segs < 2) t = {0, 0, 0};
+    return t;
+}
+}  // namespace
+extern "C" int msn_set_pgemm_tail_split(int enabled) {
+    g_pgemm_tail = enabled ? 1 : 0;
+    return MSN_OK;
+}
+
+extern "C" size_t msn_pgemm_nt_workspace_bytes(int64_t M, int N, int K, int planes, int c_planes, int epilogue, int want_colsum) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    if (want_colsum) return msn_pgemm_nt_colsum_workspace_bytes(M, N);
+    const NtTail t = nt_tail_plan(M, N, K, c_planes, epilogue, false);
+    const int total = (int)(cdiv(M, BM) * cdiv(N, 128));
+    return t.segs ? sizeof(float) * (size_t)(total - t.full) * t.segs * BM * 128 : 0;
 }
 
 template <int NP, int BN, bool DUAL, int WM = 2, int WN = 4, bool STAG = false>
@@ -1186,9 +1343,8 @@ extern "C" int msn_pgemm_nt(int64_t M, int N, int K, int planes, const void* A, 
     a.cbC = 2 * (int)cdiv(N, 32);
     a.epi = epilogue;
     // tile width 128: the 3-plane form carries two accumulator sets (see the kernel), which fill the register file at 256 x 128;
-    // the 2-plane form measured faster at 128 than at 256 on every headline shape (profiles/r04_pgemm_variants.txt), so the
-    // 256-wide instantiation is only built on request (msn_set_pgemm_tile_n(256), measurements)
-    int bn = (g_pgemm_bn == 256 && planes == 2) ? 256 : 128;
+    // the 2-plane form measured faster at 128 than at 256 on every headline shape (profiles/r04_pgemm_variants.txt)
+    const int bn = 128;
     a.tiles_m = (int)cdiv(M, BM); a.tiles_n = (int)cdiv(N, bn);
     // super-rows: tile-rows walked together while their A panels (256 rows x K x 2 NP bytes) fit half an L2
     a.super_rows = (int)std::max<int64_t>(1, std::min<int64_t>(8, (2 << 20) / ((int64_t)BM * K * 2 * planes)));
@@ -1202,6 +1358,11 @@ extern "C" int msn_pgemm_nt(int64_t M, int N, int K, int planes, const void* A, 
         }
     }
     a.skew = g_pgemm_skew;
+    const NtTail tail = nt_tail_plan(M, N, K, c_planes, epilogue, colsum_out != nullptr);
+    if (tail.segs && ws && ws_bytes >= msn_pgemm_nt_workspace_bytes(M, N, K, planes, c_planes, epilogue, 0) && aligned16p(ws)) {
+        a.tail_full = tail.full; a.tail_segs = tail.segs; a.tail_steps = tail.steps;
+        a.tail_slabs = static_cast<float*>(ws);
+    }
     a.colpart = nullptr;
     if (colsum_out) {
         const size_t need = msn_pgemm_nt_colsum_workspace_bytes(M, N);
@@ -1219,12 +1380,20 @@ extern "C" int msn_pgemm_nt(int64_t M, int N, int K, int planes, const void* A, 
             case 4: launch_nt<3, 128, true, 4, 2, true>(a, c_planes != 0, grid, st); break;
             default: launch_nt<3, 128, true, 4, 2>(a, c_planes != 0, grid, st); break;
         }
-    } else if (bn == 256) launch_nt<2, 256, false>(a, c_planes != 0, grid, st);
-    else launch_nt<2, 128, false>(a, c_planes != 0, grid, st);
+    } else {
+        launch_nt<2, 128, false>(a, c_planes != 0, grid, st);
+    }
     MSN_LAUNCH_CHECK();
-    if (colsum_out) {
-        hipLaunchKernelGGL(pcolsum_finish_kernel, dim3((unsigned)cdiv(N, 64)), dim3(256), 0, st, a.colpart, (a.colsum_rows ? a.colsum_rows : 2) * a.tiles_m, N, colsum_out);
+    if (a.tail_segs) {
+        const int64_t threads = (int64_t)(total - a.tail_full) * (BM * bn / 4);
+        hipLaunchKernelGGL(pgemm_tail_finish_kernel, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, st, a, bn);
         MSN_LAUNCH_CHECK();
+    }
+    if (colsum_out) {
+        if (colsum_finish(a.colpart, (a.colsum_rows ? a.colsum_rows : 2) * a.tiles_m, N, colsum_out, st) != MSN_OK) {
+            set_error("msn_pgemm_nt: column-sum launch failed");
+            return MSN_ERR_HIP;
+        }
     }
     return MSN_OK;
 }
@@ -1258,10 +1427,10 @@ extern "C" size_t msn_pgemm_tn_workspace_bytes(int64_t M, int N, int K, int plan
     return t.splits > 1 ? sizeof(float) * (size_t)t.splits * N * K : 0;
 }
 
-template <int NP, int BQ, bool DUAL>
+template <int NP, int BQ, bool DUAL, int WM = 2, int WN = 4>
 static void launch_tn(const PgemmArgs& a, bool swap, int grid, hipStream_t st) {
-    if (swap) hipLaunchKernelGGL((pgemm_tn_kernel<NP, BQ, true, DUAL>), dim3((unsigned)grid), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((pgemm_tn_kernel<NP, BQ, false, DUAL>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    if (swap) hipLaunchKernelGGL((pgemm_tn_kernel<NP, BQ, true, DUAL, WM, WN>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((pgemm_tn_kernel<NP, BQ, false, DUAL, WM, WN>), dim3((unsigned)grid), dim3(512), 0, st, a);
 }
 
 extern "C" int msn_pgemm_tn(int64_t M, int N, int K, int planes, const void* A, const void* B, float* C, int64_t ldc, void* ws,
@@ -1283,7 +1452,10 @@ extern "C" int msn_pgemm_tn(int64_t M, int N, int K, int planes, const void* A, 
     a.slabs = static_cast<float*>(ws);
     const int grid = t.tiles_p * t.tiles_q * t.splits;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (planes == 3) launch_tn<3, 128, true>(a, t.swap, grid, st);
+    if (planes == 3) {
+        if (g_pgemm_variant == 0 || g_pgemm_variant == 3) launch_tn<3, 128, true>(a, t.swap, grid, st);
+        else launch_tn<3, 128, true, 4, 2>(a, t.swap, grid, st);             // 64 x 64 wave tiles, as the NT kernel
+    }
     else if (t.bq == 256) launch_tn<2, 256, false>(a, t.swap, grid, st);
     else launch_tn<2, 128, false>(a, t.swap, grid, st);
     MSN_LAUNCH_CHECK();

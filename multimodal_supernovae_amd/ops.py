@@ -915,7 +915,11 @@ def attention_bf16_bwd(qkv, out, dout, lse, B, T, heads, scale, want_colsum=Fals
 
 
 # ------------------------------------------------ fp32-grade products from resident bf16 planes (csrc/pgemm.hip)
-PLANES = int(__import__("os").environ.get("MSN_PLANES", "3"))     # planes per operand: 3 = fp32 grade (6 products), 2 = 3 products
+PLANES = int(__import__("os").environ.get("MSN_PLANES", "3"))
+if __import__("os").environ.get("MSN_PGEMM_TAIL"):         # "0": multiply the tail tiles whole (measurements)
+    check(lib().msn_set_pgemm_tail_split(int(__import__("os").environ["MSN_PGEMM_TAIL"])))
+if __import__("os").environ.get("MSN_PGEMM_VARIANT"):      # wave layout / DMA stagger of the 3-plane NT kernel (measurements)
+    check(lib().msn_set_pgemm_variant(int(__import__("os").environ["MSN_PGEMM_VARIANT"])))     # planes per operand: 3 = fp32 grade (6 products), 2 = 3 products
 
 
 class Planes:
@@ -972,11 +976,9 @@ def pgemm_nt(a, w, bias=None, epilogue=EPI_NONE, aux=None, out_planes=False, wan
     if epilogue == EPI_GELU and aux is True:
         aux = torch.empty((M, N), dtype=torch.float32, device=dev)
         ret_aux = True
-    cs, ws, nb = None, None, 0
-    if want_colsum:
-        cs = torch.empty(N, dtype=torch.float32, device=dev)
-        nb = lib().msn_pgemm_nt_colsum_workspace_bytes(M, N)
-        ws = _workspace(nb, dev)
+    cs = torch.empty(N, dtype=torch.float32, device=dev) if want_colsum else None
+    nb = lib().msn_pgemm_nt_workspace_bytes(M, N, K, a.planes, 1 if out_planes else 0, epilogue, 1 if want_colsum else 0)
+    ws = _workspace(nb, dev) if nb else None
     prof = GEMM_PROFILE
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1052,3 +1054,8 @@ def layernorm_bwd_planes(dy, x, mean, rstd, gamma, planes, add=None, want_colsum
 def set_pgemm_variant(v):
     """Wave layout of the 3-plane pgemm_nt kernel (msn_set_pgemm_variant) -- measurements."""
     check(lib().msn_set_pgemm_variant(int(v)))
+
+
+def set_pgemm_tail_split(enabled):
+    """pgemm_nt: cut the tiles that do not fill a round of the persistent workgroups into K-segments (default on)."""
+    check(lib().msn_set_pgemm_tail_split(int(bool(enabled))))

@@ -27,7 +27,17 @@ def _oracle_step(P, batch):
     return oloss.clip_loss_multimodal([e_img, e_lc], P["logit_scale"], P["logit_bias"]), e_img, e_lc
 
 
-def test_headline_step_matches_oracle():
+@pytest.fixture(params=["f32", "bf16x6"])
+def gemm_precision(request):
+    """Both arithmetic routes of the wide products: the native fp32 MFMA kernels and the fp32-grade plane kernels."""
+    from multimodal_supernovae_amd import ops
+    old = ops.GEMM_PRECISION
+    ops.set_gemm_precision(request.param)
+    yield request.param
+    ops.GEMM_PRECISION = old
+
+
+def test_headline_step_matches_oracle(gemm_precision):
     """fp32 tolerance of the north star: loss and embeddings within 1e-3 relative (observed ~1e-6); gradients of every
     parameter within 2e-3 of their own scale."""
     import bench
@@ -54,7 +64,7 @@ def test_headline_step_matches_oracle():
     assert worst < 2e-3, worst
 
 
-def test_full_batch_properties():
+def test_full_batch_properties(gemm_precision):
     """Per-GPU batch 1024 (the bench size): the symmetric InfoNCE is invariant under a common permutation of the pairs,
     embeddings are unit vectors, and a sample's embedding does not depend on the rest of the batch (LayerNorm
     towers): its value inside the 1024-batch equals its value in a 16-sample batch."""
@@ -77,3 +87,25 @@ def test_full_batch_properties():
         torch.testing.assert_close(a[perm], b, rtol=1e-5, atol=1e-6)
     for a, b in zip(e, es):
         torch.testing.assert_close(a[:16], b, rtol=1e-5, atol=2e-6)
+
+
+def test_full_batch_plane_path_matches_fp32_path():
+    """One training step at the bench size (1024 pairs: the persistent plane kernels walk several tiles per workgroup, cut tail
+    tiles and chunk long reductions) under "bf16x6" against the same step under "f32": loss to 1e-5, every gradient to 1e-3
+    of its scale (both routes are fp32 grade; they differ by summation order)."""
+    import bench
+    from multimodal_supernovae_amd import ops
+    batch = bench.synthetic_batch(1024, 11, "cuda")
+    out = {}
+    for prec in ("f32", "bf16x6"):
+        model = bench.build_model("cuda", seed=5)
+        with ops.gemm_precision(prec):
+            loss = model.training_step(batch, 0)
+            loss.backward()
+        out[prec] = (float(loss.detach()), {k: p.grad.detach().clone() for k, p in model.named_parameters()})
+        del model
+    l0, g0 = out["f32"]
+    l1, g1 = out["bf16x6"]
+    assert abs(l1 - l0) <= 1e-5 * abs(l0), (l0, l1)
+    worst = max((float((g1[k] - g0[k]).abs().max()) / (float(g0[k].abs().max()) + 1e-12), k) for k in g0 if k != "logit_bias")
+    assert worst[0] < 1e-3, worst

@@ -51,7 +51,7 @@ def test_nt_exact_on_integers(M, N, K, planes):
     bias = torch.randint(-3, 4, (N,), generator=g).float()
     ref = a.double() @ w.double().T + bias.double()
     ap, wp = ops.plane_split(a.cuda(), planes), ops.plane_split(w.cuda(), planes)
-    for bn in (0, 128, 256):
+    for bn in (0, 128):
         ops.set_pgemm_tile_n(bn)
         try:
             c = ops.pgemm_nt(ap, wp, bias=bias.cuda())
@@ -179,3 +179,51 @@ def test_nt_wave_layouts_exact_on_integers(M, N, K, variant):
         ops.set_pgemm_variant(1)
     assert torch.equal(c.cpu().double(), ref)
     assert torch.equal(cp.to_float().cpu().double(), ref) and torch.equal(cs.cpu().double(), ref.sum(0))
+
+
+@pytest.mark.parametrize("M,N,K", [(66560, 384, 384), (33280, 384, 1536), (20000, 1152, 384), (66560, 384, 192)])
+def test_nt_tail_split(M, N, K):
+    """Tiles that do not fill a round of the 256 persistent workgroups are cut into K-segments + a finishing launch: exact on
+    integers, and equal to the unsplit launch up to the summation order on random data; epilogues NONE / ADD / RELU."""
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    a, w = _ints((M, K), g, -2, 3).cuda(), _ints((N, K), g, -2, 3).cuda()
+    bias = torch.randint(-3, 4, (N,), generator=g).float().cuda()
+    res = torch.randint(-3, 4, (M, N), generator=g).float().cuda()
+    ap, wp = ops.plane_split(a, 3), ops.plane_split(w, 3)
+    ref = a.double() @ w.double().T + bias.double()
+    assert torch.equal(ops.pgemm_nt(ap, wp, bias=bias).double(), ref)
+    assert torch.equal(ops.pgemm_nt(ap, wp, bias=bias, epilogue=ops.EPI_ADD, aux=res).double(), ref + res.double())
+    assert torch.equal(ops.pgemm_nt(ap, wp, bias=bias, epilogue=ops.EPI_RELU).double(), ref.clamp_min(0))
+    x, y = torch.randn(M, K, generator=g).cuda(), torch.randn(N, K, generator=g).cuda()
+    xp, yp = ops.plane_split(x, 3), ops.plane_split(y, 3)
+    c1 = ops.pgemm_nt(xp, yp)
+    ops.set_pgemm_tail_split(False)
+    try:
+        c0 = ops.pgemm_nt(xp, yp)
+    finally:
+        ops.set_pgemm_tail_split(True)
+    torch.testing.assert_close(c1, c0, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(66560, 384, 384), (66560, 1536, 384), (40000, 384, 1536)])
+def test_full_scale_exact_on_integers(M, N, K):
+    """The headline token count: persistent workgroups walk several tiles each, the ring of K-steps runs on across tile
+    boundaries, long reductions go in K chunks, tail tiles are cut.  Every output form, twice (two faults of this kind were
+    intermittent: a copy of a fragment register taken before its LDS read had landed, and a VALU write to the data registers
+    of a 16-byte LDS store one wait state early -- both only with several tiles per workgroup)."""
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    a, w = _ints((M, K), g, -2, 3).cuda(), _ints((N, K), g, -2, 3).cuda()
+    bias = torch.randint(-3, 4, (N,), generator=g).float().cuda()
+    res = torch.randint(-3, 4, (M, N), generator=g).float().cuda()
+    dact = torch.randint(-3, 4, (M, N), generator=g).float().cuda()
+    ap, wp = ops.plane_split(a, 3), ops.plane_split(w, 3)
+    prod = a.double() @ w.double().T
+    for _ in range(2):
+        assert torch.equal(ops.pgemm_nt(ap, wp, bias=bias, out_planes=True).to_float().double(), prod + bias.double())
+        cp, cs = ops.pgemm_nt(ap, wp, epilogue=ops.EPI_GELU_BWD, aux=dact, out_planes=True, want_colsum=True)
+        assert torch.equal(cp.to_float().double(), prod * dact.double()) and torch.equal(cs.double(), (prod * dact.double()).sum(0))
+        assert torch.equal(ops.pgemm_nt(ap, wp, bias=bias, epilogue=ops.EPI_ADD, aux=res).double(), prod + bias.double() + res.double())
+        assert torch.equal(ops.pgemm_nt(ap, wp).double(), prod)
+        assert torch.equal(ops.pgemm_tn(ap, ap).double(), a.double().T @ a.double())
