@@ -1293,7 +1293,9 @@ NtTail nt_tail_plan(int64_t M, int N, int K, int c_planes, int epilogue, bool wa
     const int total = (int)(cdiv(M, BM) * cdiv(N, 128)), G = 256;
     if (total <= G) return t;
     const int left = total % G, nk = 2 * (int)cdiv(K, 32);
-    if (left == 0 || left > G / 2) return t;
+    // short reductions do not gain: a unit's slab (128 KB) and the finishing launch cost what the cut saves (K = 384: proj
+    // 131 -> 131 us, qkv 360 -> 366, fc1 433 -> 448; K = 1536: 511 -> 472, K = 1152: 399 -> 373)
+    if (left == 0 || left > G / 2 || nk < 48) return t;
     int segs = std::min(std::min(G / left, nk / 2), 16);
     if (segs < 2) return t;
     t.steps = 2 * (int)cdiv(nk, 2 * segs);

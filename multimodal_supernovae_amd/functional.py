@@ -946,7 +946,8 @@ class _ConvCL(torch.autograd.Function):
         x = _c(x)
         plain = kh == 1 and kw == 1 and sh == 1 and sw == 1 and ph == 0 and pw == 0
         Cp = C if plain else (C + 3) // 4 * 4
-        implicit = CONV_IMPLICIT and (not plain) and ops.GEMM_PRECISION == ops.PREC_F32 and ops.conv2d_implicit_ok(B, H, W, C, co, kh, kw, sh, sw, ph, pw)
+        implicit = (CONV_IMPLICIT and (not plain) and ops._C_PRECISION[ops.GEMM_PRECISION] == ops.PREC_F32
+                    and ops.conv2d_implicit_ok(B, H, W, C, co, kh, kw, sh, sw, ph, pw))
         oh, ow = ops.conv_out(H, kh, sh, ph), ops.conv_out(W, kw, sw, pw)
         if implicit:
             wmat = ops.conv_weight_relayout(_c(weight), co, ci, kh * kw, True)

@@ -26,7 +26,10 @@ def plane_count(precision=None):
     """Planes per operand of the plane path under `precision` (default: the one in force), or 0 outside it."""
     p = GEMM_PRECISION if precision is None else precision
     return 3 if p == PREC_PLANES3 else 2 if p == PREC_PLANES2 else 0
-GEMM_PRECISION = _PREC_NAMES[__import__("os").environ.get("MSN_GEMM_PRECISION", "f32").lower()]
+# Default "bf16x6": the wide products of the ViT towers run fp32-grade on the bf16 matrix cores from resident planes (the gate
+# for that default: tests/test_pgemm_gpu.py::test_fp32_grade_gate_* + every golden / oracle test at unchanged tolerances;
+# DESIGN.md section 4); every other product is the native fp32 MFMA kernel, exactly as under "f32".
+GEMM_PRECISION = _PREC_NAMES[__import__("os").environ.get("MSN_GEMM_PRECISION", "bf16x6").lower()]
 
 
 class gemm_precision:

@@ -25,6 +25,8 @@ def load(root, name):
                 keys.append("msn::sgemm_*_kernel<*>")
             if "bgemm_nt_kernel" in k or "bgemm_tn_kernel" in k:    # bf16-resident GEMMs (cfg5)
                 keys.append("msn::bgemm_{nt,tn}_kernel<*>")
+            if "pgemm_nt_kernel" in k or "pgemm_tn_kernel" in k:    # plane GEMMs (fp32-grade from resident bf16 planes)
+                keys.append("msn::pgemm_{nt,tn}_kernel<*>")
             for k in keys:
                 e = d[k][r["Counter_Name"]]
                 e[0] += 1
@@ -73,6 +75,16 @@ def main():
                    "traffic_bytes_per_launch": g["traffic_bytes_per_launch"],
                    "mfma_busy_fraction": g["mfma_util"], "effective_clock_ghz": g["clock_ghz"], "launches": g["launches"],
                    "workload": f"bench.py --workload {workload} --per-gpu-batch {rows}",
+                   "collected": datetime.date.today().isoformat(), "commit": commit,
+                   "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES passes, tools/summarize_pmc.py"},
+                  open(os.path.join(os.path.dirname(out), name), "w"), indent=1)
+    pg = summary.get("msn::pgemm_{nt,tn}_kernel<*>")
+    if pg:
+        name = "pmc_pgemm.json" if (workload == "vit_s8_lc" and rows == 1024) else f"pmc_pgemm_{workload}_b{rows}.json"
+        json.dump({"kernel": "msn::pgemm_nt_kernel + msn::pgemm_tn_kernel (plane GEMM launches)",
+                   "traffic_bytes_per_launch": pg["traffic_bytes_per_launch"],
+                   "mfma_busy_fraction": pg["mfma_util"], "effective_clock_ghz": pg["clock_ghz"], "launches": pg["launches"],
+                   "workload": f"bench.py --workload {workload} --per-gpu-batch {rows} " + extra,
                    "collected": datetime.date.today().isoformat(), "commit": commit,
                    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES passes, tools/summarize_pmc.py"},
                   open(os.path.join(os.path.dirname(out), name), "w"), indent=1)
