@@ -727,7 +727,8 @@ static int sgemm_impl(int opA, int opB, int64_t M, int64_t N, int64_t K, const f
 
     if (conv == 0 && colsum_out == nullptr && precision == MSN_PREC_F32 && g_gemm_variant == 3 && streamk_shape(opA, M, N, K)) {
         const msn_gemm_desc d{opA, opB, M, N, K, A, lda, B, ldb, C, ldc, bias, epilogue, aux, ldaux, nullptr};
-        if (gemm_list_takes(1, &d) && ws && ws_bytes >= gemm_list_ws_bytes())
+        // (a stream beyond the 32 counter slices of its device keeps the flat launch below: the work-list kernel needs one)
+        if (gemm_list_takes(1, &d) && ws && ws_bytes >= gemm_list_ws_bytes() && gemm_counter_slice(static_cast<hipStream_t>(stream)))
             return gemm_list_launch(1, &d, ws, ws_bytes, static_cast<hipStream_t>(stream));
     }
     GemmArgs a;
@@ -981,9 +982,15 @@ extern "C" int msn_set_gemm_streamk(int max_tiles, int min_k) {
 }
 
 extern "C" int msn_reset_gemm_counters(msn_stream_t stream) {
-    void* sym = nullptr;
-    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_tail_counters)) != hipSuccess ||
-        hipMemsetAsync(sym, 0, sizeof(unsigned) * kTailSlices * kTailSliceTiles, static_cast<hipStream_t>(stream)) != hipSuccess) {
+    // only the slice this stream owns: the other slices belong to streams whose tail-split / work-list kernels may be in
+    // flight (the towers of a step run concurrently), and zeroing their counters under them would leave a cut tile with no
+    // finisher or with two.  A stream without a slice has nothing to reset.
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return MSN_OK;   // never record it into a graph
+    unsigned* slice = tail_counter_slice(st);
+    if (!slice) return MSN_OK;
+    if (hipMemsetAsync(slice, 0, sizeof(unsigned) * kTailSliceTiles, st) != hipSuccess) {
         set_error("msn_reset_gemm_counters: %s", hipGetErrorString(hipGetLastError()));
         return MSN_ERR_HIP;
     }

@@ -133,40 +133,54 @@ __global__ __launch_bounds__(512, 2) void bgemm_nt_kernel(const BgemmArgs p) {
         m0_ = (int64_t)tm_ * BT;
         n0_ = (j / rows_sr) * BT;
     };
-    // ---- LDS-DMA sources: wave w moves pieces 4w .. 4w+3 (8 rows x 128 B each) of both operands
-    auto make_src = [&](const u16* (&sa)[4], const u16* (&sb)[4], int64_t m0_, int n0_) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int R = 8 * (4 * wave + q) + (lane >> 3);
-            const int c = (lane & 7) ^ swz(R);
+    // ---- LDS-DMA sources: wave w moves pieces 4w .. 4w+3 (8 rows x 128 B each) of both operands, by BUFFER loads
+    // (buffer_load_dwordx4 ... lds): one resource descriptor per operand and requested tile (base = the tile's first row,
+    // num_records = the bytes from there to the end of the matrix, in SGPRs) + a 32-bit per-lane byte offset.  Rows past the
+    // edge of the matrix are out of range for the descriptor and read as zeros -- no clamping -- and the eight 64-bit per-lane
+    // pointers of rounds 2-3 (16 VGPRs: the kernel stood at 255 with 12 bytes of scratch per lane) are gone.
+    // (The bounds check covers the per-lane offset, not the scalar one: the K-tile advance goes into the scalar offset, the
+    // row of a piece into the per-lane one.)
+    const int lrow = lane >> 3;
+    __amdgpu_buffer_rsrc_t rsrcA, rsrcB;      // of the tile whose K-tiles are being REQUESTED: the next tile's from its last-but-one K-tile on
+    auto make_src = [&](int64_t m0_, int n0_) {
 #ifdef MSN_ABL_BF_SAMEPANEL               // diagnostic build: every tile reads the panels of tile (0, 0) -- L2 hits only
-            const int64_t ra = R, rb = R;
-#else
-            const int64_t ra = std::min<int64_t>(m0_ + R, p.M - 1);        // rows past the edge: clamped, never stored
-            const int64_t rb = std::min<int64_t>((int64_t)n0_ + R, p.N - 1);
+        m0_ = 0, n0_ = 0;
 #endif
-            sa[q] = p.A + ra * p.lda + 8 * c;
-            sb[q] = p.B + rb * p.ldb + 8 * c;
-        }
+        const int64_t bytesA = std::max<int64_t>(p.M - m0_, 0) * p.lda * 2, bytesB = std::max<int64_t>((int64_t)p.N - n0_, 0) * p.ldb * 2;
+        rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.A + m0_ * p.lda), (short)0,
+                                                  (int)std::min<int64_t>(bytesA, 0x7fffffff), 0x00020000);
+        rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.B + (int64_t)n0_ * p.ldb), (short)0,
+                                                  (int)std::min<int64_t>(bytesB, 0x7fffffff), 0x00020000);
     };
+    // per-lane byte offsets inside a piece: row lrow, 16-byte chunk (lane & 7) ^ swz(row)
+    // (swz depends on the row inside the tile: rows 8 q' + lrow with q' = 4 wave + q -> (row >> 1) & 7 = (4 q' + (lrow >> 1)) & 7;
+    //  4 q' & 7 is 0 or 4 by the parity of q, so two offsets per operand cover the four pieces)
+    unsigned offA[2], offB[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int sw = ((4 * par) + (lrow >> 1)) & 7;
+        const int c = (lane & 7) ^ sw;
+        offA[par] = (unsigned)(lrow * p.lda * 2 + 16 * c);
+        offB[par] = (unsigned)(lrow * p.ldb * 2 + 16 * c);
+    }
+    const unsigned pieceA = (unsigned)(8 * p.lda * 2), pieceB = (unsigned)(8 * p.ldb * 2);    // bytes from one piece to the next
     int t = blockIdx.x, tm, n0, tm_next = 0, n0_next = 0;
     int64_t m0, m0_next = 0;
     locate(t, m0, n0, tm);
-    const u16* srcA[4];            // of the tile whose K-tiles are being REQUESTED: the next tile's from its last-but-one K-tile on
-    const u16* srcB[4];
-    make_src(srcA, srcB, m0, n0);
+    make_src(m0, n0);
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t*)lds;   // LDS byte address of the array
-    auto issue = [&](int buf, const u16* const (&sa)[4], const u16* const (&sb)[4], int kt) {
+    auto issue = [&](int buf, int kt) {
 #ifdef MSN_ABL_BF_NODMA
         return;                            // diagnostic build (tools/microbench/build_ablate.sh): no operand traffic at all
 #endif
         unsigned char* dst = lds + buf * STAGE_BYTES + wave * 4096;
+        const int koff = kt * (BKS * 2);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            __builtin_amdgcn_global_load_lds((gptr_t*)(sa[q] + (int64_t)kt * BKS), (lptr_t*)(dst + q * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lptr_t*)(dst + q * 1024), 16, offA[q & 1] + (unsigned)(4 * wave + q) * pieceA, koff, 0, 0);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            __builtin_amdgcn_global_load_lds((gptr_t*)(sb[q] + (int64_t)kt * BKS), (lptr_t*)(dst + OPER_BYTES + q * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t*)(dst + OPER_BYTES + q * 1024), 16, offB[q & 1] + (unsigned)(4 * wave + q) * pieceB, koff, 0, 0);
     };
 
     // ---- fragment addresses: wave (wm, wn) owns rows 128 wm .. +127 of A, rows (= output columns) 64 wn .. +63 of B
@@ -276,10 +290,10 @@ __global__ __launch_bounds__(512, 2) void bgemm_nt_kernel(const BgemmArgs p) {
     };
 
     const int nkt = p.K / BKS;             // >= 2 whenever gridDim.x < total (host)
-    issue(0, srcA, srcB, 0);
+    issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (nkt > 1) issue(1, srcA, srcB, 1);
+    if (nkt > 1) issue(1, 1);
     unsigned gs = 0;                       // K-tiles this workgroup has started, over all its tiles: K-tile gs sits in buffer gs & 1
     for (;;) {
         const int t_next = t + (int)gridDim.x;
@@ -319,13 +333,13 @@ __global__ __launch_bounds__(512, 2) void bgemm_nt_kernel(const BgemmArgs p) {
             // here, the other behind its MULT -- gains 5 % on long K in isolation and nothing in the training step; issuing later
             // still loses: the pieces land too late for the next barrier.  Build with -DMSN_BGEMM_STAGGER=1 to try.)
             auto refill = [&]() {
-                if (kt + 2 < nkt) issue(cur, srcA, srcB, kt + 2);
+                if (kt + 2 < nkt) issue(cur, kt + 2);
                 else if (more) {                               // the ring runs on into the next tile
                     if (kt + 2 == nkt) {                       // (this tile's last K-tile was requested one K-tile ago)
                         locate(t_next, m0_next, n0_next, tm_next);
-                        make_src(srcA, srcB, m0_next, n0_next);
+                        make_src(m0_next, n0_next);
                     }
-                    issue(cur, srcA, srcB, kt + 2 - nkt);
+                    issue(cur, kt + 2 - nkt);
                 }
             };
             if (wave < 4 || !g_stagger) refill();

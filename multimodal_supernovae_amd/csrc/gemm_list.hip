@@ -409,7 +409,9 @@ extern "C" int msn_set_gemm_list(int enabled) {
 
 extern "C" int msn_sgemm_list(int n, const msn_gemm_desc* d, int precision, void* ws, size_t ws_bytes, msn_stream_t stream) {
     MSN_REQUIRE(d && n >= 1 && n <= kListMax, "msn_sgemm_list: 1 .. %d products", kListMax);
-    if (g_gemm_list && precision == MSN_PREC_F32 && gemm_list_takes(n, d))
+    // (slices of arrival counters are keyed by stream handle and never released -- 32 per device; a long-lived process that has
+    // used more streams than that gets the one-by-one path on the later ones instead of an error)
+    if (g_gemm_list && precision == MSN_PREC_F32 && gemm_list_takes(n, d) && gemm_counter_slice(static_cast<hipStream_t>(stream)))
         return gemm_list_launch(n, d, ws, ws_bytes, static_cast<hipStream_t>(stream));
     for (int i = 0; i < n; ++i) {
         int rc;

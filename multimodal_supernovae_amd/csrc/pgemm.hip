@@ -1208,7 +1208,7 @@ extern "C" int msn_set_pgemm_skew(int cycles) {
 static int g_pgemm_chunk = 0;       // K-steps per chunk of the 3-plane NT kernel (0 = whole reduction; experiments)
 static int g_pgemm_variant = 1;     // 3-plane NT kernel: 0 = 2 x 4 waves, 1 = 4 x 2 (default), 3 / 4 = 0 / 1 with staggered DMA issue
 extern "C" int msn_set_pgemm_variant(int v) {
-    MSN_REQUIRE(v >= 0 && v <= 4 + 1000 * 1000, "msn_set_pgemm_variant: 0 .. 4 (+ 1000 * K-steps per chunk)");
+    MSN_REQUIRE(v >= 0 && v % 1000 <= 4 && v / 1000 <= 1000, "msn_set_pgemm_variant: 0 .. 4 (+ 1000 * K-steps per chunk)");
     g_pgemm_chunk = v / 1000;
     v %= 1000;
     g_pgemm_variant = v;
@@ -1375,8 +1375,8 @@ extern "C" int msn_pgemm_nt(int64_t M, int N, int K, int planes, const void* A, 
     const int grid = std::min(total, 256);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (planes == 3) {
-        a.colsum_rows = g_pgemm_variant == 1 || g_pgemm_variant == 4 ? 4 : 2;
-        switch (g_pgemm_variant) {
+        a.colsum_rows = (g_pgemm_variant == 0 || g_pgemm_variant == 3) ? 2 : 4;
+        switch (g_pgemm_variant) {        // (2 = the default NT layout + the 4 x 2 TN kernel)
             case 0: launch_nt<3, 128, true>(a, c_planes != 0, grid, st); break;
             case 3: launch_nt<3, 128, true, 2, 4, true>(a, c_planes != 0, grid, st); break;
             case 4: launch_nt<3, 128, true, 4, 2, true>(a, c_planes != 0, grid, st); break;
@@ -1454,9 +1454,11 @@ extern "C" int msn_pgemm_tn(int64_t M, int N, int K, int planes, const void* A, 
     a.slabs = static_cast<float*>(ws);
     const int grid = t.tiles_p * t.tiles_q * t.splits;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // (2 x 4 waves: the 64 x 64 wave tiles that gain 7-12 % on the NT kernel LOSE 3-4 % here -- 374 / 151 / 452 / 454 us
+    // against 384 / 157 / 469 / 470 on the four headline weight gradients; msn_set_pgemm_variant(2) selects them)
     if (planes == 3) {
-        if (g_pgemm_variant == 0 || g_pgemm_variant == 3) launch_tn<3, 128, true>(a, t.swap, grid, st);
-        else launch_tn<3, 128, true, 4, 2>(a, t.swap, grid, st);             // 64 x 64 wave tiles, as the NT kernel
+        if (g_pgemm_variant == 2) launch_tn<3, 128, true, 4, 2>(a, t.swap, grid, st);
+        else launch_tn<3, 128, true>(a, t.swap, grid, st);
     }
     else if (t.bq == 256) launch_tn<2, 256, false>(a, t.swap, grid, st);
     else launch_tn<2, 128, false>(a, t.swap, grid, st);

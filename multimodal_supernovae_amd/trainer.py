@@ -220,6 +220,17 @@ class _RecordedStep:
         self.items.append(("graph", self.cur))
         self.cur = None
 
+    def abort(self):
+        """A recording that failed half-way: close the segment under capture (the stream must not stay in capture mode) and
+        drop every segment recorded so far."""
+        if self.cur is not None:
+            try:
+                self.cur.capture_end()
+            except Exception:          # noqa: BLE001 -- the capture is already invalid; the original error is the one to report
+                pass
+        self.cur = None
+        self.items = []
+
     def replay(self):
         for kind, x in self.items:
             if kind == "graph":
@@ -302,14 +313,20 @@ class GraphedTrainStep:
         ops.GRAPH_SEED = [seed0, 0]
         self._seed_base = seed0
         torch.cuda.synchronize()
-        if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        if dist.is_available() and dist.is_initialized() and dist.get_backend(self.group) == "nccl":
             import time
-            time.sleep(0.35)                  # > 3 sweeps of the process group's watchdog: the warm-up steps' finished work is retired
+            # the warm-up steps' finished RCCL work must be retired by the process group's watchdog before a segment is under
+            # capture (it polls with hipEventQuery): a barrier + synchronize makes the work complete, then > 3 watchdog sweeps
+            # (TORCH_NCCL_HEARTBEAT... is not what paces it: the sweep period is 100 ms; MSN_WATCHDOG_QUIESCE_S overrides)
+            dist.barrier(self.group)
+            torch.cuda.synchronize()
+            time.sleep(float(__import__("os").environ.get("MSN_WATCHDOG_QUIESCE_S", "0.35")))
         torch.cuda.empty_cache()              # (it must not be polled while a segment is under capture, see _RecordedStep.exchange)
         rec = _RecordedStep(device)
         stream = torch.cuda.Stream(device=device)
         stream.wait_stream(torch.cuda.current_stream(device))
         D.SEGMENTED_CAPTURE = rec
+        failure = None
         try:
             with torch.cuda.stream(stream):
                 rec.begin()
@@ -320,11 +337,25 @@ class GraphedTrainStep:
                     self.reducer.finish()
                 self.optimizer.step()
                 rec.end()
+        except Exception as exc:   # noqa: BLE001 -- out of memory in the private pool, an op that is illegal under capture, ...
+            failure = exc
+            rec.abort()            # leave capture mode, drop the segments: the next call must not record on a poisoned stream
         finally:
             D.SEGMENTED_CAPTURE = None
             ops.GRAPH_SEED = None
             model.concurrent_towers = concurrent
         torch.cuda.current_stream(device).wait_stream(stream)
+        if self.world > 1:
+            # every rank must have a recording before any rank replays: the first replay carries out the step's collectives,
+            # and a rank that failed to record would leave the others waiting in them
+            ok = torch.tensor([0.0 if failure is not None else 1.0], device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.SUM, group=self.group)       # (not a step collective: kept out of COMM_LOG)
+            if failure is None and float(ok) < self.world:
+                rec.abort()
+                failure = RuntimeError("GraphedTrainStep: another rank failed to record the step")
+        if failure is not None:
+            self.static, self.loss = None, None
+            raise failure
         self.graph = rec
 
     def static_device(self):

@@ -245,3 +245,26 @@ def test_fuzz_lists_against_fp64():
             assert _rel(c, ref) < 4e-6, (case, what, rows, [(d.M, d.N, d.K, d.opA, d.opB, d.epilogue) for d in descs])
         ops.sgemm_list(descs)
         assert all(torch.equal(c, f) for (c, _), f in zip(checks, first)), case
+
+
+def test_more_streams_than_counter_slices():
+    """The arrival-counter slices of the in-kernel tile finishes are keyed by stream (32 per device, never released): the
+    33rd stream of a long-lived process must get the flat / one-by-one launches, not an error (round-3 advisor finding)."""
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(3)
+    rows, n_out, n_in = 1024, 256, 1536
+    dy = torch.randn(rows, n_out, generator=g).cuda()
+    w = torch.randn(n_out, n_in, generator=g).cuda()
+    x = torch.randn(rows, n_in, generator=g).cuda()
+    ref_dx, ref_dw, ref_db = dy.double() @ w.double(), dy.double().T @ x.double(), dy.double().sum(0)
+    streams = [torch.cuda.Stream() for _ in range(40)]
+    for s in streams:
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            dx, dw, db = ops.dgrad_wgrad(dy, w, x)
+            c = ops.sgemm(dy, w, ops.OP_N, ops.OP_N)             # long-K single product: the stream-K detour of msn_sgemm
+        s.synchronize()
+        torch.testing.assert_close(dx.double(), ref_dx, rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(dw.double(), ref_dw, rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(db.double(), ref_db, rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(c.double(), ref_dx, rtol=1e-4, atol=1e-3)

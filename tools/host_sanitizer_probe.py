@@ -31,4 +31,18 @@ print(L.msn_infonce_workspace_bytes(128, 128, 1024, 1024, 128), L.msn_wgrad_bias
 for bad in (lambda: L.msn_set_gemm_streamk(-1, 0), lambda: L.msn_set_gemm_lds_pad(1 << 30), lambda: L.msn_set_attention_path(7),
             lambda: L.msn_sgemm_list(0, None, 0, None, 0, None), lambda: L.msn_sgemm_list(4, ctypes.cast(d, ctypes.c_void_p), 0, None, 0, None)):
     assert bad() == 1, L.msn_last_error()
+# plane GEMMs (pgemm.hip): sizes, launch plans and the argument checks that return before a launch
+print("plane bytes", L.msn_plane_bytes(66560, 384, 3), L.msn_plane_bytes(33, 17, 2), L.msn_plane_bytes(0, 4, 3))
+print("pgemm ws", L.msn_pgemm_tn_workspace_bytes(66560, 1152, 384, 3), L.msn_pgemm_tn_workspace_bytes(66560, 384, 1536, 2),
+      L.msn_pgemm_nt_workspace_bytes(66560, 384, 1536, 3, 0, 0, 0), L.msn_pgemm_nt_workspace_bytes(66560, 1536, 384, 3, 1, 4, 1),
+      L.msn_plane_split_colsum_workspace_bytes(66560, 1152))
+for bad in (lambda: L.msn_plane_split(None, 4, 4, 4, 3, 0, None, None, None, 0, None),
+            lambda: L.msn_plane_split(fake, 4, 4, 4, 5, 0, fake, None, None, 0, None),
+            lambda: L.msn_pgemm_nt(256, 130, 64, 3, fake, fake, fake, 132, 0, None, 0, None, 0, None, None, 0, None),
+            lambda: L.msn_pgemm_nt(256, 128, 64, 3, fake, fake, fake, 128, 0, None, 5, None, 0, None, None, 0, None),
+            lambda: L.msn_pgemm_nt(256, 128, 64, 4, fake, fake, fake, 128, 0, None, 0, None, 0, None, None, 0, None),
+            lambda: L.msn_pgemm_tn(256, 128, 66, 3, fake, fake, fake, 66, None, 0, None),
+            lambda: L.msn_set_pgemm_tile_n(256), lambda: L.msn_set_pgemm_variant(9),
+            lambda: L.msn_layernorm_fwd_planes(fake, 384, 8, 384, fake, fake, 1e-6, 5, fake, None, 0, fake, fake, None)):
+    assert bad() == 1, L.msn_last_error()
 print("HOST SANITIZER PROBE OK")
