@@ -8,6 +8,9 @@
  * reference maintainer would add.
  *
  * Conventions
+ *  - the msn_set_* entry points are process-wide measurement / test switches (unsynchronised statics of the library): set them
+ *    once, before work is enqueued, from the thread that enqueues it -- they are not thread-safe (INTEGRATION.md, round-4 notes);
+ *    the data path keeps no mutable global state besides the mutex-protected arrival-counter slices of the work-list kernels;
  *  - every function returns 0 on success, MSN_ERR_SHAPE for a rejected argument (nothing
  *    is launched) or MSN_ERR_HIP for a failed launch; msn_last_error() gives the text;
  *  - all pointers are DEVICE pointers to fp32 unless stated (masks: 1 byte / element);

@@ -1291,8 +1291,21 @@ NtTail nt_tail_plan(int64_t M, int N, int K, int c_planes, int epilogue, bool wa
     if (!g_pgemm_tail || c_planes || want_colsum) return t;
     if (epilogue != MSN_EPI_NONE && epilogue != MSN_EPI_RELU && epilogue != MSN_EPI_ADD) return t;
     const int total = (int)(cdiv(M, BM) * cdiv(N, 128)), G = 256;
+    const int nk = 2 * (int)cdiv(K, 32);
+    if (total <= G / 2) {
+        // fewer tiles than half the chip (the 128 - 256 rows per GPU of a strong-scaling run): EVERY tile is cut, so that the
+        // product's K-steps spread over the idle CUs (99 tiles of K = 1536: 70 -> 40 us)
+        if (nk < 24) return t;
+        int segs = std::min(std::min(G / total, nk / 4), 8);
+        if (segs < 2) return t;
+        t.steps = 2 * (int)cdiv(nk, 2 * segs);
+        t.segs = (int)cdiv(nk, t.steps);
+        t.full = 0;
+        if (t.segs < 2) t = {0, 0, 0};
+        return t;
+    }
     if (total <= G) return t;
-    const int left = total % G, nk = 2 * (int)cdiv(K, 32);
+    const int left = total % G;
     // short reductions do not gain: a unit's slab (128 KB) and the finishing launch cost what the cut saves (K = 384: proj
     // 131 -> 131 us, qkv 360 -> 366, fc1 433 -> 448; K = 1536: 511 -> 472, K = 1152: 399 -> 373)
     if (left == 0 || left > G / 2 || nk < 48) return t;
@@ -1372,7 +1385,8 @@ extern "C" int msn_pgemm_nt(int64_t M, int N, int K, int planes, const void* A, 
         a.colpart = static_cast<float*>(ws);
     }
     const int total = a.tiles_m * a.tiles_n;
-    const int grid = std::min(total, 256);
+    // one persistent workgroup per CU; a launch whose tiles are ALL cut (tail_full == 0) has one workgroup per unit
+    const int grid = a.tail_segs ? std::max(a.tail_full ? 256 : 0, (total - a.tail_full) * a.tail_segs) : std::min(total, 256);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (planes == 3) {
         a.colsum_rows = (g_pgemm_variant == 0 || g_pgemm_variant == 3) ? 2 : 4;

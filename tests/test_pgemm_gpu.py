@@ -181,7 +181,8 @@ def test_nt_wave_layouts_exact_on_integers(M, N, K, variant):
     assert torch.equal(cp.to_float().cpu().double(), ref) and torch.equal(cs.cpu().double(), ref.sum(0))
 
 
-@pytest.mark.parametrize("M,N,K", [(66560, 384, 768), (33280, 384, 1536), (20000, 1152, 1152), (66560, 384, 1152)])
+@pytest.mark.parametrize("M,N,K", [(66560, 384, 768), (33280, 384, 1536), (20000, 1152, 1152), (66560, 384, 1152),
+                                   (8320, 384, 1536), (8320, 384, 384), (16640, 384, 768), (8000, 1152, 384)])
 def test_nt_tail_split(M, N, K):
     """Tiles that do not fill a round of the 256 persistent workgroups are cut into K-segments + a finishing launch: exact on
     integers, and equal to the unsplit launch up to the summation order on random data; epilogues NONE / ADD / RELU."""

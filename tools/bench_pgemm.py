@@ -47,11 +47,8 @@ def main():
                     line += f" | 3pl v{v} {fl / t / 1e12:6.1f} ({t * 1e6:6.0f} us)"
                 ops.set_pgemm_variant(1)
             else:
-                for bn in (128, 256):
-                    ops.set_pgemm_tile_n(bn)
-                    t = timed(lambda: ops.pgemm_nt(ap, wp))
-                    line += f" | {pl}pl bn{bn} {fl / t / 1e12:6.1f} ({t * 1e6:6.0f} us)"
-                ops.set_pgemm_tile_n(0)
+                t = timed(lambda: ops.pgemm_nt(ap, wp))
+                line += f" | {pl}pl {fl / t / 1e12:6.1f} ({t * 1e6:6.0f} us)"
             tp = timed(lambda: ops.pgemm_nt(ap, wp, out_planes=True))
             line += f" planes-out {fl / tp / 1e12:6.1f} ({tp * 1e6:5.0f} us)"
             if N % 16 == 0 and os.environ.get("GELU"):

@@ -15,7 +15,7 @@ if [ "$1" = pmc ]; then
   cp "$ROOT"/gpurun_out/pmc_*.json "$ROOT/gpurun_out/final/"
 else
   cd /tmp && export TMPDIR=/tmp
-  for cfg in "vit-s8_b1024:" "vit-s8_b128:--per-gpu-batch 128" "vit-s8_b256:--per-gpu-batch 256" "vit_b16_bf16_b512:--workload vit_b16_bf16_lc --per-gpu-batch 512" "maven_lc_sp_b1024:--workload maven_lc_sp"; do
+  for cfg in "vit-s8_b1024:" "vit-s8_b128:--per-gpu-batch 128" "vit-s8_b256:--per-gpu-batch 256" "vit_b16_bf16_b512:--workload vit_b16_bf16_lc --per-gpu-batch 512" "maven_lc_sp_b1024:--workload maven_lc_sp" "convmixer_lc_sp_b1024:--workload convmixer_lc_sp" "vit_s8_lc_cnn1d_sp_b256:--workload vit_s8_lc_cnn1d_sp --per-gpu-batch 256" "resnet18_cnn1d_b256:--workload resnet18_cnn1d --per-gpu-batch 256"; do
     tag=${cfg%%:*}; flags=${cfg#*:}
     echo "== kernel trace $tag"
     rm -rf "$ROOT/gpurun_out/trace_$tag"
