@@ -738,7 +738,17 @@ static int sgemm_impl(int opA, int opB, int64_t M, int64_t N, int64_t K, const f
     const Plan pl = plan(M, N, K, opA, colsum_out == nullptr, conv != 0);
     // (short tiles: M <= bm, one row of tiles either way; of the implicit convolutions only the weight gradient of a 64-channel layer
     // -- 64 x (taps x C) over all output pixels: ResNet-18's first stage -- has a 64-row kernel, the others keep 128 rows)
-    const int bm = conv != 0 ? ((conv == 2 && pl.bm == 64 && pl.bn == 128) ? 64 : 128) : pl.bm, bn = pl.bn, splits = pl.splits, kps = pl.kps;
+    int bm = conv != 0 ? ((conv == 2 && pl.bm == 64 && pl.bn == 128) ? 64 : 128) : pl.bm;
+    const int bn = pl.bn, splits = pl.splits, kps = pl.kps;
+    {   // the 32- / 64-row tiles exist among the LDS-DMA kernels only: a product those do not take (K % 32 != 0, unaligned
+        // operands, msn_set_gemm_variant(0)) runs on the 128-row register-staged kernels -- with the 64-row plan it would launch
+        // twice the workgroups, every second one multiplying rows that do not exist (round-3 advisor finding)
+        const int64_t a_ext0 = opA == MSN_OP_T ? M : K, b_ext0 = opB == MSN_OP_N ? N : K;
+        const bool dma_pre = (g_gemm_variant != 0 || conv != 0) && K % BK == 0 && (lda % 4 == 0) && (ldb % 4 == 0) && (a_ext0 % 4 == 0) &&
+                             (b_ext0 % 4 == 0) && a_ext0 >= 4 && b_ext0 >= 4 &&
+                             ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
+        if (!dma_pre && conv == 0 && bm != 128) bm = 128;
+    }
     a.colsum = nullptr;
     a.tiles_m = (int)cdiv(M, bm);
     a.tiles_n = (int)cdiv(N, bn);
@@ -793,7 +803,9 @@ static int sgemm_impl(int opA, int opB, int64_t M, int64_t N, int64_t K, const f
     }
     if (colsum_done) *colsum_done = fuse_colsum;
     int waves = 4;   // per workgroup of the kernel chosen (the tail pass mirrors its register layout)
-    if (bm != 128) bf16_ok = false;   // the short tiles exist for the fp32 kernels only (tiny products: exact fp32 costs nothing)
+    if (bm != 128 && M <= 64) bf16_ok = false;   // the short tiles of products with few rows exist for the fp32 kernels only (tiny
+                                                 // products: exact fp32 costs nothing); a tall product keeps the precision it was asked for
+    if (bf16_ok && bm != 128) bm = 128, a.tiles_m = (int)cdiv(M, bm);
     if (conv != 0) {   // implicit-GEMM convolution: the 4-wave LDS-DMA kernels only
         MSN_REQUIRE(dma_ok && !bf16_ok && bn >= 64, "implicit convolution: shape not taken by the LDS-DMA kernels");
         if (bm == 64) rc = launch_dma_conv<64, 128, 32, 64, 32, 2>(a, conv, opB, st);
