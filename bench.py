@@ -511,9 +511,12 @@ def main():
         achieved *= products        # executed bf16 MFMA flops
     # dense matrix peak of the instruction the dominant kernel issues (MI355X_MICROARCH.md): fp32 157.3 TFLOP/s;
     # bf16 2500 TFLOP/s, of which the 3-product split can deliver at most a third as algorithmic flops
-    peak = {"f32": 157.3, "bf16x6": 2500.0, "bf16x3p": 2500.0, "bf16x3": 2500.0, "bf16": 2500.0}[args.gemm_precision]
-    kernel_name = GEMM_KERNEL_NAME[args.gemm_precision]
-    if args.workload == "vit_b16_bf16_lc" and args.gemm_precision == "f32":
+    # (a plane precision on a workload without products wide enough for the plane kernels -- the reference-native towers, the
+    # convolution towers -- runs every product on the native fp32 kernels: its roofline is the fp32 one)
+    eff_precision = "f32" if (args.gemm_precision in ("bf16x6", "bf16x3p") and not products) else args.gemm_precision
+    peak = {"f32": 157.3, "bf16x6": 2500.0, "bf16x3p": 2500.0, "bf16x3": 2500.0, "bf16": 2500.0}[eff_precision]
+    kernel_name = GEMM_KERNEL_NAME[eff_precision]
+    if args.workload == "vit_b16_bf16_lc" and eff_precision == "f32":
         peak = 2500.0           # the image tower of cfg5 issues bf16 MFMAs whatever the process default is
         kernel_name = ("msn::bgemm_nt_kernel + msn::bgemm_tn_kernel (bf16-resident operands, 256x256 tiles, LDS-DMA, "
                        "v_mfma_f32_16x16x32_bf16; the image tower's launches -- the light-curve tower's fp32 products: fp32_launches)")
@@ -563,7 +566,7 @@ def main():
         pmc_name = f"pmc_{'pgemm' if products else 'sgemm'}_{args.workload}_b{b}.json"      # tools/run_pmc.sh --workload W --per-gpu-batch B
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
-        if args.gemm_precision == "f32" or products:       # per launch on ONE GPU: the same whatever the number of ranks (rows per GPU match)
+        if eff_precision == "f32" or products:       # per launch on ONE GPU: the same whatever the number of ranks (rows per GPU match)
             traffic = pmc["traffic_bytes_per_launch"]
             traffic_source = (f"profiles/{pmc_name}: rocprofv3 --pmc passes of `{pmc.get('workload', 'python bench.py')}` "
                               f"(tools/run_pmc.sh), collected {pmc.get('collected', '?')} at commit {pmc.get('commit', '?')}; "
@@ -657,7 +660,8 @@ def main():
                        if headline else WORKLOADS[args.workload] + " (non-headline configuration)",
                        "per_gpu_batch": b, "global_batch": b * world, "parallelism": f"dp{world}",
                        "launch": "HIP graph replay" if args.graphed else "eager",
-                       "gemm_arithmetic": GEMM_ARITHMETIC[args.gemm_precision],
+                       "gemm_arithmetic": GEMM_ARITHMETIC[eff_precision] if args.workload != "vit_b16_bf16_lc" else
+                       "image tower: operands rounded to bf16, resident in HBM (BASELINE cfg5 arithmetic); light-curve tower: native fp32 MFMA",
                        "untimed_steps_after_warmup": untimed_extra,
                        "loss": loss_value, "algorithmic_gflop_per_pair": flops_per_pair() / 1e9,
                        "executed_gflop_per_pair": flops_per_pair(executed=True) / 1e9,
