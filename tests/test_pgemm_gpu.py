@@ -228,3 +228,19 @@ def test_full_scale_exact_on_integers(M, N, K):
         assert torch.equal(ops.pgemm_nt(ap, wp, bias=bias, epilogue=ops.EPI_ADD, aux=res).double(), prod + bias.double() + res.double())
         assert torch.equal(ops.pgemm_nt(ap, wp).double(), prod)
         assert torch.equal(ops.pgemm_tn(ap, ap).double(), a.double().T @ a.double())
+
+
+def test_deterministic():
+    """Same inputs, same bits: the tail split's finishing launch, the K chunks, the TN slabs and the column sums all add in a
+    fixed order (no floating-point atomics anywhere)."""
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 33280, 384, 1536
+    a, w = torch.randn(M, K, generator=g).cuda(), torch.randn(N, K, generator=g).cuda()
+    dact = torch.randn(M, N, generator=g).cuda()
+    ap, wp = ops.plane_split(a, 3), ops.plane_split(w, 3)
+    r1 = (ops.pgemm_nt(ap, wp), ops.pgemm_tn(ap, ap), *ops.pgemm_nt(ap, wp, epilogue=ops.EPI_GELU_BWD, aux=dact, out_planes=True, want_colsum=True))
+    r2 = (ops.pgemm_nt(ap, wp), ops.pgemm_tn(ap, ap), *ops.pgemm_nt(ap, wp, epilogue=ops.EPI_GELU_BWD, aux=dact, out_planes=True, want_colsum=True))
+    for x, y in zip(r1, r2):
+        x, y = (x.buf, y.buf) if isinstance(x, ops.Planes) else (x, y)
+        assert torch.equal(x, y)
