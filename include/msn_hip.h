@@ -311,10 +311,21 @@ int msn_layernorm_bwd_planes(const float* dy, int64_t lddy, const float* x, int6
                              const float* mean, const float* rstd, const float* gamma, const float* add, int64_t ldadd,
                              float* dx, int64_t lddx, int planes, void* dx_planes, float* dgamma, float* dbeta,
                              float* dx_colsum, void* ws, size_t ws_bytes, msn_stream_t stream);
+/* Backward of the ViT blocks' self-attention (msn_attention_bwd on the packed q | k | v matrix of msn_pgemm_nt's qkv
+ * product: qkv (B T x ldqkv >= 3 H hd), out / dout (B T x H hd), lse as msn_attention_fwd wrote it), writing the gradient
+ * dqkv (B T x 3 H hd) as a PLANE matrix -- the operand of the two products that consume it -- and, colsum_out non-NULL,
+ * its column sums (the bias gradient of the qkv projection; workspace msn_attention_bwd_planes_workspace_bytes).  One
+ * launch, one pass over the operands (see msn_set_attention_fused).  T <= 128, hd in {16, 32, 48, 64}, key_mask (B, T)
+ * bytes or NULL.  Replaces msn_attention_bwd + msn_plane_split for the build-defined ViT (no reference counterpart:
+ * the reference's image ViT is torch's nn.MultiheadAttention inside its build-defined encoder). */
+size_t msn_attention_bwd_planes_workspace_bytes(int B, int H, int head_dim);
+int msn_attention_bwd_planes(const float* qkv, int64_t ldqkv, const uint8_t* key_mask, int B, int H, int T, int head_dim,
+                             float scale, const float* out, int64_t ldo, const float* lse, const float* dout, int64_t ldd,
+                             int planes, void* dqkv_planes, float* colsum_out, void* ws, size_t ws_bytes,
+                             msn_stream_t stream);
 int msn_set_pgemm_tile_n(int bn);
 /* Wave layout of the 3-plane msn_pgemm_nt kernel (measurements; same results up to the summation order of the column
- * sums): 0 = 2 x 4 waves, 1 = 4 x 2 (default), 3 / 4 = 0 / 1 with the LDS-DMA issue staggered between the two waves of a
- * SIMD; + 1000 * c: K chunks of c K-steps (default 32).  Process-wide, not thread-safe (as every msn_set_* switch). */
+ * sums): 0 = 2 x 4 waves, 1 = 4 x 2 (default); + 1000 * c: K chunks of c K-steps (default 32).  Process-wide, not thread-safe (as every msn_set_* switch). */
 int msn_set_pgemm_variant(int v);
 /* Start skew of msn_pgemm_nt's persistent workgroups (shader cycles per phase, 0 = off; measurements). */
 int msn_set_pgemm_skew(int cycles);
@@ -395,6 +406,10 @@ int msn_attention_bwd(const float* q, int64_t ldq, int64_t q_bstride, const floa
  * 2 = matrix cores whenever applicable, narrow heads included (measured no faster there).
  * Process-wide; meant for tests. */
 int msn_set_attention_path(int mode);
+/* Self-attention backward over up to 128 tokens with heads up to 64 wide (the ViT towers): 1 (default) = ONE launch that
+ * holds Q, K, V and dO of a (sample, head) in LDS together -- one pass over the operands, delta never in memory; 0 = the
+ * dQ kernel followed by the dK,dV kernel (same products in the same order).  Process-wide; measurements and tests. */
+int msn_set_attention_fused(int on);
 
 /* ------------------------------------------------------------------------------------------
  * ConvMixer image tower pieces -- src/models_multimodal.py:38-95, channels-last token matrices

@@ -141,6 +141,10 @@ SIGNATURES = {
     "msn_radam_step": (c_int, [c_ptr, c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_ptr]),
     "msn_radam_step_dev": (c_int, [c_ptr, c_int, c_i64, c_ptr, c_ptr, c_ptr]),
     "msn_set_attention_path": (c_int, [c_int]),
+    "msn_set_attention_fused": (c_int, [c_int]),
+    "msn_attention_bwd_planes_workspace_bytes": (c_size, [c_int, c_int, c_int]),
+    "msn_attention_bwd_planes": (c_int, [c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_int, c_f32, c_ptr, c_i64, c_ptr, c_ptr, c_i64,
+                                         c_int, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "msn_retrieval_rank": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_size, c_ptr]),
     "msn_sigmoid_loss_fwd": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int,
                                      c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),

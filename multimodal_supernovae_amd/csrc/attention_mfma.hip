@@ -713,15 +713,6 @@ __global__ __launch_bounds__(HD > 64 ? 512 : 1024) void mattn_bwd_dkv_kernel(con
 }
 
 
-// =====================================================================================================================
-// Long sequences (more than 256 tokens: the reference's spectrum transformer on 1024-bin spectra).  Same tile products;
-// a workgroup owns a block of up to 128 rows of the fixed operand (8 waves, compiled for two workgroups per CU so that one
-// multiplies while the other stages its next chunk) and the streamed operand passes through
-// LDS in chunks of CH = 16 * KEEP rows (256 for heads up to 16 wide, 128 beyond), so the score tiles of a chunk still
-// fit in registers.  Forward: online softmax ACROSS chunks (running maximum; the output accumulators -- rows are
-// queries 4g + r -- take the rescale factor of their query from its column-owner lane), one pass WITHIN a chunk.
-// The backward kernels only accumulate over the chunks (probabilities come from the saved row statistics).
-// Workgroup -> (sample, head, row block) by locate_block: the workgroups of a sample run on one XCD and share its lines in L2.
 #ifdef MSN_ATTN_TIMELINE   // diagnostic build (tools/microbench/attn_timeline.py): shader-clock stamps of wave 0 of every workgroup
 constexpr int kDbgRows = 32768;
 __device__ unsigned long long g_mattn_dbg[kDbgRows * 8];
@@ -736,6 +727,330 @@ extern "C" int msn_mattn_debug_read(unsigned long long* out, int rows) {   // ou
 #else
 #define MSN_TL(var)
 #endif
+// ---------------------------------------------------------------------------------- backward in ONE pass: dQ, dK, dV
+// Self-attention over up to 128 tokens (the ViT towers: 65): the four images a (sample, head) needs -- Q, K, V, dO -- sit in
+// LDS TOGETHER (74 KB at T = 65, 64-wide heads: two workgroups per CU), so the backward reads them from HBM once instead of
+// twice (the dQ kernel's K | V + fragments, then the dK,dV kernel's Q | dO + fragments + the statistics), delta = dO . O never
+// goes through memory, and one launch replaces two.  Same products, same order of accumulation, same ragged-token path as
+// mattn_bwd_dq_kernel / mattn_bwd_dkv_kernel above (results equal theirs to the contraction of multiply-adds the compiler
+// picks per kernel); the fixed-tile fragments come from the LDS images instead of HBM.  Wave w owns query tile w (dQ phase), then key tile w (dK,dV phase).
+// The results leave through LDS (the images' space, once every wave is done with them) in memory order:
+//   NP = 0: fp32 rows of dq / dk / dv, 16 bytes per lane;
+//   NP = 2 | 3: bf16 PLANES of the packed gradient matrix dqkv (B T x 3 H hd; csrc/pgemm.hip's blocked layout), which is what
+//   the two products that consume it read -- the fp32 matrix and the split pass over it (144 us at the headline shape) are
+//   gone -- plus the column sums of this sample's rows (the bias gradient's partial sums; finished by colsum_finish).
+struct FusedOut {
+    unsigned char* planes;    // NP > 0: plane matrix of dqkv
+    float* colpart;           // NP > 0, nullable: [B][3 H hd] column sums per sample
+    int cb;                   // column blocks of the plane matrix = 2 ceil(3 H hd / 32)
+};
+__device__ __forceinline__ unsigned short bf16_rne_bits(float f) {
+    const __bf16 b = (__bf16)f;
+    return *reinterpret_cast<const unsigned short*>(&b);
+}
+template <int HD>
+__device__ __forceinline__ void lds_frags(float4 (&f)[HD / 16], const float* img, int row, int g, float mul) {
+    constexpr int LS = HD + 4;
+#pragma unroll
+    for (int x = 0; x < HD / 16; ++x) {
+        const float4 v = *reinterpret_cast<const float4*>(img + row * LS + 16 * x + 4 * g);
+        f[x] = make_float4(v.x * mul, v.y * mul, v.z * mul, v.w * mul);
+    }
+}
+template <int HD, int NP>
+__global__ __launch_bounds__(512) void mattn_bwd_fused_kernel(const MAttn p, const FusedOut fo) {
+    constexpr int LS = HD + 4, DT = HD / 16;
+    MSN_TL(tl0)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int T = p.Tk;                                   // == p.Tq
+    const int TP = (T + 15) / 16 * 16;
+    const int rows = p.tail ? (T + 3) / 4 * 4 : TP;       // LDS image rows (see the forward kernel)
+    float* Qs = smem;
+    float* Ks = Qs + (size_t)rows * LS;
+    float* Vs = Ks + (size_t)rows * LS;
+    float* Ds = Vs + (size_t)rows * LS;
+    float* Lm = Ds + (size_t)rows * LS;
+    float* Ll = Lm + TP;
+    float* Dl = Ll + TP;
+    uint8_t* Ms = reinterpret_cast<uint8_t*>(Dl + TP);
+    float* Zs = reinterpret_cast<float*>(Ms + TP);        // tail scratch: a broadcast row + weight vectors
+    int b, hh;
+    locate_head(p, b, hh);
+    const int col0 = hh * p.hd;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int z = T - 1;                                  // the ragged token (tail only)
+    const bool tail_wave = p.tail && wave == TP / 16 - 1;
+    const int t0 = wave * 16, trow = t0 + c;              // this wave's tile; this lane's fixed row (query, then key)
+    const bool t_ok = trow < T;
+    // ---- request: the four images, the statistics, the key mask, this wave's O fragments (delta), all in flight together
+    const float* qsrc = p.q + (int64_t)b * p.q_bs;
+    const float* ksrc = p.k + (int64_t)b * p.k_bs;
+    const float* vsrc = p.v + (int64_t)b * p.v_bs;
+    const float* dsrc = p.dout + (int64_t)b * p.d_bs;
+    Stager<HD, DT, false> s1, s2;
+    s1.request(qsrc, ksrc, p.ldq, p.ldk, col0, T, rows, p.hd);
+    s2.request(vsrc, dsrc, p.ldv, p.ldd, col0, T, rows, p.hd);
+    const int tj = threadIdx.x;
+    const int64_t sj = ((int64_t)b * p.H + hh) * T + (tj < T ? tj : 0);
+    const float s_m = p.lse[2 * sj], s_l = p.lse[2 * sj + 1];
+    uint8_t mk = 1;
+    if (p.mask) mk = p.mask[(int64_t)b * T + (tj < T ? tj : 0)];
+    float4 of[DT];
+    float dz = 0.f;                                       // tail wave: lane d's term of delta_z = dO_z . O_z
+    if (tail_wave) {
+        if (lane < p.hd)
+            dz = dsrc[(int64_t)z * p.ldd + col0 + lane] * p.o[(int64_t)b * p.o_bs + (int64_t)z * p.ldo + col0 + lane];
+    } else {
+        frags_request<HD>(of, p.o + (int64_t)b * p.o_bs, p.ldo, col0, trow, T, g, p.hd);
+    }
+    MSN_TL(tl1)
+    // ---- commit
+    s1.commit_first(Qs);
+    s1.commit_second(Qs, Ks);
+    s2.commit_first(Vs);
+    s2.commit_second(Vs, Ds);
+    if (tj < TP) {
+        Lm[tj] = tj < T ? s_m : INFINITY;                 // +inf: a padded query row gets p = exp(-inf) = 0
+        Ll[tj] = tj < T ? s_l : 0.f;
+        Ms[tj] = tj < T ? mk : 1;
+    }
+    if (!tail_wave) frags_commit<HD>(of, trow, T, g, 1.f, p.hd);
+    __syncthreads();
+    MSN_TL(tl2)
+
+    // ---- delta of this wave's queries (registers for the dQ phase, LDS for every wave's dK,dV phase)
+    float4 af[DT], bf[DT];                                // fixed-tile fragments: (q, dO), then (k, v)
+    float delta = 0.f;
+    if (tail_wave) {
+        delta = wave_sum(dz);
+        if (lane < 16 && z + lane < TP) Dl[z + lane] = lane == 0 ? delta : 0.f;
+    } else {
+        lds_frags<HD>(af, Qs, trow, g, p.scale);
+        lds_frags<HD>(bf, Ds, trow, g, 1.f);
+#pragma unroll
+        for (int x = 0; x < DT; ++x)
+            delta += bf[x].x * of[x].x + bf[x].y * of[x].y + bf[x].z * of[x].z + bf[x].w * of[x].w;
+        delta = group_sum4(delta);
+        if (g == 0) Dl[trow] = t_ok ? delta : 0.f;
+    }
+    __syncthreads();
+    MSN_TL(tl3)
+#ifdef MSN_ATTN_TIMELINE
+    unsigned long long tl4 = 0;
+#endif
+
+    const int ntile = TP / 16 - (p.tail ? 1 : 0);         // full tiles on the matrix cores
+    const int rows4 = (T + 3) / 4 * 4;
+    f32x4 dq[DT], dk[DT], dv[DT];
+    float dqz = 0.f, dkz = 0.f, dvz = 0.f;                // tail wave: lane d's element of row z
+    if (tail_wave) {
+        // ---- query z: lane = key (see mattn_bwd_dq_kernel)
+        float* Ps = Zs + 128;
+        const float lm = Lm[z], ll = Ll[z];
+        if (lane < HD) Zs[lane] = Qs[z * LS + lane] * p.scale;          // query z, scaled, as a broadcast row (wave-private)
+        const float* qz = Zs;
+        const float* dz_row = Ds + z * LS;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int j = 64 * h2 + lane;
+            float ds = 0.f;
+            if (j < z && Ms[j]) {
+                const float sjv = row_dot<HD>(Ks, j, qz), dp = row_dot<HD>(Vs, j, dz_row);
+                ds = __expf((sjv - lm) - ll) * (dp - delta);
+            }
+            Ps[j] = ds;
+        }
+        {
+            const float sz = wave_dot<HD>(Ks + z * LS, qz, lane), dpz = wave_dot<HD>(Vs + z * LS, dz_row, lane);
+            if (lane == 0) Ps[z] = Ms[z] ? __expf((sz - lm) - ll) * (dpz - delta) : 0.f;
+        }
+        if (lane < p.hd) dqz = col_sum<HD>(Ks, Ps, rows4, lane) * p.scale;
+        // ---- key z: lane = query (see mattn_bwd_dkv_kernel)
+        float* Pp = Zs + 128;
+        float* Pd = Zs + 256;
+        const bool keep_z = Ms[z] != 0;
+        if (lane < HD) Zs[lane] = Ks[z * LS + lane] * p.scale;          // key z, scaled
+        const float* kz = Zs;
+        const float* vz = Vs + z * LS;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int i = 64 * h2 + lane;
+            float pr = 0.f, ds = 0.f;
+            if (i < z) {
+                const float si = row_dot<HD>(Qs, i, kz), dp = row_dot<HD>(Ds, i, vz);
+                pr = __expf(((keep_z ? si : kFill) - Lm[i]) - Ll[i]);
+                ds = keep_z ? pr * (dp - Dl[i]) : 0.f;
+            }
+            Pp[i] = pr;
+            Pd[i] = ds;
+        }
+        {
+            const float sz = wave_dot<HD>(Qs + z * LS, kz, lane), dpz = wave_dot<HD>(Ds + z * LS, vz, lane);
+            const float pr = __expf(((keep_z ? sz : kFill) - Lm[z]) - Ll[z]);
+            if (lane == 0) {
+                Pp[z] = pr;
+                Pd[z] = keep_z ? pr * (dpz - Dl[z]) : 0.f;
+            }
+        }
+        if (lane < p.hd) {
+            dkz = col_sum<HD>(Qs, Pd, rows4, lane) * p.scale;
+            dvz = col_sum<HD>(Ds, Pp, rows4, lane);
+        }
+    } else {
+        // ---- dQ of query tile `wave`: af = q (scaled), bf = dO
+        const float lm = Lm[trow], ll = Ll[trow];
+#pragma unroll
+        for (int t = 0; t < DT; ++t) dq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < ntile; ++kt) {
+            const f32x4 s = score16<HD>(Ks + kt * 16 * LS, af, c, g);
+            const f32x4 dp = score16<HD>(Vs + kt * 16 * LS, bf, c, g);
+            f32x4 ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * kt + 4 * g + r;
+                const bool live = t_ok && key < T && Ms[key];
+                ds[r] = live ? __expf((s[r] - lm) - ll) * (dp[r] - delta) : 0.f;
+            }
+            accum16<HD>(ds, Ks + kt * 16 * LS, dq, c, g);
+        }
+        if (p.tail) {                                     // key z
+            const float sz = frag_dot_row<HD>(af, Ks + z * LS, g), dpz = frag_dot_row<HD>(bf, Vs + z * LS, g);
+            const float dsz = (t_ok && Ms[z]) ? __expf((sz - lm) - ll) * (dpz - delta) : 0.f;
+            rank1_update<HD>(dsz, Ks + z * LS, dq, c, g);
+        }
+#ifdef MSN_ATTN_TIMELINE
+        tl4 = __builtin_readcyclecounter();
+#endif
+        // ---- dK, dV of key tile `wave`: af = k (scaled), bf = v
+        lds_frags<HD>(af, Ks, trow, g, p.scale);
+        lds_frags<HD>(bf, Vs, trow, g, 1.f);
+        const bool keep = t_ok && Ms[trow] != 0;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) dk[t] = dv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int qt = 0; qt < ntile; ++qt) {
+            const f32x4 s = score16<HD>(Qs + qt * 16 * LS, af, c, g);     // rows = queries, col = this lane's key
+            const f32x4 dp = score16<HD>(Ds + qt * 16 * LS, bf, c, g);
+            f32x4 pr, ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = 16 * qt + 4 * g + r;
+                const float e = __expf(((keep ? s[r] : kFill) - Lm[q]) - Ll[q]);
+                pr[r] = t_ok ? e : 0.f;
+                ds[r] = keep ? e * (dp[r] - Dl[q]) : 0.f;
+            }
+            accum16<HD>(pr, Ds + qt * 16 * LS, dv, c, g);
+            accum16<HD>(ds, Qs + qt * 16 * LS, dk, c, g);
+        }
+        if (p.tail) {                                     // query z against this lane's key
+            const float sz = frag_dot_row<HD>(af, Qs + z * LS, g), dpz = frag_dot_row<HD>(bf, Ds + z * LS, g);
+            const float e = __expf(((keep ? sz : kFill) - Lm[z]) - Ll[z]);
+            rank1_update<HD>(t_ok ? e : 0.f, Ds + z * LS, dv, c, g);
+            rank1_update<HD>(keep ? e * (dpz - Dl[z]) : 0.f, Qs + z * LS, dk, c, g);
+        }
+    }
+    MSN_TL(tl5)
+    __syncthreads();                                      // every wave is done with the images: their space is the stage
+    MSN_TL(tl6)
+
+    // ---- stage [3][T][LS]: dq | dk | dv rows of this (sample, head)
+    float* St = smem;
+    const size_t SS = (size_t)T * LS;
+    if (tail_wave) {
+        if (lane < p.hd) {
+            St[z * LS + lane] = dqz;
+            St[SS + z * LS + lane] = dkz;
+            St[2 * SS + z * LS + lane] = dvz;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = t0 + 4 * g + r;
+            if (row < T) {
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    St[row * LS + 16 * t + c] = dq[t][r] * p.scale;
+                    St[SS + row * LS + 16 * t + c] = dk[t][r] * p.scale;
+                    St[2 * SS + row * LS + 16 * t + c] = dv[t][r];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // (compile-time divisors: an integer division by a run-time value costs more here than the 16 bytes it places)
+    if constexpr (NP == 0) {
+        constexpr int Q4 = HD / 4;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            float* base = s == 0 ? p.dq + (int64_t)b * p.dq_bs : s == 1 ? p.dk + (int64_t)b * p.dk_bs : p.dv + (int64_t)b * p.dv_bs;
+            const int64_t ld = s == 0 ? p.lddq : s == 1 ? p.lddk : p.lddv;
+            for (int idx = threadIdx.x; idx < T * Q4; idx += blockDim.x) {
+                const int row = idx / Q4, cq = 4 * (idx % Q4);
+                if (cq < p.hd)
+                    *reinterpret_cast<float4*>(base + (int64_t)row * ld + col0 + cq) =
+                        *reinterpret_cast<const float4*>(St + s * SS + row * LS + cq);
+            }
+        }
+    } else {
+        constexpr int NB = HD / 16;                       // the plane form takes whole 16-column blocks: hd == HD
+        const int e = p.H * HD;
+        const int64_t r0 = (int64_t)b * T;
+        // a lane owns 8 columns of one row: consecutive lanes are consecutive 16-byte chunks of ONE plane image (row r, half h at
+        // byte 32 r + 16 h), so a wave's store is 1 KB of contiguous bytes per image instead of 64 separate 32-byte segments
+        // (measured: the segment form kept the CU's texture path busy for ~6 000 cycles per workgroup)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            unsigned char* cbase = fo.planes + (int64_t)((s * e + col0) / 16) * (NP * 1024);
+            for (int idx = threadIdx.x; idx < 2 * T * NB; idx += blockDim.x) {
+                int j = 0;
+#pragma unroll
+                for (int q = 1; q < NB; ++q) j += idx >= 2 * T * q ? 1 : 0;
+                const int rh = idx - 2 * T * j, row = rh >> 1, half = rh & 1;
+                const float* src = St + s * SS + row * LS + 16 * j + 8 * half;
+                const float4 w0 = *reinterpret_cast<const float4*>(src), w1 = *reinterpret_cast<const float4*>(src + 4);
+                float v[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                const int64_t gr = r0 + row;
+                unsigned char* dst = cbase + ((gr >> 5) * fo.cb + j) * (int64_t)(NP * 1024) + (int)(gr & 31) * 32 + 16 * half;
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    unsigned w[4];
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        const unsigned short lo = bf16_rne_bits(v[2 * x]), hi = bf16_rne_bits(v[2 * x + 1]);
+                        v[2 * x] -= __uint_as_float((unsigned)lo << 16);          // exact
+                        v[2 * x + 1] -= __uint_as_float((unsigned)hi << 16);
+                        w[x] = lo | ((unsigned)hi << 16);
+                    }
+                    *reinterpret_cast<uint4*>(dst + k * 1024) = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
+        }
+        if (fo.colpart && (int)threadIdx.x < 3 * HD) {    // this sample's column sums, rows in order
+            const int s = threadIdx.x / HD, d = threadIdx.x % HD;
+            const float* src = St + s * SS + d;
+            float a0 = 0.f, a1 = 0.f;
+            int row = 0;
+            for (; row + 1 < T; row += 2) a0 += src[row * LS], a1 += src[(row + 1) * LS];
+            if (row < T) a0 += src[row * LS];
+            fo.colpart[(int64_t)b * 3 * e + s * e + col0 + d] = a0 + a1;
+        }
+    }
+#ifdef MSN_ATTN_TIMELINE
+    if (threadIdx.x == 0 && blockIdx.x < kDbgRows) {
+        unsigned long long* d = g_mattn_dbg + 8 * blockIdx.x;
+        d[0] = tl0, d[1] = tl1, d[2] = tl2, d[3] = tl3, d[4] = tl4, d[5] = tl5, d[6] = tl6, d[7] = __builtin_readcyclecounter();
+    }
+#endif
+}
+
+// =====================================================================================================================
+// Long sequences (more than 256 tokens: the reference's spectrum transformer on 1024-bin spectra).  Same tile products;
+// a workgroup owns a block of up to 128 rows of the fixed operand (8 waves, compiled for two workgroups per CU so that one
+// multiplies while the other stages its next chunk) and the streamed operand passes through
+// LDS in chunks of CH = 16 * KEEP rows (256 for heads up to 16 wide, 128 beyond), so the score tiles of a chunk still
+// fit in registers.  Forward: online softmax ACROSS chunks (running maximum; the output accumulators -- rows are
+// queries 4g + r -- take the rescale factor of their query from its column-owner lane), one pass WITHIN a chunk.
+// The backward kernels only accumulate over the chunks (probabilities come from the saved row statistics).
+// Workgroup -> (sample, head, row block) by locate_block: the workgroups of a sample run on one XCD and share its lines in L2.
 template <int HD>
 __global__ __launch_bounds__(512, HD > 64 ? 2 : 4) void mattn_fwd_long_kernel(const MAttn p) {
     constexpr int LS = HD + 4, DT = HD / 16, KEEP = HD <= 16 ? 16 : 8, CH = 16 * KEEP;
@@ -1084,6 +1399,53 @@ int mattn_forward(const MAttn& a0, hipStream_t st) {
     return rc;
 }
 
+// One-pass backward (mattn_bwd_fused_kernel): self-attention, up to 128 tokens, heads up to 64 wide, everything 16-byte aligned.
+static int g_attn_fused = 1;
+void mattn_set_fused(int on) { g_attn_fused = on; }
+static size_t fused_lds(const MAttn& a, bool tail) {
+    const int TP = (a.Tk + 15) / 16 * 16;
+    const int rows = tail ? (a.Tk + 3) / 4 * 4 : TP;
+    return sizeof(float) * (4 * (size_t)rows * (padded_hd(a.hd) + 4) + 3 * (size_t)TP + kTailScratch) + (size_t)TP;
+}
+bool mattn_fused_applicable(const MAttn& a) {
+    if (!mattn_applicable(a) || a.Tq != a.Tk || a.Tk > 128 || a.hd > 64 || a.hd % 4 != 0) return false;
+    const int64_t al[] = {a.ldd, a.d_bs, a.ldo, a.o_bs};
+    bool ok = ((reinterpret_cast<uintptr_t>(a.dout) | reinterpret_cast<uintptr_t>(a.o)) & 15) == 0;
+    for (int64_t v : al) ok = ok && (v % 4 == 0);
+    return ok && fused_lds(a, use_tail(a)) <= 160 * 1024;
+}
+template <int NP>
+static int launch_fused(const MAttn& a, const FusedOut& fo, hipStream_t st) {
+    const size_t lds = fused_lds(a, a.tail != 0);
+    const dim3 grid(a.B * a.H), block(64 * ((a.Tk + 15) / 16));
+#define MSN_FUSED_CASE(HDV)                                                                                               \
+    {                                                                                                                     \
+        auto kern = mattn_bwd_fused_kernel<HDV, NP>;                                                                      \
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+            set_error("attention: cannot reserve %zu bytes of LDS", lds);                                                 \
+            return MSN_ERR_HIP;                                                                                           \
+        }                                                                                                                 \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, a, fo);                                                            \
+    }
+    switch (padded_hd(a.hd)) {
+        case 16: MSN_FUSED_CASE(16) break;
+        case 32: MSN_FUSED_CASE(32) break;
+        case 48: MSN_FUSED_CASE(48) break;
+        default: MSN_FUSED_CASE(64) break;
+    }
+#undef MSN_FUSED_CASE
+    MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+// dqkv as planes (+ per-sample column sums): q, k, v are the three column groups of ONE packed matrix
+int mattn_backward_planes(const MAttn& a0, int planes, unsigned char* out, int cb, float* colpart, hipStream_t st) {
+    MAttn a = a0;
+    a.tail = use_tail(a) ? 1 : 0;
+    FusedOut fo = {out, colpart, cb};
+    return planes == 3 ? launch_fused<3>(a, fo, st) : launch_fused<2>(a, fo, st);
+}
+
 int mattn_backward(const MAttn& a0, hipStream_t st) {
     MAttn a = a0;
     a.tail = use_tail(a) ? 1 : 0;
@@ -1096,6 +1458,7 @@ int mattn_backward(const MAttn& a0, hipStream_t st) {
         set_error("attention backward: out / dout must be 16-byte aligned with strides %% 4 == 0");
         return MSN_ERR_SHAPE;
     }
+    if (g_attn_fused && mattn_fused_applicable(a)) return launch_fused<0>(a, FusedOut{nullptr, nullptr, 0}, st);
     if (is_long(a)) {
         const int CH = chunk_rows(a.hd);
         {
@@ -1122,3 +1485,55 @@ int mattn_backward(const MAttn& a0, hipStream_t st) {
 }
 
 }  // namespace msn
+
+using namespace msn;
+
+extern "C" int msn_set_attention_fused(int on) {
+    mattn_set_fused(on != 0);
+    return MSN_OK;
+}
+
+extern "C" size_t msn_attention_bwd_planes_workspace_bytes(int B, int H, int head_dim) {
+    return sizeof(float) * ((size_t)B + COLSUM_SLICES) * 3 * (size_t)H * (size_t)head_dim;
+}
+
+extern "C" int msn_attention_bwd_planes(const float* qkv, int64_t ldqkv, const uint8_t* key_mask, int B, int H, int T,
+                                        int head_dim, float scale, const float* out, int64_t ldo, const float* lse,
+                                        const float* dout, int64_t ldd, int planes, void* dqkv_planes, float* colsum_out,
+                                        void* ws, size_t ws_bytes, msn_stream_t stream) {
+    MSN_REQUIRE(qkv && out && lse && dout && dqkv_planes, "msn_attention_bwd_planes: null pointer");
+    MSN_REQUIRE(planes == 2 || planes == 3, "msn_attention_bwd_planes: planes must be 2 or 3 (got %d)", planes);
+    MSN_REQUIRE(B > 0 && H > 0 && T > 0 && head_dim > 0, "msn_attention_bwd_planes: bad shape");
+    MSN_REQUIRE(head_dim % 16 == 0 && head_dim <= 64, "msn_attention_bwd_planes: head width %d (16, 32, 48 or 64)", head_dim);
+    const int e = H * head_dim;
+    MSN_REQUIRE(ldqkv >= 3 * (int64_t)e && ldo >= e && ldd >= e, "msn_attention_bwd_planes: row strides shorter than the rows");
+    MSN_REQUIRE((reinterpret_cast<uintptr_t>(dqkv_planes) & 15) == 0, "msn_attention_bwd_planes: the plane matrix must be 16-byte aligned");
+    MAttn m = {};
+    m.q = qkv; m.k = qkv + e; m.v = qkv + 2 * e; m.o = out; m.dout = dout;
+    m.mask = key_mask; m.lse = const_cast<float*>(lse);
+    m.ldq = m.ldk = m.ldv = ldqkv; m.ldo = ldo; m.ldd = ldd;
+    m.q_bs = m.k_bs = m.v_bs = (int64_t)T * ldqkv; m.o_bs = (int64_t)T * ldo; m.d_bs = (int64_t)T * ldd;
+    m.B = B; m.H = H; m.Tq = m.Tk = T; m.hd = head_dim; m.scale = scale;
+    MSN_REQUIRE(mattn_fused_applicable(m),
+                "msn_attention_bwd_planes: up to 128 tokens, 16-byte aligned operands, row strides %% 4 == 0 (T = %d, head %d)", T, head_dim);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* part = nullptr;
+    if (colsum_out) {
+        MSN_REQUIRE(ws && ws_bytes >= msn_attention_bwd_planes_workspace_bytes(B, H, head_dim),
+                    "msn_attention_bwd_planes: workspace too small for the column sums");
+        part = static_cast<float*>(ws);
+    }
+    const int64_t M = (int64_t)B * T;
+    const int cb = 2 * (int)cdiv(3 * e, 32);
+    unsigned char* dst = static_cast<unsigned char*>(dqkv_planes);
+    if (M % 32 != 0) {            // rows behind the matrix in its last row block are zeros
+        const size_t blk = (size_t)cb * planes * 1024;
+        if (hipMemsetAsync(dst + (size_t)(M / 32) * blk, 0, blk, st) != hipSuccess) {
+            set_error("msn_attention_bwd_planes: memset failed");
+            return MSN_ERR_HIP;
+        }
+    }
+    if (int rc = mattn_backward_planes(m, planes, dst, cb, part, st)) return rc;
+    if (colsum_out) return colsum_finish(part, B, 3 * e, colsum_out, st);
+    return MSN_OK;
+}

@@ -35,6 +35,11 @@ void set_error(const char* fmt, ...);
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Column sums from partial rows (pgemm.hip): part = [nparts][N] floats followed by COLSUM_SLICES x N floats of scratch; the
+// order of the additions is fixed (two passes over fixed slices), so the sums are reproducible.
+constexpr int COLSUM_SLICES = 32;
+int colsum_finish(float* part, int nparts, int N, float* out, hipStream_t st);
+
 // ---- device helpers -------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -1178,9 +1178,8 @@ __global__ __launch_bounds__(256) void pcolsum_finish_kernel(const float* __rest
     if (rg == 0 && n < N) out[(int64_t)blockIdx.y * N + n] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
-constexpr int COLSUM_SLICES = 32;
-// part: [nparts][N] followed by COLSUM_SLICES x N floats of scratch
-static int colsum_finish(float* part, int nparts, int N, float* out, hipStream_t st) {
+// part: [nparts][N] followed by COLSUM_SLICES x N floats of scratch (declared in msn_common.h)
+int colsum_finish(float* part, int nparts, int N, float* out, hipStream_t st) {
     const dim3 block(256);
     if (nparts <= 2 * COLSUM_SLICES) {
         hipLaunchKernelGGL(pcolsum_finish_kernel, dim3((unsigned)cdiv(N, 64), 1), block, 0, st, part, nparts, nparts, N, out);
@@ -1206,9 +1205,9 @@ extern "C" int msn_set_pgemm_skew(int cycles) {
     return MSN_OK;
 }
 static int g_pgemm_chunk = 0;       // K-steps per chunk of the 3-plane NT kernel (0 = whole reduction; experiments)
-static int g_pgemm_variant = 1;     // 3-plane NT kernel: 0 = 2 x 4 waves, 1 = 4 x 2 (default), 3 / 4 = 0 / 1 with staggered DMA issue
+static int g_pgemm_variant = 1;     // 3-plane NT kernel: 0 = 2 x 4 waves, 1 = 4 x 2 (default)
 extern "C" int msn_set_pgemm_variant(int v) {
-    MSN_REQUIRE(v >= 0 && v % 1000 <= 4 && v / 1000 <= 1000, "msn_set_pgemm_variant: 0 .. 4 (+ 1000 * K-steps per chunk)");
+    MSN_REQUIRE(v >= 0 && v % 1000 <= 1 && v / 1000 <= 1000, "msn_set_pgemm_variant: 0 or 1 (+ 1000 * K-steps per chunk)");
     g_pgemm_chunk = v / 1000;
     v %= 1000;
     g_pgemm_variant = v;
@@ -1389,13 +1388,11 @@ extern "C" int msn_pgemm_nt(int64_t M, int N, int K, int planes, const void* A, 
     const int grid = a.tail_segs ? std::max(a.tail_full ? 256 : 0, (total - a.tail_full) * a.tail_segs) : std::min(total, 256);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (planes == 3) {
-        a.colsum_rows = (g_pgemm_variant == 0 || g_pgemm_variant == 3) ? 2 : 4;
-        switch (g_pgemm_variant) {        // (2 = the default NT layout + the 4 x 2 TN kernel)
-            case 0: launch_nt<3, 128, true>(a, c_planes != 0, grid, st); break;
-            case 3: launch_nt<3, 128, true, 2, 4, true>(a, c_planes != 0, grid, st); break;
-            case 4: launch_nt<3, 128, true, 4, 2, true>(a, c_planes != 0, grid, st); break;
-            default: launch_nt<3, 128, true, 4, 2>(a, c_planes != 0, grid, st); break;
-        }
+        a.colsum_rows = g_pgemm_variant == 0 ? 2 : 4;
+        // (the staggered-DMA instantiations -- variants 3 / 4 of the measurements in profiles/r04_pgemm_variants.txt -- are not
+        // built any more: nothing in the step, +9 % on one shape in isolation; STAG stays in the kernel source)
+        if (g_pgemm_variant == 0) launch_nt<3, 128, true>(a, c_planes != 0, grid, st);
+        else launch_nt<3, 128, true, 4, 2>(a, c_planes != 0, grid, st);
     } else {
         launch_nt<2, 128, false>(a, c_planes != 0, grid, st);
     }
@@ -1424,7 +1421,7 @@ TnPlan tn_plan(int64_t M, int N, int K, int planes) {
     const int wn = waste(N, 256), wk = waste(K, 256);
     t.swap = wk < wn;
     const int Pd = t.swap ? K : N, Qd = t.swap ? N : K;
-    t.bq = (planes == 3 || waste(Qd, 256) >= 128 || Qd <= 128) ? 128 : 256;     // 3 planes: two accumulator sets
+    t.bq = 128;      // (3 planes: two accumulator sets fill the register file at 256 x 128; 2 planes: 128 measured faster)
     t.tiles_p = (int)cdiv(Pd, 256);
     t.tiles_q = (int)cdiv(Qd, t.bq);
     const int tiles = t.tiles_p * t.tiles_q;
@@ -1469,12 +1466,8 @@ extern "C" int msn_pgemm_tn(int64_t M, int N, int K, int planes, const void* A, 
     const int grid = t.tiles_p * t.tiles_q * t.splits;
     hipStream_t st = static_cast<hipStream_t>(stream);
     // (2 x 4 waves: the 64 x 64 wave tiles that gain 7-12 % on the NT kernel LOSE 3-4 % here -- 374 / 151 / 452 / 454 us
-    // against 384 / 157 / 469 / 470 on the four headline weight gradients; msn_set_pgemm_variant(2) selects them)
-    if (planes == 3) {
-        if (g_pgemm_variant == 2) launch_tn<3, 128, true, 4, 2>(a, t.swap, grid, st);
-        else launch_tn<3, 128, true>(a, t.swap, grid, st);
-    }
-    else if (t.bq == 256) launch_tn<2, 256, false>(a, t.swap, grid, st);
+    // against 384 / 157 / 469 / 470 on the four headline weight gradients; that instantiation is no longer built)
+    if (planes == 3) launch_tn<3, 128, true>(a, t.swap, grid, st);
     else launch_tn<2, 128, false>(a, t.swap, grid, st);
     MSN_LAUNCH_CHECK();
     if (t.splits > 1) {

@@ -583,8 +583,8 @@ class _PlaneVitTrunk(torch.autograd.Function):
     = 3 planes / 6 products, or 2 / 3).  Same arithmetic plan as pre_norm_block -- residual adds, bias adds, GELU and GELU'
     in GEMM epilogues -- with each operand split into planes ONCE, by the kernel that produces it: LayerNorm forward writes
     planes only, the GELU epilogue writes the planes of its activation, LayerNorm backward and the GELU' epilogue write the
-    planes of the gradients they produce (and the column sums that are the bias gradients); the attention output and the
-    attention gradient are split by msn_plane_split (the one pass that is not fused yet); the weights and their transposes
+    planes of the gradients they produce (and the column sums that are the bias gradients); the attention backward writes
+    the planes of dqkv (msn_attention_bwd_planes); the attention output is split by msn_plane_split; the weights and their transposes
     (for the input-gradient products) once per call.  The residual stream, LayerNorm statistics, attention and every
     parameter gradient stay fp32.
 
@@ -646,11 +646,16 @@ class _PlaneVitTrunk(torch.autograd.Function):
             dx1, dx1p, dg2, db2, dbo = ops.layernorm_bwd_planes(dh2, x1, m2, r2, g2, NPL, add=d2, want_colsum=True)   # + skip
             dwo = ops.pgemm_tn(dx1p, ap)
             da = ops.pgemm_nt(dx1p, ops.plane_split(wo, NPL, transposed=True))
-            dqkv = torch.empty_like(qkv)
-            q3, d3 = qkv.view(B, T, 3 * e), dqkv.view(B, T, 3 * e)
-            ops.attention_bwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], None, heads, scale, a2.view(B, T, e), lse,
-                              da.view(B, T, e), d3[..., :e], d3[..., e:2 * e], d3[..., 2 * e:])
-            dqkvp, dbqkv = ops.plane_split(dqkv, NPL, want_colsum=True)
+            if ops.attention_bwd_planes_supported(T, e // heads):
+                # one launch: Q, K, V, dO of a (sample, head) together in LDS, dqkv leaves as planes + column sums
+                dqkvp, dbqkv = ops.attention_bwd_planes(qkv.view(B, T, 3 * e), heads, scale, a2.view(B, T, e), lse,
+                                                        da.view(B, T, e), NPL)
+            else:
+                dqkv = torch.empty_like(qkv)
+                q3, d3 = qkv.view(B, T, 3 * e), dqkv.view(B, T, 3 * e)
+                ops.attention_bwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], None, heads, scale, a2.view(B, T, e), lse,
+                                  da.view(B, T, e), d3[..., :e], d3[..., e:2 * e], d3[..., 2 * e:])
+                dqkvp, dbqkv = ops.plane_split(dqkv, NPL, want_colsum=True)
             dwqkv = ops.pgemm_tn(dqkvp, h1p)
             dh1 = ops.pgemm_nt(dqkvp, ops.plane_split(wqkv, NPL, transposed=True))
             grads[12 * i: 12 * i + 12] = [None, None, dwqkv, dbqkv, dwo, dbo, dg2, db2, dw1, dc1, dw2, dc2]

@@ -921,7 +921,7 @@ def attention_bf16_bwd(qkv, out, dout, lse, B, T, heads, scale, want_colsum=Fals
 PLANES = int(__import__("os").environ.get("MSN_PLANES", "3"))
 if __import__("os").environ.get("MSN_PGEMM_TAIL"):         # "0": multiply the tail tiles whole (measurements)
     check(lib().msn_set_pgemm_tail_split(int(__import__("os").environ["MSN_PGEMM_TAIL"])))
-if __import__("os").environ.get("MSN_PGEMM_VARIANT"):      # wave layout / DMA stagger of the 3-plane NT kernel (measurements)
+if __import__("os").environ.get("MSN_PGEMM_VARIANT"):      # wave layout of the 3-plane NT kernel: 0 = 2 x 4, 1 = 4 x 2 (measurements)
     check(lib().msn_set_pgemm_variant(int(__import__("os").environ["MSN_PGEMM_VARIANT"])))     # planes per operand: 3 = fp32 grade (6 products), 2 = 3 products
 
 
@@ -961,6 +961,39 @@ def plane_split(x, planes=None, transposed=False, want_colsum=False):
     check(lib().msn_plane_split(ptr(x), x.stride(0), R, C, planes, 1 if transposed else 0, ptr(out.buf), ptr(cs), ptr(ws), nb,
                                 stream_ptr()), "msn_plane_split")
     return (out, cs) if want_colsum else out
+
+
+def attention_bwd_planes(qkv, heads, scale, out, lse, dout, planes=None, want_colsum=True, mask_u8=None):
+    """Backward of self-attention on the packed (B, T, 3 E) q | k | v matrix: the gradient dqkv as Planes (B T, 3 E) and, with
+    want_colsum, its column sums -- one launch, no fp32 dqkv in memory (msn_attention_bwd_planes)."""
+    B, T, E3 = qkv.shape
+    E = E3 // 3
+    planes = PLANES if planes is None else planes
+    _f32c(qkv, "qkv"), _f32c(out, "out"), _f32c(dout, "dout")
+    assert qkv.stride(2) == 1 and qkv.stride(0) == T * qkv.stride(1) and out.shape == (B, T, E) and dout.shape == (B, T, E)
+    assert out.stride(0) == T * out.stride(1) and dout.stride(0) == T * dout.stride(1)
+    dqkv = Planes.empty(B * T, E3, planes, qkv.device)
+    cs = ws = None
+    nb = 0
+    if want_colsum:
+        cs = torch.empty(E3, dtype=torch.float32, device=qkv.device)
+        nb = lib().msn_attention_bwd_planes_workspace_bytes(B, heads, E // heads)
+        ws = _workspace(nb, qkv.device)
+    check(lib().msn_attention_bwd_planes(ptr(qkv), qkv.stride(1), ptr(mask_u8), B, heads, T, E // heads, scale, ptr(out),
+                                         out.stride(1), ptr(lse), ptr(dout), dout.stride(1), planes, ptr(dqkv.buf), ptr(cs),
+                                         ptr(ws), nb, stream_ptr()), "msn_attention_bwd_planes")
+    return (dqkv, cs) if want_colsum else dqkv
+
+
+ATTN_BWD_PLANES = __import__("os").environ.get("MSN_ATTN_BWD_PLANES", "1") != "0"      # 0: msn_attention_bwd + msn_plane_split (A/B runs)
+
+
+def attention_bwd_planes_supported(T, head_dim):
+    return ATTN_BWD_PLANES and T <= 128 and head_dim % 16 == 0 and head_dim <= 64 and 4 * (T + 3) * (head_dim + 4) * 4 + 4096 <= 160 * 1024
+
+
+def set_attention_fused(on):
+    check(lib().msn_set_attention_fused(1 if on else 0), "msn_set_attention_fused")
 
 
 def pgemm_supported(M, N, K):

@@ -219,6 +219,9 @@ def test_host_shim_under_address_and_ub_sanitizers():
     rt = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
     if not os.path.exists(lib) or not rt:
         pytest.skip("sanitized library not built (bash tools/build_host_sanitized.sh)")
+    srcs = glob.glob(os.path.join(ROOT, "multimodal_supernovae_amd", "csrc", "*")) + [os.path.join(ROOT, "include", "msn_hip.h")]
+    if os.path.getmtime(lib) < max(os.path.getmtime(f) for f in srcs):
+        pytest.skip("sanitized library older than the sources (bash tools/build_host_sanitized.sh)")
     env = dict(os.environ, LD_PRELOAD=rt[-1], ASAN_OPTIONS="detect_leaks=0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_sanitizer_probe.py")], capture_output=True, text=True,
                        env=env, timeout=300)
