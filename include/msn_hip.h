@@ -307,6 +307,10 @@ int msn_pgemm_tn(int64_t M, int N, int K, int planes, const void* A, const void*
 int msn_layernorm_fwd_planes(const float* x, int64_t ldx, int64_t rows, int cols, const float* gamma, const float* beta,
                              float eps, int planes, void* y_planes, float* y, int64_t ldy, float* mean, float* rstd,
                              msn_stream_t stream);
+/* 1 (default): msn_layernorm_fwd_planes with y == NULL, 260..400 columns and >= 32768 rows normalises whole 32-row blocks
+ * per workgroup and writes each block's plane images as contiguous memory; 2: at every row count; 0: always the row-at-a-time
+ * kernel.  Same results.  Process-wide; A/B runs and tests. */
+int msn_set_layernorm_block_planes(int on);
 int msn_layernorm_bwd_planes(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t rows, int cols,
                              const float* mean, const float* rstd, const float* gamma, const float* add, int64_t ldadd,
                              float* dx, int64_t lddx, int planes, void* dx_planes, float* dgamma, float* dbeta,

@@ -106,6 +106,31 @@ __device__ __forceinline__ float sum4(float4 a) { return (a.x + a.y) + (a.z + a.
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
 // ------------------------------------------------------------------------------------- LayerNorm
+// one row in place: v -> (v - mean) rstd gamma + beta; the row's statistics in mu / rs (every lane of the row's group)
+template <int LPR>
+__device__ __forceinline__ void ln_fwd_row(float4 (&v)[NCH], const float4 (&gm)[NCH], const float4 (&bt)[NCH], int cols, int lr,
+                                           float inv_n, float eps, float& mu, float& rs) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) s += sum4(v[k]);
+    mu = group_sum<LPR>(s) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        if (4 * (lr + k * LPR) < cols) {
+            const float a = v[k].x - mu, b = v[k].y - mu, c = v[k].z - mu, d = v[k].w - mu;
+            q += a * a + b * b + c * c + d * d;
+        }
+    }
+    rs = rsqrtf(group_sum<LPR>(q) * inv_n + eps);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        v[k].x = (v[k].x - mu) * rs * gm[k].x + bt[k].x;
+        v[k].y = (v[k].y - mu) * rs * gm[k].y + bt[k].y;
+        v[k].z = (v[k].z - mu) * rs * gm[k].z + bt[k].z;
+        v[k].w = (v[k].w - mu) * rs * gm[k].w + bt[k].w;
+    }
+}
 template <int LPR>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t ldx, RowGeom g,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -121,26 +146,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     for (int64_t r = (int64_t)blockIdx.x * RG + rg; r < g.rows; r += (int64_t)gridDim.x * RG) {
         float4 v[NCH];
         load_row<LPR>(v, x + r * ldx, g.cols, lr);
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) s += sum4(v[k]);
-        const float mu = group_sum<LPR>(s) * inv_n;
-        float q = 0.f;
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            if (4 * (lr + k * LPR) < g.cols) {
-                const float a = v[k].x - mu, b = v[k].y - mu, c = v[k].z - mu, d = v[k].w - mu;
-                q += a * a + b * b + c * c + d * d;
-            }
-        }
-        const float rs = rsqrtf(group_sum<LPR>(q) * inv_n + eps);
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            v[k].x = (v[k].x - mu) * rs * gm[k].x + bt[k].x;
-            v[k].y = (v[k].y - mu) * rs * gm[k].y + bt[k].y;
-            v[k].z = (v[k].z - mu) * rs * gm[k].z + bt[k].z;
-            v[k].w = (v[k].w - mu) * rs * gm[k].w + bt[k].w;
-        }
+        float mu, rs;
+        ln_fwd_row<LPR>(v, gm, bt, g.cols, lr, inv_n, eps, mu, rs);
         if (y) store_row<LPR>(v, y + r * ldy, g.cols, lr);
         if (yb) store_row_bf16<LPR>(v, yb + r * ldy, g.cols, lr);
         if (po.base) store_row_planes_any<LPR>(v, po, r, lr);
@@ -148,6 +155,63 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             mean[r] = mu;
             rstd[r] = rs;
         }
+    }
+}
+
+// LayerNorm forward whose ONLY output is the plane matrix (the operand of the next product).  The row-at-a-time kernel above
+// writes a lane's 4 columns as 8 bytes per plane -- 32-byte segments, 3.4 TB/s.  Here a workgroup normalises one whole ROW
+// BLOCK (32 rows: 8 waves x 4 rows), builds the block's plane images in LDS in their final layout, and then copies the block
+// -- cb x NP x 1 KB of CONTIGUOUS memory -- out in 16-byte lanes.  Same arithmetic as ln_fwd_kernel<64> (ln_fwd_row).
+template <int NP>
+__global__ __launch_bounds__(512) void ln_fwd_planes_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int cols,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float eps, float* __restrict__ mean, float* __restrict__ rstd,
+                                                            unsigned char* __restrict__ out, int cb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ln_img[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 gm[NCH], bt[NCH];
+    load_row<64>(gm, gamma, cols, lane);
+    load_row<64>(bt, beta, cols, lane);
+    const float inv_n = 1.f / (float)cols;
+    const int64_t r0 = (int64_t)blockIdx.x * 32 + wave * 4;
+    float4 v[4][NCH];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                             // the wave's four rows in flight together
+        const int64_t r = r0 + i;
+        load_row<64>(v[i], x + (r < rows ? r : 0) * ldx, cols, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t r = r0 + i;
+        float mu, rs;
+        ln_fwd_row<64>(v[i], gm, bt, cols, lane, inv_n, eps, mu, rs);
+        const bool live = r < rows;
+        // In LDS the rows of column block j are rotated by j & 7 positions: the 16 lanes of one ds_write_b64 group hold 4
+        // neighbouring column blocks, whose images are 3 KB = 0 banks apart -- unrotated, a 4-way conflict
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = 4 * (lane + k * 64);
+            if (c < cb * 16) {                                // columns past `cols` and rows past `rows`: the padding, +0
+                uint2 o[NP];
+                split4<NP>((live && c < cols) ? v[i][k] : make_float4(0.f, 0.f, 0.f, 0.f), o);
+                const int j = c >> 4;
+                unsigned char* dst = ln_img + j * (NP * 1024) + (((wave * 4 + i + (j & 7)) & 31) * 32) + (c & 15) * 2;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(dst + q * 1024) = o[q];
+            }
+        }
+        if (lane == 0 && live) {
+            mean[r] = mu;
+            rstd[r] = rs;
+        }
+    }
+    __syncthreads();
+    const int total = cb * NP * 1024;
+    unsigned char* dst = out + (int64_t)blockIdx.x * total;
+    for (int off = threadIdx.x * 16; off < total; off += 512 * 16) {
+        const int image = off >> 10, j = image / NP;
+        const int src = (image << 10) + (((off & 1023) + 32 * (j & 7)) & 1023);
+        *reinterpret_cast<uint4*>(dst + off) = *reinterpret_cast<const uint4*>(ln_img + src);
     }
 }
 
@@ -789,6 +853,12 @@ static int plane_tail_zero(void* planes_out, int64_t rows, int cols, int np, hip
     return MSN_OK;
 }
 
+static int g_ln_block_planes = 1;   // msn_layernorm_fwd_planes through ln_fwd_planes_kernel where it applies (0: the row kernel; A/B runs)
+extern "C" int msn_set_layernorm_block_planes(int on) {
+    g_ln_block_planes = on;      // 2: at every row count (tests)
+    return MSN_OK;
+}
+
 extern "C" int msn_layernorm_fwd_planes(const float* x, int64_t ldx, int64_t rows, int cols, const float* gamma,
                                         const float* beta, float eps, int planes, void* y_planes, float* y, int64_t ldy,
                                         float* mean, float* rstd, msn_stream_t stream) {
@@ -798,6 +868,23 @@ extern "C" int msn_layernorm_fwd_planes(const float* x, int64_t ldx, int64_t row
     const int lpr = pick_lpr(cols);
     const RowGeom g{rows, cols, ldx};
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const int cbn = 2 * (int)cdiv(cols, 32);
+    const size_t img = (size_t)cbn * planes * 1024;
+    // whole row blocks through LDS (two workgroups per CU); from 1024 row blocks on (4 per CU) -- below that the grid is too
+    // coarse: 520 blocks (16 640 rows) 18.4 us against the row kernel's 15.1, 2080 blocks 45.5 against 55.5
+    if (!y && lpr == 64 && img <= 78 * 1024 && g_ln_block_planes && rows >= 32 * 1024 * (g_ln_block_planes == 2 ? 0 : 1)) {
+        unsigned char* o = static_cast<unsigned char*>(y_planes);
+        const dim3 grid((unsigned)cdiv(rows, 32)), block(512);
+        if (planes == 3) {
+            if (img > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(ln_fwd_planes_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)img);
+            hipLaunchKernelGGL(ln_fwd_planes_kernel<3>, grid, block, img, st, x, ldx, rows, cols, gamma, beta, eps, mean, rstd, o, cbn);
+        } else {
+            if (img > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(ln_fwd_planes_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)img);
+            hipLaunchKernelGGL(ln_fwd_planes_kernel<2>, grid, block, img, st, x, ldx, rows, cols, gamma, beta, eps, mean, rstd, o, cbn);
+        }
+        MSN_LAUNCH_CHECK();
+        return MSN_OK;
+    }
     if (int rc = plane_tail_zero(y_planes, rows, cols, planes, st)) return rc;
     const PlaneOut po{static_cast<unsigned char*>(y_planes), planes, 2 * (int)cdiv(cols, 32), cols};
     MSN_LPR_DISPATCH(ln_fwd_kernel, lpr, dim3(ln_grid(rows, lpr)), 0, st, x, ldx, g, gamma, beta, eps, y, ldy, mean, rstd,

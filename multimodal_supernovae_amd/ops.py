@@ -921,6 +921,8 @@ def attention_bf16_bwd(qkv, out, dout, lse, B, T, heads, scale, want_colsum=Fals
 PLANES = int(__import__("os").environ.get("MSN_PLANES", "3"))
 if __import__("os").environ.get("MSN_PGEMM_TAIL"):         # "0": multiply the tail tiles whole (measurements)
     check(lib().msn_set_pgemm_tail_split(int(__import__("os").environ["MSN_PGEMM_TAIL"])))
+if __import__("os").environ.get("MSN_LN_BLOCK_PLANES"):    # 0: LayerNorm forward -> planes on the row-at-a-time kernel (A/B runs)
+    check(lib().msn_set_layernorm_block_planes(int(__import__("os").environ["MSN_LN_BLOCK_PLANES"])))
 if __import__("os").environ.get("MSN_PGEMM_VARIANT"):      # wave layout of the 3-plane NT kernel: 0 = 2 x 4, 1 = 4 x 2 (measurements)
     check(lib().msn_set_pgemm_variant(int(__import__("os").environ["MSN_PGEMM_VARIANT"])))     # planes per operand: 3 = fp32 grade (6 products), 2 = 3 products
 

@@ -33,18 +33,30 @@ def test_block_matches_fp32_block(precision, tol):
         assert err < tol, (i, err)
 
 
-@pytest.mark.parametrize("rows,cols,planes", [(260, 384, 3), (77, 64, 3), (1000, 1024, 2), (33, 200, 3)])
+@pytest.mark.parametrize("rows,cols,planes", [(260, 384, 3), (77, 64, 3), (1000, 1024, 2), (33, 200, 3), (4161, 384, 3), (95, 320, 2),
+                                              (64, 400, 3), (1, 264, 3), (1055, 384, 2)])
 def test_layernorm_plane_outputs(rows, cols, planes):
-    """LayerNorm forward / backward writing planes == the fp32 kernels' results split by msn_plane_split, bit for bit."""
-    from multimodal_supernovae_amd import ops
+    """LayerNorm forward / backward writing planes == the fp32 kernels' results split by msn_plane_split, bit for bit (the
+    forward: both the row-block kernel that takes 260..400 columns and the row-at-a-time kernel)."""
+    from multimodal_supernovae_amd import _lib, ops
     g = torch.Generator().manual_seed(rows + cols)
     x = torch.randn(rows, cols, generator=g).cuda()
     gm, bt = (torch.randn(cols, generator=g) + 1).cuda(), torch.randn(cols, generator=g).cuda()
     dy, add = torch.randn(rows, cols, generator=g).cuda(), torch.randn(rows, cols, generator=g).cuda()
     y, mean, rstd = ops.layernorm_fwd(x, gm, bt, 1e-6)
-    yp, mean2, rstd2 = ops.layernorm_fwd_planes(x, gm, bt, 1e-6, planes)
+    _lib.check(_lib.lib().msn_set_layernorm_block_planes(2))          # the row-block kernel at every row count
+    try:
+        yp, mean2, rstd2 = ops.layernorm_fwd_planes(x, gm, bt, 1e-6, planes)
+    finally:
+        _lib.lib().msn_set_layernorm_block_planes(1)
     assert torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
     assert torch.equal(yp.buf, ops.plane_split(y, planes).buf)
+    _lib.check(_lib.lib().msn_set_layernorm_block_planes(0))          # the row-at-a-time kernel writes the same bytes
+    try:
+        yq, _, _ = ops.layernorm_fwd_planes(x, gm, bt, 1e-6, planes)
+    finally:
+        _lib.lib().msn_set_layernorm_block_planes(1)
+    assert torch.equal(yq.buf, yp.buf)
     dx, dg, db = ops.layernorm_bwd(dy, x, mean, rstd, gm, add=add)
     dx2, dxp, dg2, db2, cs = ops.layernorm_bwd_planes(dy, x, mean, rstd, gm, planes, add=add, want_colsum=True)
     assert torch.equal(dx, dx2) and torch.equal(dg, dg2) and torch.equal(db, db2)

@@ -1,0 +1,37 @@
+"""LayerNorm forward writing planes at the headline shape: the row-block kernel (whole plane images, contiguous stores)
+against the row-at-a-time kernel, and the fp32-output kernel for scale.    python tools/bench_ln_planes.py [rows cols]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multimodal_supernovae_amd import _lib, ops  # noqa: E402
+
+
+def timeit(fn, n=30):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+rows, cols = (int(x) for x in sys.argv[1:3]) if len(sys.argv) >= 3 else (66560, 384)
+x = torch.randn(rows, cols, device="cuda")
+gm, bt = torch.ones(cols, device="cuda"), torch.zeros(cols, device="cuda")
+L = _lib.lib()
+t32 = timeit(lambda: ops.layernorm_fwd(x, gm, bt, 1e-6))
+res = {}
+for on in (2, 0):
+    L.msn_set_layernorm_block_planes(on)
+    res[on] = timeit(lambda: ops.layernorm_fwd_planes(x, gm, bt, 1e-6, 3))
+L.msn_set_layernorm_block_planes(1)
+mb = rows * cols * (4 + 6) / 1e6
+print(f"rows={rows} cols={cols}: fp32 out {t32:.1f} us | planes: row blocks {res[2]:.1f} us ({mb / res[2]:.2f} TB/s), "
+      f"row at a time {res[0]:.1f} us ({mb / res[0]:.2f} TB/s)")
