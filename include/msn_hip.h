@@ -287,6 +287,15 @@ size_t msn_plane_bytes(int64_t R, int64_t C, int planes);
 size_t msn_plane_split_colsum_workspace_bytes(int64_t R, int64_t C);
 int msn_plane_split(const float* x, int64_t ldx, int64_t R, int64_t C, int planes, int transposed, void* out, float* colsum,
                     void* ws, size_t ws_bytes, msn_stream_t stream);
+/* msn_plane_split of several matrices in ONE launch (per 64 items): the weights of every block of a tower, or their
+ * transposes.  items: host array; out of item i holds msn_plane_bytes(R, C, planes) bytes (transposed: of (C, R)). */
+typedef struct msn_split_item {
+    const float* x;
+    int64_t ldx, R, C;
+    int transposed;
+    void* out;
+} msn_split_item;
+int msn_plane_split_list(int n, const msn_split_item* items, int planes, msn_stream_t stream);
 int msn_plane_merge(const void* planes_in, int planes, int64_t R, int64_t C, float* y, int64_t ldy, msn_stream_t stream);
 size_t msn_pgemm_nt_colsum_workspace_bytes(int64_t M, int N);
 /* Workspace of msn_pgemm_nt: the column sums' partials (want_colsum) or the slabs of the TAIL split -- the tiles that do not

@@ -1057,10 +1057,10 @@ __global__ void pgemm_slab_sum_kernel(const float* __restrict__ slabs, int split
 // 16 columns (lane & 1): 64 contiguous bytes in, two 16-byte stores per plane out (each plane image is written whole by
 // its 32 lanes: 1-KB bursts).  Column sums of x (bias gradients) ride along when `colpart` is given: [row blocks][C].
 template <int NP>
-__global__ __launch_bounds__(256) void plane_split_kernel(const float* __restrict__ x, int64_t ld, int64_t R, int C, int RB, int CB,
-                                                          unsigned char* __restrict__ out, float* __restrict__ colpart) {
+__device__ __forceinline__ void plane_split_body(const float* __restrict__ x, int64_t ld, int64_t R, int C, int RB, int CB,
+                                                 unsigned char* __restrict__ out, float* __restrict__ colpart, int64_t wg) {
     const int lane = threadIdx.x & 63;
-    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t wid = wg * 4 + (threadIdx.x >> 6);
     const int CB2 = (CB + 1) / 2;
     const int64_t nw = (int64_t)RB * CB2;
     if (wid >= nw) return;
@@ -1108,13 +1108,18 @@ __global__ __launch_bounds__(256) void plane_split_kernel(const float* __restric
     }
 }
 
+template <int NP>
+__global__ __launch_bounds__(256) void plane_split_kernel(const float* __restrict__ x, int64_t ld, int64_t R, int C, int RB, int CB,
+                                                          unsigned char* __restrict__ out, float* __restrict__ colpart) {
+    plane_split_body<NP>(x, ld, R, C, RB, CB, out, colpart, blockIdx.x);
+}
+
 // planes of x^T: out is the plane matrix of the C x R transpose (weights: a few MB per step).  One workgroup per 32 x 32
 // tile of x through LDS.
 template <int NP>
-__global__ __launch_bounds__(256) void plane_split_t_kernel(const float* __restrict__ x, int64_t ld, int R, int C, int CBT,
-                                                            unsigned char* __restrict__ out) {
-    __shared__ float t[32][33];
-    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;        // tile of x; the transpose has rows c0.., columns r0..
+__device__ __forceinline__ void plane_split_t_body(const float* __restrict__ x, int64_t ld, int R, int C, int CBT,
+                                                   unsigned char* __restrict__ out, float (&t)[32][33], int bx, int by) {
+    const int r0 = by * 32, c0 = bx * 32;                        // tile of x; the transpose has rows c0.., columns r0..
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int i = ty; i < 32; i += 8) t[i][tx] = (r0 + i < R && c0 + tx < C) ? x[(int64_t)(r0 + i) * ld + c0 + tx] : 0.f;
     __syncthreads();
@@ -1123,7 +1128,7 @@ __global__ __launch_bounds__(256) void plane_split_t_kernel(const float* __restr
     u16 pl[4][NP];
 #pragma unroll
     for (int q = 0; q < 4; ++q) split_planes<NP>(t[j0 + q][i], pl[q]);
-    const int rbT = blockIdx.x;                                    // row block of the transpose (32 rows = c0 .. c0 + 31)
+    const int rbT = bx;                                            // row block of the transpose (32 rows = c0 .. c0 + 31)
     const int cbT = (r0 + j0) >> 4;                                // column block of the transpose
     if (cbT < CBT) {
         unsigned char* dst = out + ((int64_t)rbT * CBT + cbT) * (NP * PBLK) + i * 32 + ((r0 + j0) & 15) * 2;
@@ -1134,6 +1139,40 @@ __global__ __launch_bounds__(256) void plane_split_t_kernel(const float* __restr
             o.y = pl[2][k] | ((unsigned)pl[3][k] << 16);
             *reinterpret_cast<uint2*>(dst + k * PBLK) = o;
         }
+    }
+}
+template <int NP>
+__global__ __launch_bounds__(256) void plane_split_t_kernel(const float* __restrict__ x, int64_t ld, int R, int C, int CBT,
+                                                            unsigned char* __restrict__ out) {
+    __shared__ float t[32][33];
+    plane_split_t_body<NP>(x, ld, R, C, CBT, out, t, blockIdx.x, blockIdx.y);
+}
+
+// Several matrices in ONE launch (the weights of every block of a tower, or their transposes: 44 launches of 5-6 us each, every
+// one a bubble between two products, become one).  The table travels as the kernel argument; a workgroup finds its matrix by
+// its first-workgroup prefix.
+constexpr int SPLIT_LIST_MAX = 64;
+struct SplitEntry {
+    const float* x;
+    unsigned char* out;
+    int64_t ld;
+    int R, C, transposed, first, tiles_x, pad;
+};
+struct SplitTable {
+    int n, pad;
+    SplitEntry e[SPLIT_LIST_MAX];
+};
+template <int NP>
+__global__ __launch_bounds__(256) void plane_split_list_kernel(const SplitTable tb) {
+    __shared__ float t[32][33];
+    int i = 0;
+    for (int k = 1; k < tb.n; ++k) i += (int)blockIdx.x >= tb.e[k].first ? 1 : 0;      // entries are in workgroup order
+    const SplitEntry& en = tb.e[i];
+    const int w = blockIdx.x - en.first;
+    if (en.transposed) {
+        plane_split_t_body<NP>(en.x, en.ld, en.R, en.C, 2 * ((en.R + 31) / 32), en.out, t, w % en.tiles_x, w / en.tiles_x);
+    } else {
+        plane_split_body<NP>(en.x, en.ld, en.R, en.C, (en.R + 31) / 32, 2 * ((en.C + 31) / 32), en.out, nullptr, w);
     }
 }
 
@@ -1262,6 +1301,35 @@ extern "C" int msn_plane_split(const float* x, int64_t ldx, int64_t R, int64_t C
             set_error("msn_plane_split: column-sum launch failed");
             return MSN_ERR_HIP;
         }
+    }
+    return MSN_OK;
+}
+
+extern "C" int msn_plane_split_list(int n, const msn_split_item* items, int planes, msn_stream_t stream) {
+    MSN_REQUIRE(items && n > 0, "msn_plane_split_list: empty list");
+    MSN_REQUIRE(planes == 2 || planes == 3, "msn_plane_split_list: planes must be 2 or 3 (got %d)", planes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int base = 0; base < n; base += SPLIT_LIST_MAX) {
+        SplitTable tb = {};
+        tb.n = std::min(n - base, SPLIT_LIST_MAX);
+        int64_t wgs = 0;
+        for (int k = 0; k < tb.n; ++k) {
+            const msn_split_item& it = items[base + k];
+            MSN_REQUIRE(it.x && it.out && it.R > 0 && it.C > 0 && it.ldx >= it.C, "msn_plane_split_list: bad operand in item %d", base + k);
+            MSN_REQUIRE(aligned16p(it.out), "msn_plane_split_list: the plane matrix of item %d must be 16-byte aligned", base + k);
+            MSN_REQUIRE(it.R < (1ll << 31) && it.C < (1ll << 31), "msn_plane_split_list: item %d too large", base + k);
+            SplitEntry& e = tb.e[k];
+            e.x = it.x, e.out = static_cast<unsigned char*>(it.out), e.ld = it.ldx, e.R = (int)it.R, e.C = (int)it.C;
+            e.transposed = it.transposed ? 1 : 0;
+            e.first = (int)wgs;
+            e.tiles_x = (int)cdiv(it.C, 32);
+            const int64_t rb = cdiv(it.R, 32), cb2 = cdiv(it.C, 32);
+            wgs += e.transposed ? rb * cb2 : cdiv(rb * cb2, 4);
+            MSN_REQUIRE(wgs < (1ll << 31), "msn_plane_split_list: list too large");
+        }
+        if (planes == 3) hipLaunchKernelGGL(plane_split_list_kernel<3>, dim3((unsigned)wgs), dim3(256), 0, st, tb);
+        else hipLaunchKernelGGL(plane_split_list_kernel<2>, dim3((unsigned)wgs), dim3(256), 0, st, tb);
+        MSN_LAUNCH_CHECK();
     }
     return MSN_OK;
 }

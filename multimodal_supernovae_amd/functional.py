@@ -600,18 +600,21 @@ class _PlaneVitTrunk(torch.autograd.Function):
         scale = 1.0 / math.sqrt(e // heads)
         x2 = _c(x).view(M, e)
         saved, planes = [], []
+        # the planes of every block's four weight matrices from one launch (44 launches of 5-6 us in the headline tower)
+        wp = ops.plane_split_list([P[12 * i + k] for i in range(n_blocks) for k in (2, 4, 8, 10)], NPL)
         for i in range(n_blocks):
             g1, b1, wqkv, bqkv, wo, bo, g2, b2, w1, c1, w2, c2 = P[12 * i: 12 * i + 12]
+            wqkvp, wop, w1p, w2p = wp[4 * i: 4 * i + 4]
             h1p, m1, r1 = ops.layernorm_fwd_planes(x2, g1, b1, eps, NPL)
-            qkv = ops.pgemm_nt(h1p, ops.plane_split(wqkv, NPL), bias=bqkv)
+            qkv = ops.pgemm_nt(h1p, wqkvp, bias=bqkv)
             q3 = qkv.view(B, T, 3 * e)
             a, lse = ops.attention_fwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], None, heads, scale)
             a2 = a.view(M, e)
             ap = ops.plane_split(a2, NPL)
-            x1 = ops.pgemm_nt(ap, ops.plane_split(wo, NPL), bias=bo, epilogue=EPI_ADD, aux=x2)
+            x1 = ops.pgemm_nt(ap, wop, bias=bo, epilogue=EPI_ADD, aux=x2)
             h2p, m2, r2 = ops.layernorm_fwd_planes(x1, g2, b2, eps, NPL)
-            fp, dact = ops.pgemm_nt(h2p, ops.plane_split(w1, NPL), bias=c1, epilogue=EPI_GELU, aux=True, out_planes=True)
-            out = ops.pgemm_nt(fp, ops.plane_split(w2, NPL), bias=c2, epilogue=EPI_ADD, aux=x1)
+            fp, dact = ops.pgemm_nt(h2p, w1p, bias=c1, epilogue=EPI_GELU, aux=True, out_planes=True)
+            out = ops.pgemm_nt(fp, w2p, bias=c2, epilogue=EPI_ADD, aux=x1)
             saved += [x2, m1, r1, qkv, a2, lse, x1, m2, r2, dact]
             planes.append((h1p, ap, h2p, fp))
             x2 = out
@@ -632,20 +635,22 @@ class _PlaneVitTrunk(torch.autograd.Function):
         # the gradient entering the trunk is the one operand nobody produced in plane form; its column sums are the bias
         # gradient of the last block's second MLP layer (the other blocks get theirs from the LayerNorm backward above them)
         d2p, dc2 = ops.plane_split(d2, NPL, want_colsum=True)
+        wt = ops.plane_split_list([P[12 * i + k] for i in range(n_blocks) for k in (2, 4, 8, 10)], NPL, transposed=True)
         for i in range(n_blocks - 1, -1, -1):
+            wqkvt, wot, w1t, w2t = wt[4 * i: 4 * i + 4]
             x2, m1, r1, qkv, a2, lse, x1, m2, r2, dact = acts[NS * i: NS * i + NS]
             h1p, ap, h2p, fp = ctx.planes[i]
             g1, b1, wqkv, bqkv, wo, bo, g2, b2, w1, c1, w2, c2 = P[12 * i: 12 * i + 12]
             # input gradients dX = dY . W are NT products against the planes of the transposed weight; every bias gradient (a
             # column sum of a gradient matrix) comes out of the kernel that writes that matrix's planes
             dw2 = ops.pgemm_tn(d2p, fp)
-            dprep, dc1 = ops.pgemm_nt(d2p, ops.plane_split(w2, NPL, transposed=True), epilogue=EPI_GELU_BWD, aux=dact,
+            dprep, dc1 = ops.pgemm_nt(d2p, w2t, epilogue=EPI_GELU_BWD, aux=dact,
                                       out_planes=True, want_colsum=True)
             dw1 = ops.pgemm_tn(dprep, h2p)
-            dh2 = ops.pgemm_nt(dprep, ops.plane_split(w1, NPL, transposed=True))
+            dh2 = ops.pgemm_nt(dprep, w1t)
             dx1, dx1p, dg2, db2, dbo = ops.layernorm_bwd_planes(dh2, x1, m2, r2, g2, NPL, add=d2, want_colsum=True)   # + skip
             dwo = ops.pgemm_tn(dx1p, ap)
-            da = ops.pgemm_nt(dx1p, ops.plane_split(wo, NPL, transposed=True))
+            da = ops.pgemm_nt(dx1p, wot)
             if ops.attention_bwd_planes_supported(T, e // heads):
                 # one launch: Q, K, V, dO of a (sample, head) together in LDS, dqkv leaves as planes + column sums
                 dqkvp, dbqkv = ops.attention_bwd_planes(qkv.view(B, T, 3 * e), heads, scale, a2.view(B, T, e), lse,
@@ -657,7 +662,7 @@ class _PlaneVitTrunk(torch.autograd.Function):
                                   da.view(B, T, e), d3[..., :e], d3[..., e:2 * e], d3[..., 2 * e:])
                 dqkvp, dbqkv = ops.plane_split(dqkv, NPL, want_colsum=True)
             dwqkv = ops.pgemm_tn(dqkvp, h1p)
-            dh1 = ops.pgemm_nt(dqkvp, ops.plane_split(wqkv, NPL, transposed=True))
+            dh1 = ops.pgemm_nt(dqkvp, wqkvt)
             grads[12 * i: 12 * i + 12] = [None, None, dwqkv, dbqkv, dwo, dbo, dg2, db2, dw1, dc1, dw2, dc2]
             d2, d2p, dg1, db1, dc2 = ops.layernorm_bwd_planes(dh1, x2, m1, r1, g1, NPL, add=dx1, want_colsum=True)    # + skip
             grads[12 * i], grads[12 * i + 1] = dg1, db1

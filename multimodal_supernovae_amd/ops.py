@@ -1,5 +1,7 @@
 """Thin Python wrappers over the C-ABI (raw kernels, no autograd).  PyTorch is used only as the
 owner of device memory and of the current HIP stream; every FLOP happens in libmsn_hip.so."""
+import ctypes
+
 import torch
 
 from . import _lib
@@ -996,6 +998,33 @@ def attention_bwd_planes_supported(T, head_dim):
 
 def set_attention_fused(on):
     check(lib().msn_set_attention_fused(1 if on else 0), "msn_set_attention_fused")
+
+
+class _SplitItem(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("ldx", ctypes.c_int64), ("R", ctypes.c_int64), ("C", ctypes.c_int64),
+                ("transposed", ctypes.c_int), ("out", ctypes.c_void_p)]
+
+
+SPLIT_LIST = __import__("os").environ.get("MSN_SPLIT_LIST", "1") != "0"      # 0: one msn_plane_split launch per matrix (A/B runs)
+
+
+def plane_split_list(mats, planes=None, transposed=False):
+    """Planes of several 2-D fp32 matrices (or of their transposes) from ONE launch (msn_plane_split_list): the weights of
+    every block of a tower."""
+    planes = PLANES if planes is None else planes
+    if not SPLIT_LIST:
+        return [plane_split(m, planes, transposed=transposed) for m in mats]
+    items = (_SplitItem * len(mats))()
+    outs = []
+    for it, m in zip(items, mats):
+        _f32c(m, "x")
+        assert m.dim() == 2 and m.stride(1) == 1
+        R, C = m.shape
+        out = Planes.empty(C, R, planes, m.device) if transposed else Planes.empty(R, C, planes, m.device)
+        it.x, it.ldx, it.R, it.C, it.transposed, it.out = m.data_ptr(), m.stride(0), R, C, 1 if transposed else 0, out.buf.data_ptr()
+        outs.append(out)
+    check(lib().msn_plane_split_list(len(mats), ctypes.cast(items, ctypes.c_void_p), planes, stream_ptr()), "msn_plane_split_list")
+    return outs
 
 
 def pgemm_supported(M, N, K):

@@ -244,3 +244,18 @@ def test_deterministic():
     for x, y in zip(r1, r2):
         x, y = (x.buf, y.buf) if isinstance(x, ops.Planes) else (x, y)
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("planes", [3, 2])
+@pytest.mark.parametrize("transposed", [False, True])
+def test_split_list_equals_single_splits(planes, transposed):
+    """msn_plane_split_list (several matrices, one launch; more than one table's worth of items) == msn_plane_split of each."""
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(11)
+    shapes = [(1152, 384), (384, 384), (1536, 384), (384, 1536), (33, 17), (1, 5), (100, 260), (64, 64)] * 9      # 72 items
+    mats = [torch.randn(r, c, generator=g).cuda() for r, c in shapes]
+    mats[3] = torch.randn(384, 2000, generator=g).cuda()[:, 100:1636]           # a row stride that is not the width
+    got = ops.plane_split_list(mats, planes, transposed=transposed)
+    for m, p in zip(mats, got):
+        want = ops.plane_split(m, planes, transposed=transposed)
+        assert (p.R, p.C) == (want.R, want.C) and torch.equal(p.buf, want.buf)
