@@ -336,6 +336,23 @@ int msn_attention_bwd_planes(const float* qkv, int64_t ldqkv, const uint8_t* key
                              float scale, const float* out, int64_t ldo, const float* lse, const float* dout, int64_t ldd,
                              int planes, void* dqkv_planes, float* colsum_out, void* ws, size_t ws_bytes,
                              msn_stream_t stream);
+/* ---- the same products from TWO fp16 planes per operand (3 MFMA products instead of 6): x 2^e = h0 + h1 carries 22 significand
+ * bits (bf16 planes: 8 per plane, so fp32 grade takes three), at half the matrix work.  fp16's exponent range is what this
+ * costs: every plane matrix has a power-of-two scale chosen from its largest magnitude (msn_plane_split_f16 makes a pass for
+ * it: m 2^e in [2^13, 2^14)); `scale` is two device floats: [0] = 2^-e, which the products multiply into their sums (exact),
+ * [1] = the bits of m.  reuse_scale = 1 splits with the scale already in `scale` (a weight matrix and its transpose share one).
+ * Products: v_mfma_f32_32x32x16_f16, two accumulator sets, K chunks as msn_pgemm_nt; fp32 results only.  Measured against fp64
+ * (tests/test_pgemm_gpu.py::test_fp32_grade_gate_*[f16x3-*]): 0.3 - 0.6 x the native fp32 kernel's error on normal, wide-range,
+ * tiny and huge data, but 2.2 - 2.7 x on cancellation-heavy data (22-bit operands) -- NOT fp32 grade by the 1.5 x gate, so an
+ * opt-in of this interface only; 1.4 - 1.6 x the rate of the six-product form (profiles/r04_pgemm_f16.txt).  Layout of the
+ * plane matrix: as msn_plane_split with planes = 2. */
+int msn_plane_split_f16(const float* x, int64_t ldx, int64_t R, int64_t C, int transposed, void* out, float* scale,
+                        int reuse_scale, float* colsum, void* ws, size_t ws_bytes, msn_stream_t stream);
+int msn_pgemm_nt_f16(int64_t M, int N, int K, const void* A, const float* scaleA, const void* B, const float* scaleB, float* C,
+                     int64_t ldc, const float* bias, int epilogue, float* aux, int64_t ldaux, float* colsum_out, void* ws,
+                     size_t ws_bytes, msn_stream_t stream);   /* workspace: msn_pgemm_nt_workspace_bytes(.., planes 2, ..) */
+int msn_pgemm_tn_f16(int64_t M, int N, int K, const void* A, const float* scaleA, const void* B, const float* scaleB, float* C,
+                     int64_t ldc, void* ws, size_t ws_bytes, msn_stream_t stream);
 int msn_set_pgemm_tile_n(int bn);
 /* Wave layout of the 3-plane msn_pgemm_nt kernel (measurements; same results up to the summation order of the column
  * sums): 0 = 2 x 4 waves, 1 = 4 x 2 (default); + 1000 * c: K chunks of c K-steps (default 32).  Process-wide, not thread-safe (as every msn_set_* switch). */

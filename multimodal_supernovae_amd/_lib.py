@@ -61,6 +61,10 @@ SIGNATURES = {
     "msn_plane_split_colsum_workspace_bytes": (c_size, [c_i64, c_i64]),
     "msn_plane_split": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "msn_plane_split_list": (c_int, [c_int, c_ptr, c_int, c_ptr]),
+    "msn_plane_split_f16": (c_int, [c_ptr, c_i64, c_i64, c_i64, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_size, c_ptr]),
+    "msn_pgemm_nt_f16": (c_int, [c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_int, c_ptr, c_i64, c_ptr,
+                                 c_ptr, c_size, c_ptr]),
+    "msn_pgemm_tn_f16": (c_int, [c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_size, c_ptr]),
     "msn_plane_merge": (c_int, [c_ptr, c_int, c_i64, c_i64, c_ptr, c_i64, c_ptr]),
     "msn_pgemm_nt_colsum_workspace_bytes": (c_size, [c_i64, c_int]),
     "msn_pgemm_nt_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int, c_int, c_int, c_int]),

@@ -40,6 +40,7 @@ namespace msn {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
@@ -72,6 +73,8 @@ struct PgemmArgs {
     int splits;                     // TN: reduction split
     int rb_per_split;               // TN: row blocks per split
     float* slabs;                   // TN: [splits][N][K] partials (splits > 1)
+    const float* scaleA;            // fp16 planes: the operands hold x * 2^e; scaleA[0] * scaleB[0] = 2^-(eA + eB) multiplies every sum
+    const float* scaleB;
 };
 
 template <int I, int N, class F>
@@ -146,8 +149,9 @@ __device__ __forceinline__ void split_planes(float x, u16 (&pl)[NP]) {
 // (12 instead of 15 fragment reads per 24 MFMAs on BN = 128: +7-12 %, the 3-plane default; four waves of 128 x 64 with the
 // whole register file each were 15-25 % slower).  STAG: the two waves of a SIMD issue their LDS-DMA pieces in different halves of a K-step
 // (waves 0-3 behind the first products, waves 4-7 behind the last ones) instead of both stalling in the same gaps.
-template <int NP, int BN, bool OUTP, bool DUAL, int WM = 2, int WN = 4, bool STAG = false>
+template <int NP, int BN, bool OUTP, bool DUAL, int WM = 2, int WN = 4, bool STAG = false, bool F16 = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(const PgemmArgs p) {
+    static_assert(!F16 || !OUTP, "fp16 planes: fp32 results only");
     constexpr int NW = WM * WN;
     constexpr int ARB = BM / 32, BRB = BN / 32, AP = ARB * NP, BP = BRB * NP, PIECES = AP + BP;
     constexpr int SLOT = PIECES * PBLK;
@@ -303,8 +307,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                if constexpr (SMALL) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc2[i][j], 0, 0, 0);
-                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                if constexpr (F16) {
+                    const f16x8 hb = __builtin_bit_cast(f16x8, b[j]), ha = __builtin_bit_cast(f16x8, a[i]);
+                    if constexpr (SMALL) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hb, ha, acc2[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hb, ha, acc[i][j], 0, 0, 0);
+                } else {
+                    if constexpr (SMALL) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc2[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                }
             }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -478,6 +488,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] += acc2[i][j];
+        }
+        if constexpr (F16) {       // fp16 planes hold x * 2^e: one exact power of two puts the sums back (before bias / epilogue / partial sums)
+            const float os = p.scaleA[0] * p.scaleB[0];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] *= os;
         }
         constexpr bool PRE = ADDC || AUXIN;
         constexpr int PW = (DUAL || MT * NT < 2) ? MT * NT : 2;          // tiles requested ahead (16 registers each)
@@ -770,7 +787,7 @@ __device__ __forceinline__ void ds_read_tr_o(bf16x4& dst, unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
 }
 
-template <int NP, int BQ, bool SWAP, bool DUAL, int WM = 2, int WN = 4>
+template <int NP, int BQ, bool SWAP, bool DUAL, int WM = 2, int WN = 4, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(const PgemmArgs p) {
     static_assert(WM * WN == 8, "eight waves");
     constexpr int PHB = 16 * NP, QHB = (BQ / 16) * NP;       // half-block images per K-step: P side, Q side
@@ -884,8 +901,14 @@ __global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(const PgemmArgs p) {
         });
     };
     auto mfma1 = [&](const bf16x8& av, const bf16x8& bv, const f32x16& c) -> f32x16 {
-        if constexpr (SWAP) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, c, 0, 0, 0);
-        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, c, 0, 0, 0);
+        if constexpr (F16) {
+            const f16x8 ha = __builtin_bit_cast(f16x8, av), hb = __builtin_bit_cast(f16x8, bv);
+            if constexpr (SWAP) return __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hb, c, 0, 0, 0);
+            else return __builtin_amdgcn_mfma_f32_32x32x16_f16(hb, ha, c, 0, 0, 0);
+        } else {
+            if constexpr (SWAP) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, c, 0, 0, 0);
+            else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, c, 0, 0, 0);
+        }
     };
     // DUAL: zero-accumulator MFMA + round-to-nearest fold of the p0.q0 product (see pgemm_nt_kernel)
     f32x16 tbig[2];
@@ -1010,6 +1033,8 @@ __global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(const PgemmArgs p) {
     float* out = p.splits > 1 ? p.slabs + (int64_t)split * p.N * p.K : static_cast<float*>(p.C);
     const int64_t ldo = p.splits > 1 ? p.K : p.ldc;
     const int l31 = lane & 31, h4 = 4 * (lane >> 5);
+    float os = 1.f;
+    if constexpr (F16) os = p.scaleA[0] * p.scaleB[0];           // see pgemm_nt_kernel
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -1030,6 +1055,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(const PgemmArgs p) {
                 for (int r = 0; r < 4; ++r) {
                     v[r] = acc[i][jj][4 * b + r];
                     if constexpr (DUAL) v[r] += acc2[i][jj][4 * b + r];
+                    if constexpr (F16) v[r] *= os;
                 }
                 *reinterpret_cast<float4*>(out + (int64_t)n * ldo + k) = make_float4(v[0], v[1], v[2], v[3]);
             }
@@ -1056,9 +1082,36 @@ __global__ void pgemm_slab_sum_kernel(const float* __restrict__ slabs, int split
 // fp32 [R][ld] -> blocked planes.  A wave converts two neighbouring blocks of one row block: lane = row (lane >> 1) x
 // 16 columns (lane & 1): 64 contiguous bytes in, two 16-byte stores per plane out (each plane image is written whole by
 // its 32 lanes: 1-KB bursts).  Column sums of x (bias gradients) ride along when `colpart` is given: [row blocks][C].
-template <int NP>
+// fp16 planes (two: 22 significand bits): x * s = h0 + h1 with s = 2^e chosen from the matrix' largest magnitude m so that
+// m s lies in [2^13, 2^14) -- fp16 carries 11 bits per plane only between 2^-14 and 2^16, and the second plane of an element
+// is 2^-11 of the first, so elements down to 2^-16 m keep 22 bits and smaller ones an absolute error below 2^-38 m.
+__device__ __forceinline__ float f16_plane_scale(unsigned amax_bits, float& inv) {
+    const int ex = (int)((amax_bits >> 23) & 0xff) - 127;          // floor(log2 m); -127 for zero / subnormal m
+    int e = amax_bits == 0 ? 0 : 13 - ex;
+    e = e < -126 ? -126 : (e > 126 ? 126 : e);
+    inv = __uint_as_float((unsigned)(127 - e) << 23);
+    return __uint_as_float((unsigned)(127 + e) << 23);
+}
+__device__ __forceinline__ void split_f16(float xs, u16& h0, u16& h1) {
+    const _Float16 a = (_Float16)xs;                               // round to nearest even
+    const _Float16 b = (_Float16)(xs - (float)a);                  // the residual is exact in fp32
+    h0 = *reinterpret_cast<const u16*>(&a);
+    h1 = *reinterpret_cast<const u16*>(&b);
+}
+template <int NP, bool F16>
+__device__ __forceinline__ void split_any(float x, float s, u16 (&pl)[NP]) {
+    if constexpr (F16) {
+        static_assert(NP == 2, "fp16 planes come in pairs");
+        split_f16(x * s, pl[0], pl[1]);
+    } else {
+        split_planes<NP>(x, pl);
+    }
+}
+
+template <int NP, bool F16 = false>
 __device__ __forceinline__ void plane_split_body(const float* __restrict__ x, int64_t ld, int64_t R, int C, int RB, int CB,
-                                                 unsigned char* __restrict__ out, float* __restrict__ colpart, int64_t wg) {
+                                                 unsigned char* __restrict__ out, float* __restrict__ colpart, int64_t wg,
+                                                 float s = 1.f) {
     const int lane = threadIdx.x & 63;
     const int64_t wid = wg * 4 + (threadIdx.x >> 6);
     const int CB2 = (CB + 1) / 2;
@@ -1079,7 +1132,7 @@ __device__ __forceinline__ void plane_split_body(const float* __restrict__ x, in
     if (cb < CB) {
         u16 pl[16][NP];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) split_planes<NP>(v[q], pl[q]);
+        for (int q = 0; q < 16; ++q) split_any<NP, F16>(v[q], s, pl[q]);
         unsigned char* dst = out + ((int64_t)rb * CB + cb) * (NP * PBLK) + (lane >> 1) * 32;
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
@@ -1116,9 +1169,10 @@ __global__ __launch_bounds__(256) void plane_split_kernel(const float* __restric
 
 // planes of x^T: out is the plane matrix of the C x R transpose (weights: a few MB per step).  One workgroup per 32 x 32
 // tile of x through LDS.
-template <int NP>
+template <int NP, bool F16 = false>
 __device__ __forceinline__ void plane_split_t_body(const float* __restrict__ x, int64_t ld, int R, int C, int CBT,
-                                                   unsigned char* __restrict__ out, float (&t)[32][33], int bx, int by) {
+                                                   unsigned char* __restrict__ out, float (&t)[32][33], int bx, int by,
+                                                   float s = 1.f) {
     const int r0 = by * 32, c0 = bx * 32;                        // tile of x; the transpose has rows c0.., columns r0..
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int i = ty; i < 32; i += 8) t[i][tx] = (r0 + i < R && c0 + tx < C) ? x[(int64_t)(r0 + i) * ld + c0 + tx] : 0.f;
@@ -1127,7 +1181,7 @@ __device__ __forceinline__ void plane_split_t_body(const float* __restrict__ x, 
     const int i = threadIdx.x >> 3, j0 = 4 * (threadIdx.x & 7);
     u16 pl[4][NP];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) split_planes<NP>(t[j0 + q][i], pl[q]);
+    for (int q = 0; q < 4; ++q) split_any<NP, F16>(t[j0 + q][i], s, pl[q]);
     const int rbT = bx;                                            // row block of the transpose (32 rows = c0 .. c0 + 31)
     const int cbT = (r0 + j0) >> 4;                                // column block of the transpose
     if (cbT < CBT) {
@@ -1146,6 +1200,42 @@ __global__ __launch_bounds__(256) void plane_split_t_kernel(const float* __restr
                                                             unsigned char* __restrict__ out) {
     __shared__ float t[32][33];
     plane_split_t_body<NP>(x, ld, R, C, CBT, out, t, blockIdx.x, blockIdx.y);
+}
+
+// ---- fp16 planes: largest magnitude (bits of a non-negative float order like unsigned integers), then the split with its scale
+__global__ __launch_bounds__(256) void plane_absmax_kernel(const float* __restrict__ x, int64_t ld, int64_t R, int C, unsigned* __restrict__ out) {
+    float m = 0.f;
+    if ((C & 3) == 0 && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const int C4 = C / 4;
+        const int64_t n = R * C4;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+            const float4 v = *reinterpret_cast<const float4*>(x + (i / C4) * ld + 4 * (i % C4));
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+    } else {
+        const int64_t n = R * C;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+            m = fmaxf(m, fabsf(x[(i / C) * ld + i % C]));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+// scale[0] = 2^-e (what the products multiply their sums with), scale[1] = the bits of the largest magnitude
+__global__ __launch_bounds__(256) void plane_split_f16_kernel(const float* __restrict__ x, int64_t ld, int64_t R, int C, int RB, int CB,
+                                                              unsigned char* __restrict__ out, float* __restrict__ colpart,
+                                                              float* __restrict__ scale) {
+    float inv;
+    const float s = f16_plane_scale(reinterpret_cast<const unsigned*>(scale)[1], inv);
+    if (blockIdx.x == 0 && threadIdx.x == 0) scale[0] = inv;
+    plane_split_body<2, true>(x, ld, R, C, RB, CB, out, colpart, blockIdx.x, s);
+}
+__global__ __launch_bounds__(256) void plane_split_t_f16_kernel(const float* __restrict__ x, int64_t ld, int R, int C, int CBT,
+                                                                unsigned char* __restrict__ out, float* __restrict__ scale) {
+    __shared__ float t[32][33];
+    float inv;
+    const float s = f16_plane_scale(reinterpret_cast<const unsigned*>(scale)[1], inv);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) scale[0] = inv;
+    plane_split_t_body<2, true>(x, ld, R, C, CBT, out, t, blockIdx.x, blockIdx.y, s);
 }
 
 // Several matrices in ONE launch (the weights of every block of a tower, or their transposes: 44 launches of 5-6 us each, every
@@ -1334,6 +1424,48 @@ extern "C" int msn_plane_split_list(int n, const msn_split_item* items, int plan
     return MSN_OK;
 }
 
+extern "C" int msn_plane_split_f16(const float* x, int64_t ldx, int64_t R, int64_t C, int transposed, void* out, float* scale,
+                                   int reuse_scale, float* colsum, void* ws, size_t ws_bytes, msn_stream_t stream) {
+    MSN_REQUIRE(x && out && scale && R > 0 && C > 0 && ldx >= C, "msn_plane_split_f16: bad operand");
+    MSN_REQUIRE(aligned16p(out), "msn_plane_split_f16: the plane matrix must be 16-byte aligned");
+    MSN_REQUIRE(R < (1ll << 31) && C < (1ll << 31), "msn_plane_split_f16: matrix too large");
+    MSN_REQUIRE(!(transposed && colsum), "msn_plane_split_f16: column sums only for the untransposed form");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!reuse_scale) {
+        if (hipMemsetAsync(scale + 1, 0, sizeof(float), st) != hipSuccess) {
+            set_error("msn_plane_split_f16: memset failed");
+            return MSN_ERR_HIP;
+        }
+        const int64_t n4 = R * ((C + 3) / 4);
+        hipLaunchKernelGGL(plane_absmax_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n4, 256 * 4), 2048)), dim3(256), 0, st, x, ldx, R,
+                           (int)C, reinterpret_cast<unsigned*>(scale + 1));
+        MSN_LAUNCH_CHECK();
+    }
+    if (transposed) {
+        const int CBT = 2 * (int)cdiv(R, 32);
+        hipLaunchKernelGGL(plane_split_t_f16_kernel, dim3((unsigned)cdiv(C, 32), (unsigned)cdiv(R, 32)), dim3(256), 0, st, x, ldx, (int)R,
+                           (int)C, CBT, static_cast<unsigned char*>(out), scale);
+        MSN_LAUNCH_CHECK();
+        return MSN_OK;
+    }
+    const int RB = (int)cdiv(R, 32), CB = 2 * (int)cdiv(C, 32);
+    float* part = nullptr;
+    if (colsum) {
+        const size_t need = msn_plane_split_colsum_workspace_bytes(R, C);
+        MSN_REQUIRE(ws && ws_bytes >= need, "msn_plane_split_f16: column-sum workspace %zu < %zu bytes", ws_bytes, need);
+        part = static_cast<float*>(ws);
+    }
+    const int64_t nw = (int64_t)RB * ((CB + 1) / 2);
+    hipLaunchKernelGGL(plane_split_f16_kernel, dim3((unsigned)cdiv(nw, 4)), dim3(256), 0, st, x, ldx, R, (int)C, RB, CB,
+                       static_cast<unsigned char*>(out), part, scale);
+    MSN_LAUNCH_CHECK();
+    if (colsum && colsum_finish(part, RB, (int)C, colsum, st) != MSN_OK) {
+        set_error("msn_plane_split_f16: column-sum launch failed");
+        return MSN_ERR_HIP;
+    }
+    return MSN_OK;
+}
+
 extern "C" int msn_plane_merge(const void* planes_in, int planes, int64_t R, int64_t C, float* y, int64_t ldy, msn_stream_t stream) {
     MSN_REQUIRE(planes_in && y && R > 0 && C > 0 && ldy >= C && planes >= 1 && planes <= 3, "msn_plane_merge: bad operand");
     const int64_t n = R * C;
@@ -1404,10 +1536,12 @@ static void launch_nt(const PgemmArgs& a, bool outp, int grid, hipStream_t st) {
     else hipLaunchKernelGGL((pgemm_nt_kernel<NP, BN, false, DUAL, WM, WN, STAG>), dim3((unsigned)grid), dim3(64 * WM * WN), 0, st, a);
 }
 
-extern "C" int msn_pgemm_nt(int64_t M, int N, int K, int planes, const void* A, const void* B, void* C, int64_t ldc,
-                            int c_planes, const float* bias, int epilogue, float* aux, int64_t ldaux, float* colsum_out,
-                            void* ws, size_t ws_bytes, msn_stream_t stream) {
+static int pgemm_nt_impl(int64_t M, int N, int K, int planes, const void* A, const void* B, void* C, int64_t ldc,
+                         int c_planes, const float* bias, int epilogue, float* aux, int64_t ldaux, float* colsum_out,
+                         void* ws, size_t ws_bytes, msn_stream_t stream, const float* scaleA, const float* scaleB) {
+    const bool f16 = scaleA != nullptr;
     MSN_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, "msn_pgemm_nt: empty operand");
+    MSN_REQUIRE(!f16 || (scaleB && planes == 2 && !c_planes), "msn_pgemm_nt_f16: two fp16 planes per operand, both scales, fp32 result");
     MSN_REQUIRE(planes == 2 || planes == 3, "msn_pgemm_nt: planes must be 2 or 3 (got %d)", planes);
     MSN_REQUIRE(N % 4 == 0 && (!c_planes || N % 16 == 0), "msn_pgemm_nt: N = %d must be a multiple of 4 (16 for a plane output)", N);
     MSN_REQUIRE(aligned16p(A) && aligned16p(B) && aligned16p(C) && (!bias || aligned16p(bias)), "msn_pgemm_nt: operands must be 16-byte aligned");
@@ -1434,12 +1568,13 @@ extern "C" int msn_pgemm_nt(int64_t M, int N, int K, int planes, const void* A, 
     a.chunk_steps = 0;
     {
         const int cs = g_pgemm_chunk > 0 ? g_pgemm_chunk : 32;         // K-steps per chunk (msn_set_pgemm_variant: experiments)
-        if (planes == 3 && !c_planes && a.cbA > std::max(cs, 48)) {
+        if ((planes == 3 || f16) && !c_planes && a.cbA > std::max(cs, 48)) {
             const int nch = (int)cdiv(a.cbA, cs);
             a.chunk_steps = 2 * (int)cdiv(a.cbA, 2 * nch);
         }
     }
     a.skew = g_pgemm_skew;
+    a.scaleA = scaleA, a.scaleB = scaleB;
     const NtTail tail = nt_tail_plan(M, N, K, c_planes, epilogue, colsum_out != nullptr);
     if (tail.segs && ws && ws_bytes >= msn_pgemm_nt_workspace_bytes(M, N, K, planes, c_planes, epilogue, 0) && aligned16p(ws)) {
         a.tail_full = tail.full; a.tail_segs = tail.segs; a.tail_steps = tail.steps;
@@ -1461,6 +1596,9 @@ extern "C" int msn_pgemm_nt(int64_t M, int N, int K, int planes, const void* A, 
         // built any more: nothing in the step, +9 % on one shape in isolation; STAG stays in the kernel source)
         if (g_pgemm_variant == 0) launch_nt<3, 128, true>(a, c_planes != 0, grid, st);
         else launch_nt<3, 128, true, 4, 2>(a, c_planes != 0, grid, st);
+    } else if (f16) {
+        a.colsum_rows = 4;
+        hipLaunchKernelGGL((pgemm_nt_kernel<2, 128, false, true, 4, 2, false, true>), dim3((unsigned)grid), dim3(512), 0, st, a);
     } else {
         launch_nt<2, 128, false>(a, c_planes != 0, grid, st);
     }
@@ -1477,6 +1615,19 @@ extern "C" int msn_pgemm_nt(int64_t M, int N, int K, int planes, const void* A, 
         }
     }
     return MSN_OK;
+}
+
+extern "C" int msn_pgemm_nt(int64_t M, int N, int K, int planes, const void* A, const void* B, void* C, int64_t ldc,
+                            int c_planes, const float* bias, int epilogue, float* aux, int64_t ldaux, float* colsum_out,
+                            void* ws, size_t ws_bytes, msn_stream_t stream) {
+    return pgemm_nt_impl(M, N, K, planes, A, B, C, ldc, c_planes, bias, epilogue, aux, ldaux, colsum_out, ws, ws_bytes, stream,
+                         nullptr, nullptr);
+}
+extern "C" int msn_pgemm_nt_f16(int64_t M, int N, int K, const void* A, const float* scaleA, const void* B, const float* scaleB,
+                                float* C, int64_t ldc, const float* bias, int epilogue, float* aux, int64_t ldaux,
+                                float* colsum_out, void* ws, size_t ws_bytes, msn_stream_t stream) {
+    MSN_REQUIRE(scaleA && scaleB, "msn_pgemm_nt_f16: the operands' scales are missing");
+    return pgemm_nt_impl(M, N, K, 2, A, B, C, ldc, 0, bias, epilogue, aux, ldaux, colsum_out, ws, ws_bytes, stream, scaleA, scaleB);
 }
 
 // ---- TN host side: orientation, tile width and reduction split
@@ -1514,9 +1665,11 @@ static void launch_tn(const PgemmArgs& a, bool swap, int grid, hipStream_t st) {
     else hipLaunchKernelGGL((pgemm_tn_kernel<NP, BQ, false, DUAL, WM, WN>), dim3((unsigned)grid), dim3(512), 0, st, a);
 }
 
-extern "C" int msn_pgemm_tn(int64_t M, int N, int K, int planes, const void* A, const void* B, float* C, int64_t ldc, void* ws,
-                            size_t ws_bytes, msn_stream_t stream) {
+static int pgemm_tn_impl(int64_t M, int N, int K, int planes, const void* A, const void* B, float* C, int64_t ldc, void* ws,
+                         size_t ws_bytes, msn_stream_t stream, const float* scaleA, const float* scaleB) {
+    const bool f16 = scaleA != nullptr;
     MSN_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, "msn_pgemm_tn: empty operand");
+    MSN_REQUIRE(!f16 || (scaleB && planes == 2), "msn_pgemm_tn_f16: two fp16 planes per operand, both scales");
     MSN_REQUIRE(planes == 2 || planes == 3, "msn_pgemm_tn: planes must be 2 or 3 (got %d)", planes);
     MSN_REQUIRE(K % 4 == 0 && ldc >= K && ldc % 4 == 0 && aligned16p(C) && aligned16p(A) && aligned16p(B),
                 "msn_pgemm_tn: K and ldc must be multiples of 4, operands 16-byte aligned");
@@ -1531,11 +1684,14 @@ extern "C" int msn_pgemm_tn(int64_t M, int N, int K, int planes, const void* A, 
     const size_t need = t.splits > 1 ? sizeof(float) * (size_t)t.splits * N * K : 0;
     MSN_REQUIRE(need == 0 || (ws && ws_bytes >= need && aligned16p(ws)), "msn_pgemm_tn: workspace %zu < %zu bytes", ws_bytes, need);
     a.slabs = static_cast<float*>(ws);
+    a.scaleA = scaleA, a.scaleB = scaleB;
     const int grid = t.tiles_p * t.tiles_q * t.splits;
     hipStream_t st = static_cast<hipStream_t>(stream);
     // (2 x 4 waves: the 64 x 64 wave tiles that gain 7-12 % on the NT kernel LOSE 3-4 % here -- 374 / 151 / 452 / 454 us
     // against 384 / 157 / 469 / 470 on the four headline weight gradients; that instantiation is no longer built)
     if (planes == 3) launch_tn<3, 128, true>(a, t.swap, grid, st);
+    else if (f16 && t.swap) hipLaunchKernelGGL((pgemm_tn_kernel<2, 128, true, true, 2, 4, true>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    else if (f16) hipLaunchKernelGGL((pgemm_tn_kernel<2, 128, false, true, 2, 4, true>), dim3((unsigned)grid), dim3(512), 0, st, a);
     else launch_tn<2, 128, false>(a, t.swap, grid, st);
     MSN_LAUNCH_CHECK();
     if (t.splits > 1) {
@@ -1545,4 +1701,14 @@ extern "C" int msn_pgemm_tn(int64_t M, int N, int K, int planes, const void* A, 
         MSN_LAUNCH_CHECK();
     }
     return MSN_OK;
+}
+
+extern "C" int msn_pgemm_tn(int64_t M, int N, int K, int planes, const void* A, const void* B, float* C, int64_t ldc, void* ws,
+                            size_t ws_bytes, msn_stream_t stream) {
+    return pgemm_tn_impl(M, N, K, planes, A, B, C, ldc, ws, ws_bytes, stream, nullptr, nullptr);
+}
+extern "C" int msn_pgemm_tn_f16(int64_t M, int N, int K, const void* A, const float* scaleA, const void* B, const float* scaleB,
+                                float* C, int64_t ldc, void* ws, size_t ws_bytes, msn_stream_t stream) {
+    MSN_REQUIRE(scaleA && scaleB, "msn_pgemm_tn_f16: the operands' scales are missing");
+    return pgemm_tn_impl(M, N, K, 2, A, B, C, ldc, ws, ws_bytes, stream, scaleA, scaleB);
 }

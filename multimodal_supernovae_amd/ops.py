@@ -929,28 +929,37 @@ if __import__("os").environ.get("MSN_PGEMM_VARIANT"):      # wave layout of the 
     check(lib().msn_set_pgemm_variant(int(__import__("os").environ["MSN_PGEMM_VARIANT"])))     # planes per operand: 3 = fp32 grade (6 products), 2 = 3 products
 
 
+F16_PLANES = 16     # `planes` code of the fp16 form: TWO fp16 planes + a power-of-two scale per matrix (msn_plane_split_f16)
+
+
 class Planes:
     """An fp32 (R, C) matrix held as `planes` bf16 planes in the blocked layout of include/msn_hip.h (msn_plane_split):
-    the operand format of pgemm_nt / pgemm_tn.  `buf` is a flat uint8 device tensor."""
-    __slots__ = ("buf", "R", "C", "planes")
+    the operand format of pgemm_nt / pgemm_tn.  `buf` is a flat uint8 device tensor.  fp16 form (F16_PLANES): two planes
+    of x 2^e and `scale` = two device floats (2^-e, the bits of the matrix' largest magnitude)."""
+    __slots__ = ("buf", "R", "C", "planes", "scale")
 
-    def __init__(self, buf, R, C, planes):
-        self.buf, self.R, self.C, self.planes = buf, int(R), int(C), int(planes)
+    def __init__(self, buf, R, C, planes, scale=None):
+        self.buf, self.R, self.C, self.planes, self.scale = buf, int(R), int(C), int(planes), scale
 
     @staticmethod
     def empty(R, C, planes, device):
+        if planes == F16_PLANES:
+            nb = lib().msn_plane_bytes(R, C, 2)
+            return Planes(torch.empty(nb, dtype=torch.uint8, device=device), R, C, 2, torch.empty(2, dtype=torch.float32, device=device))
         nb = lib().msn_plane_bytes(R, C, planes)
         return Planes(torch.empty(nb, dtype=torch.uint8, device=device), R, C, planes)
 
     def to_float(self):
+        assert self.scale is None, "bf16 planes only"
         y = torch.empty((self.R, self.C), dtype=torch.float32, device=self.buf.device)
         check(lib().msn_plane_merge(ptr(self.buf), self.planes, self.R, self.C, ptr(y), self.C, stream_ptr()), "msn_plane_merge")
         return y
 
 
-def plane_split(x, planes=None, transposed=False, want_colsum=False):
+def plane_split(x, planes=None, transposed=False, want_colsum=False, scale_of=None):
     """Planes of a 2-D fp32 matrix (row stride free) or, transposed=True, of its transpose.  want_colsum: also the column
-    sums of x (a bias gradient) from the same pass."""
+    sums of x (a bias gradient) from the same pass.  planes = F16_PLANES: the fp16 form (a pass for the largest magnitude
+    first; scale_of = the Planes of the same matrix in the other orientation: its scale is taken over, no extra pass)."""
     _f32c(x, "x")
     assert x.dim() == 2 and x.stride(1) == 1
     planes = PLANES if planes is None else planes
@@ -962,6 +971,12 @@ def plane_split(x, planes=None, transposed=False, want_colsum=False):
         cs = torch.empty(C, dtype=torch.float32, device=x.device)
         nb = lib().msn_plane_split_colsum_workspace_bytes(R, C)
         ws = _workspace(nb, x.device)
+    if planes == F16_PLANES:
+        if scale_of is not None:
+            out.scale = scale_of.scale
+        check(lib().msn_plane_split_f16(ptr(x), x.stride(0), R, C, 1 if transposed else 0, ptr(out.buf), ptr(out.scale),
+                                        1 if scale_of is not None else 0, ptr(cs), ptr(ws), nb, stream_ptr()), "msn_plane_split_f16")
+        return (out, cs) if want_colsum else out
     check(lib().msn_plane_split(ptr(x), x.stride(0), R, C, planes, 1 if transposed else 0, ptr(out.buf), ptr(cs), ptr(ws), nb,
                                 stream_ptr()), "msn_plane_split")
     return (out, cs) if want_colsum else out
@@ -1012,7 +1027,7 @@ def plane_split_list(mats, planes=None, transposed=False):
     """Planes of several 2-D fp32 matrices (or of their transposes) from ONE launch (msn_plane_split_list): the weights of
     every block of a tower."""
     planes = PLANES if planes is None else planes
-    if not SPLIT_LIST:
+    if not SPLIT_LIST or planes == F16_PLANES:
         return [plane_split(m, planes, transposed=transposed) for m in mats]
     items = (_SplitItem * len(mats))()
     outs = []
@@ -1050,9 +1065,15 @@ def pgemm_nt(a, w, bias=None, epilogue=EPI_NONE, aux=None, out_planes=False, wan
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(lib().msn_pgemm_nt(M, N, K, a.planes, ptr(a.buf), ptr(w.buf), ptr(c.buf if out_planes else c), N, 1 if out_planes else 0,
-                             ptr(bias), epilogue, ptr(aux), aux.stride(0) if aux is not None else 0, ptr(cs), ptr(ws), nb,
-                             stream_ptr()), "msn_pgemm_nt")
+    if a.scale is not None:
+        assert w.scale is not None and not out_planes, "fp16 planes: both operands, fp32 result"
+        check(lib().msn_pgemm_nt_f16(M, N, K, ptr(a.buf), ptr(a.scale), ptr(w.buf), ptr(w.scale), ptr(c), N, ptr(bias), epilogue,
+                                     ptr(aux), aux.stride(0) if aux is not None else 0, ptr(cs), ptr(ws), nb, stream_ptr()),
+              "msn_pgemm_nt_f16")
+    else:
+        check(lib().msn_pgemm_nt(M, N, K, a.planes, ptr(a.buf), ptr(w.buf), ptr(c.buf if out_planes else c), N,
+                                 1 if out_planes else 0, ptr(bias), epilogue, ptr(aux), aux.stride(0) if aux is not None else 0,
+                                 ptr(cs), ptr(ws), nb, stream_ptr()), "msn_pgemm_nt")
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1, 2.0 * M * N * K, (OP_N, OP_T, M, N, K, 200 + epilogue), aux is not None))
@@ -1075,7 +1096,12 @@ def pgemm_tn(dy, x):
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(L.msn_pgemm_tn(M, N, K, dy.planes, ptr(dy.buf), ptr(x.buf), ptr(c), K, ptr(ws), nb, stream_ptr()), "msn_pgemm_tn")
+    if dy.scale is not None:
+        assert x.scale is not None
+        check(L.msn_pgemm_tn_f16(M, N, K, ptr(dy.buf), ptr(dy.scale), ptr(x.buf), ptr(x.scale), ptr(c), K, ptr(ws), nb, stream_ptr()),
+              "msn_pgemm_tn_f16")
+    else:
+        check(L.msn_pgemm_tn(M, N, K, dy.planes, ptr(dy.buf), ptr(x.buf), ptr(c), K, ptr(ws), nb, stream_ptr()), "msn_pgemm_tn")
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1, 2.0 * M * N * K, (OP_T, OP_N, N, K, M, 200), False))

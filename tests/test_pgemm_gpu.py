@@ -128,26 +128,45 @@ HEADLINE_SHAPES = [   # (N, K) of the ViT-S/8 block products, forward and input-
     (1152, 384), (384, 384), (1536, 384), (384, 1536), (384, 1152), (384, 192)]
 
 
+def _planes_code(arith):
+    from multimodal_supernovae_amd import ops
+    return {"bf16x6": 3, "f16x3": ops.F16_PLANES}[arith]
+
+
 @pytest.mark.parametrize("N,K", HEADLINE_SHAPES)
-@pytest.mark.parametrize("kind", ["normal", "cancel", "wide"])
-def test_fp32_grade_gate_nt(N, K, kind):
-    """max and RMS error of the 6-product plane GEMM against fp64 <= 1.5 x the native fp32 MFMA kernel's."""
+@pytest.mark.parametrize("kind", ["normal", "cancel", "wide", "tiny", "huge"])
+@pytest.mark.parametrize("arith", ["bf16x6", "f16x3"])
+def test_fp32_grade_gate_nt(N, K, kind, arith):
+    """max and RMS error of the plane GEMMs against fp64 <= 1.5 x the native fp32 MFMA kernel's: three bf16 planes / six
+    products (the default arithmetic: passes everywhere), and two fp16 planes / three products with the per-matrix
+    power-of-two scale (tiny / huge: the whole matrix outside fp16's own range).  The fp16 form passes on every kind of
+    data but one: its operands carry 22 significand bits, not 24, and where the inner products CANCEL (native: exact
+    products, the error is the last rounding) that shows -- measured 2.2 - 2.7 x the native kernel's.  That is why it is an
+    opt-in of the C-ABI and not the default; the bound asserted for it there is 3 x."""
     from multimodal_supernovae_amd import ops
     M = 2080                                             # 32 cutouts x 65 tokens: the error statistics do not depend on M
     g = torch.Generator().manual_seed(N + K)
-    a, w = _operands(kind, M, N, K, g)
+    a, w = _operands("normal" if kind in ("tiny", "huge") else kind, M, N, K, g)
+    if kind == "tiny":
+        a, w = a * 1e-12, w * 3e-9
+    if kind == "huge":
+        a, w = a * 1e9, w * 7e5
+    pc = _planes_code(arith)
     ref = a.double() @ w.double().T
     c_nat = ops.sgemm(a.cuda(), w.cuda(), ops.OP_N, ops.OP_T, precision=ops.PREC_F32).cpu().double()
-    c_pl = ops.pgemm_nt(ops.plane_split(a.cuda(), 3), ops.plane_split(w.cuda(), 3)).cpu().double()
+    c_pl = ops.pgemm_nt(ops.plane_split(a.cuda(), pc), ops.plane_split(w.cuda(), pc)).cpu().double()
     e_nat, e_pl = (c_nat - ref).abs(), (c_pl - ref).abs()
-    assert float(e_pl.max()) <= 1.5 * float(e_nat.max()) + 1e-30, (float(e_pl.max()), float(e_nat.max()))
-    assert float(e_pl.pow(2).mean().sqrt()) <= 1.5 * float(e_nat.pow(2).mean().sqrt()) + 1e-30
+    lim = 3.0 if (arith == "f16x3" and kind == "cancel") else 1.5
+    assert float(e_pl.max()) <= lim * float(e_nat.max()) + 1e-30, (float(e_pl.max()), float(e_nat.max()))
+    assert float(e_pl.pow(2).mean().sqrt()) <= lim * float(e_nat.pow(2).mean().sqrt()) + 1e-30
 
 
 @pytest.mark.parametrize("N,K", [(1152, 384), (384, 384), (1536, 384), (384, 1536)])
 @pytest.mark.parametrize("kind", ["normal", "cancel", "wide"])
-def test_fp32_grade_gate_tn(N, K, kind):
+@pytest.mark.parametrize("arith", ["bf16x6", "f16x3"])
+def test_fp32_grade_gate_tn(N, K, kind, arith):
     from multimodal_supernovae_amd import ops
+    pc = _planes_code(arith)
     M = 66560 // 8
     g = torch.Generator().manual_seed(N * 3 + K)
     # the reduction runs over the rows here: build the operands reduction-major
@@ -155,10 +174,11 @@ def test_fp32_grade_gate_tn(N, K, kind):
     dy, x = at.T.contiguous(), wt.T.contiguous()
     ref = dy.double().T @ x.double()
     c_nat = ops.sgemm(dy.cuda(), x.cuda(), ops.OP_T, ops.OP_N, precision=ops.PREC_F32).cpu().double()
-    c_pl = ops.pgemm_tn(ops.plane_split(dy.cuda(), 3), ops.plane_split(x.cuda(), 3)).cpu().double()
+    c_pl = ops.pgemm_tn(ops.plane_split(dy.cuda(), pc), ops.plane_split(x.cuda(), pc)).cpu().double()
     e_nat, e_pl = (c_nat - ref).abs(), (c_pl - ref).abs()
-    assert float(e_pl.max()) <= 1.5 * float(e_nat.max()) + 1e-30, (float(e_pl.max()), float(e_nat.max()))
-    assert float(e_pl.pow(2).mean().sqrt()) <= 1.5 * float(e_nat.pow(2).mean().sqrt()) + 1e-30
+    lim = 3.0 if (arith == "f16x3" and kind == "cancel") else 1.5
+    assert float(e_pl.max()) <= lim * float(e_nat.max()) + 1e-30, (float(e_pl.max()), float(e_nat.max()))
+    assert float(e_pl.pow(2).mean().sqrt()) <= lim * float(e_nat.pow(2).mean().sqrt()) + 1e-30
 
 
 @pytest.mark.parametrize("variant", [0])
@@ -259,3 +279,29 @@ def test_split_list_equals_single_splits(planes, transposed):
     for m, p in zip(mats, got):
         want = ops.plane_split(m, planes, transposed=transposed)
         assert (p.R, p.C) == (want.R, want.C) and torch.equal(p.buf, want.buf)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 272, 200), (4096, 1536, 384), (777, 384, 1536), (66560 // 4, 384, 384), (33, 16, 8)])
+def test_f16_planes_exact_on_integers(M, N, K):
+    """Two fp16 planes with their scales: small integers are exact whatever power of two the matrices are scaled by; the
+    transposed split shares the scale; bias, epilogues and column sums go through the same epilogue as the bf16 form."""
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w = _ints((M, K), g), _ints((N, K), g)
+    bias = _ints((N,), g).cuda()
+    for sa, sw in ((1.0, 1.0), (2.0 ** -30, 2.0 ** 9), (2.0 ** 40, 2.0 ** -3)):
+        A, W = (a * sa).cuda(), (w * sw).cuda()
+        ap, wp = ops.plane_split(A, ops.F16_PLANES), ops.plane_split(W, ops.F16_PLANES)
+        ref = (a.double() @ w.double().T) * (sa * sw)
+        c, cs = ops.pgemm_nt(ap, wp, want_colsum=True)
+        assert torch.equal(c.cpu().double(), ref)
+        torch.testing.assert_close(cs.cpu().double(), ref.sum(0), rtol=1e-6, atol=0)
+        if sa == 1.0:
+            r = ops.pgemm_nt(ap, wp, bias=bias, epilogue=ops.EPI_RELU)
+            assert torch.equal(r.cpu().double(), (ref + bias.cpu().double()).clamp_min(0))
+        # dX = dY . W through the transposed planes of W (scale shared), dW = dY^T . X
+        dy = _ints((M, N), g)
+        dyp = ops.plane_split(dy.cuda(), ops.F16_PLANES)
+        wt = ops.plane_split(W, ops.F16_PLANES, transposed=True, scale_of=wp)
+        assert torch.equal(ops.pgemm_nt(dyp, wt).cpu().double(), (dy.double() @ w.double()) * sw)
+        assert torch.equal(ops.pgemm_tn(dyp, ap).cpu().double(), (dy.double().T @ a.double()) * sa)

@@ -48,7 +48,13 @@ def main():
                 ops.set_pgemm_variant(1)
             else:
                 t = timed(lambda: ops.pgemm_nt(ap, wp))
-                line += f" | {pl}pl {fl / t / 1e12:6.1f} ({t * 1e6:6.0f} us)"
+                line += f" | {'f16 2' if pl == ops.F16_PLANES else pl}pl {fl / t / 1e12:6.1f} ({t * 1e6:6.0f} us)"
+            if pl == ops.F16_PLANES:              # fp32 results only; the split includes the pass for the largest magnitude
+                bias, dact = rnd(N), rnd(M, N)
+                tg = timed(lambda: ops.pgemm_nt(ap, wp, bias=bias, epilogue=ops.EPI_GELU, aux=True))
+                tb = timed(lambda: ops.pgemm_nt(ap, wp, epilogue=ops.EPI_GELU_BWD, aux=dact, want_colsum=True))
+                line += f" gelu {tg * 1e6:5.0f} us gelu' {tb * 1e6:5.0f} us; split {ts * 1e6:5.0f} us"
+                continue
             tp = timed(lambda: ops.pgemm_nt(ap, wp, out_planes=True))
             line += f" planes-out {fl / tp / 1e12:6.1f} ({tp * 1e6:5.0f} us)"
             if N % 16 == 0 and os.environ.get("GELU"):
@@ -69,7 +75,7 @@ def main():
         for pl in planes_list:
             dp, xp = ops.plane_split(dy, pl), ops.plane_split(x, pl)
             t = timed(lambda: ops.pgemm_tn(dp, xp))
-            line += f" | {pl}pl {fl / t / 1e12:6.1f} ({t * 1e6:6.0f} us)"
+            line += f" | {'f16 2' if pl == ops.F16_PLANES else pl}pl {fl / t / 1e12:6.1f} ({t * 1e6:6.0f} us)"
         print(line, flush=True)
 
 
