@@ -1327,6 +1327,9 @@ static bool aligned16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) &
 
 using namespace msn;
 
+extern "C" size_t msn_colsum_workspace_bytes(int64_t M, int64_t N);       // gemm.hip
+extern "C" int msn_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, float* out, void* ws, size_t ws_bytes, msn_stream_t stream);
+
 static int g_pgemm_bn = 0;          // 0 = planned, 128 / 256 forced (measurements)
 static int g_pgemm_skew = 0;        // NT start skew (shader cycles per phase; experiments)
 extern "C" int msn_set_pgemm_skew(int cycles) {
@@ -1524,7 +1527,7 @@ extern "C" int msn_set_pgemm_tail_split(int enabled) {
 
 extern "C" size_t msn_pgemm_nt_workspace_bytes(int64_t M, int N, int K, int planes, int c_planes, int epilogue, int want_colsum) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    if (want_colsum) return msn_pgemm_nt_colsum_workspace_bytes(M, N);
+    if (want_colsum) return std::max(msn_pgemm_nt_colsum_workspace_bytes(M, N), msn_colsum_workspace_bytes(M, N));   // (chunked K: see below)
     const NtTail t = nt_tail_plan(M, N, K, c_planes, epilogue, false);
     const int total = (int)(cdiv(M, BM) * cdiv(N, 128));
     return t.segs ? sizeof(float) * (size_t)(total - t.full) * t.segs * BM * 128 : 0;
@@ -1581,7 +1584,10 @@ static int pgemm_nt_impl(int64_t M, int N, int K, int planes, const void* A, con
         a.tail_slabs = static_cast<float*>(ws);
     }
     a.colpart = nullptr;
-    if (colsum_out) {
+    // a reduction cut into K chunks meets its partial sums in C: the column sums of the finished values are then taken from C
+    // by msn_colsum behind the product (the chunked epilogues carry no column-sum form)
+    const bool colsum_after = colsum_out && a.chunk_steps > 0;
+    if (colsum_out && !colsum_after) {
         const size_t need = msn_pgemm_nt_colsum_workspace_bytes(M, N);
         MSN_REQUIRE(ws && ws_bytes >= need && aligned16p(ws), "msn_pgemm_nt: column-sum workspace %zu < %zu bytes", ws_bytes, need);
         a.colpart = static_cast<float*>(ws);
@@ -1608,6 +1614,7 @@ static int pgemm_nt_impl(int64_t M, int N, int K, int planes, const void* A, con
         hipLaunchKernelGGL(pgemm_tail_finish_kernel, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, st, a, bn);
         MSN_LAUNCH_CHECK();
     }
+    if (colsum_after) return msn_colsum(static_cast<const float*>(C), ldc, M, N, colsum_out, ws, ws_bytes, stream);
     if (colsum_out) {
         if (colsum_finish(a.colpart, (a.colsum_rows ? a.colsum_rows : 2) * a.tiles_m, N, colsum_out, st) != MSN_OK) {
             set_error("msn_pgemm_nt: column-sum launch failed");

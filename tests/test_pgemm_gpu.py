@@ -305,3 +305,17 @@ def test_f16_planes_exact_on_integers(M, N, K):
         wt = ops.plane_split(W, ops.F16_PLANES, transposed=True, scale_of=wp)
         assert torch.equal(ops.pgemm_nt(dyp, wt).cpu().double(), (dy.double() @ w.double()) * sw)
         assert torch.equal(ops.pgemm_tn(dyp, ap).cpu().double(), (dy.double().T @ a.double()) * sa)
+
+
+@pytest.mark.parametrize("M,N,K", [(777, 384, 1536), (2080, 384, 1152), (300, 272, 200)])
+def test_column_sums_of_a_chunked_reduction(M, N, K):
+    """fp32 output + column sums with a reduction long enough to be cut into K chunks (the partial sums meet in C; the
+    sums are taken from the finished C)."""
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    a, w = _ints((M, K), g), _ints((N, K), g)
+    ref = a.double() @ w.double().T
+    for pc in (3, ops.F16_PLANES):
+        c, cs = ops.pgemm_nt(ops.plane_split(a.cuda(), pc), ops.plane_split(w.cuda(), pc), want_colsum=True)
+        assert torch.equal(c.cpu().double(), ref)
+        torch.testing.assert_close(cs.cpu().double(), ref.sum(0), rtol=1e-6, atol=0)
