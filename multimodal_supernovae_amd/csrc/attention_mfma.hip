@@ -764,7 +764,8 @@ __global__ __launch_bounds__(512) void mattn_bwd_fused_kernel(const MAttn p, con
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int T = p.Tk;                                   // == p.Tq
     const int TP = (T + 15) / 16 * 16;
-    const int rows = p.tail ? (T + 3) / 4 * 4 : TP;       // LDS image rows (see the forward kernel)
+    const bool tail = p.tail != 0;
+    const int rows = tail ? (T + 3) / 4 * 4 : TP;         // LDS image rows (see the forward kernel)
     float* Qs = smem;
     float* Ks = Qs + (size_t)rows * LS;
     float* Vs = Ks + (size_t)rows * LS;
@@ -773,21 +774,23 @@ __global__ __launch_bounds__(512) void mattn_bwd_fused_kernel(const MAttn p, con
     float* Ll = Lm + TP;
     float* Dl = Ll + TP;
     uint8_t* Ms = reinterpret_cast<uint8_t*>(Dl + TP);
-    float* Zs = reinterpret_cast<float*>(Ms + TP);        // tail scratch: a broadcast row + weight vectors
+    float* Zp = reinterpret_cast<float*>(Ms + TP);        // ragged token: [3][waves][HD] partial rows of dq_z | dk_z | dv_z
     int b, hh;
     locate_head(p, b, hh);
     const int col0 = hh * p.hd;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int nw = blockDim.x >> 6;                       // one wave per FULL 16-row tile
     const int z = T - 1;                                  // the ragged token (tail only)
-    const bool tail_wave = p.tail && wave == TP / 16 - 1;
     const int t0 = wave * 16, trow = t0 + c;              // this wave's tile; this lane's fixed row (query, then key)
     const bool t_ok = trow < T;
+    const int dl = lane < HD ? lane : 0;                  // lane = head column in the ragged token's sums
     // ---- request: the four images, the statistics, the key mask, this wave's O fragments (delta), all in flight together
+    // (DT + 1 pieces per thread: with the ragged token on the vector ALU the workgroup has one wave per FULL tile only)
     const float* qsrc = p.q + (int64_t)b * p.q_bs;
     const float* ksrc = p.k + (int64_t)b * p.k_bs;
     const float* vsrc = p.v + (int64_t)b * p.v_bs;
     const float* dsrc = p.dout + (int64_t)b * p.d_bs;
-    Stager<HD, DT, false> s1, s2;
+    Stager<HD, DT + 1, false> s1, s2;
     s1.request(qsrc, ksrc, p.ldq, p.ldk, col0, T, rows, p.hd);
     s2.request(vsrc, dsrc, p.ldv, p.ldd, col0, T, rows, p.hd);
     const int tj = threadIdx.x;
@@ -796,42 +799,46 @@ __global__ __launch_bounds__(512) void mattn_bwd_fused_kernel(const MAttn p, con
     uint8_t mk = 1;
     if (p.mask) mk = p.mask[(int64_t)b * T + (tj < T ? tj : 0)];
     float4 of[DT];
-    float dz = 0.f;                                       // tail wave: lane d's term of delta_z = dO_z . O_z
-    if (tail_wave) {
-        if (lane < p.hd)
-            dz = dsrc[(int64_t)z * p.ldd + col0 + lane] * p.o[(int64_t)b * p.o_bs + (int64_t)z * p.ldo + col0 + lane];
-    } else {
-        frags_request<HD>(of, p.o + (int64_t)b * p.o_bs, p.ldo, col0, trow, T, g, p.hd);
-    }
+    frags_request<HD>(of, p.o + (int64_t)b * p.o_bs, p.ldo, col0, trow, T, g, p.hd);
+    float dz = 0.f;                                       // wave 0: lane d's term of delta_z = dO_z . O_z
+    if (tail && wave == 0 && lane < p.hd)
+        dz = dsrc[(int64_t)z * p.ldd + col0 + lane] * p.o[(int64_t)b * p.o_bs + (int64_t)z * p.ldo + col0 + lane];
     MSN_TL(tl1)
     // ---- commit
     s1.commit_first(Qs);
     s1.commit_second(Qs, Ks);
     s2.commit_first(Vs);
     s2.commit_second(Vs, Ds);
-    if (tj < TP) {
-        Lm[tj] = tj < T ? s_m : INFINITY;                 // +inf: a padded query row gets p = exp(-inf) = 0
-        Ll[tj] = tj < T ? s_l : 0.f;
-        Ms[tj] = tj < T ? mk : 1;
+    for (int t = tj; t < TP; t += blockDim.x) {
+        const bool in = t < T;
+        float m_ = s_m, l_ = s_l;
+        uint8_t k_ = mk;
+        if (t != tj) {                                    // (fewer threads than padded rows: not the towers' shapes)
+            const int64_t st = ((int64_t)b * p.H + hh) * T + (in ? t : 0);
+            m_ = p.lse[2 * st], l_ = p.lse[2 * st + 1];
+            k_ = p.mask ? p.mask[(int64_t)b * T + (in ? t : 0)] : 1;
+        }
+        Lm[t] = in ? m_ : INFINITY;                       // +inf: a padded query row gets p = exp(-inf) = 0
+        Ll[t] = in ? l_ : 0.f;
+        Ms[t] = in ? k_ : 1;
     }
-    if (!tail_wave) frags_commit<HD>(of, trow, T, g, 1.f, p.hd);
+    frags_commit<HD>(of, trow, T, g, 1.f, p.hd);
     __syncthreads();
     MSN_TL(tl2)
 
     // ---- delta of this wave's queries (registers for the dQ phase, LDS for every wave's dK,dV phase)
     float4 af[DT], bf[DT];                                // fixed-tile fragments: (q, dO), then (k, v)
     float delta = 0.f;
-    if (tail_wave) {
-        delta = wave_sum(dz);
-        if (lane < 16 && z + lane < TP) Dl[z + lane] = lane == 0 ? delta : 0.f;
-    } else {
-        lds_frags<HD>(af, Qs, trow, g, p.scale);
-        lds_frags<HD>(bf, Ds, trow, g, 1.f);
+    lds_frags<HD>(af, Qs, trow, g, p.scale);
+    lds_frags<HD>(bf, Ds, trow, g, 1.f);
 #pragma unroll
-        for (int x = 0; x < DT; ++x)
-            delta += bf[x].x * of[x].x + bf[x].y * of[x].y + bf[x].z * of[x].z + bf[x].w * of[x].w;
-        delta = group_sum4(delta);
-        if (g == 0) Dl[trow] = t_ok ? delta : 0.f;
+    for (int x = 0; x < DT; ++x)
+        delta += bf[x].x * of[x].x + bf[x].y * of[x].y + bf[x].z * of[x].z + bf[x].w * of[x].w;
+    delta = group_sum4(delta);
+    if (g == 0) Dl[trow] = t_ok ? delta : 0.f;
+    if (tail && wave == 0) {                              // rows z .. TP - 1 belong to no wave's tile
+        const float dzs = wave_sum(dz);
+        if (lane < 16 && z + lane < TP) Dl[z + lane] = lane == 0 ? dzs : 0.f;
     }
     __syncthreads();
     MSN_TL(tl3)
@@ -839,64 +846,16 @@ __global__ __launch_bounds__(512) void mattn_bwd_fused_kernel(const MAttn p, con
     unsigned long long tl4 = 0;
 #endif
 
-    const int ntile = TP / 16 - (p.tail ? 1 : 0);         // full tiles on the matrix cores
-    const int rows4 = (T + 3) / 4 * 4;
+    // Ragged token z (T = 16 n + 1): the matrix cores see the n x n full tiles; row z of dq / dk / dv and column z of the
+    // scores go over the vector ALU INSIDE the matrix waves.  Every weight that row needs is a by-product of the rank-1 terms
+    // the waves form anyway -- ds(i, z), p(i, z) for this wave's queries i in the dQ phase, ds(z, j) for its keys j in the
+    // dK,dV phase -- so a wave adds, lane = head column, its 16 rows' share of dk_z, dv_z and dq_z (16 broadcasts + 16
+    // multiply-adds each); the shares meet in LDS, wave 0 adds the (z, z) element.  (A fifth wave of vector work per
+    // workgroup -- the form of the dQ / dK,dV kernels above -- was the last one to finish: 1 800 cycles of the other four.)
+    const int ntile = tail ? TP / 16 - 1 : TP / 16;       // full tiles on the matrix cores
     f32x4 dq[DT], dk[DT], dv[DT];
-    float dqz = 0.f, dkz = 0.f, dvz = 0.f;                // tail wave: lane d's element of row z
-    if (tail_wave) {
-        // ---- query z: lane = key (see mattn_bwd_dq_kernel)
-        float* Ps = Zs + 128;
-        const float lm = Lm[z], ll = Ll[z];
-        if (lane < HD) Zs[lane] = Qs[z * LS + lane] * p.scale;          // query z, scaled, as a broadcast row (wave-private)
-        const float* qz = Zs;
-        const float* dz_row = Ds + z * LS;
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-            const int j = 64 * h2 + lane;
-            float ds = 0.f;
-            if (j < z && Ms[j]) {
-                const float sjv = row_dot<HD>(Ks, j, qz), dp = row_dot<HD>(Vs, j, dz_row);
-                ds = __expf((sjv - lm) - ll) * (dp - delta);
-            }
-            Ps[j] = ds;
-        }
-        {
-            const float sz = wave_dot<HD>(Ks + z * LS, qz, lane), dpz = wave_dot<HD>(Vs + z * LS, dz_row, lane);
-            if (lane == 0) Ps[z] = Ms[z] ? __expf((sz - lm) - ll) * (dpz - delta) : 0.f;
-        }
-        if (lane < p.hd) dqz = col_sum<HD>(Ks, Ps, rows4, lane) * p.scale;
-        // ---- key z: lane = query (see mattn_bwd_dkv_kernel)
-        float* Pp = Zs + 128;
-        float* Pd = Zs + 256;
-        const bool keep_z = Ms[z] != 0;
-        if (lane < HD) Zs[lane] = Ks[z * LS + lane] * p.scale;          // key z, scaled
-        const float* kz = Zs;
-        const float* vz = Vs + z * LS;
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-            const int i = 64 * h2 + lane;
-            float pr = 0.f, ds = 0.f;
-            if (i < z) {
-                const float si = row_dot<HD>(Qs, i, kz), dp = row_dot<HD>(Ds, i, vz);
-                pr = __expf(((keep_z ? si : kFill) - Lm[i]) - Ll[i]);
-                ds = keep_z ? pr * (dp - Dl[i]) : 0.f;
-            }
-            Pp[i] = pr;
-            Pd[i] = ds;
-        }
-        {
-            const float sz = wave_dot<HD>(Qs + z * LS, kz, lane), dpz = wave_dot<HD>(Ds + z * LS, vz, lane);
-            const float pr = __expf(((keep_z ? sz : kFill) - Lm[z]) - Ll[z]);
-            if (lane == 0) {
-                Pp[z] = pr;
-                Pd[z] = keep_z ? pr * (dpz - Dl[z]) : 0.f;
-            }
-        }
-        if (lane < p.hd) {
-            dkz = col_sum<HD>(Qs, Pd, rows4, lane) * p.scale;
-            dvz = col_sum<HD>(Ds, Pp, rows4, lane);
-        }
-    } else {
+    float zdq = 0.f, zdk = 0.f, zdv = 0.f;                // lane d's share of row z
+    {
         // ---- dQ of query tile `wave`: af = q (scaled), bf = dO
         const float lm = Lm[trow], ll = Ll[trow];
 #pragma unroll
@@ -913,10 +872,18 @@ __global__ __launch_bounds__(512) void mattn_bwd_fused_kernel(const MAttn p, con
             }
             accum16<HD>(ds, Ks + kt * 16 * LS, dq, c, g);
         }
-        if (p.tail) {                                     // key z
+        if (tail) {                                       // key z
             const float sz = frag_dot_row<HD>(af, Ks + z * LS, g), dpz = frag_dot_row<HD>(bf, Vs + z * LS, g);
-            const float dsz = (t_ok && Ms[z]) ? __expf((sz - lm) - ll) * (dpz - delta) : 0.f;
+            const bool keep_z = Ms[z] != 0;
+            const float prz = t_ok ? __expf(((keep_z ? sz : kFill) - lm) - ll) : 0.f;       // p(i, z), this lane's query i
+            const float dsz = keep_z ? prz * (dpz - delta) : 0.f;                           // ds(i, z)
             rank1_update<HD>(dsz, Ks + z * LS, dq, c, g);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {                // this wave's queries' share of dk_z, dv_z (lane i holds query i's)
+                const float wds = __shfl(dsz, i, 64), wpr = __shfl(prz, i, 64);
+                zdk += wds * Qs[(t0 + i) * LS + dl];
+                zdv += wpr * Ds[(t0 + i) * LS + dl];
+            }
         }
 #ifdef MSN_ATTN_TIMELINE
         tl4 = __builtin_readcyclecounter();
@@ -941,11 +908,31 @@ __global__ __launch_bounds__(512) void mattn_bwd_fused_kernel(const MAttn p, con
             accum16<HD>(pr, Ds + qt * 16 * LS, dv, c, g);
             accum16<HD>(ds, Qs + qt * 16 * LS, dk, c, g);
         }
-        if (p.tail) {                                     // query z against this lane's key
+        if (tail) {                                       // query z against this lane's key
             const float sz = frag_dot_row<HD>(af, Qs + z * LS, g), dpz = frag_dot_row<HD>(bf, Ds + z * LS, g);
             const float e = __expf(((keep ? sz : kFill) - Lm[z]) - Ll[z]);
+            const float dsj = keep ? e * (dpz - Dl[z]) : 0.f;                               // ds(z, j), this lane's key j
             rank1_update<HD>(t_ok ? e : 0.f, Ds + z * LS, dv, c, g);
-            rank1_update<HD>(keep ? e * (dpz - Dl[z]) : 0.f, Qs + z * LS, dk, c, g);
+            rank1_update<HD>(dsj, Qs + z * LS, dk, c, g);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) zdq += __shfl(dsj, j, 64) * Ks[(t0 + j) * LS + dl];
+        }
+    }
+    if (tail) {
+        if (wave == 0) {                                  // the (z, z) element
+            const float szz = wave_dot<HD>(Qs + z * LS, Ks + z * LS, lane) * p.scale;
+            const float dpzz = wave_dot<HD>(Ds + z * LS, Vs + z * LS, lane);
+            const bool keep_z = Ms[z] != 0;
+            const float pzz = __expf(((keep_z ? szz : kFill) - Lm[z]) - Ll[z]);
+            const float dszz = keep_z ? pzz * (dpzz - Dl[z]) : 0.f;
+            zdq += dszz * Ks[z * LS + dl];
+            zdk += dszz * Qs[z * LS + dl];
+            zdv += pzz * Ds[z * LS + dl];
+        }
+        if (lane < HD) {
+            Zp[(0 * nw + wave) * HD + lane] = zdq;
+            Zp[(1 * nw + wave) * HD + lane] = zdk;
+            Zp[(2 * nw + wave) * HD + lane] = zdv;
         }
     }
     MSN_TL(tl5)
@@ -955,24 +942,24 @@ __global__ __launch_bounds__(512) void mattn_bwd_fused_kernel(const MAttn p, con
     // ---- stage [3][T][LS]: dq | dk | dv rows of this (sample, head)
     float* St = smem;
     const size_t SS = (size_t)T * LS;
-    if (tail_wave) {
-        if (lane < p.hd) {
-            St[z * LS + lane] = dqz;
-            St[SS + z * LS + lane] = dkz;
-            St[2 * SS + z * LS + lane] = dvz;
-        }
-    } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = t0 + 4 * g + r;
-            if (row < T) {
+    for (int r = 0; r < 4; ++r) {
+        const int row = t0 + 4 * g + r;
+        if (row < T) {
 #pragma unroll
-                for (int t = 0; t < DT; ++t) {
-                    St[row * LS + 16 * t + c] = dq[t][r] * p.scale;
-                    St[SS + row * LS + 16 * t + c] = dk[t][r] * p.scale;
-                    St[2 * SS + row * LS + 16 * t + c] = dv[t][r];
-                }
+            for (int t = 0; t < DT; ++t) {
+                St[row * LS + 16 * t + c] = dq[t][r] * p.scale;
+                St[SS + row * LS + 16 * t + c] = dk[t][r] * p.scale;
+                St[2 * SS + row * LS + 16 * t + c] = dv[t][r];
             }
+        }
+    }
+    if (tail) {                                           // row z: the waves' shares in wave order
+        for (int u = threadIdx.x; u < 3 * HD; u += blockDim.x) {
+            const int sq = u / HD, d = u % HD;
+            float a0 = 0.f;
+            for (int w = 0; w < nw; ++w) a0 += Zp[(sq * nw + w) * HD + d];
+            St[sq * SS + z * LS + d] = sq < 2 ? a0 * p.scale : a0;
         }
     }
     __syncthreads();
@@ -1024,14 +1011,16 @@ __global__ __launch_bounds__(512) void mattn_bwd_fused_kernel(const MAttn p, con
                 }
             }
         }
-        if (fo.colpart && (int)threadIdx.x < 3 * HD) {    // this sample's column sums, rows in order
-            const int s = threadIdx.x / HD, d = threadIdx.x % HD;
-            const float* src = St + s * SS + d;
-            float a0 = 0.f, a1 = 0.f;
-            int row = 0;
-            for (; row + 1 < T; row += 2) a0 += src[row * LS], a1 += src[(row + 1) * LS];
-            if (row < T) a0 += src[row * LS];
-            fo.colpart[(int64_t)b * 3 * e + s * e + col0 + d] = a0 + a1;
+        if (fo.colpart) {                                 // this sample's column sums, rows in order
+            for (int u = threadIdx.x; u < 3 * HD; u += blockDim.x) {
+                const int s = u / HD, d = u % HD;
+                const float* src = St + s * SS + d;
+                float a0 = 0.f, a1 = 0.f;
+                int row = 0;
+                for (; row + 1 < T; row += 2) a0 += src[row * LS], a1 += src[(row + 1) * LS];
+                if (row < T) a0 += src[row * LS];
+                fo.colpart[(int64_t)b * 3 * e + s * e + col0 + d] = a0 + a1;
+            }
         }
     }
 #ifdef MSN_ATTN_TIMELINE
@@ -1405,7 +1394,8 @@ void mattn_set_fused(int on) { g_attn_fused = on; }
 static size_t fused_lds(const MAttn& a, bool tail) {
     const int TP = (a.Tk + 15) / 16 * 16;
     const int rows = tail ? (a.Tk + 3) / 4 * 4 : TP;
-    return sizeof(float) * (4 * (size_t)rows * (padded_hd(a.hd) + 4) + 3 * (size_t)TP + kTailScratch) + (size_t)TP;
+    const size_t ragged = tail ? 3 * (size_t)(TP / 16) * padded_hd(a.hd) : 0;      // the waves' shares of row z
+    return sizeof(float) * (4 * (size_t)rows * (padded_hd(a.hd) + 4) + 3 * (size_t)TP + ragged) + (size_t)TP;
 }
 bool mattn_fused_applicable(const MAttn& a) {
     if (!mattn_applicable(a) || a.Tq != a.Tk || a.Tk > 128 || a.hd > 64 || a.hd % 4 != 0) return false;
@@ -1417,7 +1407,7 @@ bool mattn_fused_applicable(const MAttn& a) {
 template <int NP>
 static int launch_fused(const MAttn& a, const FusedOut& fo, hipStream_t st) {
     const size_t lds = fused_lds(a, a.tail != 0);
-    const dim3 grid(a.B * a.H), block(64 * ((a.Tk + 15) / 16));
+    const dim3 grid(a.B * a.H), block(64 * (a.tail ? a.Tk / 16 : (a.Tk + 15) / 16));      // one wave per full 16-row tile
 #define MSN_FUSED_CASE(HDV)                                                                                               \
     {                                                                                                                     \
         auto kern = mattn_bwd_fused_kernel<HDV, NP>;                                                                      \

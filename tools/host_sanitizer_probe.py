@@ -46,6 +46,10 @@ for bad in (lambda: L.msn_plane_split(None, 4, 4, 4, 3, 0, None, None, None, 0, 
             lambda: L.msn_attention_bwd_planes(fake, 1152, None, 4, 6, 65, 8, 0.125, fake, 384, fake, fake, 384, 3, fake, None, None, 0, None),
             lambda: L.msn_attention_bwd_planes(fake, 1152, None, 4, 6, 65, 64, 0.125, fake, 384, fake, fake, 384, 5, fake, None, None, 0, None),
             lambda: L.msn_attention_bwd_planes(fake, 1152, None, 4, 6, 65, 64, 0.125, fake, 384, fake, fake, 384, 3, fake, fake, fake, 16, None),
+            lambda: L.msn_plane_split_f16(fake, 4, 4, 4, 0, fake, None, 0, None, None, 0, None),
+            lambda: L.msn_pgemm_nt_f16(256, 128, 64, fake, None, fake, fake, fake, 128, None, 0, None, 0, None, None, 0, None),
+            lambda: L.msn_pgemm_tn_f16(256, 128, 64, fake, fake, fake, None, fake, 64, None, 0, None),
+            lambda: L.msn_plane_split_list(0, None, 3, None),
             lambda: L.msn_set_pgemm_tile_n(256), lambda: L.msn_set_pgemm_variant(9),
             lambda: L.msn_layernorm_fwd_planes(fake, 384, 8, 384, fake, fake, 1e-6, 5, fake, None, 0, fake, fake, None)):
     assert bad() == 1, L.msn_last_error()
