@@ -438,7 +438,9 @@ int msn_attention_bwd(const float* q, int64_t ldq, int64_t q_bstride, const floa
 int msn_set_attention_path(int mode);
 /* Self-attention backward over up to 128 tokens with heads up to 64 wide (the ViT towers): 1 (default) = ONE launch that
  * holds Q, K, V and dO of a (sample, head) in LDS together -- one pass over the operands, delta never in memory; 0 = the
- * dQ kernel followed by the dK,dV kernel (same products in the same order).  Process-wide; measurements and tests. */
+ * dQ kernel followed by the dK,dV kernel (same products in the same order); 3 = the one-pass kernel without the shared
+ * recomputation (up to 4 full tiles -- the ViT towers -- the default computes every score tile ONCE for dQ, dK and dV: the dQ
+ * parts of the four key-tile waves meet in LDS; 80 instead of 112 MFMAs per tile pair).  Process-wide; measurements and tests. */
 int msn_set_attention_fused(int on);
 
 /* ------------------------------------------------------------------------------------------

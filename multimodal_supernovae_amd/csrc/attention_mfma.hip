@@ -757,7 +757,7 @@ __device__ __forceinline__ void lds_frags(float4 (&f)[HD / 16], const float* img
         f[x] = make_float4(v.x * mul, v.y * mul, v.z * mul, v.w * mul);
     }
 }
-template <int HD, int NP>
+template <int HD, int NP, bool SHARE>
 __global__ __launch_bounds__(512) void mattn_bwd_fused_kernel(const MAttn p, const FusedOut fo) {
     constexpr int LS = HD + 4, DT = HD / 16;
     MSN_TL(tl0)
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(512) void mattn_bwd_fused_kernel(const MAttn p, con
     const int T = p.Tk;                                   // == p.Tq
     const int TP = (T + 15) / 16 * 16;
     const bool tail = p.tail != 0;
-    const int rows = tail ? (T + 3) / 4 * 4 : TP;         // LDS image rows (see the forward kernel)
+    const int rows = tail ? T : TP;                       // LDS image rows: the full tiles + the ragged token's row
     float* Qs = smem;
     float* Ks = Qs + (size_t)rows * LS;
     float* Vs = Ks + (size_t)rows * LS;
@@ -854,8 +854,72 @@ __global__ __launch_bounds__(512) void mattn_bwd_fused_kernel(const MAttn p, con
     // workgroup -- the form of the dQ / dK,dV kernels above -- was the last one to finish: 1 800 cycles of the other four.)
     const int ntile = tail ? TP / 16 - 1 : TP / 16;       // full tiles on the matrix cores
     f32x4 dq[DT], dk[DT], dv[DT];
+    f32x4 dqp[SHARE ? 4 : 1][DT];                         // SHARE: this wave's keys' share of dQ, per query tile
     float zdq = 0.f, zdk = 0.f, zdv = 0.f;                // lane d's share of row z
-    {
+    if constexpr (SHARE) {
+        // ---- ONE recomputation of the score / score-gradient tiles serves dQ, dK and dV (up to 4 full tiles: the ViT towers).
+        // Wave w owns KEY tile w.  Per query tile: s and dp as in the dK,dV phase below (rows = queries, column = this lane's
+        // key), p and ds from them, dv += p^T dO, dk += ds^T Q -- and, new, the tile's ds TRANSPOSED through a 16 x 16-float
+        // patch of LDS of this wave (4 stores + one 16-byte read per lane) as the A operand of dq_part[query tile] += ds K(own
+        // keys): 80 instead of 112 MFMAs per tile pair.  The four waves' dq parts meet in LDS behind the loop, in wave order.
+        float* Tb = Zp + (tail ? 3 * nw * HD : 0) + wave * 256;      // 16 x 16 floats (unpadded: 2-way conflict on 4 stores per tile pair)
+        lds_frags<HD>(af, Ks, trow, g, p.scale);          // af = k (scaled), bf = v
+        lds_frags<HD>(bf, Vs, trow, g, 1.f);
+        const bool keep = t_ok && Ms[trow] != 0;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) dk[t] = dv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+#pragma unroll
+            for (int t = 0; t < DT; ++t) dqp[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (qt < ntile) {
+                const f32x4 s = score16<HD>(Qs + qt * 16 * LS, af, c, g);
+                const f32x4 dp = score16<HD>(Ds + qt * 16 * LS, bf, c, g);
+                f32x4 pr, ds;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = 16 * qt + 4 * g + r;
+                    const float e = __expf(((keep ? s[r] : kFill) - Lm[q]) - Ll[q]);
+                    pr[r] = t_ok ? e : 0.f;
+                    ds[r] = keep ? e * (dp[r] - Dl[q]) : 0.f;
+                    Tb[(4 * g + r) * 16 + c] = ds[r];     // Tb[query][key]
+                }
+                accum16<HD>(pr, Ds + qt * 16 * LS, dv, c, g);
+                accum16<HD>(ds, Qs + qt * 16 * LS, dk, c, g);
+                const f32x4 dst = *reinterpret_cast<const f32x4*>(Tb + c * 16 + 4 * g);     // ds(query c, keys 4g .. 4g + 3)
+                accum16<HD>(dst, Ks + t0 * LS, dqp[qt], c, g);
+            }
+        }
+        if (tail) {
+            // query z against this lane's key (as below), then this wave's QUERY tile against key z (the rank-1 term of dq
+            // goes into this wave's own part of that tile; its weights are the tile's share of dk_z, dv_z)
+            {
+                const float sz = frag_dot_row<HD>(af, Qs + z * LS, g), dpz = frag_dot_row<HD>(bf, Ds + z * LS, g);
+                const float e = __expf(((keep ? sz : kFill) - Lm[z]) - Ll[z]);
+                const float dsj = keep ? e * (dpz - Dl[z]) : 0.f;
+                rank1_update<HD>(t_ok ? e : 0.f, Ds + z * LS, dv, c, g);
+                rank1_update<HD>(dsj, Qs + z * LS, dk, c, g);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) zdq += __shfl(dsj, j, 64) * Ks[(t0 + j) * LS + dl];
+            }
+            lds_frags<HD>(af, Qs, trow, g, p.scale);      // af = q (scaled), bf = dO
+            lds_frags<HD>(bf, Ds, trow, g, 1.f);
+            const float lm = Lm[trow], ll = Ll[trow];
+            const float sz = frag_dot_row<HD>(af, Ks + z * LS, g), dpz = frag_dot_row<HD>(bf, Vs + z * LS, g);
+            const bool keep_z = Ms[z] != 0;
+            const float prz = t_ok ? __expf(((keep_z ? sz : kFill) - lm) - ll) : 0.f;
+            const float dsz = keep_z ? prz * (dpz - delta) : 0.f;
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt)
+                if (qt == wave) rank1_update<HD>(dsz, Ks + z * LS, dqp[qt], c, g);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float wds = __shfl(dsz, i, 64), wpr = __shfl(prz, i, 64);
+                zdk += wds * Qs[(t0 + i) * LS + dl];
+                zdv += wpr * Ds[(t0 + i) * LS + dl];
+            }
+        }
+    } else {
         // ---- dQ of query tile `wave`: af = q (scaled), bf = dO
         const float lm = Lm[trow], ll = Ll[trow];
 #pragma unroll
@@ -917,7 +981,7 @@ __global__ __launch_bounds__(512) void mattn_bwd_fused_kernel(const MAttn p, con
 #pragma unroll
             for (int j = 0; j < 16; ++j) zdq += __shfl(dsj, j, 64) * Ks[(t0 + j) * LS + dl];
         }
-    }
+        }
     if (tail) {
         if (wave == 0) {                                  // the (z, z) element
             const float szz = wave_dot<HD>(Qs + z * LS, Ks + z * LS, lane) * p.scale;
@@ -942,13 +1006,49 @@ __global__ __launch_bounds__(512) void mattn_bwd_fused_kernel(const MAttn p, con
     // ---- stage [3][T][LS]: dq | dk | dv rows of this (sample, head)
     float* St = smem;
     const size_t SS = (size_t)T * LS;
+    if constexpr (SHARE) {
+        // the waves' dq parts: P[wave][16 ntile rows][LS] over the images' space, summed in wave order by lane = 16 bytes
+        // of a row, then held in registers while the stage takes the space
+        const int rows_mf = 16 * ntile;
+        float* P = smem + (size_t)wave * rows_mf * LS;
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            if (qt < ntile) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int t = 0; t < DT; ++t) P[(16 * qt + 4 * g + r) * LS + 16 * t + c] = dqp[qt][t][r];
+            }
+        }
+        __syncthreads();
+        constexpr int Q4 = HD / 4, PCS = 4;               // pieces per thread: 64 rows x 16 pieces on 256 threads
+        f32x4 sum[PCS];
+#pragma unroll
+        for (int u = 0; u < PCS; ++u) {
+            const int idx = threadIdx.x + u * blockDim.x;
+            sum[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (idx < rows_mf * Q4) {
+                const int row = idx / Q4, cq = 4 * (idx % Q4);
+                for (int w = 0; w < nw; ++w) sum[u] += *reinterpret_cast<const f32x4*>(smem + ((size_t)w * rows_mf + row) * LS + cq);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PCS; ++u) {
+            const int idx = threadIdx.x + u * blockDim.x;
+            if (idx < rows_mf * Q4) {
+                const int row = idx / Q4, cq = 4 * (idx % Q4);
+                *reinterpret_cast<f32x4*>(St + row * LS + cq) = sum[u] * p.scale;
+            }
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = t0 + 4 * g + r;
         if (row < T) {
 #pragma unroll
             for (int t = 0; t < DT; ++t) {
-                St[row * LS + 16 * t + c] = dq[t][r] * p.scale;
+                if constexpr (!SHARE) St[row * LS + 16 * t + c] = dq[t][r] * p.scale;
                 St[SS + row * LS + 16 * t + c] = dk[t][r] * p.scale;
                 St[2 * SS + row * LS + 16 * t + c] = dv[t][r];
             }
@@ -1390,12 +1490,15 @@ int mattn_forward(const MAttn& a0, hipStream_t st) {
 
 // One-pass backward (mattn_bwd_fused_kernel): self-attention, up to 128 tokens, heads up to 64 wide, everything 16-byte aligned.
 static int g_attn_fused = 1;
-void mattn_set_fused(int on) { g_attn_fused = on; }
+static int g_attn_share = 1;
+void mattn_set_fused(int on) { g_attn_fused = on & 1, g_attn_share = (on & 2) ? 0 : 1; }      // bit 1: the 7-product form of the one-pass kernel
 static size_t fused_lds(const MAttn& a, bool tail) {
     const int TP = (a.Tk + 15) / 16 * 16;
-    const int rows = tail ? (a.Tk + 3) / 4 * 4 : TP;
-    const size_t ragged = tail ? 3 * (size_t)(TP / 16) * padded_hd(a.hd) : 0;      // the waves' shares of row z
-    return sizeof(float) * (4 * (size_t)rows * (padded_hd(a.hd) + 4) + 3 * (size_t)TP + ragged) + (size_t)TP;
+    const int rows = tail ? a.Tk : TP;
+    const int waves = tail ? a.Tk / 16 : TP / 16;
+    const size_t ragged = tail ? 3 * (size_t)waves * padded_hd(a.hd) : 0;          // the waves' shares of row z
+    const size_t patches = (size_t)waves * 256;                                     // a 16 x 16 transpose patch per wave
+    return sizeof(float) * (4 * (size_t)rows * (padded_hd(a.hd) + 4) + 3 * (size_t)TP + ragged + patches) + (size_t)TP;
 }
 bool mattn_fused_applicable(const MAttn& a) {
     if (!mattn_applicable(a) || a.Tq != a.Tk || a.Tk > 128 || a.hd > 64 || a.hd % 4 != 0) return false;
@@ -1408,9 +1511,12 @@ template <int NP>
 static int launch_fused(const MAttn& a, const FusedOut& fo, hipStream_t st) {
     const size_t lds = fused_lds(a, a.tail != 0);
     const dim3 grid(a.B * a.H), block(64 * (a.tail ? a.Tk / 16 : (a.Tk + 15) / 16));      // one wave per full 16-row tile
+    // one recomputation for dQ and dK,dV where the query tiles' dQ parts fit registers and the images' space: up to 4 full tiles
+    const int full_tiles = a.tail ? a.Tk / 16 : (a.Tk + 15) / 16;
+    const bool share = g_attn_share && full_tiles <= 4;
 #define MSN_FUSED_CASE(HDV)                                                                                               \
     {                                                                                                                     \
-        auto kern = mattn_bwd_fused_kernel<HDV, NP>;                                                                      \
+        auto kern = share ? mattn_bwd_fused_kernel<HDV, NP, true> : mattn_bwd_fused_kernel<HDV, NP, false>;               \
         if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
             set_error("attention: cannot reserve %zu bytes of LDS", lds);                                                 \
@@ -1479,7 +1585,8 @@ int mattn_backward(const MAttn& a0, hipStream_t st) {
 using namespace msn;
 
 extern "C" int msn_set_attention_fused(int on) {
-    mattn_set_fused(on != 0);
+    MSN_REQUIRE(on >= 0 && on <= 3, "msn_set_attention_fused: 0, 1 or 3");
+    mattn_set_fused(on);
     return MSN_OK;
 }
 

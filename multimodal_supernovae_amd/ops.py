@@ -1012,7 +1012,8 @@ def attention_bwd_planes_supported(T, head_dim):
 
 
 def set_attention_fused(on):
-    check(lib().msn_set_attention_fused(1 if on else 0), "msn_set_attention_fused")
+    """True / 1: the one-pass backward (default); 3: its form without the shared recomputation; False / 0: two kernels."""
+    check(lib().msn_set_attention_fused(int(on)), "msn_set_attention_fused")
 
 
 class _SplitItem(ctypes.Structure):
