@@ -355,7 +355,9 @@ int msn_pgemm_tn_f16(int64_t M, int N, int K, const void* A, const float* scaleA
                      int64_t ldc, void* ws, size_t ws_bytes, msn_stream_t stream);
 int msn_set_pgemm_tile_n(int bn);
 /* Wave layout of the 3-plane msn_pgemm_nt kernel (measurements; same results up to the summation order of the column
- * sums): 0 = 2 x 4 waves, 1 = 4 x 2 (default); + 1000 * c: K chunks of c K-steps (default 32).  Process-wide, not thread-safe (as every msn_set_* switch). */
+ * sums): 0 = 2 x 4 waves, 1 = 4 x 2 (default), 2 = 4 x 2 on v_mfma_f32_16x16x32_bf16 with plane PAIRS side by side along k
+ * (same six products from three instructions per 16 x 16 tile; exact-equal results on the integer tests, equal speed as built:
+ * DESIGN.md section 7, gap 0); + 1000 * c: K chunks of c K-steps (default 32).  Process-wide, not thread-safe (as every msn_set_* switch). */
 int msn_set_pgemm_variant(int v);
 /* Start skew of msn_pgemm_nt's persistent workgroups (shader cycles per phase, 0 = off; measurements). */
 int msn_set_pgemm_skew(int cycles);

@@ -41,6 +41,8 @@ namespace msn {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
@@ -149,9 +151,10 @@ __device__ __forceinline__ void split_planes(float x, u16 (&pl)[NP]) {
 // (12 instead of 15 fragment reads per 24 MFMAs on BN = 128: +7-12 %, the 3-plane default; four waves of 128 x 64 with the
 // whole register file each were 15-25 % slower).  STAG: the two waves of a SIMD issue their LDS-DMA pieces in different halves of a K-step
 // (waves 0-3 behind the first products, waves 4-7 behind the last ones) instead of both stalling in the same gaps.
-template <int NP, int BN, bool OUTP, bool DUAL, int WM = 2, int WN = 4, bool STAG = false, bool F16 = false>
+template <int NP, int BN, bool OUTP, bool DUAL, int WM = 2, int WN = 4, bool STAG = false, bool F16 = false, bool S16 = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(const PgemmArgs p) {
     static_assert(!F16 || !OUTP, "fp16 planes: fp32 results only");
+    static_assert(!S16 || (NP == 3 && DUAL && !F16 && !STAG && WM == 4 && WN == 2 && BN == 128), "the 16 x 16 x 32 form: three bf16 planes, two accumulator sets, 4 x 2 waves");
     constexpr int NW = WM * WN;
     constexpr int ARB = BM / 32, BRB = BN / 32, AP = ARB * NP, BP = BRB * NP, PIECES = AP + BP;
     constexpr int SLOT = PIECES * PBLK;
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
     static_assert(NSLOT * SLOT + NW * STG <= 160 * 1024, "LDS: ring + staging");
     constexpr int MAXQ = (PIECES + NW - 1) / NW;     // pieces per wave and K-step (the last one only for the low waves)
     constexpr int MT = 8 / WM, NT = BN / (32 * WN);  // 32 x 32 MFMA tiles per wave: rows x columns
-    constexpr int NG = NP * (NP + 1) / 2;            // plane products per K-step
+    constexpr int NG = S16 ? 3 : NP * (NP + 1) / 2;  // MFMA groups per K-step (S16: three plane-PAIR products)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[NSLOT * SLOT + NW * STG];
 
     const int lane = threadIdx.x & 63;
@@ -204,7 +207,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
     };
 
     // ---- producer: the LDS-DMA stream.  Global K-step g (over all tiles of this workgroup) lives in slot g % NSLOT.
-    const int lane_src = (((lane >> 1) * 2) + ((lane & 1) ^ ((lane >> 4) & 1))) * 16;
+    // (S16: no swizzle -- 16-row fragments of rows r, r + 8 take opposite halves in one ds_read_b128 lane group: conflict-free as laid)
+    const int lane_src = S16 ? lane * 16 : (((lane >> 1) * 2) + ((lane & 1) ^ ((lane >> 4) & 1))) * 16;
     const unsigned char* pbase[MAXQ];                // source of piece q of the producer's tile at K-step 0 (wave-uniform)
     int p_idx = 0, p_k = 0, p_ke = 0, p_slot = 0, p_tm = 0, p_tn = 0;
     bool p_live = seg_of(0, p_tm, p_tn, p_k, p_ke);
@@ -275,6 +279,28 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
 
     f32x16 acc[MT][NT], acc2[DUAL ? MT : 1][DUAL ? NT : 1];
     bf16x8 fa[2][MT], fb0[2][NT], fbh[NP > 1 ? NP - 1 : 1][NT];
+    // ---- S16: v_mfma_f32_16x16x32_bf16 (holds 2.0 GHz under load where the 32 x 32 x 16 shape holds 1.75: profiles/
+    // r04_mfma_shape_clock.txt).  The 32 k of one instruction are the SAME 16 columns of TWO PLANES: lane group kg = lane >> 4
+    // supplies plane (kg >> 1 ? second : first), 16-byte half kg & 1 of row lane & 15 -- so [p0 | p1].[q0 | q1] = p0q0 + p1q1 (first
+    // accumulator set), [p0 | p1].[q1 | q0] = p0q1 + p1q0 and [p0 | p2].[q2 | q0] = p0q2 + p2q0 (second set): three 16-cycle
+    // instructions per 16 x 16 tile and K-step.  A 32 x 32 accumulator tile acc[i][j] is four 16 x 16 sub-tiles: chunk b =
+    // 2 (row half) + (column half); the lane holds row 16 (b >> 1) + (lane & 15), columns 16 (b & 1) + 4 (lane >> 4) + r.
+    const int r16 = lane & 15, kg = lane >> 4;
+    const unsigned s16_lane = (unsigned)(r16 * 32 + (kg & 1) * 16);
+    const unsigned s16A = lds0 + s16_lane + (unsigned)(wm * MT * NP * PBLK);
+    const unsigned s16B = lds0 + s16_lane + (unsigned)((AP + wn * NT * NP) * PBLK);
+    const unsigned fA01 = s16A + (unsigned)((kg >> 1) * PBLK), fA02 = s16A + (unsigned)((kg >> 1) * 2 * PBLK);
+    const unsigned fB01 = s16B + (unsigned)((kg >> 1) * PBLK), fB10 = s16B + (unsigned)((1 - (kg >> 1)) * PBLK);
+    const unsigned fB20 = s16B + (unsigned)((1 - (kg >> 1)) * 2 * PBLK);
+    bf16x8 fr[2][2][S16 ? 4 : 1];                    // [set][A-type | B-type][16-row sub-tile]
+    auto req16 = [&](bf16x8 (&dst)[S16 ? 4 : 1], unsigned base) {
+        if constexpr (S16) {
+            static_for<0, 4>([&](auto t_) {
+                constexpr int t = decltype(t_)::value;
+                ds_read128<(t >> 1) * NP * PBLK + (t & 1) * 512>(dst[t], base);
+            });
+        }
+    };
 
     auto req_a = [&](bf16x8 (&dst)[MT], unsigned slot_off, auto pl_) {
         constexpr int pl = decltype(pl_)::value;
@@ -318,6 +344,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
             }
         __builtin_amdgcn_sched_barrier(0);
     };
+    auto mult16 = [&](const bf16x8 (&a)[S16 ? 4 : 1], const bf16x8 (&b)[S16 ? 4 : 1], auto small_) {
+        constexpr bool SMALL = decltype(small_)::value;
+        if constexpr (S16) {
+            static_for<0, 16>([&](auto u_) {
+                constexpr int u = decltype(u_)::value, ti = u >> 2, tj = u & 3, i = ti >> 1, j = tj >> 1, bch = 2 * (ti & 1) + (tj & 1);
+                f32x16& dstv = SMALL ? acc2[i][j] : acc[i][j];
+                f32x4 c = {dstv[4 * bch], dstv[4 * bch + 1], dstv[4 * bch + 2], dstv[4 * bch + 3]};
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[tj], a[ti], c, 0, 0, 0);
+                dstv[4 * bch] = c[0], dstv[4 * bch + 1] = c[1], dstv[4 * bch + 2] = c[2], dstv[4 * bch + 3] = c[3];
+            });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
     using BIG = std::integral_constant<bool, false>;
     using SML = std::integral_constant<bool, true>;
     // request the first fragments of a K-step (A plane 0 and every B plane) -- order matters for the counted waits
@@ -336,6 +375,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
     // K-step of two MFMA tiles came out wrong in a few tiles per launch of the plane-output kernel.  So here the reads are
     // waited for, and every register is re-defined behind the wait (an empty asm) so that any copy sits behind it too.
     auto req_first_settled = [&](unsigned slot_off) {
+        if constexpr (S16) return;                   // (this form requests every fragment inside its step)
         req_first(fa[0], fb0[0], slot_off);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -356,6 +396,54 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
     // epilogue requests them once it is done -- the ring of K-steps itself runs on across tiles.
     auto step = [&](auto par_, bool last = false) {
         constexpr int PAR = decltype(par_)::value;
+        if constexpr (S16) {
+            // Every fragment is requested AND consumed inside its step: fr[0][0] = [p0 | p1] of A, fr[0][1] = [q0 | q1] of B,
+            // fr[1][0] = [p0 | p2], fr[1][1] = [q2 | q0]; [q1 | q0] is [q0 | q1] with the lane halves exchanged (two
+            // v_permlane32_swap per register pair, in place) instead of a fifth read: 16 ds_read_b128 per step (12 in the
+            // 32 x 32 x 16 form).  NOT carried over from that form: the next step's first fragments requested behind the barrier.
+            // With 16 fragment registers more than that form holds, the allocator (256 VGPRs) copies or spills the in-flight
+            // destinations at the step's merges -- multiplying fragments that have not arrived (tools/check_fragment_waits.py
+            // finds such copies in the ISA; the integer tests found them first).  What this costs is most of what the shape gains.
+            const unsigned cur = (unsigned)(c_slot * SLOT);
+            const int n_slot = (c_slot + 1 == NSLOT) ? 0 : c_slot + 1;
+            const bool p_was_live = p_live;
+            (void)last;
+            req16(fr[0][0], fA01 + cur);
+            req16(fr[0][1], fB01 + cur);
+            req16(fr[1][1], fB20 + cur);
+            wait_lgkm<4>();
+            mult16(fr[0][0], fr[0][1], BIG{});           // p0q0 + p1q1
+            issue_chunk(std::integral_constant<int, 0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            req16(fr[1][0], fA02 + cur);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                u32x4 w = __builtin_bit_cast(u32x4, fr[0][1][t]);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const u32x2 r = __builtin_amdgcn_permlane32_swap(w[2 * h], w[2 * h + 1], false, false);
+                    const u32x2 q = __builtin_amdgcn_permlane32_swap(r[1], r[0], false, false);
+                    w[2 * h] = q[0], w[2 * h + 1] = q[1];
+                }
+                fr[0][1][t] = __builtin_bit_cast(bf16x8, w);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mult16(fr[0][0], fr[0][1], SML{});           // p0q1 + p1q0
+            issue_chunk(std::integral_constant<int, 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            wait_lgkm<0>();
+            wait_vm(p_was_live ? (NSLOT - 3) * ppw + Q_BEFORE : 0);
+#ifndef MSN_ABL_PG_NOBAR
+            __builtin_amdgcn_s_barrier();
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            mult16(fr[1][0], fr[1][1], SML{});           // p0q2 + p2q0
+            issue_chunk(std::integral_constant<int, NG - 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            advance();
+            c_slot = n_slot;
+            return;
+        }
         constexpr int QA = (NP & 1) ? PAR : 0;       // fa buffer of plane 0; plane pa sits in fa[(QA + pa) & 1]
         const unsigned cur = (unsigned)(c_slot * SLOT);
         const int n_slot = (c_slot + 1 == NSLOT) ? 0 : c_slot + 1;
@@ -414,6 +502,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
     const unsigned stg = lds0 + (unsigned)(NSLOT * SLOT + wave * STG);
     // fp32 image of a tile: [32 rows][128 B], 16-byte chunk c of row r at position c ^ (r & 7) (conflict-free both ways)
     const unsigned st_acc = stg + (unsigned)(frow * 128);                       // + ((2 b + fhalf) ^ (frow & 7)) * 16
+    // chunk b of this lane's 16 accumulator values of a 32 x 32 tile: its row and its 16-byte column chunk (4 columns) in the tile
+    auto erow = [&](int b) { return S16 ? 16 * (b >> 1) + r16 : frow; };
+    auto ecolq = [&](int b) { return S16 ? 4 * (b & 1) + kg : 2 * b + fhalf; };
+    auto acc_addr = [&](int b) { return stg + (unsigned)(erow(b) * 128 + ((ecolq(b) ^ (erow(b) & 7)) * 16)); };
     const int srow = lane >> 3, schunk = lane & 7;                              // memory order: pass q -> row 8 q + srow
     const unsigned st_mem = stg + (unsigned)(srow * 128 + ((schunk ^ srow) * 16));   // + q * 1024   ((8 q + srow) & 7 == srow)
     // (s_nop behind every ds_write_b128: a VALU write to the data registers of a DS store of more than 8 bytes needs a wait
@@ -441,7 +533,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
         for (int q = 0; q < 4; ++q) asm volatile("ds_write_b128 %0, %1\n\ts_nop 1" ::"v"(st_mem + q * 1024), "v"(t[q]) : "memory");
         f32x4 r[4];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) lds_r128(r[b], st_acc + (unsigned)(((2 * b + fhalf) ^ (frow & 7)) * 16));
+        for (int b = 0; b < 4; ++b) lds_r128(r[b], acc_addr(b));
         // the wait names the registers it guards: the compiler may otherwise move a copy of them above it (it believes the
         // asm that issued the read has already defined them)
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3])::"memory");
@@ -452,7 +544,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
             for (int e = 0; e < 4; ++e) a[4 * b + e] = r[b][e];
     };
     // accumulator layout -> rows m0.., columns n0.. of `dst` in memory order: stage_chunk(b, 4 values) four times, then flush
-    auto stage_chunk = [&](int b, const float (&w)[4]) { lds_w128(st_acc + (unsigned)(((2 * b + fhalf) ^ (frow & 7)) * 16), w); };
+    auto stage_chunk = [&](int b, const float (&w)[4]) { lds_w128(acc_addr(b), w); };
     auto tile_flush = [&](float* dst, int64_t ld, int64_t m0, int n0) {
         f32x4 r[4];
 #pragma unroll
@@ -538,7 +630,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
                 if (!PARTIAL && p.bias) {
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
-                        const int n = n0 + 8 * b + 4 * fhalf;
+                        const int n = n0 + 4 * ecolq(b);
                         if (n < p.N) {
                             const float4 t = *reinterpret_cast<const float4*>(p.bias + n);
                             v[4 * b] += t.x; v[4 * b + 1] += t.y; v[4 * b + 2] += t.z; v[4 * b + 3] += t.w;
@@ -574,7 +666,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
                         else v[e] += a[e];                         // MSN_EPI_ADD
                     }
                 }
-                if (!row_ok) {
+                if constexpr (S16) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (m0 + erow(e >> 2) >= p.M) v[e] = 0.f;
+                } else if (!row_ok) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) v[e] = 0.f;       // padding rows of a plane output are zero
                 }
@@ -590,7 +686,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
                             uint2 o;
                             o.x = pl[0][k] | ((unsigned)pl[1][k] << 16);
                             o.y = pl[2][k] | ((unsigned)pl[3][k] << 16);
-                            asm volatile("ds_write_b64 %0, %1" ::"v"(stg + (unsigned)((((b >> 1) * NP + k) * PBLK) + frow * 32 + (8 * (b & 1) + 4 * fhalf) * 2)), "v"(o) : "memory");
+                            asm volatile("ds_write_b64 %0, %1" ::"v"(stg + (unsigned)((((ecolq(b) >> 2) * NP + k) * PBLK) + erow(b) * 32 + (ecolq(b) & 3) * 8)), "v"(o) : "memory");
                         }
                     }
                     f32x4 img[2 * NP];
@@ -621,7 +717,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
                     for (int e = 0; e < 16; ++e) cs[e] += v[e];
                 }
             });
-            if constexpr (CS) {   // the 32 lanes sharing lane >> 5 hold the 32 rows of every row tile: xor tree, one lane writes
+            if constexpr (CS && S16) {   // chunks b and b ^ 2 hold the two row halves of the same columns; 16 lanes per row half
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float t = cs[e] + cs[e + 8];
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o, 64);
+                    cs[e] = t;
+                }
+                if (r16 == 0) {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const int n = n0 + 4 * ecolq(b);
+                        if (n < p.N)
+                            *reinterpret_cast<float4*>(p.colpart + (int64_t)(WM * tm + wm) * p.N + n) =
+                                make_float4(cs[4 * b], cs[4 * b + 1], cs[4 * b + 2], cs[4 * b + 3]);
+                    }
+                }
+            } else if constexpr (CS) {   // the 32 lanes sharing lane >> 5 hold the 32 rows of every row tile: xor tree, one lane writes
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     float t = cs[e];
@@ -1337,9 +1450,9 @@ extern "C" int msn_set_pgemm_skew(int cycles) {
     return MSN_OK;
 }
 static int g_pgemm_chunk = 0;       // K-steps per chunk of the 3-plane NT kernel (0 = whole reduction; experiments)
-static int g_pgemm_variant = 1;     // 3-plane NT kernel: 0 = 2 x 4 waves, 1 = 4 x 2 (default)
+static int g_pgemm_variant = 1;     // 3-plane NT kernel: 0 = 2 x 4 waves, 1 = 4 x 2 (default), 2 = 4 x 2 on v_mfma_f32_16x16x32_bf16 (plane pairs along k)
 extern "C" int msn_set_pgemm_variant(int v) {
-    MSN_REQUIRE(v >= 0 && v % 1000 <= 1 && v / 1000 <= 1000, "msn_set_pgemm_variant: 0 or 1 (+ 1000 * K-steps per chunk)");
+    MSN_REQUIRE(v >= 0 && v % 1000 <= 2 && v / 1000 <= 1000, "msn_set_pgemm_variant: 0, 1 or 2 (+ 1000 * K-steps per chunk)");
     g_pgemm_chunk = v / 1000;
     v %= 1000;
     g_pgemm_variant = v;
@@ -1601,6 +1714,8 @@ static int pgemm_nt_impl(int64_t M, int N, int K, int planes, const void* A, con
         // (the staggered-DMA instantiations -- variants 3 / 4 of the measurements in profiles/r04_pgemm_variants.txt -- are not
         // built any more: nothing in the step, +9 % on one shape in isolation; STAG stays in the kernel source)
         if (g_pgemm_variant == 0) launch_nt<3, 128, true>(a, c_planes != 0, grid, st);
+        else if (g_pgemm_variant == 2 && c_planes) hipLaunchKernelGGL((pgemm_nt_kernel<3, 128, true, true, 4, 2, false, false, true>), dim3((unsigned)grid), dim3(512), 0, st, a);
+        else if (g_pgemm_variant == 2) hipLaunchKernelGGL((pgemm_nt_kernel<3, 128, false, true, 4, 2, false, false, true>), dim3((unsigned)grid), dim3(512), 0, st, a);
         else launch_nt<3, 128, true, 4, 2>(a, c_planes != 0, grid, st);
     } else if (f16) {
         a.colsum_rows = 4;

@@ -181,7 +181,7 @@ def test_fp32_grade_gate_tn(N, K, kind, arith):
     assert float(e_pl.pow(2).mean().sqrt()) <= lim * float(e_nat.pow(2).mean().sqrt()) + 1e-30
 
 
-@pytest.mark.parametrize("variant", [0])
+@pytest.mark.parametrize("variant", [0, 2])
 @pytest.mark.parametrize("M,N,K", [(300, 272, 200), (4096, 1536, 384), (777, 384, 1536)])
 def test_nt_wave_layouts_exact_on_integers(M, N, K, variant):
     """The alternative wave layouts / staggered DMA issue of the 3-plane kernel (msn_set_pgemm_variant)."""
