@@ -31,820 +31,26 @@
 //
 // NT workgroup = 8 waves (2 x 4), tile 256 x BN (BN = 256 or 128), K-step 16 = one MFMA deep, ring of 3-4 LDS slots of
 // (8 + BN / 32) * NP pieces; persistent (one workgroup per CU walks its tiles, the ring runs on across tile boundaries).
-#include <algorithm>
-#include <type_traits>
 
-#include "msn_common.h"
+
+#include "pgemm_kernels.h"
+
+// instantiated in pgemm_alt1.hip / pgemm_alt2.hip
+namespace msn {
+extern template __global__ void pgemm_nt_kernel<3, 128, true, true, 2, 4, false>(const PgemmArgs);
+extern template __global__ void pgemm_nt_kernel<3, 128, false, true, 2, 4, false>(const PgemmArgs);
+extern template __global__ void pgemm_nt_kernel<3, 128, true, true, 4, 2, false, false, true>(const PgemmArgs);
+extern template __global__ void pgemm_nt_kernel<3, 128, false, true, 4, 2, false, false, true>(const PgemmArgs);
+extern template __global__ void pgemm_nt_kernel<2, 128, true, false, 2, 4, false>(const PgemmArgs);
+extern template __global__ void pgemm_nt_kernel<2, 128, false, false, 2, 4, false>(const PgemmArgs);
+extern template __global__ void pgemm_nt_kernel<2, 128, false, true, 4, 2, false, true>(const PgemmArgs);
+extern template __global__ void pgemm_tn_kernel<2, 128, true, false, 2, 4>(const PgemmArgs);
+extern template __global__ void pgemm_tn_kernel<2, 128, false, false, 2, 4>(const PgemmArgs);
+extern template __global__ void pgemm_tn_kernel<2, 128, true, true, 2, 4, true>(const PgemmArgs);
+extern template __global__ void pgemm_tn_kernel<2, 128, false, true, 2, 4, true>(const PgemmArgs);
+}  // namespace msn
 
 namespace msn {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned short u16;
-typedef __attribute__((address_space(1))) const void gptr_t;
-typedef __attribute__((address_space(3))) void lptr_t;
-
-constexpr int PBLK = 1024;          // bytes of one plane image of one 32 x 16 block
-constexpr int BM = 256;             // tile rows
-
-struct PgemmArgs {
-    const unsigned char* A;         // NT: planes of the M x K operand.   TN: planes of dY (rows = reduction, N columns)
-    const unsigned char* B;         // NT: planes of the N x K operand.   TN: planes of X  (rows = reduction, K columns)
-    void* C;                        // fp32 matrix (ldc) or plane matrix (cbC column blocks)
-    float* aux;
-    const float* bias;
-    int64_t ldc, ldaux;
-    int64_t M;                      // NT: rows of A / C.  TN: reduction length
-    int N, K;
-    int rbA, rbB;                   // NT: row blocks of A / B.  TN: row blocks (both operands share the rows)
-    int cbA, cbB;                   // column blocks of A / B (NT: both = K-steps)
-    int cbC;                        // column blocks of a plane output
-    int tiles_m, tiles_n, super_rows, epi;
-    int colsum_rows;                // NT: column-sum partial rows per tile row (= WM of the kernel's wave layout)
-    int chunk_steps;                // NT: K-steps per chunk (0 = the whole reduction in one accumulation)
-    int tail_full;                  // NT: tiles [0, tail_full) are dealt whole; [tail_full, total) are the TAIL tiles, each cut into
-    int tail_segs, tail_steps;      //     tail_segs K-segments of tail_steps K-steps (units): unit u -> workgroup u, raw sums -> tail_slabs[u]
-    float* tail_slabs;              //     (0 segments: no tail split)
-    int skew;                       // NT: start delay unit in shader cycles (0 = none): workgroup b waits ((b >> 3) & 3) * skew
-    float* colpart;                 // NT (nullable): [2 * tiles_m][N] column sums of the values written to C
-    int splits;                     // TN: reduction split
-    int rb_per_split;               // TN: row blocks per split
-    float* slabs;                   // TN: [splits][N][K] partials (splits > 1)
-    const float* scaleA;            // fp16 planes: the operands hold x * 2^e; scaleA[0] * scaleB[0] = 2^-(eA + eB) multiplies every sum
-    const float* scaleB;
-};
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-template <int OFF>
-__device__ __forceinline__ void ds_read128(bf16x8& dst, unsigned addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
-}
-template <int N>
-__device__ __forceinline__ void wait_lgkm() {
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
-__device__ __forceinline__ void wait_vm(int n) {        // n is wave-uniform
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-    }
-}
-
-__device__ __forceinline__ u16 f2bf(float f) {          // round to nearest even; NaN stays NaN (plain cast)
-    const __bf16 b = (__bf16)f;
-    return *reinterpret_cast<const u16*>(&b);
-}
-__device__ __forceinline__ float bf2f(u16 v) { return __uint_as_float((unsigned)v << 16); }
-
-// x -> NP planes (u16 each).  Each residual x - p0 (- p1) is exact in fp32.
-template <int NP>
-__device__ __forceinline__ void split_planes(float x, u16 (&pl)[NP]) {
-    float r = x;
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        pl[k] = f2bf(r);
-        r -= bf2f(pl[k]);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// NT kernel.  LDS slot = [A: 8 row blocks][NP planes][1 KB] then [B: BN / 32 row blocks][NP][1 KB].  Inside a plane image
-// the 16-byte half h of row r sits at chunk 2 r + (h ^ swz(r)), swz(r) = (r >> 3) & 1 (applied on the DMA source address):
-// a ds_read_b128 of the 32x32x16 operand (lane l: row l & 31, half l >> 5) is served in 16-lane groups {0-3, 12-15,
-// 20-27} / {4-11, 16-19, 28-31}; row r covers banks 8 r + 4 (h ^ swz) .. + 3 (mod 64): with the swizzle every group touches
-// 16 distinct 4-bank quads -> conflict-free.
-//
-// DUAL (the fp32-grade form, NP = 3, BN = 128): TWO accumulator sets.  The bf16 MFMA adds its 16-term dot product into the
-// accumulator with a truncating (biased) rounding -- unlike the fp32-input MFMA's round-to-nearest -- so every MFMA into a
-// LARGE accumulator costs a systematic ~1/18 ulp and the error of one accumulator grows like K^1.5 (measured: 5.4 x the
-// native kernel's at K = 1536 with all six products in one accumulator).  The p0.q0 products alone go to `acc`; the five
-// small products (<= 2^-8 of it) go to `acc2`, whose roundings are 2^-8 smaller; the epilogue adds the two in fp32.  With
-// that the error is 0.3 x the native kernel's up to K = 768; longer reductions are cut into K chunks of <= 512 columns whose
-// partial sums meet in C by fp32 adds (host: chunk_steps).  (The TN kernel instead folds the p0.q0 product in by VALU adds:
-// there the reduction is thousands of rows long.  The same fold on the NT kernel costs 11 % at K = 384 and leaves the
-// maximum error at K >= 1152 where chunks put it -- profiles/r04_pgemm_accuracy.txt.)
-// Wave layout WM x WN (rows x columns of the tile): 2 x 4 = eight waves of 128 x (BN / 4); 4 x 2 = eight waves of 64 x (BN / 2)
-// (12 instead of 15 fragment reads per 24 MFMAs on BN = 128: +7-12 %, the 3-plane default; four waves of 128 x 64 with the
-// whole register file each were 15-25 % slower).  STAG: the two waves of a SIMD issue their LDS-DMA pieces in different halves of a K-step
-// (waves 0-3 behind the first products, waves 4-7 behind the last ones) instead of both stalling in the same gaps.
-template <int NP, int BN, bool OUTP, bool DUAL, int WM = 2, int WN = 4, bool STAG = false, bool F16 = false, bool S16 = false>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(const PgemmArgs p) {
-    static_assert(!F16 || !OUTP, "fp16 planes: fp32 results only");
-    static_assert(!S16 || (NP == 3 && DUAL && !F16 && !STAG && WM == 4 && WN == 2 && BN == 128), "the 16 x 16 x 32 form: three bf16 planes, two accumulator sets, 4 x 2 waves");
-    constexpr int NW = WM * WN;
-    constexpr int ARB = BM / 32, BRB = BN / 32, AP = ARB * NP, BP = BRB * NP, PIECES = AP + BP;
-    constexpr int SLOT = PIECES * PBLK;
-    constexpr int STG = 6 * 1024;                    // epilogue staging per wave (one 32 x 32 tile: 4 KB fp32 / 6 plane images)
-    constexpr int NSLOT = (4 * SLOT + NW * STG <= 160 * 1024) ? 4 : 3;
-    static_assert(NSLOT * SLOT + NW * STG <= 160 * 1024, "LDS: ring + staging");
-    constexpr int MAXQ = (PIECES + NW - 1) / NW;     // pieces per wave and K-step (the last one only for the low waves)
-    constexpr int MT = 8 / WM, NT = BN / (32 * WN);  // 32 x 32 MFMA tiles per wave: rows x columns
-    constexpr int NG = S16 ? 3 : NP * (NP + 1) / 2;  // MFMA groups per K-step (S16: three plane-PAIR products)
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSLOT * SLOT + NW * STG];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int G = gridDim.x;
-    const int total = p.tiles_m * p.tiles_n;
-    const int nk = p.cbA;                            // K-steps per tile
-
-    // tile order: ids are dealt round-robin to the 8 XCDs; each XCD gets a contiguous run of tiles walked in super-rows
-    // (SR tile-rows x all tile columns, row-fastest) so that its workgroups share A row panels and the weight in one L2
-    auto locate = [&](int t, int& tm_, int& tn_) {
-        const int q = total / 8, r = total % 8, x = t % 8, i = t / 8;
-        const int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-        const int SR = p.super_rows;
-        const int sr = bid / (SR * p.tiles_n), j = bid % (SR * p.tiles_n);
-        const int rows_sr = min(SR, p.tiles_m - sr * SR);
-        tm_ = sr * SR + j % rows_sr;
-        tn_ = j / rows_sr;
-    };
-    // idx-th SEGMENT of this workgroup: its whole tiles first (every K-step), then -- tail split -- at most one unit: a K range
-    // of one of the tiles that do not fill a round of the G workgroups (the host cuts each of them into tail_segs ranges so that
-    // the units spread over the chip instead of a few workgroups multiplying a whole extra tile while the others wait)
-    const int n_whole = p.tail_segs ? p.tail_full : total;
-    auto seg_of = [&](int idx, int& tm_, int& tn_, int& kb_, int& ke_) -> bool {
-        const int t = blockIdx.x + idx * G;
-        if (t < n_whole) {
-            locate(t, tm_, tn_);
-            kb_ = 0, ke_ = nk;
-            return true;
-        }
-        const int first_tail_idx = n_whole / G;                       // n_whole is a multiple of G when the tail is split
-        if (p.tail_segs && idx == first_tail_idx && (int)blockIdx.x < (total - n_whole) * p.tail_segs) {
-            const int u = blockIdx.x;
-            locate(n_whole + u / p.tail_segs, tm_, tn_);
-            kb_ = (u % p.tail_segs) * p.tail_steps;
-            ke_ = min(nk, kb_ + p.tail_steps);
-            return kb_ < ke_;
-        }
-        return false;
-    };
-
-    // ---- producer: the LDS-DMA stream.  Global K-step g (over all tiles of this workgroup) lives in slot g % NSLOT.
-    // (S16: no swizzle -- 16-row fragments of rows r, r + 8 take opposite halves in one ds_read_b128 lane group: conflict-free as laid)
-    const int lane_src = S16 ? lane * 16 : (((lane >> 1) * 2) + ((lane & 1) ^ ((lane >> 4) & 1))) * 16;
-    const unsigned char* pbase[MAXQ];                // source of piece q of the producer's tile at K-step 0 (wave-uniform)
-    int p_idx = 0, p_k = 0, p_ke = 0, p_slot = 0, p_tm = 0, p_tn = 0;
-    bool p_live = seg_of(0, p_tm, p_tn, p_k, p_ke);
-    auto set_bases = [&]() {
-#pragma unroll
-        for (int q = 0; q < MAXQ; ++q) {
-            const int id = wave + NW * q;
-            if (id < AP) {
-                const int rb = min(p_tm * ARB + id / NP, p.rbA - 1);            // rows past the edge: clamped, never stored
-                pbase[q] = p.A + ((int64_t)rb * nk * NP + id % NP) * PBLK;
-            } else {
-                const int id2 = min(id, PIECES - 1) - AP;
-                const int rb = min(p_tn * BRB + id2 / NP, p.rbB - 1);
-                pbase[q] = p.B + ((int64_t)rb * nk * NP + id2 % NP) * PBLK;
-            }
-        }
-    };
-    if (p_live) set_bases();
-    auto issue_q = [&](int q) {                      // piece q of the producer's current K-step
-#ifdef MSN_ABL_PG_NODMA                      // diagnostic build (tools/microbench/build_ablate.sh): no operand traffic at all
-        return;
-#endif
-        const int id = wave + NW * q;
-        if (id < PIECES)
-            __builtin_amdgcn_global_load_lds((gptr_t*)(pbase[q] + (int64_t)p_k * (NP * PBLK) + lane_src),
-                                             (lptr_t*)(lds + p_slot * SLOT + id * PBLK), 16, 0, 0);
-    };
-    // gap c of NG (behind the c-th plane product of a K-step): pieces [c MAXQ / NG, (c + 1) MAXQ / NG); STAG: the low waves
-    // issue theirs in the gaps 0 .. HG - 1, the high waves in HG .. NG - 2 (none behind the barrier: the counted wait stays
-    // the same for both halves)
-    constexpr int HG = (NG - 1) / 2;
-    const bool hi_half = wave >= NW / 2;
-    auto issue_chunk = [&](auto c_) {
-        constexpr int c = decltype(c_)::value;
-        if (p_live) {
-            if constexpr (STAG) {
-                if (c < HG && !hi_half) {
-#pragma unroll
-                    for (int q = c * MAXQ / HG; q < (c + 1) * MAXQ / HG; ++q) issue_q(q);
-                } else if (c >= HG && c < NG - 1 && hi_half) {
-#pragma unroll
-                    for (int q = (c - HG) * MAXQ / (NG - 1 - HG); q < (c - HG + 1) * MAXQ / (NG - 1 - HG); ++q) issue_q(q);
-                }
-            } else {
-#pragma unroll
-                for (int q = c * MAXQ / NG; q < (c + 1) * MAXQ / NG; ++q) issue_q(q);
-            }
-        }
-    };
-    auto advance = [&]() {                           // producer -> next global K-step
-        if (!p_live) return;
-        p_slot = (p_slot + 1 == NSLOT) ? 0 : p_slot + 1;
-        if (++p_k == p_ke) {
-            p_live = seg_of(++p_idx, p_tm, p_tn, p_k, p_ke);
-            if (p_live) set_bases();
-        }
-    };
-    // pieces of this wave issued by the chunks 0 .. NG - 2 of one K-step (all waves own every piece q < MAXQ - 1)
-    constexpr int Q_BEFORE = STAG ? MAXQ : (NG - 1) * MAXQ / NG;
-    const int ppw = (wave + NW * (MAXQ - 1) < PIECES) ? MAXQ : MAXQ - 1;      // pieces of this wave per K-step
-
-    // ---- fragments
-    const int frow = lane & 31, fhalf = lane >> 5;
-    const unsigned frag_lane = (unsigned)(frow * 32 + 16 * (fhalf ^ ((frow >> 3) & 1)));
-    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t*)lds;
-    const unsigned fragA = lds0 + frag_lane + (unsigned)(wm * MT * NP * PBLK);                   // + (i * NP + plane) KB
-    const unsigned fragB = lds0 + frag_lane + (unsigned)((AP + wn * NT * NP) * PBLK);           // + (j * NP + plane) KB
-
-    f32x16 acc[MT][NT], acc2[DUAL ? MT : 1][DUAL ? NT : 1];
-    bf16x8 fa[2][MT], fb0[2][NT], fbh[NP > 1 ? NP - 1 : 1][NT];
-    // ---- S16: v_mfma_f32_16x16x32_bf16 (holds 2.0 GHz under load where the 32 x 32 x 16 shape holds 1.75: profiles/
-    // r04_mfma_shape_clock.txt).  The 32 k of one instruction are the SAME 16 columns of TWO PLANES: lane group kg = lane >> 4
-    // supplies plane (kg >> 1 ? second : first), 16-byte half kg & 1 of row lane & 15 -- so [p0 | p1].[q0 | q1] = p0q0 + p1q1 (first
-    // accumulator set), [p0 | p1].[q1 | q0] = p0q1 + p1q0 and [p0 | p2].[q2 | q0] = p0q2 + p2q0 (second set): three 16-cycle
-    // instructions per 16 x 16 tile and K-step.  A 32 x 32 accumulator tile acc[i][j] is four 16 x 16 sub-tiles: chunk b =
-    // 2 (row half) + (column half); the lane holds row 16 (b >> 1) + (lane & 15), columns 16 (b & 1) + 4 (lane >> 4) + r.
-    const int r16 = lane & 15, kg = lane >> 4;
-    const unsigned s16_lane = (unsigned)(r16 * 32 + (kg & 1) * 16);
-    const unsigned s16A = lds0 + s16_lane + (unsigned)(wm * MT * NP * PBLK);
-    const unsigned s16B = lds0 + s16_lane + (unsigned)((AP + wn * NT * NP) * PBLK);
-    const unsigned fA01 = s16A + (unsigned)((kg >> 1) * PBLK), fA02 = s16A + (unsigned)((kg >> 1) * 2 * PBLK);
-    const unsigned fB01 = s16B + (unsigned)((kg >> 1) * PBLK), fB10 = s16B + (unsigned)((1 - (kg >> 1)) * PBLK);
-    const unsigned fB20 = s16B + (unsigned)((1 - (kg >> 1)) * 2 * PBLK);
-    bf16x8 fr[2][2][S16 ? 4 : 1];                    // [set][A-type | B-type][16-row sub-tile]
-    auto req16 = [&](bf16x8 (&dst)[S16 ? 4 : 1], unsigned base) {
-        if constexpr (S16) {
-            static_for<0, 4>([&](auto t_) {
-                constexpr int t = decltype(t_)::value;
-                ds_read128<(t >> 1) * NP * PBLK + (t & 1) * 512>(dst[t], base);
-            });
-        }
-    };
-
-    auto req_a = [&](bf16x8 (&dst)[MT], unsigned slot_off, auto pl_) {
-        constexpr int pl = decltype(pl_)::value;
-#ifdef MSN_ABL_PG_NOFRAG                     // diagnostic build: no fragment reads (the MFMAs multiply whatever the registers hold)
-#pragma unroll
-        for (int i = 0; i < MT; ++i) asm volatile("" : "=v"(dst[i]));
-        return;
-#endif
-        static_for<0, MT>([&](auto i_) {
-            constexpr int i = decltype(i_)::value;
-            ds_read128<(i * NP + pl) * PBLK>(dst[i], fragA + slot_off);
-        });
-    };
-    auto req_b = [&](bf16x8 (&dst)[NT], unsigned slot_off, auto pl_) {
-        constexpr int pl = decltype(pl_)::value;
-#ifdef MSN_ABL_PG_NOFRAG
-#pragma unroll
-        for (int j = 0; j < NT; ++j) asm volatile("" : "=v"(dst[j]));
-        return;
-#endif
-        static_for<0, NT>([&](auto j_) {
-            constexpr int j = decltype(j_)::value;
-            ds_read128<(j * NP + pl) * PBLK>(dst[j], fragB + slot_off);
-        });
-    };
-    // D^T tile = B_frag . A_frag^T: lane gets row m = lane & 31 of the tile and columns n = 8 b + 4 (lane >> 5) + r
-    auto mult = [&](const bf16x8 (&a)[MT], const bf16x8 (&b)[NT], auto small_) {
-        constexpr bool SMALL = decltype(small_)::value && DUAL;
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if constexpr (F16) {
-                    const f16x8 hb = __builtin_bit_cast(f16x8, b[j]), ha = __builtin_bit_cast(f16x8, a[i]);
-                    if constexpr (SMALL) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hb, ha, acc2[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hb, ha, acc[i][j], 0, 0, 0);
-                } else {
-                    if constexpr (SMALL) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc2[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
-                }
-            }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto mult16 = [&](const bf16x8 (&a)[S16 ? 4 : 1], const bf16x8 (&b)[S16 ? 4 : 1], auto small_) {
-        constexpr bool SMALL = decltype(small_)::value;
-        if constexpr (S16) {
-            static_for<0, 16>([&](auto u_) {
-                constexpr int u = decltype(u_)::value, ti = u >> 2, tj = u & 3, i = ti >> 1, j = tj >> 1, bch = 2 * (ti & 1) + (tj & 1);
-                f32x16& dstv = SMALL ? acc2[i][j] : acc[i][j];
-                f32x4 c = {dstv[4 * bch], dstv[4 * bch + 1], dstv[4 * bch + 2], dstv[4 * bch + 3]};
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[tj], a[ti], c, 0, 0, 0);
-                dstv[4 * bch] = c[0], dstv[4 * bch + 1] = c[1], dstv[4 * bch + 2] = c[2], dstv[4 * bch + 3] = c[3];
-            });
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    using BIG = std::integral_constant<bool, false>;
-    using SML = std::integral_constant<bool, true>;
-    // request the first fragments of a K-step (A plane 0 and every B plane) -- order matters for the counted waits
-    auto req_first = [&](bf16x8 (&a0)[MT], bf16x8 (&b0)[NT], unsigned slot_off) {
-        req_a(a0, slot_off, std::integral_constant<int, 0>{});
-        req_b(b0, slot_off, std::integral_constant<int, 0>{});
-        static_for<1, NP>([&](auto pb_) {
-            constexpr int pb = decltype(pb_)::value;
-            req_b(fbh[pb - 1], slot_off, pb_);
-        });
-    };
-
-    // req_first at a tile boundary (behind an epilogue, before the first tile): the registers have three defining sites that
-    // meet at the K loop's head, and where the register allocator does not coalesce them it copies them -- a copy of a
-    // fragment that has not ARRIVED yet (the compiler believes the asm that requested it defined it) is a stale fragment: one
-    // K-step of two MFMA tiles came out wrong in a few tiles per launch of the plane-output kernel.  So here the reads are
-    // waited for, and every register is re-defined behind the wait (an empty asm) so that any copy sits behind it too.
-    auto req_first_settled = [&](unsigned slot_off) {
-        if constexpr (S16) return;                   // (this form requests every fragment inside its step)
-        req_first(fa[0], fb0[0], slot_off);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(fa[0][i]));
-#pragma unroll
-        for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(fb0[0][j]));
-#pragma unroll
-        for (int k = 0; k < NP - 1; ++k)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(fbh[k][j]));
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    int c_slot = 0;                                  // slot of the consumer's current K-step
-    // One K-step; PAR = parity of the step inside its tile (a tile has an EVEN number of K-steps: the plane format pads K).
-    // On entry outstanding LDS reads, oldest first: A0 (MT), B0 (NT), B1 .. B_{NP-1} (NT each).  The first fragments of the
-    // next K-step are requested before this step's last product; behind the last step of a tile (or of a K chunk) the
-    // epilogue requests them once it is done -- the ring of K-steps itself runs on across tiles.
-    auto step = [&](auto par_, bool last = false) {
-        constexpr int PAR = decltype(par_)::value;
-        if constexpr (S16) {
-            // Every fragment is requested AND consumed inside its step: fr[0][0] = [p0 | p1] of A, fr[0][1] = [q0 | q1] of B,
-            // fr[1][0] = [p0 | p2], fr[1][1] = [q2 | q0]; [q1 | q0] is [q0 | q1] with the lane halves exchanged (two
-            // v_permlane32_swap per register pair, in place) instead of a fifth read: 16 ds_read_b128 per step (12 in the
-            // 32 x 32 x 16 form).  NOT carried over from that form: the next step's first fragments requested behind the barrier.
-            // With 16 fragment registers more than that form holds, the allocator (256 VGPRs) copies or spills the in-flight
-            // destinations at the step's merges -- multiplying fragments that have not arrived (tools/check_fragment_waits.py
-            // finds such copies in the ISA; the integer tests found them first).  What this costs is most of what the shape gains.
-            const unsigned cur = (unsigned)(c_slot * SLOT);
-            const int n_slot = (c_slot + 1 == NSLOT) ? 0 : c_slot + 1;
-            const bool p_was_live = p_live;
-            (void)last;
-            req16(fr[0][0], fA01 + cur);
-            req16(fr[0][1], fB01 + cur);
-            req16(fr[1][1], fB20 + cur);
-            wait_lgkm<4>();
-            mult16(fr[0][0], fr[0][1], BIG{});           // p0q0 + p1q1
-            issue_chunk(std::integral_constant<int, 0>{});
-            __builtin_amdgcn_sched_barrier(0);
-            req16(fr[1][0], fA02 + cur);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                u32x4 w = __builtin_bit_cast(u32x4, fr[0][1][t]);
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const u32x2 r = __builtin_amdgcn_permlane32_swap(w[2 * h], w[2 * h + 1], false, false);
-                    const u32x2 q = __builtin_amdgcn_permlane32_swap(r[1], r[0], false, false);
-                    w[2 * h] = q[0], w[2 * h + 1] = q[1];
-                }
-                fr[0][1][t] = __builtin_bit_cast(bf16x8, w);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mult16(fr[0][0], fr[0][1], SML{});           // p0q1 + p1q0
-            issue_chunk(std::integral_constant<int, 1>{});
-            __builtin_amdgcn_sched_barrier(0);
-            wait_lgkm<0>();
-            wait_vm(p_was_live ? (NSLOT - 3) * ppw + Q_BEFORE : 0);
-#ifndef MSN_ABL_PG_NOBAR
-            __builtin_amdgcn_s_barrier();
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            mult16(fr[1][0], fr[1][1], SML{});           // p0q2 + p2q0
-            issue_chunk(std::integral_constant<int, NG - 1>{});
-            __builtin_amdgcn_sched_barrier(0);
-            advance();
-            c_slot = n_slot;
-            return;
-        }
-        constexpr int QA = (NP & 1) ? PAR : 0;       // fa buffer of plane 0; plane pa sits in fa[(QA + pa) & 1]
-        const unsigned cur = (unsigned)(c_slot * SLOT);
-        const int n_slot = (c_slot + 1 == NSLOT) ? 0 : c_slot + 1;
-        const unsigned nxt = (unsigned)(n_slot * SLOT);
-        const bool p_was_live = p_live;
-        req_a(fa[QA ^ 1], cur, std::integral_constant<int, 1>{});
-        __builtin_amdgcn_sched_barrier(0);
-        // plane 0 of A against every plane of B
-        static_for<0, NP>([&](auto pb_) {
-            constexpr int pb = decltype(pb_)::value;
-            wait_lgkm<NT*(NP - 1 - pb) + MT>();
-            if constexpr (pb == 0) mult(fa[QA], fb0[PAR], BIG{});
-            else mult(fa[QA], fbh[pb - 1], SML{});
-            issue_chunk(std::integral_constant<int, pb>{});
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        // planes 1 .. NP - 2 of A
-        static_for<1, NP - 1>([&](auto pa_) {
-            constexpr int pa = decltype(pa_)::value;
-            constexpr int g0 = pa * NP - pa * (pa - 1) / 2;         // products before plane pa
-            req_a(fa[(QA + pa + 1) & 1], cur, std::integral_constant<int, pa + 1>{});
-            wait_lgkm<MT>();
-            static_for<0, NP - pa>([&](auto pb_) {
-                constexpr int pb = decltype(pb_)::value;
-                if constexpr (pb == 0) mult(fa[(QA + pa) & 1], fb0[PAR], SML{});
-                else mult(fa[(QA + pa) & 1], fbh[pb - 1], SML{});
-                issue_chunk(std::integral_constant<int, g0 + pb>{});
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        });
-        // every fragment of this K-step is in registers -> its slot may be refilled; the next K-step must have landed
-        wait_lgkm<0>();
-        wait_vm(p_was_live ? (NSLOT - 3) * ppw + (STAG ? ppw : Q_BEFORE) : 0);
-#ifndef MSN_ABL_PG_NOBAR
-        __builtin_amdgcn_s_barrier();
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        // (not behind a tile's or a K chunk's last step: the epilogue wants the registers -- it requests them when it is done)
-        if (!last) req_first(fa[(QA + NP) & 1], fb0[PAR ^ 1], nxt);
-        __builtin_amdgcn_sched_barrier(0);
-        mult(fa[(QA + NP - 1) & 1], fb0[PAR], SML{});
-        issue_chunk(std::integral_constant<int, NG - 1>{});
-        __builtin_amdgcn_sched_barrier(0);
-        advance();
-        c_slot = n_slot;
-    };
-
-    // ---- epilogue: lane holds, per (i, j) tile, row m = 32 i + (lane & 31) and columns n = 32 j + 8 b + 4 (lane >> 5) + r
-    // ---- epilogue.  The accumulator layout (lane = one row, 4 consecutive columns) is the wrong shape for memory: a 16-byte
-    // store per lane touches 32 different 128-byte lines per wave instruction and the address coalescer, not HBM, bounds the
-    // epilogue (64 such instructions per wave for a GELU tile: +320 us on a 470-us product).  Every 32 x 32 MFMA tile therefore
-    // goes through a per-wave LDS staging area (6 KB behind the ring) and leaves -- or enters, for the matrices an epilogue
-    // reads -- in memory order: fp32 as 8 rows x 128 bytes per instruction, planes as whole 1-KB block images.
-    // MODE 0: the tile's result.  MODE 1: the tile's result when earlier K chunks left a partial sum in C (added first).
-    // MODE 2 / 3: a K chunk's partial sum -> C (first chunk) / C += (later chunks); no bias, no epilogue (fp32 outputs only).
-    const unsigned stg = lds0 + (unsigned)(NSLOT * SLOT + wave * STG);
-    // fp32 image of a tile: [32 rows][128 B], 16-byte chunk c of row r at position c ^ (r & 7) (conflict-free both ways)
-    const unsigned st_acc = stg + (unsigned)(frow * 128);                       // + ((2 b + fhalf) ^ (frow & 7)) * 16
-    // chunk b of this lane's 16 accumulator values of a 32 x 32 tile: its row and its 16-byte column chunk (4 columns) in the tile
-    auto erow = [&](int b) { return S16 ? 16 * (b >> 1) + r16 : frow; };
-    auto ecolq = [&](int b) { return S16 ? 4 * (b & 1) + kg : 2 * b + fhalf; };
-    auto acc_addr = [&](int b) { return stg + (unsigned)(erow(b) * 128 + ((ecolq(b) ^ (erow(b) & 7)) * 16)); };
-    const int srow = lane >> 3, schunk = lane & 7;                              // memory order: pass q -> row 8 q + srow
-    const unsigned st_mem = stg + (unsigned)(srow * 128 + ((schunk ^ srow) * 16));   // + q * 1024   ((8 q + srow) & 7 == srow)
-    // (s_nop behind every ds_write_b128: a VALU write to the data registers of a DS store of more than 8 bytes needs a wait
-    // state the compiler's hazard recognizer would insert -- it cannot see the store inside the asm; without it a few lanes
-    // of a tile came out wrong once in a few launches)
-    auto lds_w128 = [&](unsigned addr, const float (&v)[4]) {
-        asm volatile("ds_write_b128 %0, %1\n\ts_nop 1" ::"v"(addr), "v"(*reinterpret_cast<const f32x4*>(v)) : "memory");
-    };
-    auto lds_r128 = [&](f32x4& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory"); };
-    // a 32 x 32 fp32 tile of a matrix the epilogue READS (residual / saved activation derivative / K-chunk partial):
-    // tile_fetch issues its four 16-byte loads per lane in memory order (for EVERY tile of the wave before the first is used:
-    // one exposed memory latency per output tile instead of one per MFMA tile), tile_take turns one through the staging
-    // area into the accumulator layout a[4 b + r]
-    auto tile_fetch = [&](const float* src, int64_t ld, int64_t m0, int n0, f32x4 (&t)[4]) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t m = m0 + 8 * q + srow;
-            const int n = n0 + 4 * schunk;
-            t[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (m < p.M && n < p.N) t[q] = *reinterpret_cast<const f32x4*>(src + m * ld + n);
-        }
-    };
-    auto tile_take = [&](const f32x4 (&t)[4], float (&a)[16]) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) asm volatile("ds_write_b128 %0, %1\n\ts_nop 1" ::"v"(st_mem + q * 1024), "v"(t[q]) : "memory");
-        f32x4 r[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) lds_r128(r[b], acc_addr(b));
-        // the wait names the registers it guards: the compiler may otherwise move a copy of them above it (it believes the
-        // asm that issued the read has already defined them)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3])::"memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[4 * b + e] = r[b][e];
-    };
-    // accumulator layout -> rows m0.., columns n0.. of `dst` in memory order: stage_chunk(b, 4 values) four times, then flush
-    auto stage_chunk = [&](int b, const float (&w)[4]) { lds_w128(acc_addr(b), w); };
-    auto tile_flush = [&](float* dst, int64_t ld, int64_t m0, int n0) {
-        f32x4 r[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) lds_r128(r[q], st_mem + q * 1024);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3])::"memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t m = m0 + 8 * q + srow;
-            const int n = n0 + 4 * schunk;
-            if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(dst + m * ld + n) = r[q];
-        }
-    };
-    auto slab_flush = [&](float* slab, int r0, int c0) {            // the staged tile -> rows r0.., columns c0.. of a 256 x BN slab
-        f32x4 r[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) lds_r128(r[q], st_mem + q * 1024);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3])::"memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(slab + (r0 + 8 * q + srow) * BN + c0 + 4 * schunk) = r[q];
-    };
-    auto store_tile_epi = [&](int tm, int tn, auto epi_, auto mode_) {
-        constexpr int epi = decltype(epi_)::value;
-        constexpr int MODE = decltype(mode_)::value & 3;
-        constexpr bool CS = (decltype(mode_)::value & 4) != 0;    // column sums of the stored values -> p.colpart
-        constexpr bool SLAB = (decltype(mode_)::value & 8) != 0;  // a tail unit's raw sums -> its slab (256 x BN, row-major)
-        constexpr bool PARTIAL = MODE >= 2, ADDC = (MODE == 1 || MODE == 3) && !OUTP;
-        constexpr bool AUXIN = !PARTIAL && (epi == MSN_EPI_RELU_BWD || epi == MSN_EPI_GELU_BWD || epi == MSN_EPI_ADD);
-        // everything the epilogue reads, requested up front: the K-chunk partial if there is one, else the aux matrix
-        if constexpr (DUAL) {      // the two accumulator sets meet here (one round-to-nearest add); acc2's registers are free from now on
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] += acc2[i][j];
-        }
-        if constexpr (F16) {       // fp16 planes hold x * 2^e: one exact power of two puts the sums back (before bias / epilogue / partial sums)
-            const float os = p.scaleA[0] * p.scaleB[0];
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] *= os;
-        }
-        constexpr bool PRE = ADDC || AUXIN;
-        constexpr int PW = (DUAL || MT * NT < 2) ? MT * NT : 2;          // tiles requested ahead (16 registers each)
-        f32x4 pre[PRE ? PW : 1][4];
-        const float* pre_src = ADDC ? static_cast<const float*>(p.C) : p.aux;
-        const int64_t pre_ld = ADDC ? p.ldc : p.ldaux;
-        auto pre_fetch = [&](auto t_) {                            // tile t = j * MT + i of this wave -> pre[t % PW]
-            constexpr int t = decltype(t_)::value;
-            if constexpr (PRE && t < MT * NT)
-                tile_fetch(pre_src, pre_ld, (int64_t)tm * BM + wm * (32 * MT) + 32 * (t % MT), tn * BN + wn * (32 * NT) + 32 * (t / MT),
-                           pre[t % PW]);
-        };
-        static_for<0, PW>([&](auto t_) { pre_fetch(t_); });
-        static_for<0, NT>([&](auto j_) {
-            constexpr int j = decltype(j_)::value;
-            const int n0 = tn * BN + wn * (32 * NT) + 32 * j;
-            float cs[CS ? 16 : 1];                                 // column sums over this wave's rows, accumulator layout
-#pragma unroll
-            for (int e = 0; e < (CS ? 16 : 1); ++e) cs[e] = 0.f;
-            static_for<0, MT>([&](auto i_) {
-                constexpr int i = decltype(i_)::value;
-                constexpr int t = j * MT + i;
-                const int64_t m0 = (int64_t)tm * BM + wm * (32 * MT) + 32 * i;
-                const int rbk = tm * ARB + wm * MT + i;           // row block of a plane output (it has the rows of A)
-                const bool live = SLAB || (n0 < p.N && (OUTP ? rbk < p.rbA : m0 < p.M));      // (wave-uniform)
-                if (!live) {
-                    pre_fetch(std::integral_constant<int, t + PW>{});
-                    return;
-                }
-                const bool row_ok = m0 + frow < p.M;
-                float v[16];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = acc[i][j][e];
-                if constexpr (ADDC) {
-                    float c0[16];
-                    tile_take(pre[t % PW], c0);
-                    pre_fetch(std::integral_constant<int, t + PW>{});
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) v[e] += c0[e];
-                }
-                if (!PARTIAL && p.bias) {
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const int n = n0 + 4 * ecolq(b);
-                        if (n < p.N) {
-                            const float4 t = *reinterpret_cast<const float4*>(p.bias + n);
-                            v[4 * b] += t.x; v[4 * b + 1] += t.y; v[4 * b + 2] += t.z; v[4 * b + 3] += t.w;
-                        }
-                    }
-                }
-                if constexpr (!PARTIAL && epi == MSN_EPI_GELU) {
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        float dg[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) gelu_both(v[4 * b + r], v[4 * b + r], dg[r]);
-                        if (p.aux) stage_chunk(b, dg);
-                    }
-                    if (p.aux) tile_flush(p.aux, p.ldaux, m0, n0);
-                } else if constexpr (!PARTIAL && epi == MSN_EPI_RELU) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
-                } else if constexpr (!PARTIAL && epi != MSN_EPI_NONE) {
-                    float a[16];
-                    if constexpr (ADDC) {                              // (both a partial and an aux matrix: the aux tile comes now)
-                        f32x4 t[4];
-                        tile_fetch(p.aux, p.ldaux, m0, n0, t);
-                        tile_take(t, a);
-                    } else {
-                        tile_take(pre[t % PW], a);
-                        pre_fetch(std::integral_constant<int, t + PW>{});
-                    }
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        if constexpr (epi == MSN_EPI_GELU_BWD) v[e] *= a[e];
-                        else if constexpr (epi == MSN_EPI_RELU_BWD) v[e] = a[e] > 0.f ? v[e] : 0.f;
-                        else v[e] += a[e];                         // MSN_EPI_ADD
-                    }
-                }
-                if constexpr (S16) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        if (m0 + erow(e >> 2) >= p.M) v[e] = 0.f;
-                } else if (!row_ok) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) v[e] = 0.f;       // padding rows of a plane output are zero
-                }
-                if constexpr (OUTP) {
-                    // planes -> the 2 * NP block images of this tile ([32 rows][16 bf16] each, as they lie in HBM) -> 1-KB stores
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        u16 pl[4][NP];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) split_planes<NP>(v[4 * b + r], pl[r]);
-#pragma unroll
-                        for (int k = 0; k < NP; ++k) {
-                            uint2 o;
-                            o.x = pl[0][k] | ((unsigned)pl[1][k] << 16);
-                            o.y = pl[2][k] | ((unsigned)pl[3][k] << 16);
-                            asm volatile("ds_write_b64 %0, %1" ::"v"(stg + (unsigned)((((ecolq(b) >> 2) * NP + k) * PBLK) + erow(b) * 32 + (ecolq(b) & 3) * 8)), "v"(o) : "memory");
-                        }
-                    }
-                    f32x4 img[2 * NP];
-#pragma unroll
-                    for (int q = 0; q < 2 * NP; ++q) lds_r128(img[q], stg + (unsigned)(q * PBLK + lane * 16));
-                    if constexpr (NP == 3)
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(img[0]), "+v"(img[1]), "+v"(img[2]), "+v"(img[3]), "+v"(img[4]), "+v"(img[5])::"memory");
-                    else
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(img[0]), "+v"(img[1]), "+v"(img[2]), "+v"(img[3])::"memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                    unsigned char* blk = static_cast<unsigned char*>(p.C) + ((int64_t)rbk * p.cbC + (n0 >> 4)) * (NP * PBLK) + lane * 16;
-#pragma unroll
-                    for (int q = 0; q < 2 * NP; ++q)
-                        if (n0 + 16 * (q / NP) < p.N) *reinterpret_cast<f32x4*>(blk + q * PBLK) = img[q];
-                } else {
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const float w[4] = {v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]};
-                        stage_chunk(b, w);
-                    }
-                    if constexpr (SLAB)
-                        slab_flush(p.tail_slabs + (int64_t)blockIdx.x * (BM * BN), wm * (32 * MT) + 32 * i, wn * (32 * NT) + 32 * j);
-                    else
-                        tile_flush(static_cast<float*>(p.C), p.ldc, m0, n0);
-                }
-                if constexpr (CS) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) cs[e] += v[e];
-                }
-            });
-            if constexpr (CS && S16) {   // chunks b and b ^ 2 hold the two row halves of the same columns; 16 lanes per row half
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float t = cs[e] + cs[e + 8];
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o, 64);
-                    cs[e] = t;
-                }
-                if (r16 == 0) {
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        const int n = n0 + 4 * ecolq(b);
-                        if (n < p.N)
-                            *reinterpret_cast<float4*>(p.colpart + (int64_t)(WM * tm + wm) * p.N + n) =
-                                make_float4(cs[4 * b], cs[4 * b + 1], cs[4 * b + 2], cs[4 * b + 3]);
-                    }
-                }
-            } else if constexpr (CS) {   // the 32 lanes sharing lane >> 5 hold the 32 rows of every row tile: xor tree, one lane writes
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float t = cs[e];
-#pragma unroll
-                    for (int o = 1; o < 32; o <<= 1) t += __shfl_xor(t, o, 64);
-                    cs[e] = t;
-                }
-                if (frow == 0) {
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const int n = n0 + 8 * b + 4 * fhalf;
-                        if (n < p.N)
-                            *reinterpret_cast<float4*>(p.colpart + (int64_t)(WM * tm + wm) * p.N + n) =
-                                make_float4(cs[4 * b], cs[4 * b + 1], cs[4 * b + 2], cs[4 * b + 3]);
-                    }
-                }
-            }
-        });
-    };
-    auto store_tile = [&](int tm, int tn, auto mode_) {
-        switch (p.epi) {
-            case MSN_EPI_RELU: store_tile_epi(tm, tn, std::integral_constant<int, MSN_EPI_RELU>{}, mode_); break;
-            case MSN_EPI_GELU: store_tile_epi(tm, tn, std::integral_constant<int, MSN_EPI_GELU>{}, mode_); break;
-            case MSN_EPI_RELU_BWD: store_tile_epi(tm, tn, std::integral_constant<int, MSN_EPI_RELU_BWD>{}, mode_); break;
-            case MSN_EPI_GELU_BWD: store_tile_epi(tm, tn, std::integral_constant<int, MSN_EPI_GELU_BWD>{}, mode_); break;
-            case MSN_EPI_ADD: store_tile_epi(tm, tn, std::integral_constant<int, MSN_EPI_ADD>{}, mode_); break;
-            default: store_tile_epi(tm, tn, std::integral_constant<int, MSN_EPI_NONE>{}, mode_); break;
-        }
-    };
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    acc[i][j][e] = 0.f;
-                    if constexpr (DUAL) acc2[i][j][e] = 0.f;
-                }
-    };
-
-    // ---- start skew: equal tiles keep the workgroups of a launch in lockstep -- all in their K loops (HBM idle), then all in
-    // their epilogues (matrix cores idle, HBM write-bound).  Four start phases a quarter tile apart spread the epilogues'
-    // stores over the others' K loops; workgroups with one tile fewer than the rest have the slack for it.
-    if (p.skew > 0) {
-        const int phase = (blockIdx.x >> 3) & 3;
-        const int mine = (total - (int)blockIdx.x + G - 1) / G, most = (total + G - 1) / G;
-        if (phase && (mine < most || p.skew < 0x40000000)) {
-            const long long until = (long long)__builtin_readcyclecounter() + (long long)phase * (p.skew & 0x3fffffff);
-            while ((long long)__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(32);
-        }
-    }
-    // ---- prologue: K-steps 0 .. NSLOT - 2 of the stream
-#pragma unroll
-    for (int s = 0; s < NSLOT - 1; ++s) {
-        if (p_live) {
-#pragma unroll
-            for (int q = 0; q < MAXQ; ++q) issue_q(q);
-        }
-        advance();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    req_first_settled(0u);
-
-    using T0 = std::integral_constant<int, 0>;
-    using T1 = std::integral_constant<int, 1>;
-    int tm, tn;
-    // K chunks (fp32 outputs of the DUAL form): the bf16 MFMA's biased accumulate costs ~K^1.5, so a long reduction is cut into
-    // chunks of p.chunk_steps K-steps whose partial sums meet in C by round-to-nearest fp32 adds (the lane that wrote a partial
-    // is the lane that reads it back: same wave, same address, program order)
-    const int csteps = (!OUTP && p.chunk_steps > 0) ? p.chunk_steps : nk;
-    int kb, ke;
-    for (int idx = 0; seg_of(idx, tm, tn, kb, ke); ++idx) {
-        zero_acc();
-        if (ke - kb < nk) {                          // a tail unit: raw sums of its K range -> its slab (finishing launch: host)
-            for (int k = kb; k < ke; k += 2) {
-                step(T0{});
-                step(T1{}, k + 2 >= ke);
-            }
-            wait_lgkm<0>();
-            store_tile_epi(tm, tn, std::integral_constant<int, MSN_EPI_NONE>{}, std::integral_constant<int, 2 + 8>{});
-            req_first_settled((unsigned)(c_slot * SLOT));
-            continue;
-        }
-        int k0 = 0;
-        for (; k0 + csteps < nk; k0 += csteps) {
-            for (int k = 0; k < csteps; k += 2) {
-                step(T0{});
-                step(T1{}, k + 2 >= csteps);
-            }
-            wait_lgkm<0>();
-            if (k0 == 0) store_tile_epi(tm, tn, std::integral_constant<int, MSN_EPI_NONE>{}, std::integral_constant<int, 2>{});
-            else store_tile_epi(tm, tn, std::integral_constant<int, MSN_EPI_NONE>{}, std::integral_constant<int, 3>{});
-            zero_acc();
-            req_first_settled((unsigned)(c_slot * SLOT));
-        }
-        for (int k = k0; k < nk; k += 2) {           // nk is even (plane format)
-            step(T0{});
-            step(T1{}, k + 2 >= nk);
-        }
-        wait_lgkm<0>();
-        if (k0 != 0) store_tile(tm, tn, std::integral_constant<int, 1>{});
-        else if (p.colpart) store_tile(tm, tn, std::integral_constant<int, 4>{});
-        else store_tile(tm, tn, std::integral_constant<int, 0>{});
-        // the next tile's first fragments (past the workgroup's last tile: whatever the slot holds, into registers nobody uses)
-        req_first_settled((unsigned)(c_slot * SLOT));
-    }
-}
 
 // Tail tiles of an NT product (PgemmArgs::tail_*): C tile = epilogue(sum over its K-segments' slabs, in K order).  One thread
 // per float4 of a 256 x 128 tile; epilogues NONE / RELU / ADD (the products whose tails are split).
@@ -882,296 +88,6 @@ __global__ __launch_bounds__(256) void pgemm_tail_finish_kernel(const PgemmArgs 
         s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f);
     }
     *reinterpret_cast<float4*>(static_cast<float*>(p.C) + m * p.ldc + n) = s;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// TN kernel (weight gradients): T[p][q] = sum_m P[m][p] . Q[m][q], both operands plane matrices with the reduction index m
-// on the ROWS.  SWAP = false: P = dY (p = n), Q = X (q = k);  SWAP = true: P = X (p = k), Q = dY (q = n) -- the 256-wide side
-// of the tile goes to whichever of N, K it divides better; the MFMA operand order is chosen so that a lane always ends up
-// with four consecutive k of one n (16-byte stores into C[n][k]).
-// K-step = 16 reduction rows = half a row block.  LDS slot = [P: 16 column blocks][NP][512 B] then [Q: BQ / 16][NP][512 B];
-// a 512-byte half-block image is [16 rows of m][32 B], its four row quads (4 rows = 128 B) stored at quad position
-// Q ^ (column block & 1).  The MFMA wants, per lane, 8 consecutive m of one column: two ds_read_b64_tr_b16 (each hands a
-// 4-row x 16-column block, column-major, to a 16-lane group: lane 4 q + p of the group supplies the address of row q,
-// bytes 8 p .. 8 p + 7; lane i receives column i).  Banking is per 32 lanes = the two column blocks of a 32-wide MFMA tile:
-// they read the same row quad, which the swizzle puts into opposite 128-byte halves of the bank row -> conflict-free.
-template <int OFF>
-__device__ __forceinline__ void ds_read_tr_o(bf16x4& dst, unsigned addr) {
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
-}
-
-template <int NP, int BQ, bool SWAP, bool DUAL, int WM = 2, int WN = 4, bool F16 = false>
-__global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(const PgemmArgs p) {
-    static_assert(WM * WN == 8, "eight waves");
-    constexpr int PHB = 16 * NP, QHB = (BQ / 16) * NP;       // half-block images per K-step: P side, Q side
-    constexpr int PIECES = (PHB + QHB) / 2;                  // 1-KB pieces (two half-block images each)
-    constexpr int PP = PHB / 2;
-    constexpr int SLOT = PIECES * PBLK;
-    constexpr int NSLOT = (4 * SLOT <= 160 * 1024) ? 4 : 3;
-    constexpr int MAXQ = (PIECES + 7) / 8;
-    constexpr int MT = 8 / WM, NT = BQ / (32 * WN);       // 32 x 32 MFMA tiles per wave: P side x Q side
-    constexpr int NG = NP * (NP + 1) / 2;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSLOT * SLOT];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int tiles = p.tiles_m * p.tiles_n;                 // tiles over (P side, Q side)
-    // workgroup ids go round-robin to the 8 XCDs: give each XCD a contiguous run of (split, tile) pairs, i.e. the tiles of
-    // one reduction range, so that its panels are shared in ONE L2
-    int bid = blockIdx.x;
-    {
-        const int nwg = gridDim.x, q = nwg / 8, r = nwg % 8, x = bid % 8, i = bid / 8;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-    }
-    const int split = bid / tiles, tile = bid % tiles;
-    const int tp = tile / p.tiles_n, tq = tile % p.tiles_n;
-    const unsigned char* Pm = SWAP ? p.B : p.A;
-    const unsigned char* Qm = SWAP ? p.A : p.B;
-    const int cbP = SWAP ? p.cbB : p.cbA, cbQ = SWAP ? p.cbA : p.cbB;    // column blocks of the plane matrices
-    const int rb0 = split * p.rb_per_split;
-    const int rb1 = min(p.rbA, rb0 + p.rb_per_split);
-    const int nk = 2 * (rb1 - rb0);                          // K-steps (>= 2)
-
-    // ---- LDS-DMA: piece id = two consecutive half-block images hb = 2 id + (lane >> 5); image hb of the P side is column
-    // block hb / NP, plane hb % NP: in the plane matrix its 1-KB block is block (cb0 * NP + hb) of the row block.
-    const int sub = lane >> 5, j = lane & 31;
-    const unsigned char* pbase[MAXQ];
-#pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
-        const int id = min(wave + 8 * q, PIECES - 1);
-        const bool isP = id < PP;
-        const int hb = 2 * (isP ? id : id - PP) + sub;
-        const int cbp = hb / NP;                                            // column block inside the tile
-        const int cb0 = isP ? tp * 16 : tq * (BQ / 16);
-        const int cbs = isP ? cbP : cbQ;
-        const int hbc = min(hb, (cbs - cb0) * NP - 1);                      // past the matrix: clamped, never stored
-        const int rpos = j >> 1;                                            // row position in the image
-        const int rsrc = (rpos & 3) + 4 * ((rpos >> 2) ^ (cbp & 1));        // source row of that position
-        pbase[q] = (isP ? Pm : Qm) + ((int64_t)rb0 * cbs + cb0) * (NP * PBLK) + (int64_t)hbc * PBLK + rsrc * 32 + (j & 1) * 16;
-    }
-    const int64_t rbstepP = (int64_t)cbP * (NP * PBLK), rbstepQ = (int64_t)cbQ * (NP * PBLK);
-    int p_k = 0, p_slot = 0;
-    auto issue_q = [&](int q) {
-        const int id = wave + 8 * q;
-        if (id < PIECES) {
-            const int64_t off = (int64_t)(p_k >> 1) * (id < PP ? rbstepP : rbstepQ) + (p_k & 1) * 512;
-            __builtin_amdgcn_global_load_lds((gptr_t*)(pbase[q] + off), (lptr_t*)(lds + p_slot * SLOT + id * PBLK), 16, 0, 0);
-        }
-    };
-    auto issue_chunk = [&](auto c_) {
-        constexpr int c = decltype(c_)::value;
-        if (p_k < nk) {
-#pragma unroll
-            for (int q = c * MAXQ / NG; q < (c + 1) * MAXQ / NG; ++q) issue_q(q);
-        }
-    };
-    auto advance = [&]() {
-        if (p_k < nk) {
-            ++p_k;
-            p_slot = (p_slot + 1 == NSLOT) ? 0 : p_slot + 1;
-        }
-    };
-    constexpr int Q_BEFORE = (NG - 1) * MAXQ / NG;
-    const int ppw = (wave + 8 * (MAXQ - 1) < PIECES) ? MAXQ : MAXQ - 1;
-
-    // ---- fragments: lane -> 16-lane group g16 = (lane >> 4) & 1 (column block of the 32-wide tile), m-octet lane >> 5;
-    // inside the group lane 4 q + pp supplies row q, bytes 8 pp.  Read t = 0, 1 of a fragment takes row quad 2 (lane >> 5) + t.
-    const int g16 = (lane >> 4) & 1, moct = lane >> 5, rq = (lane >> 2) & 3, pp = lane & 3;
-    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t*)lds;
-    // address of read t: image(cb pair * 2 + g16, plane) * 512 + ((2 moct + t) ^ g16) * 128 + rq * 32 + pp * 8
-    const unsigned tr0 = lds0 + (unsigned)(g16 * NP * 512 + ((2 * moct) ^ g16) * 128 + rq * 32 + pp * 8);
-    const unsigned tr1 = lds0 + (unsigned)(g16 * NP * 512 + ((2 * moct + 1) ^ g16) * 128 + rq * 32 + pp * 8);
-    const unsigned fragP0 = tr0 + (unsigned)(wm * 2 * MT * NP * 512), fragP1 = tr1 + (unsigned)(wm * 2 * MT * NP * 512);      // + (2 i NP + plane) * 512
-    const unsigned fragQ0 = tr0 + (unsigned)(PHB * 512 + wn * 2 * NT * NP * 512), fragQ1 = tr1 + (unsigned)(PHB * 512 + wn * 2 * NT * NP * 512);
-
-    f32x16 acc[MT][NT], acc2[DUAL ? MT : 1][DUAL ? NT : 1];        // DUAL: see pgemm_nt_kernel
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int jj = 0; jj < NT; ++jj)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                acc[i][jj][e] = 0.f;
-                if constexpr (DUAL) acc2[i][jj][e] = 0.f;
-            }
-    bf16x4 fa[2][MT][2], fb0[2][NT][2], fbh[NP > 1 ? NP - 1 : 1][NT][2];
-
-    auto req_a = [&](bf16x4 (&dst)[MT][2], unsigned slot_off, auto pl_) {
-        constexpr int pl = decltype(pl_)::value;
-        static_for<0, MT>([&](auto i_) {
-            constexpr int i = decltype(i_)::value;
-            ds_read_tr_o<(2 * i * NP + pl) * 512>(dst[i][0], fragP0 + slot_off);
-            ds_read_tr_o<(2 * i * NP + pl) * 512>(dst[i][1], fragP1 + slot_off);
-        });
-    };
-    auto req_b = [&](bf16x4 (&dst)[NT][2], unsigned slot_off, auto pl_) {
-        constexpr int pl = decltype(pl_)::value;
-        static_for<0, NT>([&](auto j_) {
-            constexpr int jj = decltype(j_)::value;
-            ds_read_tr_o<(2 * jj * NP + pl) * 512>(dst[jj][0], fragQ0 + slot_off);
-            ds_read_tr_o<(2 * jj * NP + pl) * 512>(dst[jj][1], fragQ1 + slot_off);
-        });
-    };
-    auto mfma1 = [&](const bf16x8& av, const bf16x8& bv, const f32x16& c) -> f32x16 {
-        if constexpr (F16) {
-            const f16x8 ha = __builtin_bit_cast(f16x8, av), hb = __builtin_bit_cast(f16x8, bv);
-            if constexpr (SWAP) return __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hb, c, 0, 0, 0);
-            else return __builtin_amdgcn_mfma_f32_32x32x16_f16(hb, ha, c, 0, 0, 0);
-        } else {
-            if constexpr (SWAP) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, c, 0, 0, 0);
-            else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, c, 0, 0, 0);
-        }
-    };
-    // DUAL: zero-accumulator MFMA + round-to-nearest fold of the p0.q0 product (see pgemm_nt_kernel)
-    f32x16 tbig[2];
-    auto fold = [&](auto v_) {
-        constexpr int v = decltype(v_)::value;
-        acc[v / NT][v % NT] += tbig[v & 1];
-        asm volatile("" : "+v"(acc[v / NT][v % NT]));
-    };
-    auto mult_big = [&](const bf16x4 (&a)[MT][2], const bf16x4 (&b)[NT][2]) {
-        static_for<0, MT * NT>([&](auto u_) {
-            constexpr int u = decltype(u_)::value;
-            if constexpr (u >= 2) fold(std::integral_constant<int, u - 2>{});
-            f32x16 z;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) z[e] = 0.f;
-            const bf16x8 av = __builtin_shufflevector(a[u / NT][0], a[u / NT][1], 0, 1, 2, 3, 4, 5, 6, 7);
-            const bf16x8 bv = __builtin_shufflevector(b[u % NT][0], b[u % NT][1], 0, 1, 2, 3, 4, 5, 6, 7);
-            tbig[u & 1] = mfma1(av, bv, z);
-            asm volatile("" : "+v"(tbig[u & 1]));
-        });
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto fold_pending = [&]() {
-        fold(std::integral_constant<int, MT * NT - 2>{});
-        fold(std::integral_constant<int, MT * NT - 1>{});
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto mult = [&](const bf16x4 (&a)[MT][2], const bf16x4 (&b)[NT][2], auto small_) {
-        constexpr bool SMALL = decltype(small_)::value && DUAL;
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int jj = 0; jj < NT; ++jj) {
-                const bf16x8 av = __builtin_shufflevector(a[i][0], a[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                const bf16x8 bv = __builtin_shufflevector(b[jj][0], b[jj][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                if constexpr (SMALL) acc2[i][jj] = mfma1(av, bv, acc2[i][jj]);
-                else acc[i][jj] = mfma1(av, bv, acc[i][jj]);
-            }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    using BIG = std::integral_constant<bool, false>;
-    using SML = std::integral_constant<bool, true>;
-
-    int c_slot = 0;
-    // One K-step.  On entry outstanding LDS reads, oldest first: P plane 0 (2 MT), Q plane 0 (2 NT); the other Q planes and
-    // the later P planes are requested one product ahead (lgkmcnt counts at most 15 reads).
-    auto step = [&](auto par_) {
-        constexpr int PAR = decltype(par_)::value;
-        constexpr int QA = (NP & 1) ? PAR : 0;
-        const unsigned cur = (unsigned)(c_slot * SLOT);
-        const int n_slot = (c_slot + 1 == NSLOT) ? 0 : c_slot + 1;
-        const unsigned nxt = (unsigned)(n_slot * SLOT);
-        const bool p_was_live = p_k < nk;
-        static_for<0, NP>([&](auto pb_) {
-            constexpr int pb = decltype(pb_)::value;
-            if constexpr (pb + 1 < NP) {
-                if constexpr (pb == 0 && 2 * MT + 4 * NT > 15) wait_lgkm<15 - 2 * NT>();    // never more than 15 reads in flight
-                req_b(fbh[pb], cur, std::integral_constant<int, pb + 1>{});
-                wait_lgkm<2 * NT>();
-            } else {
-                req_a(fa[QA ^ 1], cur, std::integral_constant<int, 1>{});
-                wait_lgkm<2 * MT>();
-            }
-            if constexpr (pb == 0) {
-                if constexpr (DUAL) mult_big(fa[QA], fb0[PAR]);
-                else mult(fa[QA], fb0[PAR], BIG{});
-            } else {
-                mult(fa[QA], fbh[pb - 1], SML{});
-                if constexpr (DUAL && pb == 1) fold_pending();
-            }
-            issue_chunk(std::integral_constant<int, pb>{});
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        static_for<1, NP - 1>([&](auto pa_) {
-            constexpr int pa = decltype(pa_)::value;
-            constexpr int g0 = pa * NP - pa * (pa - 1) / 2;
-            req_a(fa[(QA + pa + 1) & 1], cur, std::integral_constant<int, pa + 1>{});
-            wait_lgkm<2 * MT>();
-            static_for<0, NP - pa>([&](auto pb_) {
-                constexpr int pb = decltype(pb_)::value;
-                if constexpr (pb == 0) mult(fa[(QA + pa) & 1], fb0[PAR], SML{});
-                else mult(fa[(QA + pa) & 1], fbh[pb - 1], SML{});
-                issue_chunk(std::integral_constant<int, g0 + pb>{});
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        });
-        wait_lgkm<0>();
-        wait_vm(p_was_live ? (NSLOT - 3) * ppw + Q_BEFORE : 0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        req_a(fa[(QA + NP) & 1], nxt, std::integral_constant<int, 0>{});
-        req_b(fb0[PAR ^ 1], nxt, std::integral_constant<int, 0>{});
-        __builtin_amdgcn_sched_barrier(0);
-        mult(fa[(QA + NP - 1) & 1], fb0[PAR], SML{});
-        issue_chunk(std::integral_constant<int, NG - 1>{});
-        __builtin_amdgcn_sched_barrier(0);
-        advance();
-        c_slot = n_slot;
-    };
-
-    // ---- prologue
-#pragma unroll
-    for (int s_ = 0; s_ < NSLOT - 1; ++s_) {
-        if (p_k < nk) {
-#pragma unroll
-            for (int q = 0; q < MAXQ; ++q) issue_q(q);
-        }
-        advance();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    req_a(fa[0], 0u, std::integral_constant<int, 0>{});
-    req_b(fb0[0], 0u, std::integral_constant<int, 0>{});
-    for (int k = 0; k < nk; k += 2) {
-        step(std::integral_constant<int, 0>{});
-        step(std::integral_constant<int, 1>{});
-    }
-    wait_lgkm<0>();
-
-    // ---- epilogue: C[n][k] (or this split's slab)
-    float* out = p.splits > 1 ? p.slabs + (int64_t)split * p.N * p.K : static_cast<float*>(p.C);
-    const int64_t ldo = p.splits > 1 ? p.K : p.ldc;
-    const int l31 = lane & 31, h4 = 4 * (lane >> 5);
-    float os = 1.f;
-    if constexpr (F16) os = p.scaleA[0] * p.scaleB[0];           // see pgemm_nt_kernel
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int jj = 0; jj < NT; ++jj)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                int n, k;
-                if constexpr (SWAP) {     // D[p][q]: lane holds q = l31 (n), p = 8 b + h4 + r (k)
-                    k = tp * 256 + wm * (32 * MT) + 32 * i + 8 * b + h4;
-                    n = tq * BQ + wn * (32 * NT) + 32 * jj + l31;
-                } else {                  // D'[q][p]: lane holds p = l31 (n), q = 8 b + h4 + r (k)
-                    n = tp * 256 + wm * (32 * MT) + 32 * i + l31;
-                    k = tq * BQ + wn * (32 * NT) + 32 * jj + 8 * b + h4;
-                }
-                if (n >= p.N || k >= p.K) continue;                  // K % 4 == 0 (host)
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = acc[i][jj][4 * b + r];
-                    if constexpr (DUAL) v[r] += acc2[i][jj][4 * b + r];
-                    if constexpr (F16) v[r] *= os;
-                }
-                *reinterpret_cast<float4*>(out + (int64_t)n * ldo + k) = make_float4(v[0], v[1], v[2], v[3]);
-            }
 }
 
 // C[i] = sum_s slab[s][i] in split order (float4 per thread, eight independent loads per wait)
