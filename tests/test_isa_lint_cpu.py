@@ -1,0 +1,20 @@
+"""The hand-scheduled kernels issue their LDS fragment reads from inline asm and count the waits by hand; the compiler believes a
+destination register is defined as soon as the asm has been issued, so a copy or a spill it places between the read and the wait
+moves data that has not arrived (the intermittent faults of round 4).  tools/lint_kernels.sh compiles every
+such translation unit to ISA (no GPU needed) and tools/check_fragment_waits.py scans it for exactly that."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_no_kernel_reads_an_lds_destination_before_its_wait(tmp_path):
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc")
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "lint_kernels.sh")], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, TMPDIR=str(tmp_path)))
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("checked")]
+    assert len(lines) == 9 and all(ln.endswith("-> OK") for ln in lines), r.stdout[-3000:] + r.stderr[-1000:]
