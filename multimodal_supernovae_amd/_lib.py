@@ -206,7 +206,7 @@ def require_gpu():
 def check(rc, what=""):
     if rc != 0:
         msg = lib().msn_last_error().decode("utf-8", "replace")
-        if rc == 2 and torch.cuda.is_available() and (what.startswith("msn_sgemm") or what.startswith("msn_wgrad")):
+        if rc == 2 and torch.cuda.is_available() and what.startswith(("msn_sgemm", "msn_wgrad", "msn_conv2d")):
             # a GEMM launch failed: tiles finished inside a launch count their contributors in module memory and rely on the
             # counters being zero between launches -- put THIS stream's slice back to zero so that a caller that catches the
             # error and carries on does not inherit half-counted tiles (msn_reset_gemm_counters: only the failing stream's

@@ -1630,6 +1630,13 @@ extern "C" int msn_attention_bwd_planes(const float* qkv, int64_t ldqkv, const u
             return MSN_ERR_HIP;
         }
     }
+    if ((3 * e) % 32 != 0) {      // 3e % 32 == 16: the last column block of every row block is padding; the kernel stores real blocks only
+        const size_t blk = (size_t)planes * 1024;
+        if (hipMemset2DAsync(dst + (size_t)(cb - 1) * blk, (size_t)cb * blk, 0, blk, (size_t)cdiv(M, 32), st) != hipSuccess) {
+            set_error("msn_attention_bwd_planes: memset of the padding column block failed");
+            return MSN_ERR_HIP;
+        }
+    }
     if (int rc = mattn_backward_planes(m, planes, dst, cb, part, st)) return rc;
     if (colsum_out) return colsum_finish(part, B, 3 * e, colsum_out, st);
     return MSN_OK;

@@ -670,7 +670,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
                     unsigned char* blk = static_cast<unsigned char*>(p.C) + ((int64_t)rbk * p.cbC + (n0 >> 4)) * (NP * PBLK) + lane * 16;
 #pragma unroll
                     for (int q = 0; q < 2 * NP; ++q)
-                        if (n0 + 16 * (q / NP) < p.N) *reinterpret_cast<f32x4*>(blk + q * PBLK) = img[q];
+                        if (n0 + 16 * (q / NP) < 16 * p.cbC) *reinterpret_cast<f32x4*>(blk + q * PBLK) = img[q];   // incl. the zero padding block of N % 32 == 16
                 } else {
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {

@@ -600,6 +600,7 @@ class _PlaneVitTrunk(torch.autograd.Function):
         scale = 1.0 / math.sqrt(e // heads)
         x2 = _c(x).view(M, e)
         saved, planes = [], []
+        need_grad = any(ctx.needs_input_grad)
         # the planes of every block's four weight matrices from one launch (44 launches of 5-6 us in the headline tower)
         wp = ops.plane_split_list([P[12 * i + k] for i in range(n_blocks) for k in (2, 4, 8, 10)], NPL)
         for i in range(n_blocks):
@@ -613,14 +614,19 @@ class _PlaneVitTrunk(torch.autograd.Function):
             ap = ops.plane_split(a2, NPL)
             x1 = ops.pgemm_nt(ap, wop, bias=bo, epilogue=EPI_ADD, aux=x2)
             h2p, m2, r2 = ops.layernorm_fwd_planes(x1, g2, b2, eps, NPL)
-            fp, dact = ops.pgemm_nt(h2p, w1p, bias=c1, epilogue=EPI_GELU, aux=True, out_planes=True)
+            if need_grad:
+                fp, dact = ops.pgemm_nt(h2p, w1p, bias=c1, epilogue=EPI_GELU, aux=True, out_planes=True)
+            else:                                             # inference: no gelu' matrix, nothing kept
+                fp = ops.pgemm_nt(h2p, w1p, bias=c1, epilogue=EPI_GELU, out_planes=True)
             out = ops.pgemm_nt(fp, w2p, bias=c2, epilogue=EPI_ADD, aux=x1)
-            saved += [x2, m1, r1, qkv, a2, lse, x1, m2, r2, dact]
-            planes.append((h1p, ap, h2p, fp))
+            if need_grad:
+                saved += [x2, m1, r1, qkv, a2, lse, x1, m2, r2, dact]
+                planes.append((h1p, ap, h2p, fp))
             x2 = out
         ctx.dims = (B, T, e, heads, scale, n_blocks, NPL)
-        ctx.planes = planes                                   # plane matrices are not tensors: kept on the node
-        ctx.save_for_backward(*saved, *P)
+        if need_grad:
+            ctx.planes = planes                               # plane matrices are not tensors: kept on the node
+            ctx.save_for_backward(*saved, *P)
         return x2.view(B, T, e)
 
     @staticmethod
@@ -639,6 +645,9 @@ class _PlaneVitTrunk(torch.autograd.Function):
         for i in range(n_blocks - 1, -1, -1):
             wqkvt, wot, w1t, w2t = wt[4 * i: 4 * i + 4]
             x2, m1, r1, qkv, a2, lse, x1, m2, r2, dact = acts[NS * i: NS * i + NS]
+            if ctx.planes[i] is None:
+                raise RuntimeError("_PlaneVitTrunk: backward through this node a second time (retain_graph=True) is not supported: "
+                                   "the bf16 plane operands of a block are released as soon as its gradients exist")
             h1p, ap, h2p, fp = ctx.planes[i]
             g1, b1, wqkv, bqkv, wo, bo, g2, b2, w1, c1, w2, c2 = P[12 * i: 12 * i + 12]
             # input gradients dX = dY . W are NT products against the planes of the transposed weight; every bias gradient (a

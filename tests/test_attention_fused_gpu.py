@@ -49,7 +49,7 @@ def _bwd(qkv, dout, mu8, heads, scale, fused):
 @pytest.mark.parametrize("T", [5, 16, 17, 64, 65, 100, 113, 128])
 @pytest.mark.parametrize("hd,heads", [(64, 6), (32, 2), (16, 3), (48, 1), (24, 2)])
 @pytest.mark.parametrize("masked", [False, True])
-def test_one_pass_equals_two_kernels(T, hd, heads, masked):
+def test_one_pass_equals_two_kernels_self_comparison(T, hd, heads, masked):
     qkv, dout, mu8 = _inputs(3, T, heads, hd, 77 * T + hd, masked)
     scale = 1.0 / math.sqrt(hd)
     _, _, two = _bwd(qkv, dout, mu8, heads, scale, fused=False)
@@ -76,7 +76,8 @@ def test_narrow_heads_on_the_matrix_cores():
 
 
 @pytest.mark.parametrize("planes", [3, 2])
-@pytest.mark.parametrize("B,T,hd,heads", [(8, 65, 64, 6), (3, 65, 64, 6), (5, 17, 16, 2), (2, 128, 32, 3), (16, 64, 48, 2)])
+@pytest.mark.parametrize("B,T,hd,heads", [(8, 65, 64, 6), (3, 65, 64, 6), (5, 17, 16, 2), (2, 128, 32, 3), (16, 64, 48, 2),
+                                          (3, 33, 16, 3), (4, 65, 48, 1)])   # the last two: 3 E % 32 == 16 (a padding column block)
 @pytest.mark.parametrize("masked", [False, True])
 def test_plane_output_equals_split_of_fp32_gradient(planes, B, T, hd, heads, masked):
     """dqkv as planes == msn_plane_split of the fp32 dqkv, byte for byte (incl. the zero rows behind a matrix whose row

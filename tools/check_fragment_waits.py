@@ -26,22 +26,30 @@ def main():
     path = sys.argv[1]
     flt = sys.argv[2] if len(sys.argv) > 2 else ""
     name, pending, bad, total_bad = None, [], [], 0      # pending: list of (set of dest registers | None, line number)
+
+    def close():
+        nonlocal name, total_bad
+        if name is not None and bad and flt in name:
+            print(f"{name}: {len(bad)} read(s) of a pending LDS destination")
+            for b in bad[:6]:
+                print("   ", b)
+            total_bad += len(bad)
+        name = None
+
     for ln, line in enumerate(open(path), 1):
         t = line.strip()
         if t.startswith("_Z") and ":" in t and "kernel" in t.split(":")[0]:
+            close()
             name, pending, bad = t.split(":")[0], [], []
             continue
-        if name is None or not t or t.startswith((";", ".", "//")):
-            if t.startswith(".end_amdhsa_kernel") or t.startswith("s_endpgm"):
-                pass
+        # a kernel's code ends at its function-end label (code laid out behind an early-exit s_endpgm still belongs to it)
+        if t.startswith((".Lfunc_end", ".end_amdhsa_kernel")):
+            close()
             continue
-        if t.startswith("s_endpgm"):
-            if bad and flt in name:
-                print(f"{name}: {len(bad)} read(s) of a pending LDS destination")
-                for b in bad[:6]:
-                    print("   ", b)
-                total_bad += len(bad)
-            name = None
+        if name is None or not t or t.startswith((";", ".", "//")):
+            continue
+        if t.startswith("s_endpgm"):               # like an unconditional branch: what follows is reached from elsewhere
+            pending = []
             continue
         op = t.split()[0]
         body = t[len(op):].split(";")[0]
@@ -73,6 +81,7 @@ def main():
             if dst and dst & used:
                 bad.append(f"line {ln}: {t}   (LDS read issued at line {l0} not waited for)")
                 break
+    close()
     print("checked", path, "->", "OK" if total_bad == 0 else f"{total_bad} offending instruction(s)")
     return 1 if total_bad else 0
 

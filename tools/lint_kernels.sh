@@ -1,14 +1,24 @@
 #!/bin/bash
 # ISA lint of every translation unit with hand-counted LDS waits: hipcc -S (device only, in parallel) + tools/check_fragment_waits.py.
 # No GPU needed; about 3 minutes on 8 cores.   bash tools/lint_kernels.sh
+set -o pipefail
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${TMPDIR:-/tmp}/msn_lint
 mkdir -p "$OUT"
-FILES="gemm gemm_list gemm_pw gemm_bf16 gemm_bf16res attention_bf16 pgemm pgemm_alt1 pgemm_alt2"
+FILES="gemm gemm_list gemm_pw gemm_bf16 gemm_bf16res attention_bf16 attention_planes pgemm pgemm_alt1 pgemm_alt2"
+pids=()
 for f in $FILES; do
-  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -S --cuda-device-only "$ROOT/multimodal_supernovae_amd/csrc/$f.hip" -o "$OUT/$f.s" 2> "$OUT/$f.err" ) &
+  rm -f "$OUT/$f.s" "$OUT/$f.err" "$OUT/$f.rc"          # never lint a stale listing
+  [ -f "$ROOT/multimodal_supernovae_amd/csrc/$f.hip" ] || continue
+  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -S --cuda-device-only "$ROOT/multimodal_supernovae_amd/csrc/$f.hip" -o "$OUT/$f.s" 2> "$OUT/$f.err"; echo $? > "$OUT/$f.rc" ) &
 done
 wait
 rc=0
-for f in $FILES; do python3 "$ROOT/tools/check_fragment_waits.py" "$OUT/$f.s" | tail -n 8 || rc=1; done
+for f in $FILES; do
+  [ -f "$ROOT/multimodal_supernovae_amd/csrc/$f.hip" ] || continue
+  if [ "$(cat "$OUT/$f.rc" 2>/dev/null)" != "0" ] || [ ! -s "$OUT/$f.s" ]; then
+    echo "hipcc -S failed for $f.hip:"; tail -n 20 "$OUT/$f.err"; rc=1; continue
+  fi
+  python3 "$ROOT/tools/check_fragment_waits.py" "$OUT/$f.s" | tail -n 8 || rc=1
+done
 exit $rc

@@ -1,5 +1,6 @@
+import os
 import sys, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from multimodal_supernovae_amd import ops
 g = torch.Generator(device="cuda").manual_seed(0)
 M, N = 2080, 384

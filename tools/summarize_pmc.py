@@ -59,10 +59,18 @@ def main():
     print("\n".join(lines[:12]))
     import datetime
     import subprocess
+    # the commit the measured binary was built from: `git -C <repo>` where the checkout has its history, else the stamp
+    # tools/gpu.sh writes into the snapshot before it travels (a gpurun box has no .git)
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    commit = ""
     try:
-        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "unknown"
+        commit = subprocess.run(["git", "-C", repo, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     except OSError:
-        commit = "unknown"
+        pass
+    if not commit and os.path.exists(os.path.join(repo, ".msn_commit")):
+        commit = open(os.path.join(repo, ".msn_commit")).read().strip()
+    commit = commit or "unknown"
     extra = " ".join(sys.argv[3:])
     args = sys.argv[3:]
     rows = int(args[args.index("--per-gpu-batch") + 1]) if "--per-gpu-batch" in args else 1024
