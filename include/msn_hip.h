@@ -444,6 +444,17 @@ int msn_set_attention_path(int mode);
  * recomputation (up to 4 full tiles -- the ViT towers -- the default computes every score tile ONCE for dQ, dK and dV: the dQ
  * parts of the four key-tile waves meet in LDS; 80 instead of 112 MFMAs per tile pair).  Process-wide; measurements and tests. */
 int msn_set_attention_fused(int on);
+/* Sequences of more than 128 tokens with heads up to 16 wide (the reference's spectrum transformer on 1024-bin spectra /
+ * 220-step series: emb 32, 2 heads -- src/transformer_utils.py:36-89): fp32-GRADE attention on the bf16 matrix cores
+ * (csrc/attention_planes.hip).  Q, K, V, dO are split into three bf16 planes as they are staged into LDS (exact: three 8-bit
+ * pieces of the fp32 significand), probabilities and score gradients are split in registers, and every product is the six
+ * plane products of the plane GEMMs (v_mfma_f32_16x16x32_bf16; the head-dimension products pack two planes into one
+ * instruction's 32 k).  Same arguments, statistics layout and results (to fp32 rounding) as the exact-fp32 matrix-core
+ * kernels it replaces; the accuracy gate is tests/test_attention_planes_gpu.py (error against fp64 <= 1.5 x theirs).
+ * mode 1 (default) = on, two query tiles per wave in the forward; 3 = on, one tile per wave; 0 = off (the
+ * v_mfma_f32_16x16x4_f32 kernels).  Heads narrower than 16 take this path only under msn_set_attention_path(2).
+ * Process-wide, not thread-safe (as every msn_set_* switch). */
+int msn_set_attention_planes(int mode);
 
 /* ------------------------------------------------------------------------------------------
  * ConvMixer image tower pieces -- src/models_multimodal.py:38-95, channels-last token matrices

@@ -147,6 +147,7 @@ SIGNATURES = {
     "msn_radam_step_dev": (c_int, [c_ptr, c_int, c_i64, c_ptr, c_ptr, c_ptr]),
     "msn_set_attention_path": (c_int, [c_int]),
     "msn_set_attention_fused": (c_int, [c_int]),
+    "msn_set_attention_planes": (c_int, [c_int]),
     "msn_set_layernorm_block_planes": (c_int, [c_int]),
     "msn_attention_bwd_planes_workspace_bytes": (c_size, [c_int, c_int, c_int]),
     "msn_attention_bwd_planes": (c_int, [c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_int, c_f32, c_ptr, c_i64, c_ptr, c_ptr, c_i64,

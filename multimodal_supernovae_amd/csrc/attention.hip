@@ -20,6 +20,7 @@
 #include <math.h>
 
 #include "msn_common.h"
+#include "attention_args.h"
 
 namespace msn {
 
@@ -434,21 +435,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
 }
 
 // matrix-core path (attention_mfma.hip)
-struct MAttn {
-    const float* q; const float* k; const float* v; const float* o; const float* dout;
-    float* out; float* dq; float* dk; float* dv;
-    const uint8_t* mask;
-    float* lse;
-    float* delta;
-    int64_t ldq, ldk, ldv, ldo, ldd, lddq, lddk, lddv;
-    int64_t q_bs, k_bs, v_bs, o_bs, d_bs, dq_bs, dk_bs, dv_bs;
-    int B, H, Tq, Tk, hd;
-    float scale;
-    int tail;
-};
-bool mattn_applicable(const MAttn& a);
-int mattn_forward(const MAttn& a, hipStream_t st);
-int mattn_backward(const MAttn& a, hipStream_t st);
+// (MAttn and the mattn_* / pattn_* entry points: attention_args.h)
 static int g_attn_path = 0;  // 0 = automatic (matrix cores for head widths >= 16: narrower heads measured no faster
                              // there, tools/bench_attention.py), 1 = always the vector-ALU kernels, 2 = matrix cores
                              // whenever applicable

@@ -22,24 +22,14 @@
 #include <math.h>
 
 #include "msn_common.h"
+#include "attention_args.h"
 
 namespace msn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr float kFill = -1e7f;  // ref transformer_utils.py:77
 
-struct MAttn {
-    const float* q; const float* k; const float* v; const float* o; const float* dout;
-    float* out; float* dq; float* dk; float* dv;
-    const uint8_t* mask;      // [B][Tk] or null
-    float* lse;               // [B][H][Tq][2] = (row max, log sum)
-    float* delta;             // [B][H][Tq]
-    int64_t ldq, ldk, ldv, ldo, ldd, lddq, lddk, lddv;
-    int64_t q_bs, k_bs, v_bs, o_bs, d_bs, dq_bs, dk_bs, dv_bs;
-    int B, H, Tq, Tk, hd;
-    float scale;
-    int tail;                 // set by mattn_forward / mattn_backward: ragged last token on the vector ALU (see below)
-};
+// (struct MAttn: attention_args.h)
 
 // (batch, head) of workgroup blockIdx.x.  Workgroups go to the 8 XCDs round-robin; when B % 8 == 0 the ids are re-read so
 // that the H heads of a sample are consecutive workgroups of ONE XCD and share the 128-byte lines of its q|k|v rows in
@@ -53,20 +43,7 @@ __device__ __forceinline__ void locate_head(const MAttn& p, int& b, int& hh) {
     }
 }
 
-// Long kernels: workgroup id -> (sample, head, row block).  The H * NB workgroups of a sample read the same 128-byte
-// lines of its q|k|v rows (every head a slice of the line, every row block the whole K / V): with B % 8 == 0 they are
-// made consecutive workgroups of ONE XCD (ids go to the XCDs round-robin), so the lines come from HBM once, not H * NB times.
-__device__ __forceinline__ void locate_block(const MAttn& p, int NB, int& b, int& hh, int& blk) {
-    const unsigned per = (unsigned)(p.H * NB);
-    unsigned id = blockIdx.x;
-    if ((p.B & 7) == 0) {
-        const unsigned xcd = id & 7, j = id >> 3;
-        id = ((j / per) * 8 + xcd) * per + j % per;
-    }
-    blk = (int)(id % NB);
-    const unsigned bh = id / NB;
-    b = (int)(bh / p.H), hh = (int)(bh % p.H);
-}
+// (long kernels: workgroup id -> (sample, head, row block) by locate_block, attention_args.h)
 
 // ---- prologue reads in two halves: REQUEST everything, then COMMIT ----------------------------------------------------
 // Written the obvious way (image 1: load, store to LDS; image 2: load, store; mask; fragments, each scaled on arrival) hipcc
@@ -1470,9 +1447,14 @@ static bool is_long(const MAttn& a) { return a.Tq > 128 || a.Tk > 128; }
 static int chunk_rows(int hd) { return padded_hd(hd) <= 16 ? 256 : 128; }
 static unsigned long_block(int T) { return 64u * (unsigned)std::min(8, (T + 15) / 16); }
 
+bool pattn_forward_aligned(const MAttn& a);
+bool pattn_backward_aligned(const MAttn& a);
+
 int mattn_forward(const MAttn& a0, hipStream_t st) {
     MAttn a = a0;
     a.tail = use_tail(a) ? 1 : 0;
+    // long sequences of narrow heads: fp32-grade products on the bf16 matrix cores (attention_planes.hip)
+    if (is_long(a) && pattn_applicable(a) && pattn_forward_aligned(a)) return pattn_forward(a, st);
     if (is_long(a)) {
         const int CH = chunk_rows(a.hd), NB = (a.Tq + 127) / 128;
         const size_t lds = sizeof(float) * 2 * (size_t)CH * (padded_hd(a.hd) + 4) + (size_t)CH;
@@ -1555,6 +1537,7 @@ int mattn_backward(const MAttn& a0, hipStream_t st) {
         return MSN_ERR_SHAPE;
     }
     if (g_attn_fused && mattn_fused_applicable(a)) return launch_fused<0>(a, FusedOut{nullptr, nullptr, 0}, st);
+    if (is_long(a) && pattn_applicable(a) && pattn_backward_aligned(a)) return pattn_backward(a, st);
     if (is_long(a)) {
         const int CH = chunk_rows(a.hd);
         {

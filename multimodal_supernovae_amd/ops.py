@@ -1016,6 +1016,12 @@ def set_attention_fused(on):
     check(lib().msn_set_attention_fused(int(on)), "msn_set_attention_fused")
 
 
+def set_attention_planes(mode):
+    """1 (default): long sequences of heads up to 16 wide run fp32-grade on the bf16 matrix cores (csrc/attention_planes.hip);
+    3: the same with one query tile per wave in the forward; 0: the exact-fp32 matrix-core kernels."""
+    check(lib().msn_set_attention_planes(int(mode)), "msn_set_attention_planes")
+
+
 class _SplitItem(ctypes.Structure):
     _fields_ = [("x", ctypes.c_void_p), ("ldx", ctypes.c_int64), ("R", ctypes.c_int64), ("C", ctypes.c_int64),
                 ("transposed", ctypes.c_int), ("out", ctypes.c_void_p)]
