@@ -19,8 +19,9 @@
 //                            O^T[d][query] += V^T . P^T (A = V^T through ds_read_b64_tr_b16, B = P^T from the accumulators)
 //       dK,dV kernel:        S[query][key] = Q . K^T   -> lane (c, g) holds queries 4 g + r of key c;
 //                            dV^T[d][key] += dO^T . P, dK^T[d][key] += Q^T . dS
-//     p0 . v0 accumulates in one accumulator, the five small products in a second one (the bf16 MFMA adds into its
-//     accumulator with a truncating rounding: pgemm_kernels.h), added once at the end.
+//     p0 . v0 of every 32-token block is formed in a zero accumulator and added to the running sum by the vector ALU, the five
+//     small products accumulate in a second accumulator (the bf16 MFMA adds into its accumulator with a truncating
+//     rounding: pgemm_kernels.h), added once at the end.
 //
 // LDS images: a 32-row block of a [rows][16] operand is three 1-KB plane images [32 rows][16 bf16] -- row reads
 // (ds_read_b128: lane (c, g) takes row c, half g & 1 of plane g >> 1) and transposed reads (ds_read_b64_tr_b16: four rows x 16
@@ -28,8 +29,9 @@
 // staged (global fp32 -> registers -> three 8-byte LDS stores per 4 columns).
 // Masked keys score -1e7 (ref :77) through ONE v_min per score against a per-key cap (+inf live, -1e7 masked, -inf beyond the
 // sequence); the gradient of a masked score is zero (masked_fill), a 0 / 1 factor per key.
-// Row statistics (max, log-sum) have the layout of attention_mfma.hip; exponentials are exp2(fma(s, log2 e, -m log2 e)), the
-// backward subtracts log2 of the row sum in a second step so that a query's common factor cancels exactly as in the forward.
+// Row statistics (max, log-sum) have the layout AND the values of attention_mfma.hip (either family's backward may follow either
+// forward): exponentials are exp2((s - m) log2 e) -- the difference first, so that a row of equal scores (every key masked at
+// -1e7) gives exactly 1 -- and exp2(fma(s - m, log2 e, -log2 l)) in the backward.
 #include <algorithm>
 #include <math.h>
 
@@ -80,17 +82,16 @@ __device__ __forceinline__ Planes8 split8(const float (&v)[8]) {
     }
     return o;
 }
-// v_min_f32 as it stands (fminf also canonicalises both operands: two more instructions per score)
-__device__ __forceinline__ float vmin(float a, float b) {
-    float r;
-    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
+// min(a, b) as ONE instruction: the median of (a, b, -inf).  (fminf also canonicalises both operands -- two more instructions
+// per score; an inline-asm v_min_f32 is not an option: hipcc pads no MFMA -> VALU wait states in front of an asm statement,
+// and it read the score accumulators before the matrix core had written them.)
+__device__ __forceinline__ float vmin(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -INFINITY); }
 __device__ __forceinline__ bf16x8 as_frag(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
 __device__ __forceinline__ f32x4 mma(const bf16x8& a, const bf16x8& b, const f32x4& c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
-// reductions over the four lane groups (lanes c, c + 16, c + 32, c + 48): two register swaps, no LDS
+// reductions over the four lane groups (lanes c, c + 16, c + 32, c + 48)
+#ifdef MSN_PATTN_SWAP_REDUCE      // two register swaps, no LDS traffic
 __device__ __forceinline__ float group_max(float v) {
     u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
@@ -107,6 +108,17 @@ __device__ __forceinline__ float pair_sum16(float v) {     // v(group g) + v(gro
     const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+#else
+__device__ __forceinline__ float group_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+__device__ __forceinline__ float pair_sum16(float v) { return v + __shfl_xor(v, 16, 64); }
+#endif
 
 // ---- the three "head-dimension" fragments of one 16-row tile held in registers (the B operand of S / dP): row = lane & 15,
 // columns 8 (g & 1) .. + 7 of planes chosen by g >> 1:  f01 = [x0 | x1], f10 = [x1 | x0], f20 = [x2 | x0]
@@ -138,7 +150,8 @@ __device__ __forceinline__ HeadFrags head_frags(const float (&v)[8], int g) {
 // rows [0, nt) of two matrices (row stride ld0 / ld1, columns col0 .. col0 + hd - 1) -> the plane images img0 / img1 of a chunk
 // (blocks of 32 rows); rows beyond nt up to the next multiple of 32 and columns beyond hd are zeros.  All threads take part.
 __device__ __forceinline__ void stage_pair(unsigned char* img0, unsigned char* img1, const float* __restrict__ s0,
-                                           const float* __restrict__ s1, int64_t ld0, int64_t ld1, int col0, int nt, int hd) {
+                                           const float* __restrict__ s1, int64_t ld0, int64_t ld1, int col0, int nt, int hd,
+                                           float mul0 = 1.f) {
     const int total = ((nt + 31) & ~31) * 4;              // 16-byte pieces (4 columns) per image
     for (int base = threadIdx.x; base < total; base += UMAX * (int)blockDim.x) {
         float4 a[UMAX], b[UMAX];
@@ -158,6 +171,7 @@ __device__ __forceinline__ void stage_pair(unsigned char* img0, unsigned char* i
                 const bool ok = r < nt && 4 * q < hd;
                 float4 x = a[u], y = b[u];
                 if (!ok) x = y = make_float4(0.f, 0.f, 0.f, 0.f);
+                x.x *= mul0, x.y *= mul0, x.z *= mul0, x.w *= mul0;
                 const int off = (r >> 5) * BLK + (r & 31) * 32 + q * 8;
                 const Pair3 xa = split2(x.x, x.y), xb = split2(x.z, x.w), ya = split2(y.x, y.y), yb = split2(y.z, y.w);
                 *reinterpret_cast<u32x2*>(img0 + off) = u32x2{xa.p0, xb.p0};
@@ -195,7 +209,10 @@ __device__ __forceinline__ f32x4 head_product(const bf16x8& a01, const bf16x8& a
 // acc (+)= X^T . W over 32 tokens: xt[pl] = transposed fragments of X's planes, w = W's planes from the accumulators
 __device__ __forceinline__ void token_product(const bf16x8 (&xt)[3], const Planes8& w, f32x4& big, f32x4& small) {
     const bf16x8 w0 = as_frag(w.p0), w1 = as_frag(w.p1), w2 = as_frag(w.p2);
-    big = mma(xt[0], w0, big);
+    // x0 . w0 into a ZERO accumulator, folded in by the vector ALU (round to nearest): the bf16 MFMA truncates when it adds
+    // into its accumulator, and a running sum over 1024 tokens (32 chained instructions) collected that as a bias -- dV of a
+    // peaked softmax came out at 1.5 - 1.6 x the exact-fp32 kernels' maximum error; the small products' sum is 2^-8 of it
+    big += mma(xt[0], w0, f32x4{0.f, 0.f, 0.f, 0.f});
     small = mma(xt[2], w0, small);
     small = mma(xt[0], w2, small);
     small = mma(xt[1], w1, small);
@@ -285,11 +302,10 @@ __global__ __launch_bounds__(512, 2) void pattn_fwd_kernel(const MAttn p) {
                     ob[u] *= alpha;
                     os[u] *= alpha;
                 }
-                const float mL = m[u] * kLog2e;
                 float e[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    e[j] = __builtin_amdgcn_exp2f(fmaf(s[j], kLog2e, -mL));
+                for (int j = 0; j < 8; ++j) {                 // (s - m first: exact where it matters -- a row of equal scores,
+                    e[j] = __builtin_amdgcn_exp2f((s[j] - m[u]) * kLog2e);      //  e.g. all keys masked at -1e7, must give e = 1)
                     l[u] += e[j];
                 }
                 const Planes8 pp = split8(e);
@@ -343,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void pattn_bwd_dq_kernel(const MAttn p) {
     for (int j = 0; j < 8; ++j) delta = fmaf(dv8[j], ov[j], delta);
     delta = pair_sum16(delta);                            // the two column halves (groups g, g ^ 1)
     if (g == 0 && q_ok) p.delta[stat] = delta;
-    const float mL = q_ok ? lm * kLog2e : INFINITY;       // a query beyond the sequence: p = exp2(-inf) = 0
+    const float mq = q_ok ? lm : INFINITY;                // a query beyond the sequence: p = exp2(-inf) = 0
     const float ll2 = ll * kLog2e;
     f32x4 qb = {0.f, 0.f, 0.f, 0.f}, qs = {0.f, 0.f, 0.f, 0.f};
     for (int k0 = 0; k0 < p.Tk; k0 += CH) {
@@ -367,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void pattn_bwd_dq_kernel(const MAttn p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float s = vmin(st[r], cap[r]);                  // masked / padded key: -inf -> e = 0 -> ds = 0
-                    const float e = __builtin_amdgcn_exp2f(fmaf(s, kLog2e, -mL) - ll2);
+                    const float e = __builtin_amdgcn_exp2f(fmaf(s - mq, kLog2e, -ll2));
                     ds[4 * t + r] = e * (dp[r] - delta);
                 }
             }
@@ -402,7 +418,10 @@ __global__ __launch_bounds__(512, 2) void pattn_bwd_dkv_kernel(const MAttn p) {
     const float* qsrc = p.q + (int64_t)b * p.q_bs;
     const float* dsrc = p.dout + (int64_t)b * p.d_bs;
     float kv[8], vv[8];
-    load_row8(kv, p.k + (int64_t)b * p.k_bs, p.ldk, col0, krow, p.Tk, g, p.hd, p.scale);
+    // (the softmax scale multiplies Q here too, as in the forward and the dQ kernel: the recomputed scores are then the
+    //  forward's scores bit for bit -- with the scale on K, as the exact-fp32 kernels place it, s - m of a row's largest score
+    //  is a rounding difference instead of zero and a peaked softmax shows it in dV)
+    load_row8(kv, p.k + (int64_t)b * p.k_bs, p.ldk, col0, krow, p.Tk, g, p.hd, 1.f);
     load_row8(vv, p.v + (int64_t)b * p.v_bs, p.ldv, col0, krow, p.Tk, g, p.hd, 1.f);
     uint8_t mk = 1;
     if (p.mask) mk = p.mask[(int64_t)b * p.Tk + (in_seq ? krow : 0)];
@@ -414,10 +433,10 @@ __global__ __launch_bounds__(512, 2) void pattn_bwd_dkv_kernel(const MAttn p) {
     for (int i0 = 0; i0 < p.Tq; i0 += CH) {
         const int nt = min(CH, p.Tq - i0), nblk = (nt + 31) >> 5;
         __syncthreads();
-        stage_pair(Qi, Di, qsrc + (int64_t)i0 * p.ldq, dsrc + (int64_t)i0 * p.ldd, p.ldq, p.ldd, col0, nt, p.hd);
+        stage_pair(Qi, Di, qsrc + (int64_t)i0 * p.ldq, dsrc + (int64_t)i0 * p.ldd, p.ldq, p.ldd, col0, nt, p.hd, p.scale);
         for (int j = threadIdx.x; j < ((nt + 31) & ~31); j += blockDim.x) {
             const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + i0 + (j < nt ? j : 0);
-            Ml[j] = j < nt ? p.lse[2 * stat] * kLog2e : INFINITY;     // +inf: a padded query row gets p = exp2(-inf) = 0
+            Ml[j] = j < nt ? p.lse[2 * stat] : INFINITY;              // +inf: a padded query row gets p = exp2(-inf) = 0
             Ll[j] = j < nt ? p.lse[2 * stat + 1] * kLog2e : 0.f;
             Dl[j] = j < nt ? p.delta[stat] : 0.f;
         }
@@ -439,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void pattn_bwd_dkv_kernel(const MAttn p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float s = vmin(st[r], cap);
-                    const float e = __builtin_amdgcn_exp2f(fmaf(s, kLog2e, -ml[r]) - l2[r]);
+                    const float e = __builtin_amdgcn_exp2f(fmaf(s - ml[r], kLog2e, -l2[r]));
                     pr[4 * t + r] = e;
                     ds[4 * t + r] = e * (dp[r] - dl[r]);           // (x 0 for a masked key: once, on the finished column)
                 }
@@ -456,7 +475,7 @@ __global__ __launch_bounds__(512, 2) void pattn_bwd_dkv_kernel(const MAttn p) {
         }
     }
     if (in_seq && 4 * g < p.hd) {
-        const f32x4 dk = (kb_ + ks) * (p.scale * liv), dv = vb + vs;     // liv: the gradient of a masked key's scores is zero
+        const f32x4 dk = (kb_ + ks) * liv, dv = vb + vs;     // (Q carried the scale) liv: the gradient of a masked key's scores is zero
         *reinterpret_cast<f32x4*>(p.dk + (int64_t)b * p.dk_bs + (int64_t)krow * p.lddk + col0 + 4 * g) = dk;
         *reinterpret_cast<f32x4*>(p.dv + (int64_t)b * p.dv_bs + (int64_t)krow * p.lddv + col0 + 4 * g) = dv;
     }
