@@ -147,43 +147,54 @@ __device__ __forceinline__ HeadFrags head_frags(const float (&v)[8], int g) {
 }
 
 // ---- LDS images ------------------------------------------------------------------------------------------------------------
-// rows [0, nt) of two matrices (row stride ld0 / ld1, columns col0 .. col0 + hd - 1) -> the plane images img0 / img1 of a chunk
-// (blocks of 32 rows); rows beyond nt up to the next multiple of 32 and columns beyond hd are zeros.  All threads take part.
-__device__ __forceinline__ void stage_pair(unsigned char* img0, unsigned char* img1, const float* __restrict__ s0,
-                                           const float* __restrict__ s1, int64_t ld0, int64_t ld1, int col0, int nt, int hd,
-                                           float mul0 = 1.f) {
-    const int total = ((nt + 31) & ~31) * 4;              // 16-byte pieces (4 columns) per image
-    for (int base = threadIdx.x; base < total; base += UMAX * (int)blockDim.x) {
-        float4 a[UMAX], b[UMAX];
+// A chunk's rows of two matrices on their way into LDS: rows [0, nt) (row stride ld0 / ld1, columns col0 .. col0 + hd - 1) ->
+// the plane images img0 / img1 (blocks of 32 rows; rows beyond nt up to the next multiple of 32 and columns beyond hd are
+// zeros).  load() REQUESTS the first UMAX 16-byte pieces per thread and image into registers -- issued right after the barrier
+// that publishes the previous chunk, so they are in flight while that chunk is multiplied -- commit() splits them into planes
+// and writes them (what a small workgroup could not request up front goes through the loop at the end).
+struct StagePair {
+    float4 a[UMAX], b[UMAX];
+    const float* s0; const float* s1;
+    int64_t ld0, ld1;
+    int col0, nt, hd;
+    __device__ __forceinline__ void fetch(float4& x, float4& y, int idx) const {
+        const int total = ((nt + 31) & ~31) * 4;
+        const int r = idx >> 2, cq = 4 * (idx & 3);
+        const bool ok = idx < total && r < nt && cq < hd;
+        x = *reinterpret_cast<const float4*>(s0 + (int64_t)(ok ? r : 0) * ld0 + col0 + (ok ? cq : 0));
+        y = *reinterpret_cast<const float4*>(s1 + (int64_t)(ok ? r : 0) * ld1 + col0 + (ok ? cq : 0));
+    }
+    __device__ __forceinline__ void put(unsigned char* img0, unsigned char* img1, float4 x, float4 y, int idx, float mul0) const {
+        const int total = ((nt + 31) & ~31) * 4;
+        if (idx >= total) return;
+        const int r = idx >> 2, q = idx & 3;
+        if (r >= nt || 4 * q >= hd) x = y = make_float4(0.f, 0.f, 0.f, 0.f);
+        x.x *= mul0, x.y *= mul0, x.z *= mul0, x.w *= mul0;
+        const int off = (r >> 5) * BLK + (r & 31) * 32 + q * 8;
+        const Pair3 xa = split2(x.x, x.y), xb = split2(x.z, x.w), ya = split2(y.x, y.y), yb = split2(y.z, y.w);
+        *reinterpret_cast<u32x2*>(img0 + off) = u32x2{xa.p0, xb.p0};
+        *reinterpret_cast<u32x2*>(img0 + off + PB) = u32x2{xa.p1, xb.p1};
+        *reinterpret_cast<u32x2*>(img0 + off + 2 * PB) = u32x2{xa.p2, xb.p2};
+        *reinterpret_cast<u32x2*>(img1 + off) = u32x2{ya.p0, yb.p0};
+        *reinterpret_cast<u32x2*>(img1 + off + PB) = u32x2{ya.p1, yb.p1};
+        *reinterpret_cast<u32x2*>(img1 + off + 2 * PB) = u32x2{ya.p2, yb.p2};
+    }
+    __device__ __forceinline__ void load(const float* src0, const float* src1, int64_t l0, int64_t l1, int col, int rows, int width) {
+        s0 = src0, s1 = src1, ld0 = l0, ld1 = l1, col0 = col, nt = rows, hd = width;
 #pragma unroll
-        for (int u = 0; u < UMAX; ++u) {
-            const int idx = base + u * (int)blockDim.x;
-            const int r = idx >> 2, cq = 4 * (idx & 3);
-            const bool ok = idx < total && r < nt && cq < hd;
-            a[u] = *reinterpret_cast<const float4*>(s0 + (int64_t)(ok ? r : 0) * ld0 + col0 + (ok ? cq : 0));
-            b[u] = *reinterpret_cast<const float4*>(s1 + (int64_t)(ok ? r : 0) * ld1 + col0 + (ok ? cq : 0));
-        }
+        for (int u = 0; u < UMAX; ++u) fetch(a[u], b[u], (int)threadIdx.x + u * (int)blockDim.x);
+    }
+    __device__ __forceinline__ void commit(unsigned char* img0, unsigned char* img1, float mul0 = 1.f) {
 #pragma unroll
-        for (int u = 0; u < UMAX; ++u) {
-            const int idx = base + u * (int)blockDim.x;
-            if (idx < total) {
-                const int r = idx >> 2, q = idx & 3;
-                const bool ok = r < nt && 4 * q < hd;
-                float4 x = a[u], y = b[u];
-                if (!ok) x = y = make_float4(0.f, 0.f, 0.f, 0.f);
-                x.x *= mul0, x.y *= mul0, x.z *= mul0, x.w *= mul0;
-                const int off = (r >> 5) * BLK + (r & 31) * 32 + q * 8;
-                const Pair3 xa = split2(x.x, x.y), xb = split2(x.z, x.w), ya = split2(y.x, y.y), yb = split2(y.z, y.w);
-                *reinterpret_cast<u32x2*>(img0 + off) = u32x2{xa.p0, xb.p0};
-                *reinterpret_cast<u32x2*>(img0 + off + PB) = u32x2{xa.p1, xb.p1};
-                *reinterpret_cast<u32x2*>(img0 + off + 2 * PB) = u32x2{xa.p2, xb.p2};
-                *reinterpret_cast<u32x2*>(img1 + off) = u32x2{ya.p0, yb.p0};
-                *reinterpret_cast<u32x2*>(img1 + off + PB) = u32x2{ya.p1, yb.p1};
-                *reinterpret_cast<u32x2*>(img1 + off + 2 * PB) = u32x2{ya.p2, yb.p2};
-            }
+        for (int u = 0; u < UMAX; ++u) put(img0, img1, a[u], b[u], (int)threadIdx.x + u * (int)blockDim.x, mul0);
+        const int total = ((nt + 31) & ~31) * 4;
+        for (int idx = (int)threadIdx.x + UMAX * (int)blockDim.x; idx < total; idx += (int)blockDim.x) {   // small workgroups only
+            float4 x, y;
+            fetch(x, y, idx);
+            put(img0, img1, x, y, idx, mul0);
         }
     }
-}
+};
 // row fragments (A operand of S / dP) of the 16-row tile t of a block: a01 = [x0 | x1], a02 = [x0 | x2]
 __device__ __forceinline__ void row_frags(const unsigned char* blk, int t, int c, int g, bf16x8& a01, bf16x8& a02) {
     const unsigned char* p = blk + t * 512 + c * 32 + (g & 1) * 16;
@@ -233,8 +244,9 @@ __device__ __forceinline__ void stage_caps(float* cap, float fill, const uint8_t
 
 // ------------------------------------------------------------------------------------------ forward
 // Workgroup = (sample, head, block of 128 QT queries); wave w owns QT tiles of 16 queries; K / V stream through LDS in chunks.
-template <int QT>
-__global__ __launch_bounds__(512, 2) void pattn_fwd_kernel(const MAttn p) {
+// p.tail carries diagnostic bits (tools/bench_attention_planes.py --ablate): 1 = stage the first chunk only, 2 = no products.
+template <int QT, bool PF>
+__global__ __launch_bounds__(512, 4) void pattn_fwd_kernel(const MAttn p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* Ki = smem;
     unsigned char* Vi = smem + NBK * BLK;
@@ -247,6 +259,8 @@ __global__ __launch_bounds__(512, 2) void pattn_fwd_kernel(const MAttn p) {
     const int q0 = blk * 128 * QT + wave * 16 * QT;
     const float* ksrc = p.k + (int64_t)b * p.k_bs;
     const float* vsrc = p.v + (int64_t)b * p.v_bs;
+    StagePair sp;
+    if constexpr (PF) sp.load(ksrc, vsrc, p.ldk, p.ldv, col0, min(CH, p.Tk), p.hd);
     HeadFrags qf[QT];
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
@@ -264,35 +278,42 @@ __global__ __launch_bounds__(512, 2) void pattn_fwd_kernel(const MAttn p) {
     for (int k0 = 0; k0 < p.Tk; k0 += CH) {
         const int nt = min(CH, p.Tk - k0), nblk = (nt + 31) >> 5;
         __syncthreads();                                  // every wave is done with the previous chunk
-        stage_pair(Ki, Vi, ksrc + (int64_t)k0 * p.ldk, vsrc + (int64_t)k0 * p.ldv, p.ldk, p.ldv, col0, nt, p.hd);
+        if (!(p.tail & 1) || k0 == 0) {
+            if constexpr (!PF) sp.load(ksrc + (int64_t)k0 * p.ldk, vsrc + (int64_t)k0 * p.ldv, p.ldk, p.ldv, col0, nt, p.hd);
+            sp.commit(Ki, Vi);
+        }
         stage_caps(Cap, kFillP, p.mask, (int64_t)b * p.Tk + k0, nt);
         __syncthreads();
+        if (PF && k0 + CH < p.Tk && !(p.tail & 1))        // the next chunk's rows: in flight while this one is multiplied
+            sp.load(ksrc + (int64_t)(k0 + CH) * p.ldk, vsrc + (int64_t)(k0 + CH) * p.ldv, p.ldk, p.ldv, col0, min(CH, p.Tk - k0 - CH), p.hd);
+        if (p.tail & 2) continue;
         for (int kb = 0; kb < nblk; ++kb) {
             const unsigned char* kblk = Ki + kb * BLK;
             const unsigned char* vblk = Vi + kb * BLK;
-            bf16x8 a01[2], a02[2];
-            f32x4 cap[2];
+            float s[QT][8], mbs[QT];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                row_frags(kblk, t, c, g, a01[t], a02[t]);
-                cap[t] = *reinterpret_cast<const f32x4*>(Cap + kb * 32 + t * 16 + 4 * g);
+            for (int u = 0; u < QT; ++u) mbs[u] = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {                 // (fragments of one tile at a time: they serve every query tile of the wave)
+                bf16x8 a01, a02;
+                row_frags(kblk, t, c, g, a01, a02);
+                const f32x4 cap = *reinterpret_cast<const f32x4*>(Cap + kb * 32 + t * 16 + 4 * g);
+#pragma unroll
+                for (int u = 0; u < QT; ++u) {
+                    const f32x4 st = head_product(a01, a02, qf[u]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        s[u][4 * t + r] = vmin(st[r], cap[r]);
+                        mbs[u] = fmaxf(mbs[u], s[u][4 * t + r]);
+                    }
+                }
             }
             bf16x8 vt[3];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) vt[pl] = tr_frag(vblk, pl, c, g);
 #pragma unroll
             for (int u = 0; u < QT; ++u) {
-                float s[8];
-                float mb = -INFINITY;
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const f32x4 st = head_product(a01[t], a02[t], qf[u]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        s[4 * t + r] = vmin(st[r], cap[t][r]);
-                        mb = fmaxf(mb, s[4 * t + r]);
-                    }
-                }
+                float mb = mbs[u];
                 mb = group_max(mb);
                 if (__any(mb > m[u])) {                   // (wave-uniform; rare once the running maximum has settled)
                     const float mn = fmaxf(m[u], mb);     // finite: a block holds a key of the sequence, masked ones score -1e7
@@ -305,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void pattn_fwd_kernel(const MAttn p) {
                 float e[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {                 // (s - m first: exact where it matters -- a row of equal scores,
-                    e[j] = __builtin_amdgcn_exp2f((s[j] - m[u]) * kLog2e);      //  e.g. all keys masked at -1e7, must give e = 1)
+                    e[j] = __builtin_amdgcn_exp2f((s[u][j] - m[u]) * kLog2e);   //  e.g. all keys masked at -1e7, must give e = 1)
                     l[u] += e[j];
                 }
                 const Planes8 pp = split8(e);
@@ -333,107 +354,148 @@ __global__ __launch_bounds__(512, 2) void pattn_fwd_kernel(const MAttn p) {
 }
 
 // ------------------------------------------------------------------------------------------ backward: dQ (and delta)
-__global__ __launch_bounds__(512, 2) void pattn_bwd_dq_kernel(const MAttn p) {
+// NT tiles of 16 queries per wave (the K / V fragments of a block serve all of them)
+template <int NT, bool PF>
+__global__ __launch_bounds__(512, NT == 1 ? 4 : 2) void pattn_bwd_dq_kernel(const MAttn p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* Ki = smem;
     unsigned char* Vi = smem + NBK * BLK;
     float* Cap = reinterpret_cast<float*>(smem + 2 * NBK * BLK);
-    const int NB = (p.Tq + 127) / 128;
+    const int NB = (p.Tq + 128 * NT - 1) / (128 * NT);
     int b, hh, blk;
     locate_block(p, NB, b, hh, blk);
     const int col0 = hh * p.hd;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-    const int q0 = blk * 128 + wave * 16, qrow = q0 + c;
-    const bool q_ok = qrow < p.Tq;
+    const int q0 = blk * 128 * NT + wave * 16 * NT;
     const float* ksrc = p.k + (int64_t)b * p.k_bs;
     const float* vsrc = p.v + (int64_t)b * p.v_bs;
-    float qv[8], dv8[8], ov[8];
-    load_row8(qv, p.q + (int64_t)b * p.q_bs, p.ldq, col0, qrow, p.Tq, g, p.hd, p.scale);
-    load_row8(dv8, p.dout + (int64_t)b * p.d_bs, p.ldd, col0, qrow, p.Tq, g, p.hd, 1.f);
-    load_row8(ov, p.o + (int64_t)b * p.o_bs, p.ldo, col0, qrow, p.Tq, g, p.hd, 1.f);
-    const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + (q_ok ? qrow : 0);
-    const float lm = p.lse[2 * stat], ll = p.lse[2 * stat + 1];
-    const HeadFrags qf = head_frags(qv, g), df = head_frags(dv8, g);
-    float delta = 0.f;
+    StagePair sp;
+    if constexpr (PF) sp.load(ksrc, vsrc, p.ldk, p.ldv, col0, min(CH, p.Tk), p.hd);
+    HeadFrags qf[NT], df[NT];
+    float delta[NT], mq[NT], ll2[NT];
+    f32x4 qb[NT], qs[NT];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) delta = fmaf(dv8[j], ov[j], delta);
-    delta = pair_sum16(delta);                            // the two column halves (groups g, g ^ 1)
-    if (g == 0 && q_ok) p.delta[stat] = delta;
-    const float mq = q_ok ? lm : INFINITY;                // a query beyond the sequence: p = exp2(-inf) = 0
-    const float ll2 = ll * kLog2e;
-    f32x4 qb = {0.f, 0.f, 0.f, 0.f}, qs = {0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < NT; ++u) {
+        const int qrow = q0 + 16 * u + c;
+        const bool q_ok = qrow < p.Tq;
+        float qv[8], dv8[8], ov[8];
+        load_row8(qv, p.q + (int64_t)b * p.q_bs, p.ldq, col0, qrow, p.Tq, g, p.hd, p.scale);
+        load_row8(dv8, p.dout + (int64_t)b * p.d_bs, p.ldd, col0, qrow, p.Tq, g, p.hd, 1.f);
+        load_row8(ov, p.o + (int64_t)b * p.o_bs, p.ldo, col0, qrow, p.Tq, g, p.hd, 1.f);
+        const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + (q_ok ? qrow : 0);
+        const float lm = p.lse[2 * stat], ll = p.lse[2 * stat + 1];
+        qf[u] = head_frags(qv, g), df[u] = head_frags(dv8, g);
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d = fmaf(dv8[j], ov[j], d);
+        d = pair_sum16(d);                                // the two column halves (groups g, g ^ 1)
+        if (g == 0 && q_ok) p.delta[stat] = d;
+        delta[u] = d;
+        mq[u] = q_ok ? lm : INFINITY;                     // a query beyond the sequence: p = exp2(-inf) = 0
+        ll2[u] = ll * kLog2e;
+        qb[u] = qs[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     for (int k0 = 0; k0 < p.Tk; k0 += CH) {
         const int nt = min(CH, p.Tk - k0), nblk = (nt + 31) >> 5;
         __syncthreads();
-        stage_pair(Ki, Vi, ksrc + (int64_t)k0 * p.ldk, vsrc + (int64_t)k0 * p.ldv, p.ldk, p.ldv, col0, nt, p.hd);
+        if (!(p.tail & 1) || k0 == 0) {
+            if constexpr (!PF) sp.load(ksrc + (int64_t)k0 * p.ldk, vsrc + (int64_t)k0 * p.ldv, p.ldk, p.ldv, col0, nt, p.hd);
+            sp.commit(Ki, Vi);
+        }
         stage_caps(Cap, -INFINITY, p.mask, (int64_t)b * p.Tk + k0, nt);
         __syncthreads();
+        if (PF && k0 + CH < p.Tk && !(p.tail & 1))
+            sp.load(ksrc + (int64_t)(k0 + CH) * p.ldk, vsrc + (int64_t)(k0 + CH) * p.ldv, p.ldk, p.ldv, col0, min(CH, p.Tk - k0 - CH), p.hd);
+        if (p.tail & 2) continue;
         for (int kb = 0; kb < nblk; ++kb) {
             const unsigned char* kblk = Ki + kb * BLK;
             const unsigned char* vblk = Vi + kb * BLK;
-            float ds[8];
+            float ds[NT][8];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 bf16x8 a01, a02, v01, v02;
                 row_frags(kblk, t, c, g, a01, a02);
                 row_frags(vblk, t, c, g, v01, v02);
                 const f32x4 cap = *reinterpret_cast<const f32x4*>(Cap + kb * 32 + t * 16 + 4 * g);
-                const f32x4 st = head_product(a01, a02, qf);
-                const f32x4 dp = head_product(v01, v02, df);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float s = vmin(st[r], cap[r]);                  // masked / padded key: -inf -> e = 0 -> ds = 0
-                    const float e = __builtin_amdgcn_exp2f(fmaf(s - mq, kLog2e, -ll2));
-                    ds[4 * t + r] = e * (dp[r] - delta);
+                for (int u = 0; u < NT; ++u) {
+                    const f32x4 st = head_product(a01, a02, qf[u]);
+                    const f32x4 dp = head_product(v01, v02, df[u]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float sc = vmin(st[r], cap[r]);             // masked / padded key: -inf -> e = 0 -> ds = 0
+                        const float e = __builtin_amdgcn_exp2f(fmaf(sc - mq[u], kLog2e, -ll2[u]));
+                        ds[u][4 * t + r] = e * (dp[r] - delta[u]);
+                    }
                 }
             }
-            const Planes8 dsp = split8(ds);
             bf16x8 kt[3];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) kt[pl] = tr_frag(kblk, pl, c, g);
-            token_product(kt, dsp, qb, qs);
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const Planes8 dsp = split8(ds[u]);
+                token_product(kt, dsp, qb[u], qs[u]);
+            }
         }
     }
-    if (q_ok && 4 * g < p.hd) {
-        const f32x4 o = (qb + qs) * p.scale;
-        *reinterpret_cast<f32x4*>(p.dq + (int64_t)b * p.dq_bs + (int64_t)qrow * p.lddq + col0 + 4 * g) = o;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int qrow = q0 + 16 * u + c;
+        if (qrow < p.Tq && 4 * g < p.hd) {
+            const f32x4 o = (qb[u] + qs[u]) * p.scale;
+            *reinterpret_cast<f32x4*>(p.dq + (int64_t)b * p.dq_bs + (int64_t)qrow * p.lddq + col0 + 4 * g) = o;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
-__global__ __launch_bounds__(512, 2) void pattn_bwd_dkv_kernel(const MAttn p) {
+template <int NT, bool PF>
+__global__ __launch_bounds__(512, NT == 1 ? 4 : 2) void pattn_bwd_dkv_kernel(const MAttn p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* Qi = smem;
     unsigned char* Di = smem + NBK * BLK;
     float* Ml = reinterpret_cast<float*>(smem + 2 * NBK * BLK);
     float* Ll = Ml + CH;
     float* Dl = Ll + CH;
-    const int NB = (p.Tk + 127) / 128;
+    const int NB = (p.Tk + 128 * NT - 1) / (128 * NT);
     int b, hh, blk;
     locate_block(p, NB, b, hh, blk);
     const int col0 = hh * p.hd;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-    const int k0w = blk * 128 + wave * 16, krow = k0w + c;
-    const bool in_seq = krow < p.Tk;
+    const int k0w = blk * 128 * NT + wave * 16 * NT;
     const float* qsrc = p.q + (int64_t)b * p.q_bs;
     const float* dsrc = p.dout + (int64_t)b * p.d_bs;
-    float kv[8], vv[8];
+    StagePair sp;
+    if constexpr (PF) sp.load(qsrc, dsrc, p.ldq, p.ldd, col0, min(CH, p.Tq), p.hd);
     // (the softmax scale multiplies Q here too, as in the forward and the dQ kernel: the recomputed scores are then the
     //  forward's scores bit for bit -- with the scale on K, as the exact-fp32 kernels place it, s - m of a row's largest score
     //  is a rounding difference instead of zero and a peaked softmax shows it in dV)
-    load_row8(kv, p.k + (int64_t)b * p.k_bs, p.ldk, col0, krow, p.Tk, g, p.hd, 1.f);
-    load_row8(vv, p.v + (int64_t)b * p.v_bs, p.ldv, col0, krow, p.Tk, g, p.hd, 1.f);
-    uint8_t mk = 1;
-    if (p.mask) mk = p.mask[(int64_t)b * p.Tk + (in_seq ? krow : 0)];
-    const bool keep = in_seq && mk != 0;
-    const float cap = keep ? INFINITY : (in_seq ? kFillP : -INFINITY);
-    const float liv = keep ? 1.f : 0.f;
-    const HeadFrags kf = head_frags(kv, g), vf = head_frags(vv, g);
-    f32x4 kb_ = {0.f, 0.f, 0.f, 0.f}, ks = kb_, vb = kb_, vs = kb_;
+    HeadFrags kf[NT], vf[NT];
+    float cap[NT], liv[NT];
+    f32x4 kb_[NT], ks[NT], vb[NT], vs[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int krow = k0w + 16 * u + c;
+        const bool in_seq = krow < p.Tk;
+        float kv[8], vv[8];
+        load_row8(kv, p.k + (int64_t)b * p.k_bs, p.ldk, col0, krow, p.Tk, g, p.hd, 1.f);
+        load_row8(vv, p.v + (int64_t)b * p.v_bs, p.ldv, col0, krow, p.Tk, g, p.hd, 1.f);
+        uint8_t mk = 1;
+        if (p.mask) mk = p.mask[(int64_t)b * p.Tk + (in_seq ? krow : 0)];
+        const bool keep = in_seq && mk != 0;
+        cap[u] = keep ? INFINITY : (in_seq ? kFillP : -INFINITY);
+        liv[u] = keep ? 1.f : 0.f;
+        kf[u] = head_frags(kv, g), vf[u] = head_frags(vv, g);
+        kb_[u] = ks[u] = vb[u] = vs[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     for (int i0 = 0; i0 < p.Tq; i0 += CH) {
         const int nt = min(CH, p.Tq - i0), nblk = (nt + 31) >> 5;
         __syncthreads();
-        stage_pair(Qi, Di, qsrc + (int64_t)i0 * p.ldq, dsrc + (int64_t)i0 * p.ldd, p.ldq, p.ldd, col0, nt, p.hd, p.scale);
+        if (!(p.tail & 1) || i0 == 0) {
+            if constexpr (!PF) sp.load(qsrc + (int64_t)i0 * p.ldq, dsrc + (int64_t)i0 * p.ldd, p.ldq, p.ldd, col0, nt, p.hd);
+            sp.commit(Qi, Di, p.scale);
+        }
         for (int j = threadIdx.x; j < ((nt + 31) & ~31); j += blockDim.x) {
             const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + i0 + (j < nt ? j : 0);
             Ml[j] = j < nt ? p.lse[2 * stat] : INFINITY;              // +inf: a padded query row gets p = exp2(-inf) = 0
@@ -441,10 +503,13 @@ __global__ __launch_bounds__(512, 2) void pattn_bwd_dkv_kernel(const MAttn p) {
             Dl[j] = j < nt ? p.delta[stat] : 0.f;
         }
         __syncthreads();
+        if (PF && i0 + CH < p.Tq && !(p.tail & 1))
+            sp.load(qsrc + (int64_t)(i0 + CH) * p.ldq, dsrc + (int64_t)(i0 + CH) * p.ldd, p.ldq, p.ldd, col0, min(CH, p.Tq - i0 - CH), p.hd);
+        if (p.tail & 2) continue;
         for (int qb = 0; qb < nblk; ++qb) {
             const unsigned char* qblk = Qi + qb * BLK;
             const unsigned char* dblk = Di + qb * BLK;
-            float pr[8], ds[8];
+            float pr[NT][8], ds[NT][8];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 bf16x8 a01, a02, d01, d02;
@@ -453,31 +518,46 @@ __global__ __launch_bounds__(512, 2) void pattn_bwd_dkv_kernel(const MAttn p) {
                 const f32x4 ml = *reinterpret_cast<const f32x4*>(Ml + qb * 32 + t * 16 + 4 * g);
                 const f32x4 l2 = *reinterpret_cast<const f32x4*>(Ll + qb * 32 + t * 16 + 4 * g);
                 const f32x4 dl = *reinterpret_cast<const f32x4*>(Dl + qb * 32 + t * 16 + 4 * g);
-                const f32x4 st = head_product(a01, a02, kf);          // rows = queries 4 g + r, column = this lane's key
-                const f32x4 dp = head_product(d01, d02, vf);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float s = vmin(st[r], cap);
-                    const float e = __builtin_amdgcn_exp2f(fmaf(s - ml[r], kLog2e, -l2[r]));
-                    pr[4 * t + r] = e;
-                    ds[4 * t + r] = e * (dp[r] - dl[r]);           // (x 0 for a masked key: once, on the finished column)
+                for (int u = 0; u < NT; ++u) {
+                    const f32x4 st = head_product(a01, a02, kf[u]);            // rows = queries 4 g + r, column = this lane's key
+                    const f32x4 dp = head_product(d01, d02, vf[u]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float sc = vmin(st[r], cap[u]);
+                        const float e = __builtin_amdgcn_exp2f(fmaf(sc - ml[r], kLog2e, -l2[r]));
+                        pr[u][4 * t + r] = e;
+                        ds[u][4 * t + r] = e * (dp[r] - dl[r]);         // (x 0 for a masked key: once, on the finished column)
+                    }
                 }
             }
-            const Planes8 pp = split8(pr), dsp = split8(ds);
-            bf16x8 dt[3], qt[3];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                dt[pl] = tr_frag(dblk, pl, c, g);
-                qt[pl] = tr_frag(qblk, pl, c, g);
+            for (int u = 0; u < NT; ++u) {
+                {
+                    bf16x8 dt[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) dt[pl] = tr_frag(dblk, pl, c, g);
+                    const Planes8 pp = split8(pr[u]);
+                    token_product(dt, pp, vb[u], vs[u]);
+                }
+                {
+                    bf16x8 qt[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) qt[pl] = tr_frag(qblk, pl, c, g);
+                    const Planes8 dsp = split8(ds[u]);
+                    token_product(qt, dsp, kb_[u], ks[u]);
+                }
             }
-            token_product(dt, pp, vb, vs);
-            token_product(qt, dsp, kb_, ks);
         }
     }
-    if (in_seq && 4 * g < p.hd) {
-        const f32x4 dk = (kb_ + ks) * liv, dv = vb + vs;     // (Q carried the scale) liv: the gradient of a masked key's scores is zero
-        *reinterpret_cast<f32x4*>(p.dk + (int64_t)b * p.dk_bs + (int64_t)krow * p.lddk + col0 + 4 * g) = dk;
-        *reinterpret_cast<f32x4*>(p.dv + (int64_t)b * p.dv_bs + (int64_t)krow * p.lddv + col0 + 4 * g) = dv;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int krow = k0w + 16 * u + c;
+        if (krow < p.Tk && 4 * g < p.hd) {
+            const f32x4 dk = (kb_[u] + ks[u]) * liv[u], dv = vb[u] + vs[u];     // (Q carried the scale) liv: a masked key's score gradients are zero
+            *reinterpret_cast<f32x4*>(p.dk + (int64_t)b * p.dk_bs + (int64_t)krow * p.lddk + col0 + 4 * g) = dk;
+            *reinterpret_cast<f32x4*>(p.dv + (int64_t)b * p.dv_bs + (int64_t)krow * p.lddv + col0 + 4 * g) = dv;
+        }
     }
 }
 
@@ -495,6 +575,9 @@ int launch(K kernel, unsigned grid, unsigned block, size_t lds, hipStream_t st, 
 
 int g_planes_on = 1;
 int g_fwd_qt = 2;
+int g_bwd_nt = 1;
+int g_ablate = 0;
+int g_prefetch = 1;
 
 }  // namespace
 
@@ -510,47 +593,9 @@ bool pattn_applicable(const MAttn& a) {
         if (reinterpret_cast<uintptr_t>(ptr) & 15) return false;
     return true;
 }
-
-static unsigned block_threads(int T, int rows_per_wave) {
-    return 64u * (unsigned)std::min(8, (T + rows_per_wave - 1) / rows_per_wave);
+bool pattn_forward_aligned(const MAttn& a) {
+    return (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 && a.ldo % 4 == 0 && a.o_bs % 4 == 0;
 }
-
-int pattn_forward(const MAttn& a, hipStream_t st) {
-    const int64_t al[] = {a.ldo, a.o_bs};
-    bool ok = (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
-    for (int64_t v : al) ok = ok && (v % 4 == 0);
-    if (!ok) {
-        set_error("plane attention forward: out must be 16-byte aligned with strides %% 4 == 0");
-        return MSN_ERR_SHAPE;
-    }
-    const size_t lds = 2 * NBK * BLK + sizeof(float) * CH;
-    if (g_fwd_qt == 2 && a.Tq > 128) {
-        const unsigned grid = (unsigned)(a.B * a.H * ((a.Tq + 255) / 256));
-        return launch(pattn_fwd_kernel<2>, grid, block_threads(a.Tq, 32), lds, st, a);
-    }
-    const unsigned grid = (unsigned)(a.B * a.H * ((a.Tq + 127) / 128));
-    return launch(pattn_fwd_kernel<1>, grid, block_threads(a.Tq, 16), lds, st, a);
-}
-
-int pattn_backward(const MAttn& a, hipStream_t st) {
-    const int64_t al[] = {a.ldd, a.d_bs, a.ldo, a.o_bs, a.lddq, a.lddk, a.lddv, a.dq_bs, a.dk_bs, a.dv_bs};
-    bool ok = ((reinterpret_cast<uintptr_t>(a.dout) | reinterpret_cast<uintptr_t>(a.o) | reinterpret_cast<uintptr_t>(a.dq) |
-                reinterpret_cast<uintptr_t>(a.dk) | reinterpret_cast<uintptr_t>(a.dv)) & 15) == 0;
-    for (int64_t v : al) ok = ok && (v % 4 == 0);
-    if (!ok) {
-        set_error("plane attention backward: out / dout / dq / dk / dv must be 16-byte aligned with strides %% 4 == 0");
-        return MSN_ERR_SHAPE;
-    }
-    {
-        const size_t lds = 2 * NBK * BLK + sizeof(float) * CH;
-        const unsigned grid = (unsigned)(a.B * a.H * ((a.Tq + 127) / 128));
-        if (int rc = launch(pattn_bwd_dq_kernel, grid, block_threads(a.Tq, 16), lds, st, a)) return rc;
-    }
-    const size_t lds = 2 * NBK * BLK + sizeof(float) * 3 * CH;
-    const unsigned grid = (unsigned)(a.B * a.H * ((a.Tk + 127) / 128));
-    return launch(pattn_bwd_dkv_kernel, grid, block_threads(a.Tk, 16), lds, st, a);
-}
-
 bool pattn_backward_aligned(const MAttn& a) {
     const int64_t al[] = {a.ldd, a.d_bs, a.ldo, a.o_bs, a.lddq, a.lddk, a.lddv, a.dq_bs, a.dk_bs, a.dv_bs};
     bool ok = ((reinterpret_cast<uintptr_t>(a.dout) | reinterpret_cast<uintptr_t>(a.o) | reinterpret_cast<uintptr_t>(a.dq) |
@@ -558,8 +603,54 @@ bool pattn_backward_aligned(const MAttn& a) {
     for (int64_t v : al) ok = ok && (v % 4 == 0);
     return ok;
 }
-bool pattn_forward_aligned(const MAttn& a) {
-    return (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 && a.ldo % 4 == 0 && a.o_bs % 4 == 0;
+
+// threads of a workgroup whose waves own `rows_per_wave` rows each (at most eight waves)
+static unsigned block_threads(int T, int rows_per_wave) {
+    return 64u * (unsigned)std::min(8, (T + rows_per_wave - 1) / rows_per_wave);
+}
+
+int pattn_forward(const MAttn& a0, hipStream_t st) {
+    if (!pattn_forward_aligned(a0)) {
+        set_error("plane attention forward: out must be 16-byte aligned with strides %% 4 == 0");
+        return MSN_ERR_SHAPE;
+    }
+    MAttn a = a0;
+    a.tail = g_ablate;
+    const size_t lds = 2 * NBK * BLK + sizeof(float) * CH;
+    if (g_fwd_qt == 2 && a.Tq > 128) {
+        const unsigned grid = (unsigned)(a.B * a.H * ((a.Tq + 255) / 256)), bt = block_threads(a.Tq, 32);
+        return g_prefetch ? launch(pattn_fwd_kernel<2, true>, grid, bt, lds, st, a) : launch(pattn_fwd_kernel<2, false>, grid, bt, lds, st, a);
+    }
+    const unsigned grid = (unsigned)(a.B * a.H * ((a.Tq + 127) / 128)), bt = block_threads(a.Tq, 16);
+    return g_prefetch ? launch(pattn_fwd_kernel<1, true>, grid, bt, lds, st, a) : launch(pattn_fwd_kernel<1, false>, grid, bt, lds, st, a);
+}
+
+int pattn_backward(const MAttn& a0, hipStream_t st) {
+    if (!pattn_backward_aligned(a0)) {
+        set_error("plane attention backward: out / dout / dq / dk / dv must be 16-byte aligned with strides %% 4 == 0");
+        return MSN_ERR_SHAPE;
+    }
+    MAttn a = a0;
+    a.tail = g_ablate;
+    {
+        const size_t lds = 2 * NBK * BLK + sizeof(float) * CH;
+        int rc;
+        if (g_bwd_nt == 2 && a.Tq > 128) {
+            const unsigned grid = (unsigned)(a.B * a.H * ((a.Tq + 255) / 256)), bt = block_threads(a.Tq, 32);
+            rc = g_prefetch ? launch(pattn_bwd_dq_kernel<2, true>, grid, bt, lds, st, a) : launch(pattn_bwd_dq_kernel<2, false>, grid, bt, lds, st, a);
+        } else {
+            const unsigned grid = (unsigned)(a.B * a.H * ((a.Tq + 127) / 128)), bt = block_threads(a.Tq, 16);
+            rc = g_prefetch ? launch(pattn_bwd_dq_kernel<1, true>, grid, bt, lds, st, a) : launch(pattn_bwd_dq_kernel<1, false>, grid, bt, lds, st, a);
+        }
+        if (rc) return rc;
+    }
+    const size_t lds = 2 * NBK * BLK + sizeof(float) * 3 * CH;
+    if (g_bwd_nt == 2 && a.Tk > 128) {
+        const unsigned grid = (unsigned)(a.B * a.H * ((a.Tk + 255) / 256)), bt = block_threads(a.Tk, 32);
+        return g_prefetch ? launch(pattn_bwd_dkv_kernel<2, true>, grid, bt, lds, st, a) : launch(pattn_bwd_dkv_kernel<2, false>, grid, bt, lds, st, a);
+    }
+    const unsigned grid = (unsigned)(a.B * a.H * ((a.Tk + 127) / 128)), bt = block_threads(a.Tk, 16);
+    return g_prefetch ? launch(pattn_bwd_dkv_kernel<1, true>, grid, bt, lds, st, a) : launch(pattn_bwd_dkv_kernel<1, false>, grid, bt, lds, st, a);
 }
 
 }  // namespace msn
@@ -567,8 +658,12 @@ bool pattn_forward_aligned(const MAttn& a) {
 using namespace msn;
 
 extern "C" int msn_set_attention_planes(int mode) {
-    MSN_REQUIRE(mode >= 0 && mode <= 3, "msn_set_attention_planes: 0 (off), 1 (on, two query tiles per wave), 3 (on, one tile per wave)");
+    MSN_REQUIRE(mode >= 0 && mode < 128, "msn_set_attention_planes: bit 0 on / off, bit 1 one query tile per wave in the forward, "
+                "bit 2 two tiles per wave in the backward, bit 3 no register prefetch of the next chunk, bits 4 - 5 diagnostic ablations");
     g_planes_on = mode & 1;
     g_fwd_qt = (mode & 2) ? 1 : 2;
+    g_bwd_nt = (mode & 4) ? 2 : 1;
+    g_prefetch = (mode & 8) ? 0 : 1;
+    g_ablate = (mode >> 4) & 3;
     return MSN_OK;
 }
