@@ -35,6 +35,8 @@
 #include <algorithm>
 #include <math.h>
 
+#include <type_traits>
+
 #include "attention_args.h"
 
 namespace msn {
@@ -233,13 +235,17 @@ __device__ __forceinline__ void token_product(const bf16x8 (&xt)[3], const Plane
 
 // per-key caps of a chunk: +inf live, `fill` masked out (-1e7: ref :77; the dQ kernel passes -inf: the gradient of a masked
 // score is zero -- masked_fill -- also in a row whose keys are ALL masked, where its probability is not), -inf beyond the sequence
-__device__ __forceinline__ void stage_caps(float* cap, float fill, const uint8_t* mask, int64_t moff, int nt) {
+// Returns whether this thread staged a key that is not live (the chunk's blocks then take the form with the v_min).
+__device__ __forceinline__ int stage_caps(float* cap, float fill, const uint8_t* mask, int64_t moff, int nt) {
     const int rows = (nt + 31) & ~31;
+    int special = 0;
     for (int j = threadIdx.x; j < rows; j += blockDim.x) {
         const bool in = j < nt;
         const bool on = in && (!mask || mask[moff + j] != 0);
         cap[j] = on ? INFINITY : (in ? fill : -INFINITY);
+        special |= on ? 0 : 1;
     }
+    return special;
 }
 
 // ------------------------------------------------------------------------------------------ forward
@@ -282,11 +288,13 @@ __global__ __launch_bounds__(512, 4) void pattn_fwd_kernel(const MAttn p) {
             if constexpr (!PF) sp.load(ksrc + (int64_t)k0 * p.ldk, vsrc + (int64_t)k0 * p.ldv, p.ldk, p.ldv, col0, nt, p.hd);
             sp.commit(Ki, Vi);
         }
-        stage_caps(Cap, kFillP, p.mask, (int64_t)b * p.Tk + k0, nt);
-        __syncthreads();
+        const int special = __syncthreads_or(stage_caps(Cap, kFillP, p.mask, (int64_t)b * p.Tk + k0, nt));
         if (PF && k0 + CH < p.Tk && !(p.tail & 1))        // the next chunk's rows: in flight while this one is multiplied
             sp.load(ksrc + (int64_t)(k0 + CH) * p.ldk, vsrc + (int64_t)(k0 + CH) * p.ldv, p.ldk, p.ldv, col0, min(CH, p.Tk - k0 - CH), p.hd);
         if (p.tail & 2) continue;
+        // MASKED: the chunk holds a masked-out or padding key -> one v_min per score against the per-key caps
+        auto blocks = [&](auto masked_) {
+        constexpr bool MASKED = decltype(masked_)::value;
         for (int kb = 0; kb < nblk; ++kb) {
             const unsigned char* kblk = Ki + kb * BLK;
             const unsigned char* vblk = Vi + kb * BLK;
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(512, 4) void pattn_fwd_kernel(const MAttn p) {
                     const f32x4 st = head_product(a01, a02, qf[u]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        s[u][4 * t + r] = vmin(st[r], cap[r]);
+                        s[u][4 * t + r] = MASKED ? vmin(st[r], cap[r]) : st[r];
                         mbs[u] = fmaxf(mbs[u], s[u][4 * t + r]);
                     }
                 }
@@ -333,6 +341,9 @@ __global__ __launch_bounds__(512, 4) void pattn_fwd_kernel(const MAttn p) {
                 token_product(vt, pp, ob[u], os[u]);
             }
         }
+        };
+        if (special) blocks(std::true_type{});
+        else blocks(std::false_type{});
     }
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
@@ -402,11 +413,12 @@ __global__ __launch_bounds__(512, NT == 1 ? 4 : 2) void pattn_bwd_dq_kernel(cons
             if constexpr (!PF) sp.load(ksrc + (int64_t)k0 * p.ldk, vsrc + (int64_t)k0 * p.ldv, p.ldk, p.ldv, col0, nt, p.hd);
             sp.commit(Ki, Vi);
         }
-        stage_caps(Cap, -INFINITY, p.mask, (int64_t)b * p.Tk + k0, nt);
-        __syncthreads();
+        const int special = __syncthreads_or(stage_caps(Cap, -INFINITY, p.mask, (int64_t)b * p.Tk + k0, nt));
         if (PF && k0 + CH < p.Tk && !(p.tail & 1))
             sp.load(ksrc + (int64_t)(k0 + CH) * p.ldk, vsrc + (int64_t)(k0 + CH) * p.ldv, p.ldk, p.ldv, col0, min(CH, p.Tk - k0 - CH), p.hd);
         if (p.tail & 2) continue;
+        auto blocks = [&](auto masked_) {
+        constexpr bool MASKED = decltype(masked_)::value;
         for (int kb = 0; kb < nblk; ++kb) {
             const unsigned char* kblk = Ki + kb * BLK;
             const unsigned char* vblk = Vi + kb * BLK;
@@ -423,7 +435,7 @@ __global__ __launch_bounds__(512, NT == 1 ? 4 : 2) void pattn_bwd_dq_kernel(cons
                     const f32x4 dp = head_product(v01, v02, df[u]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float sc = vmin(st[r], cap[r]);             // masked / padded key: -inf -> e = 0 -> ds = 0
+                        const float sc = MASKED ? vmin(st[r], cap[r]) : st[r];     // masked / padded key: -inf -> e = 0 -> ds = 0
                         const float e = __builtin_amdgcn_exp2f(fmaf(sc - mq[u], kLog2e, -ll2[u]));
                         ds[u][4 * t + r] = e * (dp[r] - delta[u]);
                     }
@@ -438,6 +450,9 @@ __global__ __launch_bounds__(512, NT == 1 ? 4 : 2) void pattn_bwd_dq_kernel(cons
                 token_product(kt, dsp, qb[u], qs[u]);
             }
         }
+        };
+        if (special) blocks(std::true_type{});
+        else blocks(std::false_type{});
     }
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
@@ -489,6 +504,10 @@ __global__ __launch_bounds__(512, NT == 1 ? 4 : 2) void pattn_bwd_dkv_kernel(con
         kf[u] = head_frags(kv, g), vf[u] = head_frags(vv, g);
         kb_[u] = ks[u] = vb[u] = vs[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    int special = 0;                                      // this wave owns a key that is not live: the form with the v_min
+#pragma unroll
+    for (int u = 0; u < NT; ++u) special |= liv[u] == 0.f ? 1 : 0;
+    special = __any(special);
     for (int i0 = 0; i0 < p.Tq; i0 += CH) {
         const int nt = min(CH, p.Tq - i0), nblk = (nt + 31) >> 5;
         __syncthreads();
@@ -506,6 +525,8 @@ __global__ __launch_bounds__(512, NT == 1 ? 4 : 2) void pattn_bwd_dkv_kernel(con
         if (PF && i0 + CH < p.Tq && !(p.tail & 1))
             sp.load(qsrc + (int64_t)(i0 + CH) * p.ldq, dsrc + (int64_t)(i0 + CH) * p.ldd, p.ldq, p.ldd, col0, min(CH, p.Tq - i0 - CH), p.hd);
         if (p.tail & 2) continue;
+        auto blocks = [&](auto masked_) {
+        constexpr bool MASKED = decltype(masked_)::value;
         for (int qb = 0; qb < nblk; ++qb) {
             const unsigned char* qblk = Qi + qb * BLK;
             const unsigned char* dblk = Di + qb * BLK;
@@ -524,7 +545,7 @@ __global__ __launch_bounds__(512, NT == 1 ? 4 : 2) void pattn_bwd_dkv_kernel(con
                     const f32x4 dp = head_product(d01, d02, vf[u]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float sc = vmin(st[r], cap[u]);
+                        const float sc = MASKED ? vmin(st[r], cap[u]) : st[r];
                         const float e = __builtin_amdgcn_exp2f(fmaf(sc - ml[r], kLog2e, -l2[r]));
                         pr[u][4 * t + r] = e;
                         ds[u][4 * t + r] = e * (dp[r] - dl[r]);         // (x 0 for a masked key: once, on the finished column)
@@ -549,6 +570,9 @@ __global__ __launch_bounds__(512, NT == 1 ? 4 : 2) void pattn_bwd_dkv_kernel(con
                 }
             }
         }
+        };
+        if (special) blocks(std::true_type{});
+        else blocks(std::false_type{});
     }
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
@@ -577,7 +601,7 @@ int g_planes_on = 1;
 int g_fwd_qt = 2;
 int g_bwd_nt = 1;
 int g_ablate = 0;
-int g_prefetch = 1;
+int g_prefetch = 0;     // the next chunk's rows requested into registers under the current chunk's products: measured no faster (16 + registers)
 
 }  // namespace
 
@@ -658,12 +682,12 @@ int pattn_backward(const MAttn& a0, hipStream_t st) {
 using namespace msn;
 
 extern "C" int msn_set_attention_planes(int mode) {
-    MSN_REQUIRE(mode >= 0 && mode < 128, "msn_set_attention_planes: bit 0 on / off, bit 1 one query tile per wave in the forward, "
-                "bit 2 two tiles per wave in the backward, bit 3 no register prefetch of the next chunk, bits 4 - 5 diagnostic ablations");
+    MSN_REQUIRE(mode >= 0 && mode < 64, "msn_set_attention_planes: bit 0 on / off, bit 1 one query tile per wave in the forward, "
+                "bit 2 two tiles per wave in the backward, bit 3 register prefetch of the next chunk, bits 4 - 5 diagnostic ablations");
     g_planes_on = mode & 1;
     g_fwd_qt = (mode & 2) ? 1 : 2;
     g_bwd_nt = (mode & 4) ? 2 : 1;
-    g_prefetch = (mode & 8) ? 0 : 1;
+    g_prefetch = (mode & 8) ? 1 : 0;
     g_ablate = (mode >> 4) & 3;
     return MSN_OK;
 }

@@ -1018,7 +1018,7 @@ def set_attention_fused(on):
 
 def set_attention_planes(mode):
     """1 (default): long sequences of heads up to 16 wide run fp32-grade on the bf16 matrix cores (csrc/attention_planes.hip);
-    3: the same with one query tile per wave in the forward; 0: the exact-fp32 matrix-core kernels."""
+    0: the exact-fp32 matrix-core kernels; further bits select measurement forms (include/msn_hip.h)."""
     check(lib().msn_set_attention_planes(int(mode)), "msn_set_attention_planes")
 
 

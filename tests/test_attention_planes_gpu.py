@@ -64,7 +64,8 @@ CASES = [  # B, Tq, Tk, heads, hd, masked, gain (multiplies q: peaked softmax), 
 ]
 
 
-@pytest.mark.parametrize("mode", [1, 3 + 4 + 8])   # the default forms; one tile per wave forward + two per wave backward, no prefetch
+# 1 = the default forms; 15 = one tile per wave forward + two per wave backward, register prefetch
+@pytest.mark.parametrize("mode", [1, 15])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(str(x) for x in c))
 def test_fp32_grade_gate(case, mode):
     from multimodal_supernovae_amd import ops
