@@ -583,6 +583,8 @@ static int pgemm_nt_impl(int64_t M, int N, int K, int planes, const void* A, con
     MSN_REQUIRE(!needs_aux || aux, "msn_pgemm_nt: epilogue %d needs an aux matrix", epilogue);
     MSN_REQUIRE(!aux || (ldaux >= N && ldaux % 4 == 0 && aligned16p(aux)), "msn_pgemm_nt: bad aux matrix");
     MSN_REQUIRE(M < (1ll << 31) * 32, "msn_pgemm_nt: too many rows");
+    // the epilogue addresses C / aux through buffer descriptors per tile row with 32-bit lane offsets (pgemm_kernels.h)
+    MSN_REQUIRE(N < (1 << 20) && (c_planes || ldc < (1 << 20)) && (!aux || ldaux < (1 << 20)), "msn_pgemm_nt: row strides must be below 2^20 elements");
     PgemmArgs a = {};
     a.A = static_cast<const unsigned char*>(A); a.B = static_cast<const unsigned char*>(B); a.C = C;
     a.aux = aux; a.bias = bias; a.ldc = ldc; a.ldaux = ldaux; a.M = M; a.N = N; a.K = K;

@@ -469,15 +469,25 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
     // reads -- in memory order: fp32 as 8 rows x 128 bytes per instruction, planes as whole 1-KB block images.
     // MODE 0: the tile's result.  MODE 1: the tile's result when earlier K chunks left a partial sum in C (added first).
     // MODE 2 / 3: a K chunk's partial sum -> C (first chunk) / C += (later chunks); no bias, no epilogue (fp32 outputs only).
-    const unsigned stg = lds0 + (unsigned)(NSLOT * SLOT + wave * STG);
-    // fp32 image of a tile: [32 rows][128 B], 16-byte chunk c of row r at position c ^ (r & 7) (conflict-free both ways)
-    const unsigned st_acc = stg + (unsigned)(frow * 128);                       // + ((2 b + fhalf) ^ (frow & 7)) * 16
+    // The epilogue's lane constants (staging addresses, row / chunk of the lane in the two layouts) are derived from an OPAQUE copy
+    // of the lane id at the start of every tile's epilogue (epi_lane): computed once at kernel start they were ~30 registers that
+    // live across the K loop -- where the two accumulator sets and the fragments fill the file -- and the allocator spilled them
+    // (scratch stores in the prologue, reloads in every epilogue form).  Re-deriving them costs ~20 vector instructions per tile.
+    int eln = lane;
+    int frow_e = 0, fhalf_e = 0, r16_e = 0, kg_e = 0, srow = 0, schunk = 0;
+    unsigned stg = 0, st_mem = 0;
+    auto epi_lane = [&]() {
+        asm volatile("" : "+v"(eln));
+        frow_e = eln & 31, fhalf_e = eln >> 5, r16_e = eln & 15, kg_e = eln >> 4;
+        srow = eln >> 3, schunk = eln & 7;                                          // memory order: pass q -> row 8 q + srow
+        stg = lds0 + (unsigned)(NSLOT * SLOT + wave * STG);
+        // fp32 image of a tile: [32 rows][128 B], 16-byte chunk c of row r at position c ^ (r & 7) (conflict-free both ways)
+        st_mem = stg + (unsigned)(srow * 128 + ((schunk ^ srow) * 16));              // + q * 1024   ((8 q + srow) & 7 == srow)
+    };
     // chunk b of this lane's 16 accumulator values of a 32 x 32 tile: its row and its 16-byte column chunk (4 columns) in the tile
-    auto erow = [&](int b) { return S16 ? 16 * (b >> 1) + r16 : frow; };
-    auto ecolq = [&](int b) { return S16 ? 4 * (b & 1) + kg : 2 * b + fhalf; };
+    auto erow = [&](int b) { return S16 ? 16 * (b >> 1) + r16_e : frow_e; };
+    auto ecolq = [&](int b) { return S16 ? 4 * (b & 1) + kg_e : 2 * b + fhalf_e; };
     auto acc_addr = [&](int b) { return stg + (unsigned)(erow(b) * 128 + ((ecolq(b) ^ (erow(b) & 7)) * 16)); };
-    const int srow = lane >> 3, schunk = lane & 7;                              // memory order: pass q -> row 8 q + srow
-    const unsigned st_mem = stg + (unsigned)(srow * 128 + ((schunk ^ srow) * 16));   // + q * 1024   ((8 q + srow) & 7 == srow)
     // (s_nop behind every ds_write_b128: a VALU write to the data registers of a DS store of more than 8 bytes needs a wait
     // state the compiler's hazard recognizer would insert -- it cannot see the store inside the asm; without it a few lanes
     // of a tile came out wrong once in a few launches)
@@ -489,14 +499,33 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
     // tile_fetch issues its four 16-byte loads per lane in memory order (for EVERY tile of the wave before the first is used:
     // one exposed memory latency per output tile instead of one per MFMA tile), tile_take turns one through the staging
     // area into the accumulator layout a[4 b + r]
-    auto tile_fetch = [&](const float* src, int64_t ld, int64_t m0, int n0, f32x4 (&t)[4]) {
+    // Global accesses of the epilogue go through BUFFER instructions: one descriptor per matrix and tile row (scalar registers),
+    // a 32-bit byte offset per lane.  With 64-bit per-lane pointers the address arithmetic of the six epilogue forms held ~60
+    // registers in 2-register pairs and the allocator spilled them around the K loop (352 bytes of scratch per lane).  The
+    // descriptor covers exactly the tile row's rows that exist: rows past M read zeros / are not stored without a compare, and a
+    // lane whose columns lie past N is given an offset beyond every descriptor (row strides < 2^20 elements: host).
+    typedef __amdgpu_buffer_rsrc_t rsrc_t;
+    constexpr unsigned OOB = 0x40000000u;
+    // (the descriptor's inputs pass through v_readfirstlane: they ARE wave-uniform, but hipcc does not prove it for values that
+    //  went through the tile walk, keeps the descriptor in vector registers and wraps EVERY buffer instruction in a waterfall
+    //  loop -- 1 600 v_readfirstlane in the listing of the first attempt)
+    auto uniform_rsrc = [&](const void* base, int64_t bytes) -> rsrc_t {
+        const uint64_t a = reinterpret_cast<uint64_t>(base);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        const int nb = __builtin_amdgcn_readfirstlane((int)bytes);
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), (short)0, nb, 0x00020000);
+    };
+    auto rows_rsrc = [&](const float* base, int64_t ld, int tm_) -> rsrc_t {      // fp32 matrix, the 256 rows of tile row tm_
+        const int64_t rows = min<int64_t>(max<int64_t>(p.M - (int64_t)tm_ * BM, 0), BM);
+        return uniform_rsrc(base + (int64_t)tm_ * BM * ld, rows * ld * 4);
+    };
+    // r0 = first row of the 32 x 32 tile inside the tile row, n0 = its first column
+    auto tile_fetch = [&](rsrc_t rs, int64_t ld, int r0, int n0, f32x4 (&t)[4]) {
+        const int n = n0 + 4 * schunk;
+        const unsigned lo = n < p.N ? (unsigned)((srow * (int)ld + n) * 4) : OOB;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t m = m0 + 8 * q + srow;
-            const int n = n0 + 4 * schunk;
-            t[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (m < p.M && n < p.N) t[q] = *reinterpret_cast<const f32x4*>(src + m * ld + n);
-        }
+        for (int q = 0; q < 4; ++q)
+            t[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lo + (unsigned)((r0 + 8 * q) * (int)ld * 4)), 0, 0));
     };
     auto tile_take = [&](const f32x4 (&t)[4], float (&a)[16]) {
 #pragma unroll
@@ -515,27 +544,27 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
     };
     // accumulator layout -> rows m0.., columns n0.. of `dst` in memory order: stage_chunk(b, 4 values) four times, then flush
     auto stage_chunk = [&](int b, const float (&w)[4]) { lds_w128(acc_addr(b), w); };
-    auto tile_flush = [&](float* dst, int64_t ld, int64_t m0, int n0) {
+    auto tile_flush = [&](rsrc_t rs, int64_t ld, int r0, int n0) {
         f32x4 r[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) lds_r128(r[q], st_mem + q * 1024);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3])::"memory");
         __builtin_amdgcn_sched_barrier(0);
+        const int n = n0 + 4 * schunk;
+        const unsigned lo = n < p.N ? (unsigned)((srow * (int)ld + n) * 4) : OOB;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t m = m0 + 8 * q + srow;
-            const int n = n0 + 4 * schunk;
-            if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(dst + m * ld + n) = r[q];
-        }
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r[q]), rs, (int)(lo + (unsigned)((r0 + 8 * q) * (int)ld * 4)), 0, 0);
     };
-    auto slab_flush = [&](float* slab, int r0, int c0) {            // the staged tile -> rows r0.., columns c0.. of a 256 x BN slab
+    auto slab_flush = [&](rsrc_t rs, int r0, int c0) {              // the staged tile -> rows r0.., columns c0.. of a 256 x BN slab
         f32x4 r[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) lds_r128(r[q], st_mem + q * 1024);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3])::"memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(slab + (r0 + 8 * q + srow) * BN + c0 + 4 * schunk) = r[q];
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r[q]), rs, ((r0 + 8 * q + srow) * BN + c0 + 4 * schunk) * 4, 0, 0);
     };
     auto store_tile_epi = [&](int tm, int tn, auto epi_, auto mode_) {
         constexpr int epi = decltype(epi_)::value;
@@ -544,6 +573,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
         constexpr bool SLAB = (decltype(mode_)::value & 8) != 0;  // a tail unit's raw sums -> its slab (256 x BN, row-major)
         constexpr bool PARTIAL = MODE >= 2, ADDC = (MODE == 1 || MODE == 3) && !OUTP;
         constexpr bool AUXIN = !PARTIAL && (epi == MSN_EPI_RELU_BWD || epi == MSN_EPI_GELU_BWD || epi == MSN_EPI_ADD);
+        epi_lane();
         // everything the epilogue reads, requested up front: the K-chunk partial if there is one, else the aux matrix
         if constexpr (DUAL) {      // the two accumulator sets meet here (one round-to-nearest add); acc2's registers are free from now on
 #pragma unroll
@@ -559,15 +589,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
                 for (int j = 0; j < NT; ++j) acc[i][j] *= os;
         }
         constexpr bool PRE = ADDC || AUXIN;
-        constexpr int PW = (DUAL || MT * NT < 2) ? MT * NT : 2;          // tiles requested ahead (16 registers each)
+        // tiles requested ahead (16 registers each): all four of the wave where the merged accumulator set has freed the room;
+        // a plane output also holds six block images per tile (24 registers) -- two ahead, or the epilogue itself spills
+        constexpr int PW = (MT * NT < 2) ? MT * NT : ((DUAL && !OUTP) ? MT * NT : 1);
         f32x4 pre[PRE ? PW : 1][4];
-        const float* pre_src = ADDC ? static_cast<const float*>(p.C) : p.aux;
+        // descriptors of this tile row (scalar registers): C as an fp32 matrix or as planes, the aux matrix, bias, slab, column sums
+        const rsrc_t rsC = OUTP ? uniform_rsrc(static_cast<unsigned char*>(p.C) + (int64_t)tm * ARB * p.cbC * (NP * PBLK),
+                                               min(max(p.rbA - tm * ARB, 0), ARB) * (int64_t)p.cbC * (NP * PBLK))
+                                : rows_rsrc(static_cast<const float*>(p.C), p.ldc, tm);
+        const rsrc_t rsAux = rows_rsrc(p.aux, p.ldaux, tm);
+        const rsrc_t rsBias = uniform_rsrc(p.bias, p.bias ? p.N * 4 : 0);
+        const rsrc_t pre_rs = ADDC ? rsC : rsAux;
         const int64_t pre_ld = ADDC ? p.ldc : p.ldaux;
         auto pre_fetch = [&](auto t_) {                            // tile t = j * MT + i of this wave -> pre[t % PW]
             constexpr int t = decltype(t_)::value;
             if constexpr (PRE && t < MT * NT)
-                tile_fetch(pre_src, pre_ld, (int64_t)tm * BM + wm * (32 * MT) + 32 * (t % MT), tn * BN + wn * (32 * NT) + 32 * (t / MT),
-                           pre[t % PW]);
+                tile_fetch(pre_rs, pre_ld, wm * (32 * MT) + 32 * (t % MT), tn * BN + wn * (32 * NT) + 32 * (t / MT), pre[t % PW]);
         };
         static_for<0, PW>([&](auto t_) { pre_fetch(t_); });
         static_for<0, NT>([&](auto j_) {
@@ -586,7 +623,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
                     pre_fetch(std::integral_constant<int, t + PW>{});
                     return;
                 }
-                const bool row_ok = m0 + frow < p.M;
+                const bool row_ok = m0 + frow_e < p.M;
                 float v[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) v[e] = acc[i][j][e];
@@ -599,12 +636,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
                 }
                 if (!PARTIAL && p.bias) {
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const int n = n0 + 4 * ecolq(b);
-                        if (n < p.N) {
-                            const float4 t = *reinterpret_cast<const float4*>(p.bias + n);
-                            v[4 * b] += t.x; v[4 * b + 1] += t.y; v[4 * b + 2] += t.z; v[4 * b + 3] += t.w;
-                        }
+                    for (int b = 0; b < 4; ++b) {                   // (columns past N: beyond the descriptor, zeros)
+                        const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsBias, (n0 + 4 * ecolq(b)) * 4, 0, 0));
+                        v[4 * b] += t[0]; v[4 * b + 1] += t[1]; v[4 * b + 2] += t[2]; v[4 * b + 3] += t[3];
                     }
                 }
                 if constexpr (!PARTIAL && epi == MSN_EPI_GELU) {
@@ -615,7 +649,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
                         for (int r = 0; r < 4; ++r) gelu_both(v[4 * b + r], v[4 * b + r], dg[r]);
                         if (p.aux) stage_chunk(b, dg);
                     }
-                    if (p.aux) tile_flush(p.aux, p.ldaux, m0, n0);
+                    if (p.aux) tile_flush(rsAux, p.ldaux, wm * (32 * MT) + 32 * i, n0);
                 } else if constexpr (!PARTIAL && epi == MSN_EPI_RELU) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -623,7 +657,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
                     float a[16];
                     if constexpr (ADDC) {                              // (both a partial and an aux matrix: the aux tile comes now)
                         f32x4 t[4];
-                        tile_fetch(p.aux, p.ldaux, m0, n0, t);
+                        tile_fetch(rsAux, p.ldaux, wm * (32 * MT) + 32 * i, n0, t);
                         tile_take(t, a);
                     } else {
                         tile_take(pre[t % PW], a);
@@ -661,16 +695,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
                     }
                     f32x4 img[2 * NP];
 #pragma unroll
-                    for (int q = 0; q < 2 * NP; ++q) lds_r128(img[q], stg + (unsigned)(q * PBLK + lane * 16));
+                    for (int q = 0; q < 2 * NP; ++q) lds_r128(img[q], stg + (unsigned)(q * PBLK + eln * 16));
                     if constexpr (NP == 3)
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(img[0]), "+v"(img[1]), "+v"(img[2]), "+v"(img[3]), "+v"(img[4]), "+v"(img[5])::"memory");
                     else
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(img[0]), "+v"(img[1]), "+v"(img[2]), "+v"(img[3])::"memory");
                     __builtin_amdgcn_sched_barrier(0);
-                    unsigned char* blk = static_cast<unsigned char*>(p.C) + ((int64_t)rbk * p.cbC + (n0 >> 4)) * (NP * PBLK) + lane * 16;
+                    const int blk = ((wm * MT + i) * p.cbC + (n0 >> 4)) * (NP * PBLK) + eln * 16;      // inside the tile row's 8 row blocks
 #pragma unroll
                     for (int q = 0; q < 2 * NP; ++q)
-                        if (n0 + 16 * (q / NP) < 16 * p.cbC) *reinterpret_cast<f32x4*>(blk + q * PBLK) = img[q];   // incl. the zero padding block of N % 32 == 16
+                        if (n0 + 16 * (q / NP) < 16 * p.cbC)      // incl. the zero padding block of N % 32 == 16
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, img[q]), rsC, blk + q * PBLK, 0, 0);
                 } else {
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
@@ -678,9 +713,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
                         stage_chunk(b, w);
                     }
                     if constexpr (SLAB)
-                        slab_flush(p.tail_slabs + (int64_t)blockIdx.x * (BM * BN), wm * (32 * MT) + 32 * i, wn * (32 * NT) + 32 * j);
+                        slab_flush(uniform_rsrc(p.tail_slabs + (int64_t)blockIdx.x * (BM * BN), BM * BN * 4), wm * (32 * MT) + 32 * i,
+                                   wn * (32 * NT) + 32 * j);
                     else
-                        tile_flush(static_cast<float*>(p.C), p.ldc, m0, n0);
+                        tile_flush(rsC, p.ldc, wm * (32 * MT) + 32 * i, n0);
                 }
                 if constexpr (CS) {
 #pragma unroll
@@ -695,7 +731,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
                     for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o, 64);
                     cs[e] = t;
                 }
-                if (r16 == 0) {
+                if (r16_e == 0) {
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
                         const int n = n0 + 4 * ecolq(b);
@@ -712,10 +748,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
                     for (int o = 1; o < 32; o <<= 1) t += __shfl_xor(t, o, 64);
                     cs[e] = t;
                 }
-                if (frow == 0) {
+                if (frow_e == 0) {
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
-                        const int n = n0 + 8 * b + 4 * fhalf;
+                        const int n = n0 + 8 * b + 4 * fhalf_e;
                         if (n < p.N)
                             *reinterpret_cast<float4*>(p.colpart + (int64_t)(WM * tm + wm) * p.N + n) =
                                 make_float4(cs[4 * b], cs[4 * b + 1], cs[4 * b + 2], cs[4 * b + 3]);

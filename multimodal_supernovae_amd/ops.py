@@ -929,6 +929,10 @@ if __import__("os").environ.get("MSN_PGEMM_VARIANT"):      # wave layout of the 
     check(lib().msn_set_pgemm_variant(int(__import__("os").environ["MSN_PGEMM_VARIANT"])))     # planes per operand: 3 = fp32 grade (6 products), 2 = 3 products
 
 
+if __import__("os").environ.get("MSN_ATTN_PLANES"):        # 0: long narrow-head attention on the exact-fp32 matrix-core kernels (A/B runs)
+    check(lib().msn_set_attention_planes(int(__import__("os").environ["MSN_ATTN_PLANES"])))
+
+
 F16_PLANES = 16     # `planes` code of the fp16 form: TWO fp16 planes + a power-of-two scale per matrix (msn_plane_split_f16)
 
 

@@ -17,4 +17,8 @@ def test_no_kernel_reads_an_lds_destination_before_its_wait(tmp_path):
     r = subprocess.run(["bash", os.path.join(ROOT, "tools", "lint_kernels.sh")], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, TMPDIR=str(tmp_path)))
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("checked")]
-    assert len(lines) == 9 and all(ln.endswith("-> OK") for ln in lines), r.stdout[-3000:] + r.stderr[-1000:]
+    assert len(lines) == 10 and all(ln.endswith("-> OK") for ln in lines), r.stdout[-3000:] + r.stderr[-1000:]
+    # every pgemm_nt / pgemm_tn instantiation: no scratch (tools/check_scratch.py; the epilogues spilled 68 - 352 B / lane in round 4)
+    scratch = [ln for ln in r.stdout.splitlines() if ln.startswith("scratch check:")]
+    assert scratch and scratch[0].endswith("-> OK"), r.stdout[-3000:]
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]

@@ -1,5 +1,6 @@
 #!/bin/bash
-# ISA lint of every translation unit with hand-counted LDS waits: hipcc -S (device only, in parallel) + tools/check_fragment_waits.py.
+# ISA lint of every translation unit with hand-counted LDS waits: hipcc -S (device only, in parallel) + tools/check_fragment_waits.py,
+# and the scratch check of the plane GEMM kernels (tools/check_scratch.py on the resource-usage remarks of the same compilations).
 # No GPU needed; about 3 minutes on 8 cores.   bash tools/lint_kernels.sh
 set -o pipefail
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -10,7 +11,7 @@ pids=()
 for f in $FILES; do
   rm -f "$OUT/$f.s" "$OUT/$f.err" "$OUT/$f.rc"          # never lint a stale listing
   [ -f "$ROOT/multimodal_supernovae_amd/csrc/$f.hip" ] || continue
-  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -S --cuda-device-only "$ROOT/multimodal_supernovae_amd/csrc/$f.hip" -o "$OUT/$f.s" 2> "$OUT/$f.err"; echo $? > "$OUT/$f.rc" ) &
+  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Rpass-analysis=kernel-resource-usage -S --cuda-device-only "$ROOT/multimodal_supernovae_amd/csrc/$f.hip" -o "$OUT/$f.s" 2> "$OUT/$f.err"; echo $? > "$OUT/$f.rc" ) &
 done
 wait
 rc=0
@@ -21,4 +22,6 @@ for f in $FILES; do
   fi
   python3 "$ROOT/tools/check_fragment_waits.py" "$OUT/$f.s" | tail -n 8 || rc=1
 done
+# no register spills to memory in any plane GEMM kernel or plane attention kernel (remarks of the same compilations)
+python3 "$ROOT/tools/check_scratch.py" "$OUT"/pgemm.err "$OUT"/pgemm_alt1.err "$OUT"/pgemm_alt2.err -- pgemm_nt_kernel pgemm_tn_kernel || rc=1
 exit $rc
