@@ -50,7 +50,8 @@ for bad in (lambda: L.msn_plane_split(None, 4, 4, 4, 3, 0, None, None, None, 0, 
             lambda: L.msn_pgemm_nt_f16(256, 128, 64, fake, None, fake, fake, fake, 128, None, 0, None, 0, None, None, 0, None),
             lambda: L.msn_pgemm_tn_f16(256, 128, 64, fake, fake, fake, None, fake, 64, None, 0, None),
             lambda: L.msn_plane_split_list(0, None, 3, None),
-            lambda: L.msn_set_pgemm_tile_n(256), lambda: L.msn_set_pgemm_variant(9),
+            lambda: L.msn_set_pgemm_tile_n(256), lambda: L.msn_set_pgemm_variant(9), lambda: L.msn_set_attention_planes(64),
+            lambda: L.msn_pgemm_nt(256, 128, 64, 3, fake, fake, fake, 1 << 20, 0, None, 0, None, 0, None, None, 0, None),
             lambda: L.msn_layernorm_fwd_planes(fake, 384, 8, 384, fake, fake, 1e-6, 5, fake, None, 0, fake, fake, None)):
     assert bad() == 1, L.msn_last_error()
 print("HOST SANITIZER PROBE OK")
