@@ -75,7 +75,10 @@ def main():
                          "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "traffic": r["traffic"],
                          "traffic_source": r["traffic_source"]})
         print(f"{workload:22s} B={rows:5d} {d['ms_per_step']:8.2f} ms  {r['achieved']:7.1f} / {r['peak']} {r['unit']} = {r['frac']:.3f}", flush=True)
-    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip() or "unknown"
+    commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    if not commit and os.path.exists(os.path.join(ROOT, ".msn_commit")):      # a gpurun box has no .git: tools/gpu.sh stamps the snapshot
+        commit = open(os.path.join(ROOT, ".msn_commit")).read().strip()
+    commit = commit or "unknown"
     json.dump({"commit": commit, "device": torch.cuda.get_device_name(0), "workloads": rows_out, "hbm_bound_kernels": hbm_kernels()},
               open(out_path, "w"), indent=1)
     print("wrote", out_path)
