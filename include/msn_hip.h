@@ -429,14 +429,17 @@ int msn_attention_bwd(const float* q, int64_t ldq, int64_t q_bstride, const floa
                       const float* dout, int64_t ldd, int64_t d_bstride, float* delta, float* dq,
                       int64_t lddq, int64_t dq_bstride, float* dk, int64_t lddk, int64_t dk_bstride,
                       float* dv, int64_t lddv, int64_t dv_bstride, msn_stream_t stream);
-/* Two implementations sit behind msn_attention_*: vector-ALU kernels (any head width <= 128, any
- * length; the reference-native 8-wide heads, widths that are not a multiple of 4, unaligned operands)
- * and matrix-core kernels (v_mfma_f32_16x16x4_f32; any length -- chunked beyond 128 tokens; every head
- * width that is a multiple of 4 up to 128, run as the next multiple of 16 with zero columns: the ViT
- * towers, the reference's 16-wide spectrum heads, its default 128-wide heads (emb 256 / 2 heads)).
- * mode 0 = automatic (default: matrix cores for widths >= 16 where they apply), 1 = always vector-ALU,
- * 2 = matrix cores whenever applicable, narrow heads included (measured no faster there).
- * Process-wide; meant for tests. */
+/* Two implementations sit behind msn_attention_*: vector-ALU kernels (head widths up to 32, any length; the
+ * reference-native 8-wide heads, widths that are not a multiple of 4, unaligned operands) and matrix-core
+ * kernels (v_mfma_f32_16x16x4_f32; any length -- chunked beyond 128 tokens; every head width that is a
+ * multiple of 4 up to 128, run as the next multiple of 16 with zero columns: the ViT towers, the
+ * reference's 16-wide spectrum heads -- beyond 128 tokens on the bf16 planes, msn_set_attention_planes --
+ * and its default 128-wide heads (emb 256 / 2 heads)).  A head WIDER THAN 32 must be a multiple of 4 on
+ * 16-byte aligned rows (MSN_ERR_SHAPE otherwise: pad the heads with zero columns -- the Python binding does;
+ * the 64- / 128-wide vector-ALU instantiations of rounds 1-4 spilled up to 2 KB per lane and are gone).
+ * mode 0 = automatic (default: matrix cores for widths >= 16 where they apply), 1 = vector-ALU wherever it
+ * exists (widths up to 32), 2 = matrix cores whenever applicable, narrow heads included (measured no faster
+ * there).  Process-wide; meant for tests. */
 int msn_set_attention_path(int mode);
 /* Self-attention backward over up to 128 tokens with heads up to 64 wide (the ViT towers): 1 (default) = ONE launch that
  * holds Q, K, V and dO of a (sample, head) in LDS together -- one pass over the operands, delta never in memory; 0 = the

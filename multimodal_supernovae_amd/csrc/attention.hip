@@ -440,8 +440,12 @@ static int g_attn_path = 0;  // 0 = automatic (matrix cores for head widths >= 1
                              // there, tools/bench_attention.py), 1 = always the vector-ALU kernels, 2 = matrix cores
                              // whenever applicable
 
+// The vector-ALU kernels exist for head widths up to 32.  (Their 64- and 128-wide instantiations kept a row of the head in
+// registers per lane: 256 VGPRs + 256 AGPRs and 164 - 1972 bytes of scratch per lane in the backward -- and were only reached by
+// widths above 32 that are not a multiple of 4, or by misaligned operands; those are refused now: the caller pads the head to a
+// multiple of 4 -- ops.attention_fwd / attention_bwd do -- and the matrix-core kernels take it.)
 static int pad_head(int s) {
-    for (int c : {4, 8, 16, 32, 64, 128})
+    for (int c : {4, 8, 16, 32})
         if (s <= c) return c;
     return -1;
 }
@@ -468,9 +472,7 @@ static int rows_per_lane(int S, int t, int64_t pairs) {
             if (R == 2) hipLaunchKernelGGL((KERNEL<16, 2>), grid, block, lds, st, args);           \
             else hipLaunchKernelGGL((KERNEL<16, 1>), grid, block, lds, st, args);                  \
             break;                                                                               \
-        case 32: hipLaunchKernelGGL((KERNEL<32, 1>), grid, block, lds, st, args); break;           \
-        case 64: hipLaunchKernelGGL((KERNEL<64, 1>), grid, block, lds, st, args); break;           \
-        default: hipLaunchKernelGGL((KERNEL<128, 1>), grid, block, lds, st, args); break;          \
+        default: hipLaunchKernelGGL((KERNEL<32, 1>), grid, block, lds, st, args); break;           \
     }
 
 static int check_attn(const char* who, int B, int H, int Tq, int Tk, int s) {
@@ -505,6 +507,16 @@ extern "C" int msn_attention_fwd(const float* q, int64_t ldq, int64_t q_bstride,
         if (mattn_applicable(m) && (head_dim >= 16 || g_attn_path == 2)) return mattn_forward(m, st);
     }
     const int S = pad_head(head_dim);
+    if (S < 0) {                                           // wider than 32: matrix cores only (also under mode 1)
+        MAttn m = {};
+        m.q = q; m.k = k; m.v = v; m.out = out; m.mask = key_mask; m.lse = lse;
+        m.ldq = ldq; m.ldk = ldk; m.ldv = ldv; m.ldo = ldo;
+        m.q_bs = q_bstride; m.k_bs = k_bstride; m.v_bs = v_bstride; m.o_bs = o_bstride;
+        m.B = B; m.H = H; m.Tq = Tq; m.Tk = Tk; m.hd = head_dim; m.scale = scale;
+        MSN_REQUIRE(mattn_applicable(m), "msn_attention_fwd: a head width above 32 (%d) must be a multiple of 4 with 16-byte aligned "
+                    "rows (pad the heads with zero columns)", head_dim);
+        return mattn_forward(m, st);
+    }
     const int R = rows_per_lane(S, Tq, (int64_t)B * H);
     const unsigned bs = block_for((int)cdiv(Tq, R));
     const dim3 grid((unsigned)cdiv(Tq, (int64_t)bs * R), H, B), block(bs);
@@ -550,6 +562,18 @@ extern "C" int msn_attention_bwd(const float* q, int64_t ldq, int64_t q_bstride,
         if (mattn_applicable(m) && (head_dim >= 16 || g_attn_path == 2)) return mattn_backward(m, st);
     }
     const int S = pad_head(head_dim);
+    if (S < 0) {                                           // wider than 32: matrix cores only (also under mode 1)
+        MAttn m = {};
+        m.q = q; m.k = k; m.v = v; m.o = out; m.dout = dout; m.dq = dq; m.dk = dk; m.dv = dv;
+        m.mask = key_mask; m.lse = const_cast<float*>(lse); m.delta = delta;
+        m.ldq = ldq; m.ldk = ldk; m.ldv = ldv; m.ldo = ldo; m.ldd = ldd; m.lddq = lddq; m.lddk = lddk; m.lddv = lddv;
+        m.q_bs = q_bstride; m.k_bs = k_bstride; m.v_bs = v_bstride; m.o_bs = o_bstride; m.d_bs = d_bstride;
+        m.dq_bs = dq_bstride; m.dk_bs = dk_bstride; m.dv_bs = dv_bstride;
+        m.B = B; m.H = H; m.Tq = Tq; m.Tk = Tk; m.hd = head_dim; m.scale = scale;
+        MSN_REQUIRE(mattn_applicable(m), "msn_attention_bwd: a head width above 32 (%d) must be a multiple of 4 with 16-byte aligned "
+                    "rows (pad the heads with zero columns)", head_dim);
+        return mattn_backward(m, st);
+    }
     {
         const int R = rows_per_lane(S, Tq, (int64_t)B * H);
         const unsigned bs = block_for((int)cdiv(Tq, R));

@@ -366,11 +366,31 @@ def _bt(t):
     return t.stride(1), t.stride(0)
 
 
+def _needs_head_padding(hd, *tensors):
+    """Heads wider than 32 run on the matrix cores only, which take widths that are a multiple of 4 on 16-byte aligned rows;
+    anything else is padded with zero columns here (zero columns change no score and no output column)."""
+    if hd <= 32:
+        return False
+    return hd % 4 != 0 or any(t.data_ptr() % 16 or t.stride(1) % 4 or t.stride(0) % 4 for t in tensors)
+
+
+def _pad_heads(t, heads, hd, hp):
+    B, T, _ = t.shape
+    out = torch.zeros((B, T, heads, hp), dtype=torch.float32, device=t.device)
+    out[..., :hd] = t.reshape(B, T, heads, hd)
+    return out.view(B, T, heads * hp)
+
+
 def attention_fwd(q, k, v, mask_u8, heads, scale, q_shared=False):
     """q: (B, Tq, E) (or (1, Tq, E) with q_shared), k, v: (B, Tk, E) views (column slices allowed)."""
     B, Tk, E = k.shape
     Tq = q.shape[1]
     hd = E // heads
+    if _needs_head_padding(hd, q, k, v):
+        hp = (hd + 3) // 4 * 4
+        qp, kp, vp = (_pad_heads(t, heads, hd, hp) for t in (q, k, v))
+        op, lse = attention_fwd(qp, kp, vp, mask_u8, heads, scale, q_shared)
+        return op.view(B, Tq, heads, hp)[..., :hd].reshape(B, Tq, E), lse
     out = torch.empty((B, Tq, E), dtype=torch.float32, device=k.device)
     lse = torch.empty((B, heads, Tq, 2), dtype=torch.float32, device=k.device)
     ldq, qbs = _bt(q)
@@ -389,6 +409,14 @@ def attention_bwd(q, k, v, mask_u8, heads, scale, out, lse, dout, dq, dk, dv, q_
     B, Tk, E = k.shape
     Tq = out.shape[1]
     hd = E // heads
+    if _needs_head_padding(hd, q, k, v, out, dout, dq, dk, dv):
+        hp = (hd + 3) // 4 * 4
+        qp, kp, vp, op, dop = (_pad_heads(t, heads, hd, hp) for t in (q, k, v, out, dout))
+        gq, gk, gv = torch.empty_like(qp), torch.empty_like(kp), torch.empty_like(vp)
+        attention_bwd(qp, kp, vp, mask_u8, heads, scale, op, lse, dop, gq, gk, gv, q_shared)
+        for dst, src in ((dq, gq), (dk, gk), (dv, gv)):
+            dst.copy_(src.view(src.shape[0], src.shape[1], heads, hp)[..., :hd].reshape(src.shape[0], src.shape[1], E))
+        return dq, dk, dv
     delta = torch.empty((B, heads, Tq), dtype=torch.float32, device=k.device)
     ldq, qbs = _bt(q)
     if q_shared:

@@ -197,3 +197,62 @@ def test_long_sequence_matrix_core_path(B, heads, hd, Tq, Tk):
             torch.testing.assert_close(got.cpu().double(), want, rtol=3e-4, atol=3e-5, msg=lambda m: f"{name}: {m}")
     finally:
         _lib.lib().msn_set_attention_path(0)
+
+
+@pytest.mark.parametrize("hd,heads", [(33, 2), (50, 1), (70, 2), (127, 1)])
+@pytest.mark.parametrize("T", [40, 200])
+def test_wide_heads_of_odd_width_are_padded_on_the_host(hd, heads, T):
+    """Heads wider than 32 whose width is not a multiple of 4 (or whose rows are not 16-byte aligned): the binding pads them
+    with zero columns and the matrix-core kernels take them (the spilling 64- / 128-wide vector-ALU kernels are gone); the
+    C-ABI itself refuses such a width."""
+    from multimodal_supernovae_amd import _lib, ops
+    g = torch.Generator().manual_seed(hd * 7 + T)
+    B, E = 2, heads * hd
+    q, k, v, dout = (torch.randn(B, T, E, generator=g) for _ in range(4))
+    mask = torch.rand(B, T, generator=g) > 0.3
+    mask[:, 0] = True
+    scale = 1.0 / math.sqrt(E)
+    qr, kr, vr = (t.double().requires_grad_() for t in (q, k, v))
+    ref = _ref(qr, kr, vr, mask, heads, scale)
+    ref.backward(dout.double())
+    qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+    mu8 = ops._mask_u8(mask.cuda())
+    out, lse = ops.attention_fwd(qc, kc, vc, mu8, heads, scale)
+    torch.testing.assert_close(out.cpu().double(), ref.detach(), rtol=1e-4, atol=3e-5)
+    dq, dk, dv = (torch.full_like(t, float("nan")) for t in (qc, kc, vc))
+    ops.attention_bwd(qc, kc, vc, mu8, heads, scale, out, lse, dout.cuda(), dq, dk, dv)
+    for got, want in ((dq, qr.grad), (dk, kr.grad), (dv, vr.grad)):
+        torch.testing.assert_close(got.cpu().double(), want, rtol=3e-4, atol=3e-5)
+    if hd % 4:
+        lse_c = torch.empty(B, heads, T, 2, device="cuda")
+        rc = _lib.lib().msn_attention_fwd(ops.ptr(qc), E, T * E, ops.ptr(kc), E, T * E, ops.ptr(vc), E, T * E, ops.ptr(mu8), B, heads, T, T,
+                                          hd, scale, ops.ptr(out), E, T * E, ops.ptr(lse_c), ops.stream_ptr())
+        assert rc == 1, "the C-ABI must refuse a head wider than 32 that is not a multiple of 4"
+
+
+@pytest.mark.parametrize("B,T,hd,heads,masked", [(4, 65, 64, 6, False), (3, 65, 64, 6, True), (2, 128, 32, 3, True), (5, 17, 16, 2, False),
+                                                 (3, 33, 16, 3, True), (4, 65, 48, 1, False)])
+def test_plane_output_backward_against_fp64(B, T, hd, heads, masked):
+    """msn_attention_bwd_planes (dqkv leaves the one-pass backward as bf16 planes + column sums) against the fp64 formula --
+    until now it was only compared with msn_attention_bwd + msn_plane_split (tests/test_attention_fused_gpu.py)."""
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + T + hd)
+    E = heads * hd
+    qkv = torch.randn(B, T, 3 * E, generator=g)
+    dout = torch.randn(B, T, E, generator=g)
+    mask = None
+    if masked:
+        mask = torch.rand(B, T, generator=g) > 0.3
+        mask[:, 0] = True
+        mask[-1] = False
+    scale = 1.0 / math.sqrt(hd)
+    qr, kr, vr = (qkv[..., i * E:(i + 1) * E].double().requires_grad_() for i in range(3))
+    ref = _ref(qr, kr, vr, mask, heads, scale)
+    ref.backward(dout.double())
+    want = torch.cat([qr.grad, kr.grad, vr.grad], -1).view(B * T, 3 * E)
+    qc = qkv.cuda()
+    mu8 = ops._mask_u8(mask.cuda()) if masked else None
+    out, lse = ops.attention_fwd(qc[..., :E], qc[..., E:2 * E], qc[..., 2 * E:], mu8, heads, scale)
+    got, cs = ops.attention_bwd_planes(qc, heads, scale, out, lse, dout.cuda(), 3, want_colsum=True, mask_u8=mu8)
+    torch.testing.assert_close(got.to_float().cpu().double(), want, rtol=3e-4, atol=3e-5)
+    torch.testing.assert_close(cs.cpu().double(), want.sum(0), rtol=1e-4, atol=1e-4 * float(want.abs().sum(0).max()))

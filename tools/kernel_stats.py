@@ -12,7 +12,8 @@ top = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 40
 agg = collections.defaultdict(lambda: [0, 0])
 for r in csv.DictReader(open(path)):
     d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-    name = re.sub(r"\(.*", "", r["Kernel_Name"])
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "")     # (kernels of an unnamed namespace: keep their own name)
+    name = re.sub(r"\(.*", "", name)
     name = re.sub(r"^void ", "", name)
     a = agg[name]
     a[0] += 1

@@ -22,7 +22,7 @@ calls = collections.Counter()
 for f in glob.glob(f"gpurun_out/pmck_{tag}_*/*/*counter_collection.csv"):
     seen = set()
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         key = (f, r["Dispatch_Id"])
         if key not in seen and r["Counter_Name"] == "SQ_WAVE_CYCLES":
