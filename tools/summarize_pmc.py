@@ -18,7 +18,7 @@ def load(root, name):
     d = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0, 0]))
     for f in files:
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0]
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
             k = k.replace("void ", "")
             keys = [k]
             if "sgemm_kernel" in k or "sgemm_dma_kernel" in k or "sgemm_list_kernel" in k:      # per template instance (layout = the two bools) and the aggregate row
