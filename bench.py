@@ -475,9 +475,33 @@ def main():
     step()                      # rehearsal of the serial order (allocator blocks, first-use code objects): not measured
     torch.cuda.synchronize()
     ops.GEMM_PROFILE = []
+    ops.ATTN_PROFILE = []
     step()
     torch.cuda.synchronize()
     prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+    aprof, ops.ATTN_PROFILE = ops.ATTN_PROFILE, None
+    # the attention launches of the same step (msn_attention_fwd / _bwd; the ViT towers' one-pass backward with plane output is a
+    # different entry point and is not in this list), by (heads, head width, tokens): for the reference-native three-tower
+    # workload they, not the GEMMs, are where the step's time goes
+    attention = None
+    if aprof:
+        groups = {}
+        for ev0, ev1, fl, shape, kind in aprof:
+            gk = f"{shape[1]} heads x {shape[4]}, {shape[2]} x {shape[3]} tokens"
+            gentry = groups.setdefault(gk, {"launches_per_step": 0, "ms_per_step_in_kernel": 0.0, "algorithmic_gflop_per_step": 0.0})
+            gentry["launches_per_step"] += 1
+            gentry["ms_per_step_in_kernel"] += ev0.elapsed_time(ev1)
+            gentry["algorithmic_gflop_per_step"] += fl / 1e9
+        for gk, gentry in groups.items():
+            gentry["achieved_tflops"] = gentry["algorithmic_gflop_per_step"] / max(gentry["ms_per_step_in_kernel"], 1e-9)
+            wide = int(gk.split(" heads x ")[1].split(",")[0])
+            long = max(int(x) for x in gk.split(", ")[1].split(" tokens")[0].split(" x ")) > 128
+            gentry["kernels"] = ("msn::pattn_* (fp32-grade on v_mfma_f32_16x16x32_bf16: 6 plane products, probabilities split in registers)"
+                                 if (12 < wide <= 16 and long) else
+                                 "msn::attn_* (vector ALU)" if wide < 16 else "msn::mattn_* (v_mfma_f32_16x16x4_f32)")
+        a_ms = sum(v["ms_per_step_in_kernel"] for v in groups.values())
+        attention = {"ms_per_step_in_kernel": a_ms, "launches_per_step": len(aprof),
+                     "flop_count": "4 T^2 head_dim per (sample, head) forward, 10 T^2 head_dim backward", "by_shape": groups}
     fp32_side = None
     if args.workload == "vit_b16_bf16_lc":
         # cfg5: the roofline object is that of the bf16-resident launches (epilogue key >= 100) against the bf16 matrix peak; the
@@ -675,8 +699,10 @@ def main():
                          "algorithmic_bytes_per_launch": gemm_bytes / max(len(prof), 1),
                          **({"mfma_products_per_multiply_add": products, "algorithmic_tflops": algorithmic_tflops,
                              "note": "achieved / peak count EXECUTED bf16 MFMA flops (products x algorithmic); "
-                                     "algorithmic_tflops is the fp32-equivalent rate of the same launches"} if products else {}),
-                         **({"fp32_launches": fp32_side} if fp32_side is not None else {})},
+                                     "algorithmic_tflops is the fp32-equivalent rate of the same launches; algorithmic_bytes_per_launch counts "
+                                     "plane operands / plane results at their HBM format (2 bytes x planes per element), fp32 matrices at 4"} if products else {}),
+                         **({"fp32_launches": fp32_side} if fp32_side is not None else {}),
+                         **({"attention": attention} if attention is not None else {})},
             "comm": comm,
         }
         if not headline:

@@ -11,6 +11,7 @@ from ._lib import check, lib, ptr, stream_ptr
 # launch stream: entries are (start_event, end_event, algorithmic_flops, (opA, opB, M, N, K, epilogue), has_aux).  None = no
 # instrumentation.
 GEMM_PROFILE = None
+ATTN_PROFILE = None      # bench.py: list of (event, event, algorithmic flops, (B, H, Tq, Tk, head_dim), 'fwd' | 'bwd') per attention call
 
 # Inner-product precision used by sgemm() when the caller passes none (include/msn_hip.h):
 # PREC_F32 exact fp32 MFMA (default), PREC_BF16X3 split-bf16 (fp32-grade, ~1e-5), PREC_BF16 plain bf16.
@@ -398,9 +399,16 @@ def attention_fwd(q, k, v, mask_u8, heads, scale, q_shared=False):
         qbs = 0
     ldk, kbs = _bt(k)
     ldv, vbs = _bt(v)
+    prof = ATTN_PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     check(lib().msn_attention_fwd(ptr(_f32c(q, "q")), ldq, qbs, ptr(k), ldk, kbs, ptr(v), ldv, vbs, ptr(mask_u8),
                                   B, heads, Tq, Tk, hd, scale, ptr(out), E, Tq * E, ptr(lse), stream_ptr()),
           "msn_attention_fwd")
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, 4.0 * B * heads * Tq * Tk * hd, (B, heads, Tq, Tk, hd), "fwd"))
     return out, lse
 
 
@@ -427,10 +435,17 @@ def attention_bwd(q, k, v, mask_u8, heads, scale, out, lse, dout, dq, dk, dv, q_
     lq, bq = _bt(dq)
     lk, bk = _bt(dk)
     lv, bv = _bt(dv)
+    prof = ATTN_PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     check(lib().msn_attention_bwd(ptr(q), ldq, qbs, ptr(k), ldk, kbs, ptr(v), ldv, vbs, ptr(mask_u8), B, heads, Tq,
                                   Tk, hd, scale, ptr(out), E, Tq * E, ptr(lse), ptr(_f32c(dout, "dout")), ldd, dbs,
                                   ptr(delta), ptr(dq), lq, bq, ptr(dk), lk, bk, ptr(dv), lv, bv, stream_ptr()),
           "msn_attention_bwd")
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, 10.0 * B * heads * Tq * Tk * hd, (B, heads, Tq, Tk, hd), "bwd"))
     return dq, dk, dv
 
 
@@ -1115,7 +1130,11 @@ def pgemm_nt(a, w, bias=None, epilogue=EPI_NONE, aux=None, out_planes=False, wan
                                  ptr(cs), ptr(ws), nb, stream_ptr()), "msn_pgemm_nt")
     if prof is not None:
         ev1.record()
-        prof.append((ev0, ev1, 2.0 * M * N * K, (OP_N, OP_T, M, N, K, 200 + epilogue), aux is not None))
+        # bytes this launch MUST move in the formats it is given: plane operands are 2 bytes x planes per element (6 for the
+        # fp32-grade form), the result fp32 or planes, the aux matrix (gelu' written / read, residual read) fp32
+        pb = 2.0 * a.planes
+        nbytes = pb * (M * K + N * K) + (pb if out_planes else 4.0) * M * N + (4.0 * M * N if aux is not None else 0.0)
+        prof.append((ev0, ev1, 2.0 * M * N * K, (OP_N, OP_T, M, N, K, 200 + epilogue), aux is not None, nbytes))
     out = (c, aux) if ret_aux else (c,)
     if want_colsum:
         out = out + (cs,)
@@ -1143,7 +1162,7 @@ def pgemm_tn(dy, x):
         check(L.msn_pgemm_tn(M, N, K, dy.planes, ptr(dy.buf), ptr(x.buf), ptr(c), K, ptr(ws), nb, stream_ptr()), "msn_pgemm_tn")
     if prof is not None:
         ev1.record()
-        prof.append((ev0, ev1, 2.0 * M * N * K, (OP_T, OP_N, N, K, M, 200), False))
+        prof.append((ev0, ev1, 2.0 * M * N * K, (OP_T, OP_N, N, K, M, 200), False, 2.0 * dy.planes * (M * N + M * K) + 4.0 * N * K))
     return c
 
 

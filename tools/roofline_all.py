@@ -73,7 +73,8 @@ def main():
                          "peak": r["peak"], "unit": r["unit"], "frac": r["frac"], "launches_per_step": r["launches_per_step"],
                          "ms_per_step_in_kernel": r["ms_per_step_in_kernel"],
                          "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "traffic": r["traffic"],
-                         "traffic_source": r["traffic_source"]})
+                         "traffic_source": r["traffic_source"],
+                         "attention": r.get("attention")})      # msn_attention_fwd / _bwd launches of the same step, by shape
         print(f"{workload:22s} B={rows:5d} {d['ms_per_step']:8.2f} ms  {r['achieved']:7.1f} / {r['peak']} {r['unit']} = {r['frac']:.3f}", flush=True)
     commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     if not commit and os.path.exists(os.path.join(ROOT, ".msn_commit")):      # a gpurun box has no .git: tools/gpu.sh stamps the snapshot
