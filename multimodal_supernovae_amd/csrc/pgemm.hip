@@ -699,10 +699,10 @@ extern "C" size_t msn_pgemm_tn_workspace_bytes(int64_t M, int N, int K, int plan
     return t.splits > 1 ? sizeof(float) * (size_t)t.splits * N * K : 0;
 }
 
-template <int NP, int BQ, bool DUAL, int WM = 2, int WN = 4>
+template <int NP, int BQ, bool DUAL, int WM = 2, int WN = 4, int FOLDN = 1>
 static void launch_tn(const PgemmArgs& a, bool swap, int grid, hipStream_t st) {
-    if (swap) hipLaunchKernelGGL((pgemm_tn_kernel<NP, BQ, true, DUAL, WM, WN>), dim3((unsigned)grid), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((pgemm_tn_kernel<NP, BQ, false, DUAL, WM, WN>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    if (swap) hipLaunchKernelGGL((pgemm_tn_kernel<NP, BQ, true, DUAL, WM, WN, false, FOLDN>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((pgemm_tn_kernel<NP, BQ, false, DUAL, WM, WN, false, FOLDN>), dim3((unsigned)grid), dim3(512), 0, st, a);
 }
 
 static int pgemm_tn_impl(int64_t M, int N, int K, int planes, const void* A, const void* B, float* C, int64_t ldc, void* ws,
@@ -729,7 +729,10 @@ static int pgemm_tn_impl(int64_t M, int N, int K, int planes, const void* A, con
     hipStream_t st = static_cast<hipStream_t>(stream);
     // (2 x 4 waves: the 64 x 64 wave tiles that gain 7-12 % on the NT kernel LOSE 3-4 % here -- 374 / 151 / 452 / 454 us
     // against 384 / 157 / 469 / 470 on the four headline weight gradients; that instantiation is no longer built)
-    if (planes == 3) launch_tn<3, 128, true>(a, t.swap, grid, st);
+    // (three planes: each tile's p0 q0 temporaries run over TWO K-steps before they are folded into the running sums, the four tiles
+    // of a wave staggered so that two finish per step -- 351 / 151 / 426 / 426 us against 372 / 160 / 450 / 452 with a fold per step
+    // on the four headline weight gradients, and 0.2 - 0.4 x the exact-fp32 kernel's error either way)
+    if (planes == 3) launch_tn<3, 128, true, 2, 4, 2>(a, t.swap, grid, st);
     else if (f16 && t.swap) hipLaunchKernelGGL((pgemm_tn_kernel<2, 128, true, true, 2, 4, true>), dim3((unsigned)grid), dim3(512), 0, st, a);
     else if (f16) hipLaunchKernelGGL((pgemm_tn_kernel<2, 128, false, true, 2, 4, true>), dim3((unsigned)grid), dim3(512), 0, st, a);
     else launch_tn<2, 128, false>(a, t.swap, grid, st);

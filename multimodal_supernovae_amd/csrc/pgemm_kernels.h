@@ -868,7 +868,7 @@ __device__ __forceinline__ void ds_read_tr_o(bf16x4& dst, unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
 }
 
-template <int NP, int BQ, bool SWAP, bool DUAL, int WM = 2, int WN = 4, bool F16 = false>
+template <int NP, int BQ, bool SWAP, bool DUAL, int WM = 2, int WN = 4, bool F16 = false, int FOLDN = 1>
 __global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(const PgemmArgs p) {
     static_assert(WM * WN == 8, "eight waves");
     constexpr int PHB = 16 * NP, QHB = (BQ / 16) * NP;       // half-block images per K-step: P side, Q side
@@ -904,7 +904,21 @@ __global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(const PgemmArgs p) {
     // ---- LDS-DMA: piece id = two consecutive half-block images hb = 2 id + (lane >> 5); image hb of the P side is column
     // block hb / NP, plane hb % NP: in the plane matrix its 1-KB block is block (cb0 * NP + hb) of the row block.
     const int sub = lane >> 5, j = lane & 31;
-    const unsigned char* pbase[MAXQ];
+    // Sources through BUFFER descriptors (scalar registers: one per operand, based at this split's first row block and this
+    // tile's first column block) + a 32-bit byte offset per lane + a scalar offset per K-step: no 64-bit pointers in vector
+    // registers (the five pointer pairs of the older form were what the register file could not hold beside the temporaries
+    // of FOLDN = 2; the descriptors alone are worth 4 % of the kernel).
+    typedef __amdgpu_buffer_rsrc_t rsrc_t;
+    auto uniform_rsrc = [&](const unsigned char* base, int64_t bytes) -> rsrc_t {
+        const uint64_t a = reinterpret_cast<uint64_t>(base);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        const int nb = __builtin_amdgcn_readfirstlane((int)min<int64_t>(bytes, 0x7fffffff));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), (short)0, nb, 0x00020000);
+    };
+    const int64_t rbstepP = (int64_t)cbP * (NP * PBLK), rbstepQ = (int64_t)cbQ * (NP * PBLK);
+    const rsrc_t rsP = uniform_rsrc(Pm + ((int64_t)rb0 * cbP + tp * 16) * (NP * PBLK), (int64_t)(rb1 - rb0) * rbstepP);
+    const rsrc_t rsQ = uniform_rsrc(Qm + ((int64_t)rb0 * cbQ + tq * (BQ / 16)) * (NP * PBLK), (int64_t)(rb1 - rb0) * rbstepQ);
+    unsigned plane_off[MAXQ];                        // the lane's byte offset of piece q inside a row block
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {
         const int id = min(wave + 8 * q, PIECES - 1);
@@ -916,15 +930,14 @@ __global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(const PgemmArgs p) {
         const int hbc = min(hb, (cbs - cb0) * NP - 1);                      // past the matrix: clamped, never stored
         const int rpos = j >> 1;                                            // row position in the image
         const int rsrc = (rpos & 3) + 4 * ((rpos >> 2) ^ (cbp & 1));        // source row of that position
-        pbase[q] = (isP ? Pm : Qm) + ((int64_t)rb0 * cbs + cb0) * (NP * PBLK) + (int64_t)hbc * PBLK + rsrc * 32 + (j & 1) * 16;
+        plane_off[q] = (unsigned)(hbc * PBLK + rsrc * 32 + (j & 1) * 16);
     }
-    const int64_t rbstepP = (int64_t)cbP * (NP * PBLK), rbstepQ = (int64_t)cbQ * (NP * PBLK);
     int p_k = 0, p_slot = 0;
     auto issue_q = [&](int q) {
         const int id = wave + 8 * q;
         if (id < PIECES) {
-            const int64_t off = (int64_t)(p_k >> 1) * (id < PP ? rbstepP : rbstepQ) + (p_k & 1) * 512;
-            __builtin_amdgcn_global_load_lds((gptr_t*)(pbase[q] + off), (lptr_t*)(lds + p_slot * SLOT + id * PBLK), 16, 0, 0);
+            const int soff = (int)((p_k >> 1) * (id < PP ? rbstepP : rbstepQ)) + (p_k & 1) * 512;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(id < PP ? rsP : rsQ, (lptr_t*)(lds + p_slot * SLOT + id * PBLK), 16, (int)plane_off[q], soff, 0, 0);
         }
     };
     auto issue_chunk = [&](auto c_) {
@@ -991,30 +1004,67 @@ __global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(const PgemmArgs p) {
             else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, c, 0, 0, 0);
         }
     };
-    // DUAL: zero-accumulator MFMA + round-to-nearest fold of the p0.q0 product (see pgemm_nt_kernel)
-    f32x16 tbig[2];
+    // DUAL: zero-accumulator MFMA + round-to-nearest fold of the p0.q0 product (see pgemm_nt_kernel).  FOLDN = 1: every
+    // K-step's product is folded (64 VALU adds per tile and step, which the matrix pipe waits for: one SIMD issues either).
+    // FOLDN = 2: a temporary collects the p0.q0 products of TWO K-steps before its fold (the second MFMA truncates at one ulp
+    // of a 32-row partial sum, far below the running sum's), half the adds; the tiles are staggered, see mult_big.
+    constexpr int NTB = FOLDN > 1 ? MT * NT : 2;
+    f32x16 tbig[NTB];
+    if constexpr (FOLDN > 1) {
+#pragma unroll
+        for (int u = 0; u < NTB; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tbig[u][e] = 0.f;
+    }
     auto fold = [&](auto v_) {
         constexpr int v = decltype(v_)::value;
-        acc[v / NT][v % NT] += tbig[v & 1];
+        acc[v / NT][v % NT] += tbig[v % NTB];
         asm volatile("" : "+v"(acc[v / NT][v % NT]));
     };
-    auto mult_big = [&](const bf16x4 (&a)[MT][2], const bf16x4 (&b)[NT][2]) {
-        static_for<0, MT * NT>([&](auto u_) {
-            constexpr int u = decltype(u_)::value;
-            if constexpr (u >= 2) fold(std::integral_constant<int, u - 2>{});
+    auto big1 = [&](const bf16x4 (&a)[MT][2], const bf16x4 (&b)[NT][2], auto u_, auto chain_) {
+        constexpr int u = decltype(u_)::value;
+        constexpr bool CHAIN = decltype(chain_)::value;
+        const bf16x8 av = __builtin_shufflevector(a[u / NT][0], a[u / NT][1], 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 bv = __builtin_shufflevector(b[u % NT][0], b[u % NT][1], 0, 1, 2, 3, 4, 5, 6, 7);
+        if constexpr (CHAIN) {
+            tbig[u % NTB] = mfma1(av, bv, tbig[u % NTB]);
+        } else {
             f32x16 z;
 #pragma unroll
             for (int e = 0; e < 16; ++e) z[e] = 0.f;
-            const bf16x8 av = __builtin_shufflevector(a[u / NT][0], a[u / NT][1], 0, 1, 2, 3, 4, 5, 6, 7);
-            const bf16x8 bv = __builtin_shufflevector(b[u % NT][0], b[u % NT][1], 0, 1, 2, 3, 4, 5, 6, 7);
-            tbig[u & 1] = mfma1(av, bv, z);
-            asm volatile("" : "+v"(tbig[u & 1]));
-        });
+            tbig[u % NTB] = mfma1(av, bv, z);
+        }
+        asm volatile("" : "+v"(tbig[u % NTB]));
+    };
+    using CH = std::integral_constant<bool, true>;
+    using ZR = std::integral_constant<bool, false>;
+    auto mult_big = [&](const bf16x4 (&a)[MT][2], const bf16x4 (&b)[NT][2], auto par_) {
+        constexpr int PAR = decltype(par_)::value;
+        if constexpr (FOLDN == 1) {
+            static_for<0, MT * NT>([&](auto u_) {
+                constexpr int u = decltype(u_)::value;
+                if constexpr (u >= 2) fold(std::integral_constant<int, u - 2>{});
+                big1(a, b, u_, ZR{});
+            });
+        } else {
+            // two tiles FINISH a chain of two K-steps here (odd tiles in even steps, even tiles in odd steps) and are folded into
+            // the running sums while the other two START theirs from zero: only two temporaries live across a step boundary
+            static_assert(MT * NT == 4, "four tiles per wave");
+            constexpr int f0 = PAR == 0 ? 1 : 0, f1 = f0 + 2, s0 = 1 - f0, s1 = s0 + 2;
+            big1(a, b, std::integral_constant<int, f0>{}, CH{});
+            big1(a, b, std::integral_constant<int, f1>{}, CH{});
+            big1(a, b, std::integral_constant<int, s0>{}, ZR{});
+            fold(std::integral_constant<int, f0>{});
+            big1(a, b, std::integral_constant<int, s1>{}, ZR{});
+            fold(std::integral_constant<int, f1>{});
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto fold_pending = [&]() {
-        fold(std::integral_constant<int, MT * NT - 2>{});
-        fold(std::integral_constant<int, MT * NT - 1>{});
+    auto fold_pending = [&](auto par_) {
+        if constexpr (FOLDN == 1) {
+            fold(std::integral_constant<int, MT * NT - 2>{});
+            fold(std::integral_constant<int, MT * NT - 1>{});
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
     auto mult = [&](const bf16x4 (&a)[MT][2], const bf16x4 (&b)[NT][2], auto small_) {
@@ -1054,11 +1104,11 @@ __global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(const PgemmArgs p) {
                 wait_lgkm<2 * MT>();
             }
             if constexpr (pb == 0) {
-                if constexpr (DUAL) mult_big(fa[QA], fb0[PAR]);
+                if constexpr (DUAL) mult_big(fa[QA], fb0[PAR], par_);
                 else mult(fa[QA], fb0[PAR], BIG{});
             } else {
                 mult(fa[QA], fbh[pb - 1], SML{});
-                if constexpr (DUAL && pb == 1) fold_pending();
+                if constexpr (DUAL && pb == 1) fold_pending(par_);
             }
             issue_chunk(std::integral_constant<int, pb>{});
             __builtin_amdgcn_sched_barrier(0);
@@ -1109,6 +1159,10 @@ __global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(const PgemmArgs p) {
         step(std::integral_constant<int, 1>{});
     }
     wait_lgkm<0>();
+    if constexpr (DUAL && FOLDN > 1) {               // the odd tiles started a chain in the last step: one product each, fold it
+        fold(std::integral_constant<int, 1>{});
+        fold(std::integral_constant<int, 3>{});
+    }
 
     // ---- epilogue: C[n][k] (or this split's slab)
     float* out = p.splits > 1 ? p.slabs + (int64_t)split * p.N * p.K : static_cast<float*>(p.C);
