@@ -54,6 +54,13 @@ def build(force=False, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        # every kernel a translation unit launches must have been instantiated by one of them: resolve all symbols now (hipcc's host
+        # pass has dropped explicit instantiations without a diagnostic -- the library linked and failed only when it was loaded)
+        import ctypes
+        try:
+            ctypes.CDLL(LIB, mode=os.RTLD_NOW)
+        except OSError as e:
+            raise RuntimeError(f"{LIB} does not load: {e}") from e
         if verbose:
             print(f"built {LIB} ({os.path.getsize(LIB) / 1e6:.1f} MB) from {len(objs)} objects")
     elif verbose:

@@ -178,21 +178,46 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
 
     // ---- producer: the LDS-DMA stream.  Global K-step g (over all tiles of this workgroup) lives in slot g % NSLOT.
     // (S16: no swizzle -- 16-row fragments of rows r, r + 8 take opposite halves in one ds_read_b128 lane group: conflict-free as laid)
+    // The sources go through BUFFER descriptors: one per operand, in scalar registers, based at the first row block of the
+    // producer's tile; the lane's 16 bytes inside a 1-KB block are the vector offset (constant for the kernel), the piece and the
+    // K-step a scalar offset.  (With a 64-bit pointer per piece every DMA instruction cost a v_lshl_add_u64 -- seven vector
+    // instructions per K-step between the MFMAs, which one SIMD issues instead of, not beside, them.)
+    typedef __amdgpu_buffer_rsrc_t rsrc_t;
+    // (the descriptor's inputs pass through v_readfirstlane: they ARE wave-uniform, but hipcc does not prove it for values that
+    //  went through the tile walk, keeps the descriptor in vector registers and wraps EVERY buffer instruction in a waterfall
+    //  loop -- 1 600 v_readfirstlane in the listing of the first attempt)
+    auto uniform_rsrc = [&](const void* base, int64_t bytes) -> rsrc_t {
+        const uint64_t a = reinterpret_cast<uint64_t>(base);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        const int nb = __builtin_amdgcn_readfirstlane((int)bytes);
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), (short)0, nb, 0x00020000);
+    };
     const int lane_src = S16 ? lane * 16 : (((lane >> 1) * 2) + ((lane & 1) ^ ((lane >> 4) & 1))) * 16;
-    const unsigned char* pbase[MAXQ];                // source of piece q of the producer's tile at K-step 0 (wave-uniform)
+    // (kept as two scalar halves and made into a descriptor by the builtin AT the instruction, the scalar offset through a local:
+    //  with `poff[q] + ...` written as the builtin's argument the host pass of hipcc 7.2 drops the kernel's explicit instantiations
+    //  without a diagnostic -- no stub and no fat binary in the object, an undefined symbol when the library is loaded)
+    unsigned srcA_lo = 0, srcA_hi = 0, srcB_lo = 0, srcB_hi = 0;
+    auto halves = [&](const unsigned char* base, unsigned& lo, unsigned& hi) {
+        const uint64_t a = reinterpret_cast<uint64_t>(base);
+        lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    };
+    int poff[MAXQ];                                  // byte offset of piece q at K-step 0 behind its descriptor's base (wave-uniform)
     int p_idx = 0, p_k = 0, p_ke = 0, p_slot = 0, p_tm = 0, p_tn = 0;
     bool p_live = seg_of(0, p_tm, p_tn, p_k, p_ke);
     auto set_bases = [&]() {
+        const int rbA0 = min(p_tm * ARB, p.rbA - 1), rbB0 = min(p_tn * BRB, p.rbB - 1);
+        halves(p.A + (int64_t)rbA0 * nk * (NP * PBLK), srcA_lo, srcA_hi);
+        halves(p.B + (int64_t)rbB0 * nk * (NP * PBLK), srcB_lo, srcB_hi);
 #pragma unroll
         for (int q = 0; q < MAXQ; ++q) {
             const int id = wave + NW * q;
             if (id < AP) {
                 const int rb = min(p_tm * ARB + id / NP, p.rbA - 1);            // rows past the edge: clamped, never stored
-                pbase[q] = p.A + ((int64_t)rb * nk * NP + id % NP) * PBLK;
+                poff[q] = __builtin_amdgcn_readfirstlane(((rb - rbA0) * nk * NP + id % NP) * PBLK);
             } else {
                 const int id2 = min(id, PIECES - 1) - AP;
                 const int rb = min(p_tn * BRB + id2 / NP, p.rbB - 1);
-                pbase[q] = p.B + ((int64_t)rb * nk * NP + id2 % NP) * PBLK;
+                poff[q] = __builtin_amdgcn_readfirstlane(((rb - rbB0) * nk * NP + id2 % NP) * PBLK);
             }
         }
     };
@@ -202,9 +227,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
         return;
 #endif
         const int id = wave + NW * q;
+        const bool fromA = (AP % NW == 0) ? (q < AP / NW) : (id < AP);       // (a compile-time choice in the unrolled issue loops)
+        const int soff = poff[q] + p_k * (NP * PBLK);
+        const uint64_t src = ((uint64_t)(fromA ? srcA_hi : srcB_hi) << 32) | (fromA ? srcA_lo : srcB_lo);
         if (id < PIECES)
-            __builtin_amdgcn_global_load_lds((gptr_t*)(pbase[q] + (int64_t)p_k * (NP * PBLK) + lane_src),
-                                             (lptr_t*)(lds + p_slot * SLOT + id * PBLK), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(src), (short)0, 0x7fffffff, 0x00020000),
+                                                     (lptr_t*)(lds + p_slot * SLOT + id * PBLK), 16, lane_src, soff, 0, 0);
     };
     // gap c of NG (behind the c-th plane product of a K-step): pieces [c MAXQ / NG, (c + 1) MAXQ / NG); STAG: the low waves
     // issue theirs in the gaps 0 .. HG - 1, the high waves in HG .. NG - 2 (none behind the barrier: the counted wait stays
@@ -504,17 +532,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
     // registers in 2-register pairs and the allocator spilled them around the K loop (352 bytes of scratch per lane).  The
     // descriptor covers exactly the tile row's rows that exist: rows past M read zeros / are not stored without a compare, and a
     // lane whose columns lie past N is given an offset beyond every descriptor (row strides < 2^20 elements: host).
-    typedef __amdgpu_buffer_rsrc_t rsrc_t;
     constexpr unsigned OOB = 0x40000000u;
-    // (the descriptor's inputs pass through v_readfirstlane: they ARE wave-uniform, but hipcc does not prove it for values that
-    //  went through the tile walk, keeps the descriptor in vector registers and wraps EVERY buffer instruction in a waterfall
-    //  loop -- 1 600 v_readfirstlane in the listing of the first attempt)
-    auto uniform_rsrc = [&](const void* base, int64_t bytes) -> rsrc_t {
-        const uint64_t a = reinterpret_cast<uint64_t>(base);
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-        const int nb = __builtin_amdgcn_readfirstlane((int)bytes);
-        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), (short)0, nb, 0x00020000);
-    };
     auto rows_rsrc = [&](const float* base, int64_t ld, int tm_) -> rsrc_t {      // fp32 matrix, the 256 rows of tile row tm_
         const int64_t rows = min<int64_t>(max<int64_t>(p.M - (int64_t)tm_ * BM, 0), BM);
         return uniform_rsrc(base + (int64_t)tm_ * BM * ld, rows * ld * 4);
