@@ -288,6 +288,131 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
+// The backward whose dx ALSO leaves as a plane matrix, by row blocks (the counterpart of ln_fwd_planes_kernel): ln_bwd_kernel
+// writes a lane's 4 columns of a plane as 8 bytes -- 32-byte segments of the blocked layout, 72 of them per 384-wide row.  Here a
+// workgroup takes whole 32-row blocks (8 waves x 4 rows, one row in flight per wave: 16 waves per CU keep ~70 KB of loads in
+// the air), stores dx row by row as before, builds the block's plane images in LDS and copies them out as contiguous memory.
+// Same arithmetic per row as ln_bwd_kernel<64>; the column partials are kept per lane over the workgroup's blocks and published
+// in the same [workgroup][nacc][cols] layout for sum_slabs_kernel.  NC = 16-byte chunks per lane (cols <= 256 NC).
+template <int NP, int NC>
+__global__ __launch_bounds__(512) void ln_bwd_planes_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+                                                            int64_t ldx, int64_t rows, int cols, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                            float* __restrict__ dx, int64_t lddx, float* __restrict__ part,
+                                                            const float* __restrict__ add, int64_t ldadd, int want_dxsum,
+                                                            unsigned char* __restrict__ out, int cb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ln_img[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nacc = want_dxsum ? 3 : 2;
+    float4 gm[NC], dg[NC], db[NC], sx[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const int c = 4 * (lane + k * 64);
+        gm[k] = c < cols ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dg[k] = db[k] = sx[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float inv_n = 1.f / (float)cols;
+    const int64_t nrb = (rows + 31) >> 5;
+    const int total = cb * NP * 1024;
+    for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+        for (int i = 0; i < 4; ++i) {                         // (two rows in flight per wave, `#pragma unroll 2`: 127 registers, same time)
+            const int64_t r = rb * 32 + wave * 4 + i;
+            const bool live = r < rows;                       // wave-uniform
+            float4 d[NC];
+            if (live) {
+                float4 v[NC];
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    const int c = 4 * (lane + k * 64);
+                    const bool on = c < cols;
+                    v[k] = on ? *reinterpret_cast<const float4*>(x + r * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    d[k] = on ? *reinterpret_cast<const float4*>(dy + r * lddy + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                const float mu = mean[r], rs = rstd[r];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    const bool on = 4 * (lane + k * 64) < cols;
+                    v[k].x = on ? (v[k].x - mu) * rs : 0.f;  // xhat
+                    v[k].y = on ? (v[k].y - mu) * rs : 0.f;
+                    v[k].z = on ? (v[k].z - mu) * rs : 0.f;
+                    v[k].w = on ? (v[k].w - mu) * rs : 0.f;
+                    dg[k].x += d[k].x * v[k].x; dg[k].y += d[k].y * v[k].y; dg[k].z += d[k].z * v[k].z; dg[k].w += d[k].w * v[k].w;
+                    db[k].x += d[k].x; db[k].y += d[k].y; db[k].z += d[k].z; db[k].w += d[k].w;
+                    d[k].x *= gm[k].x; d[k].y *= gm[k].y; d[k].z *= gm[k].z; d[k].w *= gm[k].w;  // g * dy
+                    s1 += sum4(d[k]);
+                    s2 += dot4(d[k], v[k]);
+                }
+                const float m1 = group_sum<64>(s1) * inv_n, m2 = group_sum<64>(s2) * inv_n;
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    d[k].x = rs * (d[k].x - m1 - v[k].x * m2);
+                    d[k].y = rs * (d[k].y - m1 - v[k].y * m2);
+                    d[k].z = rs * (d[k].z - m1 - v[k].z * m2);
+                    d[k].w = rs * (d[k].w - m1 - v[k].w * m2);
+                }
+                if (add) {  // gradient arriving through the residual branch around this LayerNorm
+#pragma unroll
+                    for (int k = 0; k < NC; ++k) {
+                        const int c = 4 * (lane + k * 64);
+                        if (c < cols) {
+                            const float4 a = *reinterpret_cast<const float4*>(add + r * ldadd + c);
+                            d[k].x += a.x; d[k].y += a.y; d[k].z += a.z; d[k].w += a.w;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    const int c = 4 * (lane + k * 64);
+                    if (c < cols) *reinterpret_cast<float4*>(dx + r * lddx + c) = d[k];
+                }
+                if (want_dxsum) {
+#pragma unroll
+                    for (int k = 0; k < NC; ++k) { sx[k].x += d[k].x; sx[k].y += d[k].y; sx[k].z += d[k].z; sx[k].w += d[k].w; }
+                }
+            }
+            // the row's plane images (rows of column block j rotated by j & 7 positions: see ln_fwd_planes_kernel)
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const int c = 4 * (lane + k * 64);
+                if (c < cb * 16) {                            // columns past `cols` and rows past `rows`: the padding, +0
+                    uint2 o[NP];
+                    split4<NP>((live && c < cols) ? d[k] : make_float4(0.f, 0.f, 0.f, 0.f), o);
+                    const int j = c >> 4;
+                    unsigned char* dst = ln_img + j * (NP * 1024) + (((wave * 4 + i + (j & 7)) & 31) * 32) + (c & 15) * 2;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(dst + q * 1024) = o[q];
+                }
+            }
+        }
+        __syncthreads();
+        unsigned char* dst = out + rb * total;
+        for (int off = threadIdx.x * 16; off < total; off += 512 * 16) {
+            const int image = off >> 10, j = image / NP;
+            const int src = (image << 10) + (((off & 1023) + 32 * (j & 7)) & 1023);
+            *reinterpret_cast<uint4*>(dst + off) = *reinterpret_cast<const uint4*>(ln_img + src);
+        }
+        __syncthreads();
+    }
+    // the eight waves' column partials -> one [nacc][cols] slab of this workgroup (the image area is free now: 96 cols bytes)
+    float* red = reinterpret_cast<float*>(ln_img) + (int64_t)wave * nacc * cols;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const int c = 4 * (lane + k * 64);
+        if (c < cols) {
+            *reinterpret_cast<float4*>(red + c) = dg[k];
+            *reinterpret_cast<float4*>(red + cols + c) = db[k];
+            if (want_dxsum) *reinterpret_cast<float4*>(red + 2 * cols + c) = sx[k];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nacc * cols; i += 512) {
+        float s = 0.f;
+        for (int w = 0; w < 8; ++w) s += reinterpret_cast<const float*>(ln_img)[(int64_t)w * nacc * cols + i];
+        part[(int64_t)blockIdx.x * nacc * cols + i] = s;
+    }
+}
+
 // out[i] = sum_b part[b][i], i < n : 16 slab groups x 64 columns per block (each thread keeps 4 independent loads
 // in flight), LDS-combined in a fixed order
 __global__ __launch_bounds__(1024) void sum_slabs_kernel(const float* __restrict__ part, int nslabs, int n,
@@ -909,9 +1034,36 @@ extern "C" int msn_layernorm_bwd_planes(const float* dy, int64_t lddy, const flo
     MSN_REQUIRE(ws && ws_bytes >= sizeof(float) * nacc * (size_t)cols * grid, "msn_layernorm_bwd_planes: workspace too small");
     const RowGeom g{rows, cols, ldx};
     hipStream_t st = static_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(ws);
+    {   // whole row blocks through LDS (ln_bwd_planes_kernel): the same rule as the forward's
+        const int cbn = 2 * (int)cdiv(cols, 32);
+        const size_t img = (size_t)cbn * planes * 1024;
+        if (lpr == 64 && img <= 78 * 1024 && g_ln_block_planes && rows >= 32 * 1024 * (g_ln_block_planes == 2 ? 0 : 1)) {
+            const int bgrid = (int)std::min<int64_t>(cdiv(rows, 32), std::min(grid, 512));       // <= grid: the workspace holds it
+            const int nc = (int)cdiv(cols, 256);
+            unsigned char* o = static_cast<unsigned char*>(dx_planes);
+#define MSN_LN_BWD_BLOCK(NP_, NC_)                                                                                               \
+    {                                                                                                                            \
+        if (img > 64 * 1024)                                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_planes_kernel<NP_, NC_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)img); \
+        hipLaunchKernelGGL((ln_bwd_planes_kernel<NP_, NC_>), dim3(bgrid), dim3(512), img, st, dy, lddy, x, ldx, rows, cols, mean, rstd, \
+                           gamma, dx, lddx, part, add, ldadd, dx_colsum ? 1 : 0, o, cbn);                                        \
+    }
+            if (planes == 3) {
+                if (nc == 1) MSN_LN_BWD_BLOCK(3, 1) else if (nc == 2) MSN_LN_BWD_BLOCK(3, 2) else if (nc == 3) MSN_LN_BWD_BLOCK(3, 3) else MSN_LN_BWD_BLOCK(3, 4)
+            } else {
+                if (nc == 1) MSN_LN_BWD_BLOCK(2, 1) else if (nc == 2) MSN_LN_BWD_BLOCK(2, 2) else if (nc == 3) MSN_LN_BWD_BLOCK(2, 3) else MSN_LN_BWD_BLOCK(2, 4)
+            }
+#undef MSN_LN_BWD_BLOCK
+            MSN_LAUNCH_CHECK();
+            hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)cdiv(nacc * cols, 64)), dim3(1024), 0, st, part, bgrid, nacc * cols,
+                               dgamma, dbeta, cols, dx_colsum);
+            MSN_LAUNCH_CHECK();
+            return MSN_OK;
+        }
+    }
     if (int rc = plane_tail_zero(dx_planes, rows, cols, planes, st)) return rc;
     const PlaneOut po{static_cast<unsigned char*>(dx_planes), planes, 2 * (int)cdiv(cols, 32), cols};
-    float* part = static_cast<float*>(ws);
     const size_t lds = sizeof(float) * nacc * (size_t)cols * (256 / lpr);
     MSN_LPR_DISPATCH(ln_bwd_kernel, lpr, dim3(grid), lds, st, dy, lddy, x, ldx, g, mean, rstd, gamma, dx, lddx, part, add, ldadd,
                      (unsigned short*)nullptr, dx_colsum ? 1 : 0, po)
