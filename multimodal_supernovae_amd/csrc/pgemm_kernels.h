@@ -90,7 +90,28 @@ __device__ __forceinline__ u16 f2bf(float f) {          // round to nearest even
 }
 __device__ __forceinline__ float bf2f(u16 v) { return __uint_as_float((unsigned)v << 16); }
 
+template <int OFF>
+__device__ __forceinline__ void ds_write64_o(unsigned addr, uint2 v) {
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
 // x -> NP planes (u16 each).  Each residual x - p0 (- p1) is exact in fp32.
+// two values -> NP words (low half: a's plane, high half: b's), the same roundings as split_planes: one v_cvt_pk_bf16_f32 per
+// plane and pair, the two planes' values back out of the word by a shift and a mask (11 instructions per pair for three planes;
+// split_planes element by element and the packing afterwards cost 14 per ELEMENT in the plane-output epilogue)
+template <int NP>
+__device__ __forceinline__ void split_pair(float a, float b, unsigned (&pk)[NP]) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const f32x2_t ab = {a, b};
+        pk[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(ab, bf16x2_t));
+        if (k + 1 < NP) {
+            a -= __uint_as_float(pk[k] << 16);                    // exact
+            b -= __uint_as_float(pk[k] & 0xffff0000u);
+        }
+    }
+}
 template <int NP>
 __device__ __forceinline__ void split_planes(float x, u16 (&pl)[NP]) {
     float r = x;
@@ -700,16 +721,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
                     // planes -> the 2 * NP block images of this tile ([32 rows][16 bf16] each, as they lie in HBM) -> 1-KB stores
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
-                        u16 pl[4][NP];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) split_planes<NP>(v[4 * b + r], pl[r]);
-#pragma unroll
-                        for (int k = 0; k < NP; ++k) {
+                        unsigned lo[NP], hi[NP];
+                        split_pair<NP>(v[4 * b], v[4 * b + 1], lo);
+                        split_pair<NP>(v[4 * b + 2], v[4 * b + 3], hi);
+                        unsigned at = stg + (unsigned)(((ecolq(b) >> 2) * NP) * PBLK + erow(b) * 32 + (ecolq(b) & 3) * 8);
+                        static_for<0, NP>([&](auto k_) {
+                            constexpr int k = decltype(k_)::value;
                             uint2 o;
-                            o.x = pl[0][k] | ((unsigned)pl[1][k] << 16);
-                            o.y = pl[2][k] | ((unsigned)pl[3][k] << 16);
-                            asm volatile("ds_write_b64 %0, %1" ::"v"(stg + (unsigned)((((ecolq(b) >> 2) * NP + k) * PBLK) + erow(b) * 32 + (ecolq(b) & 3) * 8)), "v"(o) : "memory");
-                        }
+                            o.x = lo[k];
+                            o.y = hi[k];
+                            ds_write64_o<k * PBLK>(at, o);
+                        });
                     }
                     f32x4 img[2 * NP];
 #pragma unroll
