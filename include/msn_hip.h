@@ -316,9 +316,11 @@ int msn_pgemm_tn(int64_t M, int N, int K, int planes, const void* A, const void*
 int msn_layernorm_fwd_planes(const float* x, int64_t ldx, int64_t rows, int cols, const float* gamma, const float* beta,
                              float eps, int planes, void* y_planes, float* y, int64_t ldy, float* mean, float* rstd,
                              msn_stream_t stream);
-/* 1 (default): msn_layernorm_fwd_planes with y == NULL, 260..400 columns and >= 32768 rows normalises whole 32-row blocks
- * per workgroup and writes each block's plane images as contiguous memory; 2: at every row count; 0: always the row-at-a-time
- * kernel.  Same results.  Process-wide; A/B runs and tests. */
+/* 1 (default): msn_layernorm_fwd_planes with y == NULL and msn_layernorm_bwd_planes (round 5: ln_bwd_planes_kernel), 260..400
+ * columns and >= 32768 rows, take whole 32-row blocks per workgroup and write each block's plane images as contiguous memory;
+ * 2: at every row count; 0: always the row-at-a-time kernels.  y, dx and every plane byte are the same either way; the backward's
+ * dgamma / dbeta / dx_colsum are the same terms summed in another fixed order (bit-identical from call to call, equal to the row
+ * kernel's within fp32 rounding).  Process-wide, not thread-safe; A/B runs and tests. */
 int msn_set_layernorm_block_planes(int on);
 int msn_layernorm_bwd_planes(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t rows, int cols,
                              const float* mean, const float* rstd, const float* gamma, const float* add, int64_t ldadd,

@@ -1048,6 +1048,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(const PgemmArgs p) {
     // K-step's product is folded (64 VALU adds per tile and step, which the matrix pipe waits for: one SIMD issues either).
     // FOLDN = 2: a temporary collects the p0.q0 products of TWO K-steps before its fold (the second MFMA truncates at one ulp
     // of a 32-row partial sum, far below the running sum's), half the adds; the tiles are staggered, see mult_big.
+    static_assert(FOLDN == 1 || FOLDN == 2, "a fold per K-step or per two (four do not fit the register file: profiles/r05_experiments_tried.txt)");
     constexpr int NTB = FOLDN > 1 ? MT * NT : 2;
     f32x16 tbig[NTB];
     if constexpr (FOLDN > 1) {
@@ -1100,7 +1101,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(const PgemmArgs p) {
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto fold_pending = [&](auto par_) {
+    auto fold_pending = [&]() {                      // FOLDN = 1: the last two tiles of the step; FOLDN = 2 folds inside mult_big
         if constexpr (FOLDN == 1) {
             fold(std::integral_constant<int, MT * NT - 2>{});
             fold(std::integral_constant<int, MT * NT - 1>{});
@@ -1148,7 +1149,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_tn_kernel(const PgemmArgs p) {
                 else mult(fa[QA], fb0[PAR], BIG{});
             } else {
                 mult(fa[QA], fbh[pb - 1], SML{});
-                if constexpr (DUAL && pb == 1) fold_pending(par_);
+                if constexpr (DUAL && pb == 1) fold_pending();
             }
             issue_chunk(std::integral_constant<int, pb>{});
             __builtin_amdgcn_sched_barrier(0);
