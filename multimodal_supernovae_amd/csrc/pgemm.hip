@@ -686,6 +686,9 @@ TnPlan tn_plan(int64_t M, int N, int K, int planes) {
     const int tiles = t.tiles_p * t.tiles_q;
     const int rbs = (int)cdiv(M, 32);
     int s = std::max(1, 256 / tiles);                 // enough workgroups for the 256 CUs (one 144-KB workgroup per CU)
+    // the kernel addresses a split's row blocks through a buffer descriptor with 32-bit offsets: a split spans < 2 GB of either operand
+    const int64_t rb_bytes = 2 * std::max(cdiv(N, 32), cdiv(K, 32)) * (int64_t)planes * 1024;
+    s = (int)std::max<int64_t>(s, cdiv(rbs, std::max<int64_t>(1, ((1ll << 31) - 1) / rb_bytes)));
     s = std::min(s, rbs);
     t.rb_per_split = (int)cdiv(rbs, s);
     t.splits = (int)cdiv(rbs, t.rb_per_split);
@@ -713,6 +716,7 @@ static int pgemm_tn_impl(int64_t M, int N, int K, int planes, const void* A, con
     MSN_REQUIRE(planes == 2 || planes == 3, "msn_pgemm_tn: planes must be 2 or 3 (got %d)", planes);
     MSN_REQUIRE(K % 4 == 0 && ldc >= K && ldc % 4 == 0 && aligned16p(C) && aligned16p(A) && aligned16p(B),
                 "msn_pgemm_tn: K and ldc must be multiples of 4, operands 16-byte aligned");
+    MSN_REQUIRE(std::max(N, K) < (1 << 19), "msn_pgemm_tn: N and K must be below 2^19 (32-bit offsets inside a row block of planes)");
     const TnPlan t = tn_plan(M, N, K, planes);
     PgemmArgs a = {};
     a.A = static_cast<const unsigned char*>(A); a.B = static_cast<const unsigned char*>(B); a.C = C;

@@ -50,6 +50,12 @@ def test_shape_errors_are_reported_without_a_gpu():
     # 6240 tiles = 12 rounds of 512 + 96: those 96 run as 3 K-slabs each (tail split)
     assert lib.msn_sgemm_workspace_bytes(0, 1, 66560, 1536, 384) == 96 * 3 * 128 * 128 * 4
     assert lib.msn_sgemm_workspace_bytes(0, 1, 4096, 4096, 4096) == 0      # 1024 tiles: two full rounds
+    # plane weight gradient: 15 tiles -> 17 reduction splits (one workgroup per CU); a reduction split never spans 2 GB of an operand
+    # (the kernel addresses it through a buffer descriptor with 32-bit offsets): 131 072 row blocks of 1.5 MB -> 97 splits, not 1
+    assert lib.msn_pgemm_tn_workspace_bytes(66560, 1152, 384, 3) == 17 * 1152 * 384 * 4
+    assert lib.msn_pgemm_tn_workspace_bytes(1 << 22, 8192, 8192, 3) == 97 * 8192 * 8192 * 4
+    rc = lib.msn_pgemm_tn(256, 1 << 19, 64, 3, fake, fake, fake, 64, None, 0, None)
+    assert rc == 1 and b"2^19" in lib.msn_last_error()
 
 
 def test_no_cpu_fallback():

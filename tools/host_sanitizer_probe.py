@@ -34,6 +34,7 @@ for bad in (lambda: L.msn_set_gemm_streamk(-1, 0), lambda: L.msn_set_gemm_lds_pa
 # plane GEMMs (pgemm.hip): sizes, launch plans and the argument checks that return before a launch
 print("plane bytes", L.msn_plane_bytes(66560, 384, 3), L.msn_plane_bytes(33, 17, 2), L.msn_plane_bytes(0, 4, 3))
 print("pgemm ws", L.msn_pgemm_tn_workspace_bytes(66560, 1152, 384, 3), L.msn_pgemm_tn_workspace_bytes(66560, 384, 1536, 2),
+      L.msn_pgemm_tn_workspace_bytes(1 << 22, 8192, 8192, 3),
       L.msn_pgemm_nt_workspace_bytes(66560, 384, 1536, 3, 0, 0, 0), L.msn_pgemm_nt_workspace_bytes(66560, 1536, 384, 3, 1, 4, 1),
       L.msn_plane_split_colsum_workspace_bytes(66560, 1152))
 for bad in (lambda: L.msn_plane_split(None, 4, 4, 4, 3, 0, None, None, None, 0, None),
@@ -42,6 +43,7 @@ for bad in (lambda: L.msn_plane_split(None, 4, 4, 4, 3, 0, None, None, None, 0, 
             lambda: L.msn_pgemm_nt(256, 128, 64, 3, fake, fake, fake, 128, 0, None, 5, None, 0, None, None, 0, None),
             lambda: L.msn_pgemm_nt(256, 128, 64, 4, fake, fake, fake, 128, 0, None, 0, None, 0, None, None, 0, None),
             lambda: L.msn_pgemm_tn(256, 128, 66, 3, fake, fake, fake, 66, None, 0, None),
+            lambda: L.msn_pgemm_tn(256, 1 << 19, 64, 3, fake, fake, fake, 64, None, 0, None),
             lambda: L.msn_attention_bwd_planes(fake, 1152, None, 4, 6, 200, 64, 0.125, fake, 384, fake, fake, 384, 3, fake, None, None, 0, None),
             lambda: L.msn_attention_bwd_planes(fake, 1152, None, 4, 6, 65, 8, 0.125, fake, 384, fake, fake, 384, 3, fake, None, None, 0, None),
             lambda: L.msn_attention_bwd_planes(fake, 1152, None, 4, 6, 65, 64, 0.125, fake, 384, fake, fake, 384, 5, fake, None, None, 0, None),
