@@ -370,7 +370,6 @@ __global__ __launch_bounds__(512, 2) void bgemm_nt_kernel(const BgemmArgs p) {
 // groups = rows {8 g2 + 4 h + q : g2 in 0..1, q in 0..3} x 32 bytes: the 32-byte chunk index (low three bits) of row r
 // is XORed with tsw(r) = (r & 3) | ((r >> 3) & 1) << 2, which is distinct over those eight rows -> conflict-free.
 __device__ __forceinline__ int tsw(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
-__device__ __align__(16) const unsigned char g_zero_page[16] = {0};
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void ds_read_tr(bf16x4& dst, unsigned addr) {
@@ -398,33 +397,40 @@ __global__ __launch_bounds__(512, 2) void bgemm_tn_kernel(const BgemmArgs p) {
 
     // ---- LDS-DMA: a piece = 2 rows x 512 B; wave w moves pieces 4w .. 4w+3 (rows 8w .. 8w+7) of both operands.
     // lane i of a piece: row i / 32, 16-byte slot s = i % 32 <- source chunk c = (s >> 1) with its low 3 bits ^ tsw(row)
-    int64_t offA[4], offB[4];
-    int rloc[4];
+    // Sources through BUFFER descriptors (round 5): one per operand in scalar registers, based at this split's first row and
+    // covering exactly its rows -- a row of the K-step past the reduction range lies beyond the descriptor and reads zeros (the
+    // older form chose between the row and a zero page per piece: a compare, an exec mask and a 64-bit address per instruction,
+    // 24 vector instructions per K-step which the matrix pipe does not overlap) -- the lane's byte offset inside a K-step in one
+    // register per piece, the K-step as the scalar offset.
+    const int rows_here = (int)(m_end - m_begin);
+    auto uniform_rsrc = [&](const u16* base, int64_t bytes) -> __amdgpu_buffer_rsrc_t {
+        const uint64_t a = reinterpret_cast<uint64_t>(base);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        const int nb = __builtin_amdgcn_readfirstlane((int)std::min<int64_t>(bytes, 0x7fffffff));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), (short)0, nb, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rsA = uniform_rsrc(p.A + m_begin * p.lda, 2 * ((int64_t)(rows_here - 1) * p.lda + p.N));
+    const __amdgpu_buffer_rsrc_t rsB = uniform_rsrc(p.B + m_begin * p.ldb, 2 * ((int64_t)(rows_here - 1) * p.ldb + p.K));
+    unsigned offA[4], offB[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int R = 2 * (4 * wave + q) + (lane >> 5);
         const int s = lane & 31;
         const int c = (((s >> 1) & 7) ^ tsw(R)) | ((s >> 1) & 8);
         const int col = 16 * c + 8 * (s & 1);                     // element column inside the 256-wide tile
-        rloc[q] = R;
         // columns past N / K: clamped (their products are never stored)
-        offA[q] = (int64_t)R * p.lda + std::min(n0 + col, p.N - 8);
-        offB[q] = (int64_t)R * p.ldb + std::min(k0 + col, p.K - 8);
+        offA[q] = (unsigned)(2 * ((int64_t)R * p.lda + std::min(n0 + col, p.N - 8)));
+        offB[q] = (unsigned)(2 * ((int64_t)R * p.ldb + std::min(k0 + col, p.K - 8)));
     }
+    const int kstepA = (int)(2 * BKS * p.lda), kstepB = (int)(2 * BKS * p.ldb);      // bytes from one K-step to the next
     auto issue = [&](int buf, int kt) {
         unsigned char* dst = lds + buf * STAGE_BYTES + wave * 4096;
-        const int64_t mb = m_begin + (int64_t)kt * BKS;
-        const int left = (int)std::min<int64_t>(m_end - mb, BKS);  // rows of this K-step that exist: the rest read zeros
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const u16* sa = rloc[q] < left ? p.A + mb * p.lda + offA[q] : reinterpret_cast<const u16*>(g_zero_page);
-            __builtin_amdgcn_global_load_lds((gptr_t*)sa, (lptr_t*)(dst + q * 1024), 16, 0, 0);
-        }
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t*)(dst + q * 1024), 16, (int)offA[q], kt * kstepA, 0, 0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const u16* sb = rloc[q] < left ? p.B + mb * p.ldb + offB[q] : reinterpret_cast<const u16*>(g_zero_page);
-            __builtin_amdgcn_global_load_lds((gptr_t*)sb, (lptr_t*)(dst + OPER_BYTES + q * 1024), 16, 0, 0);
-        }
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t*)(dst + OPER_BYTES + q * 1024), 16, (int)offB[q], kt * kstepB, 0, 0);
     };
 
     // ---- fragments.  Output tile rows = n (operand A = dY), columns = k (operand B = X).  Wave (wr, wc): n in
@@ -713,6 +719,10 @@ extern "C" int msn_bgemm_tn(int64_t M, int N, int K, const void* A, int64_t lda,
     a.splits = tn_splits(tiles, M);
     a.rows_per_split = cdiv(cdiv(M, a.splits), BKS) * BKS;
     a.splits = (int)cdiv(M, a.rows_per_split);
+    // (the kernel addresses a split's rows through buffer descriptors with 32-bit byte offsets)
+    MSN_REQUIRE((a.rows_per_split + BKS) * std::max(lda, ldb) * 2 < (1ll << 31),
+                "msn_bgemm_tn: a reduction split spans 2 GB of an operand (%lld rows x %lld elements)", (long long)a.rows_per_split,
+                (long long)std::max(lda, ldb));
     const size_t need = a.splits > 1 ? sizeof(float) * (size_t)a.splits * N * K : 0;
     MSN_REQUIRE(need == 0 || (ws && ws_bytes >= need && aligned16(ws)), "msn_bgemm_tn: workspace %zu < %zu bytes", ws_bytes, need);
     a.slabs = static_cast<float*>(ws);
