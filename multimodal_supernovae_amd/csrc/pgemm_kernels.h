@@ -249,7 +249,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
 #endif
         const int id = wave + NW * q;
         const bool fromA = (AP % NW == 0) ? (q < AP / NW) : (id < AP);       // (a compile-time choice in the unrolled issue loops)
+#ifdef MSN_ABL_PG_SAMEK                      // diagnostic build: every K-step fetches the tile's FIRST one (cache hits: what the ring's
+        const int soff = poff[q];            // sources cost beyond their instructions and LDS writes; results are garbage)
+#else
         const int soff = poff[q] + p_k * (NP * PBLK);
+#endif
         const uint64_t src = ((uint64_t)(fromA ? srcA_hi : srcB_hi) << 32) | (fromA ? srcA_lo : srcB_lo);
         if (id < PIECES)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(src), (short)0, 0x7fffffff, 0x00020000),
