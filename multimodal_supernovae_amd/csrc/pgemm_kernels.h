@@ -249,6 +249,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
 #endif
         const int id = wave + NW * q;
         const bool fromA = (AP % NW == 0) ? (q < AP / NW) : (id < AP);       // (a compile-time choice in the unrolled issue loops)
+#ifdef MSN_ABL_PG_NODMA_A                    // diagnostic build: the A operand's pieces are not fetched (upper bound of an A operand
+        if (fromA) return;                   // that bypasses LDS; the counted waits become optimistic)
+#endif
 #ifdef MSN_ABL_PG_SAMEK                      // diagnostic build: every K-step fetches the tile's FIRST one (cache hits: what the ring's
         const int soff = poff[q];            // sources cost beyond their instructions and LDS writes; results are garbage)
 #else
@@ -327,8 +330,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
 
     auto req_a = [&](bf16x8 (&dst)[MT], unsigned slot_off, auto pl_) {
         constexpr int pl = decltype(pl_)::value;
-#ifdef MSN_ABL_PG_NOFRAG                     // diagnostic build: no fragment reads (the MFMAs multiply whatever the registers hold)
-#pragma unroll
+#if defined(MSN_ABL_PG_NOFRAG) || defined(MSN_ABL_PG_NOFRAG_A)   // diagnostic build: no fragment reads (the MFMAs multiply whatever
+#pragma unroll                                                  // the registers hold); _A: none of the A operand only
         for (int i = 0; i < MT; ++i) asm volatile("" : "=v"(dst[i]));
         return;
 #endif

@@ -10,7 +10,8 @@ mkdir -p "$ROOT/tools/microbench/ablate"
 DEFS=""; NAME=""
 #   BF_NODMA / BF_NOFRAG: the same for the bf16-resident NT kernel (gemm_bf16res.hip)
 #   PG_NODMA / PG_NOFRAG / PG_NOBAR: the same for the plane NT kernel (pgemm.hip); PG_SAMEK: the ring fetches K-step 0 of the tile every
-#   step (cache hits: memory latency out, DMA instructions and LDS writes in)
+#   step (cache hits: memory latency out, DMA instructions and LDS writes in); PG_NODMA_A / PG_NOFRAG_A: the A operand alone (the
+#   upper bound of an A operand that does not pass through LDS)
 SRC=gemm
 for a in "$@"; do case $a in ACC_AGPR) DEFS="$DEFS -DMSN_ACC_AGPR";; BF_*) DEFS="$DEFS -DMSN_ABL_$a"; SRC=gemm_bf16res;; PG_*) DEFS="$DEFS -DMSN_ABL_$a"; SRC=pgemm;; *) DEFS="$DEFS -DMSN_ABL_$a";; esac; NAME="${NAME}_$a"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -I"$ROOT/include" $DEFS -c "$PKG/csrc/$SRC.hip" -o "/tmp/gemm_abl$NAME.o"
