@@ -285,7 +285,9 @@ def launch_ranks(n, argv):
             except subprocess.TimeoutExpired:
                 p.kill()
     reader.join(timeout=30)
-    sys.stdout.write(b"".join(chunks).decode())
+    # ONE JSON line on stdout: anything else rank 0 wrote there (gloo announces its connections on stdout) goes to stderr
+    for line in b"".join(chunks).decode().splitlines():
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     codes = [p.returncode for p in procs]
     if failed is not None or any(codes):
