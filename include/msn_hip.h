@@ -326,6 +326,13 @@ int msn_layernorm_bwd_planes(const float* dy, int64_t lddy, const float* x, int6
                              const float* mean, const float* rstd, const float* gamma, const float* add, int64_t ldadd,
                              float* dx, int64_t lddx, int planes, void* dx_planes, float* dgamma, float* dbeta,
                              float* dx_colsum, void* ws, size_t ws_bytes, msn_stream_t stream);
+/* Self-attention forward over a packed qkv matrix (rows = (sample, token), columns q | k | v; ref src/transformer_utils.py:36-89)
+ * whose output is written twice by the one kernel: `out` (fp32, (B T) x (H head_dim), row stride ldo -- the backward reads it) and
+ * `out_planes` (msn_plane_bytes(B T, H head_dim, planes) bytes, 16-byte aligned): the operand of the output projection, bit for bit
+ * what msn_plane_split(out) would write.  T <= 128 tokens, head_dim in {16, 32, 48, 64}, 16-byte aligned rows with strides % 4 == 0;
+ * lse as msn_attention_fwd ([B][H][T][2]).  MSN_ERR_SHAPE otherwise (the caller runs msn_attention_fwd + msn_plane_split). */
+int msn_attention_fwd_planes(const float* qkv, int64_t ldqkv, const uint8_t* key_mask, int B, int H, int T, int head_dim,
+                             float scale, float* out, int64_t ldo, float* lse, int planes, void* out_planes, msn_stream_t stream);
 /* Backward of the ViT blocks' self-attention (msn_attention_bwd on the packed q | k | v matrix of msn_pgemm_nt's qkv
  * product: qkv (B T x ldqkv >= 3 H hd), out / dout (B T x H hd), lse as msn_attention_fwd wrote it), writing the gradient
  * dqkv (B T x 3 H hd) as a PLANE matrix -- the operand of the two products that consume it -- and, colsum_out non-NULL,

@@ -150,6 +150,7 @@ SIGNATURES = {
     "msn_set_attention_planes": (c_int, [c_int]),
     "msn_set_layernorm_block_planes": (c_int, [c_int]),
     "msn_attention_bwd_planes_workspace_bytes": (c_size, [c_int, c_int, c_int]),
+    "msn_attention_fwd_planes": (c_int, [c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_int, c_f32, c_ptr, c_i64, c_ptr, c_int, c_ptr, c_ptr]),
     "msn_attention_bwd_planes": (c_int, [c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_int, c_f32, c_ptr, c_i64, c_ptr, c_ptr, c_i64,
                                          c_int, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "msn_retrieval_rank": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_size, c_ptr]),

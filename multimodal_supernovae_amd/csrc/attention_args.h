@@ -16,6 +16,10 @@ struct MAttn {
     int B, H, Tq, Tk, hd;
     float scale;
     int tail;                 // set by mattn_forward / mattn_backward: ragged last token on the vector ALU
+    // forward only (msn_attention_fwd_planes): the output ALSO as a plane matrix of (B Tq) rows x (H hd) columns -- the operand
+    // of the output projection -- written by the kernel that computes it instead of a split pass; null: off
+    unsigned char* oplanes;
+    int o_np, o_cb;           // planes (2 | 3), column blocks of the plane matrix
 };
 
 bool mattn_applicable(const MAttn& a);

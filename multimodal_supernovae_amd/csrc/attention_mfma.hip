@@ -225,6 +225,43 @@ __device__ __forceinline__ float wave_dot(const float* a, const float* b, int la
 }
 constexpr int kTailScratch = 384;   // floats of LDS behind the images: 2 broadcast rows (64 each) + 2 weight vectors (128)
 
+__device__ __forceinline__ unsigned short bf16_rne_bits(float f) {
+    const __bf16 b = (__bf16)f;
+    return *reinterpret_cast<const unsigned short*>(&b);
+}
+
+// The output tile of one (sample, head) -- Tq rows x hd columns in LDS, row stride HD + 4 -- as planes in the blocked layout of
+// msn_plane_split: a thread takes 8 columns of one row (16 bytes of one plane image), consecutive threads consecutive 16-byte
+// chunks of ONE image, so a wave's store is a contiguous run of it (the form of the one-pass backward's dqkv output).  Rows of a
+// sample start anywhere in a 32-row block: global row = b Tq + row.  Round to nearest even, residuals exact: the bytes
+// msn_plane_split writes for the same fp32 values.
+template <int HD>
+__device__ __forceinline__ void planes_from_tile(const MAttn& p, const float* tile, int b, int col0) {
+    constexpr int LS = HD + 4;
+    const int NB = p.hd / 16, T = p.Tq, NP = p.o_np;
+    unsigned char* cbase = p.oplanes + (int64_t)(col0 / 16) * (NP * 1024);
+    const int64_t r0 = (int64_t)b * T;
+    for (int idx = threadIdx.x; idx < 2 * T * NB; idx += blockDim.x) {
+        const int j = idx / (2 * T), rh = idx - 2 * T * j, row = rh >> 1, half = rh & 1;
+        const float* src = tile + row * LS + 16 * j + 8 * half;
+        const float4 w0 = *reinterpret_cast<const float4*>(src), w1 = *reinterpret_cast<const float4*>(src + 4);
+        float v[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        const int64_t gr = r0 + row;
+        unsigned char* dst = cbase + ((gr >> 5) * p.o_cb + j) * (int64_t)(NP * 1024) + (int)(gr & 31) * 32 + 16 * half;
+        for (int k = 0; k < NP; ++k) {
+            unsigned w[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const unsigned short lo = bf16_rne_bits(v[2 * x]), hi = bf16_rne_bits(v[2 * x + 1]);
+                v[2 * x] -= __uint_as_float((unsigned)lo << 16);          // exact
+                v[2 * x + 1] -= __uint_as_float((unsigned)hi << 16);
+                w[x] = lo | ((unsigned)hi << 16);
+            }
+            *reinterpret_cast<uint4*>(dst + k * 1024) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ forward
 template <int HD>
 __global__ __launch_bounds__(HD > 64 ? 512 : 1024) void mattn_fwd_kernel(const MAttn p) {
@@ -297,15 +334,21 @@ __global__ __launch_bounds__(HD > 64 ? 512 : 1024) void mattn_fwd_kernel(const M
         const float ez = __expf(sz - m);
         if (lane == 0) Ps[z] = ez;
         l = wave_sum(l) + ez;
+        float oz = 0.f;
         if (lane < p.hd) {
-            const float o = col_sum<HD>(Vs, Ps, (p.Tk + 3) / 4 * 4, lane);
-            p.out[(int64_t)b * p.o_bs + (int64_t)z * p.ldo + col0 + lane] = o / l;
+            oz = col_sum<HD>(Vs, Ps, (p.Tk + 3) / 4 * 4, lane) / l;
+            p.out[(int64_t)b * p.o_bs + (int64_t)z * p.ldo + col0 + lane] = oz;
         }
         if (lane == 0) {
             float* st = p.lse + 2 * (((int64_t)b * p.H + hh) * p.Tq + z);
             st[0] = m;
             st[1] = __logf(l);
         }
+        if (!p.oplanes) return;
+        __syncthreads();                                  // every wave is done with the K / V rows: they become the output tile
+        if (lane < HD) Ks[z * LS + lane] = lane < p.hd ? oz : 0.f;
+        __syncthreads();
+        planes_from_tile<HD>(p, Ks, b, col0);
         return;
     }
 
@@ -387,12 +430,14 @@ __global__ __launch_bounds__(HD > 64 ? 512 : 1024) void mattn_fwd_kernel(const M
     for (int r = 0; r < 4; ++r) {
         const float lq = __shfl(l, 4 * g + r, 64);
         const int q = q0 + 4 * g + r;
+        const float inv = 1.f / lq;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) o[t][r] *= inv;
         if (q < p.Tq) {
             float* op = p.out + (int64_t)b * p.o_bs + (int64_t)q * p.ldo + col0 + c;
-            const float inv = 1.f / lq;
 #pragma unroll
             for (int t = 0; t < DT; ++t)
-                if (16 * t + c < p.hd) op[16 * t] = o[t][r] * inv;
+                if (16 * t + c < p.hd) op[16 * t] = o[t][r];
         }
     }
     if (g == 0 && qrow < p.Tq) {
@@ -400,6 +445,20 @@ __global__ __launch_bounds__(HD > 64 ? 512 : 1024) void mattn_fwd_kernel(const M
         st[0] = m;
         st[1] = __logf(l);
     }
+    if (!p.oplanes) return;
+    // ---- the same values as a plane matrix: the tile goes through LDS (the K rows are no longer read) and leaves as
+    // contiguous runs of the block images (planes_from_tile)
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int q = q0 + 4 * g + r;
+        if (q < p.Tq) {
+#pragma unroll
+            for (int t = 0; t < DT; ++t) Ks[q * LS + 16 * t + c] = (16 * t + c < p.hd) ? o[t][r] : 0.f;
+        }
+    }
+    __syncthreads();
+    planes_from_tile<HD>(p, Ks, b, col0);
 }
 
 // ------------------------------------------------------------------------------- backward: dQ, delta
@@ -721,10 +780,6 @@ struct FusedOut {
     float* colpart;           // NP > 0, nullable: [B][3 H hd] column sums per sample
     int cb;                   // column blocks of the plane matrix = 2 ceil(3 H hd / 32)
 };
-__device__ __forceinline__ unsigned short bf16_rne_bits(float f) {
-    const __bf16 b = (__bf16)f;
-    return *reinterpret_cast<const unsigned short*>(&b);
-}
 template <int HD>
 __device__ __forceinline__ void lds_frags(float4 (&f)[HD / 16], const float* img, int row, int g, float mul) {
     constexpr int LS = HD + 4;
@@ -1575,6 +1630,49 @@ extern "C" int msn_set_attention_fused(int on) {
 
 extern "C" size_t msn_attention_bwd_planes_workspace_bytes(int B, int H, int head_dim) {
     return sizeof(float) * ((size_t)B + COLSUM_SLICES) * 3 * (size_t)H * (size_t)head_dim;
+}
+
+// Self-attention forward over a packed qkv matrix (rows = (sample, token), columns q | k | v) whose output leaves BOTH as the fp32
+// matrix the backward reads and as the plane matrix the output projection multiplies (ref src/transformer_utils.py:36-89: the
+// `unifyheads` Linear follows the attention directly) -- the split pass between the two launches is gone.
+extern "C" int msn_attention_fwd_planes(const float* qkv, int64_t ldqkv, const uint8_t* key_mask, int B, int H, int T, int head_dim,
+                                        float scale, float* out, int64_t ldo, float* lse, int planes, void* out_planes,
+                                        msn_stream_t stream) {
+    MSN_REQUIRE(qkv && out && lse && out_planes, "msn_attention_fwd_planes: null pointer");
+    MSN_REQUIRE(planes == 2 || planes == 3, "msn_attention_fwd_planes: planes must be 2 or 3 (got %d)", planes);
+    MSN_REQUIRE(B > 0 && H > 0 && T > 0 && head_dim > 0, "msn_attention_fwd_planes: bad shape");
+    MSN_REQUIRE(head_dim % 16 == 0 && head_dim <= 64, "msn_attention_fwd_planes: head width %d (16, 32, 48 or 64)", head_dim);
+    const int e = H * head_dim;
+    MSN_REQUIRE(ldqkv >= 3 * (int64_t)e && ldo >= e, "msn_attention_fwd_planes: row strides shorter than the rows");
+    MSN_REQUIRE((reinterpret_cast<uintptr_t>(out_planes) & 15) == 0, "msn_attention_fwd_planes: the plane matrix must be 16-byte aligned");
+    MAttn m = {};
+    m.q = qkv; m.k = qkv + e; m.v = qkv + 2 * e; m.out = out;
+    m.mask = key_mask; m.lse = lse;
+    m.ldq = m.ldk = m.ldv = ldqkv; m.ldo = ldo;
+    m.q_bs = m.k_bs = m.v_bs = (int64_t)T * ldqkv; m.o_bs = (int64_t)T * ldo;
+    m.B = B; m.H = H; m.Tq = m.Tk = T; m.hd = head_dim; m.scale = scale;
+    MSN_REQUIRE(mattn_applicable(m) && T <= 128,
+                "msn_attention_fwd_planes: up to 128 tokens, 16-byte aligned operands, row strides %% 4 == 0 (T = %d, head %d)", T, head_dim);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t M = (int64_t)B * T;
+    const int cb = 2 * (int)cdiv(e, 32);
+    unsigned char* dst = static_cast<unsigned char*>(out_planes);
+    if (M % 32 != 0) {            // rows behind the matrix in its last row block are zeros
+        const size_t blk = (size_t)cb * planes * 1024;
+        if (hipMemsetAsync(dst + (size_t)(M / 32) * blk, 0, blk, st) != hipSuccess) {
+            set_error("msn_attention_fwd_planes: memset failed");
+            return MSN_ERR_HIP;
+        }
+    }
+    if (e % 32 != 0) {            // e % 32 == 16: the last column block of every row block is padding; the kernel stores real blocks only
+        const size_t blk = (size_t)planes * 1024;
+        if (hipMemset2DAsync(dst + (size_t)(cb - 1) * blk, (size_t)cb * blk, 0, blk, (size_t)cdiv(M, 32), st) != hipSuccess) {
+            set_error("msn_attention_fwd_planes: memset of the padding column block failed");
+            return MSN_ERR_HIP;
+        }
+    }
+    m.oplanes = dst; m.o_np = planes; m.o_cb = cb;
+    return mattn_forward(m, st);
 }
 
 extern "C" int msn_attention_bwd_planes(const float* qkv, int64_t ldqkv, const uint8_t* key_mask, int B, int H, int T,

@@ -609,9 +609,13 @@ class _PlaneVitTrunk(torch.autograd.Function):
             h1p, m1, r1 = ops.layernorm_fwd_planes(x2, g1, b1, eps, NPL)
             qkv = ops.pgemm_nt(h1p, wqkvp, bias=bqkv)
             q3 = qkv.view(B, T, 3 * e)
-            a, lse = ops.attention_fwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], None, heads, scale)
-            a2 = a.view(M, e)
-            ap = ops.plane_split(a2, NPL)
+            if ops.attention_fwd_planes_supported(T, e // heads):     # the output projection's operand from the attention kernel
+                a, lse, ap = ops.attention_fwd_planes(q3, heads, scale, NPL)
+                a2 = a.view(M, e)
+            else:
+                a, lse = ops.attention_fwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], None, heads, scale)
+                a2 = a.view(M, e)
+                ap = ops.plane_split(a2, NPL)
             x1 = ops.pgemm_nt(ap, wop, bias=bo, epilogue=EPI_ADD, aux=x2)
             h2p, m2, r2 = ops.layernorm_fwd_planes(x1, g2, b2, eps, NPL)
             if need_grad:

@@ -1051,7 +1051,36 @@ def attention_bwd_planes(qkv, heads, scale, out, lse, dout, planes=None, want_co
     return (dqkv, cs) if want_colsum else dqkv
 
 
+def attention_fwd_planes(qkv, heads, scale, planes=None, mask_u8=None):
+    """Forward of self-attention on the packed (B, T, 3 E) q | k | v matrix: (out (B, T, E) fp32, lse, out as Planes (B T, E)) from
+    one launch -- the operand of the output projection without a split pass (msn_attention_fwd_planes)."""
+    B, T, E3 = qkv.shape
+    E = E3 // 3
+    planes = PLANES if planes is None else planes
+    _f32c(qkv, "qkv")
+    assert qkv.stride(2) == 1 and qkv.stride(0) == T * qkv.stride(1)
+    out = torch.empty((B, T, E), dtype=torch.float32, device=qkv.device)
+    lse = torch.empty((B, heads, T, 2), dtype=torch.float32, device=qkv.device)
+    op = Planes.empty(B * T, E, planes, qkv.device)
+    hd = E // heads
+    prof = ATTN_PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().msn_attention_fwd_planes(ptr(qkv), qkv.stride(1), ptr(mask_u8), B, heads, T, hd, scale, ptr(out), E, ptr(lse), planes,
+                                         ptr(op.buf), stream_ptr()), "msn_attention_fwd_planes")
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, 4.0 * B * heads * T * T * hd, (B, heads, T, T, hd), "fwd"))
+    return out, lse, op
+
+
 ATTN_BWD_PLANES = __import__("os").environ.get("MSN_ATTN_BWD_PLANES", "1") != "0"      # 0: msn_attention_bwd + msn_plane_split (A/B runs)
+ATTN_FWD_PLANES = __import__("os").environ.get("MSN_ATTN_FWD_PLANES", "1") != "0"      # 0: msn_attention_fwd + msn_plane_split (A/B runs)
+
+
+def attention_fwd_planes_supported(T, head_dim):
+    return ATTN_FWD_PLANES and T <= 128 and head_dim % 16 == 0 and head_dim <= 64
 
 
 def attention_bwd_planes_supported(T, head_dim):

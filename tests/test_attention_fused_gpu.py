@@ -125,3 +125,24 @@ def test_rejects_what_it_cannot_do():
     out, lse = torch.empty(2, 65, 16, device="cuda"), torch.empty(2, 2, 65, 2, device="cuda")
     with pytest.raises(MsnError):
         ops.attention_bwd_planes(qkv, 2, 0.125, out, lse, dout, 3)
+
+
+@pytest.mark.parametrize("B,T,H,hd", [(8, 65, 6, 64), (3, 33, 2, 32), (5, 64, 4, 16), (2, 128, 3, 64), (7, 17, 2, 64), (3, 65, 1, 16),
+                                      (2, 40, 3, 16), (4, 1, 2, 64), (1024, 65, 6, 64)])
+@pytest.mark.parametrize("planes", [3, 2])
+def test_forward_writing_planes(B, T, H, hd, planes):
+    """msn_attention_fwd_planes: out and lse are msn_attention_fwd's, bit for bit, and the plane matrix is msn_plane_split(out)'s bytes
+    (rows of a sample start anywhere in a 32-row block; (B T) % 32 != 0 and E % 32 == 16 leave padding the call must zero)."""
+    from multimodal_supernovae_amd import ops
+    e = H * hd
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    qkv = torch.randn(B, T, 3 * e, generator=g).cuda()
+    mask = (torch.rand(B, T, generator=g) > 0.2).to(torch.uint8).cuda() if T > 4 and B < 100 else None
+    scale = 1.0 / math.sqrt(e)
+    ref, lse_ref = ops.attention_fwd(qkv[..., :e], qkv[..., e:2 * e], qkv[..., 2 * e:], mask, H, scale)
+    out, lse, op = ops.attention_fwd_planes(qkv, H, scale, planes, mask_u8=mask)
+    assert torch.equal(out, ref) and torch.equal(lse, lse_ref)
+    want = ops.plane_split(ref.view(B * T, e), planes)
+    assert torch.equal(op.buf, want.buf)
+    again = ops.attention_fwd_planes(qkv, H, scale, planes, mask_u8=mask)[2]      # into a fresh (uninitialised) buffer: padding written
+    assert torch.equal(again.buf, want.buf)

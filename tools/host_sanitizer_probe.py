@@ -45,6 +45,9 @@ for bad in (lambda: L.msn_plane_split(None, 4, 4, 4, 3, 0, None, None, None, 0, 
             lambda: L.msn_pgemm_tn(256, 128, 66, 3, fake, fake, fake, 66, None, 0, None),
             lambda: L.msn_pgemm_tn(256, 1 << 19, 64, 3, fake, fake, fake, 64, None, 0, None),
             lambda: L.msn_attention_bwd_planes(fake, 1152, None, 4, 6, 200, 64, 0.125, fake, 384, fake, fake, 384, 3, fake, None, None, 0, None),
+            lambda: L.msn_attention_fwd_planes(fake, 1152, None, 4, 6, 200, 64, 0.125, fake, 384, fake, 3, fake, None),
+            lambda: L.msn_attention_fwd_planes(fake, 1152, None, 4, 6, 65, 24, 0.125, fake, 384, fake, 3, fake, None),
+            lambda: L.msn_attention_fwd_planes(fake, 1152, None, 4, 6, 65, 64, 0.125, fake, 384, fake, 4, fake, None),
             lambda: L.msn_attention_bwd_planes(fake, 1152, None, 4, 6, 65, 8, 0.125, fake, 384, fake, fake, 384, 3, fake, None, None, 0, None),
             lambda: L.msn_attention_bwd_planes(fake, 1152, None, 4, 6, 65, 64, 0.125, fake, 384, fake, fake, 384, 5, fake, None, None, 0, None),
             lambda: L.msn_attention_bwd_planes(fake, 1152, None, 4, 6, 65, 64, 0.125, fake, 384, fake, fake, 384, 3, fake, fake, fake, 16, None),
