@@ -304,6 +304,9 @@ size_t msn_pgemm_nt_colsum_workspace_bytes(int64_t M, int N);
  * workspace (NULL / too small) the tail tiles are multiplied whole.  msn_set_pgemm_tail_split(0) turns the split off. */
 size_t msn_pgemm_nt_workspace_bytes(int64_t M, int N, int K, int planes, int c_planes, int epilogue, int want_colsum);
 int msn_set_pgemm_tail_split(int enabled);
+/* Tile walk of msn_pgemm_nt (measurements; 0 = the planner's choice): tile columns per column group -- an XCD's run of tiles
+ * stays inside one group and re-reads only that group's weight planes -- and tile rows per super-row. */
+int msn_set_pgemm_walk(int col_group, int super_rows);
 int msn_pgemm_nt(int64_t M, int N, int K, int planes, const void* A, const void* B, void* C, int64_t ldc, int c_planes,
                  const float* bias, int epilogue, float* aux, int64_t ldaux, float* colsum_out, void* ws, size_t ws_bytes,
                  msn_stream_t stream);

@@ -69,6 +69,7 @@ SIGNATURES = {
     "msn_pgemm_nt_colsum_workspace_bytes": (c_size, [c_i64, c_int]),
     "msn_pgemm_nt_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int, c_int, c_int, c_int]),
     "msn_set_pgemm_tail_split": (c_int, [c_int]),
+    "msn_set_pgemm_walk": (c_int, [c_int, c_int]),
     "msn_pgemm_nt": (c_int, [c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_i64, c_ptr,
                              c_ptr, c_size, c_ptr]),
     "msn_pgemm_tn_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int]),

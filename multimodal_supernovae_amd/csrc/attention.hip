@@ -507,13 +507,13 @@ extern "C" int msn_attention_fwd(const float* q, int64_t ldq, int64_t q_bstride,
         if (mattn_applicable(m) && (head_dim >= 16 || g_attn_path == 2)) return mattn_forward(m, st);
     }
     const int S = pad_head(head_dim);
-    if (S < 0) {                                           // wider than 32: matrix cores only (also under mode 1)
+    if (S < 0) {                                           // wider than 32: matrix cores only (also under mode 1), shared query included
         MAttn m = {};
         m.q = q; m.k = k; m.v = v; m.out = out; m.mask = key_mask; m.lse = lse;
         m.ldq = ldq; m.ldk = ldk; m.ldv = ldv; m.ldo = ldo;
         m.q_bs = q_bstride; m.k_bs = k_bstride; m.v_bs = v_bstride; m.o_bs = o_bstride;
         m.B = B; m.H = H; m.Tq = Tq; m.Tk = Tk; m.hd = head_dim; m.scale = scale;
-        MSN_REQUIRE(mattn_applicable(m), "msn_attention_fwd: a head width above 32 (%d) must be a multiple of 4 with 16-byte aligned "
+        MSN_REQUIRE(mattn_applicable(m, true), "msn_attention_fwd: a head width above 32 (%d) must be a multiple of 4 with 16-byte aligned "
                     "rows (pad the heads with zero columns)", head_dim);
         return mattn_forward(m, st);
     }
@@ -562,7 +562,7 @@ extern "C" int msn_attention_bwd(const float* q, int64_t ldq, int64_t q_bstride,
         if (mattn_applicable(m) && (head_dim >= 16 || g_attn_path == 2)) return mattn_backward(m, st);
     }
     const int S = pad_head(head_dim);
-    if (S < 0) {                                           // wider than 32: matrix cores only (also under mode 1)
+    if (S < 0) {                                           // wider than 32: matrix cores only (also under mode 1), shared query included
         MAttn m = {};
         m.q = q; m.k = k; m.v = v; m.o = out; m.dout = dout; m.dq = dq; m.dk = dk; m.dv = dv;
         m.mask = key_mask; m.lse = const_cast<float*>(lse); m.delta = delta;
@@ -570,7 +570,7 @@ extern "C" int msn_attention_bwd(const float* q, int64_t ldq, int64_t q_bstride,
         m.q_bs = q_bstride; m.k_bs = k_bstride; m.v_bs = v_bstride; m.o_bs = o_bstride; m.d_bs = d_bstride;
         m.dq_bs = dq_bstride; m.dk_bs = dk_bstride; m.dv_bs = dv_bstride;
         m.B = B; m.H = H; m.Tq = Tq; m.Tk = Tk; m.hd = head_dim; m.scale = scale;
-        MSN_REQUIRE(mattn_applicable(m), "msn_attention_bwd: a head width above 32 (%d) must be a multiple of 4 with 16-byte aligned "
+        MSN_REQUIRE(mattn_applicable(m, true), "msn_attention_bwd: a head width above 32 (%d) must be a multiple of 4 with 16-byte aligned "
                     "rows (pad the heads with zero columns)", head_dim);
         return mattn_backward(m, st);
     }

@@ -22,7 +22,8 @@ struct MAttn {
     int o_np, o_cb;           // planes (2 | 3), column blocks of the plane matrix
 };
 
-bool mattn_applicable(const MAttn& a);
+// shared_q: also accept q_bs == 0 (one query shared by the batch: every kernel reads Q at q + b * q_bs and writes dq per sample)
+bool mattn_applicable(const MAttn& a, bool shared_q = false);
 int mattn_forward(const MAttn& a, hipStream_t st);
 int mattn_backward(const MAttn& a, hipStream_t st);
 

@@ -1470,8 +1470,8 @@ static int launch_big_lds(K kernel, dim3 grid, dim3 block, size_t lds, hipStream
 // Is the matrix-core path applicable?  (16-B aligned operands, head width a multiple of 4 up to 128: a width that is not a
 // multiple of 16 runs as the next one, its missing columns zeros in LDS / registers only.)
 static int padded_hd(int hd) { return (hd + 15) / 16 * 16; }
-bool mattn_applicable(const MAttn& a) {
-    if (a.hd % 4 != 0 || a.hd > 128 || a.hd < 4 || a.Tq > 65535 || a.Tk > 65535 || a.q_bs == 0) return false;
+bool mattn_applicable(const MAttn& a, bool shared_q) {
+    if (a.hd % 4 != 0 || a.hd > 128 || a.hd < 4 || a.Tq > 65535 || a.Tk > 65535 || (a.q_bs == 0 && !shared_q)) return false;
     if ((int64_t)a.B * a.H * ((std::max(a.Tq, a.Tk) + 127) / 128) > 0x7fffffffLL) return false;
     const int64_t lds[] = {a.ldq, a.ldk, a.ldv, a.q_bs, a.k_bs, a.v_bs};
     for (int64_t v : lds)

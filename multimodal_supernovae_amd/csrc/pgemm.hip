@@ -60,14 +60,8 @@ __global__ __launch_bounds__(256) void pgemm_tail_finish_kernel(const PgemmArgs 
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)tiles_tail * per_tile) return;
     const int tt = (int)(i / per_tile), e = (int)(i % per_tile);
-    // the tile's position: the same XCD-aware map as the kernel's
-    const int total = p.tiles_m * p.tiles_n, t = p.tail_full + tt;
-    const int q = total / 8, r = total % 8, x = t % 8, ii = t / 8;
-    const int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + ii;
-    const int SR = p.super_rows;
-    const int sr = bid / (SR * p.tiles_n), j = bid % (SR * p.tiles_n);
-    const int rows_sr = min(SR, p.tiles_m - sr * SR);
-    const int tm = sr * SR + j % rows_sr, tn = j / rows_sr;
+    int tm, tn;
+    nt_locate(p, p.tail_full + tt, tm, tn);       // the tile's position: the kernel's own map
     const int row = e / (bn / 4), c4 = e % (bn / 4);
     const int64_t m = (int64_t)tm * BM + row;
     const int n = tn * bn + 4 * c4;
@@ -360,6 +354,8 @@ extern "C" size_t msn_colsum_workspace_bytes(int64_t M, int64_t N);       // gem
 extern "C" int msn_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, float* out, void* ws, size_t ws_bytes, msn_stream_t stream);
 
 static int g_pgemm_bn = 0;          // 0 = planned, 128 / 256 forced (measurements)
+static int g_pgemm_colgroup = 0;    // NT tile walk: tile columns per column group (0 = the planner's choice; experiments)
+static int g_pgemm_sr = 0;          // NT tile walk: tile rows per super-row (0 = the planner's choice; experiments)
 static int g_pgemm_skew = 0;        // NT start skew (shader cycles per phase; experiments)
 extern "C" int msn_set_pgemm_skew(int cycles) {
     g_pgemm_skew = cycles;
@@ -549,6 +545,11 @@ NtTail nt_tail_plan(int64_t M, int N, int K, int c_planes, int epilogue, bool wa
     return t;
 }
 }  // namespace
+extern "C" int msn_set_pgemm_walk(int col_group, int super_rows) {
+    MSN_REQUIRE(col_group >= 0 && super_rows >= 0 && super_rows <= 64, "msn_set_pgemm_walk: col_group >= 0, 0 <= super_rows <= 64 (0 = the planner's choice)");
+    g_pgemm_colgroup = col_group, g_pgemm_sr = super_rows;
+    return MSN_OK;
+}
 extern "C" int msn_set_pgemm_tail_split(int enabled) {
     g_pgemm_tail = enabled ? 1 : 0;
     return MSN_OK;
@@ -585,6 +586,8 @@ static int pgemm_nt_impl(int64_t M, int N, int K, int planes, const void* A, con
     MSN_REQUIRE(M < (1ll << 31) * 32, "msn_pgemm_nt: too many rows");
     // the epilogue addresses C / aux through buffer descriptors per tile row with 32-bit lane offsets (pgemm_kernels.h)
     MSN_REQUIRE(N < (1 << 20) && (c_planes || ldc < (1 << 20)) && (!aux || ldaux < (1 << 20)), "msn_pgemm_nt: row strides must be below 2^20 elements");
+    // the ring addresses its sources by 32-bit byte offsets inside a 2-GB descriptor: up to 8 row blocks of K / 16 column blocks, `planes` 1-KB images each
+    MSN_REQUIRE(K < (1 << 19), "msn_pgemm_nt: K must be below 2^19 (32-bit offsets inside the row blocks of a tile)");
     PgemmArgs a = {};
     a.A = static_cast<const unsigned char*>(A); a.B = static_cast<const unsigned char*>(B); a.C = C;
     a.aux = aux; a.bias = bias; a.ldc = ldc; a.ldaux = ldaux; a.M = M; a.N = N; a.K = K;
@@ -598,6 +601,9 @@ static int pgemm_nt_impl(int64_t M, int N, int K, int planes, const void* A, con
     a.tiles_m = (int)cdiv(M, BM); a.tiles_n = (int)cdiv(N, bn);
     // super-rows: tile-rows walked together while their A panels (256 rows x K x 2 NP bytes) fit half an L2
     a.super_rows = (int)std::max<int64_t>(1, std::min<int64_t>(8, (2 << 20) / ((int64_t)BM * K * 2 * planes)));
+    a.col_group = a.tiles_n;
+    if (g_pgemm_sr > 0) a.super_rows = g_pgemm_sr;
+    if (g_pgemm_colgroup > 0) a.col_group = std::min(g_pgemm_colgroup, a.tiles_n);
     // fp32 grade: reductions longer than 768 columns are cut into chunks of at most 512 (the partial sums meet in C by fp32 adds)
     a.chunk_steps = 0;
     {

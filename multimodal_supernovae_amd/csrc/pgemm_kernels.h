@@ -19,6 +19,13 @@ typedef unsigned short u16;
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
+// Cache policy of the NT epilogue's FINAL stores (buffer aux bits; diagnostic builds: 2 = nt).  Measured in round 6 (profiles/
+// r06_experiments_tried.txt, item 2): nt on the final stores is -3 % on the K = 384 launches in isolation (+1 % when K-chunk partial
+// sums, which are re-read within microseconds, go out nt as well) and NOTHING on the training step (64.60 vs 64.59 ms): the next
+// kernel reads what this one wrote.  Default policy kept.
+#ifndef MSN_PG_ST_AUX
+#define MSN_PG_ST_AUX 0
+#endif
 constexpr int PBLK = 1024;          // bytes of one plane image of one 32 x 16 block
 constexpr int BM = 256;             // tile rows
 
@@ -35,6 +42,7 @@ struct PgemmArgs {
     int cbA, cbB;                   // column blocks of A / B (NT: both = K-steps)
     int cbC;                        // column blocks of a plane output
     int tiles_m, tiles_n, super_rows, epi;
+    int col_group;                  // NT: tile columns per column group of the tile walk (tiles_n = one group: super-rows span every column)
     int colsum_rows;                // NT: column-sum partial rows per tile row (= WM of the kernel's wave layout)
     int chunk_steps;                // NT: K-steps per chunk (0 = the whole reduction in one accumulation)
     int tail_full;                  // NT: tiles [0, tail_full) are dealt whole; [tail_full, total) are the TAIL tiles, each cut into
@@ -122,6 +130,26 @@ __device__ __forceinline__ void split_planes(float x, u16 (&pl)[NP]) {
     }
 }
 
+// The NT kernel's tile walk (also used by its tail-finishing launch): tile ids are dealt round-robin to the 8 XCDs; each XCD gets a
+// contiguous run of the walk, which covers the tile grid in super-rows (SR tile-rows x the columns of a group, row-fastest) so
+// that the workgroups of an XCD share A row panels and the weight planes in one L2.
+// COLUMN GROUPS (col_group < tiles_n): the walk covers the grid one group of col_group tile columns after the other, so an XCD's
+// run lies inside one group (or two) and re-reads only THAT group's weight planes row after row -- a weight whose planes do
+// not stay in a 4-MB L2 beside the A panels of a round (N = 1536: 3.5 MB) is otherwise fetched once per super-row; the price
+// is that a tile row's A panel is read by the XCDs of every group.
+__device__ __forceinline__ void nt_locate(const PgemmArgs& p, int t, int& tm_, int& tn_) {
+    const int total = p.tiles_m * p.tiles_n;
+    const int q = total / 8, r = total % 8, x = t % 8, i = t / 8;
+    const int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    const int SR = p.super_rows, CG = p.col_group;
+    const int grp = min(bid / (p.tiles_m * CG), (p.tiles_n - 1) / CG), within = bid - grp * (p.tiles_m * CG);
+    const int gcols = min(CG, p.tiles_n - grp * CG);
+    const int sr = within / (SR * gcols), j = within % (SR * gcols);
+    const int rows_sr = min(SR, p.tiles_m - sr * SR);
+    tm_ = sr * SR + j % rows_sr;
+    tn_ = grp * CG + j / rows_sr;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // NT kernel.  LDS slot = [A: 8 row blocks][NP planes][1 KB] then [B: BN / 32 row blocks][NP][1 KB].  Inside a plane image
 // the 16-byte half h of row r sits at chunk 2 r + (h ^ swz(r)), swz(r) = (r >> 3) & 1 (applied on the DMA source address):
@@ -164,17 +192,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
     const int total = p.tiles_m * p.tiles_n;
     const int nk = p.cbA;                            // K-steps per tile
 
-    // tile order: ids are dealt round-robin to the 8 XCDs; each XCD gets a contiguous run of tiles walked in super-rows
-    // (SR tile-rows x all tile columns, row-fastest) so that its workgroups share A row panels and the weight in one L2
-    auto locate = [&](int t, int& tm_, int& tn_) {
-        const int q = total / 8, r = total % 8, x = t % 8, i = t / 8;
-        const int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-        const int SR = p.super_rows;
-        const int sr = bid / (SR * p.tiles_n), j = bid % (SR * p.tiles_n);
-        const int rows_sr = min(SR, p.tiles_m - sr * SR);
-        tm_ = sr * SR + j % rows_sr;
-        tn_ = j / rows_sr;
-    };
+    // tile order: nt_locate above
+    auto locate = [&](int t, int& tm_, int& tn_) { nt_locate(p, t, tm_, tn_); };
     // idx-th SEGMENT of this workgroup: its whole tiles first (every K-step), then -- tail split -- at most one unit: a K range
     // of one of the tiles that do not fill a round of the G workgroups (the host cuts each of them into tail_segs ranges so that
     // the units spread over the chip instead of a few workgroups multiplying a whole extra tile while the others wait)
@@ -258,9 +277,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
         const int soff = poff[q] + p_k * (NP * PBLK);
 #endif
         const uint64_t src = ((uint64_t)(fromA ? srcA_hi : srcB_hi) << 32) | (fromA ? srcA_lo : srcB_lo);
-        if (id < PIECES)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(src), (short)0, 0x7fffffff, 0x00020000),
-                                                     (lptr_t*)(lds + p_slot * SLOT + id * PBLK), 16, lane_src, soff, 0, 0);
+#ifndef MSN_PG_A_AUX                         // diagnostic builds: cache policy of the A operand's pieces (2 = nt: streamed, first to leave the L2)
+#define MSN_PG_A_AUX 0
+#endif
+        if (id < PIECES) {
+            if (fromA)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(src), (short)0, 0x7fffffff, 0x00020000),
+                                                         (lptr_t*)(lds + p_slot * SLOT + id * PBLK), 16, lane_src, soff, 0, MSN_PG_A_AUX);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(src), (short)0, 0x7fffffff, 0x00020000),
+                                                         (lptr_t*)(lds + p_slot * SLOT + id * PBLK), 16, lane_src, soff, 0, 0);
+        }
     };
     // gap c of NG (behind the c-th plane product of a K-step): pieces [c MAXQ / NG, (c + 1) MAXQ / NG); STAG: the low waves
     // issue theirs in the gaps 0 .. HG - 1, the high waves in HG .. NG - 2 (none behind the barrier: the counted wait stays
@@ -590,7 +617,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
     };
     // accumulator layout -> rows m0.., columns n0.. of `dst` in memory order: stage_chunk(b, 4 values) four times, then flush
     auto stage_chunk = [&](int b, const float (&w)[4]) { lds_w128(acc_addr(b), w); };
-    auto tile_flush = [&](rsrc_t rs, int64_t ld, int r0, int n0) {
+    auto tile_flush = [&](rsrc_t rs, int64_t ld, int r0, int n0, auto final_) {
+        constexpr int AUX = decltype(final_)::value ? MSN_PG_ST_AUX : 0;
         f32x4 r[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) lds_r128(r[q], st_mem + q * 1024);
@@ -600,7 +628,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
         const unsigned lo = n < p.N ? (unsigned)((srow * (int)ld + n) * 4) : OOB;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r[q]), rs, (int)(lo + (unsigned)((r0 + 8 * q) * (int)ld * 4)), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r[q]), rs, (int)(lo + (unsigned)((r0 + 8 * q) * (int)ld * 4)), 0, AUX);
     };
     auto slab_flush = [&](rsrc_t rs, int r0, int c0) {              // the staged tile -> rows r0.., columns c0.. of a 256 x BN slab
         f32x4 r[4];
@@ -692,10 +720,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
                     for (int b = 0; b < 4; ++b) {
                         float dg[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) gelu_both(v[4 * b + r], v[4 * b + r], dg[r]);
+                        for (int r = 0; r < 4; ++r) {
+#ifdef MSN_ABL_PG_NOGELU                     // diagnostic build (plane-output ablations, profiles/r06_pgemm_planeout_ablation.txt): no GELU arithmetic
+                            dg[r] = v[4 * b + r];
+#else
+                            gelu_both(v[4 * b + r], v[4 * b + r], dg[r]);
+#endif
+                        }
+#ifndef MSN_ABL_PG_NOAUXST                   // diagnostic build: the saved GELU' matrix is neither staged nor stored
                         if (p.aux) stage_chunk(b, dg);
+#endif
                     }
-                    if (p.aux) tile_flush(rsAux, p.ldaux, wm * (32 * MT) + 32 * i, n0);
+#ifndef MSN_ABL_PG_NOAUXST
+                    if (p.aux) tile_flush(rsAux, p.ldaux, wm * (32 * MT) + 32 * i, n0, std::true_type{});
+#endif
                 } else if constexpr (!PARTIAL && epi == MSN_EPI_RELU) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -729,8 +767,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
                         unsigned lo[NP], hi[NP];
+#ifdef MSN_ABL_PG_NOSPLIT                    // diagnostic build: no split arithmetic (the raw words go out as "planes")
+#pragma unroll
+                        for (int k = 0; k < NP; ++k) lo[k] = __float_as_uint(v[4 * b + (k & 1)]), hi[k] = __float_as_uint(v[4 * b + 2 + (k & 1)]);
+#else
                         split_pair<NP>(v[4 * b], v[4 * b + 1], lo);
                         split_pair<NP>(v[4 * b + 2], v[4 * b + 3], hi);
+#endif
                         unsigned at = stg + (unsigned)(((ecolq(b) >> 2) * NP) * PBLK + erow(b) * 32 + (ecolq(b) & 3) * 8);
                         static_for<0, NP>([&](auto k_) {
                             constexpr int k = decltype(k_)::value;
@@ -749,10 +792,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(img[0]), "+v"(img[1]), "+v"(img[2]), "+v"(img[3])::"memory");
                     __builtin_amdgcn_sched_barrier(0);
                     const int blk = ((wm * MT + i) * p.cbC + (n0 >> 4)) * (NP * PBLK) + eln * 16;      // inside the tile row's 8 row blocks
+#ifndef MSN_ABL_PG_NOPSTORE                  // diagnostic build: the plane images are built but not stored
 #pragma unroll
                     for (int q = 0; q < 2 * NP; ++q)
                         if (n0 + 16 * (q / NP) < 16 * p.cbC)      // incl. the zero padding block of N % 32 == 16
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, img[q]), rsC, blk + q * PBLK, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, img[q]), rsC, blk + q * PBLK, 0, MSN_PG_ST_AUX);
+#else
+                    asm volatile("" ::"v"(img[0]), "v"(img[1]), "v"(img[2]), "v"(img[3]));
+                    (void)blk;
+#endif
                 } else {
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
@@ -763,7 +811,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
                         slab_flush(uniform_rsrc(p.tail_slabs + (int64_t)blockIdx.x * (BM * BN), BM * BN * 4), wm * (32 * MT) + 32 * i,
                                    wn * (32 * NT) + 32 * j);
                     else
-                        tile_flush(rsC, p.ldc, wm * (32 * MT) + 32 * i, n0);
+                        tile_flush(rsC, p.ldc, wm * (32 * MT) + 32 * i, n0, std::integral_constant<bool, !PARTIAL>{});
                 }
                 if constexpr (CS) {
 #pragma unroll

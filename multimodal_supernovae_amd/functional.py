@@ -593,14 +593,15 @@ class _PlaneVitTrunk(torch.autograd.Function):
     NS = 10   # tensors saved per block
 
     @staticmethod
-    def forward(ctx, x, heads, eps, n_blocks, *P):
+    def forward(ctx, x, heads, eps, n_blocks, need_grad, *P):
+        # need_grad comes from the caller (plane_vit_trunk): ctx.needs_input_grad reflects requires_grad flags, not the grad mode, and
+        # inside forward() the grad mode is always off -- under torch.no_grad() with trainable parameters it would stay True
         B, T, e = x.shape
         M = B * T
         NPL = ops.plane_count()
         scale = 1.0 / math.sqrt(e // heads)
         x2 = _c(x).view(M, e)
         saved, planes = [], []
-        need_grad = any(ctx.needs_input_grad)
         # the planes of every block's four weight matrices from one launch (44 launches of 5-6 us in the headline tower)
         wp = ops.plane_split_list([P[12 * i + k] for i in range(n_blocks) for k in (2, 4, 8, 10)], NPL)
         for i in range(n_blocks):
@@ -680,13 +681,14 @@ class _PlaneVitTrunk(torch.autograd.Function):
             d2, d2p, dg1, db1, dc2 = ops.layernorm_bwd_planes(dh1, x2, m1, r1, g1, NPL, add=dx1, want_colsum=True)    # + skip
             grads[12 * i], grads[12 * i + 1] = dg1, db1
             ctx.planes[i] = None                              # this block's planes are done with
-        return (d2.view(B, T, e), None, None, None, *grads)
+        return (d2.view(B, T, e), None, None, None, None, *grads)
 
 
 def plane_vit_trunk(x, heads, eps, block_params):
     """block_params: one 12-tuple (g1, b1, wqkv, bqkv, wo, bo, g2, b2, w1, c1, w2, c2) per block."""
     flat = [p for blk in block_params for p in blk]
-    return _PlaneVitTrunk.apply(x, heads, eps, len(block_params), *flat)
+    need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in flat))
+    return _PlaneVitTrunk.apply(x, heads, eps, len(block_params), need_grad, *flat)
 
 
 def plane_path_ok(x):

@@ -420,7 +420,7 @@ def attention_bwd(q, k, v, mask_u8, heads, scale, out, lse, dout, dq, dk, dv, q_
     if _needs_head_padding(hd, q, k, v, out, dout, dq, dk, dv):
         hp = (hd + 3) // 4 * 4
         qp, kp, vp, op, dop = (_pad_heads(t, heads, hd, hp) for t in (q, k, v, out, dout))
-        gq, gk, gv = torch.empty_like(qp), torch.empty_like(kp), torch.empty_like(vp)
+        gq, gk, gv = torch.empty_like(op), torch.empty_like(kp), torch.empty_like(vp)     # (dq per sample, also for a shared query)
         attention_bwd(qp, kp, vp, mask_u8, heads, scale, op, lse, dop, gq, gk, gv, q_shared)
         for dst, src in ((dq, gq), (dk, gk), (dv, gv)):
             dst.copy_(src.view(src.shape[0], src.shape[1], heads, hp)[..., :hd].reshape(src.shape[0], src.shape[1], E))
@@ -1234,6 +1234,11 @@ def layernorm_bwd_planes(dy, x, mean, rstd, gamma, planes, add=None, want_colsum
 def set_pgemm_variant(v):
     """Wave layout of the 3-plane pgemm_nt kernel (msn_set_pgemm_variant) -- measurements."""
     check(lib().msn_set_pgemm_variant(int(v)))
+
+
+def set_pgemm_walk(col_group=0, super_rows=0):
+    """pgemm_nt tile walk (msn_set_pgemm_walk; 0 = the planner's choice) -- measurements."""
+    check(lib().msn_set_pgemm_walk(int(col_group), int(super_rows)))
 
 
 def set_pgemm_tail_split(enabled):

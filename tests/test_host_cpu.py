@@ -56,6 +56,11 @@ def test_shape_errors_are_reported_without_a_gpu():
     assert lib.msn_pgemm_tn_workspace_bytes(1 << 22, 8192, 8192, 3) == 97 * 8192 * 8192 * 4
     rc = lib.msn_pgemm_tn(256, 1 << 19, 64, 3, fake, fake, fake, 64, None, 0, None)
     assert rc == 1 and b"2^19" in lib.msn_last_error()
+    # the NT product's ring uses 32-bit offsets over K as well (8 row blocks x K / 16 column blocks x planes x 1 KB < 2 GB)
+    rc = lib.msn_pgemm_nt(256, 128, 1 << 19, 3, fake, fake, fake, 128, 0, None, 0, None, 0, None, None, 0, None)
+    assert rc == 1 and b"K must be below 2^19" in lib.msn_last_error()
+    rc = lib.msn_pgemm_nt(256, 1 << 20, 64, 3, fake, fake, fake, 1 << 20, 0, None, 0, None, 0, None, None, 0, None)
+    assert rc == 1 and b"2^20" in lib.msn_last_error()
 
 
 def test_no_cpu_fallback():

@@ -168,11 +168,15 @@ def test_attention_fwd_bwd_packed_qkv(B, T, E, heads, masked, path, attention_pa
     torch.testing.assert_close(dqkv.cpu().double(), r.grad, rtol=2e-4, atol=2e-5)
 
 
-def test_attention_single_shared_query():
-    """The attn-pooling shape: one learnable query shared by the batch, no mask, scale 1/sqrt(head_dim)."""
+@pytest.mark.parametrize("T,E", [(50, 16), (50, 64), (50, 128), (50, 256), (300, 128), (300, 256), (50, 140), (50, 36)])
+def test_attention_single_shared_query(T, E):
+    """The attn-pooling shape: one learnable query shared by the batch (q_bstride = 0), no mask, scale 1/sqrt(head_dim).
+    Heads up to 32 wide run on the vector-ALU kernels, wider ones (emb 128 / 256 of ref transformer_utils.py:197-204 with its 2
+    pooling heads = 64- / 128-wide heads) on the matrix cores, below and above their 128-token limit; 70- and 18-wide heads exercise
+    the binding's zero-column padding with a shared query."""
     from multimodal_supernovae_amd import ops
-    g = _g(77)
-    B, T, E, heads = 4, 50, 16, 2
+    g = _g(77 + T + E)
+    B, heads = 4, 2
     q = torch.randn(1, 1, E, generator=g)
     k, v = torch.randn(B, T, E, generator=g), torch.randn(B, T, E, generator=g)
     dout = torch.randn(B, 1, E, generator=g)

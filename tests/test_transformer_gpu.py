@@ -130,6 +130,34 @@ def test_maven_sized_towers_against_oracle():
             close(p.grad.cpu(), P[k].grad, "grad " + k)
 
 
+@pytest.mark.parametrize("e,h,T", [(128, 2, 40), (256, 2, 40), (128, 4, 160)])
+def test_attention_pooling_with_wide_heads_against_oracle(e, h, T):
+    """agg="attn" (ref transformer_utils.py:197-204, 240-246): nn.MultiheadAttention(emb, 2 heads) with ONE learnable query shared
+    by the batch.  At the reference's default emb 256 (and at 128) the pooling heads are 128 / 64 wide: a shared query on the
+    matrix-core kernels (the vector-ALU kernels stop at 32)."""
+    from multimodal_supernovae_amd.transformer_utils import TransformerWithTimeEmbeddings
+    from oracle import encoders as oenc
+    g = torch.Generator().manual_seed(e + T)
+    torch.manual_seed(3)
+    m = TransformerWithTimeEmbeddings(n_out=16, nband=1, agg="attn", time_norm=1000.0, emb=e, heads=h, depth=1)
+    P = {k: v.clone().requires_grad_() for k, v in m.state_dict().items()}
+    B = 6
+    x = torch.randn(B, T, 1, generator=g)
+    t = torch.sort(torch.rand(B, T, generator=g) * 100, dim=1)[0]
+    mask = torch.ones(B, T, dtype=torch.bool)
+    mask[1, T // 2:] = False
+    mask[4, 5:] = False
+    cot = torch.randn(B, 16, generator=g)
+    ref = oenc.transformer_with_time_embeddings(P, "", x, t, mask, emb=e, heads=h, depth=1, time_norm=1000.0, nband=1, agg="attn")
+    (ref * cot).sum().backward()
+    m.cuda()
+    y = m(x.cuda(), t.cuda(), mask.cuda())
+    close(y.detach().cpu(), ref.detach(), "y")
+    y.backward(cot.cuda())
+    for k, p in m.named_parameters():
+        close(p.grad.cpu(), P[k].grad, "grad " + k)
+
+
 def test_stacked_qkv_weights_are_one_persistent_buffer():
     """The fused q|k|v projection multiplies by ONE (3e, e) matrix; the three reference parameters are its row blocks
     (no per-step concatenation): values and state_dict keys unchanged, optimiser updates visible through the stacked
