@@ -466,10 +466,12 @@ int msn_set_attention_fused(int on);
  * plane products of the plane GEMMs (v_mfma_f32_16x16x32_bf16; the head-dimension products pack two planes into one
  * instruction's 32 k).  Same arguments, statistics layout and results (to fp32 rounding) as the exact-fp32 matrix-core
  * kernels it replaces; the accuracy gate is tests/test_attention_planes_gpu.py (error against fp64 <= 1.5 x theirs).
- * mode bit 0 = on (default 1; 0 = the v_mfma_f32_16x16x4_f32 kernels); measurement forms: bit 1 = one query tile per wave in the
- * forward (default two), bit 2 = two tiles per wave in the backward kernels (default one), bit 3 = the next chunk's rows
- * requested into registers under the current chunk's products, bits 4 - 5 = diagnostic ablations (wrong results).  Heads
- * narrower than 16 take this path only under msn_set_attention_path(2) (measured equal to the vector-ALU kernels there).
+ * The backward is ONE pass for 256 or more (sample, head) pairs -- every score tile computed once, dS transposed through LDS for
+ * the dQ product, a workgroup per pair walking all key blocks and summing dq over them in place (a small launch computes
+ * delta = rowsum(dO o O) first) -- and the dQ kernel followed by the dK,dV kernel below that.
+ * mode: 0 = off (the v_mfma_f32_16x16x4_f32 kernels), 1 = on (default), 3 = on with the two-kernel backward everywhere, 5 = on
+ * with the one-pass backward everywhere (tests, A/B runs).  Heads narrower than 16 take this path only under
+ * msn_set_attention_path(2) (measured equal to the vector-ALU kernels there).
  * Process-wide, not thread-safe (as every msn_set_* switch). */
 int msn_set_attention_planes(int mode);
 

@@ -560,6 +560,7 @@ extern "C" int msn_attention_bwd(const float* q, int64_t ldq, int64_t q_bstride,
         m.dq_bs = dq_bstride; m.dk_bs = dk_bstride; m.dv_bs = dv_bstride;
         m.B = B; m.H = H; m.Tq = Tq; m.Tk = Tk; m.hd = head_dim; m.scale = scale;
         if (mattn_applicable(m) && (head_dim >= 16 || g_attn_path == 2)) return mattn_backward(m, st);
+        if (g_attn_path == 0 && pattn_backward_preferred(m)) return pattn_backward(m, st);
     }
     const int S = pad_head(head_dim);
     if (S < 0) {                                           // wider than 32: matrix cores only (also under mode 1), shared query included

@@ -31,6 +31,7 @@ int mattn_backward(const MAttn& a, hipStream_t st);
 bool pattn_applicable(const MAttn& a);
 int pattn_forward(const MAttn& a, hipStream_t st);
 int pattn_backward(const MAttn& a, hipStream_t st);
+bool pattn_backward_preferred(const MAttn& a);   // heads narrower than 16 whose BACKWARD is faster on the planes (forward: vector ALU)
 
 // (sample, head, row block) of workgroup blockIdx.x; with B % 8 == 0 the H * NB workgroups of a sample are consecutive
 // workgroups of ONE XCD (ids go to the XCDs round-robin) and share the 128-byte lines of its q|k|v rows in that L2

@@ -67,6 +67,9 @@ __device__ __forceinline__ unsigned hi_pack(float a, float b) {
 struct Pair3 {
     unsigned p0, p1, p2;
 };
+// (Written on 2-vectors -- one v_pk_add_f32 per level and pair instead of two v_sub_f32, 9 instead of 11 instructions per pair --
+//  every kernel of this file got SLOWER by 3 - 5 %: r06 log, item 6.  A packed fp32 add is two issue cycles, and its operands
+//  want aligned register pairs.)
 __device__ __forceinline__ Pair3 split2(float a, float b) {
     const float ra = a - trunc16(a), rb = b - trunc16(b);
     const float sa = ra - trunc16(ra), sb = rb - trunc16(rb);
@@ -181,22 +184,29 @@ struct StagePair {
         *reinterpret_cast<u32x2*>(img1 + off + PB) = u32x2{ya.p1, yb.p1};
         *reinterpret_cast<u32x2*>(img1 + off + 2 * PB) = u32x2{ya.p2, yb.p2};
     }
-    __device__ __forceinline__ void load(const float* src0, const float* src1, int64_t l0, int64_t l1, int col, int rows, int width) {
+    // (tid: the thread's index, handed in as an OPAQUE copy per chunk by the callers -- opaque_tid() -- so that the piece indices
+    //  derived from it are recomputed per chunk instead of living across the block loop: they were what the allocator spilled)
+    __device__ __forceinline__ void load(const float* src0, const float* src1, int64_t l0, int64_t l1, int col, int rows, int width, int tid) {
         s0 = src0, s1 = src1, ld0 = l0, ld1 = l1, col0 = col, nt = rows, hd = width;
 #pragma unroll
-        for (int u = 0; u < UMAX; ++u) fetch(a[u], b[u], (int)threadIdx.x + u * (int)blockDim.x);
+        for (int u = 0; u < UMAX; ++u) fetch(a[u], b[u], tid + u * (int)blockDim.x);
     }
-    __device__ __forceinline__ void commit(unsigned char* img0, unsigned char* img1, float mul0 = 1.f) {
+    __device__ __forceinline__ void commit(unsigned char* img0, unsigned char* img1, int tid, float mul0 = 1.f) {
 #pragma unroll
-        for (int u = 0; u < UMAX; ++u) put(img0, img1, a[u], b[u], (int)threadIdx.x + u * (int)blockDim.x, mul0);
+        for (int u = 0; u < UMAX; ++u) put(img0, img1, a[u], b[u], tid + u * (int)blockDim.x, mul0);
         const int total = ((nt + 31) & ~31) * 4;
-        for (int idx = (int)threadIdx.x + UMAX * (int)blockDim.x; idx < total; idx += (int)blockDim.x) {   // small workgroups only
+        for (int idx = tid + UMAX * (int)blockDim.x; idx < total; idx += (int)blockDim.x) {   // small workgroups only
             float4 x, y;
             fetch(x, y, idx);
             put(img0, img1, x, y, idx, mul0);
         }
     }
 };
+__device__ __forceinline__ int opaque_tid() {
+    int t = (int)threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
 // row fragments (A operand of S / dP) of the 16-row tile t of a block: a01 = [x0 | x1], a02 = [x0 | x2]
 __device__ __forceinline__ void row_frags(const unsigned char* blk, int t, int c, int g, bf16x8& a01, bf16x8& a02) {
     const unsigned char* p = blk + t * 512 + c * 32 + (g & 1) * 16;
@@ -250,8 +260,8 @@ __device__ __forceinline__ int stage_caps(float* cap, float fill, const uint8_t*
 
 // ------------------------------------------------------------------------------------------ forward
 // Workgroup = (sample, head, block of 128 QT queries); wave w owns QT tiles of 16 queries; K / V stream through LDS in chunks.
-// p.tail carries diagnostic bits (tools/bench_attention_planes.py --ablate): 1 = stage the first chunk only, 2 = no products.
-template <int QT, bool PF>
+// (MSN_ABL_PATTN diagnostic builds: p.tail carries ablation bits -- 1 = stage the first chunk only, 2 = no products)
+template <int QT>
 __global__ __launch_bounds__(512, 4) void pattn_fwd_kernel(const MAttn p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* Ki = smem;
@@ -266,7 +276,6 @@ __global__ __launch_bounds__(512, 4) void pattn_fwd_kernel(const MAttn p) {
     const float* ksrc = p.k + (int64_t)b * p.k_bs;
     const float* vsrc = p.v + (int64_t)b * p.v_bs;
     StagePair sp;
-    if constexpr (PF) sp.load(ksrc, vsrc, p.ldk, p.ldv, col0, min(CH, p.Tk), p.hd);
     HeadFrags qf[QT];
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
@@ -284,14 +293,18 @@ __global__ __launch_bounds__(512, 4) void pattn_fwd_kernel(const MAttn p) {
     for (int k0 = 0; k0 < p.Tk; k0 += CH) {
         const int nt = min(CH, p.Tk - k0), nblk = (nt + 31) >> 5;
         __syncthreads();                                  // every wave is done with the previous chunk
-        if (!(p.tail & 1) || k0 == 0) {
-            if constexpr (!PF) sp.load(ksrc + (int64_t)k0 * p.ldk, vsrc + (int64_t)k0 * p.ldv, p.ldk, p.ldv, col0, nt, p.hd);
-            sp.commit(Ki, Vi);
+#ifdef MSN_ABL_PATTN
+        if (!(p.tail & 1) || k0 == 0)
+#endif
+        {
+            const int tid = opaque_tid();
+            sp.load(ksrc + (int64_t)k0 * p.ldk, vsrc + (int64_t)k0 * p.ldv, p.ldk, p.ldv, col0, nt, p.hd, tid);
+            sp.commit(Ki, Vi, tid);
         }
         const int special = __syncthreads_or(stage_caps(Cap, kFillP, p.mask, (int64_t)b * p.Tk + k0, nt));
-        if (PF && k0 + CH < p.Tk && !(p.tail & 1))        // the next chunk's rows: in flight while this one is multiplied
-            sp.load(ksrc + (int64_t)(k0 + CH) * p.ldk, vsrc + (int64_t)(k0 + CH) * p.ldv, p.ldk, p.ldv, col0, min(CH, p.Tk - k0 - CH), p.hd);
+#ifdef MSN_ABL_PATTN
         if (p.tail & 2) continue;
+#endif
         // MASKED: the chunk holds a masked-out or padding key -> one v_min per score against the per-key caps
         auto blocks = [&](auto masked_) {
         constexpr bool MASKED = decltype(masked_)::value;
@@ -345,10 +358,13 @@ __global__ __launch_bounds__(512, 4) void pattn_fwd_kernel(const MAttn p) {
         if (special) blocks(std::true_type{});
         else blocks(std::false_type{});
     }
+    // (the lane's place in the output, from an opaque copy of the thread index: kept from the kernel's start it was spilled)
+    const int te = opaque_tid(), ce = te & 15, ge = (te >> 4) & 3, q0e = blk * 128 * QT + (te >> 6) * 16 * QT;
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
         const float lt = group_sum(l[u]);
-        const int q = q0 + 16 * u + c;
+        const int q = q0e + 16 * u + ce;
+        const int g = ge;
         if (q < p.Tq) {
             const float inv = 1.f / lt;
             if (4 * g < p.hd) {                           // O^T[d = 4 g + r][query c]: one 16-byte store per lane
@@ -365,9 +381,10 @@ __global__ __launch_bounds__(512, 4) void pattn_fwd_kernel(const MAttn p) {
 }
 
 // ------------------------------------------------------------------------------------------ backward: dQ (and delta)
-// NT tiles of 16 queries per wave (the K / V fragments of a block serve all of them)
-template <int NT, bool PF>
-__global__ __launch_bounds__(512, NT == 1 ? 4 : 2) void pattn_bwd_dq_kernel(const MAttn p) {
+// (the two-kernel backward: cross attention, few (sample, head) pairs, and msn_set_attention_planes(3); self-attention over many
+//  pairs takes pattn_bwd_fused_kernel below)
+constexpr int NT = 1;                           // 16-row tiles per wave (two measured slower in both backward kernels: r05 log, item 3)
+__global__ __launch_bounds__(512, 4) void pattn_bwd_dq_kernel(const MAttn p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* Ki = smem;
     unsigned char* Vi = smem + NBK * BLK;
@@ -381,7 +398,6 @@ __global__ __launch_bounds__(512, NT == 1 ? 4 : 2) void pattn_bwd_dq_kernel(cons
     const float* ksrc = p.k + (int64_t)b * p.k_bs;
     const float* vsrc = p.v + (int64_t)b * p.v_bs;
     StagePair sp;
-    if constexpr (PF) sp.load(ksrc, vsrc, p.ldk, p.ldv, col0, min(CH, p.Tk), p.hd);
     HeadFrags qf[NT], df[NT];
     float delta[NT], mq[NT], ll2[NT];
     f32x4 qb[NT], qs[NT];
@@ -409,14 +425,18 @@ __global__ __launch_bounds__(512, NT == 1 ? 4 : 2) void pattn_bwd_dq_kernel(cons
     for (int k0 = 0; k0 < p.Tk; k0 += CH) {
         const int nt = min(CH, p.Tk - k0), nblk = (nt + 31) >> 5;
         __syncthreads();
-        if (!(p.tail & 1) || k0 == 0) {
-            if constexpr (!PF) sp.load(ksrc + (int64_t)k0 * p.ldk, vsrc + (int64_t)k0 * p.ldv, p.ldk, p.ldv, col0, nt, p.hd);
-            sp.commit(Ki, Vi);
+#ifdef MSN_ABL_PATTN
+        if (!(p.tail & 1) || k0 == 0)
+#endif
+        {
+            const int tid = opaque_tid();
+            sp.load(ksrc + (int64_t)k0 * p.ldk, vsrc + (int64_t)k0 * p.ldv, p.ldk, p.ldv, col0, nt, p.hd, tid);
+            sp.commit(Ki, Vi, tid);
         }
         const int special = __syncthreads_or(stage_caps(Cap, -INFINITY, p.mask, (int64_t)b * p.Tk + k0, nt));
-        if (PF && k0 + CH < p.Tk && !(p.tail & 1))
-            sp.load(ksrc + (int64_t)(k0 + CH) * p.ldk, vsrc + (int64_t)(k0 + CH) * p.ldv, p.ldk, p.ldv, col0, min(CH, p.Tk - k0 - CH), p.hd);
+#ifdef MSN_ABL_PATTN
         if (p.tail & 2) continue;
+#endif
         auto blocks = [&](auto masked_) {
         constexpr bool MASKED = decltype(masked_)::value;
         for (int kb = 0; kb < nblk; ++kb) {
@@ -465,8 +485,7 @@ __global__ __launch_bounds__(512, NT == 1 ? 4 : 2) void pattn_bwd_dq_kernel(cons
 }
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
-template <int NT, bool PF>
-__global__ __launch_bounds__(512, NT == 1 ? 4 : 2) void pattn_bwd_dkv_kernel(const MAttn p) {
+__global__ __launch_bounds__(512, 4) void pattn_bwd_dkv_kernel(const MAttn p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* Qi = smem;
     unsigned char* Di = smem + NBK * BLK;
@@ -482,7 +501,6 @@ __global__ __launch_bounds__(512, NT == 1 ? 4 : 2) void pattn_bwd_dkv_kernel(con
     const float* qsrc = p.q + (int64_t)b * p.q_bs;
     const float* dsrc = p.dout + (int64_t)b * p.d_bs;
     StagePair sp;
-    if constexpr (PF) sp.load(qsrc, dsrc, p.ldq, p.ldd, col0, min(CH, p.Tq), p.hd);
     // (the softmax scale multiplies Q here too, as in the forward and the dQ kernel: the recomputed scores are then the
     //  forward's scores bit for bit -- with the scale on K, as the exact-fp32 kernels place it, s - m of a row's largest score
     //  is a rounding difference instead of zero and a peaked softmax shows it in dV)
@@ -511,9 +529,13 @@ __global__ __launch_bounds__(512, NT == 1 ? 4 : 2) void pattn_bwd_dkv_kernel(con
     for (int i0 = 0; i0 < p.Tq; i0 += CH) {
         const int nt = min(CH, p.Tq - i0), nblk = (nt + 31) >> 5;
         __syncthreads();
-        if (!(p.tail & 1) || i0 == 0) {
-            if constexpr (!PF) sp.load(qsrc + (int64_t)i0 * p.ldq, dsrc + (int64_t)i0 * p.ldd, p.ldq, p.ldd, col0, nt, p.hd);
-            sp.commit(Qi, Di, p.scale);
+#ifdef MSN_ABL_PATTN
+        if (!(p.tail & 1) || i0 == 0)
+#endif
+        {
+            const int tid = opaque_tid();
+            sp.load(qsrc + (int64_t)i0 * p.ldq, dsrc + (int64_t)i0 * p.ldd, p.ldq, p.ldd, col0, nt, p.hd, tid);
+            sp.commit(Qi, Di, tid, p.scale);
         }
         for (int j = threadIdx.x; j < ((nt + 31) & ~31); j += blockDim.x) {
             const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + i0 + (j < nt ? j : 0);
@@ -522,9 +544,9 @@ __global__ __launch_bounds__(512, NT == 1 ? 4 : 2) void pattn_bwd_dkv_kernel(con
             Dl[j] = j < nt ? p.delta[stat] : 0.f;
         }
         __syncthreads();
-        if (PF && i0 + CH < p.Tq && !(p.tail & 1))
-            sp.load(qsrc + (int64_t)(i0 + CH) * p.ldq, dsrc + (int64_t)(i0 + CH) * p.ldd, p.ldq, p.ldd, col0, min(CH, p.Tq - i0 - CH), p.hd);
+#ifdef MSN_ABL_PATTN
         if (p.tail & 2) continue;
+#endif
         auto blocks = [&](auto masked_) {
         constexpr bool MASKED = decltype(masked_)::value;
         for (int qb = 0; qb < nblk; ++qb) {
@@ -585,6 +607,238 @@ __global__ __launch_bounds__(512, NT == 1 ? 4 : 2) void pattn_bwd_dkv_kernel(con
     }
 }
 
+// ------------------------------------------------------------------------------------------ backward in ONE pass: dQ, dK, dV
+// S, dP, the exponentials and the plane split of dS were computed twice -- once with the queries on the lanes (dQ kernel), once
+// with the keys (dK,dV kernel) -- because a token product needs its reduction index on the REGISTERS of both operands: ~30 % of the
+// backward's instructions.  Here every score tile is computed ONCE, in the dK,dV orientation (S[query][key] = Q . K^T, lane = key):
+//   * dV^T += dO^T . P and dK^T += Q^T . dS as in pattn_bwd_dkv_kernel;
+//   * the planes of dS -- already split for the dK product -- go to a patch of LDS as dS^T[key][query] (8-byte stores) and come back
+//     through ds_read_b64_tr_b16 with the KEYS on the registers: the B operand of dQ^T[d][query] += K^T[d][key] . dS^T[key][query].
+//     A pair of waves (32 keys = one instruction's k) shares a patch; wave 2 j + i multiplies query tile i of the 32-query block
+//     against the pair's keys (K^T fragments: transposed reads of a plane image of the key block's 128 keys, staged once per key
+//     block -- held in registers they were the twelve that made the allocator spill accumulators inside the block loop), so each
+//     wave adds 6 instructions per block, none of them wasted;
+//   * the four pairs' shares of a block's dQ (32 queries x 16 columns) meet in LDS and are summed in pair order by the 512 threads,
+//     one output element each;
+//   * a workgroup owns a (sample, head) and walks ALL its key blocks of 128, so the sum over key blocks is that thread's own
+//     read-modify-write of dq in memory (first key block: a plain store; L2-resident in between, 64 KB per (sample, head) at 1024
+//     tokens; the same thread, hence the same CU, wrote the 16 bytes it reads; streaming accesses that do not linger in the CU's
+//     L1) -- no slabs, no second launch, a fixed order.
+// delta = rowsum(dO o O) comes from pattn_delta_kernel (one pass over dO and O; the two-kernel form computed it in the dQ kernel).
+// Two barriers per 32-query block (patch written | shares written); 69.5 KB of LDS: two workgroups per CU.
+constexpr int CHB = 128;                        // streamed query rows per chunk
+constexpr int NBKB = CHB / 32;
+constexpr int XP = 64;                          // bytes per key row of a patch plane: 32 queries (bf16) = eight 8-byte chunks; chunk j of
+                                                // row r sits at position j ^ xswz(r) -- the 8-byte stores of a block (16 rows x 2
+                                                // chunks per half wave) and the transposed reads (8 rows x 4 chunks) both conflict-free
+constexpr int PATCH = 32 * XP;                  // one plane of a pair's patch: [32 keys][32 queries]
+__device__ __forceinline__ int xswz(int row) { return ((row >> 2) & 1) << 2 | ((row >> 3) & 1) << 1; }
+constexpr int FUSED_LDS = 2 * NBKB * BLK + 3 * CHB * 4 + 4 * 3 * PATCH + 4 * 32 * 16 * 4 + 4 * BLK;
+
+__global__ __launch_bounds__(256) void pattn_delta_kernel(const MAttn p) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;             // (sample, query, head)
+    const int64_t n = (int64_t)p.B * p.Tq * p.H;
+    if (i >= n) return;
+    const int hh = (int)(i % p.H);
+    const int64_t bq = i / p.H;
+    const int q = (int)(bq % p.Tq), b = (int)(bq / p.Tq);
+    const float* o = p.o + (int64_t)b * p.o_bs + (int64_t)q * p.ldo + hh * p.hd;
+    const float* d = p.dout + (int64_t)b * p.d_bs + (int64_t)q * p.ldd + hh * p.hd;
+    float acc = 0.f;
+    for (int k = 0; k < p.hd; k += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(o + k), y = *reinterpret_cast<const float4*>(d + k);
+        acc = fmaf(x.x, y.x, acc), acc = fmaf(x.y, y.y, acc), acc = fmaf(x.z, y.z, acc), acc = fmaf(x.w, y.w, acc);
+    }
+    p.delta[((int64_t)b * p.H + hh) * p.Tq + q] = acc;
+}
+
+__global__ __launch_bounds__(512, 4) void pattn_bwd_fused_kernel(const MAttn p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    unsigned char* Qi = smem;
+    unsigned char* Di = smem + NBKB * BLK;
+    float* Ml = reinterpret_cast<float*>(smem + 2 * NBKB * BLK);
+    float* Ll = Ml + CHB;
+    float* Dl = Ll + CHB;
+    unsigned char* Xp = reinterpret_cast<unsigned char*>(Dl + CHB);       // [4 pairs][3 planes][32 keys][XP]
+    float* Ex = reinterpret_cast<float*>(Xp + 4 * 3 * PATCH);             // [4 pairs][32 queries][16]
+    unsigned char* Kimg = reinterpret_cast<unsigned char*>(Ex + 4 * 32 * 16);   // the key block's K as plane images: four 32-key blocks
+    int b, hh, blk;
+    locate_block(p, 1, b, hh, blk);
+    const int col0 = hh * p.hd;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int pair = wave >> 1, qtile = wave & 1;
+    const float* qsrc = p.q + (int64_t)b * p.q_bs;
+    const float* dsrc = p.dout + (int64_t)b * p.d_bs;
+    const float* kbase = p.k + (int64_t)b * p.k_bs;
+    const float* vbase = p.v + (int64_t)b * p.v_bs;
+    float* dqb = p.dq + (int64_t)b * p.dq_bs + col0;
+    StagePair sp;
+    // this lane's 8-byte slots in its pair's patch (dS^T[key = 16 (wave & 1) + c][queries 4 g .. + 3 | 16 + 4 g .. + 3]) and the
+    // chunks it reads back (keys 4 g + (c >> 2) | + 16, queries 16 qtile + 4 (c & 3) .. + 3)
+    // (32-bit offsets, not pointers: a generic pointer per lane is a register pair the allocator would rather spill)
+    const int xw_off = pair * 3 * PATCH + (16 * qtile + c) * XP + 8 * (g ^ xswz(16 * qtile + c));      // + 32: chunk 4 + g
+    const int xr_off = pair * 3 * PATCH + (4 * g + (c >> 2)) * XP + 8 * ((4 * qtile + (c & 3)) ^ xswz(4 * g + (c >> 2)));   // + 16 rows: same swizzle
+    for (int kb0 = 0; kb0 < p.Tk; kb0 += 128) {
+        // ---- this wave's 16 keys (B operands of S / dP); the key block's K as a plane image (A operand of the dQ product)
+        HeadFrags kf, vf;
+        float cap, liv;
+        {
+            // (lane constants of this prologue from an opaque copy of the thread index: hoisted out of the key-block loop as 64-bit
+            //  offsets they were spilled)
+            const int tid = opaque_tid(), pc = tid & 15, pg = (tid >> 4) & 3;
+            const int krow = kb0 + (tid >> 6) * 16 + pc;
+            const bool in_seq = krow < p.Tk;
+            float kv[8], vv[8];
+            load_row8(kv, kbase, p.ldk, col0, krow, p.Tk, pg, p.hd, 1.f);
+            load_row8(vv, vbase, p.ldv, col0, krow, p.Tk, pg, p.hd, 1.f);
+            uint8_t mk = 1;
+            if (p.mask) mk = p.mask[(int64_t)b * p.Tk + (in_seq ? krow : 0)];
+            const bool keep = in_seq && mk != 0;
+            cap = keep ? INFINITY : (in_seq ? kFillP : -INFINITY);
+            liv = keep ? 1.f : 0.f;
+            kf = head_frags(kv, pg), vf = head_frags(vv, pg);
+            // 128 rows x four 16-byte pieces = one piece per thread (the previous key block's last reads of the image lie before the
+            // barrier that closed its last query block)
+            const int r = tid >> 2, q4 = tid & 3;
+            const bool ok = kb0 + r < p.Tk && 4 * q4 < p.hd;
+            float4 x = *reinterpret_cast<const float4*>(kbase + (int64_t)(ok ? kb0 + r : 0) * p.ldk + col0 + (ok ? 4 * q4 : 0));
+            if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
+            const Pair3 xa = split2(x.x, x.y), xb = split2(x.z, x.w);
+            unsigned char* dst = Kimg + (r >> 5) * BLK + (r & 31) * 32 + q4 * 8;
+            *reinterpret_cast<u32x2*>(dst) = u32x2{xa.p0, xb.p0};
+            *reinterpret_cast<u32x2*>(dst + PB) = u32x2{xa.p1, xb.p1};
+            *reinterpret_cast<u32x2*>(dst + 2 * PB) = u32x2{xa.p2, xb.p2};
+        }
+        f32x4 kbg = {0.f, 0.f, 0.f, 0.f}, ksm = kbg, vbg = kbg, vsm = kbg;
+        const int special = __any(liv == 0.f ? 1 : 0);    // this wave owns a key that is not live: the form with the v_min
+        for (int i0 = 0; i0 < p.Tq; i0 += CHB) {
+            const int nt = min(CHB, p.Tq - i0), nblk = (nt + 31) >> 5;
+            __syncthreads();                              // every wave is done with the previous chunk's images
+            {
+                const int tid = opaque_tid();
+                sp.load(qsrc + (int64_t)i0 * p.ldq, dsrc + (int64_t)i0 * p.ldd, p.ldq, p.ldd, col0, nt, p.hd, tid);
+                sp.commit(Qi, Di, tid, p.scale);
+                if (tid < CHB) {
+                    const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + i0 + (tid < nt ? tid : 0);
+                    Ml[tid] = tid < nt ? p.lse[2 * stat] : INFINITY;          // +inf: a padded query row gets p = exp2(-inf) = 0
+                    Ll[tid] = tid < nt ? p.lse[2 * stat + 1] * kLog2e : 0.f;
+                    Dl[tid] = tid < nt ? p.delta[stat] : 0.f;
+                }
+            }
+            __syncthreads();
+            auto blocks = [&](auto masked_) {
+            constexpr bool MASKED = decltype(masked_)::value;
+            for (int qb = 0; qb < nblk; ++qb) {
+                const unsigned char* qblk = Qi + qb * BLK;
+                const unsigned char* dblk = Di + qb * BLK;
+                float pr[8], ds[8];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    bf16x8 a01, a02, d01, d02;
+                    row_frags(qblk, t, c, g, a01, a02);
+                    row_frags(dblk, t, c, g, d01, d02);
+                    const f32x4 ml = *reinterpret_cast<const f32x4*>(Ml + qb * 32 + t * 16 + 4 * g);
+                    const f32x4 l2 = *reinterpret_cast<const f32x4*>(Ll + qb * 32 + t * 16 + 4 * g);
+                    const f32x4 dl = *reinterpret_cast<const f32x4*>(Dl + qb * 32 + t * 16 + 4 * g);
+                    const f32x4 st = head_product(a01, a02, kf);              // rows = queries 4 g + r, column = this lane's key
+                    const f32x4 dp = head_product(d01, d02, vf);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float sc = MASKED ? vmin(st[r], cap) : st[r];
+                        const float e = __builtin_amdgcn_exp2f(fmaf(sc - ml[r], kLog2e, -l2[r]));
+                        pr[4 * t + r] = e;
+                        const float dsv = e * (dp[r] - dl[r]);
+                        ds[4 * t + r] = MASKED ? dsv * liv : dsv;             // a masked key's score gradients are zero (masked_fill)
+                    }
+                }
+                {
+                    bf16x8 dt[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) dt[pl] = tr_frag(dblk, pl, c, g);
+                    const Planes8 pp = split8(pr);
+                    token_product(dt, pp, vbg, vsm);
+                }
+                {
+                    bf16x8 qt[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) qt[pl] = tr_frag(qblk, pl, c, g);
+                    const Planes8 dsp = split8(ds);
+                    token_product(qt, dsp, kbg, ksm);
+                    // dS^T[key][query] into the pair's patch: p?[0 .. 1] = queries 4 g .. + 3, p?[2 .. 3] = queries 16 + 4 g .. + 3
+                    unsigned char* xw = Xp + xw_off;
+                    unsigned char* xw2 = Xp + (xw_off ^ 32);      // chunk (4 + g) ^ swizzle = (g ^ swizzle) ^ 4
+                    *reinterpret_cast<u32x2*>(xw) = u32x2{dsp.p0[0], dsp.p0[1]};
+                    *reinterpret_cast<u32x2*>(xw2) = u32x2{dsp.p0[2], dsp.p0[3]};
+                    *reinterpret_cast<u32x2*>(xw + PATCH) = u32x2{dsp.p1[0], dsp.p1[1]};
+                    *reinterpret_cast<u32x2*>(xw2 + PATCH) = u32x2{dsp.p1[2], dsp.p1[3]};
+                    *reinterpret_cast<u32x2*>(xw + 2 * PATCH) = u32x2{dsp.p2[0], dsp.p2[1]};
+                    *reinterpret_cast<u32x2*>(xw2 + 2 * PATCH) = u32x2{dsp.p2[2], dsp.p2[3]};
+                }
+#ifdef MSN_ABL_PATTN                         // diagnostic builds: bit 1 = no barriers in the block loop, bit 0 = no dq traffic (wrong results)
+                if (!(p.tail & 2))
+#endif
+                __syncthreads();                          // the pair's patch is complete
+                // the four elements of dq this thread owns in the block (threads 0 .. 127: query t >> 2, columns 4 (t & 3) .. + 3 -- 16-byte
+                // accesses: one dword per thread over all 512 made the read-modify-write 12 % of the kernel): their value so far, requested
+                // here (not at the head of the block: four registers across its widest part) and in flight under the dQ product
+                const int te = opaque_tid();
+                const int oq = i0 + 32 * qb + (te >> 2), od = 4 * (te & 3);
+                const bool o_ok = te < 128 && oq < p.Tq && od < p.hd;
+                float* optr = dqb + (int64_t)(o_ok ? oq : 0) * p.lddq + (o_ok ? od : 0);
+                f32x4 old = {0.f, 0.f, 0.f, 0.f};
+#ifdef MSN_ABL_PATTN
+                if (!(p.tail & 1))
+#endif
+                if (kb0 > 0 && o_ok) old = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(optr));
+                {
+                    const unsigned char* xr = Xp + xr_off;
+                    Planes8 w;
+                    u32x4* wp[3] = {&w.p0, &w.p1, &w.p2};
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xr + pl * PATCH));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xr + pl * PATCH + 16 * XP));
+                        const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        *wp[pl] = __builtin_bit_cast(u32x4, v);
+                    }
+                    const int ec = te & 15, eg = (te >> 4) & 3, epair = te >> 7, eqt = (te >> 6) & 1;   // (lane constants per block: see `te`)
+                    bf16x8 kt[3];                         // K^T[d = c][the pair's keys, in the k order of the patch reads]
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) kt[pl] = tr_frag(Kimg + epair * BLK, pl, ec, eg);
+                    f32x4 qbg = {0.f, 0.f, 0.f, 0.f}, qsm = qbg;
+                    token_product(kt, w, qbg, qsm);       // dQ^T[d = 4 g + r][query 16 qtile + c] over the pair's 32 keys
+                    // (16-byte column group j of query row q at position j ^ ((q >> 2) & 3): stores and the reduction's reads conflict-free)
+                    *reinterpret_cast<f32x4*>(Ex + ((epair * 32 + 16 * eqt + ec) * 16 + 4 * (eg ^ ((ec >> 2) & 3)))) = qbg + qsm;
+                }
+#ifdef MSN_ABL_PATTN
+                if (!(p.tail & 2))
+#endif
+                __syncthreads();                          // the four pairs' shares are in place
+#ifdef MSN_ABL_PATTN
+                if (!(p.tail & 1))
+#endif
+                if (te < 128) {
+                    const f32x4* ex = reinterpret_cast<const f32x4*>(Ex) + (te ^ ((te >> 4) & 3));   // [pair][query][4 column groups, swizzled]
+                    const f32x4 sum = ((ex[0] + ex[128]) + ex[256]) + ex[384];
+                    if (o_ok) __builtin_nontemporal_store(sum * p.scale + old, reinterpret_cast<f32x4*>(optr));
+                }
+            }
+            };
+            if (special) blocks(std::true_type{});
+            else blocks(std::false_type{});
+        }
+        {
+            const int te = opaque_tid(), ce = te & 15, ge = (te >> 4) & 3;
+            const int krow = kb0 + (te >> 6) * 16 + ce;
+            if (krow < p.Tk && 4 * ge < p.hd) {
+                const f32x4 dk = (kbg + ksm) * liv, dv = vbg + vsm;             // (Q carried the scale)
+                *reinterpret_cast<f32x4*>(p.dk + (int64_t)b * p.dk_bs + (int64_t)krow * p.lddk + col0 + 4 * ge) = dk;
+                *reinterpret_cast<f32x4*>(p.dv + (int64_t)b * p.dv_bs + (int64_t)krow * p.lddv + col0 + 4 * ge) = dv;
+            }
+        }
+    }
+}
+
 template <typename K>
 int launch(K kernel, unsigned grid, unsigned block, size_t lds, hipStream_t st, const MAttn& a) {
     if (lds > 64 * 1024 &&
@@ -598,10 +852,10 @@ int launch(K kernel, unsigned grid, unsigned block, size_t lds, hipStream_t st, 
 }
 
 int g_planes_on = 1;
-int g_fwd_qt = 2;
-int g_bwd_nt = 1;
+int g_fused_bwd = 1;    // backward in one pass where it applies (0: always the dQ kernel followed by the dK,dV kernel; 2: always one pass)
+#ifdef MSN_ABL_PATTN
 int g_ablate = 0;
-int g_prefetch = 0;     // the next chunk's rows requested into registers under the current chunk's products: measured no faster (16 + registers)
+#endif
 
 }  // namespace
 
@@ -639,14 +893,25 @@ int pattn_forward(const MAttn& a0, hipStream_t st) {
         return MSN_ERR_SHAPE;
     }
     MAttn a = a0;
+    a.tail = 0;
+#ifdef MSN_ABL_PATTN
     a.tail = g_ablate;
+#endif
     const size_t lds = 2 * NBK * BLK + sizeof(float) * CH;
-    if (g_fwd_qt == 2 && a.Tq > 128) {
-        const unsigned grid = (unsigned)(a.B * a.H * ((a.Tq + 255) / 256)), bt = block_threads(a.Tq, 32);
-        return g_prefetch ? launch(pattn_fwd_kernel<2, true>, grid, bt, lds, st, a) : launch(pattn_fwd_kernel<2, false>, grid, bt, lds, st, a);
-    }
-    const unsigned grid = (unsigned)(a.B * a.H * ((a.Tq + 127) / 128)), bt = block_threads(a.Tq, 16);
-    return g_prefetch ? launch(pattn_fwd_kernel<1, true>, grid, bt, lds, st, a) : launch(pattn_fwd_kernel<1, false>, grid, bt, lds, st, a);
+    if (a.Tq > 128)       // two query tiles per wave: the K / V fragments of a block serve both (1185 -> 1112 us at 1024 tokens)
+        return launch(pattn_fwd_kernel<2>, (unsigned)(a.B * a.H * ((a.Tq + 255) / 256)), block_threads(a.Tq, 32), lds, st, a);
+    return launch(pattn_fwd_kernel<1>, (unsigned)(a.B * a.H * ((a.Tq + 127) / 128)), block_threads(a.Tq, 16), lds, st, a);
+}
+
+// The one-pass backward holds a (sample, head) in ONE workgroup: it needs enough pairs to fill the chip (two workgroups per CU)
+// and the dq accumulation in memory (a stride of whole floats); everything else takes the two kernels.
+static bool fused_backward_applies(const MAttn& a) { return g_fused_bwd == 2 || (g_fused_bwd && (int64_t)a.B * a.H >= 256); }
+
+// Heads NARROWER than 16 (the light-curve tower's 8-wide heads) run their forward on the vector-ALU kernels -- the plane forward
+// ties with them at best (304 vs 242 us at 1024 x 8 heads x 200 tokens) -- but their backward is faster in one pass on the planes
+// (676 vs 753 us): the row statistics are the same (max, log-sum) pairs in every family.
+bool pattn_backward_preferred(const MAttn& a) {
+    return a.hd < 16 && (a.Tq > 128 || a.Tk > 128) && pattn_applicable(a) && pattn_backward_aligned(a) && fused_backward_applies(a);
 }
 
 int pattn_backward(const MAttn& a0, hipStream_t st) {
@@ -655,26 +920,22 @@ int pattn_backward(const MAttn& a0, hipStream_t st) {
         return MSN_ERR_SHAPE;
     }
     MAttn a = a0;
+    a.tail = 0;
+#ifdef MSN_ABL_PATTN
     a.tail = g_ablate;
+#endif
+    if (fused_backward_applies(a)) {
+        const int64_t n = (int64_t)a.B * a.Tq * a.H;
+        hipLaunchKernelGGL(pattn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+        MSN_LAUNCH_CHECK();
+        return launch(pattn_bwd_fused_kernel, (unsigned)(a.B * a.H), 512u, (size_t)FUSED_LDS, st, a);
+    }
     {
         const size_t lds = 2 * NBK * BLK + sizeof(float) * CH;
-        int rc;
-        if (g_bwd_nt == 2 && a.Tq > 128) {
-            const unsigned grid = (unsigned)(a.B * a.H * ((a.Tq + 255) / 256)), bt = block_threads(a.Tq, 32);
-            rc = g_prefetch ? launch(pattn_bwd_dq_kernel<2, true>, grid, bt, lds, st, a) : launch(pattn_bwd_dq_kernel<2, false>, grid, bt, lds, st, a);
-        } else {
-            const unsigned grid = (unsigned)(a.B * a.H * ((a.Tq + 127) / 128)), bt = block_threads(a.Tq, 16);
-            rc = g_prefetch ? launch(pattn_bwd_dq_kernel<1, true>, grid, bt, lds, st, a) : launch(pattn_bwd_dq_kernel<1, false>, grid, bt, lds, st, a);
-        }
-        if (rc) return rc;
+        if (int rc = launch(pattn_bwd_dq_kernel, (unsigned)(a.B * a.H * ((a.Tq + 127) / 128)), block_threads(a.Tq, 16), lds, st, a)) return rc;
     }
     const size_t lds = 2 * NBK * BLK + sizeof(float) * 3 * CH;
-    if (g_bwd_nt == 2 && a.Tk > 128) {
-        const unsigned grid = (unsigned)(a.B * a.H * ((a.Tk + 255) / 256)), bt = block_threads(a.Tk, 32);
-        return g_prefetch ? launch(pattn_bwd_dkv_kernel<2, true>, grid, bt, lds, st, a) : launch(pattn_bwd_dkv_kernel<2, false>, grid, bt, lds, st, a);
-    }
-    const unsigned grid = (unsigned)(a.B * a.H * ((a.Tk + 127) / 128)), bt = block_threads(a.Tk, 16);
-    return g_prefetch ? launch(pattn_bwd_dkv_kernel<1, true>, grid, bt, lds, st, a) : launch(pattn_bwd_dkv_kernel<1, false>, grid, bt, lds, st, a);
+    return launch(pattn_bwd_dkv_kernel, (unsigned)(a.B * a.H * ((a.Tk + 127) / 128)), block_threads(a.Tk, 16), lds, st, a);
 }
 
 }  // namespace msn
@@ -682,12 +943,14 @@ int pattn_backward(const MAttn& a0, hipStream_t st) {
 using namespace msn;
 
 extern "C" int msn_set_attention_planes(int mode) {
-    MSN_REQUIRE(mode >= 0 && mode < 64, "msn_set_attention_planes: bit 0 on / off, bit 1 one query tile per wave in the forward, "
-                "bit 2 two tiles per wave in the backward, bit 3 register prefetch of the next chunk, bits 4 - 5 diagnostic ablations");
-    g_planes_on = mode & 1;
-    g_fwd_qt = (mode & 2) ? 1 : 2;
-    g_bwd_nt = (mode & 4) ? 2 : 1;
-    g_prefetch = (mode & 8) ? 1 : 0;
+#ifdef MSN_ABL_PATTN
+    MSN_REQUIRE(mode >= 0 && mode < 64, "msn_set_attention_planes (diagnostic build): bits 4 - 5 = ablations");
     g_ablate = (mode >> 4) & 3;
+    mode &= 3;
+#endif
+    MSN_REQUIRE(mode == 0 || mode == 1 || mode == 3 || mode == 5, "msn_set_attention_planes: 0 = off (the exact-fp32 matrix-core kernels), "
+                "1 = on, 3 = on with the two-kernel backward (dQ, then dK,dV) everywhere, 5 = on with the one-pass backward everywhere");
+    g_planes_on = mode & 1;
+    g_fused_bwd = (mode & 2) ? 0 : ((mode & 4) ? 2 : 1);
     return MSN_OK;
 }

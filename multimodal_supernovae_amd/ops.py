@@ -972,7 +972,7 @@ if __import__("os").environ.get("MSN_PGEMM_VARIANT"):      # wave layout of the 
     check(lib().msn_set_pgemm_variant(int(__import__("os").environ["MSN_PGEMM_VARIANT"])))     # planes per operand: 3 = fp32 grade (6 products), 2 = 3 products
 
 
-if __import__("os").environ.get("MSN_ATTN_PLANES"):        # 0: long narrow-head attention on the exact-fp32 matrix-core kernels (A/B runs)
+if __import__("os").environ.get("MSN_ATTN_PLANES"):        # 0: long narrow-head attention on the exact-fp32 matrix-core kernels; 3 / 5: backward forms (A/B runs)
     check(lib().msn_set_attention_planes(int(__import__("os").environ["MSN_ATTN_PLANES"])))
 
 
@@ -1094,7 +1094,7 @@ def set_attention_fused(on):
 
 def set_attention_planes(mode):
     """1 (default): long sequences of heads up to 16 wide run fp32-grade on the bf16 matrix cores (csrc/attention_planes.hip);
-    0: the exact-fp32 matrix-core kernels; further bits select measurement forms (include/msn_hip.h)."""
+    0: the exact-fp32 matrix-core kernels; 3 / 5: planes with the two-kernel / the one-pass backward everywhere (tests, A/B runs)."""
     check(lib().msn_set_attention_planes(int(mode)), "msn_set_attention_planes")
 
 

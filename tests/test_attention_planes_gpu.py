@@ -5,7 +5,7 @@ THE GATE (the rule the plane GEMMs passed): on every output --
 against the reference's formula in fp64 at most 1.5 x those of the exact-fp32 matrix-core kernels it replaces
 (v_mfma_f32_16x16x4_f32, msn_set_attention_planes(0)) on the same inputs: N(0,1) data, masked keys, a fully padded sample,
 large-magnitude scores (peaked softmax), cross attention, the ragged ends of every tile size.  The measured ratios go to
-gpurun_out/r05_attention_planes_accuracy.txt."""
+gpurun_out/r06_attention_planes_accuracy.txt."""
 import math
 import os
 
@@ -29,7 +29,7 @@ def _report(line):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     try:
         os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(root, "gpurun_out", "r05_attention_planes_accuracy.txt"), "a") as f:
+        with open(os.path.join(root, "gpurun_out", "r06_attention_planes_accuracy.txt"), "a") as f:
             f.write(line + "\n")
     except OSError:
         pass
@@ -64,14 +64,13 @@ CASES = [  # B, Tq, Tk, heads, hd, masked, gain (multiplies q: peaked softmax), 
 ]
 
 
-# 1 = the default forms; 15 = one tile per wave forward + two per wave backward, register prefetch
-@pytest.mark.parametrize("mode", [1, 15])
+# 3 = the two-kernel backward (dQ, then dK,dV: what few (sample, head) pairs take by default); 5 = the one-pass backward (what 256 or
+# more pairs take by default: every training shape)
+@pytest.mark.parametrize("mode", [3, 5])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(str(x) for x in c))
 def test_fp32_grade_gate(case, mode):
     from multimodal_supernovae_amd import ops
     B, Tq, Tk, heads, hd, masked, gain, path = case
-    if mode != 1 and max(Tq, Tk) <= 128:
-        pytest.skip("one form")
     E = heads * hd
     g = torch.Generator().manual_seed(B * 1000 + Tq + Tk + hd)
     q = torch.randn(B, Tq, E, generator=g) * gain
@@ -153,3 +152,71 @@ def test_deterministic_and_strided():
     qc, kc, vc = (t.contiguous() for t in (q, k, v))
     out2, _, dq, dk, dv = _run(qc, kc, vc, dout, mu8, heads, scale, 1, 0)
     assert torch.equal(out2, res[0][0]) and torch.equal(torch.cat([dq, dk, dv], -1), res[0][2])
+
+
+@pytest.mark.parametrize("B,T,heads,hd,masked", [(160, 300, 2, 16, True), (130, 1024, 2, 16, False), (64, 220, 4, 12, True)])
+def test_one_pass_backward_at_training_batches(B, T, heads, hd, masked):
+    """256 or more (sample, head) pairs take pattn_bwd_fused_kernel by default: one workgroup per pair walks every key block and sums
+    dq over them in memory.  Same bits twice (the accumulation order is fixed), no element left unwritten, dq / dk / dv equal to the
+    two-kernel backward's to rounding, gradients into column slices of a packed buffer."""
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(B + T)
+    E = heads * hd
+    qkv = torch.randn(B, T, 3 * E, generator=g).cuda()
+    dout = torch.randn(B, T, E, generator=g).cuda()
+    mu8 = None
+    if masked:
+        mask = torch.rand(B, T, generator=g) > 0.25
+        mask[:, 0] = True
+        mask[-1] = False
+        mu8 = ops._mask_u8(mask.cuda())
+    scale = 1.0 / math.sqrt(E)
+    q, k, v = qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:]
+    out, lse = ops.attention_fwd(q, k, v, mu8, heads, scale)
+    res = []
+    for mode in (1, 1, 3):
+        ops.set_attention_planes(mode)
+        try:
+            d = torch.full_like(qkv, float("nan"))
+            ops.attention_bwd(q, k, v, mu8, heads, scale, out, lse, dout, d[..., :E], d[..., E:2 * E], d[..., 2 * E:])
+        finally:
+            ops.set_attention_planes(1)
+        res.append(d)
+    assert not torch.isnan(res[0]).any()
+    assert torch.equal(res[0], res[1])
+    torch.testing.assert_close(res[0], res[2], rtol=2e-5, atol=2e-5 * float(res[2].abs().max()))
+
+
+
+@pytest.mark.parametrize("B,T,heads,hd,masked", [(40, 200, 8, 8, True), (64, 333, 4, 12, False)])
+def test_narrow_heads_vector_forward_plane_backward(B, T, heads, hd, masked):
+    """Heads narrower than 16 over more than 128 tokens (the light-curve tower: 8 x 8, 200 steps) keep the vector-ALU forward and,
+    from 256 (sample, head) pairs on, take the one-pass plane backward behind it (msn_attention_bwd's default route): the row
+    statistics of the two families are the same (max, log-sum) pairs.  Gate as above, against the vector-ALU backward it replaces."""
+    from multimodal_supernovae_amd import ops
+    E = heads * hd
+    g = torch.Generator().manual_seed(B + T + hd)
+    q, k, v, dout = (torch.randn(B, T, E, generator=g) for _ in range(4))
+    mask = None
+    if masked:
+        mask = torch.rand(B, T, generator=g) > 0.3
+        mask[:, 0] = True
+        mask[-1] = False
+    scale = 1.0 / math.sqrt(E)
+    qr, kr, vr = (t.double().cuda().requires_grad_() for t in (q, k, v))
+    ref = _ref(qr, kr, vr, mask.cuda() if masked else None, heads, scale)
+    ref.backward(dout.double().cuda())
+    want = (qr.grad, kr.grad, vr.grad)
+    qc, kc, vc, dc = q.cuda(), k.cuda(), v.cuda(), dout.cuda()
+    mu8 = ops._mask_u8(mask.cuda()) if masked else None
+    valu = _run(qc, kc, vc, dc, mu8, heads, scale, 0, 0)          # planes off: vector-ALU forward and backward
+    mixed = _run(qc, kc, vc, dc, mu8, heads, scale, 1, 0)         # default: vector-ALU forward, plane backward
+    assert torch.equal(valu[0], mixed[0]) and torch.equal(valu[1], mixed[1])      # the same forward
+    assert not any(torch.isnan(t).any() for t in mixed)
+    for name, w, a, b in zip(("dq", "dk", "dv"), want, valu[2:], mixed[2:]):
+        e_v, e_m = (a.double() - w).abs(), (b.double() - w).abs()
+        floor = 1e-7 * float(w.abs().max())
+        rmax = float(e_m.max()) / max(float(e_v.max()), floor)
+        rrms = float(e_m.pow(2).mean().sqrt()) / max(float(e_v.pow(2).mean().sqrt()), floor / 8)
+        _report(f"narrow heads {(B, T, heads, hd, masked)} {name}: plane backward / vector-ALU backward error  max {rmax:.3f}  rms {rrms:.3f}")
+        assert rmax <= 1.5 and rrms <= 1.5, (name, rmax, rrms)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Long-sequence attention of the reference-native towers: exact-fp32 matrix-core kernels (planes 0), the fp32-grade bf16
-plane kernels in their forms (msn_set_attention_planes bits: 2 = one query tile per wave in the forward, 4 = two tiles per wave
-in the backward, 8 = register prefetch of the next chunk; + 16 = only the first chunk is staged, + 32 = staging only, no products -- diagnostic, wrong results), and for 8-wide heads the vector-ALU kernels.
+plane kernels (msn_set_attention_planes 1 = default: one-pass backward at these batches; --variants: 3 = the two-kernel backward),
+and for 8-wide heads the vector-ALU kernels.
 Per launch: us, and useful TFLOP/s (4 T^2 hd flop per (b, h) forward, 10 T^2 hd backward)."""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,7 +26,7 @@ for B, T, E, H, what in SHAPES:
     scale = 1 / math.sqrt(E)
     variants = [("fp32 MFMA", 2, 0), ("planes (default)", 2, 1)]
     if full:
-        variants += [(f"planes mode {m}", 2, m) for m in (9, 3, 5, 1 + 16, 1 + 32)]
+        variants += [("planes, two-kernel bwd", 2, 3)]
     if hd < 16:
         variants.insert(0, ("vector ALU", 1, 0))
     for name, path, planes in variants:
@@ -37,6 +37,6 @@ for B, T, E, H, what in SHAPES:
         tf = timeit(lambda: ops.attention_fwd(q, k, v, None, H, scale))
         tb = timeit(lambda: ops.attention_bwd(q, k, v, None, H, scale, out, lse, dout, dqkv[..., :E], dqkv[..., E:2 * E], dqkv[..., 2 * E:]))
         fl = B * H * T * T * hd
-        print(f"{what:34s} B={B} T={T} e={E} h={H} {name:18s}: fwd {tf:8.1f} us ({4 * fl / tf * 1e-6:6.1f} TFLOP/s)   bwd {tb:8.1f} us ({10 * fl / tb * 1e-6:6.1f} TFLOP/s)", flush=True)
+        print(f"{what:34s} B={B} T={T} e={E} h={H} {name:22s}: fwd {tf:8.1f} us ({4 * fl / tf * 1e-6:6.1f} TFLOP/s)   bwd {tb:8.1f} us ({10 * fl / tb * 1e-6:6.1f} TFLOP/s)", flush=True)
 _lib.lib().msn_set_attention_path(0)
 ops.set_attention_planes(1)
