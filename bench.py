@@ -319,8 +319,6 @@ def main():
                     help="fp32 GEMM kernel family: 0 register-staged, 1 / 2 / 3 LDS-DMA rings (3 = default)")
     ap.add_argument("--gemm-tail", type=int, default=1, choices=[0, 1, 2],
                     help="tail tiles of the fp32 GEMMs: 1 = K-slabs summed by the last workgroup to arrive (default), 2 = by a finishing launch, 0 = unsplit")
-    ap.add_argument("--bgemm-one-tile", action="store_true",
-                    help="bf16-resident NT products: one workgroup per tile instead of persistent workgroups (A/B measurement)")
     ap.add_argument("--gemm-precision", default="bf16x6", choices=["f32", "bf16x6", "bf16x3p", "bf16x3", "bf16"],
                     help="inner-product arithmetic of the wide GEMMs: bf16x6 (default) = fp32-grade from three resident bf16 planes, 6 bf16 MFMA "
                          "products, error within 1.5x of the native kernel (tests/test_pgemm_gpu.py gate); f32 = native fp32 MFMA; "
@@ -343,13 +341,6 @@ def main():
     ops.set_gemm_precision(args.gemm_precision)
     ops.set_gemm_variant(args.gemm_variant)
     ops.set_gemm_tail_split(args.gemm_tail)
-    if os.environ.get("MSN_GEMM_LDS_PAD"):
-        _lib.check(_lib.lib().msn_set_gemm_lds_pad(int(os.environ["MSN_GEMM_LDS_PAD"])))
-    if os.environ.get("MSN_GEMM_STREAMK"):          # "max_tiles,min_k": experiment switch for the work-list rule of single products
-        ops.set_gemm_streamk(*(int(v) for v in os.environ["MSN_GEMM_STREAMK"].split(",")))
-    if args.bgemm_one_tile:
-        from multimodal_supernovae_amd import _lib
-        _lib.check(_lib.lib().msn_set_bgemm_persistent(0))
     rank, local, world = D.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")

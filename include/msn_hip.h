@@ -96,9 +96,6 @@ int msn_set_gemm_variant(int mode);
  * same launch; 2: a finishing launch does (bit-identical: same order); 0: no slabs.  Results of the tail tiles
  * differ from the unsplit order in the last bits.  Process-wide. */
 int msn_set_gemm_tail_split(int enabled);
-/* Unused dynamic LDS (bytes) added to every launch of the 128 x 128 fp32 kernel: >= 17 KB keeps a second workgroup of
- * the kernel off the CU and leaves half the register file + the rest of the LDS to kernels of another stream. 0 = off. */
-int msn_set_gemm_lds_pad(int bytes);
 /* Measurement switch: tile width of products with N > 64: 0 = planned (default), 64, 128. */
 int msn_set_gemm_tile_n(int bn);
 int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
@@ -116,9 +113,10 @@ int msn_sgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, const float* A,
  * sums of A, i.e. the bias gradient of the same Linear.  Products the kernel does not take (N or M <= 64, K % 32 != 0,
  * unaligned operands, precision != fp32) are issued one by one through msn_sgemm / msn_wgrad_bias -- same results as
  * calling those.  Against the one-by-one path the list kernel's results differ in the last bits (another k order).
- * msn_set_gemm_list(0) forces the one-by-one path (measurements).  msn_set_gemm_streamk(t, k): msn_sgemm itself takes the
- * list kernel for an opA = N product of at most t 128 x 128 tiles and K >= k (t = 0: never; default t = 1024, k = 1024:
- * the long-K products of an under-filled launch, where the balance gained outweighs the slabs of the cut tiles). */
+ * msn_sgemm itself takes the list kernel for an opA = N product of at most 1024 128 x 128 tiles and K >= 1024 whose last round of
+ * workgroups is under-filled (the balance gained outweighs the slabs of the cut tiles).
+ * msn_set_gemm_list(mode): 1 = all of the above (default); 0 = no work-list launch at all (lists one by one; measurements, bit
+ * comparisons); 2 = lists only, single products never; 3 = lists + every single product the kernel can take (tests).  Process-wide. */
 typedef struct msn_gemm_desc {
     int opA, opB;
     int64_t M, N, K;
@@ -136,8 +134,7 @@ typedef struct msn_gemm_desc {
 } msn_gemm_desc;
 size_t msn_sgemm_list_workspace_bytes(int n, const msn_gemm_desc* products);
 int msn_sgemm_list(int n, const msn_gemm_desc* products, int precision, void* ws, size_t ws_bytes, msn_stream_t stream);
-int msn_set_gemm_list(int enabled);
-int msn_set_gemm_streamk(int max_tiles, int min_k);
+int msn_set_gemm_list(int mode);
 /* Zero the arrival counters of the in-kernel tile finishes (tail split, work-list launch) of the current device: they
  * are zero between launches by construction, but a launch that faulted or was aborted half-way leaves them dirty. */
 int msn_reset_gemm_counters(msn_stream_t stream);
@@ -282,7 +279,7 @@ int msn_add_rows(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t
  *   msn_pgemm_tn:     C[N][K] (fp32) = sum_m A[m][N]^T . B[m][K] (weight gradient dY^T . X); A, B plane matrices with the
  *                     reduction on the rows (M x N, M x K); reduction split over workgroups, fixed-order slab sums;
  *                     ws >= msn_pgemm_tn_workspace_bytes.
- * Results are deterministic.  msn_set_pgemm_tile_n (0 | 128): tile width of msn_pgemm_nt (256-wide tiles were slower on every shape). */
+ * Results are deterministic. */
 size_t msn_plane_bytes(int64_t R, int64_t C, int planes);
 size_t msn_plane_split_colsum_workspace_bytes(int64_t R, int64_t C);
 int msn_plane_split(const float* x, int64_t ldx, int64_t R, int64_t C, int planes, int transposed, void* out, float* colsum,
@@ -304,9 +301,6 @@ size_t msn_pgemm_nt_colsum_workspace_bytes(int64_t M, int N);
  * workspace (NULL / too small) the tail tiles are multiplied whole.  msn_set_pgemm_tail_split(0) turns the split off. */
 size_t msn_pgemm_nt_workspace_bytes(int64_t M, int N, int K, int planes, int c_planes, int epilogue, int want_colsum);
 int msn_set_pgemm_tail_split(int enabled);
-/* Tile walk of msn_pgemm_nt (measurements; 0 = the planner's choice): tile columns per column group -- an XCD's run of tiles
- * stays inside one group and re-reads only that group's weight planes -- and tile rows per super-row. */
-int msn_set_pgemm_walk(int col_group, int super_rows);
 int msn_pgemm_nt(int64_t M, int N, int K, int planes, const void* A, const void* B, void* C, int64_t ldc, int c_planes,
                  const float* bias, int epilogue, float* aux, int64_t ldaux, float* colsum_out, void* ws, size_t ws_bytes,
                  msn_stream_t stream);
@@ -319,12 +313,9 @@ int msn_pgemm_tn(int64_t M, int N, int K, int planes, const void* A, const void*
 int msn_layernorm_fwd_planes(const float* x, int64_t ldx, int64_t rows, int cols, const float* gamma, const float* beta,
                              float eps, int planes, void* y_planes, float* y, int64_t ldy, float* mean, float* rstd,
                              msn_stream_t stream);
-/* 1 (default): msn_layernorm_fwd_planes with y == NULL and msn_layernorm_bwd_planes (round 5: ln_bwd_planes_kernel), 260..400
- * columns and >= 32768 rows, take whole 32-row blocks per workgroup and write each block's plane images as contiguous memory;
- * 2: at every row count; 0: always the row-at-a-time kernels.  y, dx and every plane byte are the same either way; the backward's
- * dgamma / dbeta / dx_colsum are the same terms summed in another fixed order (bit-identical from call to call, equal to the row
- * kernel's within fp32 rounding).  Process-wide, not thread-safe; A/B runs and tests. */
-int msn_set_layernorm_block_planes(int on);
+/* (With y == NULL and 260..400 columns, from 32 768 rows on, both directions take whole 32-row blocks per workgroup and write each
+ * block's plane images as contiguous memory; y, dx and every plane byte are the same as the row-at-a-time kernels', the backward's
+ * dgamma / dbeta / dx_colsum the same terms summed in another fixed order.) */
 int msn_layernorm_bwd_planes(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t rows, int cols,
                              const float* mean, const float* rstd, const float* gamma, const float* add, int64_t ldadd,
                              float* dx, int64_t lddx, int planes, void* dx_planes, float* dgamma, float* dbeta,
@@ -365,14 +356,6 @@ int msn_pgemm_nt_f16(int64_t M, int N, int K, const void* A, const float* scaleA
                      size_t ws_bytes, msn_stream_t stream);   /* workspace: msn_pgemm_nt_workspace_bytes(.., planes 2, ..) */
 int msn_pgemm_tn_f16(int64_t M, int N, int K, const void* A, const float* scaleA, const void* B, const float* scaleB, float* C,
                      int64_t ldc, void* ws, size_t ws_bytes, msn_stream_t stream);
-int msn_set_pgemm_tile_n(int bn);
-/* Wave layout of the 3-plane msn_pgemm_nt kernel (measurements; same results up to the summation order of the column
- * sums): 0 = 2 x 4 waves, 1 = 4 x 2 (default), 2 = 4 x 2 on v_mfma_f32_16x16x32_bf16 with plane PAIRS side by side along k
- * (same six products from three instructions per 16 x 16 tile; exact-equal results on the integer tests, equal speed as built:
- * DESIGN.md section 7, gap 0); + 1000 * c: K chunks of c K-steps (default 32).  Process-wide, not thread-safe (as every msn_set_* switch). */
-int msn_set_pgemm_variant(int v);
-/* Start skew of msn_pgemm_nt's persistent workgroups (shader cycles per phase, 0 = off; measurements). */
-int msn_set_pgemm_skew(int cycles);
 
 /* ------------------------------------------------------------------------------------------
  * bf16-RESIDENT products for BASELINE.json configs[4] (ViT-B/16 "bf16 on MFMA"; build-defined encoder, no reference
@@ -389,10 +372,8 @@ int msn_set_pgemm_skew(int cycles);
 int msn_bgemm_nt(int64_t M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                  int c_bf16, const float* bias, int epilogue, void* aux, int64_t ldaux, float* colsum_out, void* ws,
                  size_t ws_bytes, msn_stream_t stream);
-/* msn_bgemm_nt launches one persistent workgroup per CU that walks the 256 x 256 tiles and keeps its LDS ring of K-tiles
- * running across tile boundaries (default); enabled = 0: one workgroup per tile (measurements; same results). */
-int msn_set_bgemm_persistent(int enabled);
-  /* colsum_out (nullable): out[n] = sum_m C[m][n] from the epilogue (the
+  /* one persistent workgroup per CU walks the 256 x 256 tiles and keeps its LDS ring of K-tiles running across tile boundaries (one
+     workgroup per tile below 257 tiles).  colsum_out (nullable): out[n] = sum_m C[m][n] from the epilogue (the
                  bias gradient of the Linear whose output gradient C is); ws >= msn_bgemm_nt_colsum_workspace_bytes(M, N) */
 size_t msn_bgemm_nt_colsum_workspace_bytes(int64_t M, int N);
 size_t msn_bgemm_tn_workspace_bytes(int64_t M, int N, int K);

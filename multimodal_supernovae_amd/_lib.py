@@ -29,11 +29,8 @@ SIGNATURES = {
     "msn_sgemm_list_workspace_bytes": (c_size, [c_int, c_ptr]),
     "msn_sgemm_list": (c_int, [c_int, c_ptr, c_int, c_ptr, c_size, c_ptr]),
     "msn_set_gemm_list": (c_int, [c_int]),
-    "msn_set_gemm_streamk": (c_int, [c_int, c_int]),
     "msn_reset_gemm_counters": (c_int, [c_ptr]),
-    "msn_set_gemm_lds_pad": (c_int, [c_int]),
     "msn_set_gemm_variant": (c_int, [c_int]),
-    "msn_set_bgemm_persistent": (c_int, [c_int]),
     "msn_set_gemm_tail_split": (c_int, [c_int]),
     "msn_set_gemm_tile_n": (c_int, [c_int]),
     "msn_wgrad_bias_workspace_bytes": (c_size, [c_i64, c_i64, c_i64]),
@@ -69,18 +66,14 @@ SIGNATURES = {
     "msn_pgemm_nt_colsum_workspace_bytes": (c_size, [c_i64, c_int]),
     "msn_pgemm_nt_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int, c_int, c_int, c_int]),
     "msn_set_pgemm_tail_split": (c_int, [c_int]),
-    "msn_set_pgemm_walk": (c_int, [c_int, c_int]),
     "msn_pgemm_nt": (c_int, [c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_i64, c_ptr,
                              c_ptr, c_size, c_ptr]),
     "msn_pgemm_tn_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int]),
     "msn_pgemm_tn": (c_int, [c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_size, c_ptr]),
-    "msn_set_pgemm_tile_n": (c_int, [c_int]),
     "msn_layernorm_fwd_planes": (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_f32, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr,
                                          c_ptr]),
     "msn_layernorm_bwd_planes": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr,
                                          c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
-    "msn_set_pgemm_variant": (c_int, [c_int]),
-    "msn_set_pgemm_skew": (c_int, [c_int]),
     "msn_bgemm_nt": (c_int, [c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_i64,
                              c_ptr, c_ptr, c_size, c_ptr]),
     "msn_bgemm_nt_colsum_workspace_bytes": (c_size, [c_i64, c_int]),
@@ -149,7 +142,6 @@ SIGNATURES = {
     "msn_set_attention_path": (c_int, [c_int]),
     "msn_set_attention_fused": (c_int, [c_int]),
     "msn_set_attention_planes": (c_int, [c_int]),
-    "msn_set_layernorm_block_planes": (c_int, [c_int]),
     "msn_attention_bwd_planes_workspace_bytes": (c_size, [c_int, c_int, c_int]),
     "msn_attention_fwd_planes": (c_int, [c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_int, c_f32, c_ptr, c_i64, c_ptr, c_int, c_ptr, c_ptr]),
     "msn_attention_bwd_planes": (c_int, [c_ptr, c_i64, c_ptr, c_int, c_int, c_int, c_int, c_f32, c_ptr, c_i64, c_ptr, c_ptr, c_i64,

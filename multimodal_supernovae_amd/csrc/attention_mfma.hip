@@ -1263,21 +1263,28 @@ __global__ __launch_bounds__(512, HD > 64 ? 2 : 4) void mattn_fwd_long_kernel(co
         }
 #endif
     }
-    l = group_sum4(l);
+    // (the lane's place in the output from an OPAQUE copy of the thread index: kept from the kernel's start, these registers -- and
+    //  the width bound __shfl_xor derives from the lane id -- were what the 16-wide instantiation spilled around its chunk loop:
+    //  20 bytes of scratch at 128 VGPRs)
+    int te = (int)threadIdx.x;
+    asm volatile("" : "+v"(te));
+    const int ce = te & 15, ge = (te >> 4) & 3, q0e = blk * 128 + (te >> 6) * 16;
+    l += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((te ^ 16) & 63) << 2, __builtin_bit_cast(int, l)));
+    l += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((te ^ 32) & 63) << 2, __builtin_bit_cast(int, l)));
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const float lq = __shfl(l, 4 * g + r, 64);
-        const int q = q0 + 4 * g + r;
+        const float lq = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((te & 48) + 4 * ge + r) << 2, __builtin_bit_cast(int, l)));
+        const int q = q0e + 4 * ge + r;
         if (q < p.Tq) {
-            float* op = p.out + (int64_t)b * p.o_bs + (int64_t)q * p.ldo + col0 + c;
+            float* op = p.out + (int64_t)b * p.o_bs + (int64_t)q * p.ldo + col0 + ce;
             const float inv = 1.f / lq;
 #pragma unroll
             for (int t = 0; t < DT; ++t)
-                if (16 * t + c < p.hd) op[16 * t] = o[t][r] * inv;
+                if (16 * t + ce < p.hd) op[16 * t] = o[t][r] * inv;
         }
     }
-    if (g == 0 && qrow < p.Tq) {
-        float* st = p.lse + 2 * (((int64_t)b * p.H + hh) * p.Tq + qrow);
+    if (ge == 0 && q0e + ce < p.Tq) {
+        float* st = p.lse + 2 * (((int64_t)b * p.H + hh) * p.Tq + q0e + ce);
         st[0] = m;
         st[1] = __logf(l);
     }

@@ -481,19 +481,16 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 }
 static int colsum_blocks(int64_t M) { return (int)std::min<int64_t>(cdiv(M, 16 * CS_RG), CS_MAX_BLOCKS); }
 
-// Unused dynamic LDS added to the launches of the 128 x 128 kernel (msn_set_gemm_lds_pad): with 64 KB of its own, a pad
-// of 17 KB and more keeps a SECOND workgroup of the kernel off the CU, which leaves half the register file and the rest of
-// the LDS to kernels of another stream (the light-curve / spectrum towers beside the image tower's products).
-static int g_gemm_lds_pad = 0;
+// (msn_set_gemm_lds_pad -- unused dynamic LDS that kept a second workgroup of the 128 x 128 kernel off the CU for the sake of the side
+// streams -- went in round 6: the image tower slows by 9 % for 0.8 ms more of the light-curve tower hidden, DESIGN section 4 "Streams".)
 template <typename K>
 static void launch_padded(K kernel, dim3 grid, dim3 block, size_t pad, hipStream_t st, const GemmArgs& a) {
-    if (pad > 0) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
     hipLaunchKernelGGL(kernel, grid, block, pad, st, a);
 }
 template <int BM, int BN, int WM, int WN, int DBK, int STAGES>
 static int launch_dma(const GemmArgs& a, int opA, int opB, hipStream_t st) {
     const dim3 grid(gemm_grid(a)), block(64 * (BM / WM) * (BN / WN));
-    const size_t pad = (BM == 128 && BN == 128) ? (size_t)g_gemm_lds_pad : 0;
+    const size_t pad = 0;
     if (opA == MSN_OP_N && opB == MSN_OP_T) launch_padded(sgemm_dma_kernel<BM, BN, WM, WN, false, false, DBK, STAGES>, grid, block, pad, st, a);
     else if (opA == MSN_OP_N && opB == MSN_OP_N) launch_padded(sgemm_dma_kernel<BM, BN, WM, WN, false, true, DBK, STAGES>, grid, block, pad, st, a);
     else if (opA == MSN_OP_T && opB == MSN_OP_N && a.colsum) launch_padded(sgemm_dma_kernel<BM, BN, WM, WN, true, true, DBK, STAGES, true>, grid, block, pad, st, a);
@@ -568,7 +565,8 @@ static unsigned* tail_counter_slice(hipStream_t st) {
 }
 unsigned* gemm_counter_slice(hipStream_t st) { return tail_counter_slice(st); }
 static int g_gemm_streamk = 1024, g_gemm_streamk_min_k = 1024;   // msn_sgemm: opA = N products of at most this many 128 x 128 tiles and at
-                                                                 // least this K take the work-list kernel (0 tiles = never)
+                                                                 // least this K take the work-list kernel (0 tiles = never); set by
+                                                                 // msn_set_gemm_list (gemm_set_single_rule)
 static int g_gemm_bn = 0;        // measurement switch (msn_set_gemm_tile_n): 0 = planned, 64 / 128 = forced tile width for N > 64
 
 // Launch geometry of one product.
@@ -986,12 +984,14 @@ extern "C" int msn_wgrad_bias(int64_t M, int64_t N, int64_t K, const float* dY, 
     return msn_colsum(dY, lddy, K, M, db, ws, ws_bytes, stream);   // shapes / precisions the fused kernel does not take
 }
 
-extern "C" int msn_set_gemm_streamk(int max_tiles, int min_k) {
-    MSN_REQUIRE(max_tiles >= 0 && min_k >= 0, "msn_set_gemm_streamk: a tile count and a K, both >= 0");
-    g_gemm_streamk = max_tiles;
-    g_gemm_streamk_min_k = min_k;
-    return MSN_OK;
+namespace msn {
+// msn_set_gemm_list's rule for SINGLE products: 0 = msn_sgemm never takes the work-list kernel, 1 = the planner's rule (products of at
+// most 1024 tiles with K >= 1024 whose last round of workgroups is under-filled), 2 = every product the kernel can take (tests)
+void gemm_set_single_rule(int rule) {
+    g_gemm_streamk = rule == 0 ? 0 : (rule == 2 ? (1 << 20) : 1024);
+    g_gemm_streamk_min_k = rule == 2 ? 32 : 1024;
 }
+}  // namespace msn
 
 extern "C" int msn_reset_gemm_counters(msn_stream_t stream) {
     // only the slice this stream owns: the other slices belong to streams whose tail-split / work-list kernels may be in
@@ -1006,12 +1006,6 @@ extern "C" int msn_reset_gemm_counters(msn_stream_t stream) {
         set_error("msn_reset_gemm_counters: %s", hipGetErrorString(hipGetLastError()));
         return MSN_ERR_HIP;
     }
-    return MSN_OK;
-}
-
-extern "C" int msn_set_gemm_lds_pad(int bytes) {
-    MSN_REQUIRE(bytes >= 0 && bytes <= 96 * 1024, "msn_set_gemm_lds_pad: 0 .. 98304 bytes");
-    g_gemm_lds_pad = bytes;
     return MSN_OK;
 }
 

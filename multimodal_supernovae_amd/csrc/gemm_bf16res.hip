@@ -639,12 +639,6 @@ static int tn_splits(int tiles, int64_t M) {
 
 using namespace msn;
 
-static int g_bgemm_persistent = 1;
-extern "C" int msn_set_bgemm_persistent(int enabled) {
-    g_bgemm_persistent = enabled ? 1 : 0;
-    return MSN_OK;
-}
-
 extern "C" size_t msn_bgemm_nt_colsum_workspace_bytes(int64_t M, int N) {
     if (M <= 0 || N <= 0) return 0;
     return sizeof(float) * 2 * (size_t)cdiv(M, BT) * (size_t)N;
@@ -677,7 +671,7 @@ extern "C" int msn_bgemm_nt(int64_t M, int N, int K, const void* A, int64_t lda,
     // one persistent workgroup per CU walking the tiles (the ring of K-tiles runs on across tile boundaries) once there is
     // more than one tile per CU and a tile has at least two K-tiles; otherwise one workgroup per tile
     const int total_tiles = a.tiles_m * a.tiles_n;
-    const bool persistent = g_bgemm_persistent && total_tiles > 256 && K / BKS >= 2;
+    const bool persistent = total_tiles > 256 && K / BKS >= 2;       // (one workgroup per tile at every size: bit-identical, 3 - 6 % slower on K = 768; r02)
     const dim3 grid((unsigned)(persistent ? 256 : total_tiles)), block(512);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (epilogue == EPI_B_GELU) hipLaunchKernelGGL((bgemm_nt_kernel<EPI_B_GELU, true>), grid, block, 0, st, a);

@@ -401,9 +401,12 @@ extern "C" size_t msn_sgemm_list_workspace_bytes(int n, const msn_gemm_desc* d) 
 }
 
 static int g_gemm_list = 1;   // 0: msn_sgemm_list issues its products one by one (measurements, bit-comparison of the two paths)
-extern "C" int msn_set_gemm_list(int enabled) {
-    MSN_REQUIRE(enabled == 0 || enabled == 1, "msn_set_gemm_list: 0 or 1");
-    g_gemm_list = enabled;
+namespace msn { void gemm_set_single_rule(int rule); }
+extern "C" int msn_set_gemm_list(int mode) {
+    MSN_REQUIRE(mode >= 0 && mode <= 3, "msn_set_gemm_list: 0 = no work-list launches at all, 1 = default, 2 = lists only (single products never take "
+                "the kernel), 3 = lists + every single product the kernel can take");
+    g_gemm_list = mode != 0;
+    msn::gemm_set_single_rule(mode == 1 ? 1 : (mode == 3 ? 2 : 0));
     return MSN_OK;
 }
 

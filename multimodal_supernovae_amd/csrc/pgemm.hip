@@ -35,12 +35,8 @@
 
 #include "pgemm_kernels.h"
 
-// instantiated in pgemm_alt1.hip / pgemm_alt2.hip
+// instantiated in pgemm_alt2.hip
 namespace msn {
-extern template __global__ void pgemm_nt_kernel<3, 128, true, true, 2, 4, false>(const PgemmArgs);
-extern template __global__ void pgemm_nt_kernel<3, 128, false, true, 2, 4, false>(const PgemmArgs);
-extern template __global__ void pgemm_nt_kernel<3, 128, true, true, 4, 2, false, false, true>(const PgemmArgs);
-extern template __global__ void pgemm_nt_kernel<3, 128, false, true, 4, 2, false, false, true>(const PgemmArgs);
 extern template __global__ void pgemm_nt_kernel<2, 128, true, false, 2, 4, false>(const PgemmArgs);
 extern template __global__ void pgemm_nt_kernel<2, 128, false, false, 2, 4, false>(const PgemmArgs);
 extern template __global__ void pgemm_nt_kernel<2, 128, false, true, 4, 2, false, true>(const PgemmArgs);
@@ -353,28 +349,10 @@ using namespace msn;
 extern "C" size_t msn_colsum_workspace_bytes(int64_t M, int64_t N);       // gemm.hip
 extern "C" int msn_colsum(const float* X, int64_t ldx, int64_t M, int64_t N, float* out, void* ws, size_t ws_bytes, msn_stream_t stream);
 
-static int g_pgemm_bn = 0;          // 0 = planned, 128 / 256 forced (measurements)
-static int g_pgemm_colgroup = 0;    // NT tile walk: tile columns per column group (0 = the planner's choice; experiments)
-static int g_pgemm_sr = 0;          // NT tile walk: tile rows per super-row (0 = the planner's choice; experiments)
-static int g_pgemm_skew = 0;        // NT start skew (shader cycles per phase; experiments)
-extern "C" int msn_set_pgemm_skew(int cycles) {
-    g_pgemm_skew = cycles;
-    return MSN_OK;
-}
-static int g_pgemm_chunk = 0;       // K-steps per chunk of the 3-plane NT kernel (0 = whole reduction; experiments)
-static int g_pgemm_variant = 1;     // 3-plane NT kernel: 0 = 2 x 4 waves, 1 = 4 x 2 (default), 2 = 4 x 2 on v_mfma_f32_16x16x32_bf16 (plane pairs along k)
-extern "C" int msn_set_pgemm_variant(int v) {
-    MSN_REQUIRE(v >= 0 && v % 1000 <= 2 && v / 1000 <= 1000, "msn_set_pgemm_variant: 0, 1 or 2 (+ 1000 * K-steps per chunk)");
-    g_pgemm_chunk = v / 1000;
-    v %= 1000;
-    g_pgemm_variant = v;
-    return MSN_OK;
-}
-extern "C" int msn_set_pgemm_tile_n(int bn) {
-    MSN_REQUIRE(bn == 0 || bn == 128, "msn_set_pgemm_tile_n: 0 or 128 (the 256-wide tiles were slower on every shape and are no longer built)");
-    g_pgemm_bn = bn;
-    return MSN_OK;
-}
+// (Round 6 retired the measurement switches of this file with their decided A/Bs: msn_set_pgemm_variant -- the 2 x 4 wave layout
+// and the 16 x 16 x 32 form of the 3-plane NT kernel, both slower or equal: profiles/r04_pgemm_variants.txt, r05_experiments_tried.txt
+// item 10 --, msn_set_pgemm_skew -- a start skew of the workgroups: nothing in time, and more than a few K-steps of it destroy the
+// sharing of operand panels in L2: r06_experiments_tried.txt item 1 --, msn_set_pgemm_tile_n and msn_set_pgemm_walk.)
 
 extern "C" size_t msn_plane_bytes(int64_t R, int64_t C, int planes) {
     if (R <= 0 || C <= 0 || planes < 1 || planes > 3) return 0;
@@ -545,11 +523,6 @@ NtTail nt_tail_plan(int64_t M, int N, int K, int c_planes, int epilogue, bool wa
     return t;
 }
 }  // namespace
-extern "C" int msn_set_pgemm_walk(int col_group, int super_rows) {
-    MSN_REQUIRE(col_group >= 0 && super_rows >= 0 && super_rows <= 64, "msn_set_pgemm_walk: col_group >= 0, 0 <= super_rows <= 64 (0 = the planner's choice)");
-    g_pgemm_colgroup = col_group, g_pgemm_sr = super_rows;
-    return MSN_OK;
-}
 extern "C" int msn_set_pgemm_tail_split(int enabled) {
     g_pgemm_tail = enabled ? 1 : 0;
     return MSN_OK;
@@ -601,19 +574,15 @@ static int pgemm_nt_impl(int64_t M, int N, int K, int planes, const void* A, con
     a.tiles_m = (int)cdiv(M, BM); a.tiles_n = (int)cdiv(N, bn);
     // super-rows: tile-rows walked together while their A panels (256 rows x K x 2 NP bytes) fit half an L2
     a.super_rows = (int)std::max<int64_t>(1, std::min<int64_t>(8, (2 << 20) / ((int64_t)BM * K * 2 * planes)));
-    a.col_group = a.tiles_n;
-    if (g_pgemm_sr > 0) a.super_rows = g_pgemm_sr;
-    if (g_pgemm_colgroup > 0) a.col_group = std::min(g_pgemm_colgroup, a.tiles_n);
     // fp32 grade: reductions longer than 768 columns are cut into chunks of at most 512 (the partial sums meet in C by fp32 adds)
     a.chunk_steps = 0;
     {
-        const int cs = g_pgemm_chunk > 0 ? g_pgemm_chunk : 32;         // K-steps per chunk (msn_set_pgemm_variant: experiments)
+        const int cs = 32;                                             // K-steps per chunk
         if ((planes == 3 || f16) && !c_planes && a.cbA > std::max(cs, 48)) {
             const int nch = (int)cdiv(a.cbA, cs);
             a.chunk_steps = 2 * (int)cdiv(a.cbA, 2 * nch);
         }
     }
-    a.skew = g_pgemm_skew;
     a.scaleA = scaleA, a.scaleB = scaleB;
     const NtTail tail = nt_tail_plan(M, N, K, c_planes, epilogue, colsum_out != nullptr);
     if (tail.segs && ws && ws_bytes >= msn_pgemm_nt_workspace_bytes(M, N, K, planes, c_planes, epilogue, 0) && aligned16p(ws)) {
@@ -634,13 +603,8 @@ static int pgemm_nt_impl(int64_t M, int N, int K, int planes, const void* A, con
     const int grid = a.tail_segs ? std::max(a.tail_full ? 256 : 0, (total - a.tail_full) * a.tail_segs) : std::min(total, 256);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (planes == 3) {
-        a.colsum_rows = g_pgemm_variant == 0 ? 2 : 4;
-        // (the staggered-DMA instantiations -- variants 3 / 4 of the measurements in profiles/r04_pgemm_variants.txt -- are not
-        // built any more: nothing in the step, +9 % on one shape in isolation; STAG stays in the kernel source)
-        if (g_pgemm_variant == 0) launch_nt<3, 128, true>(a, c_planes != 0, grid, st);
-        else if (g_pgemm_variant == 2 && c_planes) hipLaunchKernelGGL((pgemm_nt_kernel<3, 128, true, true, 4, 2, false, false, true>), dim3((unsigned)grid), dim3(512), 0, st, a);
-        else if (g_pgemm_variant == 2) hipLaunchKernelGGL((pgemm_nt_kernel<3, 128, false, true, 4, 2, false, false, true>), dim3((unsigned)grid), dim3(512), 0, st, a);
-        else launch_nt<3, 128, true, 4, 2>(a, c_planes != 0, grid, st);
+        a.colsum_rows = 4;
+        launch_nt<3, 128, true, 4, 2>(a, c_planes != 0, grid, st);      // 4 x 2 waves of 64 x 64 (the 2 x 4 layout: -7 ... -12 %)
     } else if (f16) {
         a.colsum_rows = 4;
         hipLaunchKernelGGL((pgemm_nt_kernel<2, 128, false, true, 4, 2, false, true>), dim3((unsigned)grid), dim3(512), 0, st, a);

@@ -1,5 +1,5 @@
 // The two hand-scheduled plane GEMM kernels (templates) of csrc/pgemm.hip, in a header so that their instantiations compile in
-// three translation units side by side (pgemm.hip: the default forms; pgemm_alt1.hip / pgemm_alt2.hip: the measurement variants,
+// two translation units side by side (pgemm.hip: the default forms; pgemm_alt2.hip:
 // the 2-plane and the fp16 forms) -- one unit took 2.5 minutes.  See pgemm.hip for the format and the entry points.
 #pragma once
 #include <algorithm>
@@ -42,13 +42,11 @@ struct PgemmArgs {
     int cbA, cbB;                   // column blocks of A / B (NT: both = K-steps)
     int cbC;                        // column blocks of a plane output
     int tiles_m, tiles_n, super_rows, epi;
-    int col_group;                  // NT: tile columns per column group of the tile walk (tiles_n = one group: super-rows span every column)
     int colsum_rows;                // NT: column-sum partial rows per tile row (= WM of the kernel's wave layout)
     int chunk_steps;                // NT: K-steps per chunk (0 = the whole reduction in one accumulation)
     int tail_full;                  // NT: tiles [0, tail_full) are dealt whole; [tail_full, total) are the TAIL tiles, each cut into
     int tail_segs, tail_steps;      //     tail_segs K-segments of tail_steps K-steps (units): unit u -> workgroup u, raw sums -> tail_slabs[u]
     float* tail_slabs;              //     (0 segments: no tail split)
-    int skew;                       // NT: start delay unit in shader cycles (0 = none): workgroup b waits ((b >> 3) & 3) * skew
     float* colpart;                 // NT (nullable): [2 * tiles_m][N] column sums of the values written to C
     int splits;                     // TN: reduction split
     int rb_per_split;               // TN: row blocks per split
@@ -131,23 +129,21 @@ __device__ __forceinline__ void split_planes(float x, u16 (&pl)[NP]) {
 }
 
 // The NT kernel's tile walk (also used by its tail-finishing launch): tile ids are dealt round-robin to the 8 XCDs; each XCD gets a
-// contiguous run of the walk, which covers the tile grid in super-rows (SR tile-rows x the columns of a group, row-fastest) so
-// that the workgroups of an XCD share A row panels and the weight planes in one L2.
-// COLUMN GROUPS (col_group < tiles_n): the walk covers the grid one group of col_group tile columns after the other, so an XCD's
-// run lies inside one group (or two) and re-reads only THAT group's weight planes row after row -- a weight whose planes do
-// not stay in a 4-MB L2 beside the A panels of a round (N = 1536: 3.5 MB) is otherwise fetched once per super-row; the price
-// is that a tile row's A panel is read by the XCDs of every group.
+// contiguous run of the walk, which covers the tile grid in super-rows (SR tile-rows x every tile column, row-fastest) so that
+// the workgroups of an XCD share A row panels and the weight planes in one L2.
+// (Round 6 tried COLUMN GROUPS on top -- the walk covering one group of tile columns after the other, so that an XCD re-reads only
+//  its group's weight planes; commit 03e790c has the code and its test -- and measured nothing: a round of an XCD's 32 workgroups
+//  fetches >= 4.7 MB of A panels + weight planes whatever its shape, more than the 4-MB L2, so nothing survives from one round to
+//  the next; profiles/r06_experiments_tried.txt, item 1.)
 __device__ __forceinline__ void nt_locate(const PgemmArgs& p, int t, int& tm_, int& tn_) {
     const int total = p.tiles_m * p.tiles_n;
     const int q = total / 8, r = total % 8, x = t % 8, i = t / 8;
     const int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-    const int SR = p.super_rows, CG = p.col_group;
-    const int grp = min(bid / (p.tiles_m * CG), (p.tiles_n - 1) / CG), within = bid - grp * (p.tiles_m * CG);
-    const int gcols = min(CG, p.tiles_n - grp * CG);
-    const int sr = within / (SR * gcols), j = within % (SR * gcols);
+    const int SR = p.super_rows;
+    const int sr = bid / (SR * p.tiles_n), j = bid % (SR * p.tiles_n);
     const int rows_sr = min(SR, p.tiles_m - sr * SR);
     tm_ = sr * SR + j % rows_sr;
-    tn_ = grp * CG + j / rows_sr;
+    tn_ = j / rows_sr;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -170,10 +166,9 @@ __device__ __forceinline__ void nt_locate(const PgemmArgs& p, int t, int& tm_, i
 // (12 instead of 15 fragment reads per 24 MFMAs on BN = 128: +7-12 %, the 3-plane default; four waves of 128 x 64 with the
 // whole register file each were 15-25 % slower).  STAG: the two waves of a SIMD issue their LDS-DMA pieces in different halves of a K-step
 // (waves 0-3 behind the first products, waves 4-7 behind the last ones) instead of both stalling in the same gaps.
-template <int NP, int BN, bool OUTP, bool DUAL, int WM = 2, int WN = 4, bool STAG = false, bool F16 = false, bool S16 = false>
+template <int NP, int BN, bool OUTP, bool DUAL, int WM = 2, int WN = 4, bool STAG = false, bool F16 = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(const PgemmArgs p) {
     static_assert(!F16 || !OUTP, "fp16 planes: fp32 results only");
-    static_assert(!S16 || (NP == 3 && DUAL && !F16 && !STAG && WM == 4 && WN == 2 && BN == 128), "the 16 x 16 x 32 form: three bf16 planes, two accumulator sets, 4 x 2 waves");
     constexpr int NW = WM * WN;
     constexpr int ARB = BM / 32, BRB = BN / 32, AP = ARB * NP, BP = BRB * NP, PIECES = AP + BP;
     constexpr int SLOT = PIECES * PBLK;
@@ -182,7 +177,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
     static_assert(NSLOT * SLOT + NW * STG <= 160 * 1024, "LDS: ring + staging");
     constexpr int MAXQ = (PIECES + NW - 1) / NW;     // pieces per wave and K-step (the last one only for the low waves)
     constexpr int MT = 8 / WM, NT = BN / (32 * WN);  // 32 x 32 MFMA tiles per wave: rows x columns
-    constexpr int NG = S16 ? 3 : NP * (NP + 1) / 2;  // MFMA groups per K-step (S16: three plane-PAIR products)
+    constexpr int NG = NP * (NP + 1) / 2;            // MFMA groups (plane products) per K-step
     __shared__ __attribute__((aligned(1024))) unsigned char lds[NSLOT * SLOT + NW * STG];
 
     const int lane = threadIdx.x & 63;
@@ -217,7 +212,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
     };
 
     // ---- producer: the LDS-DMA stream.  Global K-step g (over all tiles of this workgroup) lives in slot g % NSLOT.
-    // (S16: no swizzle -- 16-row fragments of rows r, r + 8 take opposite halves in one ds_read_b128 lane group: conflict-free as laid)
     // The sources go through BUFFER descriptors: one per operand, in scalar registers, based at the first row block of the
     // producer's tile; the lane's 16 bytes inside a 1-KB block are the vector offset (constant for the kernel), the piece and the
     // K-step a scalar offset.  (With a 64-bit pointer per piece every DMA instruction cost a v_lshl_add_u64 -- seven vector
@@ -232,7 +226,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
         const int nb = __builtin_amdgcn_readfirstlane((int)bytes);
         return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), (short)0, nb, 0x00020000);
     };
-    const int lane_src = S16 ? lane * 16 : (((lane >> 1) * 2) + ((lane & 1) ^ ((lane >> 4) & 1))) * 16;
+    const int lane_src = (((lane >> 1) * 2) + ((lane & 1) ^ ((lane >> 4) & 1))) * 16;
     // (kept as two scalar halves and made into a descriptor by the builtin AT the instruction, the scalar offset through a local:
     //  with `poff[q] + ...` written as the builtin's argument the host pass of hipcc 7.2 drops the kernel's explicit instantiations
     //  without a diagnostic -- no stub and no fat binary in the object, an undefined symbol when the library is loaded)
@@ -332,29 +326,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
 
     f32x16 acc[MT][NT], acc2[DUAL ? MT : 1][DUAL ? NT : 1];
     bf16x8 fa[2][MT], fb0[2][NT], fbh[NP > 1 ? NP - 1 : 1][NT];
-    // ---- S16: v_mfma_f32_16x16x32_bf16 (holds 2.0 GHz under load where the 32 x 32 x 16 shape holds 1.75: profiles/
-    // r04_mfma_shape_clock.txt).  The 32 k of one instruction are the SAME 16 columns of TWO PLANES: lane group kg = lane >> 4
-    // supplies plane (kg >> 1 ? second : first), 16-byte half kg & 1 of row lane & 15 -- so [p0 | p1].[q0 | q1] = p0q0 + p1q1 (first
-    // accumulator set), [p0 | p1].[q1 | q0] = p0q1 + p1q0 and [p0 | p2].[q2 | q0] = p0q2 + p2q0 (second set): three 16-cycle
-    // instructions per 16 x 16 tile and K-step.  A 32 x 32 accumulator tile acc[i][j] is four 16 x 16 sub-tiles: chunk b =
-    // 2 (row half) + (column half); the lane holds row 16 (b >> 1) + (lane & 15), columns 16 (b & 1) + 4 (lane >> 4) + r.
-    const int r16 = lane & 15, kg = lane >> 4;
-    const unsigned s16_lane = (unsigned)(r16 * 32 + (kg & 1) * 16);
-    const unsigned s16A = lds0 + s16_lane + (unsigned)(wm * MT * NP * PBLK);
-    const unsigned s16B = lds0 + s16_lane + (unsigned)((AP + wn * NT * NP) * PBLK);
-    const unsigned fA01 = s16A + (unsigned)((kg >> 1) * PBLK), fA02 = s16A + (unsigned)((kg >> 1) * 2 * PBLK);
-    const unsigned fB01 = s16B + (unsigned)((kg >> 1) * PBLK), fB10 = s16B + (unsigned)((1 - (kg >> 1)) * PBLK);
-    const unsigned fB20 = s16B + (unsigned)((1 - (kg >> 1)) * 2 * PBLK);
-    bf16x8 fr[2][2][S16 ? 4 : 1];                    // [set][A-type | B-type][16-row sub-tile]
-    auto req16 = [&](bf16x8 (&dst)[S16 ? 4 : 1], unsigned base) {
-        if constexpr (S16) {
-            static_for<0, 4>([&](auto t_) {
-                constexpr int t = decltype(t_)::value;
-                ds_read128<(t >> 1) * NP * PBLK + (t & 1) * 512>(dst[t], base);
-            });
-        }
-    };
-
+    // (A 16 x 16 x 32 form of this loop -- the 32 k of one instruction = the same 16 columns of TWO planes, three instructions per
+    //  16 x 16 tile and K-step -- was built in round 4 and rebuilt with its cross-step prefetch in round 5: all three loop forms
+    //  within 1.5 % of each other, profiles/r05_experiments_tried.txt item 10; removed in round 6 with its switch.)
     auto req_a = [&](bf16x8 (&dst)[MT], unsigned slot_off, auto pl_) {
         constexpr int pl = decltype(pl_)::value;
 #if defined(MSN_ABL_PG_NOFRAG) || defined(MSN_ABL_PG_NOFRAG_A)   // diagnostic build: no fragment reads (the MFMAs multiply whatever
@@ -397,19 +371,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
             }
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto mult16 = [&](const bf16x8 (&a)[S16 ? 4 : 1], const bf16x8 (&b)[S16 ? 4 : 1], auto small_) {
-        constexpr bool SMALL = decltype(small_)::value;
-        if constexpr (S16) {
-            static_for<0, 16>([&](auto u_) {
-                constexpr int u = decltype(u_)::value, ti = u >> 2, tj = u & 3, i = ti >> 1, j = tj >> 1, bch = 2 * (ti & 1) + (tj & 1);
-                f32x16& dstv = SMALL ? acc2[i][j] : acc[i][j];
-                f32x4 c = {dstv[4 * bch], dstv[4 * bch + 1], dstv[4 * bch + 2], dstv[4 * bch + 3]};
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[tj], a[ti], c, 0, 0, 0);
-                dstv[4 * bch] = c[0], dstv[4 * bch + 1] = c[1], dstv[4 * bch + 2] = c[2], dstv[4 * bch + 3] = c[3];
-            });
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
     using BIG = std::integral_constant<bool, false>;
     using SML = std::integral_constant<bool, true>;
     // request the first fragments of a K-step (A plane 0 and every B plane) -- order matters for the counted waits
@@ -428,7 +389,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
     // K-step of two MFMA tiles came out wrong in a few tiles per launch of the plane-output kernel.  So here the reads are
     // waited for, and every register is re-defined behind the wait (an empty asm) so that any copy sits behind it too.
     auto req_first_settled = [&](unsigned slot_off) {
-        if constexpr (S16) return;                   // (this form requests every fragment inside its step)
         req_first(fa[0], fb0[0], slot_off);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -449,54 +409,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
     // epilogue requests them once it is done -- the ring of K-steps itself runs on across tiles.
     auto step = [&](auto par_, bool last = false) {
         constexpr int PAR = decltype(par_)::value;
-        if constexpr (S16) {
-            // Every fragment is requested AND consumed inside its step: fr[0][0] = [p0 | p1] of A, fr[0][1] = [q0 | q1] of B,
-            // fr[1][0] = [p0 | p2], fr[1][1] = [q2 | q0]; [q1 | q0] is [q0 | q1] with the lane halves exchanged (two
-            // v_permlane32_swap per register pair, in place) instead of a fifth read: 16 ds_read_b128 per step (12 in the
-            // 32 x 32 x 16 form).  NOT carried over from that form: the next step's first fragments requested behind the barrier.
-            // With 16 fragment registers more than that form holds, the allocator (256 VGPRs) copies or spills the in-flight
-            // destinations at the step's merges -- multiplying fragments that have not arrived (tools/check_fragment_waits.py
-            // finds such copies in the ISA; the integer tests found them first).  What this costs is most of what the shape gains.
-            const unsigned cur = (unsigned)(c_slot * SLOT);
-            const int n_slot = (c_slot + 1 == NSLOT) ? 0 : c_slot + 1;
-            const bool p_was_live = p_live;
-            (void)last;
-            req16(fr[0][0], fA01 + cur);
-            req16(fr[0][1], fB01 + cur);
-            req16(fr[1][1], fB20 + cur);
-            wait_lgkm<4>();
-            mult16(fr[0][0], fr[0][1], BIG{});           // p0q0 + p1q1
-            issue_chunk(std::integral_constant<int, 0>{});
-            __builtin_amdgcn_sched_barrier(0);
-            req16(fr[1][0], fA02 + cur);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                u32x4 w = __builtin_bit_cast(u32x4, fr[0][1][t]);
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const u32x2 r = __builtin_amdgcn_permlane32_swap(w[2 * h], w[2 * h + 1], false, false);
-                    const u32x2 q = __builtin_amdgcn_permlane32_swap(r[1], r[0], false, false);
-                    w[2 * h] = q[0], w[2 * h + 1] = q[1];
-                }
-                fr[0][1][t] = __builtin_bit_cast(bf16x8, w);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mult16(fr[0][0], fr[0][1], SML{});           // p0q1 + p1q0
-            issue_chunk(std::integral_constant<int, 1>{});
-            __builtin_amdgcn_sched_barrier(0);
-            wait_lgkm<0>();
-            wait_vm(p_was_live ? (NSLOT - 3) * ppw + Q_BEFORE : 0);
-#ifndef MSN_ABL_PG_NOBAR
-            __builtin_amdgcn_s_barrier();
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            mult16(fr[1][0], fr[1][1], SML{});           // p0q2 + p2q0
-            issue_chunk(std::integral_constant<int, NG - 1>{});
-            __builtin_amdgcn_sched_barrier(0);
-            advance();
-            c_slot = n_slot;
-            return;
-        }
         constexpr int QA = (NP & 1) ? PAR : 0;       // fa buffer of plane 0; plane pa sits in fa[(QA + pa) & 1]
         const unsigned cur = (unsigned)(c_slot * SLOT);
         const int n_slot = (c_slot + 1 == NSLOT) ? 0 : c_slot + 1;
@@ -557,19 +469,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
     // live across the K loop -- where the two accumulator sets and the fragments fill the file -- and the allocator spilled them
     // (scratch stores in the prologue, reloads in every epilogue form).  Re-deriving them costs ~20 vector instructions per tile.
     int eln = lane;
-    int frow_e = 0, fhalf_e = 0, r16_e = 0, kg_e = 0, srow = 0, schunk = 0;
+    int frow_e = 0, fhalf_e = 0, srow = 0, schunk = 0;
     unsigned stg = 0, st_mem = 0;
     auto epi_lane = [&]() {
         asm volatile("" : "+v"(eln));
-        frow_e = eln & 31, fhalf_e = eln >> 5, r16_e = eln & 15, kg_e = eln >> 4;
+        frow_e = eln & 31, fhalf_e = eln >> 5;
         srow = eln >> 3, schunk = eln & 7;                                          // memory order: pass q -> row 8 q + srow
         stg = lds0 + (unsigned)(NSLOT * SLOT + wave * STG);
         // fp32 image of a tile: [32 rows][128 B], 16-byte chunk c of row r at position c ^ (r & 7) (conflict-free both ways)
         st_mem = stg + (unsigned)(srow * 128 + ((schunk ^ srow) * 16));              // + q * 1024   ((8 q + srow) & 7 == srow)
     };
     // chunk b of this lane's 16 accumulator values of a 32 x 32 tile: its row and its 16-byte column chunk (4 columns) in the tile
-    auto erow = [&](int b) { return S16 ? 16 * (b >> 1) + r16_e : frow_e; };
-    auto ecolq = [&](int b) { return S16 ? 4 * (b & 1) + kg_e : 2 * b + fhalf_e; };
+    auto erow = [&](int) { return frow_e; };
+    auto ecolq = [&](int b) { return 2 * b + fhalf_e; };
     auto acc_addr = [&](int b) { return stg + (unsigned)(erow(b) * 128 + ((ecolq(b) ^ (erow(b) & 7)) * 16)); };
     // (s_nop behind every ds_write_b128: a VALU write to the data registers of a DS store of more than 8 bytes needs a wait
     // state the compiler's hazard recognizer would insert -- it cannot see the store inside the asm; without it a few lanes
@@ -754,11 +666,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
                         else v[e] += a[e];                         // MSN_EPI_ADD
                     }
                 }
-                if constexpr (S16) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        if (m0 + erow(e >> 2) >= p.M) v[e] = 0.f;
-                } else if (!row_ok) {
+                if (!row_ok) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) v[e] = 0.f;       // padding rows of a plane output are zero
                 }
@@ -818,24 +726,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
                     for (int e = 0; e < 16; ++e) cs[e] += v[e];
                 }
             });
-            if constexpr (CS && S16) {   // chunks b and b ^ 2 hold the two row halves of the same columns; 16 lanes per row half
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float t = cs[e] + cs[e + 8];
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o, 64);
-                    cs[e] = t;
-                }
-                if (r16_e == 0) {
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        const int n = n0 + 4 * ecolq(b);
-                        if (n < p.N)
-                            *reinterpret_cast<float4*>(p.colpart + (int64_t)(WM * tm + wm) * p.N + n) =
-                                make_float4(cs[4 * b], cs[4 * b + 1], cs[4 * b + 2], cs[4 * b + 3]);
-                    }
-                }
-            } else if constexpr (CS) {   // the 32 lanes sharing lane >> 5 hold the 32 rows of every row tile: xor tree, one lane writes
+            if constexpr (CS) {   // the 32 lanes sharing lane >> 5 hold the 32 rows of every row tile: xor tree, one lane writes
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     float t = cs[e];
@@ -877,17 +768,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void pgemm_nt_kernel(c
                 }
     };
 
-    // ---- start skew: equal tiles keep the workgroups of a launch in lockstep -- all in their K loops (HBM idle), then all in
-    // their epilogues (matrix cores idle, HBM write-bound).  Four start phases a quarter tile apart spread the epilogues'
-    // stores over the others' K loops; workgroups with one tile fewer than the rest have the slack for it.
-    if (p.skew > 0) {
-        const int phase = (blockIdx.x >> 3) & 3;
-        const int mine = (total - (int)blockIdx.x + G - 1) / G, most = (total + G - 1) / G;
-        if (phase && (mine < most || p.skew < 0x40000000)) {
-            const long long until = (long long)__builtin_readcyclecounter() + (long long)phase * (p.skew & 0x3fffffff);
-            while ((long long)__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(32);
-        }
-    }
     // ---- prologue: K-steps 0 .. NSLOT - 2 of the stream
 #pragma unroll
     for (int s = 0; s < NSLOT - 1; ++s) {

@@ -978,12 +978,9 @@ static int plane_tail_zero(void* planes_out, int64_t rows, int cols, int np, hip
     return MSN_OK;
 }
 
-static int g_ln_block_planes = 1;   // msn_layernorm_fwd_planes through ln_fwd_planes_kernel where it applies (0: the row kernel; A/B runs)
-extern "C" int msn_set_layernorm_block_planes(int on) {
-    g_ln_block_planes = on;      // 2: at every row count (tests)
-    return MSN_OK;
-}
-
+// Row-block kernels (ln_fwd_planes_kernel / ln_bwd_planes_kernel) from 32 768 rows on; below, the coarse grid of whole row blocks
+// loses to the row-at-a-time kernels (25.7 vs 25.9 us at 8 320 rows: r05 log, item 14).  Both write the same bytes.
+static constexpr int64_t kLnBlockRows = 32 * 1024;
 extern "C" int msn_layernorm_fwd_planes(const float* x, int64_t ldx, int64_t rows, int cols, const float* gamma,
                                         const float* beta, float eps, int planes, void* y_planes, float* y, int64_t ldy,
                                         float* mean, float* rstd, msn_stream_t stream) {
@@ -997,7 +994,7 @@ extern "C" int msn_layernorm_fwd_planes(const float* x, int64_t ldx, int64_t row
     const size_t img = (size_t)cbn * planes * 1024;
     // whole row blocks through LDS (two workgroups per CU); from 1024 row blocks on (4 per CU) -- below that the grid is too
     // coarse: 520 blocks (16 640 rows) 18.4 us against the row kernel's 15.1, 2080 blocks 45.5 against 55.5
-    if (!y && lpr == 64 && img <= 78 * 1024 && g_ln_block_planes && rows >= 32 * 1024 * (g_ln_block_planes == 2 ? 0 : 1)) {
+    if (!y && lpr == 64 && img <= 78 * 1024 && rows >= kLnBlockRows) {
         unsigned char* o = static_cast<unsigned char*>(y_planes);
         const dim3 grid((unsigned)cdiv(rows, 32)), block(512);
         if (planes == 3) {
@@ -1038,7 +1035,7 @@ extern "C" int msn_layernorm_bwd_planes(const float* dy, int64_t lddy, const flo
     {   // whole row blocks through LDS (ln_bwd_planes_kernel): the same rule as the forward's
         const int cbn = 2 * (int)cdiv(cols, 32);
         const size_t img = (size_t)cbn * planes * 1024;
-        if (lpr == 64 && img <= 78 * 1024 && g_ln_block_planes && rows >= 32 * 1024 * (g_ln_block_planes == 2 ? 0 : 1)) {
+        if (lpr == 64 && img <= 78 * 1024 && rows >= kLnBlockRows) {
             const int bgrid = (int)std::min<int64_t>(cdiv(rows, 32), std::min(grid, 512));       // <= grid: the workspace holds it
             const int nc = (int)cdiv(cols, 256);
             unsigned char* o = static_cast<unsigned char*>(dx_planes);

@@ -3,7 +3,6 @@ sequences of libmsn_hip kernels (ops.py).  One node per transformer block / line
 step, so residual adds, bias adds, activations and their derivatives ride in GEMM epilogues and no
 stock ATen arithmetic runs on the hot path.  Reference lines are cited per node."""
 import math
-import os
 
 import torch
 
@@ -698,8 +697,8 @@ def plane_path_ok(x):
 
 
 # Backward pairs (dX and dW of one Linear) as ONE work-list launch: bit 1 = the qkv and ff1 pairs (e-wide dX), bit 4 = the ff2
-# pair (4e-wide dX), bit 2 = the e x e output projection.  MSN_PAIR_BACKWARD overrides; unset: by row count (_pair_backward).
-PAIR_BACKWARD = os.environ.get("MSN_PAIR_BACKWARD")
+# pair (4e-wide dX), bit 2 = the e x e output projection.  None: by row count (_pair_backward); tests set the module attribute.
+PAIR_BACKWARD = None
 
 
 def _pair_backward(rows):
@@ -951,7 +950,7 @@ def take_token(x, idx):
 
 
 # ------------------------------------------------------ channels-last convolution (build-defined encoders)
-CONV_IMPLICIT = os.environ.get("MSN_CONV_IMPLICIT", "1") != "0"   # measurements: 0 = always im2col + GEMM
+CONV_IMPLICIT = True   # False (tests, measurements): always im2col + GEMM
 @_remember_precision
 class _ConvCL(torch.autograd.Function):
     """y = conv(x) (+ bias) (+ ReLU) on channels-last tensors as an MFMA GEMM; weight keeps torch's (C_out, C_in, kh, kw)

@@ -150,15 +150,11 @@ def wgrad_bias(dy, x, precision=None, out=None):
     return dw, db
 
 
-def set_gemm_list(enabled):
-    """msn_sgemm_list: True (default) = one work-list launch, False = its products one by one (measurements, comparisons)."""
-    check(lib().msn_set_gemm_list(int(bool(enabled))))
-
-
-def set_gemm_streamk(max_tiles=1024, min_k=1024):
-    """msn_sgemm itself takes the work-list kernel for opA = N products of at most `max_tiles` 128 x 128 tiles with
-    K >= min_k (max_tiles = 0: never; the defaults are the library's)."""
-    check(lib().msn_set_gemm_streamk(int(max_tiles), int(min_k)))
+def set_gemm_list(mode=1):
+    """msn_set_gemm_list: 1 / True (default) = work-list launches for msn_sgemm_list and, by the planner's rule, for long-K under-filled
+    single products; 0 / False = none at all (lists one by one: measurements, bit comparisons); 2 = lists only, single products never
+    (tests that pin the flat kernels); 3 = lists + every single product the kernel can take (tests)."""
+    check(lib().msn_set_gemm_list(int(mode)))
 
 
 def _gemm_desc(a, b, op_a, op_b, c, bias=None, epilogue=EPI_NONE, aux=None, colsum_out=None):
@@ -963,15 +959,7 @@ def attention_bf16_bwd(qkv, out, dout, lse, B, T, heads, scale, want_colsum=Fals
 
 
 # ------------------------------------------------ fp32-grade products from resident bf16 planes (csrc/pgemm.hip)
-PLANES = int(__import__("os").environ.get("MSN_PLANES", "3"))
-if __import__("os").environ.get("MSN_PGEMM_TAIL"):         # "0": multiply the tail tiles whole (measurements)
-    check(lib().msn_set_pgemm_tail_split(int(__import__("os").environ["MSN_PGEMM_TAIL"])))
-if __import__("os").environ.get("MSN_LN_BLOCK_PLANES"):    # 0: LayerNorm forward -> planes on the row-at-a-time kernel (A/B runs)
-    check(lib().msn_set_layernorm_block_planes(int(__import__("os").environ["MSN_LN_BLOCK_PLANES"])))
-if __import__("os").environ.get("MSN_PGEMM_VARIANT"):      # wave layout of the 3-plane NT kernel: 0 = 2 x 4, 1 = 4 x 2 (measurements)
-    check(lib().msn_set_pgemm_variant(int(__import__("os").environ["MSN_PGEMM_VARIANT"])))     # planes per operand: 3 = fp32 grade (6 products), 2 = 3 products
-
-
+PLANES = 3          # planes per operand when a caller does not say: 3 = fp32 grade (6 products), 2 = 3 products
 if __import__("os").environ.get("MSN_ATTN_PLANES"):        # 0: long narrow-head attention on the exact-fp32 matrix-core kernels; 3 / 5: backward forms (A/B runs)
     check(lib().msn_set_attention_planes(int(__import__("os").environ["MSN_ATTN_PLANES"])))
 
@@ -1075,16 +1063,14 @@ def attention_fwd_planes(qkv, heads, scale, planes=None, mask_u8=None):
     return out, lse, op
 
 
-ATTN_BWD_PLANES = __import__("os").environ.get("MSN_ATTN_BWD_PLANES", "1") != "0"      # 0: msn_attention_bwd + msn_plane_split (A/B runs)
-ATTN_FWD_PLANES = __import__("os").environ.get("MSN_ATTN_FWD_PLANES", "1") != "0"      # 0: msn_attention_fwd + msn_plane_split (A/B runs)
 
 
 def attention_fwd_planes_supported(T, head_dim):
-    return ATTN_FWD_PLANES and T <= 128 and head_dim % 16 == 0 and head_dim <= 64
+    return T <= 128 and head_dim % 16 == 0 and head_dim <= 64
 
 
 def attention_bwd_planes_supported(T, head_dim):
-    return ATTN_BWD_PLANES and T <= 128 and head_dim % 16 == 0 and head_dim <= 64 and 4 * (T + 3) * (head_dim + 4) * 4 + 4096 <= 160 * 1024
+    return T <= 128 and head_dim % 16 == 0 and head_dim <= 64 and 4 * (T + 3) * (head_dim + 4) * 4 + 4096 <= 160 * 1024
 
 
 def set_attention_fused(on):
@@ -1103,14 +1089,11 @@ class _SplitItem(ctypes.Structure):
                 ("transposed", ctypes.c_int), ("out", ctypes.c_void_p)]
 
 
-SPLIT_LIST = __import__("os").environ.get("MSN_SPLIT_LIST", "1") != "0"      # 0: one msn_plane_split launch per matrix (A/B runs)
-
-
 def plane_split_list(mats, planes=None, transposed=False):
     """Planes of several 2-D fp32 matrices (or of their transposes) from ONE launch (msn_plane_split_list): the weights of
     every block of a tower."""
     planes = PLANES if planes is None else planes
-    if not SPLIT_LIST or planes == F16_PLANES:
+    if planes == F16_PLANES:
         return [plane_split(m, planes, transposed=transposed) for m in mats]
     items = (_SplitItem * len(mats))()
     outs = []
@@ -1195,11 +1178,6 @@ def pgemm_tn(dy, x):
     return c
 
 
-def set_pgemm_tile_n(bn):
-    """Tile width of pgemm_nt: 0 = planned (default), 128, 256 -- measurements / tests."""
-    check(lib().msn_set_pgemm_tile_n(int(bn)))
-
-
 def layernorm_fwd_planes(x, gamma, beta, eps, planes):
     """LayerNorm whose output goes straight to bf16 planes (the next product's operand); returns (Planes, mean, rstd)."""
     x2 = _rows2d(_f32c(x, "x"))
@@ -1229,16 +1207,6 @@ def layernorm_bwd_planes(dy, x, mean, rstd, gamma, planes, add=None, want_colsum
                                      ptr(add2), add2.stride(0) if add2 is not None else 0, ptr(dx), cols, planes, ptr(dxp.buf),
                                      ptr(dg), ptr(db), ptr(cs), ptr(ws), nb, stream_ptr()), "msn_layernorm_bwd_planes")
     return (dx, dxp, dg, db, cs) if want_colsum else (dx, dxp, dg, db)
-
-
-def set_pgemm_variant(v):
-    """Wave layout of the 3-plane pgemm_nt kernel (msn_set_pgemm_variant) -- measurements."""
-    check(lib().msn_set_pgemm_variant(int(v)))
-
-
-def set_pgemm_walk(col_group=0, super_rows=0):
-    """pgemm_nt tile walk (msn_set_pgemm_walk; 0 = the planner's choice) -- measurements."""
-    check(lib().msn_set_pgemm_walk(int(col_group), int(super_rows)))
 
 
 def set_pgemm_tail_split(enabled):

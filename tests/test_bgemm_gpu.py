@@ -167,29 +167,32 @@ def test_bf16_attention_forward_backward(B, H, T):
                                        (70000, 1000, 128, "none")])
 def test_nt_persistent_workgroups_equal_one_tile_launches(M, N, K, epi):
     """BASELINE cfg5 sizes (batch 512: 100 864 token rows): the persistent launch (one workgroup per CU walking its tiles, the
-    LDS ring running on across tile boundaries) gives the bits of the one-workgroup-per-tile launch -- ragged last row tile,
-    ragged last column tile, epilogues with aux reads / writes, column sums."""
-    from multimodal_supernovae_amd import ops, _lib
+    LDS ring running on across tile boundaries) gives the bits of one-workgroup-per-tile launches -- what a product of at most 256
+    tiles gets: the same product issued in row slabs of at most 256 tiles each -- ragged last row tile, ragged last column tile,
+    epilogues with aux reads / writes."""
+    from multimodal_supernovae_amd import ops
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     a = (torch.randn(M, K, device="cuda", generator=g) * 0.5).to(torch.bfloat16)
     w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
     bias = torch.randn(N, device="cuda", generator=g)
     res = torch.randn(M, N, device="cuda", generator=g) if epi == "add" else None
-    outs = []
-    try:
-        for persistent in (1, 0):
-            _lib.check(_lib.lib().msn_set_bgemm_persistent(persistent))
-            if epi == "gelu":
-                aux = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-                y = ops.bgemm_nt(a, w, bias=bias, epilogue=ops.BEPI_GELU, aux=aux, out_bf16=True)
-                outs.append((y, aux))
-            elif epi == "add":
-                outs.append((ops.bgemm_nt(a, w, bias=bias, epilogue=ops.BEPI_ADD, aux=res),))
-            else:
-                outs.append(ops.bgemm_nt(a, w, bias=bias, out_bf16=True, want_colsum=True))
-    finally:
-        _lib.check(_lib.lib().msn_set_bgemm_persistent(1))
+
+    def run(rows):
+        lo, hi = rows
+        if epi == "gelu":
+            aux = torch.empty(hi - lo, N, device="cuda", dtype=torch.bfloat16)
+            y = ops.bgemm_nt(a[lo:hi], w, bias=bias, epilogue=ops.BEPI_GELU, aux=aux, out_bf16=True)
+            return [y, aux]
+        if epi == "add":
+            return [ops.bgemm_nt(a[lo:hi], w, bias=bias, epilogue=ops.BEPI_ADD, aux=res[lo:hi])]
+        return [ops.bgemm_nt(a[lo:hi], w, bias=bias, out_bf16=True)]
+
     def flat(o):
         return [o] if torch.is_tensor(o) else [t for e in o for t in flat(e)]
-    a0, a1 = flat(outs[0]), flat(outs[1])
-    assert len(a0) == len(a1) and all(torch.equal(x, y) for x, y in zip(a0, a1))
+
+    whole = flat(run((0, M)))
+    slab = 256 * max(1, 256 // ((N + 255) // 256))          # rows of a slab of at most 256 tiles (whole 256-row tiles)
+    parts = [flat(run((lo, min(M, lo + slab)))) for lo in range(0, M, slab)]
+    assert len(parts) > 1
+    for k, t in enumerate(whole):
+        assert torch.equal(t, torch.cat([p[k] for p in parts]))

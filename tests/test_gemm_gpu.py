@@ -12,9 +12,9 @@ def _flat_launches_only():
     """These tests pin the planned FLAT launches (tile shapes, tail split, kernel families bit for bit); msn_sgemm's own
     detour through the work-list kernel (long-K under-filled products, tests/test_gemm_list_gpu.py) is switched off here."""
     from multimodal_supernovae_amd import ops
-    ops.set_gemm_streamk(0, 0)
+    ops.set_gemm_list(2)
     yield
-    ops.set_gemm_streamk()
+    ops.set_gemm_list(1)
 
 
 def _ref(a, b, op_a, op_b):

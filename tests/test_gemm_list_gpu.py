@@ -22,9 +22,9 @@ def _rel(x, ref):
 @pytest.fixture
 def streamk():
     from multimodal_supernovae_amd import ops
-    ops.set_gemm_streamk(1 << 20, 32)
+    ops.set_gemm_list(3)
     yield ops
-    ops.set_gemm_streamk()
+    ops.set_gemm_list(1)
 
 
 @pytest.mark.parametrize("M,N,K", [(8320, 384, 384), (8320, 1152, 384), (8320, 384, 1536), (1000, 384, 384), (200, 130, 64),
@@ -42,7 +42,7 @@ def test_single_product_through_msn_sgemm(streamk, M, N, K, ob):
     assert _rel(out, ref) < 2e-6
     again = ops.sgemm(a, b, 0, ob)
     assert torch.equal(out, again)                      # no dependence on arrival order
-    ops.set_gemm_streamk(0, 0)
+    ops.set_gemm_list(2)
     flat = ops.sgemm(a, b, 0, ob)
     torch.testing.assert_close(out, flat, rtol=1e-4, atol=1e-3)
 
@@ -158,7 +158,7 @@ def test_vit_block_backward_with_paired_launches(mode):
     cot = torch.randn(B, T, e, device="cuda")
 
     def grads(pair):
-        old, F.PAIR_BACKWARD = F.PAIR_BACKWARD, str(pair)
+        old, F.PAIR_BACKWARD = F.PAIR_BACKWARD, pair
         try:
             out = F.pre_norm_block(x, heads, P)
             return torch.autograd.grad(out, [x] + P, cot)

@@ -51,13 +51,8 @@ def test_nt_exact_on_integers(M, N, K, planes):
     bias = torch.randint(-3, 4, (N,), generator=g).float()
     ref = a.double() @ w.double().T + bias.double()
     ap, wp = ops.plane_split(a.cuda(), planes), ops.plane_split(w.cuda(), planes)
-    for bn in (0, 128):
-        ops.set_pgemm_tile_n(bn)
-        try:
-            c = ops.pgemm_nt(ap, wp, bias=bias.cuda())
-        finally:
-            ops.set_pgemm_tile_n(0)
-        assert c.dtype == torch.float32 and torch.equal(c.cpu().double(), ref), f"tile width {bn}"
+    c = ops.pgemm_nt(ap, wp, bias=bias.cuda())
+    assert c.dtype == torch.float32 and torch.equal(c.cpu().double(), ref)
     # the operand of the dgrad products: planes of the transposed weight
     wt = ops.plane_split(w.T.contiguous().cuda(), planes, transposed=True)
     assert torch.equal(ops.pgemm_nt(ap, wt).cpu().double(), a.double() @ w.double().T)
@@ -291,26 +286,6 @@ def test_fp32_grade_gate_step_operands():
     assert not bad, bad
 
 
-@pytest.mark.parametrize("variant", [0, 2])
-@pytest.mark.parametrize("M,N,K", [(300, 272, 200), (4096, 1536, 384), (777, 384, 1536)])
-def test_nt_wave_layouts_exact_on_integers(M, N, K, variant):
-    """The alternative wave layouts / staggered DMA issue of the 3-plane kernel (msn_set_pgemm_variant)."""
-    from multimodal_supernovae_amd import ops
-    g = torch.Generator().manual_seed(M + N + K)
-    a, w = _ints((M, K), g), _ints((N, K), g)
-    bias = torch.randint(-3, 4, (N,), generator=g).float()
-    ref = a.double() @ w.double().T + bias.double()
-    ap, wp = ops.plane_split(a.cuda(), 3), ops.plane_split(w.cuda(), 3)
-    ops.set_pgemm_variant(variant)
-    try:
-        c = ops.pgemm_nt(ap, wp, bias=bias.cuda())
-        cp, cs = ops.pgemm_nt(ap, wp, bias=bias.cuda(), out_planes=True, want_colsum=True)
-    finally:
-        ops.set_pgemm_variant(1)
-    assert torch.equal(c.cpu().double(), ref)
-    assert torch.equal(cp.to_float().cpu().double(), ref) and torch.equal(cs.cpu().double(), ref.sum(0))
-
-
 @pytest.mark.parametrize("M,N,K", [(66560, 384, 768), (33280, 384, 1536), (20000, 1152, 1152), (66560, 384, 1152),
                                    (8320, 384, 1536), (8320, 384, 384), (16640, 384, 768), (8000, 1152, 384)])
 def test_nt_tail_split(M, N, K):
@@ -335,28 +310,6 @@ def test_nt_tail_split(M, N, K):
     finally:
         ops.set_pgemm_tail_split(True)
     torch.testing.assert_close(c1, c0, rtol=1e-5, atol=1e-4)
-
-
-@pytest.mark.parametrize("col_group,super_rows", [(1, 0), (2, 1), (5, 3), (6, 8), (0, 5), (64, 64)])
-@pytest.mark.parametrize("M,N,K", [(20000, 1536, 384), (33280, 384, 1536), (9000, 1152, 64), (700, 1408, 96)])
-def test_nt_tile_walks_cover_the_grid_exactly_once(M, N, K, col_group, super_rows):
-    """The tile walk of the NT kernel (msn_set_pgemm_walk: column groups, super-rows) is a bijection of the tile grid whatever its
-    parameters -- groups that do not divide the tile columns, super-rows that do not divide the tile rows, a tail split on top
-    (33280 x 384 x 1536 cuts its last round into K-segments; its finishing launch uses the same map): exact on integers."""
-    from multimodal_supernovae_amd import ops
-    g = torch.Generator().manual_seed(M + N + col_group)
-    a, w = _ints((M, K), g, -2, 3).cuda(), _ints((N, K), g, -2, 3).cuda()
-    bias = torch.randint(-3, 4, (N,), generator=g).float().cuda()
-    ap, wp = ops.plane_split(a, 3), ops.plane_split(w, 3)
-    ref = a.double() @ w.double().T + bias.double()
-    ops.set_pgemm_walk(col_group, super_rows)
-    try:
-        c = ops.pgemm_nt(ap, wp, bias=bias)
-        cp, cs = ops.pgemm_nt(ap, wp, bias=bias, out_planes=True, want_colsum=True)
-    finally:
-        ops.set_pgemm_walk(0, 0)
-    assert torch.equal(c.double(), ref)
-    assert torch.equal(cp.to_float().double(), ref) and torch.equal(cs.double(), ref.sum(0))
 
 
 @pytest.mark.parametrize("M,N,K", [(66560, 384, 384), (66560, 1536, 384), (40000, 384, 1536)])

@@ -23,9 +23,6 @@ def timed(fn, reps=20):
 
 def main():
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 512 * 197
-    if os.environ.get("BGEMM_PERSISTENT"):
-        from multimodal_supernovae_amd import _lib
-        _lib.check(_lib.lib().msn_set_bgemm_persistent(int(os.environ["BGEMM_PERSISTENT"])))
     g = torch.Generator(device="cuda").manual_seed(0)
     rnd = lambda *s: (torch.randn(*s, device="cuda", generator=g) * 0.3).to(torch.bfloat16)
     for name, N, K in [("qkv   fwd", 2304, 768), ("proj  fwd", 768, 768), ("fc1   fwd", 3072, 768), ("fc2   fwd", 768, 3072),

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Work-list (stream-K) launches against the planned flat launches on the headline's ViT-S/8 shapes:
-forward / dgrad products one at a time (msn_set_gemm_streamk) and the backward pair of every Linear (ops.dgrad_wgrad
+forward / dgrad products one at a time (msn_set_gemm_list 2 / 3) and the backward pair of every Linear (ops.dgrad_wgrad
 against msn_sgemm + msn_wgrad_bias)."""
 import os
 import sys
@@ -31,11 +31,11 @@ for B in batches:
         a = torch.randn(M, K, device="cuda")
         b = torch.randn((K, N) if ob == 0 else (N, K), device="cuda")
         out = torch.empty(M, N, device="cuda")
-        ops.set_gemm_streamk(0, 0)
+        ops.set_gemm_list(2)
         t0 = timeit(lambda: ops.sgemm(a, b, 0, ob, out=out))
-        ops.set_gemm_streamk(1 << 20, 32)
+        ops.set_gemm_list(3)
         t1 = timeit(lambda: ops.sgemm(a, b, 0, ob, out=out))
-        ops.set_gemm_streamk()
+        ops.set_gemm_list(1)
         tot[0] += t0
         tot[1] += t1
         print(f"B={B:4d} {tag:10s} M={M:6d} N={N:5d} K={K:5d}  flat {t0:7.1f} us ({2.0 * M * N * K / t0 / 1e6:6.1f} TF)  "

@@ -25,9 +25,8 @@ def timed(fn, reps=10):
 def main():
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 1024 * 65
     planes_list = [int(v) for v in os.environ.get("PLANES", "3,2").split(",")]
-    if os.environ.get("SKEW"):
-        from multimodal_supernovae_amd import _lib
-        _lib.check(_lib.lib().msn_set_pgemm_skew(int(os.environ["SKEW"])))
+    if os.environ.get("TAIL") == "0":           # the tiles of the last, partly filled round multiplied whole
+        ops.set_pgemm_tail_split(False)
     g = torch.Generator(device="cuda").manual_seed(0)
     rnd = lambda *s: torch.randn(*s, device="cuda", generator=g) * 0.3
     shapes = [("qkv   fwd", 1152, 384), ("proj  fwd", 384, 384), ("fc1   fwd", 1536, 384), ("fc2   fwd", 384, 1536),
@@ -41,11 +40,8 @@ def main():
             ap, wp = ops.plane_split(a, pl), ops.plane_split(w, pl)
             ts = timed(lambda: ops.plane_split(a, pl))
             if pl == 3:
-                for v in [int(x) for x in os.environ.get("PG_VARIANTS", "1").split(",")]:
-                    ops.set_pgemm_variant(v)
-                    t = timed(lambda: ops.pgemm_nt(ap, wp))
-                    line += f" | 3pl v{v} {fl / t / 1e12:6.1f} ({t * 1e6:6.0f} us)"
-                ops.set_pgemm_variant(1)
+                t = timed(lambda: ops.pgemm_nt(ap, wp))
+                line += f" | 3pl {fl / t / 1e12:6.1f} ({t * 1e6:6.0f} us)"
             else:
                 t = timed(lambda: ops.pgemm_nt(ap, wp))
                 line += f" | {'f16 2' if pl == ops.F16_PLANES else pl}pl {fl / t / 1e12:6.1f} ({t * 1e6:6.0f} us)"

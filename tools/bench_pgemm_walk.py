@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Tile walk of the plane NT kernel (msn_set_pgemm_walk: column groups x super-rows) on the headline shapes: us per launch, HIP
-events, warm clocks, configurations interleaved in one process (boxes differ by up to 7 %).
+"""The plane NT kernel on the headline shapes in its output forms, ONE shape per process: us per launch, HIP events (the bench of
+the round-6 diagnostic builds -- tools/microbench/build_ablate.sh PG_* through MSN_HIP_LIB -- and of tools/pmc_walk.sh's FETCH_SIZE /
+WRITE_SIZE passes; the two numeric arguments were the tile walk's column group and super-rows while msn_set_pgemm_walk existed:
+commit 03e790c, profiles/r06_experiments_tried.txt item 1 -- they are ignored now).
 
-    python tools/bench_pgemm_walk.py                       # sweep, every shape
-    python tools/bench_pgemm_walk.py --one fc1g 6 3 40     # ONE configuration, 40 launches (for rocprofv3 --pmc FETCH_SIZE passes)
-MSN_HIP_LIB=tools/microbench/ablate/libmsn_PG_ANT.so runs the same sweep on the build whose A pieces carry the nt cache policy."""
+    python tools/bench_pgemm_walk.py --one fc1g 0 0 40     # 40 launches of fc1 with GELU and plane output"""
 import os
 import sys
 
@@ -45,39 +45,16 @@ def timed(fn, reps):
 
 
 def main():
-    if os.environ.get("SKEW"):                  # start skew of the workgroups (msn_set_pgemm_skew, shader cycles per phase)
-        from multimodal_supernovae_amd import _lib
-        _lib.check(_lib.lib().msn_set_pgemm_skew(int(os.environ["SKEW"])))
     if len(sys.argv) > 1 and sys.argv[1] == "--one":
         name, cg, sr, reps = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
         fn = make(name)
-        ops.set_pgemm_walk(cg, sr)
         print(f"{name} cg {cg} sr {sr}: {timed(fn, reps):.1f} us", flush=True)
         return
-    names = sys.argv[1:] or list(SHAPES)
-    print("lib:", os.environ.get("MSN_HIP_LIB", "default"), flush=True)
-    for name in names:
-        N, K, _ = SHAPES[name]
-        tn = (N + 127) // 128
+    for name in sys.argv[1:] or list(SHAPES):
         fn = make(name)
-        cgs = sorted({0} | {c for c in (2, 3, 4, 6) if c < tn})
-        srs = [0, 1, 2, 4, 8] if K <= 384 else [0, 2]
-        cfgs = [(c, s) for c in cgs for s in srs]
         for _ in range(10):
             fn()
-        best = {c: [] for c in cfgs}
-        for rnd_ in range(3):
-            for c in cfgs:
-                ops.set_pgemm_walk(*c)
-                fn()
-                best[c].append(timed(fn, 12))
-        ops.set_pgemm_walk(0, 0)
-        base = min(best[(0, 0)])
-        line = f"{name:6s} N={N:4d} K={K:4d} default {base:6.1f} us |"
-        for c in cfgs[1:]:
-            t = min(best[c])
-            line += f" cg{c[0]}/sr{c[1]} {t:6.1f} ({(t / base - 1) * 100:+.1f}%)"
-        print(line, flush=True)
+        print(f"{name}: {min(timed(fn, 12) for _ in range(3)):.1f} us", flush=True)
 
 
 if __name__ == "__main__":

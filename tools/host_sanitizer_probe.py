@@ -28,7 +28,7 @@ for i, (oa, ob, M, N, K) in enumerate([(0, 0, 8320, 384, 1536), (1, 0, 1536, 384
 print("list ws", L.msn_sgemm_list_workspace_bytes(2, ctypes.cast(d, ctypes.c_void_p)))
 print(L.msn_conv2d_workspace_bytes(8, 64, 64, 64, 128, 3, 3, 1, 1, 1, 1), L.msn_conv2d_implicit_ok(8, 64, 64, 64, 128, 3, 3, 1, 1, 1, 1))
 print(L.msn_infonce_workspace_bytes(128, 128, 1024, 1024, 128), L.msn_wgrad_bias_workspace_bytes(64, 256, 204800))
-for bad in (lambda: L.msn_set_gemm_streamk(-1, 0), lambda: L.msn_set_gemm_lds_pad(1 << 30), lambda: L.msn_set_attention_path(7),
+for bad in (lambda: L.msn_set_gemm_list(7), lambda: L.msn_set_gemm_tile_n(96), lambda: L.msn_set_attention_path(7),
             lambda: L.msn_sgemm_list(0, None, 0, None, 0, None), lambda: L.msn_sgemm_list(4, ctypes.cast(d, ctypes.c_void_p), 0, None, 0, None)):
     assert bad() == 1, L.msn_last_error()
 # plane GEMMs (pgemm.hip): sizes, launch plans and the argument checks that return before a launch
@@ -55,7 +55,8 @@ for bad in (lambda: L.msn_plane_split(None, 4, 4, 4, 3, 0, None, None, None, 0, 
             lambda: L.msn_pgemm_nt_f16(256, 128, 64, fake, None, fake, fake, fake, 128, None, 0, None, 0, None, None, 0, None),
             lambda: L.msn_pgemm_tn_f16(256, 128, 64, fake, fake, fake, None, fake, 64, None, 0, None),
             lambda: L.msn_plane_split_list(0, None, 3, None),
-            lambda: L.msn_set_pgemm_tile_n(256), lambda: L.msn_set_pgemm_variant(9), lambda: L.msn_set_attention_planes(64),
+            lambda: L.msn_set_attention_planes(2), lambda: L.msn_set_attention_planes(64),
+            lambda: L.msn_pgemm_nt(256, 128, 1 << 19, 3, fake, fake, fake, 128, 0, None, 0, None, 0, None, None, 0, None),
             lambda: L.msn_pgemm_nt(256, 128, 64, 3, fake, fake, fake, 1 << 20, 0, None, 0, None, 0, None, None, 0, None),
             lambda: L.msn_layernorm_fwd_planes(fake, 384, 8, 384, fake, fake, 1e-6, 5, fake, None, 0, fake, fake, None)):
     assert bad() == 1, L.msn_last_error()

@@ -1,17 +1,18 @@
 #!/bin/bash
 # ISA lint of every translation unit with hand-counted LDS waits: hipcc -S (device only, in parallel) + tools/check_fragment_waits.py,
-# and the scratch check of the plane GEMM kernels (tools/check_scratch.py on the resource-usage remarks of the same compilations).
-# No GPU needed; about 3 minutes on 8 cores.   bash tools/lint_kernels.sh
+# and the scratch check (tools/check_scratch.py on the resource-usage remarks of the same compilations): no register spills to memory
+# in any plane GEMM kernel and in ANY attention kernel (vector-ALU attn_*, fp32 matrix-core mattn_*, plane pattn_*, bf16 battn_*).
+# No GPU needed; about 4 minutes on 8 cores.   bash tools/lint_kernels.sh
 set -o pipefail
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${TMPDIR:-/tmp}/msn_lint
 mkdir -p "$OUT"
-FILES="gemm gemm_list gemm_pw gemm_bf16 gemm_bf16res attention_bf16 attention_planes pgemm pgemm_alt1 pgemm_alt2"
+FILES="gemm gemm_list gemm_pw gemm_bf16 gemm_bf16res attention_bf16 attention_planes attention_mfma attention pgemm pgemm_alt2"
 pids=()
 for f in $FILES; do
   rm -f "$OUT/$f.s" "$OUT/$f.err" "$OUT/$f.rc"          # never lint a stale listing
   [ -f "$ROOT/multimodal_supernovae_amd/csrc/$f.hip" ] || continue
-  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Rpass-analysis=kernel-resource-usage -S --cuda-device-only "$ROOT/multimodal_supernovae_amd/csrc/$f.hip" -o "$OUT/$f.s" 2> "$OUT/$f.err"; echo $? > "$OUT/$f.rc" ) &
+  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=fast -Rpass-analysis=kernel-resource-usage -S --cuda-device-only "$ROOT/multimodal_supernovae_amd/csrc/$f.hip" -o "$OUT/$f.s" 2> "$OUT/$f.err"; echo $? > "$OUT/$f.rc" ) &
 done
 wait
 rc=0
@@ -22,6 +23,7 @@ for f in $FILES; do
   fi
   python3 "$ROOT/tools/check_fragment_waits.py" "$OUT/$f.s" | tail -n 8 || rc=1
 done
-# no register spills to memory in any plane GEMM kernel or plane attention kernel (remarks of the same compilations)
-python3 "$ROOT/tools/check_scratch.py" "$OUT"/pgemm.err "$OUT"/pgemm_alt1.err "$OUT"/pgemm_alt2.err -- pgemm_nt_kernel pgemm_tn_kernel || rc=1
+# no register spills to memory in any plane GEMM kernel or attention kernel (remarks of the same compilations)
+python3 "$ROOT/tools/check_scratch.py" "$OUT"/pgemm.err "$OUT"/pgemm_alt2.err -- pgemm_nt_kernel pgemm_tn_kernel | tail -n 1 || rc=1
+python3 "$ROOT/tools/check_scratch.py" "$OUT"/attention_planes.err "$OUT"/attention_mfma.err "$OUT"/attention.err "$OUT"/attention_bf16.err -- attn_ | tail -n 1 || rc=1
 exit $rc
