@@ -522,6 +522,9 @@ def main():
     # output / residual in the backward and residual-add epilogues)
     gemm_bytes = sum(e[5] if len(e) > 5 else 4.0 * (e[3][2] * e[3][4] + e[3][4] * e[3][3] + e[3][2] * e[3][3] * (2 if e[4] else 1))
                      for e in prof)
+    # the same launches with EVERY element at 4 bytes (SURVEY 8d's algorithmic bytes of an fp32 path: what `traffic` is scored against;
+    # the plane-format count above is what the launches must move at the least as built)
+    gemm_bytes_fp32 = sum(4.0 * (e[3][2] * e[3][4] + e[3][4] * e[3][3] + e[3][2] * e[3][3] * (2 if e[4] else 1)) for e in prof)
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     algorithmic_tflops = achieved
     if products:
@@ -537,6 +540,24 @@ def main():
         peak = 2500.0           # the image tower of cfg5 issues bf16 MFMAs whatever the process default is
         kernel_name = ("msn::bgemm_nt_kernel + msn::bgemm_tn_kernel (bf16-resident operands, 256x256 tiles, LDS-DMA, "
                        "v_mfma_f32_16x16x32_bf16; the image tower's launches -- the light-curve tower's fp32 products: fp32_launches)")
+
+    # ---- the shader clock the chip holds under this step's load (boxes of the pool differ by up to 7 % on the matrix-core-dense
+    # kernels and the clock falls as the matrix pipe fills): a one-wave probe on a side stream stamps the shader-cycle and the 100-MHz
+    # real-time counters ~one step apart while a step runs on the main stream (msn_clock_probe)
+    shader_clock_ghz = None
+    if world == 1:
+        try:
+            probe_out = torch.zeros(2, dtype=torch.int64, device=device)
+            side = torch.cuda.Stream(device=device)
+            step_us = max(2000, int(dt / args.steps * 1e6 * 0.8))
+            torch.cuda.synchronize()
+            _lib.check(_lib.lib().msn_clock_probe(probe_out.data_ptr(), step_us, side.cuda_stream), "msn_clock_probe")
+            step()
+            torch.cuda.synchronize()
+            cyc, ticks = (int(v) for v in probe_out.tolist())
+            shader_clock_ghz = cyc / ticks * 0.1 if ticks > 0 else None
+        except Exception as exc:       # a measurement beside the metric: never fails the line
+            print(f"# clock probe failed: {exc}", file=sys.stderr)
 
     # ---- per-tower split (serial order, HIP events): what each tower costs alone, and the serial step next to the
     # concurrent one, so the gain of running the towers on separate streams can be read off the JSON
@@ -689,11 +710,18 @@ def main():
                          "traffic_source": traffic_source,
                          "launches_per_step": len(prof), "ms_per_step_in_kernel": gemm_ms,
                          "algorithmic_gflop_per_step": gemm_flops / 1e9,
-                         "algorithmic_bytes_per_launch": gemm_bytes / max(len(prof), 1),
+                         "algorithmic_bytes_per_launch": gemm_bytes_fp32 / max(len(prof), 1),
+                         "algorithmic_bytes_is": "operands + result (+ the aux matrix an epilogue reads or writes) of the launches at 4 bytes per element",
+                         "traffic_over_algorithmic": (traffic / (gemm_bytes_fp32 / max(len(prof), 1))) if traffic else None,
+                         **({"algorithmic_bytes_per_launch_plane_format": gemm_bytes / max(len(prof), 1),
+                             "traffic_over_plane_format_bytes": (traffic / (gemm_bytes / max(len(prof), 1))) if traffic else None}
+                            if products else {}),
+                         "shader_clock_ghz": shader_clock_ghz,
+                         "shader_clock_is": "d s_memtime / d s_memrealtime x 100 MHz of a one-wave probe on a side stream beside one training step (nominal 2.4)",
                          **({"mfma_products_per_multiply_add": products, "algorithmic_tflops": algorithmic_tflops,
                              "note": "achieved / peak count EXECUTED bf16 MFMA flops (products x algorithmic); "
-                                     "algorithmic_tflops is the fp32-equivalent rate of the same launches; algorithmic_bytes_per_launch counts "
-                                     "plane operands / plane results at their HBM format (2 bytes x planes per element), fp32 matrices at 4"} if products else {}),
+                                     "algorithmic_tflops is the fp32-equivalent rate of the same launches; algorithmic_bytes_per_launch_plane_format "
+                                     "counts plane operands / plane results at their HBM format (2 bytes x planes per element), fp32 matrices at 4"} if products else {}),
                          **({"fp32_launches": fp32_side} if fp32_side is not None else {}),
                          **({"attention": attention} if attention is not None else {})},
             "comm": comm,
@@ -709,6 +737,8 @@ def main():
             out["towers"] = towers
         if alt is not None:
             out["alt_arithmetic"] = alt
+            if "f32" in alt:       # box-independent figure of merit: the default arithmetic's step over the native-fp32 step of the SAME run
+                out["headline_over_native_fp32"] = ms / alt["f32"]["ms_per_step"]
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_batch, args.cpu_steps)
         elif world == 1:

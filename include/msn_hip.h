@@ -37,6 +37,10 @@ typedef void* msn_stream_t; /* hipStream_t */
 
 int msn_version(void);
 const char* msn_last_error(void);
+/* Measurement: one wave that stamps the shader-cycle and the 100-MHz real-time counters `microseconds` apart on `stream`:
+ * out2[0] = shader cycles, out2[1] = real-time ticks (device memory) -> the clock the chip holds while whatever else runs meanwhile
+ * (bench.py launches it on a side stream beside a training step: roofline.shader_clock_ghz). */
+int msn_clock_probe(unsigned long long* out2, int microseconds, msn_stream_t stream);
 /* number of visible HIP devices, or -1 when the HIP runtime cannot be initialised */
 int msn_device_count(void);
 
