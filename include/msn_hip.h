@@ -362,6 +362,25 @@ int msn_pgemm_tn_f16(int64_t M, int N, int K, const void* A, const float* scaleA
                      int64_t ldc, void* ws, size_t ws_bytes, msn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The feed-forward half of the reference's TransformerBlock for the NARROW towers -- z = x + Linear(4e -> e)(ReLU(Linear(e -> 4e)(x))),
+ * ref src/transformer_utils.py:102-106, 114; emb 32 / hidden 128 (the spectrum transformer) -- as ONE kernel per direction whose
+ * 4e-wide hidden activations never reach HBM (csrc/ffn_planes.hip): fp32-grade arithmetic on the bf16 matrix cores (three planes per
+ * operand, six products, as msn_pgemm_*), both weights resident in LDS as the plane matrices msn_plane_split writes:
+ *   w1_planes  = planes of ff.0.weight [4e][e];  w2t_planes = planes of ff.2.weight TRANSPOSED [4e][e] (msn_plane_split, transposed = 1).
+ *   msn_ffn_fwd:  z[M][e] = x + relu(x W1^T + c1) W2^T + c2.
+ *   msn_ffn_bwd:  dx = dz + ((dz W2) o (pre > 0)) W1 (the hidden tile is RECOMPUTED with the forward's instructions: the same bits, no
+ *                 mask is stored), dw1 [4e][e], dc1 [4e], dw2 [e][4e], dc2 [e] (per-workgroup partials in ws, summed in a fixed order
+ *                 by a finishing launch: deterministic); ws >= msn_ffn_bwd_workspace_bytes.
+ * msn_ffn_supported(M, emb, hidden): the shapes this build takes (emb 32, hidden 128); every other block keeps msn_sgemm. */
+int msn_ffn_supported(int64_t M, int emb, int hidden);
+int msn_ffn_fwd(const float* x, int64_t ldx, int64_t M, int emb, int hidden, const void* w1_planes, const void* w2t_planes,
+                const float* c1, const float* c2, float* z, int64_t ldz, msn_stream_t stream);
+size_t msn_ffn_bwd_workspace_bytes(int64_t M, int emb, int hidden);
+int msn_ffn_bwd(const float* x, int64_t ldx, const float* dz, int64_t lddz, int64_t M, int emb, int hidden, const void* w1_planes,
+                const void* w2t_planes, const float* c1, float* dx, int64_t lddx, float* dw1, float* dc1, float* dw2, float* dc2,
+                void* ws, size_t ws_bytes, msn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * bf16-RESIDENT products for BASELINE.json configs[4] (ViT-B/16 "bf16 on MFMA"; build-defined encoder, no reference
  * counterpart -- the reference has no mixed precision): operands are bf16 in HBM (uint16 bit patterns), accumulation fp32.
  *   msn_bgemm_nt:  C[M][N] = epi(A[M][K] . B[N][K]^T + bias); K % 64 == 0, N % 4 == 0, 16-byte aligned rows.

@@ -23,6 +23,11 @@ SIGNATURES = {
     "msn_version": (c_int, []),
     "msn_last_error": (ctypes.c_char_p, []),
     "msn_clock_probe": (c_int, [c_ptr, c_int, c_ptr]),
+    "msn_ffn_supported": (c_int, [c_i64, c_int, c_int]),
+    "msn_ffn_fwd": (c_int, [c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
+    "msn_ffn_bwd_workspace_bytes": (c_size, [c_i64, c_int, c_int]),
+    "msn_ffn_bwd": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr,
+                            c_ptr, c_ptr, c_size, c_ptr]),
     "msn_device_count": (c_int, []),
     "msn_sgemm_workspace_bytes": (c_size, [c_int, c_int, c_i64, c_i64, c_i64]),
     "msn_sgemm": (c_int, [c_int, c_int, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr,

@@ -247,6 +247,9 @@ def self_attention(x, mask, heads, tokeys, toqueries, tovalues, unify_w, unify_b
 
 
 # ---------------------------------------------------------------- post-norm transformer block
+FUSED_FF = True       # False (tests, A/B runs): the feed-forward half as four msn_sgemm products with the hidden matrix in memory
+
+
 @_remember_precision
 class _PostNormBlock(torch.autograd.Function):
     """ref transformer_utils.py:109-116: x = LN1(attn(x) + x); x = LN2(FF(x) + x), FF = Linear ->
@@ -264,30 +267,43 @@ class _PostNormBlock(torch.autograd.Function):
         if drop_p > 0.0:                 # x = do(norm1(...)) / x = do(norm2(...)), ref :111-116
             seeds = (ops.new_seed(), ops.new_seed())
             ops.dropout(y1, drop_p, seeds[0], out=y1)
-        hdn = sgemm(y1, w1, OP_N, OP_T, bias=c1, epilogue=EPI_RELU)
-        z2 = sgemm(hdn, w2, OP_N, OP_T, bias=c2, epilogue=EPI_ADD, aux=y1)
+        # the feed-forward half: one kernel per direction whose 4e-wide hidden matrix stays on chip where the fused kernels take the
+        # width (emb 32: the spectrum transformer) and the process arithmetic is the plane one they compute in (csrc/ffn_planes.hip)
+        fused_ff = FUSED_FF and ops.plane_count() == 3 and ops.ffn_supported(B * T, e, w1.shape[0])
+        if fused_ff:
+            w1p, w2tp = ops.ffn_weight_planes(w1, w2)
+            z2 = ops.ffn_fwd(y1, w1p, w2tp, c1, c2)
+            hdn = y1.new_empty(0)
+            ctx.ff_planes = (w1p, w2tp)
+        else:
+            hdn = sgemm(y1, w1, OP_N, OP_T, bias=c1, epilogue=EPI_RELU)
+            z2 = sgemm(hdn, w2, OP_N, OP_T, bias=c2, epilogue=EPI_ADD, aux=y1)
+            ctx.ff_planes = None
         y2, m2, r2 = ops.layernorm_fwd(z2, g2, b2)
         if seeds:
             ops.dropout(y2, drop_p, seeds[1], out=y2)
         ctx.drop = (drop_p, seeds)
         ctx.dims = (B, T, e, heads, scale)
         ctx.mask = mask_u8
-        ctx.save_for_backward(x2, wq, wk, wv, wu, g1, w1, w2, g2, qkv, a2, lse, z1, m1, r1, y1, hdn, z2, m2, r2, wcat)
+        ctx.save_for_backward(x2, wq, wk, wv, wu, g1, w1, w2, g2, qkv, a2, lse, z1, m1, r1, y1, hdn, z2, m2, r2, wcat, c1)
         return y2.view(B, T, e)
 
     @staticmethod
     def backward(ctx, dy):
         B, T, e, heads, scale = ctx.dims
-        (x2, wq, wk, wv, wu, g1, w1, w2, g2, qkv, a2, lse, z1, m1, r1, y1, hdn, z2, m2, r2, wcat) = ctx.saved_tensors
+        (x2, wq, wk, wv, wu, g1, w1, w2, g2, qkv, a2, lse, z1, m1, r1, y1, hdn, z2, m2, r2, wcat, c1) = ctx.saved_tensors
         dy2 = _c(dy).view(B * T, e)
         drop_p, seeds = ctx.drop
         if seeds:
             dy2 = ops.dropout(dy2, drop_p, seeds[1])
         dz2, dg2, db2 = ops.layernorm_bwd(dy2, z2, m2, r2, g2)
-        dw2, dc2 = ops.wgrad_bias(dz2, hdn)
-        dpre = sgemm(dz2, w2, OP_N, OP_N, epilogue=EPI_RELU_BWD, aux=hdn)
-        dw1, dc1 = ops.wgrad_bias(dpre, y1)
-        dy1 = sgemm(dpre, w1, OP_N, OP_N, epilogue=EPI_ADD, aux=dz2)       # + residual branch of LN2's input
+        if ctx.ff_planes is not None:     # hidden tile recomputed on chip; dy1 comes with the residual branch of LN2's input added
+            dy1, dw1, dc1, dw2, dc2 = ops.ffn_bwd(y1, dz2, ctx.ff_planes[0], ctx.ff_planes[1], c1)
+        else:
+            dw2, dc2 = ops.wgrad_bias(dz2, hdn)
+            dpre = sgemm(dz2, w2, OP_N, OP_N, epilogue=EPI_RELU_BWD, aux=hdn)
+            dw1, dc1 = ops.wgrad_bias(dpre, y1)
+            dy1 = sgemm(dpre, w1, OP_N, OP_N, epilogue=EPI_ADD, aux=dz2)   # + residual branch of LN2's input
         if seeds:
             ops.dropout(dy1, drop_p, seeds[0], out=dy1)
         dz1, dg1, db1 = ops.layernorm_bwd(dy1, z1, m1, r1, g1)

@@ -1017,6 +1017,45 @@ def plane_split(x, planes=None, transposed=False, want_colsum=False, scale_of=No
     return (out, cs) if want_colsum else out
 
 
+# ----------------------------------------------------------------------------------------- fused feed-forward (narrow towers)
+def ffn_supported(M, emb, hidden):
+    """Shapes msn_ffn_fwd / _bwd take (emb 32, hidden 128: the reference's spectrum transformer)."""
+    return bool(lib().msn_ffn_supported(int(M), int(emb), int(hidden)))
+
+
+def ffn_weight_planes(w1, w2):
+    """The two operands msn_ffn_* keep in LDS: planes of ff.0.weight (4e, e) and of ff.2.weight (e, 4e) transposed -- one launch."""
+    w1p, w2tp = plane_split_list([w1, w2], 3, transposed=[False, True])
+    return w1p, w2tp
+
+
+def ffn_fwd(x, w1p, w2tp, c1, c2):
+    """z = x + relu(x W1^T + c1) W2^T + c2 without the hidden matrix in memory (msn_ffn_fwd).  x: (M, e) fp32, rows ld apart."""
+    _f32c(x, "x")
+    M, e = x.shape
+    z = torch.empty((M, e), dtype=torch.float32, device=x.device)
+    check(lib().msn_ffn_fwd(ptr(x), x.stride(0), M, e, c1.numel(), ptr(w1p.buf), ptr(w2tp.buf), ptr(_f32c(c1, "c1")), ptr(_f32c(c2, "c2")),
+                            ptr(z), e, stream_ptr()), "msn_ffn_fwd")
+    return z
+
+
+def ffn_bwd(x, dz, w1p, w2tp, c1):
+    """-> dx = dz + ((dz W2) o relu'(x W1^T + c1)) W1, dw1, dc1, dw2, dc2 (msn_ffn_bwd: the hidden tile is recomputed on chip)."""
+    _f32c(x, "x"), _f32c(dz, "dz")
+    M, e = x.shape
+    hid = c1.numel()
+    dx = torch.empty((M, e), dtype=torch.float32, device=x.device)
+    dw1 = torch.empty((hid, e), dtype=torch.float32, device=x.device)
+    dw2 = torch.empty((e, hid), dtype=torch.float32, device=x.device)
+    dc1 = torch.empty(hid, dtype=torch.float32, device=x.device)
+    dc2 = torch.empty(e, dtype=torch.float32, device=x.device)
+    nb = lib().msn_ffn_bwd_workspace_bytes(M, e, hid)
+    ws = _workspace(nb, x.device)
+    check(lib().msn_ffn_bwd(ptr(x), x.stride(0), ptr(dz), dz.stride(0), M, e, hid, ptr(w1p.buf), ptr(w2tp.buf), ptr(_f32c(c1, "c1")),
+                            ptr(dx), e, ptr(dw1), ptr(dc1), ptr(dw2), ptr(dc2), ptr(ws), nb, stream_ptr()), "msn_ffn_bwd")
+    return dx, dw1, dc1, dw2, dc2
+
+
 def attention_bwd_planes(qkv, heads, scale, out, lse, dout, planes=None, want_colsum=True, mask_u8=None):
     """Backward of self-attention on the packed (B, T, 3 E) q | k | v matrix: the gradient dqkv as Planes (B T, 3 E) and, with
     want_colsum, its column sums -- one launch, no fp32 dqkv in memory (msn_attention_bwd_planes)."""
@@ -1090,19 +1129,20 @@ class _SplitItem(ctypes.Structure):
 
 
 def plane_split_list(mats, planes=None, transposed=False):
-    """Planes of several 2-D fp32 matrices (or of their transposes) from ONE launch (msn_plane_split_list): the weights of
-    every block of a tower."""
+    """Planes of several 2-D fp32 matrices (or of their transposes; `transposed` may be one flag per matrix) from ONE launch
+    (msn_plane_split_list): the weights of every block of a tower."""
     planes = PLANES if planes is None else planes
+    flags = list(transposed) if isinstance(transposed, (list, tuple)) else [transposed] * len(mats)
     if planes == F16_PLANES:
-        return [plane_split(m, planes, transposed=transposed) for m in mats]
+        return [plane_split(m, planes, transposed=f) for m, f in zip(mats, flags)]
     items = (_SplitItem * len(mats))()
     outs = []
-    for it, m in zip(items, mats):
+    for it, m, tr in zip(items, mats, flags):
         _f32c(m, "x")
         assert m.dim() == 2 and m.stride(1) == 1
         R, C = m.shape
-        out = Planes.empty(C, R, planes, m.device) if transposed else Planes.empty(R, C, planes, m.device)
-        it.x, it.ldx, it.R, it.C, it.transposed, it.out = m.data_ptr(), m.stride(0), R, C, 1 if transposed else 0, out.buf.data_ptr()
+        out = Planes.empty(C, R, planes, m.device) if tr else Planes.empty(R, C, planes, m.device)
+        it.x, it.ldx, it.R, it.C, it.transposed, it.out = m.data_ptr(), m.stride(0), R, C, 1 if tr else 0, out.buf.data_ptr()
         outs.append(out)
     check(lib().msn_plane_split_list(len(mats), ctypes.cast(items, ctypes.c_void_p), planes, stream_ptr()), "msn_plane_split_list")
     return outs
