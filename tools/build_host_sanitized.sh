@@ -9,9 +9,12 @@ OUT=$ROOT/multimodal_supernovae_amd/build_asan
 mkdir -p "$OUT"
 FLAGS="--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -ffp-contract=fast -fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer"
 pids=""
+# (objects are rebuilt when their source OR any header is newer; objects without a source -- a removed translation unit -- are dropped)
+NEWEST_H=$(ls -t "$ROOT"/multimodal_supernovae_amd/csrc/*.h "$ROOT"/include/msn_hip.h | head -1)
+for o in "$OUT"/*.o; do [ -f "$ROOT/multimodal_supernovae_amd/csrc/$(basename "${o%.o}").hip" ] || rm -f "$o"; done
 for f in "$ROOT"/multimodal_supernovae_amd/csrc/*.hip; do
     o=$OUT/$(basename "${f%.hip}").o
-    if [ ! -f "$o" ] || [ "$f" -nt "$o" ]; then /opt/rocm/bin/hipcc $FLAGS -c "$f" -o "$o" & pids="$pids $!"; fi
+    if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$NEWEST_H" -nt "$o" ]; then /opt/rocm/bin/hipcc $FLAGS -I"$ROOT/include" -c "$f" -o "$o" & pids="$pids $!"; fi
     if [ $(jobs -r | wc -l) -ge 6 ]; then wait -n; fi
 done
 wait

@@ -60,4 +60,14 @@ for bad in (lambda: L.msn_plane_split(None, 4, 4, 4, 3, 0, None, None, None, 0, 
             lambda: L.msn_pgemm_nt(256, 128, 64, 3, fake, fake, fake, 1 << 20, 0, None, 0, None, 0, None, None, 0, None),
             lambda: L.msn_layernorm_fwd_planes(fake, 384, 8, 384, fake, fake, 1e-6, 5, fake, None, 0, fake, fake, None)):
     assert bad() == 1, L.msn_last_error()
+# fused feed-forward of the narrow towers (ffn_planes.hip) and the clock probe: sizes and the checks that return before a launch
+print("ffn", L.msn_ffn_supported(1000, 32, 128), L.msn_ffn_supported(1000, 64, 256), L.msn_ffn_bwd_workspace_bytes(225280, 32, 128),
+      L.msn_ffn_bwd_workspace_bytes(10, 32, 128), L.msn_ffn_bwd_workspace_bytes(10, 48, 128))
+for bad in (lambda: L.msn_ffn_fwd(fake, 32, 100, 64, 256, fake, fake, fake, fake, fake, 32, None),
+            lambda: L.msn_ffn_fwd(fake, 30, 100, 32, 128, fake, fake, fake, fake, fake, 32, None),
+            lambda: L.msn_ffn_fwd(None, 32, 100, 32, 128, fake, fake, fake, fake, fake, 32, None),
+            lambda: L.msn_ffn_bwd(fake, 32, fake, 32, 100, 32, 128, fake, fake, fake, fake, 32, fake, fake, fake, fake, None, 0, None),
+            lambda: L.msn_ffn_bwd(fake, 32, fake, 32, 100, 32, 96, fake, fake, fake, fake, 32, fake, fake, fake, fake, fake, 1 << 30, None),
+            lambda: L.msn_clock_probe(None, 100, None), lambda: L.msn_clock_probe(fake, 0, None)):
+    assert bad() == 1, L.msn_last_error()
 print("HOST SANITIZER PROBE OK")
