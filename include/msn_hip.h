@@ -419,9 +419,11 @@ int msn_attention_bf16_bwd(const void* qkv, int64_t ld, const void* out, int64_t
                            bias gradient of the packed projection; colsum_ws: B x 3*H*64 floats */
 int msn_layernorm_bwd_bf16(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t rows, int cols,
                            const float* mean, const float* rstd, const float* gamma, const float* add, int64_t ldadd,
-                           float* dx, int64_t lddx, void* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum, void* ws,
-                           size_t ws_bytes, msn_stream_t stream);   /* dx_colsum (nullable): column sums of dx = the bias gradient of
-                           the Linear feeding this LayerNorm's residual add; ws >= 1.5 x msn_layernorm_bwd_workspace_bytes then */
+                           float* dx, int64_t lddx, void* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum, int dy_is_bf16,
+                           void* ws, size_t ws_bytes, msn_stream_t stream);   /* dx_colsum (nullable): column sums of dx = the bias
+                           gradient of the Linear feeding this LayerNorm's residual add; ws >= 1.5 x msn_layernorm_bwd_workspace_bytes
+                           then.  dy_is_bf16: dy points at bf16 values, lddy in bf16 elements (the input-gradient product of cfg5
+                           writes its result as bf16: half the bytes out of the GEMM epilogue and into this kernel) */
 
 /* ------------------------------------------------------------------------------------------
  * Fused multi-head attention, exact fp32, no T x T tensor in memory -- SelfAttention.forward,

@@ -94,7 +94,7 @@ SIGNATURES = {
     "msn_bcolsum": (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_size, c_ptr]),
     "msn_layernorm_fwd_bf16": (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_f32, c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
     "msn_layernorm_bwd_bf16": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr,
-                                       c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+                                       c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_size, c_ptr]),
     "msn_attention_fwd": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr,
                                   c_int, c_int, c_int, c_int, c_int, c_f32, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     "msn_attention_bwd": (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr,

@@ -48,6 +48,19 @@ __device__ __forceinline__ unsigned short f2bf_bits(float f) {
     return *reinterpret_cast<const unsigned short*>(&b);
 }
 template <int LPR>
+__device__ __forceinline__ void load_row_bf16(float4 (&v)[NCH], const unsigned short* __restrict__ p, int cols, int lr) {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c = 4 * (lr + k * LPR);
+        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < cols) {
+            const uint2 w = *reinterpret_cast<const uint2*>(p + c);
+            v[k] = make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                               __uint_as_float(w.y & 0xffff0000u));
+        }
+    }
+}
+template <int LPR>
 __device__ __forceinline__ void store_row_bf16(const float4 (&v)[NCH], unsigned short* __restrict__ p, int cols, int lr) {
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
@@ -227,6 +240,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     constexpr int RG = 256 / LPR;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [RG][2 or 3][cols]
     const int lr = threadIdx.x % LPR, rg = threadIdx.x / LPR;
+    const bool dy_bf16 = (want_dxsum & 2) != 0;   // dy holds bf16 (lddy in bf16 elements): the input-gradient product wrote it so (cfg5)
+    want_dxsum &= 1;
     const int nacc = want_dxsum ? 3 : 2;     // third accumulator: column sums of dx (the bias gradient of the Linear
                                              // that produced this LayerNorm's input through a residual add)
     float4 gm[NCH], dg[NCH], db[NCH], sx[NCH];
@@ -237,7 +252,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     for (int64_t r = (int64_t)blockIdx.x * RG + rg; r < g.rows; r += (int64_t)gridDim.x * RG) {
         float4 v[NCH], d[NCH];
         load_row<LPR>(v, x + r * ldx, g.cols, lr);
-        load_row<LPR>(d, dy + r * lddy, g.cols, lr);
+        if (dy_bf16) load_row_bf16<LPR>(d, reinterpret_cast<const unsigned short*>(dy) + r * lddy, g.cols, lr);
+        else load_row<LPR>(d, dy + r * lddy, g.cols, lr);
         const float mu = mean[r], rs = rstd[r];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -942,7 +958,7 @@ extern "C" int msn_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
 extern "C" int msn_layernorm_bwd_bf16(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t rows, int cols,
                                       const float* mean, const float* rstd, const float* gamma, const float* add,
                                       int64_t ldadd, float* dx, int64_t lddx, void* dx_bf16, float* dgamma, float* dbeta,
-                                      float* dx_colsum, void* ws, size_t ws_bytes, msn_stream_t stream) {
+                                      float* dx_colsum, int dy_is_bf16, void* ws, size_t ws_bytes, msn_stream_t stream) {
     if (int rc = check_rows("msn_layernorm_bwd_bf16", rows, cols, {lddy, ldx, lddx}, {dy, x, dx, gamma})) return rc;
     MSN_REQUIRE(mean && rstd && dgamma && dbeta && dx_bf16 && (reinterpret_cast<uintptr_t>(dx_bf16) & 7) == 0,
                 "msn_layernorm_bwd_bf16: null pointer");
@@ -957,7 +973,7 @@ extern "C" int msn_layernorm_bwd_bf16(const float* dy, int64_t lddy, const float
     float* part = static_cast<float*>(ws);
     const size_t lds = sizeof(float) * nacc * (size_t)cols * (256 / lpr);
     MSN_LPR_DISPATCH(ln_bwd_kernel, lpr, dim3(grid), lds, st, dy, lddy, x, ldx, g, mean, rstd, gamma, dx, lddx, part, add, ldadd,
-                     static_cast<unsigned short*>(dx_bf16), dx_colsum ? 1 : 0, PlaneOut{nullptr, 0, 0, 0})
+                     static_cast<unsigned short*>(dx_bf16), (dx_colsum ? 1 : 0) | (dy_is_bf16 ? 2 : 0), PlaneOut{nullptr, 0, 0, 0})
     MSN_LAUNCH_CHECK();
     hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)cdiv(nacc * cols, 64)), dim3(1024), 0, st, part, grid, nacc * cols,
                        dgamma, dbeta, cols, dx_colsum);

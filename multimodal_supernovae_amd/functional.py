@@ -801,6 +801,9 @@ def pre_norm_last_block(x, heads, p, eps=1e-6):
     return _PreNormLastBlock.apply(x, heads, eps, *p)
 
 
+BF16_DGRAD = True      # bf16-resident trunk (cfg5): input gradients that feed a LayerNorm backward are written as bf16
+
+
 class _Bf16VitTrunk(torch.autograd.Function):
     """Blocks 0 .. n-1 of the build-defined pre-norm ViT as ONE node with bf16-RESIDENT GEMM operands (BASELINE cfg5:
     "ViT-B/16 bf16 on MFMA"): LayerNorm writes bf16, the GELU epilogue writes the bf16 activation and pre-activation, the
@@ -865,7 +868,9 @@ class _Bf16VitTrunk(torch.autograd.Function):
             dpre, dc1 = ops.bgemm_nt(d2b, ops.cast_bf16_t(w2), epilogue=ops.BEPI_GELU_BWD, aux=pre, out_bf16=True,
                                      want_colsum=True)
             dw1 = ops.bgemm_tn(dpre, h2)
-            dh2 = ops.bgemm_nt(dpre, ops.cast_bf16_t(w1))
+            # (the gradients entering the LayerNorm backwards leave their products as bf16 -- what autocast's dgrad gives: 155 MB less
+            #  out of each epilogue and into each LayerNorm backward at 100 864 x 768; BF16_DGRAD = False: fp32)
+            dh2 = ops.bgemm_nt(dpre, ops.cast_bf16_t(w1), out_bf16=BF16_DGRAD)
             dx1, dx1b, dg2, db2, dbo = ops.layernorm_bwd_bf16(dh2, x1, m2, r2, g2, add=d2, want_colsum=True)   # + skip
             dwo = ops.bgemm_tn(dx1b, ab)
             if battn:
@@ -880,7 +885,7 @@ class _Bf16VitTrunk(torch.autograd.Function):
                 dqkvb = ops.cast_bf16(dqkv)
                 dbqkv = colsum(dqkv)
             dwqkv = ops.bgemm_tn(dqkvb, h1)
-            dh1 = ops.bgemm_nt(dqkvb, ops.cast_bf16_t(wqkv))
+            dh1 = ops.bgemm_nt(dqkvb, ops.cast_bf16_t(wqkv), out_bf16=BF16_DGRAD)
             grads[12 * i: 12 * i + 12] = [None, None, dwqkv, dbqkv, dwo, dbo, dg2, db2, dw1, dc1, dw2, dc2]
             d2, d2b, dg1, db1, dc2 = ops.layernorm_bwd_bf16(dh1, x2, m1, r1, g1, add=dx1, want_colsum=True)   # + skip
             grads[12 * i], grads[12 * i + 1] = dg1, db1

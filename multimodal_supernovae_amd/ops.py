@@ -908,8 +908,10 @@ def layernorm_fwd_bf16(x, gamma, beta, eps=1e-5):
 
 
 def layernorm_bwd_bf16(dy, x, mean, rstd, gamma, add=None, want_colsum=False):
-    """LayerNorm backward returning (dx fp32, dx bf16 copy, dgamma, dbeta[, column sums of dx])."""
-    dy2, x2 = _rows2d(_f32c(dy, "dy")), _rows2d(x)
+    """LayerNorm backward returning (dx fp32, dx bf16 copy, dgamma, dbeta[, column sums of dx]).  dy: fp32, or bf16 as the
+    input-gradient product of the bf16-resident trunk writes it."""
+    dy_b = dy.dtype == torch.bfloat16
+    dy2, x2 = _rows2d(dy if dy_b else _f32c(dy, "dy")), _rows2d(x)
     add2 = _rows2d(add) if add is not None else None
     rows, cols = x2.shape
     dx = torch.empty((rows, cols), dtype=torch.float32, device=x.device)
@@ -922,7 +924,7 @@ def layernorm_bwd_bf16(dy, x, mean, rstd, gamma, add=None, want_colsum=False):
     ws = _workspace(nb, x.device)
     check(L.msn_layernorm_bwd_bf16(ptr(dy2), dy2.stride(0), ptr(x2), x2.stride(0), rows, cols, ptr(mean), ptr(rstd),
                                    ptr(gamma), ptr(add2), add2.stride(0) if add2 is not None else 0, ptr(dx), cols, ptr(dxb),
-                                   ptr(dg), ptr(db), ptr(cs), ptr(ws), nb, stream_ptr()), "msn_layernorm_bwd_bf16")
+                                   ptr(dg), ptr(db), ptr(cs), 1 if dy_b else 0, ptr(ws), nb, stream_ptr()), "msn_layernorm_bwd_bf16")
     return (dx, dxb, dg, db, cs) if want_colsum else (dx, dxb, dg, db)
 
 

@@ -181,12 +181,12 @@ def test_fp32_grade_gate_tn(N, K, kind, arith):
 
 
 def _report(line):
-    """Measured gate ratios -> gpurun_out/r05_pgemm_accuracy.txt (copied to profiles/ by hand)."""
+    """Measured gate ratios -> gpurun_out/r06_pgemm_accuracy.txt (copied to profiles/ by hand)."""
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     try:
         os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(root, "gpurun_out", "r05_pgemm_accuracy.txt"), "a") as f:
+        with open(os.path.join(root, "gpurun_out", "r06_pgemm_accuracy.txt"), "a") as f:
             f.write(line + "\n")
     except OSError:
         pass
