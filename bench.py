@@ -469,10 +469,22 @@ def main():
     torch.cuda.synchronize()
     ops.GEMM_PROFILE = []
     ops.ATTN_PROFILE = []
+    ops.FFN_PROFILE = []
     step()
     torch.cuda.synchronize()
     prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
     aprof, ops.ATTN_PROFILE = ops.ATTN_PROFILE, None
+    fprof, ops.FFN_PROFILE = ops.FFN_PROFILE, None
+    # the fused feed-forward launches of the narrow towers (msn_ffn_fwd / _bwd: the four Linear products of a block's feed-forward half
+    # per direction, the hidden matrix on chip) are not msn_sgemm launches: reported beside the GEMM family, in the flops of the
+    # products they replace
+    fused_ff = None
+    if fprof:
+        f_ms, f_fl = sum(e[0].elapsed_time(e[1]) for e in fprof), sum(e[2] for e in fprof)
+        fused_ff = {"launches_per_step": len(fprof), "ms_per_step_in_kernel": f_ms, "algorithmic_gflop_per_step": f_fl / 1e9,
+                    "achieved_tflops": f_fl / (f_ms * 1e-3) / 1e12 if f_ms > 0 else 0.0,
+                    "kernels": "msn::ffn_fwd_kernel / msn::ffn_bwd_kernel (+ finish): fp32-grade on v_mfma_f32_16x16x32_bf16, 6 plane products",
+                    "flop_count": "4 M e hidden forward, 8 M e hidden backward (the products of the unfused block; the backward's recomputation is not counted)"}
     # the attention launches of the same step (msn_attention_fwd / _bwd; the ViT towers' one-pass backward with plane output is a
     # different entry point and is not in this list), by (heads, head width, tokens): for the reference-native three-tower
     # workload they, not the GEMMs, are where the step's time goes
@@ -491,6 +503,8 @@ def main():
             long = max(int(x) for x in gk.split(", ")[1].split(" tokens")[0].split(" x ")) > 128
             gentry["kernels"] = ("msn::pattn_* (fp32-grade on v_mfma_f32_16x16x32_bf16: 6 plane products, probabilities split in registers)"
                                  if (12 < wide <= 16 and long) else
+                                 "forward msn::attn_fwd_kernel (vector ALU); backward msn::pattn_bwd_fused_kernel (one pass on the bf16 planes) from 256 (sample, head) pairs on"
+                                 if (wide < 16 and long) else
                                  "msn::attn_* (vector ALU)" if wide < 16 else "msn::mattn_* (v_mfma_f32_16x16x4_f32)")
         a_ms = sum(v["ms_per_step_in_kernel"] for v in groups.values())
         attention = {"ms_per_step_in_kernel": a_ms, "launches_per_step": len(aprof),
@@ -723,7 +737,8 @@ def main():
                                      "algorithmic_tflops is the fp32-equivalent rate of the same launches; algorithmic_bytes_per_launch_plane_format "
                                      "counts plane operands / plane results at their HBM format (2 bytes x planes per element), fp32 matrices at 4"} if products else {}),
                          **({"fp32_launches": fp32_side} if fp32_side is not None else {}),
-                         **({"attention": attention} if attention is not None else {})},
+                         **({"attention": attention} if attention is not None else {}),
+                         **({"fused_feed_forward": fused_ff} if fused_ff is not None else {})},
             "comm": comm,
         }
         if not headline:

@@ -1031,13 +1031,23 @@ def ffn_weight_planes(w1, w2):
     return w1p, w2tp
 
 
+FFN_PROFILE = None      # a list while bench.py times the fused feed-forward launches of one step: (event, event, algorithmic flops, kind)
+
+
 def ffn_fwd(x, w1p, w2tp, c1, c2):
     """z = x + relu(x W1^T + c1) W2^T + c2 without the hidden matrix in memory (msn_ffn_fwd).  x: (M, e) fp32, rows ld apart."""
     _f32c(x, "x")
     M, e = x.shape
     z = torch.empty((M, e), dtype=torch.float32, device=x.device)
+    prof = FFN_PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     check(lib().msn_ffn_fwd(ptr(x), x.stride(0), M, e, c1.numel(), ptr(w1p.buf), ptr(w2tp.buf), ptr(_f32c(c1, "c1")), ptr(_f32c(c2, "c2")),
                             ptr(z), e, stream_ptr()), "msn_ffn_fwd")
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, 4.0 * M * e * c1.numel(), "fwd"))
     return z
 
 
@@ -1053,8 +1063,15 @@ def ffn_bwd(x, dz, w1p, w2tp, c1):
     dc2 = torch.empty(e, dtype=torch.float32, device=x.device)
     nb = lib().msn_ffn_bwd_workspace_bytes(M, e, hid)
     ws = _workspace(nb, x.device)
+    prof = FFN_PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     check(lib().msn_ffn_bwd(ptr(x), x.stride(0), ptr(dz), dz.stride(0), M, e, hid, ptr(w1p.buf), ptr(w2tp.buf), ptr(_f32c(c1, "c1")),
                             ptr(dx), e, ptr(dw1), ptr(dc1), ptr(dw2), ptr(dc2), ptr(ws), nb, stream_ptr()), "msn_ffn_bwd")
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, 8.0 * M * e * hid, "bwd"))       # the four products of an unfused backward (the recomputation is not counted)
     return dx, dw1, dc1, dw2, dc2
 
 
