@@ -248,6 +248,41 @@ def gen_transformer(ref_tr):
                                     "grad": grads_of(m)})
 
 
+def gen_transformer_e32(ref_tr):
+    """The reference's spectrum-transformer width (emb 32, 2 heads: transformer_kwargs_spectral of configs/maven-lite.yaml): the
+    shapes whose feed-forward half runs as the fused kernels of csrc/ffn_planes.hip and -- beyond 128 tokens -- whose attention
+    runs on the bf16 planes.  Same generators as gen_transformer, their own seed (the fixtures of gen_transformer stay byte-identical)."""
+    g = torch.Generator().manual_seed(61)
+    e, h = 32, 2
+    for mname, (b, t) in {"full": (3, 12), "ragged": (3, 12), "long": (2, 160)}.items():
+        x = torch.randn(b, t, e, generator=g)
+        cot = torch.randn(b, t, e, generator=g)
+        mask = torch.ones(b, t, dtype=torch.bool) if mname == "full" else ragged_mask(b, t, g)
+        if mname == "ragged":
+            mask[2] = False
+        blk = ref_tr.TransformerBlock(e, h, ff_hidden_mult=4, dropout=0.0)
+        randomise(blk, g)
+        xi = x.clone().requires_grad_()
+        y = blk(xi, mask)
+        (y * cot).sum().backward()
+        save(f"block_e32_{mname}", cfg={"emb": e, "heads": h}, P=sd_of(blk), **{
+            "in": {"x": x, "mask": mask, "cot": cot}, "out": {"y": y},
+            "grad": {"x": xi.grad, **grads_of(blk)}})
+    n_out = 8
+    for mname, (b, t, nband, agg) in {"mean_nb1_e32_long": (2, 160, 1, "mean"), "attn_nb2_e32_ragged": (3, 24, 2, "attn")}.items():
+        mask = ragged_mask(b, t, g, nband)
+        m = ref_tr.TransformerWithTimeEmbeddings(n_out=n_out, nband=nband, agg=agg, time_norm=17945.14, emb=e, heads=h, depth=3,
+                                                 dropout=0.0)
+        randomise(m, g)
+        xv = torch.randn(b, t, 1, generator=g)
+        tv = torch.sort(torch.rand(b, t, generator=g) * 6000.0 + 3000.0, dim=1)[0]
+        y = m(xv, tv, mask)
+        c = torch.randn(y.shape, generator=g)
+        (y * c).sum().backward()
+        save(f"tenc_{mname}", cfg={"emb": e, "heads": h, "depth": 3, "time_norm": 17945.14, "nband": nband, "agg": agg, "n_out": n_out},
+             P=sd_of(m), **{"in": {"x": xv, "t": tv, "mask": mask, "cot": c}, "out": {"y": y}, "grad": grads_of(m)})
+
+
 def gen_convmixer_mlp(ref_mm):
     g = torch.Generator().manual_seed(37)
     for name, (hw, p) in {"p4": (16, 4), "p10floor": (23, 10)}.items():
@@ -566,7 +601,7 @@ def main():
     torch.set_num_threads(4)
     ref_loss, ref_tr, ref_mm = import_reference()
     only = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else None
-    jobs = {"loss": lambda: gen_loss(ref_loss), "transformer": lambda: gen_transformer(ref_tr),
+    jobs = {"loss": lambda: gen_loss(ref_loss), "transformer": lambda: gen_transformer(ref_tr), "transformer_e32": lambda: gen_transformer_e32(ref_tr),
             "convmixer_mlp": lambda: gen_convmixer_mlp(ref_mm), "clip": lambda: gen_clip(ref_mm),
             "real_checkpoint": lambda: gen_real_checkpoint(ref_mm), "auc": gen_auc, "pretraining": gen_pretraining, "random_masks": gen_random_masks,
             "val_loop": lambda: gen_val_loop(ref_mm), "augment": gen_augment}
