@@ -624,7 +624,8 @@ __global__ __launch_bounds__(512, 4) void pattn_bwd_dkv_kernel(const MAttn p) {
 //     read-modify-write of dq in memory (first key block: a plain store; L2-resident in between, 64 KB per (sample, head) at 1024
 //     tokens; the same thread, hence the same CU, wrote the 16 bytes it reads; streaming accesses that do not linger in the CU's
 //     L1) -- no slabs, no second launch, a fixed order.
-// delta = rowsum(dO o O) comes from pattn_delta_kernel (one pass over dO and O; the two-kernel form computed it in the dQ kernel).
+// delta = rowsum(dO o O) is formed by the first key block from the dO pieces it stages (+ the matching pieces of O) and kept in p.delta
+// for the others (a 16 - 25 us launch of its own at first: 1.6 % of the Maven step).
 // Two barriers per 32-query block (patch written | shares written); 69.5 KB of LDS: two workgroups per CU.
 constexpr int CHB = 128;                        // streamed query rows per chunk
 constexpr int NBKB = CHB / 32;
@@ -634,23 +635,6 @@ constexpr int XP = 64;                          // bytes per key row of a patch 
 constexpr int PATCH = 32 * XP;                  // one plane of a pair's patch: [32 keys][32 queries]
 __device__ __forceinline__ int xswz(int row) { return ((row >> 2) & 1) << 2 | ((row >> 3) & 1) << 1; }
 constexpr int FUSED_LDS = 2 * NBKB * BLK + 3 * CHB * 4 + 4 * 3 * PATCH + 4 * 32 * 16 * 4 + 4 * BLK;
-
-__global__ __launch_bounds__(256) void pattn_delta_kernel(const MAttn p) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;             // (sample, query, head)
-    const int64_t n = (int64_t)p.B * p.Tq * p.H;
-    if (i >= n) return;
-    const int hh = (int)(i % p.H);
-    const int64_t bq = i / p.H;
-    const int q = (int)(bq % p.Tq), b = (int)(bq / p.Tq);
-    const float* o = p.o + (int64_t)b * p.o_bs + (int64_t)q * p.ldo + hh * p.hd;
-    const float* d = p.dout + (int64_t)b * p.d_bs + (int64_t)q * p.ldd + hh * p.hd;
-    float acc = 0.f;
-    for (int k = 0; k < p.hd; k += 4) {
-        const float4 x = *reinterpret_cast<const float4*>(o + k), y = *reinterpret_cast<const float4*>(d + k);
-        acc = fmaf(x.x, y.x, acc), acc = fmaf(x.y, y.y, acc), acc = fmaf(x.z, y.z, acc), acc = fmaf(x.w, y.w, acc);
-    }
-    p.delta[((int64_t)b * p.H + hh) * p.Tq + q] = acc;
-}
 
 __global__ __launch_bounds__(512, 4) void pattn_bwd_fused_kernel(const MAttn p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -717,12 +701,29 @@ __global__ __launch_bounds__(512, 4) void pattn_bwd_fused_kernel(const MAttn p) 
             {
                 const int tid = opaque_tid();
                 sp.load(qsrc + (int64_t)i0 * p.ldq, dsrc + (int64_t)i0 * p.ldd, p.ldq, p.ldd, col0, nt, p.hd, tid);
+                if (kb0 == 0) {
+                    // delta = rowsum(dO o O) of the chunk's rows, once per (sample, head): the FIRST key block forms it from the dO
+                    // pieces it is staging anyway (a 128-row chunk = one 4-column piece per thread: sp.b[0]) and the matching pieces
+                    // of O, sums a row's four pieces over four neighbouring lanes and leaves it in p.delta for the later key blocks
+                    // (same workgroup: the barriers in between order the store and their loads) -- a launch of its own before
+                    const int r = tid >> 2, cq = 4 * (tid & 3);
+                    const bool ok = r < nt && cq < p.hd;
+                    const float4 o = *reinterpret_cast<const float4*>(p.o + (int64_t)b * p.o_bs + (int64_t)(i0 + (ok ? r : 0)) * p.ldo + col0 + (ok ? cq : 0));
+                    const float4 d = sp.b[0];
+                    float part = ok ? fmaf(d.x, o.x, fmaf(d.y, o.y, fmaf(d.z, o.z, d.w * o.w))) : 0.f;
+                    part += __shfl_xor(part, 1, 64);
+                    part += __shfl_xor(part, 2, 64);
+                    if ((tid & 3) == 0) {
+                        Dl[r] = part;                                        // (rows beyond nt: 0)
+                        if (r < nt) p.delta[((int64_t)b * p.H + hh) * p.Tq + i0 + r] = part;
+                    }
+                }
                 sp.commit(Qi, Di, tid, p.scale);
                 if (tid < CHB) {
                     const int64_t stat = ((int64_t)b * p.H + hh) * p.Tq + i0 + (tid < nt ? tid : 0);
                     Ml[tid] = tid < nt ? p.lse[2 * stat] : INFINITY;          // +inf: a padded query row gets p = exp2(-inf) = 0
                     Ll[tid] = tid < nt ? p.lse[2 * stat + 1] * kLog2e : 0.f;
-                    Dl[tid] = tid < nt ? p.delta[stat] : 0.f;
+                    if (kb0 > 0) Dl[tid] = tid < nt ? p.delta[stat] : 0.f;
                 }
             }
             __syncthreads();
@@ -925,9 +926,6 @@ int pattn_backward(const MAttn& a0, hipStream_t st) {
     a.tail = g_ablate;
 #endif
     if (fused_backward_applies(a)) {
-        const int64_t n = (int64_t)a.B * a.Tq * a.H;
-        hipLaunchKernelGGL(pattn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
-        MSN_LAUNCH_CHECK();
         return launch(pattn_bwd_fused_kernel, (unsigned)(a.B * a.H), 512u, (size_t)FUSED_LDS, st, a);
     }
     {

@@ -257,7 +257,7 @@ class _PostNormBlock(torch.autograd.Function):
     residual-branch gradients ride in the dgrad epilogues."""
 
     @staticmethod
-    def forward(ctx, x, mask_u8, heads, drop_p, wk, wq, wv, wu, bu, g1, b1, w1, c1, w2, c2, g2, b2, wcat):
+    def forward(ctx, x, mask_u8, heads, drop_p, wk, wq, wv, wu, bu, g1, b1, w1, c1, w2, c2, g2, b2, wcat, ff_planes=None):
         B, T, e = x.shape
         x2 = _c(x).view(B * T, e)
         scale = 1.0 / math.sqrt(e)
@@ -271,7 +271,8 @@ class _PostNormBlock(torch.autograd.Function):
         # width (emb 32: the spectrum transformer) and the process arithmetic is the plane one they compute in (csrc/ffn_planes.hip)
         fused_ff = FUSED_FF and ops.plane_count() == 3 and ops.ffn_supported(B * T, e, w1.shape[0])
         if fused_ff:
-            w1p, w2tp = ops.ffn_weight_planes(w1, w2)
+            # (ff_planes: the two plane matrices handed in by the tower, which splits the weights of ALL its blocks in one launch)
+            w1p, w2tp = ff_planes if ff_planes is not None else ops.ffn_weight_planes(w1, w2)
             z2 = ops.ffn_fwd(y1, w1p, w2tp, c1, c2)
             hdn = y1.new_empty(0)
             ctx.ff_planes = (w1p, w2tp)
@@ -309,16 +310,22 @@ class _PostNormBlock(torch.autograd.Function):
         dz1, dg1, db1 = ops.layernorm_bwd(dy1, z1, m1, r1, g1)
         dx, dwq, dwk, dwv, dwu, dbu = _attn_backward_raw(dz1, x2, B, T, (qkv, a2, lse, wcat), wq, wk, wv, wu, ctx.mask,
                                                          heads, scale, dz1)  # + residual branch of LN1's input
-        return (dx.view(B, T, e), None, None, None, dwk, dwq, dwv, dwu, dbu, dg1, db1, dw1, dc1, dw2, dc2, dg2, db2, None)
+        return (dx.view(B, T, e), None, None, None, dwk, dwq, dwv, dwu, dbu, dg1, db1, dw1, dc1, dw2, dc2, dg2, db2, None, None)
 
 
-def post_norm_block(x, mask_u8, heads, p, drop_p=0.0, wcat=None):
+def fused_ff_applies(x, emb, hidden):
+    """Will post_norm_block run its feed-forward half as the fused kernels for a (B, T, emb) input?"""
+    return FUSED_FF and x.is_cuda and ops.plane_count() == 3 and ops.ffn_supported(x.shape[0] * x.shape[1], emb, hidden)
+
+
+def post_norm_block(x, mask_u8, heads, p, drop_p=0.0, wcat=None, ff_planes=None):
     """p: dict with tokeys, toqueries, tovalues, unify_w, unify_b, norm1_w, norm1_b, ff0_w, ff0_b,
     ff2_w, ff2_b, norm2_w, norm2_b.  drop_p > 0: dropout after both LayerNorms (train mode).
-    wcat: the persistent stacked [toqueries ; tokeys ; tovalues] matrix (SelfAttention.stacked_qkv) or None."""
+    wcat: the persistent stacked [toqueries ; tokeys ; tovalues] matrix (SelfAttention.stacked_qkv) or None.
+    ff_planes: (planes of ff0_w, planes of ff2_w transposed) when the caller has split them already (ops.ffn_weight_planes)."""
     return _PostNormBlock.apply(x, mask_u8, heads, float(drop_p), p["tokeys"], p["toqueries"], p["tovalues"], p["unify_w"],
                                 p["unify_b"], p["norm1_w"], p["norm1_b"], p["ff0_w"], p["ff0_b"], p["ff2_w"],
-                                p["ff2_b"], p["norm2_w"], p["norm2_b"], wcat)
+                                p["ff2_b"], p["norm2_w"], p["norm2_b"], wcat, ff_planes)
 
 
 # ------------------------------------------------------------------- time / band embedding

@@ -87,10 +87,10 @@ class TransformerBlock(nn.Module):
                 "ff0_w": self.ff[0].weight, "ff0_b": self.ff[0].bias, "ff2_w": self.ff[2].weight,
                 "ff2_b": self.ff[2].bias, "norm2_w": self.norm2.weight, "norm2_b": self.norm2.bias}
 
-    def forward(self, x, mask=None):
+    def forward(self, x, mask=None, ff_planes=None):
         return F_.post_norm_block(x, _mask_bytes(mask) if mask is None or mask.dtype != torch.uint8 else mask,
                                   self.attention.heads, self._params(), drop_p=self.do.p if self.training else 0.0,
-                                  wcat=self.attention.stacked_qkv())
+                                  wcat=self.attention.stacked_qkv(), ff_planes=ff_planes)
 
 
 class Transformer(nn.Module):
@@ -105,8 +105,13 @@ class Transformer(nn.Module):
     def forward(self, x, mask=None):
         m = _mask_bytes(mask)
         x = F_.dropout(x, self.do.p, self.training)           # ref :150
-        for blk in self.tblocks:
-            x = blk(x, m)
+        planes = None
+        if len(self.tblocks) and F_.fused_ff_applies(x, x.shape[-1], self.tblocks[0].ff[0].weight.shape[0]):
+            # the fused feed-forward kernels keep both weights in LDS as plane matrices: ONE launch splits those of every block
+            mats = [w for blk in self.tblocks for w in (blk.ff[0].weight, blk.ff[2].weight)]
+            planes = ops.plane_split_list(mats, 3, transposed=[False, True] * len(self.tblocks))
+        for i, blk in enumerate(self.tblocks):
+            x = blk(x, m, ff_planes=None if planes is None else (planes[2 * i], planes[2 * i + 1]))
         return x
 
 
