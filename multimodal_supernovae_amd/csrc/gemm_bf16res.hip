@@ -13,13 +13,14 @@
 //                   (wgrad: dY^T . X; fragments come out of LDS transposed by ds_read_b64_tr_b16; split over m,
 //                    fp32 partial slabs summed in a fixed order)
 //
-// Workgroup = 8 waves (2 x 4), tile 256 x 256, K-step 64, two LDS K-tile buffers of 64 KB.  A wave owns 128 x 64 of
-// the tile = 8 x 4 MFMA tiles of 16 x 16 (128 accumulator registers) and walks a K-tile in four phases of 16 MFMAs
-// (k32 half x 64-row half); the fragments of the next phase are requested before the MFMAs of the current one
+// Workgroup = 8 waves (NT: 4 x 2, TN: 2 x 4), tile 256 x 256, K-step 64, two LDS K-tile buffers of 64 KB.  A wave owns 64 x 128
+// (TN: 128 x 64) of the tile = 4 x 8 MFMA tiles of 16 x 16 (128 accumulator registers) and walks a K-tile in four phases of 16
+// MFMAs (k32 half x 64-column half); the fragments of the next phase are requested before the MFMAs of the current one
 // (ds_read from inline asm with hand-counted lgkmcnt: hipcc would otherwise drain the LDS-DMA queue with vmcnt(0)
 // before every LDS read), the LDS-DMA of K-tile t + 2 is issued in the middle of K-tile t (one full K-tile of lead),
-// ONE raw s_barrier per K-tile.  MFMA operands are swapped (D^T = B . A^T) so that a lane ends up with four CONSECUTIVE
-// output columns of one row: 16-byte stores.  LDS images are written linearly by the DMA and XOR-swizzled on the
+// ONE raw s_barrier per K-tile.  NT: the weight rows of a tile sit PERMUTED in LDS so that a lane ends up with eight (fp32
+// output: two runs of four) CONSECUTIVE output columns of a row and sixteen lanes side by side on it: a store instruction is
+// 4 rows x 256 contiguous bytes (see `offB`).  LDS images are written linearly by the DMA and XOR-swizzled on the
 // SOURCE address, with the same XOR on the fragment reads: conflict-free for both read shapes (derivation at `swz`).
 #include <algorithm>
 #include <type_traits>
@@ -31,6 +32,8 @@ namespace msn {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
@@ -84,7 +87,7 @@ struct BgemmArgs {
     int N, K;                  // NT: C is M x N, reduction K.  TN: C is N x K
     int tiles_m, tiles_n;      // NT: tile grid.  TN: tiles over N and K
     int super_rows;            // NT: tile-rows walked together (L2 blocking)
-    float* colpart;            // NT (nullable): [2 * tiles_m][N] column sums of the values written to C, per 128-row slab
+    float* colpart;            // NT (nullable): [4 * tiles_m][N] column sums of the values written to C, per 64-row slab
     int splits; int64_t rows_per_split;   // TN: reduction split
     float* slabs;              // TN: [splits][N][K] partials (splits > 1)
 };
@@ -153,23 +156,35 @@ __global__ __launch_bounds__(512, 2) void bgemm_nt_kernel(const BgemmArgs p) {
         rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(p.B + (int64_t)n0_ * p.ldb), (short)0,
                                                   (int)std::min<int64_t>(bytesB, 0x7fffffff), 0x00020000);
     };
-    // per-lane byte offsets inside a piece: row lrow, 16-byte chunk (lane & 7) ^ swz(row)
-    // (swz depends on the row inside the tile: rows 8 q' + lrow with q' = 4 wave + q -> (row >> 1) & 7 = (4 q' + (lrow >> 1)) & 7;
-    //  4 q' & 7 is 0 or 4 by the parity of q, so two offsets per operand cover the four pieces)
-    // (bf16 output: B rows are swizzled by swzB -- bit 1 and bits 3-4 of the row, see the fragment reads; row 8 q' + lrow has bits 3-4 =
-    //  q' & 3 = q: one offset per piece)
-    unsigned offA[2], offB[4];     // (fp32 output: offB[0 .. 1] only)
+    // per-lane byte offsets inside a piece: LDS row 8 q' + lrow (q' = 4 wave + q), 16-byte chunk (lane & 7) ^ swz(LDS row);
+    // swz(row) = (row >> 1) & 7 = (4 q' + (lrow >> 1)) & 7, and 4 q' & 7 is 0 or 4 by the parity of q: two offsets per operand.
+    // A: LDS row = tile row.  B: the LDS image holds the tile's 256 weight rows (= output columns) PERMUTED -- LDS row 128 h + 16 j + l
+    // (h: the wave column, j: n-tile, l: the MFMA column index) is output column
+    //     bf16 output:  128 h + 8 l + j               (lane l of n-tile j = 0 .. 7: EIGHT consecutive columns per lane, 16 bytes)
+    //     fp32 output:  128 h + 64 (j >> 2) + 4 l + (j & 3)   (two runs of FOUR consecutive columns per lane, 16 bytes each)
+    // so that, with the accumulator layout of the un-swapped product (lane = column index l, registers = rows 4 g + r), ONE store
+    // instruction writes 4 rows x 256 contiguous bytes: sixteen lanes side by side on a row.  That shape is what the memory pipe of
+    // a CU takes fastest, by far (tools/microbench/store_patterns.hip, 128 KB per tile and CU between 20-us idle phases: 1.9 us;
+    // 16 rows x 64 B 4.3; 8 rows x 128 B and 16 rows x 32 B 8 - 9), and behind a 1.9-us K-tile the epilogue's stores are what a
+    // persistent workgroup waits for (profiles/r06_bgemm_epilogue.txt).  The permutation costs nothing: an LDS-DMA piece is 8 rows of
+    // 128 B either way; its rows are STR = 8 (4) weight rows apart instead of adjacent.
+    constexpr int STR = OUT_BF16 ? 8 : 4;
+    unsigned offA[2], offB[2];
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
         const int sw = ((4 * par) + (lrow >> 1)) & 7;
         offA[par] = (unsigned)(lrow * p.lda * 2 + 16 * ((lane & 7) ^ sw));
-        if constexpr (!OUT_BF16) offB[par] = (unsigned)(lrow * p.ldb * 2 + 16 * ((lane & 7) ^ sw));
+        offB[par] = (unsigned)(STR * lrow * p.ldb * 2 + 16 * ((lane & 7) ^ sw));
     }
-    if constexpr (OUT_BF16) {
+    const unsigned pieceA = (unsigned)(8 * p.lda * 2);    // bytes from one piece of A to the next
+    // first weight row of piece q' = 4 wave + q (LDS rows 8 q' ..: h = q' >> 4, j = (q' >> 1) & 7, l = 8 (q' & 1) + lrow), in bytes
+    unsigned baseB[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) offB[q] = (unsigned)(lrow * p.ldb * 2 + 16 * ((lane & 7) ^ (((lrow >> 1) & 1) | (q << 1))));
+    for (int q = 0; q < 4; ++q) {
+        const int qq = 4 * wave + q, h = qq >> 4, j = (qq >> 1) & 7, half = qq & 1;
+        const int row = OUT_BF16 ? 128 * h + 64 * half + j : 128 * h + 64 * (j >> 2) + 32 * half + (j & 3);
+        baseB[q] = (unsigned)(row * p.ldb * 2);
     }
-    const unsigned pieceA = (unsigned)(8 * p.lda * 2), pieceB = (unsigned)(8 * p.ldb * 2);    // bytes from one piece to the next
     int t = blockIdx.x, tm, n0, tm_next = 0, n0_next = 0;
     int64_t m0, m0_next = 0;
     locate(t, m0, n0, tm);
@@ -186,209 +201,216 @@ __global__ __launch_bounds__(512, 2) void bgemm_nt_kernel(const BgemmArgs p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lptr_t*)(dst + q * 1024), 16, offA[q & 1] + (unsigned)(4 * wave + q) * pieceA, koff, 0, 0);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t*)(dst + OPER_BYTES + q * 1024), 16, offB[OUT_BF16 ? q : (q & 1)] + (unsigned)(4 * wave + q) * pieceB, koff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t*)(dst + OPER_BYTES + q * 1024), 16, offB[q & 1] + baseB[q], koff, 0, 0);
     };
 
-    // ---- fragment addresses: wave (wm, wn) owns rows 128 wm .. +127 of A, rows (= output columns) 64 wn .. +63 of B
-    const int wm = wave >> 2, wn = wave & 3;
+    // ---- fragment addresses: wave (wm, wn) owns rows 64 wm .. + 63 of A (4 m-tiles), LDS rows 128 wn .. + 127 of B (8 n-tiles)
+    const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, g = lane >> 4;
-    // row = base + 16 i + l15: swz(row) = l15 >> 1 for every i;  chunk(kk) = (4 kk + g) ^ swz
-    const unsigned fragA = (unsigned)((wm * 128 + l15) * 128 + 16 * (g ^ (l15 >> 1)));
-    // B (= output columns).  fp32 output: n-tile j = rows 16 j + l15 of the wave's 64 -- MFMA row 4 g + r of tile j is output column
-    // 16 j + 4 g + r: a lane stores 16 bytes per tile and the four lanes of a row 64 contiguous bytes per instruction.
-    // bf16 output: n-tile j takes rows 32 (j >> 1) + 8 (l15 >> 2) + 4 (j & 1) + (l15 & 3) -- MFMA row 4 g + r of tile j is output
-    // column 32 (j >> 1) + 8 g + 4 (j & 1) + r, so the tile PAIR (2 i, 2 i + 1) leaves a lane with EIGHT consecutive columns: 16-byte
-    // stores again, 64 contiguous bytes per row and instruction (with 16 j + l15 a wave's bf16 store was 16 rows x 32 bytes, two
-    // instructions per 16 bytes of a lane: the epilogue's stores, not its arithmetic, are what a persistent workgroup waits for --
-    // profiles/r06_bgemm_epilogue.txt).  swzB(row) = bit 1 | bits 3-4 << 1: over a ds_read_b128 issue group (lanes {0-3, 12-15} of
-    // one g with {4-11} of g ^ 1: MI355X_MICROARCH.md, LDS) the 16 rows 8 q + s give 16 distinct 16-byte slots --
-    // 8 (s & 1) + ((g ^ (s >> 1)) | q << 1) -- whatever j.
-    const unsigned fragB = OUT_BF16
-        ? (unsigned)(OPER_BYTES + (wn * 64 + 8 * (l15 >> 2) + (l15 & 3)) * 128 + 16 * (g ^ (((l15 >> 1) & 1) | ((l15 >> 2) << 1))))
-        : (unsigned)(OPER_BYTES + (wn * 64 + l15) * 128 + 16 * (g ^ (l15 >> 1)));
-    auto tile_b = [](int j) { return OUT_BF16 ? (32 * (j >> 1) + 4 * (j & 1)) * 128 : 2048 * j; };     // byte offset of n-tile j
+    // LDS row = base + 16 i + l15: swz(row) = l15 >> 1 for every tile;  chunk(kk) = (4 kk + g) ^ swz
+    const unsigned fragA = (unsigned)((wm * 64 + l15) * 128 + 16 * (g ^ (l15 >> 1)));
+    const unsigned fragB = (unsigned)(OPER_BYTES + (wn * 128 + l15) * 128 + 16 * (g ^ (l15 >> 1)));
 
-    f32x4 acc[8][4];
+    f32x4 acc[4][8];
     bf16x8 fa[2][4], fb[2][4];
 
-    // set S of A fragments <- m-tiles 4 mh .. 4 mh + 3 at k32 half kk;  set S of B fragments <- all 4 n-tiles at kk
+    // set S of B fragments <- n-tiles 4 nh .. 4 nh + 3 at k32 half kk;  set S of A fragments <- all 4 m-tiles at kk
 #ifdef MSN_ABL_BF_NOFRAG                   // diagnostic build: no fragment reads (the MFMAs multiply whatever the registers hold)
     for (int s_ = 0; s_ < 2; ++s_)
         for (int i = 0; i < 4; ++i) { asm volatile("" : "=v"(fa[s_][i])); asm volatile("" : "=v"(fb[s_][i])); }
-#define REQ_A(S, buf, kk, mh)
-#define REQ_B(S, buf, kk)
+#define REQ_B(S, buf, kk, nh)
+#define REQ_A(S, buf, kk)
 #else
-#define REQ_A(S, buf, kk, mh)                                                                                      \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                  \
-        ds_read128(fa[S][i], lds0 + (buf) * STAGE_BYTES + (fragA ^ ((kk) << 6)) + (4 * (mh) + i) * 2048);
-#define REQ_B(S, buf, kk)                                                                                          \
+#define REQ_B(S, buf, kk, nh)                                                                                      \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                  \
-        ds_read128(fb[S][j], lds0 + (buf) * STAGE_BYTES + (fragB ^ ((kk) << 6)) + tile_b(j));
+        ds_read128(fb[S][j], lds0 + (buf) * STAGE_BYTES + (fragB ^ ((kk) << 6)) + (4 * (nh) + j) * 2048);
+#define REQ_A(S, buf, kk)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                  \
+        ds_read128(fa[S][i], lds0 + (buf) * STAGE_BYTES + (fragA ^ ((kk) << 6)) + i * 2048);
 #endif
-    // D^T tile = B_frag . A_frag^T: lane gets row m = l15 of the row tile and four consecutive output columns of n-tile j (ncol below)
-#define MULT(SA, SB, mh)                                                                                           \
+    // D tile = A_frag . B_frag^T: lane (l15, g) gets column index l15 of n-tile j and rows 4 g .. 4 g + 3 of m-tile i
+#define MULT(SA, SB, nh)                                                                                           \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)                    \
-        acc[4 * (mh) + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[SB][j], fa[SA][i], acc[4 * (mh) + i][j], 0, 0, 0);
+        acc[i][4 * (nh) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[SA][i], fb[SB][j], acc[i][4 * (nh) + j], 0, 0, 0);
 #define WAIT_LGKM(n)                                           \
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory"); \
     __builtin_amdgcn_sched_barrier(0);
 
+    // store instructions of a FULL tile's epilogue per wave (what the first K-tile behind it may leave in flight)
+    constexpr int kEpiStores = (EPI == EPI_B_GELU || !OUT_BF16) ? 32 : 16;
+
     auto store_tile = [&](int64_t m0, int n0, int tm) {
-        // ---- epilogue: lane holds, per row tile i, row m = 16 i + l15 and columns ncol(j) + r (acc[i][j][r]): bf16 output, two runs of eight
-        // In groups of RG row tiles.  Whatever the epilogue READS (saved pre-activation, residual) is requested BEFORE the group's
-        // stores are issued -- the next group's pieces between this group's arithmetic and its stores, into the same registers:
-        // vector-memory operations complete in order (one counter for loads and stores), and a load issued behind a store waited for it
-        // (GELU' launch 738 -> 678 us with the loads first).  Stores and loads are 16 bytes per lane where the rows allow it.
-        const int64_t mrow0 = m0 + wm * 128 + l15;
-        auto ncol = [&](int j) { return n0 + wn * 64 + (OUT_BF16 ? 32 * (j >> 1) + 8 * g + 4 * (j & 1) : 16 * j + 4 * g); };
-        auto nok = [&](int j) { return ncol(j) + 3 < p.N; };       // N % 4 == 0 (host)
-        // bf16: the pair (2 pr, 2 pr + 1) as ONE 16-byte access when its rows are 16-byte aligned; else four columns at a time
-        [[maybe_unused]] const bool rows16_c = p.ldc % 8 == 0, rows16_x = p.ldaux % 8 == 0;
-        float4 bias4[4];
+        // ---- epilogue: lane (l15, g) holds rows m = 16 i + 4 g + r (register r of m-tile i) and, of n-tile j, one column (above):
+        // eight consecutive columns cb .. cb + 7 (bf16 output; acc[i][j][r] = column cb + j) or two runs of four, cf(hh) .. + 3
+        // (fp32 output; acc[i][4 hh + jj][r] = column cf(hh) + jj).  One m-tile at a time.  Whatever the epilogue READS (saved
+        // pre-activation, residual) is requested BEFORE the m-tile's stores are issued -- the next m-tile's pieces between this
+        // one's arithmetic and its stores, into the same registers: vector-memory operations complete in order (one counter for
+        // loads and stores), and a load issued behind a store waited for it (GELU' launch 738 -> 678 us with the loads first).
+        // Every access goes through a buffer descriptor of the TILE's rows (scalar registers; rows past the matrix are out of its
+        // range: stores dropped, loads zero) + one 32-bit lane offset + a scalar row offset -- sixteen 64-bit row pointers per lane
+        // were 32 registers the K loop's 128 accumulators do not leave.
+        // (lane constants and row strides of the epilogue from OPAQUE copies of the thread index / the strides: computed at kernel start
+        //  they stay alive across the K loop -- three vector registers and 32 scalar row offsets the allocator then spills)
+        int tid_e = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid_e));
+        const int l15 = tid_e & 15, g = (tid_e >> 4) & 3, wave_e = __builtin_amdgcn_readfirstlane(tid_e >> 6), wm = wave_e >> 1, wn = wave_e & 1;
+        constexpr int ES = OUT_BF16 ? 2 : 4;                       // bytes per element of C
+        constexpr int XS = EPI == EPI_B_ADD ? 4 : 2;               // ... of aux
+        constexpr unsigned OOB = 0x40000000u;                      // beyond any tile (256 rows x ld < 2^20 elements: host)
+        const int cb = n0 + wn * 128 + 8 * l15;
+        auto cf = [&](int hh) { return n0 + wn * 128 + 64 * hh + 4 * l15; };
+        // column of acc[.][j] and whether its group of four columns lies inside the matrix (N % 4 == 0: host)
+        auto ncol4 = [&](int q4) { return OUT_BF16 ? cb + 4 * q4 : cf(q4); };      // group q4 = tiles 4 q4 .. 4 q4 + 3
+        const bool ok4[2] = {ncol4(0) + 3 < p.N, ncol4(1) + 3 < p.N};
+        [[maybe_unused]] const bool rows16_c = p.ldc % 8 == 0, rows16_x = p.ldaux % 8 == 0;   // bf16 rows start on 16 bytes
+        const int rows_here = (int)std::min<int64_t>(std::max<int64_t>(p.M - m0, 0), BT);
+        auto tile_rsrc = [&](const void* base, int64_t ld, int es) {
+            const uint64_t a0 = reinterpret_cast<uint64_t>(base) + (uint64_t)((m0 * ld + n0) * es);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a0), hi = __builtin_amdgcn_readfirstlane((unsigned)(a0 >> 32));
+            const int nb = __builtin_amdgcn_readfirstlane((int)(((int64_t)rows_here * ld - n0) * es));
+            return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), (short)0, nb, 0x00020000);
+        };
+        const __amdgpu_buffer_rsrc_t rsC = tile_rsrc(p.C, p.ldc, ES);
+        [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsX = tile_rsrc(p.aux ? p.aux : p.C, p.aux ? p.ldaux : p.ldc, XS);
+        // lane offsets of the two column groups in row 64 wm + 4 g of the tile (bytes); the row of (i, r) goes into the scalar offset
+        const int lrow0 = wm * 64 + 4 * g;
+        unsigned vc[2], vx[2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            bias4[j] = (p.bias && nok(j)) ? *reinterpret_cast<const float4*>(p.bias + ncol(j)) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float cs[4][4];                                            // column sums of this wave's 128 rows (bias gradient)
+        for (int q4 = 0; q4 < 2; ++q4) {
+            vc[q4] = ok4[q4] ? (unsigned)((lrow0 * (int)p.ldc + ncol4(q4) - n0) * ES) : OOB;
+            vx[q4] = ok4[q4] ? (unsigned)((lrow0 * (int)p.ldaux + ncol4(q4) - n0) * XS) : OOB;
+        }
+        int srowC = (int)p.ldc * ES, srowX = (int)p.ldaux * XS;
+        asm volatile("" : "+s"(srowC), "+s"(srowX));
+        const int rows_left = rows_here - lrow0;                   // rows 16 i + r < rows_left of this lane are inside the matrix
+        float4 bias4[2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cs[j][r] = 0.f;
+        for (int q4 = 0; q4 < 2; ++q4)
+            bias4[q4] = (p.bias && ok4[q4]) ? *reinterpret_cast<const float4*>(p.bias + ncol4(q4)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x4 cs[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};     // column sums over this lane's rows (bias gradient)
         constexpr bool READS = EPI == EPI_B_GELU_BWD || EPI == EPI_B_ADD;
-        using AuxT = std::conditional_t<EPI == EPI_B_ADD, float4, uint2>;
-        constexpr int RG = EPI == EPI_B_ADD ? 1 : READS ? 2 : 4;   // (more row tiles of pieces in flight beside 128 accumulators: scratch)
-        AuxT ax[READS ? RG : 1][4];
-        auto request = [&](int h) {
+        using AuxT = std::conditional_t<EPI == EPI_B_ADD, u32x4, u32x2>;
+        AuxT ax[READS ? 4 : 1][2];                                  // [r][group of four columns]
+        auto request = [&](int i) {
             if constexpr (READS) {
 #pragma unroll
-                for (int ii = 0; ii < RG; ++ii) {
-                    const int64_t m = mrow0 + 16 * (RG * h + ii);
-                    const int64_t mc = m < p.M ? m : 0;            // (a row past the edge re-reads row 0: never used)
+                for (int r = 0; r < 4; ++r) {
+                    const int so = (16 * i + r) * srowX;
                     if constexpr (EPI == EPI_B_ADD) {
-                        const float* row = static_cast<const float*>(p.aux) + mc * p.ldaux;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) ax[ii][j] = *reinterpret_cast<const float4*>(row + (nok(j) ? ncol(j) : 0));
+                        for (int q4 = 0; q4 < 2; ++q4) ax[r][q4] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)vx[q4], so, 0);
                     } else {
-                        const u16* row = static_cast<const u16*>(p.aux) + mc * p.ldaux;
 #ifndef MSN_ABL_BF_NOAUX
+                        if (OUT_BF16 && rows16_x && ok4[1]) {
+                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)vx[0], so, 0);
+                            ax[r][0] = u32x2{v[0], v[1]}, ax[r][1] = u32x2{v[2], v[3]};
+                        } else {
 #pragma unroll
-                        for (int pr = 0; pr < 2; ++pr) {
-                            if (OUT_BF16 && rows16_x && nok(2 * pr + 1)) {
-                                const uint4 v = *reinterpret_cast<const uint4*>(row + ncol(2 * pr));
-                                ax[ii][2 * pr] = make_uint2(v.x, v.y), ax[ii][2 * pr + 1] = make_uint2(v.z, v.w);
-                            } else {
-                                ax[ii][2 * pr] = *reinterpret_cast<const uint2*>(row + (nok(2 * pr) ? ncol(2 * pr) : 0));
-                                ax[ii][2 * pr + 1] = *reinterpret_cast<const uint2*>(row + (nok(2 * pr + 1) ? ncol(2 * pr + 1) : 0));
-                            }
+                            for (int q4 = 0; q4 < 2; ++q4) ax[r][q4] = __builtin_amdgcn_raw_buffer_load_b64(rsX, (int)vx[q4], so, 0);
                         }
 #else
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) ax[ii][j] = make_uint2(0x3f803f80u + (unsigned)ii, 0x3f803f80u);
+                        for (int q4 = 0; q4 < 2; ++q4) ax[r][q4] = u32x2{0x3f803f80u + (unsigned)r, 0x3f803f80u};
 #endif
                     }
                 }
             }
         };
         auto pack2 = [](float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); };
-        // 16 bf16 of one row (o[2 j], o[2 j + 1] = tile j): two 16-byte stores, or 8 bytes per in-range column group
-        auto put_bf16 = [&](u16* row, const unsigned (&o)[8], bool rows16) {
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                if (OUT_BF16 && rows16 && nok(2 * pr + 1)) {
-                    *reinterpret_cast<uint4*>(row + ncol(2 * pr)) = make_uint4(o[4 * pr], o[4 * pr + 1], o[4 * pr + 2], o[4 * pr + 3]);
-                } else {
-                    if (nok(2 * pr)) *reinterpret_cast<uint2*>(row + ncol(2 * pr)) = make_uint2(o[4 * pr], o[4 * pr + 1]);
-                    if (nok(2 * pr + 1)) *reinterpret_cast<uint2*>(row + ncol(2 * pr + 1)) = make_uint2(o[4 * pr + 2], o[4 * pr + 3]);
-                }
+        // eight bf16 of one row: one 16-byte store, or 8 bytes per in-range group of four
+        auto put_bf16 = [&](__amdgpu_buffer_rsrc_t rs, const unsigned (&v)[2], int so, const unsigned (&o)[4], bool rows16) {
+            if (rows16 && ok4[1]) {
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{o[0], o[1], o[2], o[3]}, rs, (int)v[0], so, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{o[0], o[1]}, rs, (int)v[0], so, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{o[2], o[3]}, rs, (int)v[1], so, 0);
             }
         };
         request(0);
 #pragma unroll
-        for (int h = 0; h < 8 / RG; ++h) {
-            // arithmetic, in place
+        for (int i = 0; i < 4; ++i) {
+            // arithmetic, in place (acc[i][4 q4 + jj][r]: row r, column ncol4(q4) + jj)
 #pragma unroll
-            for (int ii = 0; ii < RG; ++ii) {
-                const int i = RG * h + ii;
+            for (int q4 = 0; q4 < 2; ++q4) {
+                const float bj[4] = {bias4[q4].x, bias4[q4].y, bias4[q4].z, bias4[q4].w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x4 v = acc[i][j] + f32x4{bias4[j].x, bias4[j].y, bias4[j].z, bias4[j].w};
+                for (int jj = 0; jj < 4; ++jj) {
+                    f32x4 v = acc[i][4 * q4 + jj] + bj[jj];
                     if constexpr (EPI == EPI_B_GELU_BWD) {         // x gelu'(saved bf16 pre-activation)
-                        const uint2 pre = ax[ii][j];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const unsigned w = ax[r][q4][jj >> 1];
+                            const float pre = __uint_as_float((jj & 1) ? (w & 0xffff0000u) : (w << 16));
 #ifndef MSN_ABL_BF_NOGELU
-                        v[0] *= gelu_grad_fast(__uint_as_float(pre.x << 16)), v[1] *= gelu_grad_fast(__uint_as_float(pre.x & 0xffff0000u));
-                        v[2] *= gelu_grad_fast(__uint_as_float(pre.y << 16)), v[3] *= gelu_grad_fast(__uint_as_float(pre.y & 0xffff0000u));
+                            v[r] *= gelu_grad_fast(pre);
 #else
-                        v[0] *= __uint_as_float(pre.x << 16), v[1] *= __uint_as_float(pre.x & 0xffff0000u);
-                        v[2] *= __uint_as_float(pre.y << 16), v[3] *= __uint_as_float(pre.y & 0xffff0000u);
+                            v[r] *= pre;
 #endif
+                        }
                     } else if constexpr (EPI == EPI_B_ADD) {       // + fp32 residual
-                        v += f32x4{ax[ii][j].x, ax[ii][j].y, ax[ii][j].z, ax[ii][j].w};
+                        v += f32x4{__uint_as_float(ax[0][q4][jj]), __uint_as_float(ax[1][q4][jj]), __uint_as_float(ax[2][q4][jj]),
+                                   __uint_as_float(ax[3][q4][jj])};
                     }
-                    acc[i][j] = v;
+                    acc[i][4 * q4 + jj] = v;
                 }
             }
-            if (h + 1 < 8 / RG) request(h + 1);
-            // stores
+            if (i + 1 < 4) request(i + 1);
+            // stores: row r of the m-tile per instruction -- 4 rows (g) x 256 contiguous bytes
 #pragma unroll
-            for (int ii = 0; ii < RG; ++ii) {
-                const int i = RG * h + ii;
-                const int64_t m = mrow0 + 16 * i;
-                if (m >= p.M) continue;
+            for (int r = 0; r < 4; ++r) {
+                const int soC = (16 * i + r) * srowC;
                 if constexpr (EPI == EPI_B_GELU) {                 // aux <- pre-activation (bf16), C <- gelu(pre)
-                    unsigned o[8];
+                    unsigned o[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[2 * j] = pack2(acc[i][j][0], acc[i][j][1]), o[2 * j + 1] = pack2(acc[i][j][2], acc[i][j][3]);
+                    for (int x = 0; x < 4; ++x) o[x] = pack2(acc[i][2 * x][r], acc[i][2 * x + 1][r]);
 #ifndef MSN_ABL_BF_NOAUX               // diagnostic builds (tools/microbench/build_ablate.sh BF_NOAUX / BF_NOGELU / BF_NOCST): timing only
-                    put_bf16(static_cast<u16*>(p.aux) + m * p.ldaux, o, rows16_x);
+                    put_bf16(rsX, vx, (16 * i + r) * srowX, o, rows16_x);
 #endif
 #ifndef MSN_ABL_BF_NOGELU
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[i][j][r] = gelu_fast(acc[i][j][r]);
+                    for (int j = 0; j < 8; ++j) acc[i][j][r] = gelu_fast(acc[i][j][r]);
 #endif
                 }
                 if constexpr (OUT_BF16) {
-                    unsigned o[8];
+                    unsigned o[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[2 * j] = pack2(acc[i][j][0], acc[i][j][1]), o[2 * j + 1] = pack2(acc[i][j][2], acc[i][j][3]);
+                    for (int x = 0; x < 4; ++x) o[x] = pack2(acc[i][2 * x][r], acc[i][2 * x + 1][r]);
 #ifdef MSN_ABL_BF_NOCST
                     if (o[0] == 0x7fc17fc1u)
 #endif
-                    put_bf16(static_cast<u16*>(p.C) + m * p.ldc, o, rows16_c);
-                    if (p.colpart) {                               // sums of the values AS STORED (what the next products read)
+                    put_bf16(rsC, vc, soC, o, rows16_c);
+                    if (p.colpart && 16 * i + r < rows_left) {     // sums of the values AS STORED (what the next products read)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (nok(j)) {
-                                cs[j][0] += __uint_as_float(o[2 * j] << 16), cs[j][1] += __uint_as_float(o[2 * j] & 0xffff0000u);
-                                cs[j][2] += __uint_as_float(o[2 * j + 1] << 16), cs[j][3] += __uint_as_float(o[2 * j + 1] & 0xffff0000u);
-                            }
+                        for (int x = 0; x < 4; ++x) {
+                            cs[x >> 1][2 * (x & 1)] += __uint_as_float(o[x] << 16);
+                            cs[x >> 1][2 * (x & 1) + 1] += __uint_as_float(o[x] & 0xffff0000u);
+                        }
                     }
                 } else {
-                    float* row = static_cast<float*>(p.C) + m * p.ldc;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (nok(j)) {
-                            *reinterpret_cast<f32x4*>(row + ncol(j)) = acc[i][j];
-                            if (p.colpart) { cs[j][0] += acc[i][j][0]; cs[j][1] += acc[i][j][1]; cs[j][2] += acc[i][j][2]; cs[j][3] += acc[i][j][3]; }
-                        }
+                    for (int q4 = 0; q4 < 2; ++q4) {
+                        const f32x4 v = {acc[i][4 * q4][r], acc[i][4 * q4 + 1][r], acc[i][4 * q4 + 2][r], acc[i][4 * q4 + 3][r]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, (int)vc[q4], soC, 0);
+                        if (p.colpart && 16 * i + r < rows_left) cs[q4] += v;
+                    }
                 }
             }
         }
-        if (p.colpart) {   // the 16 lanes sharing g hold the 16 rows of every row tile: xor tree, then lane l15 == 0 writes its columns
+        if (p.colpart) {   // the four lanes sharing l15 hold the wave's 64 rows: two xor steps, then the lanes of g == 0 write their columns
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int q4 = 0; q4 < 2; ++q4)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float t = cs[j][r];
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) t += __shfl_xor(t, o, 64);
-                    cs[j][r] = t;
+                for (int x = 0; x < 4; ++x) {
+                    float t = cs[q4][x];
+                    t += __shfl_xor(t, 16, 64);
+                    t += __shfl_xor(t, 32, 64);
+                    cs[q4][x] = t;
                 }
-            if (l15 == 0) {
-                float* row = p.colpart + (int64_t)(2 * tm + wm) * p.N;
+            if (g == 0) {
+                float* row = p.colpart + (int64_t)(4 * tm + wm) * p.N;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (nok(j)) *reinterpret_cast<float4*>(row + ncol(j)) = make_float4(cs[j][0], cs[j][1], cs[j][2], cs[j][3]);
+                for (int q4 = 0; q4 < 2; ++q4)
+                    if (ok4[q4]) *reinterpret_cast<f32x4*>(row + ncol4(q4)) = cs[q4];
             }
         }
     };
@@ -399,37 +421,43 @@ __global__ __launch_bounds__(512, 2) void bgemm_nt_kernel(const BgemmArgs p) {
     __builtin_amdgcn_s_barrier();
     if (nkt > 1) issue(1, 1);
     unsigned gs = 0;                       // K-tiles this workgroup has started, over all its tiles: K-tile gs sits in buffer gs & 1
+    bool behind_full_tile = false;         // the previous tile's epilogue issued exactly kEpiStores store instructions per wave
     for (;;) {
         const int t_next = t + (int)gridDim.x;
         const bool more = t_next < total;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        REQ_A(0, gs & 1, 0, 0)
-        REQ_B(0, gs & 1, 0)
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        REQ_B(0, gs & 1, 0, 0)
+        REQ_A(0, gs & 1, 0)
         for (int kt = 0; kt < nkt; ++kt, ++gs) {
             const int cur = gs & 1;
-            // phase 0: k32 half 0, m-tiles 0-3
-            REQ_A(1, cur, 0, 1)
+            // phase 0: k32 half 0, n-tiles 0-3
+            REQ_B(1, cur, 0, 1)
             WAIT_LGKM(4)
             MULT(0, 0, 0)
             __builtin_amdgcn_sched_barrier(0);
-            // phase 1: k32 half 0, m-tiles 4-7
-            REQ_A(0, cur, 1, 0)
-            REQ_B(1, cur, 1)
+            // phase 1: k32 half 0, n-tiles 4-7
+            REQ_B(0, cur, 1, 0)
+            REQ_A(1, cur, 1)
             WAIT_LGKM(8)
-            MULT(1, 0, 1)
+            MULT(0, 1, 1)
             __builtin_amdgcn_sched_barrier(0);
-            // phase 2: k32 half 1, m-tiles 0-3
-            REQ_A(1, cur, 1, 1)
+            // phase 2: k32 half 1, n-tiles 0-3
+            REQ_B(1, cur, 1, 1)
             WAIT_LGKM(4)
-            MULT(0, 1, 0)
+            MULT(1, 0, 0)
             __builtin_amdgcn_sched_barrier(0);
             // phase 3: every fragment of this K-tile is in registers -> the buffer may be refilled; the next K-tile of the
             // stream (issued one K-tile ago; the next tile's first one at the end of a tile) must have landed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (vector-memory operations complete IN ORDER, loads and stores on one counter: K-tile 1 of a tile was requested BEFORE
+            //  the previous tile's epilogue issued its stores, so behind a FULL tile's epilogue -- a fixed number of store instructions
+            //  per wave -- the first K-tile waits for everything but those stores instead of draining them; they have until K-tile 2,
+            //  requested behind them, is waited for)
+            if (kt == 0 && behind_full_tile) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kEpiStores) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             // (The 8 LDS-DMA instructions of a wave are what the loop pays most for -- profiles/r03_bgemm_kloop_ablation.txt: without
@@ -448,8 +476,8 @@ __global__ __launch_bounds__(512, 2) void bgemm_nt_kernel(const BgemmArgs p) {
             };
             if (wave < 4 || !g_stagger) refill();
             if (kt + 1 < nkt) {
-                REQ_A(0, cur ^ 1, 0, 0)
-                REQ_B(0, cur ^ 1, 0)
+                REQ_B(0, cur ^ 1, 0, 0)
+                REQ_A(0, cur ^ 1, 0)
             }
             __builtin_amdgcn_sched_barrier(0);
             MULT(1, 1, 1)
@@ -458,6 +486,7 @@ __global__ __launch_bounds__(512, 2) void bgemm_nt_kernel(const BgemmArgs p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         store_tile(m0, n0, tm);
+        behind_full_tile = m0 + BT <= p.M && n0 + BT <= p.N;
         if (!more) break;
         t = t_next, m0 = m0_next, n0 = n0_next, tm = tm_next;
     }
@@ -745,7 +774,7 @@ using namespace msn;
 
 extern "C" size_t msn_bgemm_nt_colsum_workspace_bytes(int64_t M, int N) {
     if (M <= 0 || N <= 0) return 0;
-    return sizeof(float) * 2 * (size_t)cdiv(M, BT) * (size_t)N;
+    return sizeof(float) * 4 * (size_t)cdiv(M, BT) * (size_t)N;
 }
 
 extern "C" int msn_bgemm_nt(int64_t M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
@@ -789,7 +818,7 @@ extern "C" int msn_bgemm_nt(int64_t M, int N, int K, const void* A, int64_t lda,
     }
     MSN_LAUNCH_CHECK();
     if (colsum_out) {   // every (row slab, column) partial was written by exactly one wave: fixed-order sum over the slabs
-        hipLaunchKernelGGL(bcolsum_finish_kernel, dim3((unsigned)cdiv(N, 64)), dim3(256), 0, st, a.colpart, 2 * a.tiles_m, N,
+        hipLaunchKernelGGL(bcolsum_finish_kernel, dim3((unsigned)cdiv(N, 64)), dim3(256), 0, st, a.colpart, 4 * a.tiles_m, N,
                            colsum_out);
         MSN_LAUNCH_CHECK();
     }
