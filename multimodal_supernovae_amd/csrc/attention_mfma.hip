@@ -1070,7 +1070,9 @@ __global__ __launch_bounds__(512) void mattn_bwd_fused_kernel(const MAttn p, con
             const int idx = threadIdx.x + u * blockDim.x;
             if (idx < rows_mf * Q4) {
                 const int row = idx / Q4, cq = 4 * (idx % Q4);
-                *reinterpret_cast<f32x4*>(St + row * LS + cq) = sum[u] * p.scale;
+                // (rows T .. rows_mf - 1 are padding of the last query tile: in the stage they would be rows 0 .. of the dk block, which
+                //  the waves write below without a barrier in between -- a sequence of 16 n + 15 tokens lost dk of its first key now and then)
+                if (row < T) *reinterpret_cast<f32x4*>(St + row * LS + cq) = sum[u] * p.scale;
             }
         }
     }

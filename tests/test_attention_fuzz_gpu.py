@@ -256,3 +256,34 @@ def test_plane_output_backward_against_fp64(B, T, hd, heads, masked):
     got, cs = ops.attention_bwd_planes(qc, heads, scale, out, lse, dout.cuda(), 3, want_colsum=True, mask_u8=mu8)
     torch.testing.assert_close(got.to_float().cpu().double(), want, rtol=3e-4, atol=3e-5)
     torch.testing.assert_close(cs.cpu().double(), want.sum(0), rtol=1e-4, atol=1e-4 * float(want.abs().sum(0).max()))
+
+
+@pytest.mark.parametrize("T", [15, 31, 47, 63])
+def test_fused_backward_padded_last_tile_is_stable(T):
+    """Sequences of 16 n + 15 tokens: the padding row of the last query tile must not reach the stage of the one-pass backward
+    (it is row 0 of the dk block there; written without a barrier it overwrote dk of the first key in some launches)."""
+    from multimodal_supernovae_amd import _lib, ops
+    g = torch.Generator().manual_seed(T)
+    B, heads, hd = 2, 4, 32
+    E = heads * hd
+    q, k, v, dout = (torch.randn(B, T, E, generator=g) for _ in range(4))
+    scale = 1.0 / math.sqrt(E)
+    qr, kr, vr = (t.double().requires_grad_() for t in (q, k, v))
+    _ref(qr, kr, vr, None, heads, scale).backward(dout.double())
+    qc, kc, vc, dc = q.cuda(), k.cuda(), v.cuda(), dout.cuda()
+    _lib.check(_lib.lib().msn_set_attention_path(2))
+    try:
+        out, lse = ops.attention_fwd(qc, kc, vc, None, heads, scale)
+        first = None
+        for _ in range(40):
+            dq, dk, dv = torch.empty_like(qc), torch.empty_like(kc), torch.empty_like(vc)
+            ops.attention_bwd(qc, kc, vc, None, heads, scale, out, lse, dc, dq, dk, dv)
+            got = torch.stack([dq, dk, dv]).cpu()
+            if first is None:
+                first = got
+                for x, want, name in ((dq, qr.grad, "dq"), (dk, kr.grad, "dk"), (dv, vr.grad, "dv")):
+                    torch.testing.assert_close(x.cpu().double(), want, rtol=3e-4, atol=3e-5, msg=lambda m: f"{name} T={T}: {m}")
+            else:
+                assert torch.equal(got, first)
+    finally:
+        _lib.lib().msn_set_attention_path(0)
