@@ -114,6 +114,10 @@ __global__ __launch_bounds__(512, 2) void bgemm_nt_kernel(const BgemmArgs p) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // static priority for the second-dispatched half of the workgroup: waves 4-7 lose the per-SIMD issue arbitration (priority, then
+    // age) on every phase otherwise (MI355X_MICROARCH.md, two waves per SIMD); cfg5 step -0.4 % in three interleaved pairs.  (The plane
+    // GEMMs of pgemm_kernels.h: +0.3 % with the same line -- not there.)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     // Persistent: workgroup b multiplies the tiles t = b, b + gridDim.x, ... (one workgroup per CU; gridDim.x is a multiple
     // of 8 or the number of tiles).  The ring of K-tiles runs on ACROSS tile boundaries: the first two K-tiles of the next
     // tile are requested during the last two K-tiles of this one, so they land under the epilogue instead of in front of
@@ -316,7 +320,13 @@ __global__ __launch_bounds__(512, 2) void bgemm_nt_kernel(const BgemmArgs p) {
                 }
             }
         };
-        auto pack2 = [](float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); };
+        // (one v_cvt_pk_bf16_f32 per pair: the vector conversion; two scalar casts + a merge were three instructions)
+        auto pack2 = [](float a, float b) {
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            const f32x2_t ab = {a, b};
+            return __builtin_bit_cast(unsigned, __builtin_convertvector(ab, bf16x2_t));
+        };
         // eight bf16 of one row: one 16-byte store, or 8 bytes per in-range group of four
         auto put_bf16 = [&](__amdgpu_buffer_rsrc_t rs, const unsigned (&v)[2], int so, const unsigned (&o)[4], bool rows16) {
             if (rows16 && ok4[1]) {
@@ -513,6 +523,10 @@ __global__ __launch_bounds__(512, 2) void bgemm_tn_kernel(const BgemmArgs p) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // static priority for the second-dispatched half of the workgroup: waves 4-7 lose the per-SIMD issue arbitration (priority, then
+    // age) on every phase otherwise (MI355X_MICROARCH.md, two waves per SIMD); cfg5 step -0.4 % in three interleaved pairs.  (The plane
+    // GEMMs of pgemm_kernels.h: +0.3 % with the same line -- not there.)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     const int tiles = p.tiles_m * p.tiles_n;               // tiles over (N, K)
     // workgroup ids go round-robin to the 8 XCDs: give each XCD a contiguous run of (split, tile) pairs, i.e. the tiles of
     // one reduction range, so that its dY / X panels are shared in ONE L2 instead of being fetched by all eight
