@@ -447,6 +447,20 @@ int msn_attention_bwd(const float* q, int64_t ldq, int64_t q_bstride, const floa
                       const float* dout, int64_t ldd, int64_t d_bstride, float* delta, float* dq,
                       int64_t lddq, int64_t dq_bstride, float* dk, int64_t lddk, int64_t dk_bstride,
                       float* dv, int64_t lddv, int64_t dv_bstride, msn_stream_t stream);
+/* Attention of ONE query per (sample, head) over T keys: the class-token row of the LAST block of the build-defined ViT (the head
+ * reads token 0 only; the arithmetic is SelfAttention of ref src/transformer_utils.py:36-89 for a single query, no mask).
+ * q / out / dout / dq: (B, H * 64) fp32 rows; kv / dkv: (B * T, >= 2 * H * 64) rows, keys in columns [0, H 64), values in
+ * [H 64, 2 H 64), fp32 (kv_bf16 = 0) or bf16 (1: the bf16-resident tower; dkv is written in the same type, round to nearest
+ * even); probs: (B, H, T) fp32, written by the forward and read by the backward.  A wave per pair, eight lanes on a key's 64
+ * columns, every K and V row read once per direction (csrc/cls_attention.hip).  head_dim must be 64 and T <= 256
+ * (msn_cls_attention_supported); every row 16-byte aligned.  Everything else stays with msn_attention_fwd / _bwd, which run this
+ * shape as a 16-row query tile with fifteen rows of padding. */
+int msn_cls_attention_supported(int T, int head_dim);
+int msn_cls_attention_fwd(const float* q, int64_t ldq, const void* kv, int64_t ldkv, int kv_bf16, int B, int H, int T, int head_dim,
+                          float scale, float* out, int64_t ldo, float* probs, msn_stream_t stream);
+int msn_cls_attention_bwd(const float* q, int64_t ldq, const void* kv, int64_t ldkv, int kv_bf16, int B, int H, int T, int head_dim,
+                          float scale, const float* out, int64_t ldo, const float* probs, const float* dout, int64_t ldd, float* dq,
+                          int64_t lddq, void* dkv, int64_t lddkv, msn_stream_t stream);
 /* Two implementations sit behind msn_attention_*: vector-ALU kernels (head widths up to 32, any length; the
  * reference-native 8-wide heads, widths that are not a multiple of 4, unaligned operands) and matrix-core
  * kernels (v_mfma_f32_16x16x4_f32; any length -- chunked beyond 128 tokens; every head width that is a

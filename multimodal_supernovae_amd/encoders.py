@@ -83,18 +83,21 @@ class VisionTransformer(nn.Module):
             raise ValueError(f"image {tuple(x.shape)} does not match the {self.grid}x{self.grid} patch grid")
         patches = F_.patchify(x, self.patch_size)
         pe = self.patch_embed.proj
-        emb = F_.linear(patches, pe.weight.view(e, -1), pe.bias)
-        h = F_.vit_tokens(emb, self.cls_token, self.pos_embed, B, T)
         last = len(self.blocks) - 1
+        dense_blocks = last if self.cls_only_last_block else last + 1
+        # BASELINE cfg5: bf16-resident operands, 256 x 256 LDS-DMA tiles -- trunk, last block's token-sized products, patch embedding
+        resident = (self.gemm_precision == "bf16" and self.bf16_resident and dense_blocks > 0 and e % 64 == 0
+                    and all(b.norm1.eps == self.blocks[0].norm1.eps for b in self.blocks))
+        emb = (F_.bf16_linear if resident else F_.linear)(patches, pe.weight.view(e, -1), pe.bias)
+        h = F_.vit_tokens(emb, self.cls_token, self.pos_embed, B, T)
         params = [(blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight,
                    blk.attn.proj.bias, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
                    blk.mlp.fc2.weight, blk.mlp.fc2.bias) for blk in self.blocks]
         from . import ops
         dense = len(params) - 1 if self.cls_only_last_block else len(params)       # blocks evaluated for every token
         first = 0
-        if (self.gemm_precision == "bf16" and self.bf16_resident and dense > 0 and e % 64 == 0
-                and all(b.norm1.eps == self.blocks[0].norm1.eps for b in self.blocks)):
-            # BASELINE cfg5: bf16-resident operands, 256 x 256 LDS-DMA tiles (functional._Bf16VitTrunk)
+        if resident:
+            # (functional._Bf16VitTrunk)
             h = F_.bf16_vit_trunk(h, self.heads, self.blocks[0].norm1.eps, params[:dense])
             first = dense
         elif (dense > 0 and F_.plane_path_ok(h) and all(b.norm1.eps == self.blocks[0].norm1.eps for b in self.blocks)):
@@ -105,7 +108,7 @@ class VisionTransformer(nn.Module):
             if i == last and self.cls_only_last_block:
                 # the head reads the class token only: the last block is evaluated for that row alone (identical output
                 # and gradients; keys / values still come from every token)
-                h = F_.pre_norm_last_block(h, self.heads, params[i], eps=self.blocks[i].norm1.eps)
+                h = F_.pre_norm_last_block(h, self.heads, params[i], eps=self.blocks[i].norm1.eps, bf16_resident=resident)
             else:
                 h = F_.pre_norm_block(h, self.heads, params[i], eps=self.blocks[i].norm1.eps)
         cls = h if (last >= 0 and self.cls_only_last_block) else F_.take_token(h, 0)

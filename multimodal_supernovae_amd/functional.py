@@ -760,21 +760,25 @@ class _PreNormLastBlock(torch.autograd.Function):
         kv = sgemm(h1, wqkv[e:], OP_N, OP_T, bias=bqkv[e:])                   # keys | values of every token
         h1c = h1.view(B, T, e)[:, 0, :]                                       # class rows (row stride T * e)
         q = sgemm(h1c, wqkv[:e], OP_N, OP_T, bias=bqkv[:e])                   # (B, e): the one query per sample
-        kv3 = kv.view(B, T, 2 * e)
-        a, lse = ops.attention_fwd(q.view(B, 1, e), kv3[..., :e], kv3[..., e:], None, heads, scale)
-        a2 = a.view(B, e)
+        cls_kernels = ops.cls_attention_supported(T, e // heads)                # one query per (sample, head): csrc/cls_attention.hip
+        if cls_kernels:
+            a2, lse = ops.cls_attention_fwd(q, kv, T, heads, scale)             # (lse: the probabilities here)
+        else:
+            kv3 = kv.view(B, T, 2 * e)
+            a, lse = ops.attention_fwd(q.view(B, 1, e), kv3[..., :e], kv3[..., e:], None, heads, scale)
+            a2 = a.view(B, e)
         x1 = sgemm(a2, wo, OP_N, OP_T, bias=bo, epilogue=EPI_ADD, aux=x3[:, 0, :])
         h2, m2, r2 = ops.layernorm_fwd(x1, g2, b2, eps)
         pre = torch.empty((B, w1.shape[0]), dtype=torch.float32, device=x.device)
         f = sgemm(h2, w1, OP_N, OP_T, bias=c1, epilogue=EPI_GELU, aux=pre)
         out = sgemm(f, w2, OP_N, OP_T, bias=c2, epilogue=EPI_ADD, aux=x1)
-        ctx.dims = (B, T, e, heads, scale)
+        ctx.dims = (B, T, e, heads, scale, cls_kernels)
         ctx.save_for_backward(x2, g1, wqkv, wo, g2, w1, w2, m1, r1, h1, kv, q, a2, lse, x1, m2, r2, h2, pre, f)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        B, T, e, heads, scale = ctx.dims
+        B, T, e, heads, scale, cls_kernels = ctx.dims
         (x2, g1, wqkv, wo, g2, w1, w2, m1, r1, h1, kv, q, a2, lse, x1, m2, r2, h2, pre, f) = ctx.saved_tensors
         d = _c(dy)
         dw2, dc2 = ops.wgrad_bias(d, f)
@@ -784,12 +788,15 @@ class _PreNormLastBlock(torch.autograd.Function):
         dx1, dg2, db2 = ops.layernorm_bwd(dh2, x1, m2, r2, g2, add=d)         # + skip connection
         dwo, dbo = ops.wgrad_bias(dx1, a2)
         da = sgemm(dx1, wo, OP_N, OP_N)
-        dq = torch.empty((B, 1, e), dtype=torch.float32, device=d.device)
-        dkv = torch.empty_like(kv)
-        kv3, d3 = kv.view(B, T, 2 * e), dkv.view(B, T, 2 * e)
-        ops.attention_bwd(q.view(B, 1, e), kv3[..., :e], kv3[..., e:], None, heads, scale, a2.view(B, 1, e), lse,
-                          da.view(B, 1, e), dq, d3[..., :e], d3[..., e:])
-        dq2 = dq.view(B, e)
+        if cls_kernels:
+            dq2, dkv = ops.cls_attention_bwd(q, kv, T, heads, scale, a2, lse, da)
+        else:
+            dq = torch.empty((B, 1, e), dtype=torch.float32, device=d.device)
+            dkv = torch.empty_like(kv)
+            kv3, d3 = kv.view(B, T, 2 * e), dkv.view(B, T, 2 * e)
+            ops.attention_bwd(q.view(B, 1, e), kv3[..., :e], kv3[..., e:], None, heads, scale, a2.view(B, 1, e), lse,
+                              da.view(B, 1, e), dq, d3[..., :e], d3[..., e:])
+            dq2 = dq.view(B, e)
         h1c = h1.view(B, T, e)[:, 0, :]
         dwqkv = torch.empty_like(wqkv)
         dbqkv = torch.empty(3 * e, dtype=torch.float32, device=d.device)
@@ -803,8 +810,66 @@ class _PreNormLastBlock(torch.autograd.Function):
         return (dx.view(B, T, e), None, None, dg1, db1, dwqkv, dbqkv, dwo, dbo, dg2, db2, dw1, dc1, dw2, dc2)
 
 
-def pre_norm_last_block(x, heads, p, eps=1e-6):
-    """(B, T, e) -> (B, e): the class-token row of pre_norm_block(x, ...)."""
+class _Bf16LastBlock(torch.autograd.Function):
+    """_PreNormLastBlock for the bf16-RESIDENT tower (BASELINE cfg5; arithmetic of _Bf16VitTrunk below): the three products of
+    the block that run over every token -- the key | value projection, its input gradient and its weight gradient -- take bf16
+    operands from HBM on msn_bgemm_nt / msn_bgemm_tn (LayerNorm writes bf16, the projection writes bf16 keys | values, the
+    class-token attention reads them and writes a bf16 gradient) instead of rounding fp32 operands inside the older 128 x 128
+    kernel; the class-row products (B rows) stay where they were.  Same output and gradients as _PreNormLastBlock under the
+    "bf16" GEMM precision up to the bf16 storage of keys | values and their gradient."""
+
+    @staticmethod
+    def forward(ctx, x, heads, eps, g1, b1, wqkv, bqkv, wo, bo, g2, b2, w1, c1, w2, c2):
+        B, T, e = x.shape
+        x3 = _c(x)
+        x2 = x3.view(B * T, e)
+        scale = 1.0 / math.sqrt(e // heads)
+        h1, m1, r1 = ops.layernorm_fwd_bf16(x2, g1, b1, eps)
+        kv = ops.bgemm_nt(h1, ops.cast_bf16(wqkv[e:]), bias=bqkv[e:], out_bf16=True)   # keys | values of every token, bf16
+        h1c = h1.view(B, T, e)[:, 0, :].float()                               # class rows
+        q = sgemm(h1c, wqkv[:e], OP_N, OP_T, bias=bqkv[:e])                   # (B, e): the one query per sample
+        a2, probs = ops.cls_attention_fwd(q, kv, T, heads, scale)
+        x1 = sgemm(a2, wo, OP_N, OP_T, bias=bo, epilogue=EPI_ADD, aux=x3[:, 0, :])
+        h2, m2, r2 = ops.layernorm_fwd(x1, g2, b2, eps)
+        pre = torch.empty((B, w1.shape[0]), dtype=torch.float32, device=x.device)
+        f = sgemm(h2, w1, OP_N, OP_T, bias=c1, epilogue=EPI_GELU, aux=pre)
+        out = sgemm(f, w2, OP_N, OP_T, bias=c2, epilogue=EPI_ADD, aux=x1)
+        ctx.dims = (B, T, e, heads, scale)
+        ctx.save_for_backward(x2, g1, wqkv, wo, g2, w1, w2, m1, r1, h1, kv, q, a2, probs, x1, m2, r2, h2, pre, f)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, e, heads, scale = ctx.dims
+        (x2, g1, wqkv, wo, g2, w1, w2, m1, r1, h1, kv, q, a2, probs, x1, m2, r2, h2, pre, f) = ctx.saved_tensors
+        d = _c(dy)
+        dw2, dc2 = ops.wgrad_bias(d, f)
+        dpre = sgemm(d, w2, OP_N, OP_N, epilogue=EPI_GELU_BWD, aux=pre)
+        dw1, dc1 = ops.wgrad_bias(dpre, h2)
+        dh2 = sgemm(dpre, w1, OP_N, OP_N)
+        dx1, dg2, db2 = ops.layernorm_bwd(dh2, x1, m2, r2, g2, add=d)         # + skip connection
+        dwo, dbo = ops.wgrad_bias(dx1, a2)
+        da = sgemm(dx1, wo, OP_N, OP_N)
+        dq2, dkv = ops.cls_attention_bwd(q, kv, T, heads, scale, a2, probs, da)   # dkv: bf16, the operand of the two products below
+        h1c = h1.view(B, T, e)[:, 0, :].float()
+        dwqkv = torch.empty_like(wqkv)
+        dbqkv = torch.empty(3 * e, dtype=torch.float32, device=d.device)
+        ops.wgrad_bias(dq2, h1c, out=(dwqkv[:e], dbqkv[:e]))
+        dwqkv[e:].copy_(ops.bgemm_tn(dkv, h1))
+        dbqkv[e:].copy_(ops.bcolsum(dkv))
+        dh1 = ops.bgemm_nt(dkv, ops.cast_bf16_t(wqkv[e:]))                    # fp32: the class rows take the query branch below
+        dh1c = dh1.view(B, T, e)[:, 0, :]
+        sgemm(dq2, wqkv[:e], OP_N, OP_N, epilogue=EPI_ADD, aux=dh1c, out=dh1c)
+        dx, dg1, db1 = ops.layernorm_bwd(dh1, x2, m1, r1, g1)
+        ops.add_rows(dx.view(B, T, e)[:, 0, :], dx1)                          # skip connection of the class rows
+        return (dx.view(B, T, e), None, None, dg1, db1, dwqkv, dbqkv, dwo, dbo, dg2, db2, dw1, dc1, dw2, dc2)
+
+
+def pre_norm_last_block(x, heads, p, eps=1e-6, bf16_resident=False):
+    """(B, T, e) -> (B, e): the class-token row of pre_norm_block(x, ...).  bf16_resident: the form for the bf16-resident tower."""
+    B, T, e = x.shape
+    if bf16_resident and e % 64 == 0 and ops.cls_attention_supported(T, e // heads):
+        return _Bf16LastBlock.apply(x, heads, eps, *p)
     return _PreNormLastBlock.apply(x, heads, eps, *p)
 
 
@@ -897,6 +962,37 @@ class _Bf16VitTrunk(torch.autograd.Function):
             d2, d2b, dg1, db1, dc2 = ops.layernorm_bwd_bf16(dh1, x2, m1, r1, g1, add=dx1, want_colsum=True)   # + skip
             grads[12 * i], grads[12 * i + 1] = dg1, db1
         return (d2.view(B, T, e), None, None, None, *grads)
+
+
+class _Bf16Linear(torch.autograd.Function):
+    """y = x W^T + b with bf16-resident operands (msn_bgemm_nt / msn_bgemm_tn): the patch embedding of the bf16-resident tower --
+    100 352 x 768 x 768 at cfg5, which the older 128 x 128 kernel ran from fp32 operands at a quarter of the rate."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        shape = x.shape
+        xb = ops.cast_bf16(_c(x).view(-1, shape[-1]))
+        y = ops.bgemm_nt(xb, ops.cast_bf16(_c(w)), bias=b)
+        ctx.save_for_backward(xb, w)
+        ctx.shape, ctx.need_dx = shape, x.requires_grad
+        return y.view(*shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, w = ctx.saved_tensors
+        d = _c(dy).view(-1, dy.shape[-1])
+        db16 = ops.cast_bf16(d)
+        dw = ops.bgemm_tn(db16, xb)
+        dx = ops.bgemm_nt(db16, ops.cast_bf16_t(_c(w))).view(ctx.shape) if ctx.need_dx else None
+        return dx, dw, colsum(d)
+
+
+def bf16_linear(x, weight, bias):
+    """nn.Linear on the bf16-resident kernels (K % 64 == 0, N % 4 == 0, rows x K % 8 == 0); else `linear`."""
+    K, N = x.shape[-1], weight.shape[0]
+    if K % 64 == 0 and N % 4 == 0 and bias is not None and x.numel() % 8 == 0 and weight.numel() % 8 == 0:
+        return _Bf16Linear.apply(x, weight, bias)
+    return linear(x, weight, bias)
 
 
 def bf16_vit_trunk(x, heads, eps, block_params):

@@ -1123,6 +1123,41 @@ def attention_fwd_planes(qkv, heads, scale, planes=None, mask_u8=None):
 
 
 
+def cls_attention_supported(T, head_dim):
+    return bool(lib().msn_cls_attention_supported(int(T), int(head_dim)))
+
+
+def _kv_rows(kv, B, T, e):
+    assert kv.dim() == 2 and kv.shape[0] == B * T and kv.shape[1] == 2 * e and kv.stride(1) == 1 and kv.dtype in (torch.float32, torch.bfloat16)
+    return 1 if kv.dtype == torch.bfloat16 else 0
+
+
+def cls_attention_fwd(q, kv, T, heads, scale):
+    """One query per (sample, head) over T keys (the class-token row of the ViT's last block): q (B, e) fp32, kv (B T, 2 e) fp32 or
+    bf16 rows (keys | values) -> (out (B, e) fp32, probabilities (B, heads, T) fp32 for the backward).  msn_cls_attention_fwd."""
+    B, e = q.shape
+    _f32c(q, "q")
+    bf = _kv_rows(kv, B, T, e)
+    out = torch.empty((B, e), dtype=torch.float32, device=q.device)
+    probs = torch.empty((B, heads, T), dtype=torch.float32, device=q.device)
+    check(lib().msn_cls_attention_fwd(ptr(q), q.stride(0), ptr(kv), kv.stride(0), bf, B, heads, T, e // heads, scale, ptr(out), e,
+                                      ptr(probs), stream_ptr()), "msn_cls_attention_fwd")
+    return out, probs
+
+
+def cls_attention_bwd(q, kv, T, heads, scale, out, probs, dout):
+    """-> (dq (B, e) fp32, dkv (B T, 2 e) in kv's type).  msn_cls_attention_bwd."""
+    B, e = q.shape
+    bf = _kv_rows(kv, B, T, e)
+    _f32c(dout, "dout")
+    dq = torch.empty((B, e), dtype=torch.float32, device=q.device)
+    dkv = torch.empty((B * T, 2 * e), dtype=kv.dtype, device=q.device)
+    check(lib().msn_cls_attention_bwd(ptr(q), q.stride(0), ptr(kv), kv.stride(0), bf, B, heads, T, e // heads, scale, ptr(out),
+                                      out.stride(0), ptr(probs), ptr(dout), dout.stride(0), ptr(dq), e, ptr(dkv), 2 * e, stream_ptr()),
+          "msn_cls_attention_bwd")
+    return dq, dkv
+
+
 def attention_fwd_planes_supported(T, head_dim):
     return T <= 128 and head_dim % 16 == 0 and head_dim <= 64
 
