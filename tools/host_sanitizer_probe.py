@@ -70,4 +70,13 @@ for bad in (lambda: L.msn_ffn_fwd(fake, 32, 100, 64, 256, fake, fake, fake, fake
             lambda: L.msn_ffn_bwd(fake, 32, fake, 32, 100, 32, 96, fake, fake, fake, fake, 32, fake, fake, fake, fake, fake, 1 << 30, None),
             lambda: L.msn_clock_probe(None, 100, None), lambda: L.msn_clock_probe(fake, 0, None)):
     assert bad() == 1, L.msn_last_error()
+# class-token attention (cls_attention.hip): the shapes it takes and the checks that return before a launch
+print("cls attention", L.msn_cls_attention_supported(197, 64), L.msn_cls_attention_supported(257, 64), L.msn_cls_attention_supported(65, 32))
+for bad in (lambda: L.msn_cls_attention_fwd(fake, 768, fake, 1536, 0, 2, 12, 300, 64, 0.125, fake, 768, fake, None),
+            lambda: L.msn_cls_attention_fwd(fake, 768, fake, 1536, 0, 2, 12, 197, 32, 0.125, fake, 768, fake, None),
+            lambda: L.msn_cls_attention_fwd(fake, 768, fake, 1530, 1, 2, 12, 197, 64, 0.125, fake, 768, fake, None),
+            lambda: L.msn_cls_attention_fwd(None, 768, fake, 1536, 0, 2, 12, 197, 64, 0.125, fake, 768, fake, None),
+            lambda: L.msn_cls_attention_bwd(fake, 768, fake, 1536, 1, 2, 12, 197, 64, 0.125, fake, 768, fake, fake, 768, fake, 760, fake, 1536, None),
+            lambda: L.msn_cls_attention_bwd(fake, 768, fake, 1536, 0, 2, 12, 197, 64, 0.125, fake, 768, fake, fake, 768, fake, 768, None, 1536, None)):
+    assert bad() == 1, L.msn_last_error()
 print("HOST SANITIZER PROBE OK")
