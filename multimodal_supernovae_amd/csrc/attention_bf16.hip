@@ -442,20 +442,33 @@ __global__ __launch_bounds__(64 * AWAVES) void battn_bwd_dkv_kernel(const BAttn 
     }
 }
 
-// out[n] = sum over the batch of part[b][n], eight independent loads per wait, fixed order
-__global__ void battn_colsum_finish_kernel(const float* __restrict__ part, int nparts, int N, float* __restrict__ out) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+// out[n] = sum over the batch of part[b][n]: 64 columns x 16 sample groups per workgroup (group rg sums samples rg, rg + 16, ...: eight
+// independent loads per wait), the group sums combined through LDS in a fixed order.  (One thread per column walked all 512 samples:
+// 64 dependent round trips on nine workgroups, 40 us per launch.)
+__global__ __launch_bounds__(1024) void battn_colsum_finish_kernel(const float* __restrict__ part, int nparts, int N, float* __restrict__ out) {
+    __shared__ float red[16][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int k0 = 0; k0 < nparts; k0 += 8) {
-        float v[8];
+    if (n < N) {
+        const int mine = (nparts - rg + 15) / 16;
+        for (int k0 = 0; k0 < mine; k0 += 8) {
+            float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = part[(int64_t)min(k0 + j, nparts - 1) * N + n];
+            for (int j = 0; j < 8; ++j) v[j] = part[(int64_t)(rg + 16 * min(k0 + j, mine - 1)) * N + n];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (k0 + j < nparts) s += v[j];
+            for (int j = 0; j < 8; ++j)
+                if (k0 + j < mine) s += v[j];
+        }
     }
-    out[n] = s;
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][cl];
+        out[n] = t;
+    }
 }
 
 static int check_battn(const char* who, int B, int H, int T, int64_t ld, int64_t ldo) {
@@ -504,7 +517,7 @@ extern "C" int msn_attention_bf16_bwd(const void* qkv, int64_t ld, const void* o
     hipLaunchKernelGGL(battn_bwd_dkv_kernel, dim3((unsigned)(B * H)), dim3(64 * AWAVES), 0, st, a);
     MSN_LAUNCH_CHECK();
     if (colsum_out) {
-        hipLaunchKernelGGL(battn_colsum_finish_kernel, dim3((unsigned)cdiv(3 * H * AHD, 256)), dim3(256), 0, st, colsum_ws, B,
+        hipLaunchKernelGGL(battn_colsum_finish_kernel, dim3((unsigned)cdiv(3 * H * AHD, 64)), dim3(1024), 0, st, colsum_ws, B,
                            3 * H * AHD, colsum_out);
         MSN_LAUNCH_CHECK();
     }
