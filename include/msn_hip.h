@@ -404,6 +404,15 @@ int msn_bgemm_tn(int64_t M, int N, int K, const void* A, int64_t lda, const void
                  void* ws, size_t ws_bytes, msn_stream_t stream);
 int msn_cast_bf16(const float* x, int64_t n, void* y, msn_stream_t stream);
 int msn_cast_bf16_transposed(const float* x, int R, int C, void* y, msn_stream_t stream);
+/* msn_cast_bf16 / msn_cast_bf16_transposed of a LIST of contiguous (R, C) fp32 matrices in ONE launch (the bf16-resident trunk: four
+ * weights per block forward, four transposed copies backward): y (R, C) or, transposed != 0, (C, R), bf16, round to nearest even. */
+typedef struct msn_cast_item {
+    const float* x;
+    int64_t R, C;
+    int transposed;
+    void* y;
+} msn_cast_item;
+int msn_cast_bf16_list(int n, const msn_cast_item* items, msn_stream_t stream);
 size_t msn_bcolsum_workspace_bytes(int64_t M, int N);
 int msn_bcolsum(const void* X, int64_t ldx, int64_t M, int N, float* out, void* ws, size_t ws_bytes, msn_stream_t stream);
 int msn_layernorm_fwd_bf16(const float* x, int64_t ldx, int64_t rows, int cols, const float* gamma, const float* beta,

@@ -32,6 +32,7 @@ SIGNATURES = {
     "msn_cls_attention_fwd": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_int, c_f32, c_ptr, c_i64, c_ptr, c_ptr]),
     "msn_cls_attention_bwd": (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_int, c_f32, c_ptr, c_i64, c_ptr, c_ptr,
                                       c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
+    "msn_cast_bf16_list": (c_int, [c_int, c_ptr, c_ptr]),
     "msn_device_count": (c_int, []),
     "msn_sgemm_workspace_bytes": (c_size, [c_int, c_int, c_i64, c_i64, c_i64]),
     "msn_sgemm": (c_int, [c_int, c_int, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr,

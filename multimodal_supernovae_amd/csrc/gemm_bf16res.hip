@@ -718,6 +718,39 @@ __global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float* __restric
         if (c0 + i < C && r0 + tx < R) y[(int64_t)(c0 + i) * R + r0 + tx] = f2bf(t[tx][i]);
 }
 
+// A LIST of weight matrices rounded to bf16 in ONE launch (msn_cast_bf16_list): the bf16-resident trunk rounds four weights per block in
+// its forward and makes four transposed copies in its backward -- 94 launches of 6 - 10 us per step one by one.  Workgroup -> (entry,
+// 32 x 32 tile) through the entries' first-workgroup table (kernel argument); plain entries
+// copy row-wise through the same tile shape, transposed ones go through the 32 x 33 LDS tile of cast_bf16_t_kernel.
+constexpr int CAST_LIST_MAX = 64;
+struct CastEntry {
+    const float* x; u16* y;
+    int R, C, transposed, first, tiles_x;
+};
+struct CastTable {
+    int n;
+    CastEntry e[CAST_LIST_MAX];
+};
+__global__ __launch_bounds__(256) void cast_bf16_list_kernel(const CastTable tb) {
+    __shared__ float t[32][33];
+    int k = 0;
+    for (int j = 1; j < tb.n; ++j) k = (int)blockIdx.x >= tb.e[j].first ? j : k;          // (uniform; at most 64 entries)
+    const CastEntry e = tb.e[k];
+    const int tile = (int)blockIdx.x - e.first;
+    const int r0 = (tile / e.tiles_x) * 32, c0 = (tile % e.tiles_x) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if (e.transposed) {
+        for (int i = ty; i < 32; i += 8)
+            t[i][tx] = (r0 + i < e.R && c0 + tx < e.C) ? e.x[(int64_t)(r0 + i) * e.C + c0 + tx] : 0.f;
+        __syncthreads();
+        for (int i = ty; i < 32; i += 8)
+            if (c0 + i < e.C && r0 + tx < e.R) e.y[(int64_t)(c0 + i) * e.R + r0 + tx] = f2bf(t[tx][i]);
+    } else {
+        for (int i = ty; i < 32; i += 8)
+            if (r0 + i < e.R && c0 + tx < e.C) e.y[(int64_t)(r0 + i) * e.C + c0 + tx] = f2bf(e.x[(int64_t)(r0 + i) * e.C + c0 + tx]);
+    }
+}
+
 // out[n] = sum_m X[m][n] for bf16 X: block partials of 8 columns per thread, then one fixed-order pass
 __global__ __launch_bounds__(256) void bcolsum_part_kernel(const u16* __restrict__ x, int64_t ld, int64_t M, int N8,
                                                            int rows_per_block, float* __restrict__ part) {
@@ -898,6 +931,29 @@ extern "C" int msn_cast_bf16_transposed(const float* x, int R, int C, void* y, m
     hipLaunchKernelGGL(cast_bf16_t_kernel, dim3((unsigned)cdiv(C, 32), (unsigned)cdiv(R, 32)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, R, C, static_cast<u16*>(y));
     MSN_LAUNCH_CHECK();
+    return MSN_OK;
+}
+
+extern "C" int msn_cast_bf16_list(int n, const msn_cast_item* items, msn_stream_t stream) {
+    MSN_REQUIRE(items && n > 0, "msn_cast_bf16_list: empty list");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int base = 0; base < n; base += CAST_LIST_MAX) {
+        CastTable tb = {};
+        tb.n = std::min(n - base, CAST_LIST_MAX);
+        int64_t wgs = 0;
+        for (int k = 0; k < tb.n; ++k) {
+            const msn_cast_item& it = items[base + k];
+            MSN_REQUIRE(it.x && it.y && it.R > 0 && it.C > 0 && it.R < (1ll << 31) && it.C < (1ll << 31), "msn_cast_bf16_list: bad item %d", base + k);
+            CastEntry& e = tb.e[k];
+            e.x = it.x, e.y = static_cast<u16*>(it.y), e.R = (int)it.R, e.C = (int)it.C, e.transposed = it.transposed ? 1 : 0;
+            e.first = (int)wgs;
+            e.tiles_x = (int)cdiv(it.C, 32);
+            wgs += cdiv(it.R, 32) * cdiv(it.C, 32);
+            MSN_REQUIRE(wgs < (1ll << 31), "msn_cast_bf16_list: list too large");
+        }
+        hipLaunchKernelGGL(cast_bf16_list_kernel, dim3((unsigned)wgs), dim3(256), 0, st, tb);
+        MSN_LAUNCH_CHECK();
+    }
     return MSN_OK;
 }
 

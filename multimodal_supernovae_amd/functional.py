@@ -897,23 +897,26 @@ class _Bf16VitTrunk(torch.autograd.Function):
         x2 = _c(x).view(M, e)
         saved = []
         empty = x2.new_empty(0)
+        # every block's four weights rounded to bf16 by ONE launch (with the backward's transposed copies: 94 launches of 6 - 10 us per step)
+        wb = ops.cast_bf16_list([_c(P[12 * i + j]) for i in range(n_blocks) for j in (2, 4, 8, 10)])
         for i in range(n_blocks):
             g1, b1, wqkv, bqkv, wo, bo, g2, b2, w1, c1, w2, c2 = P[12 * i: 12 * i + 12]
+            wqkv_b, wo_b, w1_b, w2_b = wb[4 * i: 4 * i + 4]
             h1, m1, r1 = ops.layernorm_fwd_bf16(x2, g1, b1, eps)
             if battn:
-                qkv = ops.bgemm_nt(h1, ops.cast_bf16(wqkv), bias=bqkv, out_bf16=True)
+                qkv = ops.bgemm_nt(h1, wqkv_b, bias=bqkv, out_bf16=True)
                 ab, lse = ops.attention_bf16_fwd(qkv, B, T, heads, scale)
                 a2 = empty
             else:
-                qkv = ops.bgemm_nt(h1, ops.cast_bf16(wqkv), bias=bqkv)                # fp32: the fp32 attention kernels' input
+                qkv = ops.bgemm_nt(h1, wqkv_b, bias=bqkv)                             # fp32: the fp32 attention kernels' input
                 q3 = qkv.view(B, T, 3 * e)
                 a, lse = ops.attention_fwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], None, heads, scale)
                 a2 = a.view(M, e)
                 ab = ops.cast_bf16(a2)
-            x1 = ops.bgemm_nt(ab, ops.cast_bf16(wo), bias=bo, epilogue=ops.BEPI_ADD, aux=x2)
+            x1 = ops.bgemm_nt(ab, wo_b, bias=bo, epilogue=ops.BEPI_ADD, aux=x2)
             h2, m2, r2 = ops.layernorm_fwd_bf16(x1, g2, b2, eps)
-            f, pre = ops.bgemm_nt(h2, ops.cast_bf16(w1), bias=c1, epilogue=ops.BEPI_GELU, out_bf16=True)
-            out = ops.bgemm_nt(f, ops.cast_bf16(w2), bias=c2, epilogue=ops.BEPI_ADD, aux=x1)
+            f, pre = ops.bgemm_nt(h2, w1_b, bias=c1, epilogue=ops.BEPI_GELU, out_bf16=True)
+            out = ops.bgemm_nt(f, w2_b, bias=c2, epilogue=ops.BEPI_ADD, aux=x1)
             saved += [x2, m1, r1, h1, qkv, a2, ab, lse, x1, m2, r2, h2, pre, f]
             x2 = out
         ctx.dims = (B, T, e, heads, scale, n_blocks, battn)
@@ -931,25 +934,28 @@ class _Bf16VitTrunk(torch.autograd.Function):
         d2 = _c(dy).view(M, e)
         d2b = ops.cast_bf16(d2)
         dc2 = colsum(d2)                      # bias gradient of the last block's second MLP layer; the other blocks get
+        # the transposed bf16 weight copies of every block from ONE launch
+        wt = ops.cast_bf16_list([_c(P[12 * i + j]) for i in range(n_blocks) for j in (2, 4, 8, 10)], transposed=True)
         for i in range(n_blocks - 1, -1, -1):  # theirs from the LayerNorm backward that produced their d2
             x2, m1, r1, h1, qkv, a2, ab, lse, x1, m2, r2, h2, pre, f = acts[NS * i: NS * i + NS]
             g1, b1, wqkv, bqkv, wo, bo, g2, b2, w1, c1, w2, c2 = P[12 * i: 12 * i + 12]
+            wqkv_t, wo_t, w1_t, w2_t = wt[4 * i: 4 * i + 4]
             # input gradients dX = dY . W are NT products against the transposed bf16 weight copy (K-contiguous operands);
             # every bias gradient (a column sum of a gradient matrix) comes out of the kernel that writes that matrix
             dw2 = ops.bgemm_tn(d2b, f)
-            dpre, dc1 = ops.bgemm_nt(d2b, ops.cast_bf16_t(w2), epilogue=ops.BEPI_GELU_BWD, aux=pre, out_bf16=True,
+            dpre, dc1 = ops.bgemm_nt(d2b, w2_t, epilogue=ops.BEPI_GELU_BWD, aux=pre, out_bf16=True,
                                      want_colsum=True)
             dw1 = ops.bgemm_tn(dpre, h2)
             # (the gradients entering the LayerNorm backwards leave their products as bf16 -- what autocast's dgrad gives: 155 MB less
             #  out of each epilogue and into each LayerNorm backward at 100 864 x 768; BF16_DGRAD = False: fp32)
-            dh2 = ops.bgemm_nt(dpre, ops.cast_bf16_t(w1), out_bf16=BF16_DGRAD)
+            dh2 = ops.bgemm_nt(dpre, w1_t, out_bf16=BF16_DGRAD)
             dx1, dx1b, dg2, db2, dbo = ops.layernorm_bwd_bf16(dh2, x1, m2, r2, g2, add=d2, want_colsum=True)   # + skip
             dwo = ops.bgemm_tn(dx1b, ab)
             if battn:
-                da = ops.bgemm_nt(dx1b, ops.cast_bf16_t(wo), out_bf16=True)
+                da = ops.bgemm_nt(dx1b, wo_t, out_bf16=True)
                 dqkvb, dbqkv = ops.attention_bf16_bwd(qkv, ab, da, lse, B, T, heads, scale, want_colsum=True)
             else:
-                da = ops.bgemm_nt(dx1b, ops.cast_bf16_t(wo))
+                da = ops.bgemm_nt(dx1b, wo_t)
                 dqkv = torch.empty_like(qkv)
                 q3, d3 = qkv.view(B, T, 3 * e), dqkv.view(B, T, 3 * e)
                 ops.attention_bwd(q3[..., :e], q3[..., e:2 * e], q3[..., 2 * e:], None, heads, scale, a2.view(B, T, e), lse,
@@ -957,7 +963,7 @@ class _Bf16VitTrunk(torch.autograd.Function):
                 dqkvb = ops.cast_bf16(dqkv)
                 dbqkv = colsum(dqkv)
             dwqkv = ops.bgemm_tn(dqkvb, h1)
-            dh1 = ops.bgemm_nt(dqkvb, ops.cast_bf16_t(wqkv), out_bf16=BF16_DGRAD)
+            dh1 = ops.bgemm_nt(dqkvb, wqkv_t, out_bf16=BF16_DGRAD)
             grads[12 * i: 12 * i + 12] = [None, None, dwqkv, dbqkv, dwo, dbo, dg2, db2, dw1, dc1, dw2, dc2]
             d2, d2b, dg1, db1, dc2 = ops.layernorm_bwd_bf16(dh1, x2, m1, r1, g1, add=dx1, want_colsum=True)   # + skip
             grads[12 * i], grads[12 * i + 1] = dg1, db1

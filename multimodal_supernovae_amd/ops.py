@@ -882,6 +882,27 @@ def cast_bf16_t(w):
     return y
 
 
+class _CastItem(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("R", ctypes.c_int64), ("C", ctypes.c_int64), ("transposed", ctypes.c_int), ("y", ctypes.c_void_p)]
+
+
+def cast_bf16_list(mats, transposed=False):
+    """bf16 copies (transposed: (C, R) copies) of a list of contiguous 2-D fp32 matrices from ONE launch (msn_cast_bf16_list)."""
+    if not mats:
+        return []
+    items = (_CastItem * len(mats))()
+    outs = []
+    for i, w in enumerate(mats):
+        _f32c(w, "w")
+        assert w.dim() == 2 and w.is_contiguous()
+        R, C = w.shape
+        y = torch.empty((C, R) if transposed else (R, C), dtype=torch.bfloat16, device=w.device)
+        items[i].x, items[i].R, items[i].C, items[i].transposed, items[i].y = ptr(w), R, C, 1 if transposed else 0, ptr(y)
+        outs.append(y)
+    check(lib().msn_cast_bf16_list(len(mats), ctypes.cast(items, ctypes.c_void_p), stream_ptr()), "msn_cast_bf16_list")
+    return outs
+
+
 def bcolsum(x):
     """Column sums of a bf16 (M, N) matrix -> (N,) fp32."""
     _bf16c(x, "x")

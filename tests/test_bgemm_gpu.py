@@ -196,3 +196,16 @@ def test_nt_persistent_workgroups_equal_one_tile_launches(M, N, K, epi):
     assert len(parts) > 1
     for k, t in enumerate(whole):
         assert torch.equal(t, torch.cat([p[k] for p in parts]))
+
+
+def test_cast_bf16_list_matches_torch():
+    """msn_cast_bf16_list: plain and transposed bf16 copies of a list of matrices from one launch == torch's round-to-nearest-even."""
+    from multimodal_supernovae_amd import ops
+    g = torch.Generator().manual_seed(3)
+    mats = [torch.randn(r, c, generator=g).cuda() for r, c in [(2304, 768), (768, 768), (40, 72), (1, 8), (33, 31), (3072, 768)]]
+    for transposed in (False, True):
+        outs = ops.cast_bf16_list(mats, transposed=transposed)
+        for w, y in zip(mats, outs):
+            want = (w.t().contiguous() if transposed else w).to(torch.bfloat16)
+            assert y.shape == want.shape and torch.equal(y, want)
+    assert ops.cast_bf16_list([]) == []
