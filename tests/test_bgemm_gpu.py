@@ -13,7 +13,8 @@ def _ints(shape, g, lo=-4, hi=5):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (16, 8, 64), (300, 264, 192), (1000, 768, 768),
-                                   (513, 2304, 768), (777, 768, 3072), (4096, 3072, 768)])
+                                   (513, 2304, 768), (777, 768, 3072), (4096, 3072, 768),
+                                   (300, 260, 192), (70, 132, 64)])      # N % 8 == 4: bf16 rows not 16-byte aligned (8-byte stores)
 def test_nt_exact_on_integers(M, N, K):
     from multimodal_supernovae_amd import ops
     g = torch.Generator().manual_seed(M + N + K)
@@ -27,7 +28,7 @@ def test_nt_exact_on_integers(M, N, K):
     torch.testing.assert_close(cb.cpu().double(), (a.double() @ w.double().T).to(torch.bfloat16).double(), rtol=0, atol=0)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 264, 192), (2048, 768, 768), (1030, 3072, 768)])
+@pytest.mark.parametrize("M,N,K", [(300, 264, 192), (2048, 768, 768), (1030, 3072, 768), (300, 260, 192), (513, 388, 128)])
 def test_nt_epilogues(M, N, K):
     from multimodal_supernovae_amd import ops
     g = torch.Generator().manual_seed(7)
@@ -93,7 +94,7 @@ def test_casts_colsum_and_layernorm_variants():
     torch.testing.assert_close(cs.double(), dx32.double().sum(0), rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 264, 192), (4000, 3072, 768), (257, 768, 64)])
+@pytest.mark.parametrize("M,N,K", [(300, 264, 192), (4000, 3072, 768), (257, 768, 64), (300, 260, 192)])
 def test_nt_epilogue_column_sums(M, N, K):
     """Bias gradients from the epilogue of the product that writes the gradient matrix: out[n] = sum_m C[m][n] of the
     values AS STORED (bf16-rounded when C is bf16), for the plain and the GELU' epilogue."""
