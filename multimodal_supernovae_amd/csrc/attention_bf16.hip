@@ -60,6 +60,15 @@ __device__ __forceinline__ void a_read128(bf16x8& dst, unsigned addr) { asm vola
 __device__ __forceinline__ void a_read_tr(bf16x4& dst, unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr));
 }
+// (the same with an immediate byte offset: the tile index of an image read is added by the instruction, not by the vector ALU)
+template <int OFF>
+__device__ __forceinline__ void a_read128_o(bf16x8& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void a_read_tr_o(bf16x4& dst, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
 __device__ __forceinline__ void a_wait_lds() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -165,60 +174,82 @@ __global__ __launch_bounds__(64 * AWAVES) void battn_fwd_kernel(const BAttn p) {
     const int ntile = (T + 15) / 16, nblk = (T + 31) / 32;
     const float sl = p.scale * ALOG2E;
 
+    // Lane addresses of the image reads, once per kernel: the XOR swizzle depends on the row INSIDE a 16-token tile only, so tile t of an
+    // image is +2048 t bytes -- an immediate offset of the read -- and a 32-key block +4096 j: one vector add per address and block.
+    // (Recomputed per read they were 24 of the ~165 vector instructions per block against 8 MFMAs; the kernel's vector-instruction
+    //  issue time was 3.5 x its matrix time: profiles/r06_battn_counters.txt.)
+    const unsigned kb0 = kimg + row_frag_addr(0, 0, l15, g), kb1 = kimg + row_frag_addr(0, 1, l15, g);
+    unsigned vb[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vb[dt] = vimg + tr_frag_addr(0, dt, g, tq, tp);
+    const bool ragged = (T & 31) != 0;                    // the last 32-key block holds keys past the sequence
+
     for (int qt = wave; qt < ntile; qt += AWAVES) {
         bf16x8 qf[2];
         load_rows(qf, base, p.ld, 16 * qt, T, l15, g);
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float m = -INFINITY, l = 0.f;                       // running max (log2 domain) and sum of this lane's query
+        float m = -INFINITY, l = 0.f;                       // running max (log2 domain); this LANE's share of the sum (its keys 4 g .. + 3)
         for (int j = 0; j < nblk; ++j) {
             // scores of 32 keys (tiles 2j, 2j+1): S^T tile = K_tile . Q^T -> lane: query l15, keys 4g..4g+3 of each tile
+            const unsigned boff = (unsigned)j * 4096u;
             bf16x8 kf[2][2];
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) a_read128(kf[t2][kk], kimg + row_frag_addr(2 * j + t2, kk, l15, g));
+            a_read128_o<0>(kf[0][0], kb0 + boff);
+            a_read128_o<0>(kf[0][1], kb1 + boff);
+            a_read128_o<2048>(kf[1][0], kb0 + boff);
+            a_read128_o<2048>(kf[1][1], kb1 + boff);
             // V^T fragments of the same 32 keys for the four d tiles (transposed reads), requested early
             bf16x4 vf[4][2];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int t2 = 0; t2 < 2; ++t2) a_read_tr(vf[dt][t2], vimg + tr_frag_addr(2 * j + t2, dt, g, tq, tp));
+            for (int dt = 0; dt < 4; ++dt) {
+                a_read_tr_o<0>(vf[dt][0], vb[dt] + boff);
+                a_read_tr_o<2048>(vf[dt][1], vb[dt] + boff);
+            }
             a_wait_lds();
-            float s[2][4];
+            f32x4 acc[2];
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) {
-                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t2][0], qf[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t2][1], qf[1], acc, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[t2][r] = (32 * j + 16 * t2 + 4 * g + r < T) ? acc[r] * sl : -INFINITY;
+                acc[t2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t2][0], qf[0], acc[t2], 0, 0, 0);
+                acc[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t2][1], qf[1], acc[t2], 0, 0, 0);
             }
-            float bm = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])),
-                             fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
-            bm = group_max4(bm);
-            const float mn = fmaxf(m, bm);                   // finite: every block holds at least one real key
-            const float f = exp2f(m - mn);                   // 0 on the first block (m = -inf)
-            float ps = 0.f;
+            if (ragged && j == nblk - 1) {                  // (uniform) keys past the sequence score -inf: p = 0
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (32 * j + 16 * t2 + 4 * g + r >= T) acc[t2][r] = -INFINITY;
+            }
+            // block maximum on the raw scores (the scale is positive), scaled once
+            float bm = fmaxf(fmaxf(fmaxf(acc[0][0], acc[0][1]), fmaxf(acc[0][2], acc[0][3])),
+                             fmaxf(fmaxf(acc[1][0], acc[1][1]), fmaxf(acc[1][2], acc[1][3])));
+            bm = group_max4(bm) * sl;                        // finite: every block holds at least one real key
+            if (__any(bm > m)) {                             // (wave-uniform; rare once the running maximum has settled)
+                const float mn = fmaxf(m, bm);
+                const float f = __builtin_amdgcn_exp2f(m - mn);   // 0 on the first block (m = -inf)
+                m = mn;
+                l *= f;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[dt] *= f;
+            }
+            // p = exp2(s sl - m): one multiply-add and one v_exp_f32 per score (exp2f's range handling was five instructions more)
+            float s[2][4];
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    s[t2][r] = exp2f(s[t2][r] - mn);
-                    ps += s[t2][r];
+                    s[t2][r] = __builtin_amdgcn_exp2f(fmaf(acc[t2][r], sl, -m));
+                    l += s[t2][r];
                 }
-            l = l * f + group_sum4(ps);
-            m = mn;
             const bf16x8 pf = pack8(s[0], s[1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[dt][r] *= f;
                 const bf16x8 vv = __builtin_shufflevector(vf[dt][0], vf[dt][1], 0, 1, 2, 3, 4, 5, 6, 7);
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vv, pf, o[dt], 0, 0, 0);
             }
         }
+        l = group_sum4(l);                                   // the four lanes of a query hold its keys 4 g .. + 3 of every tile
         // lane: query 16 qt + l15, d = 16 dt + 4 g .. + 3
         const int q = 16 * qt + l15;
         if (q < T) {
@@ -254,6 +285,12 @@ __global__ __launch_bounds__(64 * AWAVES) void battn_bwd_dq_kernel(const BAttn p
 
     __shared__ float cst[AWAVES * 64];                   // per-wave column sums of dq (bias gradient), see add_tile_colsum
     if (lane < 64) cst[wave * 64 + lane] = 0.f;
+    // lane addresses of the image reads, once per kernel; tile t = + 2048 t (immediate), block j = + 4096 j (see the forward)
+    const unsigned kb0 = kimg + row_frag_addr(0, 0, l15, g), kb1 = kimg + row_frag_addr(0, 1, l15, g);
+    unsigned tb[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) tb[dt] = kimg + tr_frag_addr(0, dt, g, tq, tp);
+    const bool ragged = (T & 31) != 0;
     for (int qt = wave; qt < ntile; qt += AWAVES) {
         bf16x8 qf[2], df[2], of[2];
         load_rows(qf, base, p.ld, 16 * qt, T, l15, g);
@@ -273,22 +310,27 @@ __global__ __launch_bounds__(64 * AWAVES) void battn_bwd_dq_kernel(const BAttn p
         f32x4 dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float dls = dl * p.scale;
         for (int j = 0; j < nblk; ++j) {
+            const unsigned boff = (unsigned)j * 4096u;
             bf16x8 kf[2][2], vf[2][2];
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    a_read128(kf[t2][kk], kimg + row_frag_addr(2 * j + t2, kk, l15, g));
-                    a_read128(vf[t2][kk], vimg + row_frag_addr(2 * j + t2, kk, l15, g));
-                }
+            a_read128_o<0>(kf[0][0], kb0 + boff);
+            a_read128_o<0>(kf[0][1], kb1 + boff);
+            a_read128_o<2048>(kf[1][0], kb0 + boff);
+            a_read128_o<2048>(kf[1][1], kb1 + boff);
+            a_read128_o<AIMG>(vf[0][0], kb0 + boff);            // (the V image follows the K image)
+            a_read128_o<AIMG>(vf[0][1], kb1 + boff);
+            a_read128_o<AIMG + 2048>(vf[1][0], kb0 + boff);
+            a_read128_o<AIMG + 2048>(vf[1][1], kb1 + boff);
             bf16x4 kt[4][2];                                    // K^T fragments (transposed reads) for dQ^T += K^T dS^T
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int t2 = 0; t2 < 2; ++t2) a_read_tr(kt[dt][t2], kimg + tr_frag_addr(2 * j + t2, dt, g, tq, tp));
+            for (int dt = 0; dt < 4; ++dt) {
+                a_read_tr_o<0>(kt[dt][0], tb[dt] + boff);
+                a_read_tr_o<2048>(kt[dt][1], tb[dt] + boff);
+            }
             a_wait_lds();
             float ds[2][4];
+            const bool mask_now = ragged && j == nblk - 1;      // (uniform) keys past the sequence: p = 0
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) {
                 f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -298,9 +340,9 @@ __global__ __launch_bounds__(64 * AWAVES) void battn_bwd_dq_kernel(const BAttn p
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[t2][1], df[1], dp, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const bool live = 32 * j + 16 * t2 + 4 * g + r < T;
-                    const float pr = live ? exp2f(s[r] * sl - lse2) : 0.f;
-                    ds[t2][r] = pr * (dp[r] - dl) * p.scale;
+                    float pr = __builtin_amdgcn_exp2f(fmaf(s[r], sl, -lse2));       // (one multiply-add + v_exp_f32: exp2f carries range handling)
+                    if (mask_now && 32 * j + 16 * t2 + 4 * g + r >= T) pr = 0.f;
+                    ds[t2][r] = pr * fmaf(dp[r], p.scale, -dls);
                 }
             }
             const bf16x8 dsf = pack8(ds[0], ds[1]);
@@ -331,7 +373,7 @@ __global__ __launch_bounds__(64 * AWAVES) void battn_bwd_dq_kernel(const BAttn p
 // ------------------------------------------------------------------------------------------------------- dK, dV pass
 __global__ __launch_bounds__(64 * AWAVES) void battn_bwd_dkv_kernel(const BAttn p) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * AIMG];      // Q image | dO image
-    __shared__ float stat_l[AMAXT], stat_d[AMAXT];                               // lse * log2e, delta per query
+    __shared__ __attribute__((aligned(16))) float stat_l[AMAXT], stat_d[AMAXT];      // lse * log2e (+inf past the sequence), delta * scale per query
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
@@ -342,8 +384,8 @@ __global__ __launch_bounds__(64 * AWAVES) void battn_bwd_dkv_kernel(const BAttn 
     stage_image(lds + AIMG, p.dout + (int64_t)b * T * p.ldd + h * AHD, p.ldd, T, wave, lane);
     for (int i = threadIdx.x; i < AMAXT; i += 64 * AWAVES) {
         const int64_t st = ((int64_t)b * p.H + h) * T + min(i, T - 1);
-        stat_l[i] = p.lse[st] * ALOG2E;
-        stat_d[i] = p.delta[st];
+        stat_l[i] = i < T ? p.lse[st] * ALOG2E : INFINITY;       // a query past the sequence: p = exp2(-inf) = 0, no mask in the loop
+        stat_d[i] = i < T ? p.delta[st] * p.scale : 0.f;         // (delta arrives scaled: ds = p (dp scale - delta scale))
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -354,6 +396,11 @@ __global__ __launch_bounds__(64 * AWAVES) void battn_bwd_dkv_kernel(const BAttn 
     __shared__ float cst[2 * AWAVES * 64];               // per-wave column sums of dk | dv, see add_tile_colsum
     cst[wave * 64 + lane] = 0.f;
     cst[AWAVES * 64 + wave * 64 + lane] = 0.f;
+    // lane addresses of the image reads, once per kernel; tile t = + 2048 t (immediate), block j = + 4096 j, dO image = + AIMG (see the forward)
+    const unsigned qb0 = qimg + row_frag_addr(0, 0, l15, g), qb1 = qimg + row_frag_addr(0, 1, l15, g);
+    unsigned tb[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) tb[dt] = qimg + tr_frag_addr(0, dt, g, tq, tp);
     for (int kt = wave; kt < ntile; kt += AWAVES) {
         bf16x8 kf[2], vf[2];
         load_rows(kf, base + E, p.ld, 16 * kt, T, l15, g);
@@ -362,14 +409,16 @@ __global__ __launch_bounds__(64 * AWAVES) void battn_bwd_dkv_kernel(const BAttn 
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int j = 0; j < nblk; ++j) {                        // 32 queries per step
+            const unsigned boff = (unsigned)j * 4096u;
             bf16x8 qf[2][2], df[2][2];
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    a_read128(qf[t2][kk], qimg + row_frag_addr(2 * j + t2, kk, l15, g));
-                    a_read128(df[t2][kk], dimg + row_frag_addr(2 * j + t2, kk, l15, g));
-                }
+            a_read128_o<0>(qf[0][0], qb0 + boff);
+            a_read128_o<0>(qf[0][1], qb1 + boff);
+            a_read128_o<2048>(qf[1][0], qb0 + boff);
+            a_read128_o<2048>(qf[1][1], qb1 + boff);
+            a_read128_o<AIMG>(df[0][0], qb0 + boff);
+            a_read128_o<AIMG>(df[0][1], qb1 + boff);
+            a_read128_o<AIMG + 2048>(df[1][0], qb0 + boff);
+            a_read128_o<AIMG + 2048>(df[1][1], qb1 + boff);
             a_wait_lds();
             float pr[2][4], ds[2][4];
 #pragma unroll
@@ -380,12 +429,13 @@ __global__ __launch_bounds__(64 * AWAVES) void battn_bwd_dkv_kernel(const BAttn 
                 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[t2][1], kf[1], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[t2][0], vf[0], dp, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[t2][1], vf[1], dp, 0, 0, 0);
+                const f32x4 sl4 = *reinterpret_cast<const f32x4*>(stat_l + 32 * j + 16 * t2 + 4 * g);
+                const f32x4 sd4 = *reinterpret_cast<const f32x4*>(stat_d + 32 * j + 16 * t2 + 4 * g);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int qi = 32 * j + 16 * t2 + 4 * g + r;
-                    const float pv = qi < T ? exp2f(s[r] * sl - stat_l[qi]) : 0.f;
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], sl, -sl4[r]));   // (one multiply-add + v_exp_f32; -inf past the sequence)
                     pr[t2][r] = pv;
-                    ds[t2][r] = pv * (dp[r] - stat_d[qi]) * p.scale;
+                    ds[t2][r] = pv * fmaf(dp[r], p.scale, -sd4[r]);
                 }
             }
             const bf16x8 pf = pack8(pr[0], pr[1]), dsf = pack8(ds[0], ds[1]);
@@ -395,12 +445,12 @@ __global__ __launch_bounds__(64 * AWAVES) void battn_bwd_dkv_kernel(const BAttn 
             for (int half = 0; half < 2; ++half) {
                 bf16x4 qT[2][2], dT[2][2];
 #pragma unroll
-                for (int d2 = 0; d2 < 2; ++d2)
-#pragma unroll
-                    for (int t2 = 0; t2 < 2; ++t2) {
-                        a_read_tr(qT[d2][t2], qimg + tr_frag_addr(2 * j + t2, 2 * half + d2, g, tq, tp));
-                        a_read_tr(dT[d2][t2], dimg + tr_frag_addr(2 * j + t2, 2 * half + d2, g, tq, tp));
-                    }
+                for (int d2 = 0; d2 < 2; ++d2) {
+                    a_read_tr_o<0>(qT[d2][0], tb[2 * half + d2] + boff);
+                    a_read_tr_o<2048>(qT[d2][1], tb[2 * half + d2] + boff);
+                    a_read_tr_o<AIMG>(dT[d2][0], tb[2 * half + d2] + boff);
+                    a_read_tr_o<AIMG + 2048>(dT[d2][1], tb[2 * half + d2] + boff);
+                }
                 a_wait_lds();
 #pragma unroll
                 for (int d2 = 0; d2 < 2; ++d2) {
