@@ -838,6 +838,9 @@ extern "C" int msn_bgemm_nt(int64_t M, int N, int K, const void* A, int64_t lda,
     MSN_REQUIRE(lda >= K && ldb >= K && lda % 8 == 0 && ldb % 8 == 0 && aligned16(A) && aligned16(B),
                 "msn_bgemm_nt: operand rows must be 16-byte aligned (lda %lld, ldb %lld)", (long long)lda, (long long)ldb);
     MSN_REQUIRE(ldc >= N && ldc % 4 == 0 && aligned16(C) && (!bias || aligned16(bias)), "msn_bgemm_nt: bad output / bias");
+    // (the epilogue addresses a tile's 256 rows through one buffer descriptor and 32-bit offsets below 2^30)
+    MSN_REQUIRE(ldc < (1 << 20) && ldaux < (1 << 20), "msn_bgemm_nt: ldc = %lld / ldaux = %lld must be below 2^20 elements", (long long)ldc,
+                (long long)ldaux);
     MSN_REQUIRE(epilogue >= EPI_B_NONE && epilogue <= EPI_B_ADD, "msn_bgemm_nt: unknown epilogue %d", epilogue);
     MSN_REQUIRE(epilogue == EPI_B_NONE || (aux && ldaux >= N && ldaux % 4 == 0 && aligned16(aux)),
                 "msn_bgemm_nt: epilogue %d needs an aux matrix", epilogue);
