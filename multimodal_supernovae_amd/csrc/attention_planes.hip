@@ -695,9 +695,31 @@ __global__ __launch_bounds__(512, 4) void pattn_bwd_fused_kernel(const MAttn p) 
         }
         f32x4 kbg = {0.f, 0.f, 0.f, 0.f}, ksm = kbg, vbg = kbg, vsm = kbg;
         const int special = __any(liv == 0.f ? 1 : 0);    // this wave owns a key that is not live: the form with the v_min
+        // A wave whose 16 keys ALL lie past the sequence (the last key block of a 200- or 220-token series: 3 or 2 of its 8 waves) skips
+        // the score work -- its rows of the pair's dS^T patch are zeroed once here and never rewritten -- and, when its partner is past
+        // the sequence too, the pair's dQ product (its shares zeroed once): the kernel is bound by the instructions a SIMD issues, so
+        // what these waves do not issue the waves beside them do sooner.  (Zeroed behind the first barrier of the key block: the previous
+        // key block's last reads of the patch lie before its last barrier, those of the shares behind it.)
+        const int wave_u = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const bool dead = kb0 + 16 * wave_u >= p.Tk, pair_dead = kb0 + 32 * (wave_u >> 1) >= p.Tk;
         for (int i0 = 0; i0 < p.Tq; i0 += CHB) {
             const int nt = min(CHB, p.Tq - i0), nblk = (nt + 31) >> 5;
-            __syncthreads();                              // every wave is done with the previous chunk's images
+            __syncthreads();                              // every wave is done with the previous chunk's images (and shares)
+            if (i0 == 0) {
+                if (dead) {
+                    unsigned char* xw = Xp + xw_off;
+                    unsigned char* xw2 = Xp + (xw_off ^ 32);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        *reinterpret_cast<u32x2*>(xw + pl * PATCH) = u32x2{0u, 0u};
+                        *reinterpret_cast<u32x2*>(xw2 + pl * PATCH) = u32x2{0u, 0u};
+                    }
+                }
+                if (pair_dead) {
+                    const int te = opaque_tid(), ec = te & 15, eg = (te >> 4) & 3, epair = te >> 7, eqt = (te >> 6) & 1;
+                    *reinterpret_cast<f32x4*>(Ex + ((epair * 32 + 16 * eqt + ec) * 16 + 4 * (eg ^ ((ec >> 2) & 3)))) = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
             {
                 const int tid = opaque_tid();
                 sp.load(qsrc + (int64_t)i0 * p.ldq, dsrc + (int64_t)i0 * p.ldd, p.ldq, p.ldd, col0, nt, p.hd, tid);
@@ -732,6 +754,7 @@ __global__ __launch_bounds__(512, 4) void pattn_bwd_fused_kernel(const MAttn p) 
             for (int qb = 0; qb < nblk; ++qb) {
                 const unsigned char* qblk = Qi + qb * BLK;
                 const unsigned char* dblk = Di + qb * BLK;
+                if (!dead) {
                 float pr[8], ds[8];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -775,6 +798,7 @@ __global__ __launch_bounds__(512, 4) void pattn_bwd_fused_kernel(const MAttn p) 
                     *reinterpret_cast<u32x2*>(xw + 2 * PATCH) = u32x2{dsp.p2[0], dsp.p2[1]};
                     *reinterpret_cast<u32x2*>(xw2 + 2 * PATCH) = u32x2{dsp.p2[2], dsp.p2[3]};
                 }
+                }       // !dead
 #ifdef MSN_ABL_PATTN                         // diagnostic builds: bit 1 = no barriers in the block loop, bit 0 = no dq traffic (wrong results)
                 if (!(p.tail & 2))
 #endif
@@ -791,7 +815,7 @@ __global__ __launch_bounds__(512, 4) void pattn_bwd_fused_kernel(const MAttn p) 
                 if (!(p.tail & 1))
 #endif
                 if (kb0 > 0 && o_ok) old = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(optr));
-                {
+                if (!pair_dead) {
                     const unsigned char* xr = Xp + xr_off;
                     Planes8 w;
                     u32x4* wp[3] = {&w.p0, &w.p1, &w.p2};
