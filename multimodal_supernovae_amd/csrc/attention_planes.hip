@@ -151,6 +151,40 @@ __device__ __forceinline__ HeadFrags head_frags(const float (&v)[8], int g) {
     return f;
 }
 
+// ---- heads up to 8 wide: the 32 k of one instruction hold FOUR 8-column plane blocks, so the four small products share ONE instruction
+//   [a0 | a1 | a0 | a2] . [b1 | b0 | b2 | b0] = a0 b1 + a1 b0 + a0 b2 + a2 b0      then      [a0 | a1 | . | .] . [b0 | b1 | 0 | 0] += a0 b0 + a1 b1
+// -- two instead of three per 16 x 16 tile (the round-5 verdict's item 5).  Lane group g supplies columns 0 .. 7 of plane {0, 1, 0, 2}[g]
+// (small) / {0, 1, 0, 0}[g] (big: groups 2 - 3 are multiplied by zeros) of the A operand, {1, 0, 2, 0}[g] / {0, 1, -, -}[g] of the B operand.
+// The same struct carries them: f10 = the small-product operand, f01 = the big one.
+__device__ __forceinline__ void load_row8_narrow(float (&v)[8], const float* __restrict__ src, int64_t ld, int col0, int row, int T, int hd, float mul) {
+    const float* p = src + (int64_t)(row < T ? row : T - 1) * ld + col0;
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + (4 < hd ? 4 : 0));
+    const bool oka = row < T, okb = row < T && 4 < hd;
+    v[0] = oka ? a.x * mul : 0.f, v[1] = oka ? a.y * mul : 0.f, v[2] = oka ? a.z * mul : 0.f, v[3] = oka ? a.w * mul : 0.f;
+    v[4] = okb ? b.x * mul : 0.f, v[5] = okb ? b.y * mul : 0.f, v[6] = okb ? b.z * mul : 0.f, v[7] = okb ? b.w * mul : 0.f;
+}
+__device__ __forceinline__ HeadFrags head_frags_narrow(const float (&v)[8], int g) {
+    const Planes8 s = split8(v);
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    HeadFrags f;
+    f.f10 = as_frag(g == 0 ? s.p1 : g == 2 ? s.p2 : s.p0);          // [b1 | b0 | b2 | b0]
+    f.f01 = as_frag(g == 0 ? s.p0 : g == 1 ? s.p1 : zero);          // [b0 | b1 | 0 | 0]
+    f.f20 = f.f01;
+    return f;
+}
+// row fragments of the 16-row tile t of a block, columns 0 .. 7: a_small = [x0 | x1 | x0 | x2], a_big = [x0 | x1 | x0 | x0]
+__device__ __forceinline__ void row_frags_narrow(const unsigned char* blk, int t, int c, int g, bf16x8& a_small, bf16x8& a_big) {
+    const unsigned char* p = blk + t * 512 + c * 32;
+    a_small = *reinterpret_cast<const bf16x8*>(p + (g == 1 ? 1 : g == 3 ? 2 : 0) * PB);
+    a_big = *reinterpret_cast<const bf16x8*>(p + (g == 1 ? PB : 0));
+}
+__device__ __forceinline__ f32x4 head_product_narrow(const bf16x8& a_small, const bf16x8& a_big, const HeadFrags& b) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    s = mma(a_small, b.f10, s);
+    return mma(a_big, b.f01, s);
+}
+
 // ---- LDS images ------------------------------------------------------------------------------------------------------------
 // A chunk's rows of two matrices on their way into LDS: rows [0, nt) (row stride ld0 / ld1, columns col0 .. col0 + hd - 1) ->
 // the plane images img0 / img1 (blocks of 32 rows; rows beyond nt up to the next multiple of 32 and columns beyond hd are
@@ -636,6 +670,7 @@ constexpr int PATCH = 32 * XP;                  // one plane of a pair's patch: 
 __device__ __forceinline__ int xswz(int row) { return ((row >> 2) & 1) << 2 | ((row >> 3) & 1) << 1; }
 constexpr int FUSED_LDS = 2 * NBKB * BLK + 3 * CHB * 4 + 4 * 3 * PATCH + 4 * 32 * 16 * 4 + 4 * BLK;
 
+template <bool NARROW>      // heads up to 8 wide: two head-dimension instructions per score tile instead of three (see head_frags_narrow)
 __global__ __launch_bounds__(512, 4) void pattn_bwd_fused_kernel(const MAttn p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* Qi = smem;
@@ -673,14 +708,20 @@ __global__ __launch_bounds__(512, 4) void pattn_bwd_fused_kernel(const MAttn p) 
             const int krow = kb0 + (tid >> 6) * 16 + pc;
             const bool in_seq = krow < p.Tk;
             float kv[8], vv[8];
-            load_row8(kv, kbase, p.ldk, col0, krow, p.Tk, pg, p.hd, 1.f);
-            load_row8(vv, vbase, p.ldv, col0, krow, p.Tk, pg, p.hd, 1.f);
+            if constexpr (NARROW) {
+                load_row8_narrow(kv, kbase, p.ldk, col0, krow, p.Tk, p.hd, 1.f);
+                load_row8_narrow(vv, vbase, p.ldv, col0, krow, p.Tk, p.hd, 1.f);
+            } else {
+                load_row8(kv, kbase, p.ldk, col0, krow, p.Tk, pg, p.hd, 1.f);
+                load_row8(vv, vbase, p.ldv, col0, krow, p.Tk, pg, p.hd, 1.f);
+            }
             uint8_t mk = 1;
             if (p.mask) mk = p.mask[(int64_t)b * p.Tk + (in_seq ? krow : 0)];
             const bool keep = in_seq && mk != 0;
             cap = keep ? INFINITY : (in_seq ? kFillP : -INFINITY);
             liv = keep ? 1.f : 0.f;
-            kf = head_frags(kv, pg), vf = head_frags(vv, pg);
+            if constexpr (NARROW) kf = head_frags_narrow(kv, pg), vf = head_frags_narrow(vv, pg);
+            else kf = head_frags(kv, pg), vf = head_frags(vv, pg);
             // 128 rows x four 16-byte pieces = one piece per thread (the previous key block's last reads of the image lie before the
             // barrier that closed its last query block)
             const int r = tid >> 2, q4 = tid & 3;
@@ -759,13 +800,19 @@ __global__ __launch_bounds__(512, 4) void pattn_bwd_fused_kernel(const MAttn p) 
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     bf16x8 a01, a02, d01, d02;
-                    row_frags(qblk, t, c, g, a01, a02);
-                    row_frags(dblk, t, c, g, d01, d02);
+                    if constexpr (NARROW) {
+                        row_frags_narrow(qblk, t, c, g, a01, a02);
+                        row_frags_narrow(dblk, t, c, g, d01, d02);
+                    } else {
+                        row_frags(qblk, t, c, g, a01, a02);
+                        row_frags(dblk, t, c, g, d01, d02);
+                    }
                     const f32x4 ml = *reinterpret_cast<const f32x4*>(Ml + qb * 32 + t * 16 + 4 * g);
                     const f32x4 l2 = *reinterpret_cast<const f32x4*>(Ll + qb * 32 + t * 16 + 4 * g);
                     const f32x4 dl = *reinterpret_cast<const f32x4*>(Dl + qb * 32 + t * 16 + 4 * g);
-                    const f32x4 st = head_product(a01, a02, kf);              // rows = queries 4 g + r, column = this lane's key
-                    const f32x4 dp = head_product(d01, d02, vf);
+                    // rows = queries 4 g + r, column = this lane's key
+                    const f32x4 st = NARROW ? head_product_narrow(a01, a02, kf) : head_product(a01, a02, kf);
+                    const f32x4 dp = NARROW ? head_product_narrow(d01, d02, vf) : head_product(d01, d02, vf);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float sc = MASKED ? vmin(st[r], cap) : st[r];
@@ -950,7 +997,10 @@ int pattn_backward(const MAttn& a0, hipStream_t st) {
     a.tail = g_ablate;
 #endif
     if (fused_backward_applies(a)) {
-        return launch(pattn_bwd_fused_kernel, (unsigned)(a.B * a.H), 512u, (size_t)FUSED_LDS, st, a);
+#ifndef MSN_PATTN_NO_NARROW
+        if (a.hd <= 8) return launch(pattn_bwd_fused_kernel<true>, (unsigned)(a.B * a.H), 512u, (size_t)FUSED_LDS, st, a);
+#endif
+        return launch(pattn_bwd_fused_kernel<false>, (unsigned)(a.B * a.H), 512u, (size_t)FUSED_LDS, st, a);
     }
     {
         const size_t lds = 2 * NBK * BLK + sizeof(float) * CH;

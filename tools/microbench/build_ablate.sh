@@ -17,7 +17,7 @@ SRC=gemm
 #   plane-output epilogue without its GELU arithmetic / the saved GELU' matrix / the split arithmetic / the plane stores
 #   PG_STNT: the NT epilogue's final stores with the nt cache policy
 #   PATTN: the plane attention kernels with their diagnostic switches compiled in (msn_set_attention_planes bits 4 - 5)
-for a in "$@"; do case $a in PATTN) DEFS="$DEFS -DMSN_ABL_PATTN"; SRC=attention_planes;; PG_ANT) DEFS="$DEFS -DMSN_PG_A_AUX=2"; SRC=pgemm;; PG_STNT) DEFS="$DEFS -DMSN_PG_ST_AUX=2"; SRC=pgemm;; ACC_AGPR) DEFS="$DEFS -DMSN_ACC_AGPR";;  BF_*) DEFS="$DEFS -DMSN_ABL_$a"; SRC=gemm_bf16res;; PG_*) DEFS="$DEFS -DMSN_ABL_$a"; SRC=pgemm;; *) DEFS="$DEFS -DMSN_ABL_$a";; esac; NAME="${NAME}_$a"; done
+for a in "$@"; do case $a in PATTN) DEFS="$DEFS -DMSN_ABL_PATTN"; SRC=attention_planes;; PATTN_NO_NARROW) DEFS="$DEFS -DMSN_PATTN_NO_NARROW"; SRC=attention_planes;; PG_ANT) DEFS="$DEFS -DMSN_PG_A_AUX=2"; SRC=pgemm;; PG_STNT) DEFS="$DEFS -DMSN_PG_ST_AUX=2"; SRC=pgemm;; ACC_AGPR) DEFS="$DEFS -DMSN_ACC_AGPR";;  BF_*) DEFS="$DEFS -DMSN_ABL_$a"; SRC=gemm_bf16res;; PG_*) DEFS="$DEFS -DMSN_ABL_$a"; SRC=pgemm;; *) DEFS="$DEFS -DMSN_ABL_$a";; esac; NAME="${NAME}_$a"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -I"$ROOT/include" $DEFS -c "$PKG/csrc/$SRC.hip" -o "/tmp/gemm_abl$NAME.o"
 OBJS=$(ls "$PKG"/build/*.o | grep -v "build/$SRC.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/tools/microbench/ablate/libmsn$NAME.so" "/tmp/gemm_abl$NAME.o" $OBJS
